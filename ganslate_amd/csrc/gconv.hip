@@ -1,0 +1,279 @@
+// Generalised convolution as an implicit GEMM on the gfx950 matrix cores.
+//
+//   out[n, i*so+py, j*so+px, co] = act(bias[co] + sum_t sum_ci in[n, B(i*si+dh[t]), B(j*si+dw[t]), ci] * w[co][t*Ci+ci])
+//
+// One kernel covers Conv2d forward (any stride), the data-gradient of stride-1 convs, and — one launch per
+// output parity class — ConvTranspose2d(stride 2) forward and the data-gradient of stride-2 convs.
+// Replaces the cuDNN/MIOpen calls behind nn.Conv2d / nn.ConvTranspose2d in
+// ganslate/nn/generators/resnet/resnet2d.py:25,35,52-57,65,80-87 and
+// ganslate/nn/discriminators/patchgan/patchgan2d.py:29,36-62 (forward) and their autograd backward.
+//
+// GEMM view: D[co][pixel] = W[co][k] * X[pixel][k]^T, k = (tap, ci). Weights are the MFMA A operand so each
+// lane ends up with 4 consecutive output channels of one pixel (8-byte NHWC stores).
+// Both tiles are staged by LDS-DMA (global_load_lds_dwordx4): the LDS image is lane-linear, rows of 64 bf16
+// (128 B), and the bank swizzle (16-B slot ^= row&7) is applied on the per-lane SOURCE address and again on
+// the ds_read_b128 address. The im2col gather happens in that per-lane source address (reflect / replicate /
+// zero borders; out-of-range lanes read a zero page). Two LDS stages, one barrier per K-step of 64.
+#include "common.hpp"
+
+struct GConvK {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  float* stats;
+  const char* zero;
+  int tiles_m, tiles_n, ci_shift;
+  float rcp_wc;
+  gs_gconv_desc d;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
+  constexpr int WT = BN * 128;          // weight tile bytes per stage
+  constexpr int XT = BM * 128;          // pixel tile bytes per stage
+  constexpr int STAGE = WT + XT;
+  constexpr int TI = BN / WN / 16;      // 16-channel tiles per wave
+  constexpr int TJ = BM / WM / 16;      // 16-pixel tiles per wave
+  constexpr int NXI = BM / 32;          // pixel-tile DMA instructions per wave per stage
+  constexpr int NWI = (BN / 8 + 3) / 4; // weight-tile DMA instructions per wave per stage (upper bound)
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  short* taps = reinterpret_cast<short*>(smem + 2 * STAGE);
+
+  const gs_gconv_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+
+  int b = blockIdx.x;
+  const int nt = b % p.tiles_n;
+  b /= p.tiles_n;
+  const int mt = b % p.tiles_m;
+  const int n = b / p.tiles_m;
+
+  if (tid < d.T) taps[tid] = (short)(((int)d.dh[tid] & 0xff) | ((int)d.dw[tid] << 8));
+
+  // ---- per-lane DMA bookkeeping -------------------------------------------------------------------
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;  // 16-B k-chunk fetched by this lane (swizzled source)
+  const int HWc = d.Hc * d.Wc;
+  int xbh[NXI], xbw[NXI];
+  bool xv[NXI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int row = (wave + 4 * i) * 8 + lrow;
+    const int m = mt * BM + row;
+    xv[i] = m < HWc;
+    const int ii = div_small(m, d.Wc, p.rcp_wc);
+    const int jj = m - ii * d.Wc;
+    xbh[i] = ii * d.si;
+    xbw[i] = jj * d.si;
+  }
+  const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+  const char* wsrc[NWI];
+  int winc[NWI];  // 128 B per K-step for a real weight row, 0 for a masked row (stays on the zero page)
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) {
+    const int wi = wave + 4 * i;
+    const int co = nt * BN + wi * 8 + lrow;
+    const bool wv = co < d.w_rows;
+    const char* real = p.w + ((size_t)co * d.Kp + chunk * 8) * 2;
+    wsrc[i] = wv ? real : p.zero;
+    winc[i] = wv ? 128 : 0;
+  }
+  const int cmask = (1 << p.ci_shift) - 1;
+
+  auto issue = [&](int ks, int buf) {
+    char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int wi = wave + 4 * i;
+      if ((BN / 8) % 4 == 0 || wi < BN / 8) glds16(wsrc[i] + ks * winc[i], sb + wi * 1024);
+    }
+    const int q = ks * 8 + chunk;
+    const int t = q >> p.ci_shift;
+    const int c8 = q & cmask;
+    const bool tv = t < d.T;
+    const short tp = taps[tv ? t : 0];
+    const int dh = (int)(signed char)(tp & 0xff);
+    const int dw = (int)tp >> 8;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      bool ok = tv && xv[i];
+      const int ih = border_index(xbh[i] + dh, d.Hi, d.border, ok);
+      const int iw = border_index(xbw[i] + dw, d.Wi, d.border, ok);
+      unsigned off = ((unsigned)(ih * d.Wi + iw) * (unsigned)d.in_cs + (unsigned)(c8 * 8)) * 2u;
+      asm volatile("" : "+v"(off));  // keep the address math unconditional: select, don't branch
+      const char* src = ok ? in_n + off : p.zero;
+      glds16(src, sb + WT + (wave + 4 * i) * 1024);
+    }
+  };
+
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 15;           // row inside a 16-row fragment
+  const int fk = lane >> 4;             // k-chunk (8 bf16) inside a 32-deep MFMA step
+  const int swz = lane & 7;             // == row & 7 for every fragment row of this lane
+  const int nk = d.Kp >> 6;
+
+  __syncthreads();  // taps visible
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+    const char* wb = smem + cur * STAGE + (wn * (BN / WN) + frow) * 128;
+    const char* xb = smem + cur * STAGE + WT + (wm * (BM / WM) + frow) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + fk) ^ swz) << 4;
+      bf16x8 wf[TI], xf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's share)
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, InstanceNorm partial statistics, activation, bf16 NHWC store -----------------
+  const bool want_stats = d.stats_slots > 0;
+  float s1[TI][4], s2[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int m = mt * BM + wm * (BM / WM) + j * 16 + frow;
+    const bool pv = m < HWc;
+    const int ii = div_small(m, d.Wc, p.rcp_wc);
+    const int jj = m - ii * d.Wc;
+    const size_t opix = ((size_t)n * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+    char* orow = p.out + (opix * d.out_cs + d.out_co) * 2;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
+      if (co < d.Co) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] + (p.bias ? p.bias[co + r] : 0.f);
+          if (pv) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+          v[r] = apply_act(v[r], d.act, d.slope);
+        }
+        if (pv) {
+          uint2 o;
+          o.x = pack_bf2(v[0], v[1]);
+          o.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(orow + co * 2) = o;
+        }
+      }
+    }
+  }
+
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]; the stage buffers are dead after the loop
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[i][r], q = s2[i][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        if (frow == 0) {
+          const int cl = wn * (BN / WN) + i * 16 + fk * 4 + r;
+          red[(wm * BN + cl) * 2 + 0] = a;
+          red[(wm * BN + cl) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = nt * BN + tid;
+      if (co < d.Co) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+        sp[co] = a;
+        sp[d.Co + co] = q;
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+namespace {
+struct TileCfg { int bm, bn; };
+TileCfg pick_tile(const gs_gconv_desc* d) {
+  if (d->Co <= 16) return {256, 16};
+  if (d->Co <= 64) return {128, 64};
+  return {128, 128};
+}
+template <int BM, int BN, int WM, int WN>
+int launch(const GConvK& k, int blocks, hipStream_t st) {
+  constexpr int lds = 2 * (BM + BN) * 128 + GS_MAX_TAPS * 2;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN>), dim3(blocks), dim3(256), lds, st, k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
+
+extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                                void* out, float* stats, void* stream) {
+  GS_REQUIRE(d && in && w_pack && out, "gs_gconv_forward: null argument");
+  GS_REQUIRE(d->Ci >= 8 && (d->Ci & 7) == 0 && ((d->Ci >> 3) & ((d->Ci >> 3) - 1)) == 0,
+             "gs_gconv_forward: Ci=%d must be 8*2^k", d->Ci);
+  GS_REQUIRE((d->Co & 7) == 0 && d->Co > 0, "gs_gconv_forward: Co=%d must be a multiple of 8", d->Co);
+  GS_REQUIRE(d->T >= 1 && d->T <= GS_MAX_TAPS, "gs_gconv_forward: T=%d out of range", d->T);
+  GS_REQUIRE(d->Kp % 64 == 0 && d->Kp >= d->T * d->Ci, "gs_gconv_forward: bad Kp=%d", d->Kp);
+  GS_REQUIRE((d->in_cs & 7) == 0 && (d->in_co & 7) == 0 && (d->out_cs & 3) == 0 && (d->out_co & 3) == 0,
+             "gs_gconv_forward: channel strides/offsets must keep 16-B input / 8-B output alignment");
+  GS_REQUIRE((long long)d->Hc * d->Wc < (1 << 24), "gs_gconv_forward: class extent too large");
+  GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward: stats requested without buffer");
+  const TileCfg tc = pick_tile(d);
+  GConvK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_pack);
+  k.bias = bias;
+  k.out = static_cast<char*>(out);
+  k.stats = stats;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
+  k.tiles_m = (d->Hc * d->Wc + tc.bm - 1) / tc.bm;
+  k.tiles_n = (d->Co + tc.bn - 1) / tc.bn;
+  int sh = 0;
+  while ((8 << sh) < d->Ci) ++sh;
+  k.ci_shift = sh;
+  k.rcp_wc = 1.0f / (float)d->Wc;
+  k.d = *d;
+  const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
+  GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tc.bn == 16) return launch<256, 16, 4, 1>(k, (int)blocks, st);
+  if (tc.bn == 64) return launch<128, 64, 2, 2>(k, (int)blocks, st);
+  return launch<128, 128, 2, 2>(k, (int)blocks, st);
+}

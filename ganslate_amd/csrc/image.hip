@@ -1,0 +1,133 @@
+// Network boundary: NCHW fp32 images (the reference's `visuals`, cyclegan.py:39,84-90) <-> NHWC bf16
+// activations with the channel count padded to a multiple of 8, plus the gradients of both conversions
+// (tanh' of resnet2d.py:65 and the ReflectionPad2d adjoint of resnet2d.py:24 folded in).
+#include "common.hpp"
+
+__global__ __launch_bounds__(256) void image_to_act_kernel(const float* img, unsigned short* act, int C, long long hw,
+                                                           int Cp) {
+  const int n = blockIdx.y;
+  const float* in = img + (size_t)n * C * hw;
+  unsigned short* out = act + (size_t)n * hw * Cp;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = (c0 + k < C) ? in[(size_t)(c0 + k) * hw + p] : 0.f;
+      uint4 o;
+      o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+      *reinterpret_cast<uint4*>(out + (size_t)p * Cp + c0) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void act_to_image_kernel(const unsigned short* act, float* img, int C, long long hw,
+                                                           int Cp, int act_kind) {
+  const int n = blockIdx.y;
+  const unsigned short* in = act + (size_t)n * hw * Cp;
+  float* out = img + (size_t)n * C * hw;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x)
+    for (int c = 0; c < C; ++c) out[(size_t)c * hw + p] = apply_act(bf2f(in[(size_t)p * Cp + c]), act_kind, 0.f);
+}
+
+__global__ __launch_bounds__(256) void act_to_image_bwd_kernel(const float* g_img, const float* out_img,
+                                                               unsigned short* g_act, int C, long long hw, int Cp,
+                                                               int act_kind) {
+  const int n = blockIdx.y;
+  const float* gi = g_img + (size_t)n * C * hw;
+  const float* oi = out_img ? out_img + (size_t)n * C * hw : nullptr;
+  unsigned short* out = g_act + (size_t)n * hw * Cp;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        float v = 0.f;
+        if (c < C) {
+          v = gi[(size_t)c * hw + p];
+          if (oi) v *= act_grad_from_out(oi[(size_t)c * hw + p], act_kind, 0.f);
+        }
+        f[k] = v;
+      }
+      uint4 o;
+      o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+      *reinterpret_cast<uint4*>(out + (size_t)p * Cp + c0) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void image_to_act_bwd_kernel(const unsigned short* g_pad, float* g_img, int C, int H,
+                                                               int W, int Cp, int fold, int accumulate) {
+  const int n = blockIdx.y;
+  const int Hp = H + 2 * fold, Wp = W + 2 * fold;
+  const unsigned short* gp = g_pad + (size_t)n * Hp * Wp * Cp;
+  float* out = g_img + (size_t)n * C * H * W;
+  const long long hw = (long long)H * W;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    const int ih = (int)(p / W), iw = (int)(p - (long long)ih * W);
+    int hs[3], ws[3], nh = 1, nw = 1;
+    hs[0] = ih + fold; ws[0] = iw + fold;
+    if (fold > 0) {
+      if (ih >= 1 && ih <= fold) hs[nh++] = fold - ih;
+      if (ih >= H - 1 - fold && ih <= H - 2) hs[nh++] = fold + 2 * (H - 1) - ih;
+      if (iw >= 1 && iw <= fold) ws[nw++] = fold - iw;
+      if (iw >= W - 1 - fold && iw <= W - 2) ws[nw++] = fold + 2 * (W - 1) - iw;
+    }
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) s += bf2f(gp[((size_t)hs[a] * Wp + ws[b]) * Cp + c]);
+      if (accumulate) out[(size_t)c * hw + p] += s; else out[(size_t)c * hw + p] = s;
+    }
+  }
+}
+
+static inline dim3 img_grid(long long hw, int N) {
+  long long bx = (hw + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  return dim3((unsigned)bx, N);
+}
+
+extern "C" int gs_image_to_act(const float* img, void* act, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                               void* stream) {
+  GS_REQUIRE(img && act && N > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "gs_image_to_act: bad argument");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(image_to_act_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream), img,
+                     static_cast<unsigned short*>(act), C, hw, Cp);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_act_to_image(const void* act, float* img, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                               int32_t act_kind, void* stream) {
+  GS_REQUIRE(img && act && N > 0 && C > 0 && Cp >= C, "gs_act_to_image: bad argument");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(act_to_image_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(act), img, C, hw, Cp, act_kind);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_act_to_image_backward(const float* g_img, const float* out_img, void* g_act, int32_t N, int32_t C,
+                                        int32_t H, int32_t W, int32_t Cp, int32_t act_kind, void* stream) {
+  GS_REQUIRE(g_img && g_act && N > 0 && C > 0 && Cp >= C && (Cp & 7) == 0, "gs_act_to_image_backward: bad argument");
+  GS_REQUIRE(act_kind == GS_ACT_NONE || out_img, "gs_act_to_image_backward: activation needs the forward output");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(act_to_image_bwd_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream), g_img,
+                     act_kind == GS_ACT_NONE ? nullptr : out_img, static_cast<unsigned short*>(g_act), C, hw, Cp,
+                     act_kind);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t H, int32_t W,
+                                        int32_t Cp, int32_t fold, int32_t fold_mode, int32_t accumulate,
+                                        void* stream) {
+  GS_REQUIRE(g_pad && g_img && N > 0 && C > 0 && Cp >= C, "gs_image_to_act_backward: bad argument");
+  GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT, "gs_image_to_act_backward: only reflect fold implemented");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(image_to_act_bwd_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(g_pad), g_img, C, H, W, Cp, fold, accumulate);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,218 @@
+// Loss / metric reductions on the boundary tensors (fp32): wavefront shuffle reduction -> workgroup -> a
+// fixed-order final sum by the last-arriving workgroup (deterministic, single launch).
+// Replaces nn.MSELoss vs an expanded constant target (ganslate/nn/losses/adversarial_loss.py:28-29,60-62),
+// nn.L1Loss (cyclegan_losses.py:64,75,97-101; pix2pix_losses.py:15-19), tensor.mean() of
+// utils/metrics/train_metrics.py:27-33 and SSIMLoss (nn/losses/utils/ssim.py:65-99).
+#include "common.hpp"
+
+float* gs_reduce_workspace();   // >= 1024 floats + 1 counter (api.hip)
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+
+// publish this workgroup's partial; the last workgroup to arrive sums all partials in index order
+__device__ __forceinline__ void finish_reduction(float partial, float* ws, float scale, float* out) {
+  __shared__ int last;
+  unsigned* counter = reinterpret_cast<unsigned*>(ws + 1024);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(ws + blockIdx.x, partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == gridDim.x - 1);
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    double s = 0.0;
+    for (unsigned i = 0; i < gridDim.x; ++i) s += (double)__hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[0] = (float)(s * (double)scale);
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_const_kernel(const float* x, long long n, float target, float* ws,
+                                                        float* loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = x[i] - target;
+    s += d * d;
+  }
+  s = block_sum(s, sh);
+  finish_reduction(s, ws, 1.0f / (float)n, loss);
+}
+__global__ __launch_bounds__(256) void mse_const_grad_kernel(const float* x, long long n, float target, float* grad,
+                                                             const float* gscale) {
+  const float k = (gscale ? gscale[0] : 1.f) * 2.0f / (float)n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    grad[i] = k * (x[i] - target);
+}
+
+__global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b, long long n, float* ws, float* loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    s += fabsf(a[i] - b[i]);
+  s = block_sum(s, sh);
+  finish_reduction(s, ws, 1.0f / (float)n, loss);
+}
+__global__ __launch_bounds__(256) void l1_grad_kernel(const float* a, const float* b, long long n, float* grad,
+                                                      const float* gscale) {
+  const float k = (gscale ? gscale[0] : 1.f) / (float)n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    grad[i] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void mean_kernel(const float* x, long long n, float* ws, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    s += x[i];
+  s = block_sum(s, sh);
+  finish_reduction(s, ws, 1.0f / (float)n, out);
+}
+
+static inline unsigned red_blocks(long long n) {
+  long long b = (n + 256 * 8 - 1) / (256 * 8);
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (unsigned)b;
+}
+
+extern "C" int gs_mse_const(const float* x, int64_t n, float target, float* loss, float* grad,
+                            const float* grad_scale, void* stream) {
+  GS_REQUIRE(x && n > 0 && (loss || grad), "gs_mse_const: bad argument");
+  float* ws = gs_reduce_workspace();
+  GS_REQUIRE(ws, "gs_mse_const: library not initialised (call gs_init)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (loss) hipLaunchKernelGGL(mse_const_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, ws, loss);
+  if (grad) hipLaunchKernelGGL(mse_const_grad_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, grad, grad_scale);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int gs_l1(const float* a, const float* b, int64_t n, float* loss, float* grad_a, const float* grad_scale,
+                     void* stream) {
+  GS_REQUIRE(a && b && n > 0 && (loss || grad_a), "gs_l1: bad argument");
+  float* ws = gs_reduce_workspace();
+  GS_REQUIRE(ws, "gs_l1: library not initialised (call gs_init)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (loss) hipLaunchKernelGGL(l1_kernel, dim3(red_blocks(n)), dim3(256), 0, st, a, b, (long long)n, ws, loss);
+  if (grad_a) hipLaunchKernelGGL(l1_grad_kernel, dim3(red_blocks(n)), dim3(256), 0, st, a, b, (long long)n, grad_a, grad_scale);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int gs_mean(const float* x, int64_t n, float* out, void* stream) {
+  GS_REQUIRE(x && out && n > 0, "gs_mean: bad argument");
+  float* ws = gs_reduce_workspace();
+  GS_REQUIRE(ws, "gs_mean: library not initialised (call gs_init)");
+  hipLaunchKernelGGL(mean_kernel, dim3(red_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)n, ws, out);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- SSIM distance -----------------------------------------------------------------------------------------
+// One workgroup = one 16x32 tile of the valid (H-10)x(W-10) output of one plane. Horizontal 11-tap Gaussian of
+// the five maps X, Y, XX, YY, XY into LDS, then the vertical pass, S1/S2, sqrt(relu(2-S1-S2)).
+#define SSIM_TH 16
+#define SSIM_TW 32
+__constant__ float c_gauss[11];
+
+__global__ __launch_bounds__(256) void ssim_kernel(const float* x, const float* y, int H, int W, int tiles_w,
+                                                   int tiles_h, float* partial) {
+  __shared__ float sx[SSIM_TH + 10][SSIM_TW + 10];
+  __shared__ float sy[SSIM_TH + 10][SSIM_TW + 10];
+  __shared__ float hz[5][SSIM_TH + 10][SSIM_TW];
+  __shared__ float sh[4];
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w;
+  const int th = b % tiles_h; const int plane = b / tiles_h;
+  const int Ho = H - 10, Wo = W - 10;
+  const int oh0 = th * SSIM_TH, ow0 = tw * SSIM_TW;
+  const float* xp = x + (size_t)plane * H * W;
+  const float* yp = y + (size_t)plane * H * W;
+  for (int e = threadIdx.x; e < (SSIM_TH + 10) * (SSIM_TW + 10); e += 256) {
+    const int r = e / (SSIM_TW + 10), c = e % (SSIM_TW + 10);
+    const int ih = oh0 + r, iw = ow0 + c;
+    float a = 0.f, bb = 0.f;
+    if (ih < H && iw < W) { a = (xp[(size_t)ih * W + iw] + 1.f) * 0.5f; bb = (yp[(size_t)ih * W + iw] + 1.f) * 0.5f; }
+    sx[r][c] = a; sy[r][c] = bb;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < (SSIM_TH + 10) * SSIM_TW; e += 256) {
+    const int r = e / SSIM_TW, c = e % SSIM_TW;
+    float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = c_gauss[k], a = sx[r][c + k], bb = sy[r][c + k];
+      m1 += g * a; m2 += g * bb; xx += g * a * a; yy += g * bb * bb; xy += g * a * bb;
+    }
+    hz[0][r][c] = m1; hz[1][r][c] = m2; hz[2][r][c] = xx; hz[3][r][c] = yy; hz[4][r][c] = xy;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < SSIM_TH * SSIM_TW; e += 256) {
+    const int r = e / SSIM_TW, c = e % SSIM_TW;
+    if (oh0 + r < Ho && ow0 + c < Wo) {
+      float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float g = c_gauss[k];
+        m1 += g * hz[0][r + k][c]; m2 += g * hz[1][r + k][c]; xx += g * hz[2][r + k][c];
+        yy += g * hz[3][r + k][c]; xy += g * hz[4][r + k][c];
+      }
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float s1sq = xx - m1 * m1, s2sq = yy - m2 * m2, s12 = xy - m1 * m2;
+      const float S1 = (2.f * m1 * m2 + C1) / (m1 * m1 + m2 * m2 + C1);
+      const float S2 = (2.f * s12 + C2) / (s1sq + s2sq + C2);
+      const float S = fmaxf(2.f - (S1 + S2), 0.f);
+      acc += sqrtf(S);
+    }
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ void ssim_final_kernel(const float* partial, int n, float scale, float* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = (float)(sh[0] * (double)scale);
+}
+
+extern "C" int64_t gs_ssim_scratch_floats(int32_t NC, int32_t H, int32_t W) {
+  const int64_t th = (H - 10 + SSIM_TH - 1) / SSIM_TH, tw = (W - 10 + SSIM_TW - 1) / SSIM_TW;
+  return (int64_t)NC * th * tw;
+}
+extern "C" int gs_ssim_distance(const float* x, const float* y, int32_t NC, int32_t H, int32_t W, float* out,
+                                float* scratch, void* stream) {
+  GS_REQUIRE(x && y && out && scratch && NC > 0 && H > 10 && W > 10, "gs_ssim_distance: bad argument");
+  static bool init = false;
+  if (!init) {
+    // fp32 restatement of _fspecial_gauss_1d(11, 1.5) (ssim.py:22-40)
+    float g[11], s = 0.f;
+    for (int i = 0; i < 11; ++i) { const float c = (float)(i - 5); g[i] = expf(-(c * c) / (2.f * 1.5f * 1.5f)); s += g[i]; }
+    for (int i = 0; i < 11; ++i) g[i] /= s;
+    GS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
+    init = true;
+  }
+  const int th = (H - 10 + SSIM_TH - 1) / SSIM_TH, tw = (W - 10 + SSIM_TW - 1) / SSIM_TW;
+  const int blocks = NC * th * tw;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(ssim_kernel, dim3(blocks), dim3(256), 0, st, x, y, H, W, tw, th, scratch);
+  const double cnt = (double)NC * (H - 10) * (W - 10);
+  hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, (float)(1.0 / cnt), out);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,290 @@
+// InstanceNorm (+activation, +residual) forward/backward on NHWC bf16 activations; HBM-bound streaming
+// kernels, 16 B (8 channels) per lane access, fp32 statistics.
+// Replaces nn.InstanceNorm2d(eps=1e-5, affine=False, track_running_stats=False) + nn.ReLU / nn.LeakyReLU
+// (ganslate/nn/utils.py:53-59; resnet2d.py:26-27,36-37,83-87,93; patchgan2d.py:45-46,58-59) and their
+// autograd backward, including the adjoint of nn.ReflectionPad2d (the `fold`).
+#include "common.hpp"
+
+// ---- statistics finalize: partial [N][slots][2][C] -> mean_rstd [N][2][C] ---------------------------
+__global__ void inorm_finalize_kernel(const float* partial, int N, int slots, int C, float inv_hw, float eps,
+                                      float* mean_rstd) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * C) return;
+  const int n = idx / C, c = idx - n * C;
+  double s1 = 0.0, s2 = 0.0;
+  const float* pp = partial + (size_t)n * slots * 2 * C + c;
+  for (int s = 0; s < slots; ++s) {
+    s1 += (double)pp[(size_t)s * 2 * C];
+    s2 += (double)pp[(size_t)s * 2 * C + C];
+  }
+  const double mean = s1 * (double)inv_hw;
+  double var = s2 * (double)inv_hw - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[(size_t)n * 2 * C + c] = (float)mean;
+  mean_rstd[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
+                                 float* mean_rstd, void* stream) {
+  GS_REQUIRE(partial && mean_rstd && N > 0 && slots > 0 && C > 0 && hw > 0, "gs_inorm_finalize: bad argument");
+  const int total = N * C;
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), partial, N, slots, C, 1.0f / (float)hw, eps, mean_rstd);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- forward apply -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inorm_act_fwd_kernel(const uint4* y, const float* mean_rstd, const uint4* res,
+                                                            uint4* x, long long hw, int C8, int act, float slope) {
+  const int n = blockIdx.y;
+  const long long per_img = hw * C8;
+  const float* mr = mean_rstd + (size_t)n * 2 * C8 * 8;
+  const uint4* yn = y + (size_t)n * per_img;
+  const uint4* rn = res ? res + (size_t)n * per_img : nullptr;
+  uint4* xn = x + (size_t)n * per_img;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per_img;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(e % C8);
+    const uint4 v = yn[e];
+    const float4 m0 = *reinterpret_cast<const float4*>(mr + c8 * 8);
+    const float4 m1 = *reinterpret_cast<const float4*>(mr + c8 * 8 + 4);
+    const float4 r0 = *reinterpret_cast<const float4*>(mr + C8 * 8 + c8 * 8);
+    const float4 r1 = *reinterpret_cast<const float4*>(mr + C8 * 8 + c8 * 8 + 4);
+    float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+    const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    const float rs[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = apply_act((f[k] - mu[k]) * rs[k], act, slope);
+    if (rn) {
+      const uint4 r = rn[e];
+      f[0] += bf_lo(r.x); f[1] += bf_hi(r.x); f[2] += bf_lo(r.y); f[3] += bf_hi(r.y);
+      f[4] += bf_lo(r.z); f[5] += bf_hi(r.z); f[6] += bf_lo(r.w); f[7] += bf_hi(r.w);
+    }
+    uint4 o;
+    o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+    xn[e] = o;
+  }
+}
+
+extern "C" int gs_inorm_act_forward(const void* y, const float* mean_rstd, const void* res, void* x, int32_t N,
+                                    int64_t hw, int32_t C, int32_t act, float slope, void* stream) {
+  GS_REQUIRE(y && mean_rstd && x && N > 0 && hw > 0 && C > 0 && (C & 7) == 0, "gs_inorm_act_forward: bad argument");
+  const long long per_img = hw * (C / 8);
+  long long bx = (per_img + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(inorm_act_fwd_kernel, dim3((unsigned)bx, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4*>(y), mean_rstd, static_cast<const uint4*>(res),
+                     static_cast<uint4*>(x), (long long)hw, C / 8, act, slope);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+// folded gradient: g(n, ih, iw, c8) = sum over the padded-domain positions that the padding maps to (ih, iw)
+struct FoldIdx { int idx[3]; int cnt; };
+__device__ __forceinline__ FoldIdx fold_sources(int x, int n, int p, int mode) {
+  FoldIdx f;
+  f.idx[0] = x + p;
+  f.cnt = 1;
+  if (p > 0) {
+    if (mode == GS_BORDER_REFLECT) {
+      if (x >= 1 && x <= p) f.idx[f.cnt++] = p - x;
+      if (x >= n - 1 - p && x <= n - 2) f.idx[f.cnt++] = p + 2 * (n - 1) - x;
+    } else if (mode == GS_BORDER_REPLICATE) {
+      // handled by the caller through a loop (all p pad cells map to the border); not used in 2-D nets
+    }
+  }
+  return f;
+}
+
+__device__ __forceinline__ void add_bf8(float* f, const uint4 v) {
+  f[0] += bf_lo(v.x); f[1] += bf_hi(v.x); f[2] += bf_lo(v.y); f[3] += bf_hi(v.y);
+  f[4] += bf_lo(v.z); f[5] += bf_hi(v.z); f[6] += bf_lo(v.w); f[7] += bf_hi(v.w);
+}
+
+__device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const uint4* g2_n, int ih, int iw, int H,
+                                            int W, int C8, int c8, int fold, int mode) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] = 0.f;
+  if (fold == 0) {
+    add_bf8(f, gpad_n[((size_t)ih * W + iw) * C8 + c8]);
+  } else {
+    const int Wp = W + 2 * fold;
+    const FoldIdx fh = fold_sources(ih, H, fold, mode);
+    const FoldIdx fw = fold_sources(iw, W, fold, mode);
+    for (int a = 0; a < fh.cnt; ++a)
+      for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.idx[a] * Wp + fw.idx[b]) * C8 + c8]);
+  }
+  if (g2_n) add_bf8(f, g2_n[((size_t)ih * W + iw) * C8 + c8]);
+}
+
+// pass 1: per (n, pixel-chunk) partial sums of ghat and ghat*yhat  -> scratch [N][chunks][2][C]
+__global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
+                                                               const float* mean_rstd, float* partial, int H, int W,
+                                                               int C8, int fold, int mode, int act, float slope,
+                                                               int pix_per_block, int chunks) {
+  __shared__ float red[256 * 16 / 4];  // reused per 8-channel column: [rows][16] -> sized for 64 rows
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int cols = C8 < 64 ? C8 : 64;           // 8-channel columns handled per pass
+  const int rows = 256 / cols;                  // pixel lanes
+  const int col = tid % cols, row = tid / cols;
+  const int HW = H * W;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  const size_t pad_img = (size_t)(H + 2 * fold) * (W + 2 * fold) * C8;
+  const uint4* gpad_n = gpad + (size_t)n * pad_img;
+  const uint4* g2_n = g2 ? g2 + (size_t)n * HW * C8 : nullptr;
+  const uint4* y_n = y + (size_t)n * HW * C8;
+  const float* mr = mean_rstd + (size_t)n * 2 * C8 * 8;
+  float* out = partial + ((size_t)n * chunks + blockIdx.x) * 2 * C8 * 8;
+  for (int cb = 0; cb < C8; cb += cols) {
+    const int c8 = cb + col;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a1[k] = a2[k] = 0.f;
+    if (row < rows && c8 < C8) {
+      float mu[8], rs[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { mu[k] = mr[c8 * 8 + k]; rs[k] = mr[C8 * 8 + c8 * 8 + k]; }
+      for (int px = p0 + row; px < p1; px += rows) {
+        const int ih = px / W, iw = px - ih * W;
+        float g[8];
+        load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
+        const uint4 yv = y_n[(size_t)px * C8 + c8];
+        const float yy[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
+                             bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float yh = (yy[k] - mu[k]) * rs[k];
+          const float gh = g[k] * act_grad_from_out(yh, act, slope);
+          a1[k] += gh;
+          a2[k] += gh * yh;
+        }
+      }
+    }
+    // reduce over `rows` pixel lanes through LDS, 4 floats at a time to bound LDS use (256*4 floats)
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = part < 2 ? a1[(part & 1) * 4 + k] : a2[(part & 1) * 4 + k];
+        red[tid * 4 + k] = v;
+      }
+      __syncthreads();
+      if (tid < cols * 4 && cb + tid / 4 < C8) {
+        const int cc = tid / 4, k = tid & 3;
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += red[(r * cols + cc) * 4 + k];
+        const int ch = (cb + cc) * 8 + (part & 1) * 4 + k;
+        out[(part < 2 ? 0 : C8 * 8) + ch] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: dy = rstd * (ghat - S1/hw - yhat*S2/hw) ; optional gsum = folded gradient (before act')
+__global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
+                                                              const float* mean_rstd, const float* sums, uint4* dy,
+                                                              uint4* gsum, int H, int W, int C8, int fold, int mode,
+                                                              int act, float slope) {
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const long long per_img = (long long)HW * C8;
+  const size_t pad_img = (size_t)(H + 2 * fold) * (W + 2 * fold) * C8;
+  const uint4* gpad_n = gpad + (size_t)n * pad_img;
+  const uint4* g2_n = g2 ? g2 + (size_t)n * per_img : nullptr;
+  const uint4* y_n = y + (size_t)n * per_img;
+  const float inv_hw = 1.0f / (float)HW;
+  const float* mr = mean_rstd ? mean_rstd + (size_t)n * 2 * C8 * 8 : nullptr;
+  const float* sm = sums ? sums + (size_t)n * 2 * C8 * 8 : nullptr;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per_img;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(e % C8);
+    const int px = (int)(e / C8);
+    const int ih = px / W, iw = px - ih * W;
+    float g[8];
+    load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
+    if (gsum) {
+      uint4 o;
+      o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]); o.z = pack_bf2(g[4], g[5]); o.w = pack_bf2(g[6], g[7]);
+      gsum[(size_t)n * per_img + e] = o;
+    }
+    const uint4 yv = y_n[e];
+    const float yy[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
+                         bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
+    float d[8];
+    if (mr) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float rs = mr[C8 * 8 + c8 * 8 + k];
+        const float yh = (yy[k] - mr[c8 * 8 + k]) * rs;
+        const float gh = g[k] * act_grad_from_out(yh, act, slope);
+        d[k] = rs * (gh - sm[c8 * 8 + k] * inv_hw - yh * sm[C8 * 8 + c8 * 8 + k] * inv_hw);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = g[k] * act_grad_from_out(yy[k], act, slope);
+    }
+    uint4 o;
+    o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
+    dy[(size_t)n * per_img + e] = o;
+  }
+}
+
+// sums over chunks: scratch [N][chunks][2][C] -> [N][2][C] (stored behind the partials)
+__global__ void inorm_bwd_sum_kernel(const float* partial, float* sums, int N, int chunks, int C2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * C2) return;
+  const int n = idx / C2, c = idx - n * C2;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[((size_t)n * chunks + k) * C2 + c];
+  sums[(size_t)n * C2 + c] = s;
+}
+
+static const int kBwdPixPerBlock = 512;
+
+extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C) {
+  const int64_t chunks = ((int64_t)H * W + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
+  return (int64_t)N * (chunks + 1) * 2 * C;
+}
+
+extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
+                                     void* dy, void* gsum, float* scratch, int32_t N, int32_t H, int32_t W,
+                                     int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
+                                     void* stream) {
+  GS_REQUIRE(g_pad && y && dy && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0,
+             "gs_inorm_act_backward: bad argument");
+  GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT, "gs_inorm_act_backward: only reflect fold implemented");
+  GS_REQUIRE(fold == 0 || (H > 2 * fold && W > 2 * fold), "gs_inorm_act_backward: fold larger than image");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int C8 = C / 8;
+  const int HW = H * W;
+  float* sums = nullptr;
+  if (mean_rstd) {
+    GS_REQUIRE(scratch, "gs_inorm_act_backward: scratch required with normalisation");
+    const int chunks = (HW + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
+    sums = scratch + (size_t)N * chunks * 2 * C;
+    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(chunks, N), dim3(256), 0, st,
+                       static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2),
+                       static_cast<const uint4*>(y), mean_rstd, scratch, H, W, C8, fold, fold_mode, act, slope,
+                       kBwdPixPerBlock, chunks);
+    GS_CHECK_HIP(hipGetLastError());
+    const int total = N * 2 * C;
+    hipLaunchKernelGGL(inorm_bwd_sum_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, sums, N, chunks,
+                       2 * C);
+    GS_CHECK_HIP(hipGetLastError());
+  }
+  const long long per_img = (long long)HW * C8;
+  long long bx = (per_img + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)bx, N), dim3(256), 0, st,
+                     static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y),
+                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), H, W, C8, fold, fold_mode,
+                     act, slope);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}

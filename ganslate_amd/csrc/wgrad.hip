@@ -1,0 +1,255 @@
+// Weight gradient of the generalised convolution family on the gfx950 matrix cores:
+//
+//   dw[p][t*Q+q] += sum_{n,i,j} a[n,i,j,p] * g[n, B(i*si+dh[t]), B(j*si+dw[t]), q]
+//
+// `a` is the dense side (dY for Conv2d, X for ConvTranspose2d), `g` the gathered side. Replaces the
+// autograd weight-gradient kernels behind loss.backward() (ganslate/nn/gans/base.py:170) for every conv of
+// resnet2d.py / patchgan2d.py.
+//
+// GEMM view: C[p][n'] = A[m][p]^T * G[m][n'], contraction over pixels m. Both operands are pixel-major in
+// memory (NHWC), so MFMA fragments (8 consecutive k per lane) are read with the LDS transpose read
+// ds_read_b64_tr_b16 from [64 pixels][128 channels] tiles staged by LDS-DMA. The pixel range of every image
+// is split over workgroups (split-K); partial tiles are accumulated with fp32 atomics.
+#include "common.hpp"
+
+struct WGradK {
+  const char* a;
+  const char* g;
+  float* dw;
+  const char* zero;
+  int tiles_p, tiles_q, splits, chunk, q_shift;
+  float rcp_wa;
+  gs_wgrad_desc d;
+};
+
+// 16-B slot swizzle of a 256-B row R so that the 8 rows touched by one half-wave transpose read spread
+// over all 16 slots
+__device__ __forceinline__ int wg_swz(int R) { return ((R & 3) << 1) | (((R >> 3) & 1) << 3); }
+
+template <int WP, int WQ>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
+  constexpr int BP = 128, BQ = 128, BK = 64;
+  constexpr int AT = BK * BP * 2, GT = BK * BQ * 2, STAGE = AT + GT;  // 16 KiB + 16 KiB
+  constexpr int TI = BP / WP / 16, TJ = BQ / WQ / 16;
+  static_assert(WP * WQ == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  short* taps = reinterpret_cast<short*>(smem + 2 * STAGE);
+  const gs_wgrad_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+
+  int b = blockIdx.x;
+  const int tq = b % p.tiles_q;
+  b /= p.tiles_q;
+  const int tp = b % p.tiles_p;
+  b /= p.tiles_p;
+  const int sp = b % p.splits;
+  const int n = b / p.splits;
+  const int HW = d.Ha * d.Wa;
+  const int k0 = sp * p.chunk;
+  const int k1 = min(HW, k0 + p.chunk);
+  if (k0 >= k1) return;
+
+  if (tid < d.T) taps[tid] = (short)(((int)d.dh[tid] & 0xff) | ((int)d.dw_[tid] << 8));
+
+  // DMA: every wave-instruction moves 4 rows x 256 B; instruction k covers rows 4k..4k+3.
+  const int lrow = lane >> 4;   // row inside the instruction
+  const int slot = lane & 15;   // destination 16-B slot inside the row
+  const char* a_n = p.a + ((size_t)n * HW * d.a_cs + d.a_co) * 2;
+  const char* g_n = p.g + ((size_t)n * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+  const int qmask = (1 << p.q_shift) - 1;
+
+  auto issue = [&](int ks, int buf) {
+    char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = wave + 4 * i;
+      const int R = k * 4 + lrow;
+      const int m = k0 + ks * BK + R;
+      const bool mv = m < k1;
+      const int chunk = slot ^ wg_swz(R);
+      // dense side
+      {
+        const int pch = tp * BP + chunk * 8;
+        const char* src = (mv && pch < d.P) ? a_n + ((size_t)m * d.a_cs + pch) * 2 : p.zero;
+        glds16(src, sb + k * 1024);
+      }
+      // gathered side
+      {
+        const int col = tq * BQ + chunk * 8;          // n' = t*Q + q
+        const int t = (col >> 3) >> p.q_shift;
+        const int q8 = (col >> 3) & qmask;
+        bool ok = mv && t < d.T;
+        const short tpv = taps[ok ? t : 0];
+        const int ii = div_small(m, d.Wa, p.rcp_wa);
+        const int jj = m - ii * d.Wa;
+        const int ih = border_index(ii * d.si + (int)(signed char)(tpv & 0xff), d.Hg, d.border, ok);
+        const int iw = border_index(jj * d.si + ((int)tpv >> 8), d.Wg, d.border, ok);
+        const char* src = ok ? g_n + ((size_t)(ih * d.Wg + iw) * d.g_cs + q8 * 8) * 2 : p.zero;
+        glds16(src, sb + AT + k * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wp = wave / WQ, wq = wave % WQ;
+  const int nk = (k1 - k0 + BK - 1) / BK;
+  // transpose-read geometry: lane supplies the address of 4 consecutive channels of one pixel row
+  const int fk = lane >> 4;            // 8-pixel block inside a 32-deep MFMA step
+  const int frr = (lane & 15) >> 2;    // pixel row inside a 4-row block
+  const int fcc = lane & 3;            // 4-channel group inside the 16-channel tile
+
+  __syncthreads();
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+    const char* ab = smem + cur * STAGE;
+    const char* gb = ab + AT;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[TI], gf[TJ];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int R = kk * 32 + fk * 8 + h * 4 + frr;
+        const int sw = wg_swz(R);
+        const int rbase = R * 256 + (fcc & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int ch = (wp * (BP / WP) / 8) + i * 2 + (fcc >> 1);
+          s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(ab + rbase + ((ch ^ sw) << 4)));
+          af[i][h * 4 + 0] = v[0]; af[i][h * 4 + 1] = v[1]; af[i][h * 4 + 2] = v[2]; af[i][h * 4 + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int ch = (wq * (BQ / WQ) / 8) + j * 2 + (fcc >> 1);
+          s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(gb + rbase + ((ch ^ sw) << 4)));
+          gf[j][h * 4 + 0] = v[0]; gf[j][h * 4 + 1] = v[1]; gf[j][h * 4 + 2] = v[2]; gf[j][h * 4 + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: C[p][n'] accumulated with fp32 atomics -------------------------------------------
+  const int frow = lane & 15;
+  const int TQ = d.T * d.Q;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pp = tp * BP + wp * (BP / WP) + i * 16 + fk * 4 + r;
+      if (pp < d.P) {
+        float* row = p.dw + (size_t)pp * d.dw_ld;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int col = tq * BQ + wq * (BQ / WQ) + j * 16 + frow;
+          if (col < TQ) unsafeAtomicAdd(row + col, acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream) {
+  GS_REQUIRE(d && a && g && dw, "gs_wgrad: null argument");
+  GS_REQUIRE(d->Q >= 8 && (d->Q & 7) == 0 && ((d->Q >> 3) & ((d->Q >> 3) - 1)) == 0,
+             "gs_wgrad: Q=%d must be 8*2^k", d->Q);
+  GS_REQUIRE((d->P & 7) == 0, "gs_wgrad: P=%d must be a multiple of 8", d->P);
+  GS_REQUIRE(d->T >= 1 && d->T <= GS_MAX_TAPS, "gs_wgrad: T=%d out of range", d->T);
+  GS_REQUIRE((d->a_cs & 7) == 0 && (d->a_co & 7) == 0 && (d->g_cs & 7) == 0 && (d->g_co & 7) == 0,
+             "gs_wgrad: channel strides/offsets must be multiples of 8");
+  GS_REQUIRE((long long)d->Ha * d->Wa < (1 << 24), "gs_wgrad: image too large");
+  WGradK k;
+  k.a = static_cast<const char*>(a);
+  k.g = static_cast<const char*>(g);
+  k.dw = dw;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_wgrad: library not initialised (call gs_init)");
+  k.tiles_p = (d->P + 127) / 128;
+  k.tiles_q = (d->T * d->Q + 127) / 128;
+  const int HW = d->Ha * d->Wa;
+  // enough workgroups to fill 256 CUs a few times over, but at least 4 K-steps per split
+  long long tiles = (long long)k.tiles_p * k.tiles_q * d->N;
+  int splits = (int)((1024 + tiles - 1) / tiles);
+  const int max_splits = (HW + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int chunk = (HW + splits - 1) / splits;
+  chunk = (chunk + 63) / 64 * 64;
+  splits = (HW + chunk - 1) / chunk;
+  k.splits = splits;
+  k.chunk = chunk;
+  int sh = 0;
+  while ((8 << sh) < d->Q) ++sh;
+  k.q_shift = sh;
+  k.rcp_wa = 1.0f / (float)d->Wa;
+  k.d = *d;
+  const long long blocks = tiles * splits;
+  GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_wgrad: bad grid %lld", blocks);
+  constexpr int lds = 2 * (64 * 128 * 2 * 2) + GS_MAX_TAPS * 2;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<2, 2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- bias gradient: db[c] += sum_pixels dy[pix][c] ---------------------------------------------------
+__global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy, long long pixels, int C, int cs,
+                                                        int co, float* db, int pix_per_block) {
+  // thread -> one channel; rows of pixels strided over the 256/C' thread groups
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int cpb = C < 256 ? C : 256;           // channels per block pass
+  const int groups = 256 / cpb;                // pixel lanes
+  const int c_in = tid % cpb, gidx = tid / cpb;
+  const long long p0 = (long long)blockIdx.x * pix_per_block;
+  const long long p1 = min(pixels, p0 + pix_per_block);
+  for (int cb = 0; cb < C; cb += cpb) {
+    const int c = cb + c_in;
+    float s = 0.f;
+    if (gidx < groups && c < C)
+      for (long long px = p0 + gidx; px < p1; px += groups) s += bf2f(dy[px * cs + co + c]);
+    red[tid] = s;
+    __syncthreads();
+    if (tid < cpb && cb + tid < C) {
+      float t = 0.f;
+      for (int g = 0; g < groups; ++g) t += red[g * cpb + tid];
+      unsafeAtomicAdd(db + cb + tid, t);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db,
+                            void* stream) {
+  GS_REQUIRE(dy && db && pixels > 0 && C > 0, "gs_bias_grad: bad argument");
+  const int ppb = 2048;
+  const long long blocks = (pixels + ppb - 1) / ppb;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(dy), (long long)pixels, C, cs, co, db, ppb);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,99 @@
+"""Loader + ctypes prototypes for libganslate_hip.so.
+
+The library is the product path: if it is missing or fails to load, importing the ops raises — there is no
+CPU fallback (the CPU oracle under oracle/ is test infrastructure only)."""
+import ctypes as C
+import os
+from pathlib import Path
+
+GS_MAX_TAPS = 128
+BORDER = {"zero": 0, "reflect": 1, "replicate": 2}
+ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
+
+
+class GConvDesc(C.Structure):
+    """Mirror of gs_gconv_desc (include/ganslate_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Hi", "Wi", "Ci", "in_cs", "in_co", "Ho", "Wo", "Co", "out_cs", "out_co", "Hc", "Wc",
+        "so", "py", "px", "si", "T", "Kp", "w_rows", "border", "act")] + [
+        ("slope", C.c_float), ("stats_slots", C.c_int32), ("stats_slot0", C.c_int32),
+        ("dh", C.c_int8 * GS_MAX_TAPS), ("dw", C.c_int8 * GS_MAX_TAPS)]
+
+
+class WGradDesc(C.Structure):
+    """Mirror of gs_wgrad_desc."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Ha", "Wa", "P", "a_cs", "a_co", "Hg", "Wg", "Q", "g_cs", "g_co", "si", "T", "border", "dw_ld")] + [
+        ("dh", C.c_int8 * GS_MAX_TAPS), ("dw_", C.c_int8 * GS_MAX_TAPS)]
+
+
+_PROTOS = {
+    "gs_init": (C.c_int, [C.c_int]),
+    "gs_shutdown": (None, []),
+    "gs_last_error": (C.c_char_p, []),
+    "gs_tile_m": (C.c_int, [C.POINTER(GConvDesc)]),
+    "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "gs_wgrad": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_bias_grad": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gs_inorm_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float,
+                                    C.c_void_p, C.c_void_p]),
+    "gs_inorm_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                       C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "gs_inorm_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "gs_inorm_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gs_image_to_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p]),
+    "gs_act_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
+    "gs_act_to_image_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_image_to_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_mse_const": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_l1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gs_ssim_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "gs_ssim_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float),
+                               C.c_float, C.c_int32, C.c_void_p]),
+    "gs_repack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+EXPORTS = tuple(_PROTOS)
+_lib = None
+
+
+def library_path() -> Path:
+    env = os.environ.get("GANSLATE_HIP_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent.parent / "libganslate_hip.so"
+
+
+def load():
+    """dlopen the library and attach prototypes (no GPU call is made here)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.is_file():
+        raise RuntimeError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C ganslate_amd/csrc). There is no CPU fallback for the training step.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # raises AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed (rc={rc}): {load().gs_last_error().decode()}")

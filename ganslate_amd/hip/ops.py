@@ -1,0 +1,158 @@
+"""Tensor-level wrappers over the C ABI (include/ganslate_hip.h). Every call enqueues on torch's current
+stream; tensors are device tensors owned by the caller. No fallback: a missing library raises in lib.load()."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from ..nn.native.spec import GConv, WGrad
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipOps:
+    """The product backend: hand-written gfx950 kernels behind libganslate_hip.so."""
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        L.check(self.lib.gs_init(self.device.index or 0), "gs_init")
+        self._desc_cache = {}
+
+    # ---- descriptors ------------------------------------------------------------------------------------
+    def _gdesc(self, g: GConv, N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0):
+        key = (id(g), N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0)
+        d = self._desc_cache.get(key)
+        if d is None:
+            d = L.GConvDesc()
+            d.N, d.Hi, d.Wi, d.Ci, d.in_cs, d.in_co = N, g.Hi, g.Wi, g.Ci, in_cs, in_co
+            d.Ho, d.Wo, d.Co, d.out_cs, d.out_co = g.Ho, g.Wo, g.Co, out_cs, out_co
+            d.Hc, d.Wc, d.so, d.py, d.px, d.si = g.Hc, g.Wc, g.so, g.py, g.px, g.si
+            d.T, d.Kp, d.w_rows = g.T, g.Kp, g.w_rows
+            d.border, d.act, d.slope = L.BORDER[g.border], L.ACT[act], slope
+            d.stats_slots, d.stats_slot0 = stats_slots, stats_slot0
+            for i, (a, b) in enumerate(zip(g.dh, g.dw)):
+                d.dh[i], d.dw[i] = a, b
+            self._desc_cache[key] = (d, g)   # keep g alive so id() stays unique
+            return d
+        return d[0]
+
+    def tile_m(self, g: GConv) -> int:
+        return self.lib.gs_tile_m(C.byref(self._gdesc(g, 1, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+
+    # ---- convolution family -------------------------------------------------------------------------------
+    def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
+              slope=0.2, stats=None, stats_slots=0, stats_slot0=0):
+        N = x.shape[0]
+        in_cs = in_cs if in_cs is not None else x.shape[-1]
+        out_cs = out_cs if out_cs is not None else out.shape[-1]
+        d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0)
+        w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
+        L.check(self.lib.gs_gconv_forward(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _stream()),
+                "gs_gconv_forward")
+
+    def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
+        key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)
+        ent = self._desc_cache.get(key)
+        if ent is None:
+            d = L.WGradDesc()
+            d.N, d.Ha, d.Wa, d.P = a.shape[0], w.Ha, w.Wa, w.P
+            d.a_cs, d.a_co = (a_cs if a_cs is not None else a.shape[-1]), a_co
+            d.Hg, d.Wg, d.Q = w.Hg, w.Wg, w.Q
+            d.g_cs, d.g_co = (g_cs if g_cs is not None else g.shape[-1]), g_co
+            d.si, d.T, d.border, d.dw_ld = w.si, w.T, L.BORDER[w.border], w.T * w.Q
+            for i, (p, q) in enumerate(zip(w.dh, w.dw)):
+                d.dh[i], d.dw_[i] = p, q
+            ent = (d, w)
+            self._desc_cache[key] = ent
+        L.check(self.lib.gs_wgrad(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(dw), _stream()), "gs_wgrad")
+
+    def bias_grad(self, dy, C_, db, *, cs=None, co=0):
+        pixels = dy.numel() // dy.shape[-1]
+        L.check(self.lib.gs_bias_grad(_ptr(dy), pixels, C_, cs if cs is not None else dy.shape[-1], co, _ptr(db),
+                                      _stream()), "gs_bias_grad")
+
+    # ---- InstanceNorm + activation ----------------------------------------------------------------------
+    def inorm_finalize(self, partial, N, slots, Cc, hw, mean_rstd, eps=1e-5):
+        L.check(self.lib.gs_inorm_finalize(_ptr(partial), N, slots, Cc, hw, eps, _ptr(mean_rstd), _stream()),
+                "gs_inorm_finalize")
+
+    def inorm_act_forward(self, y, mean_rstd, res, x, act="none", slope=0.2):
+        N, H, W, Cc = y.shape
+        L.check(self.lib.gs_inorm_act_forward(_ptr(y), _ptr(mean_rstd), _ptr(res), _ptr(x), N, H * W, Cc,
+                                              L.ACT[act], slope, _stream()), "gs_inorm_act_forward")
+
+    def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
+                           slope=0.2):
+        N, H, W, Cc = y.shape
+        scratch = None
+        if mean_rstd is not None:
+            n = self.lib.gs_inorm_backward_scratch_floats(N, H, W, Cc)
+            scratch = torch.empty(n, dtype=torch.float32, device=y.device)
+        L.check(self.lib.gs_inorm_act_backward(_ptr(g_pad), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(dy),
+                                               _ptr(gsum), _ptr(scratch), N, H, W, Cc, fold,
+                                               L.BORDER[fold_mode], L.ACT[act], slope, _stream()),
+                "gs_inorm_act_backward")
+
+    # ---- network boundary -----------------------------------------------------------------------------------
+    def image_to_act(self, img, act_t):
+        N, Cc, H, W = img.shape
+        L.check(self.lib.gs_image_to_act(_ptr(img), _ptr(act_t), N, Cc, H, W, act_t.shape[-1], _stream()),
+                "gs_image_to_act")
+
+    def act_to_image(self, act_t, img, act="none"):
+        N, Cc, H, W = img.shape
+        L.check(self.lib.gs_act_to_image(_ptr(act_t), _ptr(img), N, Cc, H, W, act_t.shape[-1], L.ACT[act],
+                                         _stream()), "gs_act_to_image")
+
+    def act_to_image_backward(self, g_img, out_img, g_act, act="none"):
+        N, Cc, H, W = g_img.shape
+        L.check(self.lib.gs_act_to_image_backward(_ptr(g_img), _ptr(out_img), _ptr(g_act), N, Cc, H, W,
+                                                  g_act.shape[-1], L.ACT[act], _stream()),
+                "gs_act_to_image_backward")
+
+    def image_to_act_backward(self, g_pad, g_img, fold=0, fold_mode="reflect", accumulate=False):
+        N, Cc, H, W = g_img.shape
+        L.check(self.lib.gs_image_to_act_backward(_ptr(g_pad), _ptr(g_img), N, Cc, H, W, g_pad.shape[-1], fold,
+                                                  L.BORDER[fold_mode], int(accumulate), _stream()),
+                "gs_image_to_act_backward")
+
+    # ---- losses ---------------------------------------------------------------------------------------------
+    def mse_const(self, x, target, loss=None, grad=None, grad_scale=None):
+        L.check(self.lib.gs_mse_const(_ptr(x), x.numel(), float(target), _ptr(loss), _ptr(grad), _ptr(grad_scale),
+                                      _stream()), "gs_mse_const")
+
+    def l1(self, a, b, loss=None, grad_a=None, grad_scale=None):
+        L.check(self.lib.gs_l1(_ptr(a), _ptr(b), a.numel(), _ptr(loss), _ptr(grad_a), _ptr(grad_scale), _stream()),
+                "gs_l1")
+
+    def mean(self, x, out):
+        L.check(self.lib.gs_mean(_ptr(x), x.numel(), _ptr(out), _stream()), "gs_mean")
+
+    def ssim_distance(self, x, y, out):
+        NC = x.numel() // (x.shape[-1] * x.shape[-2])
+        H, W = x.shape[-2], x.shape[-1]
+        scratch = torch.empty(self.lib.gs_ssim_scratch_floats(NC, H, W), dtype=torch.float32, device=x.device)
+        L.check(self.lib.gs_ssim_distance(_ptr(x), _ptr(y), NC, H, W, _ptr(out), _ptr(scratch), _stream()),
+                "gs_ssim_distance")
+
+    # ---- optimiser -----------------------------------------------------------------------------------------
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=True):
+        bc1 = 1.0 - beta1 ** step
+        bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+        hyper = (C.c_float * 6)(lr, beta1, beta2, eps, bc1, bc2_sqrt)
+        L.check(self.lib.gs_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), hyper, float(grad_scale),
+                                      int(zero_grad), _stream()), "gs_adam_step")
+
+    def repack(self, master, index, pack):
+        L.check(self.lib.gs_repack_bf16(_ptr(master), _ptr(index), _ptr(pack), pack.numel(), _stream()),
+                "gs_repack_bf16")

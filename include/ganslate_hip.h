@@ -1,0 +1,151 @@
+/*
+ * ganslate_hip.h — C ABI of libganslate_hip.so, the MI355X (gfx950) drop-in for the arithmetic of
+ * ganslate's GAN training step.
+ *
+ * The reference (ganslate-team/ganslate @ v1) has no native code: every entry point below replaces a
+ * torch / cuDNN / apex call site on the hot path `BaseGAN.optimize_parameters`
+ * (ganslate/nn/gans/unpaired/cyclegan.py:92-124). The reference call site each function stands in for is
+ * cited next to it. Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - every call enqueues on the caller's `stream` (a hipStream_t passed as void*) and never
+ *     synchronises; the caller owns all tensors, the library owns nothing but a 256-byte zero page;
+ *   - return value 0 = ok, non-zero = error, message via gs_last_error();
+ *   - not thread-safe per process (one process per GPU, like the reference's DDP launch).
+ *
+ * Data layout: activations are NHWC bf16 with the channel count padded to a multiple
+ * of 8 ("act" below); images at the network boundary are NCHW fp32 exactly as the reference's
+ * `visuals` (cyclegan.py:39); master weights/grads/Adam state are fp32 in the "OTI" layout
+ * [P][T][Q] (P = out channels for Conv, in channels for ConvTranspose; T = kh*kw taps, row-major;
+ * Q = the other channel count, padded to a multiple of 8); bf16 weight packs are [rows][Kp] with
+ * Kp = roundup(T_class*Q, 64), K contiguous.
+ */
+#ifndef GANSLATE_HIP_H
+#define GANSLATE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_MAX_TAPS 128
+
+/* border handling of the gathered operand (reference: nn.ReflectionPad2d resnet2d.py:24,
+ * nn.ReplicationPad3d resnet3d.py:15, Conv2d(padding=1) zero padding resnet2d.py:35) */
+enum { GS_BORDER_ZERO = 0, GS_BORDER_REFLECT = 1, GS_BORDER_REPLICATE = 2 };
+/* activations (nn.ReLU resnet2d.py:27, nn.LeakyReLU(0.2) patchgan2d.py:30, nn.Tanh resnet2d.py:65) */
+enum { GS_ACT_NONE = 0, GS_ACT_RELU = 1, GS_ACT_LRELU = 2, GS_ACT_TANH = 3 };
+
+/* One "generalised convolution" class:
+ *   out[n, i*so+py, j*so+px, co] = bias[co] + sum_{t<T} sum_{ci<Ci}
+ *        in[n, B(i*si+dh[t]), B(j*si+dw[t]), ci] * w[co][t*Ci+ci]          (i<Hc, j<Wc)
+ * With so=1 it is nn.Conv2d forward (stride si) or the data-gradient of a stride-1 conv; with so=2 it
+ * is one output-parity class of nn.ConvTranspose2d(stride=2) forward or of the data-gradient of a
+ * stride-2 conv. B() applies `border`. */
+typedef struct gs_gconv_desc {
+  int32_t N, Hi, Wi, Ci;       /* gathered input: logical dims; Ci multiple of 8, Ci/8 a power of two */
+  int32_t in_cs, in_co;        /* input channel stride / channel offset in elements (concat views) */
+  int32_t Ho, Wo, Co;          /* full output dims; Co = number of channels written, multiple of 8 */
+  int32_t out_cs, out_co;      /* output channel stride / offset */
+  int32_t Hc, Wc;              /* class extent */
+  int32_t so, py, px, si;      /* output stride+phase, input stride */
+  int32_t T;                   /* taps in this class */
+  int32_t Kp;                  /* padded K of the weight pack = roundup(T*Ci, 64) */
+  int32_t w_rows;              /* rows present in the weight pack (>= Co) */
+  int32_t border;              /* GS_BORDER_* */
+  int32_t act;                 /* GS_ACT_* applied in the epilogue (after bias) */
+  float   slope;               /* LeakyReLU slope */
+  int32_t stats_slots;         /* partial-stat slots per image in `stats` (0 = no stats) */
+  int32_t stats_slot0;         /* first slot this class writes; it writes ceil(Hc*Wc/tile_m) slots */
+  int8_t  dh[GS_MAX_TAPS];
+  int8_t  dw[GS_MAX_TAPS];
+} gs_gconv_desc;
+
+/* Weight-gradient of the same family:
+ *   dw[p][t*Q+q] += sum_{n,i,j} a[n,i,j,p] * g[n, B(i*si+dh[t]), B(j*si+dw[t]), q]
+ * (`a` is the dense side: dY for Conv, X for ConvTranspose; `g` the gathered side). */
+typedef struct gs_wgrad_desc {
+  int32_t N, Ha, Wa, P, a_cs, a_co;
+  int32_t Hg, Wg, Q, g_cs, g_co;    /* Q multiple of 8, Q/8 a power of two */
+  int32_t si, T, border;
+  int32_t dw_ld;                    /* leading dimension of dw rows = T*Q */
+  int8_t  dh[GS_MAX_TAPS];
+  int8_t  dw_[GS_MAX_TAPS];
+} gs_wgrad_desc;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+int gs_init(int device);                 /* torch.cuda.set_device + lazy cuDNN handle (base.py:84-91) */
+void gs_shutdown(void);
+const char* gs_last_error(void);
+int gs_tile_m(const gs_gconv_desc* d);   /* pixel-tile height the kernel will use (stats slot count) */
+
+/* ---- convolution family (torch.nn.Conv2d / ConvTranspose2d forward + autograd backward) --------- */
+/* resnet2d.py:25,35,52-57,65,80-87; patchgan2d.py:29,36-62; backward via loss.backward() base.py:170 */
+int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                     void* out, float* stats, void* stream);
+int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream);
+/* db[c] += sum over pixels of dy[pix, c]  (bias gradient of any conv) */
+int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, void* stream);
+
+/* ---- InstanceNorm + activation (nn.InstanceNorm2d eps=1e-5 affine=False, nn/utils.py:53-59) ------ */
+/* partial [N][slots][2][C] -> mean_rstd [N][2][C] */
+int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
+                      float* mean_rstd, void* stream);
+/* x = act((y-mean)*rstd) [+ res]   (resnet2d.py:26-27, 83-84, 87, 93) */
+int gs_inorm_act_forward(const void* y, const float* mean_rstd, const void* res, void* x, int32_t N,
+                         int64_t hw, int32_t C, int32_t act, float slope, void* stream);
+/* Backward of the above. g_pad is the incoming gradient on a domain padded by `fold` on each side
+ * (the data-gradient of a reflect/replicate-padded conv; fold=0 for a plain gradient) — the border is
+ * folded back here (adjoint of ReflectionPad2d). g2 (optional, unpadded) is added (residual join).
+ * Outputs dy (gradient w.r.t. the conv output y) and optionally gsum = fold(g_pad)+g2 (skip path).
+ * If mean_rstd is NULL there is no norm: `y` then holds the activation OUTPUT and dy = g*act'(y). */
+int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
+                          void* dy, void* gsum, float* scratch, int32_t N, int32_t H, int32_t W,
+                          int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
+                          void* stream);
+int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C);
+
+/* ---- network boundary: NCHW fp32 images <-> NHWC bf16 activations ------------------------------- */
+/* x NCHW fp32 [N,C,H,W] -> act [N,H,W,Cp]  (set_input, cyclegan.py:84-90) */
+int gs_image_to_act(const float* img, void* act, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                    void* stream);
+/* act -> NCHW fp32, optional tanh (resnet2d.py:65) */
+int gs_act_to_image(const void* act, float* img, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                    int32_t act_kind, void* stream);
+/* gradient of gs_act_to_image: g_img NCHW fp32, out = forward output image (for tanh') -> g_act */
+int gs_act_to_image_backward(const float* g_img, const float* out_img, void* g_act, int32_t N, int32_t C,
+                             int32_t H, int32_t W, int32_t Cp, int32_t act_kind, void* stream);
+/* gradient of gs_image_to_act composed with the first conv's padding fold: g_pad act (padded by fold)
+ * -> NCHW fp32 image gradient; accumulate != 0 adds into g_img */
+int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t H, int32_t W,
+                             int32_t Cp, int32_t fold, int32_t fold_mode, int32_t accumulate, void* stream);
+
+/* ---- losses (fp32, on the boundary images / discriminator maps) --------------------------------- */
+/* loss[0] = mean((x-target)^2); if grad != NULL: grad = grad_scale * 2*(x-target)/n
+ * (nn.MSELoss vs expanded constant, adversarial_loss.py:28-29,60-62) */
+int gs_mse_const(const float* x, int64_t n, float target, float* loss, float* grad, const float* grad_scale,
+                 void* stream);
+/* loss[0] = mean(|a-b|); if grad_a != NULL: grad_a = grad_scale * sign(a-b)/n
+ * (nn.L1Loss, cyclegan_losses.py:64,75,97-101) */
+int gs_l1(const float* a, const float* b, int64_t n, float* loss, float* grad_a, const float* grad_scale,
+          void* stream);
+/* out[0] = mean(x)  (train_metrics.py:27-33) */
+int gs_mean(const float* x, int64_t n, float* out, void* stream);
+/* SSIM distance of ganslate/nn/losses/utils/ssim.py:65-99 on (x+1)/2,(y+1)/2, window 11, sigma 1.5:
+ * out[0] = mean(sqrt(relu(2 - S1 - S2))) over [N*C, H-10, W-10] */
+int gs_ssim_distance(const float* x, const float* y, int32_t NC, int32_t H, int32_t W, float* out,
+                     float* scratch, void* stream);
+int64_t gs_ssim_scratch_floats(int32_t NC, int32_t H, int32_t W);
+
+/* ---- optimiser (torch.optim.Adam betas=(0.5,0.999) eps=1e-8, cyclegan.py:81-82) ------------------ */
+/* hyper (host pointer to 6 floats): lr, beta1, beta2, eps, bias_correction1, sqrt(bias_correction2).
+ * grad_scale multiplies the gradient (1/world_size after an all-reduce SUM). zero_grad != 0 clears g. */
+int gs_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_host,
+                 float grad_scale, int32_t zero_grad, void* stream);
+/* pack[e] = bf16(master[index[e]]) (index < 0 -> 0): refresh the bf16 forward/dgrad weight packs */
+int gs_repack_bf16(const float* master, const int32_t* index, void* pack, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANSLATE_HIP_H */

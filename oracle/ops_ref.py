@@ -1,0 +1,244 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+Op-level CPU restatement of every entry point of include/ganslate_hip.h, in plain torch fp32 on the CPU, with
+the same tensor conventions as ganslate_amd.hip.ops.HipOps (NHWC bf16 activations, OTI fp32 master weights,
+[rows][Kp] bf16 packs). It serves two purposes:
+  * `-m gpu` tests compare each HIP kernel with the function of the same name here on identical inputs;
+  * `-m "not gpu"` tests run the network executor (ganslate_amd/nn/native) on this backend and compare it with
+    torch.nn.functional / autograd, which pins the host-side lowering (taps, packs, folds) without a GPU.
+
+The arithmetic restated is torch's own: nn.Conv2d / nn.ConvTranspose2d (resnet2d.py:25,35,52-57,65,80-87;
+patchgan2d.py:29,36-62), nn.InstanceNorm2d(eps=1e-5, affine=False) (nn/utils.py:53-59), nn.ReflectionPad2d
+(resnet2d.py:24), nn.MSELoss / nn.L1Loss (adversarial_loss.py:28-29; cyclegan_losses.py:64), SSIMLoss
+(nn/losses/utils/ssim.py:65-99), torch.optim.Adam (cyclegan.py:81-82).
+Pinned against torch.nn.functional in tests/test_lowering_cpu.py and, through the network-level oracle
+(oracle/torch_ref.py), against golden vectors generated from the imported reference (tests/golden/).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _border(idx, n, mode):
+    """index tensor -> (clamped index, validity mask)"""
+    if mode == "zero":
+        ok = (idx >= 0) & (idx < n)
+        return idx.clamp(0, n - 1), ok
+    if mode == "reflect":
+        i = idx.abs()
+        i = torch.where(i >= n, 2 * n - 2 - i, i)
+        return i, torch.ones_like(idx, dtype=torch.bool)
+    return idx.clamp(0, n - 1), torch.ones_like(idx, dtype=torch.bool)
+
+
+def _act(v, act, slope):
+    if act == "relu":
+        return F.relu(v)
+    if act == "lrelu":
+        return F.leaky_relu(v, slope)
+    if act == "tanh":
+        return torch.tanh(v)
+    return v
+
+
+def _act_grad_from_out(o, act, slope):
+    if act == "relu":
+        return (o > 0).float()
+    if act == "lrelu":
+        return torch.where(o > 0, torch.ones_like(o), torch.full_like(o, slope))
+    if act == "tanh":
+        return 1 - o * o
+    return torch.ones_like(o)
+
+
+def _fold(gpad, H, W, fold, mode="reflect"):
+    """adjoint of ReflectionPad2d(fold) on an NHWC tensor padded by `fold`"""
+    if fold == 0:
+        return gpad
+    assert mode == "reflect"
+    N, Hp, Wp, C = gpad.shape
+    out = torch.zeros(N, H, W, C, dtype=gpad.dtype)
+    ih, _ = _border(torch.arange(Hp) - fold, H, "reflect")
+    iw, _ = _border(torch.arange(Wp) - fold, W, "reflect")
+    tmp = torch.zeros(N, H, Wp, C, dtype=gpad.dtype)
+    tmp.index_add_(1, ih, gpad)
+    out.index_add_(2, iw, tmp)
+    return out
+
+
+class RefOps:
+    """Same method names and argument conventions as HipOps, CPU tensors."""
+    name = "oracle"
+    device = torch.device("cpu")
+
+    def tile_m(self, g):
+        return 1 << 30  # one statistics slot per class
+
+    # ---- convolution family ---------------------------------------------------------------------------
+    def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
+              stats=None, stats_slots=0, stats_slot0=0):
+        N = x.shape[0]
+        xin = x[..., in_co:in_co + g.Ci].float()
+        Wt = wpack[g.pack_offset:g.pack_offset + g.w_rows * g.Kp].view(g.w_rows, g.Kp).float()
+        Wt = Wt[:g.Co, :g.T * g.Ci].reshape(g.Co, g.T, g.Ci)
+        i = torch.arange(g.Hc) * g.si
+        j = torch.arange(g.Wc) * g.si
+        acc = torch.zeros(N, g.Hc, g.Wc, g.Co)
+        for t in range(g.T):
+            ih, okh = _border(i + g.dh[t], g.Hi, g.border)
+            iw, okw = _border(j + g.dw[t], g.Wi, g.border)
+            patch = xin[:, ih][:, :, iw] * (okh[:, None] & okw[None, :]).float()[None, :, :, None]
+            acc += patch @ Wt[:, t, :].t()
+        if bias is not None:
+            acc += bias[:g.Co].float()
+        if stats_slots > 0:
+            sv = stats.view(N, stats_slots, 2, g.Co)
+            sv[:, stats_slot0, 0] = acc.sum((1, 2))
+            sv[:, stats_slot0, 1] = (acc * acc).sum((1, 2))
+        acc = _act(acc, act, slope)
+        oh = torch.arange(g.Hc) * g.so + g.py
+        ow = torch.arange(g.Wc) * g.so + g.px
+        out[:, oh[:, None], ow[None, :], out_co:out_co + g.Co] = acc.to(out.dtype)
+
+    def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
+        av = a[..., a_co:a_co + w.P].float()
+        gv = g[..., g_co:g_co + w.Q].float()
+        i = torch.arange(w.Ha) * w.si
+        j = torch.arange(w.Wa) * w.si
+        d = dw.view(w.P, w.T, w.Q)
+        for t in range(w.T):
+            ih, okh = _border(i + w.dh[t], w.Hg, w.border)
+            iw, okw = _border(j + w.dw[t], w.Wg, w.border)
+            patch = gv[:, ih][:, :, iw] * (okh[:, None] & okw[None, :]).float()[None, :, :, None]
+            d[:, t, :] += torch.einsum("nijp,nijq->pq", av, patch)
+
+    def bias_grad(self, dy, C_, db, *, cs=None, co=0):
+        db[:C_] += dy[..., co:co + C_].float().reshape(-1, C_).sum(0)
+
+    # ---- InstanceNorm + activation -------------------------------------------------------------------
+    def inorm_finalize(self, partial, N, slots, Cc, hw, mean_rstd, eps=1e-5):
+        p = partial.view(N, slots, 2, Cc).double().sum(1)
+        mean = p[:, 0] / hw
+        var = (p[:, 1] / hw - mean * mean).clamp_min(0)
+        mr = mean_rstd.view(N, 2, Cc)
+        mr[:, 0] = mean.float()
+        mr[:, 1] = (1.0 / torch.sqrt(var + eps)).float()
+
+    def inorm_act_forward(self, y, mean_rstd, res, x, act="none", slope=0.2):
+        N, H, W, Cc = y.shape
+        mr = mean_rstd.view(N, 2, Cc)
+        v = (y.float() - mr[:, 0][:, None, None, :]) * mr[:, 1][:, None, None, :]
+        v = _act(v, act, slope)
+        if res is not None:
+            v = v + res.float()
+        x.copy_(v.to(x.dtype))
+
+    def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
+                           slope=0.2):
+        N, H, W, Cc = y.shape
+        g = _fold(g_pad.float(), H, W, fold, fold_mode)
+        if g2 is not None:
+            g = g + g2.float()
+        if gsum is not None:
+            gsum.copy_(g.to(gsum.dtype))
+        if mean_rstd is None:
+            dy.copy_((g * _act_grad_from_out(y.float(), act, slope)).to(dy.dtype))
+            return
+        mr = mean_rstd.view(N, 2, Cc)
+        rstd = mr[:, 1][:, None, None, :]
+        yh = (y.float() - mr[:, 0][:, None, None, :]) * rstd
+        gh = g * _act_grad_from_out(yh, act, slope)
+        s1 = gh.mean((1, 2), keepdim=True)
+        s2 = (gh * yh).mean((1, 2), keepdim=True)
+        dy.copy_((rstd * (gh - s1 - yh * s2)).to(dy.dtype))
+
+    # ---- network boundary --------------------------------------------------------------------------------
+    def image_to_act(self, img, act_t):
+        N, Cc, H, W = img.shape
+        act_t.zero_()
+        act_t[..., :Cc] = img.permute(0, 2, 3, 1).to(act_t.dtype)
+
+    def act_to_image(self, act_t, img, act="none"):
+        Cc = img.shape[1]
+        img.copy_(_act(act_t[..., :Cc].float(), act, 0.0).permute(0, 3, 1, 2))
+
+    def act_to_image_backward(self, g_img, out_img, g_act, act="none"):
+        Cc = g_img.shape[1]
+        g = g_img
+        if act != "none":
+            g = g * _act_grad_from_out(out_img, act, 0.0)
+        g_act.zero_()
+        g_act[..., :Cc] = g.permute(0, 2, 3, 1).to(g_act.dtype)
+
+    def image_to_act_backward(self, g_pad, g_img, fold=0, fold_mode="reflect", accumulate=False):
+        N, Cc, H, W = g_img.shape
+        g = _fold(g_pad.float(), H, W, fold, fold_mode)[..., :Cc].permute(0, 3, 1, 2)
+        if accumulate:
+            g_img += g
+        else:
+            g_img.copy_(g)
+
+    # ---- losses -----------------------------------------------------------------------------------------
+    def mse_const(self, x, target, loss=None, grad=None, grad_scale=None):
+        if loss is not None:
+            loss.copy_(((x - target) ** 2).mean())
+        if grad is not None:
+            s = grad_scale if grad_scale is not None else 1.0
+            grad.copy_(s * 2.0 * (x - target) / x.numel())
+
+    def l1(self, a, b, loss=None, grad_a=None, grad_scale=None):
+        if loss is not None:
+            loss.copy_((a - b).abs().mean())
+        if grad_a is not None:
+            s = grad_scale if grad_scale is not None else 1.0
+            grad_a.copy_(s * torch.sign(a - b) / a.numel())
+
+    def mean(self, x, out):
+        out.copy_(x.mean())
+
+    def ssim_distance(self, x, y, out):
+        out.copy_(ssim_distance(x, y))
+
+    # ---- optimiser ---------------------------------------------------------------------------------------
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=True):
+        gi = g * grad_scale
+        m.lerp_(gi, 1 - beta1)
+        v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2s = math.sqrt(1 - beta2 ** step)
+        p.addcdiv_(m, (v.sqrt() / bc2s).add_(eps), value=-lr / bc1)
+        if zero_grad:
+            g.zero_()
+
+    def repack(self, master, index, pack):
+        idx = index.long()
+        vals = master.reshape(-1)[idx.clamp_min(0)]
+        pack.copy_(torch.where(idx >= 0, vals, torch.zeros_like(vals)).to(pack.dtype))
+
+
+def ssim_distance(X, Y):
+    """Restatement of SSIMLoss.forward (ganslate/nn/losses/utils/ssim.py:65-99) on inputs in [-1, 1]
+    mapped to [0, 1] by the caller's (x+1)/2 (cyclegan_losses.py:83-84, train_metrics.py:41-42)."""
+    X = (X + 1) / 2
+    Y = (Y + 1) / 2
+    if X.ndim == 5:
+        X = X.reshape(-1, *X.shape[2:])
+        Y = Y.reshape(-1, *Y.shape[2:])
+    ch = X.shape[1]
+    coords = torch.arange(11, dtype=torch.float32) - 5
+    g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+    g = (g / g.sum()).view(1, 1, 1, 11).repeat(ch, 1, 1, 1)
+
+    def blur(t):
+        t = F.conv2d(t, g, groups=ch)
+        return F.conv2d(t, g.transpose(2, 3), groups=ch)
+
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    mu1, mu2 = blur(X), blur(Y)
+    s1 = blur(X * X) - mu1 ** 2
+    s2 = blur(Y * Y) - mu2 ** 2
+    s12 = blur(X * Y) - mu1 * mu2
+    S1 = (2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)
+    S2 = (2 * s12 + C2) / (s1 + s2 + C2)
+    return torch.sqrt(torch.relu(2 - (S1 + S2))).mean()

@@ -1,0 +1,80 @@
+"""Host-side lowering (taps, parity classes, weight packs, pad fold) checked against torch.nn.functional and
+autograd on the CPU through the op-level oracle (oracle/ops_ref.py). fp32 packs/activations -> tight tolerance."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ganslate_amd.nn.native.spec import ConvSpec, lower, pad8
+from oracle.ops_ref import RefOps, _fold
+
+SPECS = [
+    ConvSpec("conv", 5, 6, 3, 1, 1, pad_mode="reflect"),      # resnet2d.py:80-87 residual conv
+    ConvSpec("conv", 3, 12, 7, 1, 3, pad_mode="reflect"),     # resnet2d.py:24-25 stem
+    ConvSpec("conv", 8, 16, 3, 2, 1),                         # resnet2d.py:35 down-sampling
+    ConvSpec("conv", 3, 8, 4, 2, 1),                          # patchgan2d.py:29
+    ConvSpec("conv", 16, 9, 4, 1, 1),                         # patchgan2d.py:50-62 stride-1 k4
+    ConvSpec("conv", 16, 1, 4, 1, 1),
+    ConvSpec("convT", 16, 8, 3, 2, 1, 1),                     # resnet2d.py:52-57
+    ConvSpec("convT", 8, 3, 4, 2, 1, 0),                      # unet2d.py:122
+]
+
+
+def torch_forward(spec, x, w, b):
+    if spec.kind == "conv":
+        if spec.pad_mode == "reflect":
+            return F.conv2d(F.pad(x, (spec.pad,) * 4, mode="reflect"), w, b, stride=spec.stride)
+        return F.conv2d(x, w, b, stride=spec.stride, padding=spec.pad)
+    return F.conv_transpose2d(x, w, b, stride=spec.stride, padding=spec.pad, output_padding=spec.out_pad)
+
+
+@pytest.mark.parametrize("spec", SPECS, ids=lambda s: f"{s.kind}{s.k}s{s.stride}{s.pad_mode}{s.cin}x{s.cout}")
+@pytest.mark.parametrize("hw", [(10, 12), (9, 11)])
+def test_lowering_matches_torch(spec, hw):
+    torch.manual_seed(0)
+    ops = RefOps()
+    H, W = hw
+    N = 2
+    x = torch.randn(N, spec.cin, H, W, requires_grad=True)
+    w = torch.randn(spec.torch_weight_shape(), requires_grad=True) * 0.2
+    w.retain_grad()
+    b = torch.randn(spec.cout, requires_grad=True)
+    y = torch_forward(spec, x, w, b)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+
+    low = lower(spec, H, W)
+    assert (low.Ho, low.Wo) == tuple(y.shape[2:])
+    master = spec.master_from_torch(w.detach())
+    fpack = torch.empty(low.fwd_index.size, dtype=torch.float32)
+    ops.repack(master, torch.from_numpy(low.fwd_index), fpack)
+    dpack = torch.empty(low.dgrad_index.size, dtype=torch.float32)
+    ops.repack(master, torch.from_numpy(low.dgrad_index), dpack)
+    bias = torch.zeros(spec.cout_p); bias[:spec.cout] = b.detach()
+
+    xa = torch.zeros(N, H, W, spec.cin_p); ops.image_to_act(x.detach(), xa)
+    ya = torch.full((N, low.Ho, low.Wo, spec.cout_p), float("nan"))
+    for g in low.fwd:
+        ops.gconv(g, xa, fpack, bias, ya)
+    assert torch.allclose(ya[..., :spec.cout].permute(0, 3, 1, 2), y.detach(), atol=1e-4, rtol=1e-4)
+    assert torch.all(ya[..., spec.cout:] == 0)
+
+    gya = torch.zeros(N, low.Ho, low.Wo, spec.cout_p); ops.image_to_act(gy, gya)
+    f = low.dgrad_fold
+    gxa = torch.full((N, H + 2 * f, W + 2 * f, spec.cin_p), float("nan"))
+    for g in low.dgrad:
+        ops.gconv(g, gya, dpack, None, gxa)
+    gx = _fold(gxa, H, W, f)[..., :spec.cin].permute(0, 3, 1, 2)
+    assert torch.allclose(gx, x.grad, atol=1e-4, rtol=1e-4)
+
+    dw = torch.zeros(spec.P, spec.T, spec.Q)
+    a, gth = (gya, xa) if spec.kind == "conv" else (xa, gya)
+    ops.wgrad(low.wgrad, a, gth, dw)
+    assert torch.allclose(spec.torch_from_master(dw), w.grad, atol=1e-3, rtol=1e-4)
+    db = torch.zeros(spec.cout_p); ops.bias_grad(gya, spec.cout_p, db)
+    assert torch.allclose(db[:spec.cout], b.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_master_roundtrip():
+    for spec in SPECS:
+        w = torch.randn(spec.torch_weight_shape())
+        assert torch.equal(spec.torch_from_master(spec.master_from_torch(w)), w)
