@@ -1,0 +1,3 @@
+from .image_datasets import (PairedImageDataset, PairedImageDatasetConfig, UnpairedImageDataset,  # noqa: F401
+                             UnpairedImageDatasetConfig)
+from .synthetic import SyntheticImageDataset, SyntheticImageDatasetConfig  # noqa: F401

@@ -1,0 +1,100 @@
+"""Config dataclasses (and thin PIL loaders) for the reference's image-folder datasets so that
+projects/*/experiments/*.yaml load unchanged (ganslate/data/unpaired_image_dataset.py:19-62,
+paired_image_dataset.py:20-60). Host-side image decoding is outside the hot path: the
+loaders implement resize / random_crop / random_flip with PIL + torch only and [-1,1] normalisation."""
+import random
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Tuple
+
+import torch
+from torch.utils.data import Dataset
+
+from .. import configs
+
+EXTENSIONS = [".jpg", ".jpeg", ".png"]
+
+
+@dataclass
+class UnpairedImageDatasetConfig(configs.base.BaseDatasetConfig):
+    image_channels: int = 3
+    preprocess: Tuple[str] = ("resize", "random_crop", "random_flip")
+    load_size: Tuple[int, int] = field(default_factory=lambda: [286, 286])
+    final_size: Tuple[int, int] = field(default_factory=lambda: [256, 256])
+
+
+@dataclass
+class PairedImageDatasetConfig(configs.base.BaseDatasetConfig):
+    image_channels: int = 3
+    preprocess: Tuple[str] = ("resize", "random_crop", "random_flip")
+    load_size: Tuple[int, int] = field(default_factory=lambda: [286, 286])
+    final_size: Tuple[int, int] = field(default_factory=lambda: [256, 256])
+
+
+def _files(root):
+    root = Path(root)
+    assert root.is_dir(), f"{root} is not a valid directory"
+    return sorted(p for p in root.rglob("*") if p.suffix.lower() in EXTENSIONS)
+
+
+class _Transform:
+    def __init__(self, conf):
+        d = conf[conf.mode].dataset
+        self.pre, self.load, self.final = list(d.preprocess), tuple(d.load_size), tuple(d.final_size)
+
+    def params(self):
+        return {"crop": (random.random(), random.random()), "flip": random.random() > 0.5}
+
+    def __call__(self, img, prm):
+        import numpy as np
+        from PIL import Image
+        if "resize" in self.pre:
+            img = img.resize((self.load[1], self.load[0]), Image.BICUBIC)
+        if "random_crop" in self.pre:
+            W, H = img.size
+            top = int(prm["crop"][0] * max(H - self.final[0], 0))
+            left = int(prm["crop"][1] * max(W - self.final[1], 0))
+            img = img.crop((left, top, left + self.final[1], top + self.final[0]))
+        if "random_flip" in self.pre and prm["flip"]:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        a = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0)
+        a = a.unsqueeze(0) if a.ndim == 2 else a.permute(2, 0, 1)
+        return (a - 0.5) / 0.5
+
+
+class UnpairedImageDataset(Dataset):
+
+    def __init__(self, conf):
+        root = Path(conf[conf.mode].dataset.root)
+        self.A_paths, self.B_paths = _files(root / "A"), _files(root / "B")
+        self.transform = _Transform(conf)
+        self.mode = "RGB" if conf[conf.mode].dataset.image_channels == 3 else "L"
+
+    def __getitem__(self, index):
+        from PIL import Image
+        A = Image.open(self.A_paths[index % len(self.A_paths)]).convert(self.mode)
+        B = Image.open(self.B_paths[random.randint(0, len(self.B_paths) - 1)]).convert(self.mode)
+        return {"A": self.transform(A, self.transform.params()), "B": self.transform(B, self.transform.params())}
+
+    def __len__(self):
+        return max(len(self.A_paths), len(self.B_paths))
+
+
+class PairedImageDataset(Dataset):
+
+    def __init__(self, conf):
+        root = Path(conf[conf.mode].dataset.root)
+        self.A_paths, self.B_paths = _files(root / "A"), _files(root / "B")
+        assert len(self.A_paths) == len(self.B_paths)
+        self.transform = _Transform(conf)
+        self.mode = "RGB" if conf[conf.mode].dataset.image_channels == 3 else "L"
+
+    def __getitem__(self, index):
+        from PIL import Image
+        prm = self.transform.params()   # same random transform for both images of the pair
+        A = Image.open(self.A_paths[index]).convert(self.mode)
+        B = Image.open(self.B_paths[index]).convert(self.mode)
+        return {"A": self.transform(A, prm), "B": self.transform(B, prm)}
+
+    def __len__(self):
+        return len(self.A_paths)

@@ -19,6 +19,7 @@ def _stream():
 class HipOps:
     """The product backend: hand-written gfx950 kernels behind libganslate_hip.so."""
     name = "hip"
+    act_dtype = torch.bfloat16   # storage type of activations and weight packs
 
     def __init__(self, device=None):
         self.lib = L.load()

@@ -1,0 +1,382 @@
+"""Executor for conv networks (Resnet2D, PatchGAN2D, ...) on the HIP kernel library.
+
+A network is a list of `Node`s (conv -> [InstanceNorm] -> activation [+ residual]). The executor owns
+  * one flat fp32 master buffer (OTI-layout weights + biases of every layer), exposed as a single
+    torch.nn.Parameter whose .grad is the flat fp32 gradient buffer the weight-gradient kernels accumulate
+    into (this is also the bucket the data-parallel all-reduce works on),
+  * the bf16 forward / data-gradient weight packs, refreshed from the master after every optimiser step,
+  * hand-written forward and backward passes (no per-layer autograd): the whole network is ONE
+    torch.autograd.Function, so recipe code keeps the reference's shape — `loss.backward()` drives it
+    (ganslate/nn/gans/base.py:155-170) and images cross the boundary as NCHW fp32 tensors like the
+    reference's `visuals` (cyclegan.py:39).
+
+Reference semantics: layer order / hyper-parameters of ganslate/nn/generators/resnet/resnet2d.py:14-93 and
+ganslate/nn/discriminators/patchgan/patchgan2d.py:17-66; weight init of ganslate/nn/utils.py:13-36.
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .backend import get_ops
+from .spec import ConvSpec, Lowered, lower
+
+
+@dataclass
+class Node:
+    spec: ConvSpec
+    norm: bool = True
+    act: str = "relu"            # applied after the norm, or in the conv epilogue when norm is False
+    slope: float = 0.2
+    res: Optional[int] = None    # index of the node whose output is added after the norm (residual block tail)
+    name: str = ""               # torch module path of the conv in the reference net, e.g. "model.1"
+    aliases: Tuple[str, ...] = ()  # additional state_dict prefixes holding the same tensors
+
+
+class _Saved:
+    __slots__ = ("x_img", "acts", "ys", "mrs", "out_img", "lows", "N")
+
+
+class NativeNet:
+    """Hand-written fwd/bwd of a conv network over an ops backend (HIP in production)."""
+
+    def __init__(self, nodes: List[Node], in_channels: int, out_channels: int, out_act: str = "none", ops=None):
+        self.ops = ops if ops is not None else get_ops()
+        self.device = self.ops.device
+        self.nodes = nodes
+        self.in_channels, self.out_channels, self.out_act = in_channels, out_channels, out_act
+        assert nodes[0].spec.cin == in_channels and nodes[-1].spec.cout == out_channels
+        assert not nodes[-1].norm, "last node feeds the image boundary directly"
+        # ---- flat parameter layout: [w_0 | b_0 | w_1 | b_1 | ...] ------------------------------------------
+        self.w_off, self.b_off, off = [], [], 0
+        for nd in nodes:
+            self.w_off.append(off); off += nd.spec.master_numel
+            self.b_off.append(off); off += nd.spec.cout_p
+        self.numel = off
+        self.master = torch.nn.Parameter(torch.zeros(off, dtype=torch.float32, device=self.device))
+        self.master.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.master._owner_net = self
+        self._token = torch.zeros(1, requires_grad=True, device=self.device)
+        self._low_cache: Dict[Tuple[int, int], list] = {}
+        self._packs: Dict[Tuple[int, int], dict] = {}
+        self._packs_dirty = True
+        self.training = True
+        # data-parallel state (set by parallelize())
+        self._dist = None
+        self._fw_pending = 0
+        self._reduce_handles = []
+        self._reduced = False
+        self.grad_dirty = False
+
+    # ---- torch.nn.Module-like surface used by BaseGAN ----------------------------------------------------------
+    def parameters(self):
+        return [self.master]
+
+    @property
+    def requires_grad(self) -> bool:
+        return self.master.requires_grad
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        return self
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    # ---- weights ------------------------------------------------------------------------------------------------------
+    def init_weights(self, init_type="normal", gain=0.02):
+        """ganslate/nn/utils.py:13-36 — N(0, gain) (or xavier/kaiming/orthogonal) conv weights, zero biases; drawn
+        with torch's CPU RNG in layer order."""
+        from torch.nn import init
+        flat = torch.zeros(self.numel, dtype=torch.float32)
+        for i, nd in enumerate(self.nodes):
+            w = torch.empty(nd.spec.torch_weight_shape())
+            if init_type == "normal":
+                init.normal_(w, 0.0, gain)
+            elif init_type == "xavier":
+                init.xavier_normal_(w, gain=gain)
+            elif init_type == "kaiming":
+                init.kaiming_normal_(w, a=0, mode="fan_in")
+            elif init_type == "orthogonal":
+                init.orthogonal_(w, gain=gain)
+            else:
+                raise NotImplementedError(f"initialization method `{init_type}` is not implemented")
+            flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
+        with torch.no_grad():
+            self.master.copy_(flat.to(self.device))
+        self._packs_dirty = True
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """torch-layout tensors under the reference's module names (incl. aliases such as encoder.N == model.N)."""
+        sd = {}
+        m = self.master.detach()
+        for i, nd in enumerate(self.nodes):
+            w = nd.spec.torch_from_master(m[self.w_off[i]:self.w_off[i] + nd.spec.master_numel])
+            b = m[self.b_off[i]:self.b_off[i] + nd.spec.cout].clone()
+            for prefix in (nd.name,) + tuple(nd.aliases):
+                sd[f"{prefix}.weight"] = w
+                if nd.spec.bias:
+                    sd[f"{prefix}.bias"] = b
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        flat = torch.zeros(self.numel, dtype=torch.float32)
+        for i, nd in enumerate(self.nodes):
+            w = sd[f"{nd.name}.weight"].detach().float().cpu()
+            assert tuple(w.shape) == tuple(nd.spec.torch_weight_shape()), (nd.name, w.shape)
+            flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
+            if nd.spec.bias and f"{nd.name}.bias" in sd:
+                flat[self.b_off[i]:self.b_off[i] + nd.spec.cout] = sd[f"{nd.name}.bias"].detach().float().cpu()
+        with torch.no_grad():
+            self.master.copy_(flat.to(self.device))
+        self._packs_dirty = True
+
+    def grads_state_dict(self) -> Dict[str, torch.Tensor]:
+        """gradients in torch layout (for parity tests / inspection)."""
+        sd = {}
+        g = self.master.grad
+        for i, nd in enumerate(self.nodes):
+            sd[f"{nd.name}.weight"] = nd.spec.torch_from_master(g[self.w_off[i]:self.w_off[i] + nd.spec.master_numel])
+            sd[f"{nd.name}.bias"] = g[self.b_off[i]:self.b_off[i] + nd.spec.cout].clone()
+        return sd
+
+    def mark_packs_dirty(self):
+        self._packs_dirty = True
+
+    # ---- lowering / packs (per input size) -----------------------------------------------------------------------
+    def _lowered(self, H, W) -> List[Lowered]:
+        key = (H, W)
+        if key not in self._low_cache:
+            lows, h, w = [], H, W
+            for nd in self.nodes:
+                lw = lower(nd.spec, h, w)
+                lows.append(lw)
+                h, w = lw.Ho, lw.Wo
+            self._low_cache[key] = lows
+        return self._low_cache[key]
+
+    def _get_packs(self, H, W):
+        """bf16 packs are size-independent except for the parity-class split, which only depends on the spec;
+        one pack set per (H, W) key keeps the bookkeeping trivial (a net sees one or two sizes in practice)."""
+        key = (H, W)
+        pk = self._packs.get(key)
+        if pk is None:
+            lows = self._lowered(H, W)
+            f_idx, d_idx, f_off, d_off = [], [], [], []
+            fo = do = 0
+            for i, lw in enumerate(lows):
+                fi = lw.fwd_index.astype(np.int64); fi[fi >= 0] += self.w_off[i]
+                di = lw.dgrad_index.astype(np.int64); di[di >= 0] += self.w_off[i]
+                f_idx.append(fi); d_idx.append(di); f_off.append(fo); d_off.append(do)
+                fo += fi.size; do += di.size
+            pk = {
+                "f_index": torch.from_numpy(np.concatenate(f_idx).astype(np.int32)).to(self.device),
+                "d_index": torch.from_numpy(np.concatenate(d_idx).astype(np.int32)).to(self.device),
+                "f_off": f_off, "d_off": d_off,
+                # + 64 elements of slack so the last row's padded K-steps stay inside the allocation
+                "fpack": torch.zeros(fo + 64, dtype=self.ops.act_dtype, device=self.device),
+                "dpack": torch.zeros(do + 64, dtype=self.ops.act_dtype, device=self.device),
+                "fresh": False,
+            }
+            self._packs[key] = pk
+        if self._packs_dirty:
+            for p in self._packs.values():
+                p["fresh"] = False
+            self._packs_dirty = False
+        if not pk["fresh"]:
+            m = self.master.detach()
+            self.ops.repack(m, pk["f_index"], pk["fpack"][:pk["f_index"].numel()])
+            self.ops.repack(m, pk["d_index"], pk["dpack"][:pk["d_index"].numel()])
+            pk["fresh"] = True
+        return pk
+
+    # ---- forward ----------------------------------------------------------------------------------------------------------
+    def forward(self, x):
+        assert x.dim() == 4 and x.shape[1] == self.in_channels, f"expected N x {self.in_channels} x H x W"
+        x = x.contiguous().float()
+        record = torch.is_grad_enabled() and (x.requires_grad or self.requires_grad)
+        if not record:
+            out, _ = self._forward(x.detach(), save=False)
+            return out
+        return _NetFn.apply(x, self._token, self)
+
+    def _forward(self, x, save):
+        ops, dev = self.ops, self.device
+        N, _, H, W = x.shape
+        lows = self._lowered(H, W)
+        pk = self._get_packs(H, W)
+        m = self.master.detach()
+        a = torch.empty(N, H, W, self.nodes[0].spec.cin_p, dtype=self.ops.act_dtype, device=dev)
+        ops.image_to_act(x, a)
+        acts, ys, mrs = [a], [], []
+        for i, (nd, lw) in enumerate(zip(self.nodes, lows)):
+            sp = nd.spec
+            bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
+            fpack = pk["fpack"][pk["f_off"][i]:]
+            y = torch.empty(N, lw.Ho, lw.Wo, sp.cout_p, dtype=self.ops.act_dtype, device=dev)
+            if nd.norm:
+                slots, offs = 0, []
+                for g in lw.fwd:
+                    offs.append(slots)
+                    tm = ops.tile_m(g)
+                    slots += (g.Hc * g.Wc + tm - 1) // tm
+                part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=dev)
+                for g, o in zip(lw.fwd, offs):
+                    ops.gconv(g, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
+                mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=dev)
+                ops.inorm_finalize(part, N, slots, sp.cout_p, lw.Ho * lw.Wo, mr)
+                xo = torch.empty_like(y)
+                res = acts[nd.res + 1] if nd.res is not None else None
+                ops.inorm_act_forward(y, mr, res, xo, act=nd.act, slope=nd.slope)
+                ys.append(y if save else None); mrs.append(mr if save else None)
+                acts.append(xo)
+            else:
+                assert nd.res is None
+                for g in lw.fwd:
+                    ops.gconv(g, acts[-1], fpack, bias, y, act=nd.act, slope=nd.slope)
+                ys.append(None); mrs.append(None)
+                acts.append(y)
+        lw = lows[-1]
+        out = torch.empty(N, self.out_channels, lw.Ho, lw.Wo, dtype=torch.float32, device=dev)
+        ops.act_to_image(acts[-1], out, act=self.out_act)
+        if not save:
+            return out, None
+        s = _Saved()
+        s.x_img, s.acts, s.ys, s.mrs, s.out_img, s.lows, s.N = x, acts, ys, mrs, out, lows, N
+        return out, s
+
+    # ---- backward ---------------------------------------------------------------------------------------------------------
+    def _backward(self, s: _Saved, g_img, need_input_grad: bool, want_w: bool):
+        ops, dev = self.ops, self.device
+        nodes, lows, N = self.nodes, s.lows, s.N
+        if self.master.grad is None:
+            self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        H, W = s.x_img.shape[2], s.x_img.shape[3]
+        pk = self._get_packs(H, W)
+        grad = self.master.grad
+        last = len(nodes) - 1
+        ga = torch.empty_like(s.acts[-1])
+        ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
+        pending = (ga, 0, None)       # gradient w.r.t. the output of node i: (tensor on padded domain, fold, extra)
+        skip: Dict[int, torch.Tensor] = {}
+        final_pass = want_w and self._dist is not None and self._fw_pending == 0
+        for i in range(last, -1, -1):
+            nd, lw, sp = nodes[i], lows[i], nodes[i].spec
+            g_pad, fold, g2 = pending
+            x_out = s.acts[i + 1]
+            # ---- gradient w.r.t. the conv output y ---------------------------------------------------------------
+            need_total = nd.res is not None
+            if nd.norm or nd.act != "none" or fold > 0 or g2 is not None:
+                dy = torch.empty_like(x_out)
+                gsum = torch.empty_like(x_out) if (need_total and (fold > 0 or g2 is not None)) else None
+                if nd.norm:
+                    ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, act=nd.act,
+                                           slope=nd.slope)
+                else:
+                    ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, act=nd.act, slope=nd.slope)
+                total = gsum if gsum is not None else g_pad
+            else:
+                dy, total = g_pad, g_pad
+            if need_total:
+                skip[nd.res] = total
+            # ---- parameter gradients ---------------------------------------------------------------------------------
+            if want_w:
+                dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
+                a_t, g_t = (dy, s.acts[i]) if sp.kind == "conv" else (s.acts[i], dy)
+                ops.wgrad(lw.wgrad, a_t, g_t, dw)
+                if sp.bias:
+                    ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
+                self.grad_dirty = True
+                if final_pass:
+                    self._maybe_reduce_bucket(i)
+            # ---- data gradient ------------------------------------------------------------------------------------------
+            if i > 0 or need_input_grad:
+                f = lw.dgrad_fold
+                gx = torch.empty(N, lw.Hi + 2 * f, lw.Wi + 2 * f, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
+                dpack = pk["dpack"][pk["d_off"][i]:]
+                for g in lw.dgrad:
+                    ops.gconv(g, dy, dpack, None, gx)
+                pending = (gx, f, skip.pop(i - 1, None))
+            s.acts[i + 1] = None  # release as we go
+        if not need_input_grad:
+            return None
+        gx, f, _ = pending
+        g_in = torch.empty_like(s.x_img)
+        ops.image_to_act_backward(gx, g_in, fold=f)
+        return g_in
+
+    # ---- data parallelism (reference: DistributedDataParallel per network, base.py:172-189) -------------
+    def parallelize(self, process_group=None, bucket_bytes=8 << 20):
+        """Mark the net data-parallel: master is broadcast from rank 0 (DDP ctor, C3) and the flat gradient is
+        all-reduced in buckets as the last backward pass of a step produces them (C4)."""
+        import torch.distributed as dist
+        self._dist = process_group if process_group is not None else dist.group.WORLD
+        with torch.no_grad():
+            dist.broadcast(self.master.data, 0, group=self._dist)
+        self._packs_dirty = True
+        # buckets = contiguous [start, end) element ranges of whole layers, built from the LAST layer backwards
+        self._buckets, end, cur = [], self.numel, self.numel
+        for i in range(len(self.nodes) - 1, -1, -1):
+            cur = self.w_off[i]
+            if (end - cur) * 4 >= bucket_bytes or i == 0:
+                self._buckets.append((i, cur, end))   # ready once node i's wgrad has been issued
+                end = cur
+        self._bucket_at = {i: (s, e) for i, s, e in self._buckets}
+        return self
+
+    def _maybe_reduce_bucket(self, i):
+        rng = self._bucket_at.get(i)
+        if rng is None:
+            return
+        import torch.distributed as dist
+        s, e = rng
+        h = dist.all_reduce(self.master.grad[s:e], op=dist.ReduceOp.SUM, group=self._dist, async_op=True)
+        self._reduce_handles.append(h)
+        if i == 0:
+            self._reduced = True
+
+    def finish_grad_reduction(self) -> float:
+        """Called by the optimiser before the update. Returns the factor the summed gradient must be scaled by."""
+        if self._dist is None:
+            return 1.0
+        import torch.distributed as dist
+        if not self._reduced and self.grad_dirty:
+            # backward passes did not line up with forward passes (custom recipe): reduce the whole buffer now
+            self._reduce_handles.append(
+                dist.all_reduce(self.master.grad, op=dist.ReduceOp.SUM, group=self._dist, async_op=True))
+        for h in self._reduce_handles:
+            h.wait()          # stream-level wait on GPU backends; no host sync
+        self._reduce_handles = []
+        self._reduced = False
+        self._fw_pending = 0
+        return 1.0 / dist.get_world_size(self._dist)
+
+
+class _NetFn(torch.autograd.Function):
+    """The whole network as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, token, net: NativeNet):
+        out, saved = net._forward(x.detach(), save=True)
+        ctx.net, ctx.saved = net, saved
+        ctx.need_x = ctx.needs_input_grad[0]
+        ctx.want_w = net.requires_grad     # autograd semantics: decided when the graph is recorded
+        if ctx.want_w:
+            net._fw_pending += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        if ctx.want_w:
+            net._fw_pending -= 1
+        gx = net._backward(ctx.saved, g, ctx.need_x, ctx.want_w)
+        ctx.saved = None
+        return gx, None, None

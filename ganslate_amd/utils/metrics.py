@@ -1,0 +1,34 @@
+"""Training-time metrics computed inside optimize_parameters (ganslate/utils/metrics/train_metrics.py:5-67):
+mean discriminator outputs and SSIM between real and cycle-reconstructed images, both on fused kernels."""
+import torch
+
+from ..nn.losses.functional import mean_nograd, ssim_distance_nograd
+
+
+class TrainingMetrics:
+
+    def __init__(self, conf):
+        self.output_distributions = bool(conf.train.metrics.discriminator_evolution)
+        self.ssim = bool(conf.train.metrics.ssim)
+
+    def get_output_metric_D(self, out):
+        if not self.output_distributions:
+            return None
+        if isinstance(out, dict):
+            return torch.stack([mean_nograd(e) for e in out.values()])
+        return mean_nograd(out) if out.dim() > 1 else out.detach()
+
+    def get_SSIM_metric(self, input, target):
+        return 1 - ssim_distance_nograd(input, target) if self.ssim else None
+
+    def compute_metrics_D(self, discriminator, pred_real, pred_fake):
+        return {f"{discriminator}_real": self.get_output_metric_D(pred_real),
+                f"{discriminator}_fake": self.get_output_metric_D(pred_fake)}
+
+    def compute_metrics_G(self, visuals):
+        m = {}
+        if all(k in visuals for k in ("rec_A", "real_A")):
+            m["ssim_A"] = self.get_SSIM_metric(visuals["real_A"], visuals["rec_A"])
+        if all(k in visuals for k in ("rec_B", "real_B")):
+            m["ssim_B"] = self.get_SSIM_metric(visuals["real_B"], visuals["rec_B"])
+        return m

@@ -1,0 +1,133 @@
+"""Generates tests/golden/*.json by running the REAL reference (/root/reference, imported through the stand-in
+modules under oracle/ref_stubs) on the CPU. Only runs in the build container; the fixtures it writes are
+data (seeds, scalars, a few samples) — no reference source travels.
+
+    python -m oracle.gen_golden            # rewrites tests/golden/cyclegan_steps.json, nets.json
+
+Inputs are U(-1,1) from torch.Generator(seed); weights come from oracle.torch_ref.seeded_state_dict so the
+restatement and the HIP nets can be given bit-identical parameters without storing them.
+"""
+import json
+import random
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle" / "ref_stubs"))
+sys.path.insert(1, "/root/reference")
+sys.path.insert(2, str(ROOT))
+
+from omegaconf import DictConfig  # noqa: E402  (the stand-in)
+import ganslate.configs.base  # noqa: E402,F401
+from ganslate.nn.gans.unpaired.cyclegan import CycleGAN  # noqa: E402
+from ganslate.nn.generators import Resnet2D  # noqa: E402
+from ganslate.nn.discriminators import PatchGAN2D  # noqa: E402
+
+from oracle.torch_ref import seeded_state_dict  # noqa: E402
+
+CASES = {
+    # horse2zebra yaml hyper-parameters (projects/horse2zebra/experiments/default.yaml:28-53) at 64x64
+    "c64_default": dict(size=64, batch=2, steps=30, n_iters=20, n_iters_decay=10, pool_size=50,
+                        lambda_identity=0.0, proportion_ssim=0.0, seed=11),
+    # first-run template values: SSIM-weighted cycle loss + identity loss
+    "c64_idt_ssim": dict(size=64, batch=1, steps=5, n_iters=100, n_iters_decay=100, pool_size=50,
+                         lambda_identity=0.5, proportion_ssim=0.84, seed=12),
+    # BASELINE config 1 shape: 256x256, batch 1
+    "cfg1_256": dict(size=256, batch=1, steps=2, n_iters=100, n_iters_decay=100, pool_size=50,
+                     lambda_identity=0.0, proportion_ssim=0.0, seed=13),
+}
+
+
+def make_conf(c):
+    return DictConfig({
+        "mode": "train",
+        "train": {
+            "output_dir": "/tmp/ganslate_ref_out", "cuda": False, "mixed_precision": False, "opt_level": "O1",
+            "batch_size": c["batch"], "n_iters": c["n_iters"], "n_iters_decay": c["n_iters_decay"],
+            "checkpointing": {"load_iter": None, "freq": 10 ** 9, "start_after": 0, "load_optimizers": True},
+            "metrics": {"discriminator_evolution": True, "ssim": True},
+            "gan": {
+                "_target_": "ganslate.nn.gans.unpaired.CycleGAN", "norm_type": "instance",
+                "weight_init_type": "normal", "weight_init_gain": 0.02, "pool_size": c["pool_size"],
+                "generator": {"_target_": "ganslate.nn.generators.Resnet2D", "n_residual_blocks": 9,
+                              "in_out_channels": {"AB": [3, 3], "BA": [3, 3]}},
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN2D", "ndf": 64, "n_layers": 3,
+                                  "kernel_size": [4, 4], "in_channels": {"B": 3, "A": 3}},
+                "optimizer": {"adversarial_loss_type": "lsgan", "beta1": 0.5, "beta2": 0.999, "lr_D": 0.0002,
+                              "lr_G": 0.0002, "lambda_AB": 10.0, "lambda_BA": 10.0,
+                              "lambda_identity": c["lambda_identity"], "proportion_ssim": c["proportion_ssim"]},
+            },
+        },
+    })
+
+
+def inputs(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 3, c["size"], c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+def run_case(name, c):
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    model = CycleGAN(make_conf(c))
+    for k, (n, net) in enumerate(model.networks.items()):
+        net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+    random.seed(c["seed"])
+    rec = []
+    for s in range(c["steps"]):
+        A, B = inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        rec.append({
+            "lrs": {k: float(v) for k, v in lrs.items()},
+            "losses": {k: float(v) for k, v in losses.items() if v is not None},
+            "metrics": {k: float(v) for k, v in metrics.items() if v is not None},
+        })
+        model.update_learning_rate()
+        print(name, s, rec[-1]["losses"], flush=True)
+    norms = {n: float(torch.sqrt(sum((p.detach() ** 2).sum() for p in net.parameters())))
+             for n, net in model.networks.items()}
+    return {"config": c, "steps": rec, "final_param_norms": norms}
+
+
+def net_case(name, net, x_shape, seed):
+    net.load_state_dict(seeded_state_dict(net, seed))
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(x_shape, generator=g) * 2 - 1).requires_grad_()
+    y = net(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    sd_keys = list(net.state_dict().keys())
+    flat = y.detach().flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 32).long()
+    return {
+        "seed": seed, "x_shape": list(x_shape), "y_shape": list(y.shape), "state_dict_keys": sd_keys,
+        "n_params": sum(p.numel() for p in net.parameters()),
+        "y_sum": float(flat.double().sum()), "y_abs_sum": float(flat.double().abs().sum()),
+        "y_samples": [float(v) for v in flat[idx]], "sample_idx": [int(i) for i in idx],
+        "x_grad_abs_sum": float(x.grad.double().abs().sum()),
+        "x_grad_samples": [float(v) for v in x.grad.flatten()[torch.linspace(0, x.numel() - 1, 32).long()]],
+        "param_grad_norms": {n: float(p.grad.norm()) for n, p in net.named_parameters()},
+    }
+
+
+def main():
+    out = ROOT / "tests" / "golden"
+    out.mkdir(parents=True, exist_ok=True)
+    nets = {
+        "resnet2d_64": net_case("resnet2d_64", Resnet2D(3, 3, "instance", 9), (2, 3, 64, 64), 21),
+        "resnet2d_40x56_3blocks": net_case("r", Resnet2D(3, 3, "instance", 3), (1, 3, 40, 56), 22),
+        "patchgan2d_64": net_case("patchgan2d_64", PatchGAN2D(3, 64, 3, 4, "instance"), (2, 3, 64, 64), 23),
+        "patchgan2d_6ch_4layers": net_case("p", PatchGAN2D(6, 64, 4, 4, "instance"), (1, 6, 96, 128), 24),
+    }
+    (out / "nets.json").write_text(json.dumps(nets, indent=1))
+    steps = {name: run_case(name, c) for name, c in CASES.items()}
+    (out / "cyclegan_steps.json").write_text(json.dumps(steps, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,10 @@ class RefOps:
     name = "oracle"
     device = torch.device("cpu")
 
+    def __init__(self, act_dtype=torch.bfloat16):
+        # bf16 emulates the HIP storage precision; fp32 isolates the executor/lowering logic from rounding
+        self.act_dtype = act_dtype
+
     def tile_m(self, g):
         return 1 << 30  # one statistics slot per class
 

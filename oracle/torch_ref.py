@@ -1,0 +1,210 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+Network- and step-level CPU restatement of the reference hot path in plain torch fp32 (torch.nn + autograd):
+  * Resnet2D            ganslate/nn/generators/resnet/resnet2d.py:14-93
+  * PatchGAN2D          ganslate/nn/discriminators/patchgan/patchgan2d.py:17-66
+  * AdversarialLoss     ganslate/nn/losses/adversarial_loss.py:7-98 (lsgan / vanilla / wgangp)
+  * CycleGAN losses     ganslate/nn/losses/cyclegan_losses.py:7-101
+  * ImagePool           ganslate/data/utils/image_pool.py:5-60
+  * CycleGAN step       ganslate/nn/gans/unpaired/cyclegan.py:92-214 (+ base.py:155-170, nn/utils.py:83-99)
+  * training metrics    ganslate/utils/metrics/train_metrics.py:5-67
+Module/parameter names equal the reference's, so state_dicts are interchangeable.
+
+PINNING: tests/test_oracle_pinned.py checks this file against golden vectors produced by the REAL reference code
+imported in the build container (oracle/gen_golden.py -> tests/golden/*.json). The reference's own test-suite
+holds no numeric fixtures for this path (tests/test_first_run.py:24-28 only asserts run() returns None).
+"""
+import random
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .ops_ref import ssim_distance
+
+
+# ---- networks ------------------------------------------------------------------------------------------------------
+class _Residual(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv_block = nn.Sequential(
+            nn.ReflectionPad2d(1), nn.Conv2d(ch, ch, 3), nn.InstanceNorm2d(ch), nn.ReLU(True),
+            nn.ReflectionPad2d(1), nn.Conv2d(ch, ch, 3), nn.InstanceNorm2d(ch))
+
+    def forward(self, x):
+        return x + self.conv_block(x)
+
+
+class Resnet2D(nn.Module):
+    def __init__(self, in_channels, out_channels, n_residual_blocks=9):
+        super().__init__()
+        layers = [nn.ReflectionPad2d(3), nn.Conv2d(in_channels, 64, 7), nn.InstanceNorm2d(64), nn.ReLU(True)]
+        ch = 64
+        for _ in range(2):
+            layers += [nn.Conv2d(ch, ch * 2, 3, stride=2, padding=1), nn.InstanceNorm2d(ch * 2), nn.ReLU(True)]
+            ch *= 2
+        layers += [_Residual(ch) for _ in range(n_residual_blocks)]
+        self.encoder = nn.ModuleList(layers)       # aliases the modules above (duplicated state_dict keys)
+        for _ in range(2):
+            layers += [nn.ConvTranspose2d(ch, ch // 2, 3, stride=2, padding=1, output_padding=1),
+                       nn.InstanceNorm2d(ch // 2), nn.ReLU(True)]
+            ch //= 2
+        layers += [nn.ReflectionPad2d(3), nn.Conv2d(64, out_channels, 7), nn.Tanh()]
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class PatchGAN2D(nn.Module):
+    def __init__(self, in_channels, ndf=64, n_layers=3, kernel_size=4):
+        super().__init__()
+        kw = kernel_size
+        seq = [nn.Conv2d(in_channels, ndf, kw, 2, 1), nn.LeakyReLU(0.2, True)]
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 2, 1), nn.InstanceNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        prev, mult = mult, min(2 ** n_layers, 8)
+        seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 1, 1), nn.InstanceNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        seq += [nn.Conv2d(ndf * mult, 1, kw, 1, 1)]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+def seeded_state_dict(module: nn.Module, seed: int, gain=0.02, bias_gain=0.01):
+    """Deterministic weights independent of module construction order / torch's default init RNG use:
+    every tensor of the state_dict (in key order, aliases share one draw) ~ N(0, gain) (biases N(0, bias_gain))
+    from its own torch.Generator. Used for the reference AND the restatement AND the HIP nets."""
+    sd, seen = OrderedDict(), {}
+    for k, (name, t) in enumerate(module.state_dict().items()):
+        if t.data_ptr() in seen:
+            sd[name] = seen[t.data_ptr()]
+            continue
+        g = torch.Generator().manual_seed(seed * 1000 + k)
+        v = torch.randn(t.shape, generator=g) * (bias_gain if name.endswith("bias") else gain)
+        sd[name] = v
+        seen[t.data_ptr()] = v
+    return sd
+
+
+# ---- losses ----------------------------------------------------------------------------------------------------------
+def adversarial_loss(pred, target_is_real, mode="lsgan"):
+    if mode == "lsgan":
+        return ((pred - (1.0 if target_is_real else 0.0)) ** 2).mean()
+    if mode == "vanilla":
+        t = torch.full_like(pred, 1.0 if target_is_real else 0.0)
+        return nn.functional.binary_cross_entropy_with_logits(pred, t)
+    if mode == "wgangp":
+        return -pred.mean() if target_is_real else pred.mean()
+    raise NotImplementedError(mode)
+
+
+def cycle_loss(real, rec, proportion_ssim):
+    l1 = (rec - real).abs().mean()
+    if proportion_ssim > 0:
+        return proportion_ssim * ssim_distance(rec, real) + (1 - proportion_ssim) * l1
+    return l1
+
+
+class ImagePool:
+    def __init__(self, size):
+        self.size, self.images = size, []
+
+    def query(self, images):
+        if self.size == 0:
+            return images
+        out = []
+        for img in images:
+            img = img.detach().unsqueeze(0)
+            if len(self.images) < self.size:
+                self.images.append(img)
+                out.append(img)
+            elif random.uniform(0, 1) > 0.5:
+                i = random.randint(0, self.size - 1)
+                out.append(self.images[i].clone())
+                self.images[i] = img
+            else:
+                out.append(img)
+        return torch.cat(out, 0)
+
+
+# ---- the CycleGAN training step ----------------------------------------------------------------------------
+class CycleGANStep:
+    """fp32 restatement of CycleGAN.optimize_parameters with the reference's defaults."""
+
+    def __init__(self, in_ch=3, out_ch=3, n_blocks=9, ndf=64, n_layers=3, lr_G=2e-4, lr_D=2e-4, beta1=0.5,
+                 beta2=0.999, lambda_AB=10.0, lambda_BA=10.0, lambda_identity=0.0, proportion_ssim=0.0,
+                 pool_size=50, adv="lsgan", n_iters=100, n_iters_decay=100, metrics_ssim=True, metrics_D=True,
+                 seed=0):
+        self.nets = OrderedDict(G_AB=Resnet2D(in_ch, out_ch, n_blocks), G_BA=Resnet2D(out_ch, in_ch, n_blocks),
+                                D_B=PatchGAN2D(out_ch, ndf, n_layers), D_A=PatchGAN2D(in_ch, ndf, n_layers))
+        for k, (name, net) in enumerate(self.nets.items()):
+            net.load_state_dict(seeded_state_dict(net, seed + k))
+        self.hp = dict(lambda_AB=lambda_AB, lambda_BA=lambda_BA, lambda_identity=lambda_identity,
+                       proportion_ssim=proportion_ssim, adv=adv, metrics_ssim=metrics_ssim, metrics_D=metrics_D)
+        pG = list(self.nets["G_AB"].parameters()) + list(self.nets["G_BA"].parameters())
+        pD = list(self.nets["D_B"].parameters()) + list(self.nets["D_A"].parameters())
+        self.opt_G = torch.optim.Adam(pG, lr=lr_G, betas=(beta1, beta2))
+        self.opt_D = torch.optim.Adam(pD, lr=lr_D, betas=(beta1, beta2))
+        rule = lambda it: 1.0 - max(0, it + 1 - n_iters) / float(n_iters_decay + 1)
+        self.sched = [torch.optim.lr_scheduler.LambdaLR(o, rule) for o in (self.opt_G, self.opt_D)]
+        self.pool_A, self.pool_B = ImagePool(pool_size), ImagePool(pool_size)
+        self.visuals = {}
+
+    def _set_D_grad(self, flag):
+        for n in ("D_B", "D_A"):
+            for p in self.nets[n].parameters():
+                p.requires_grad = flag
+
+    def step(self, real_A, real_B):
+        hp, nets = self.hp, self.nets
+        losses, metrics = {}, {}
+        fake_B = nets["G_AB"](real_A); rec_A = nets["G_BA"](fake_B)
+        fake_A = nets["G_BA"](real_B); rec_B = nets["G_AB"](fake_A)
+        idt_A = idt_B = None
+        if hp["lambda_identity"] > 0:
+            idt_B = nets["G_AB"](real_B); idt_A = nets["G_BA"](real_A)
+        self.visuals = dict(real_A=real_A, real_B=real_B, fake_A=fake_A, fake_B=fake_B, rec_A=rec_A, rec_B=rec_B,
+                            idt_A=idt_A, idt_B=idt_B)
+        if hp["metrics_ssim"]:
+            with torch.no_grad():
+                metrics["ssim_A"] = 1 - ssim_distance(real_A, rec_A)
+                metrics["ssim_B"] = 1 - ssim_distance(real_B, rec_B)
+        # ---- generators ----
+        self._set_D_grad(False)
+        self.opt_G.zero_grad(set_to_none=True)
+        losses["G_AB"] = adversarial_loss(nets["D_B"](fake_B), True, hp["adv"])
+        losses["G_BA"] = adversarial_loss(nets["D_A"](fake_A), True, hp["adv"])
+        losses["cycle_A"] = hp["lambda_AB"] * cycle_loss(real_A, rec_A, hp["proportion_ssim"])
+        losses["cycle_B"] = hp["lambda_BA"] * cycle_loss(real_B, rec_B, hp["proportion_ssim"])
+        total = losses["cycle_A"] + losses["cycle_B"]
+        if hp["lambda_identity"] > 0:
+            losses["idt_B"] = hp["lambda_AB"] * (idt_B - real_B).abs().mean() * hp["lambda_identity"]
+            losses["idt_A"] = hp["lambda_BA"] * (idt_A - real_A).abs().mean() * hp["lambda_identity"]
+            total = total + losses["idt_B"] + losses["idt_A"]
+        (total + losses["G_AB"] + losses["G_BA"]).backward()
+        self.opt_G.step()
+        # ---- discriminators ----
+        self._set_D_grad(True)
+        self.opt_D.zero_grad(set_to_none=True)
+        for name, real, fake, pool in (("D_B", real_B, fake_B, self.pool_B), ("D_A", real_A, fake_A, self.pool_A)):
+            fake = pool.query(fake)
+            pred_real = nets[name](real)
+            pred_fake = nets[name](fake.detach())
+            losses[name] = adversarial_loss(pred_real, True, hp["adv"]) + adversarial_loss(pred_fake, False, hp["adv"])
+            losses[name].backward()
+            if hp["metrics_D"]:
+                metrics[f"{name}_real"] = pred_real.detach().mean()
+                metrics[f"{name}_fake"] = pred_fake.detach().mean()
+        self.opt_D.step()
+        return {k: float(v.detach()) for k, v in losses.items()}, {k: float(v) for k, v in metrics.items()}
+
+    def update_learning_rate(self):
+        for s in self.sched:
+            s.step()
+
+    def lrs(self):
+        return {"lr_G": self.opt_G.param_groups[0]["lr"], "lr_D": self.opt_D.param_groups[0]["lr"]}

@@ -1,0 +1,51 @@
+"""Shared helpers for step-level parity tests (CPU oracle backend and GPU)."""
+import json
+import random
+from pathlib import Path
+
+import torch
+
+GOLD = Path(__file__).parent / "golden"
+CONF = Path(__file__).parent / "configs" / "cyclegan_synthetic.yaml"
+
+
+def golden_inputs(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 3, c["size"], c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+def load_golden_steps():
+    return json.loads((GOLD / "cyclegan_steps.json").read_text())
+
+
+def build_product_cyclegan(c, extra=()):
+    """product CycleGAN configured like golden case `c`, with the oracle's seeded weights loaded"""
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle import torch_ref
+    conf = build_conf([f"config={CONF}", f"train.batch_size={c['batch']}", f"train.n_iters={c['n_iters']}",
+                       f"train.n_iters_decay={c['n_iters_decay']}", f"train.gan.pool_size={c['pool_size']}",
+                       f"train.gan.optimizer.lambda_identity={c['lambda_identity']}",
+                       f"train.gan.optimizer.proportion_ssim={c['proportion_ssim']}", *extra])
+    torch.manual_seed(c["seed"])
+    model = build_gan(conf)
+    shadow = {"G_AB": torch_ref.Resnet2D(3, 3, 9), "G_BA": torch_ref.Resnet2D(3, 3, 9),
+              "D_B": torch_ref.PatchGAN2D(3), "D_A": torch_ref.PatchGAN2D(3)}
+    for k, name in enumerate(["G_AB", "G_BA", "D_B", "D_A"]):
+        model.networks[name].load_state_dict(torch_ref.seeded_state_dict(shadow[name], c["seed"] + k))
+    random.seed(c["seed"])
+    return model
+
+
+def run_product_steps(model, c, n_steps):
+    out = []
+    for s in range(n_steps):
+        A, B = golden_inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        out.append({"lrs": dict(lrs),
+                    "losses": {k: float(v.detach()) for k, v in losses.items() if v is not None},
+                    "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
+        model.update_learning_rate()
+    return out

@@ -1,0 +1,40 @@
+"""The product recipe + executor (hand-written backward, folds, residual joins, flat Adam, LR schedule, image
+pool) run on the CPU through the op-level oracle backend in fp32 and compared with the golden vectors of the real
+reference. This pins all host-side logic of the training step without a GPU; kernels are pinned in -m gpu tests."""
+import pytest
+import torch
+
+from ganslate_amd.nn.native import backend
+from oracle.ops_ref import RefOps
+
+from .helpers import build_product_cyclegan, load_golden_steps, run_product_steps
+
+
+@pytest.fixture()
+def fp32_oracle_backend():
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    yield
+    backend.set_ops(None)
+
+
+@pytest.mark.parametrize("name,n_steps", [("c64_default", 4), ("c64_idt_ssim", 2)])
+def test_product_step_matches_reference_golden_fp32(fp32_oracle_backend, name, n_steps):
+    gold = load_golden_steps()[name]
+    c = gold["config"]
+    model = build_product_cyclegan(c)
+    got = run_product_steps(model, c, n_steps)
+    for s in range(n_steps):
+        g = gold["steps"][s]
+        assert got[s]["lrs"] == pytest.approx(g["lrs"], abs=1e-12)
+        assert set(got[s]["losses"]) == set(g["losses"])
+        # Step 0 (same weights, same batch) is arithmetic parity: tight. From step 1 on Adam's first updates are
+        # +-lr*sign(g), so reduction-order noise on near-zero gradients flips ~0.1 % of the weights by 2*lr and the
+        # GAN dynamics amplify it: the reference restatement run with 1 thread instead of 8 drifts from its own
+        # golden curve by 1-4 % within 7 steps. Later steps are therefore checked against that envelope.
+        tol_adv, tol_cyc = (1e-4, 1e-4) if s == 0 else (0.10, 0.02)
+        for k, v in g["losses"].items():
+            tol = tol_cyc if k.startswith(("cycle", "idt")) else tol_adv
+            assert got[s]["losses"][k] == pytest.approx(v, rel=tol, abs=1e-5), (s, k)
+        for k, v in g["metrics"].items():
+            tol = tol_adv if s == 0 else (0.02 if k.startswith("ssim") else 0.25)
+            assert got[s]["metrics"][k] == pytest.approx(v, rel=tol, abs=2e-2 if s else 1e-5), (s, k)

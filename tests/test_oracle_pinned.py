@@ -1,0 +1,74 @@
+"""Pins the oracle (oracle/torch_ref.py, oracle/ops_ref.py) against golden vectors produced by the REAL reference
+imported in the build container (oracle/gen_golden.py). CPU only."""
+import json
+import random
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import torch_ref
+from oracle.torch_ref import CycleGANStep, seeded_state_dict
+
+GOLD = Path(__file__).parent / "golden"
+NETS = json.loads((GOLD / "nets.json").read_text())
+STEPS = json.loads((GOLD / "cyclegan_steps.json").read_text())
+
+NET_BUILDERS = {
+    "resnet2d_64": lambda: torch_ref.Resnet2D(3, 3, 9),
+    "resnet2d_40x56_3blocks": lambda: torch_ref.Resnet2D(3, 3, 3),
+    "patchgan2d_64": lambda: torch_ref.PatchGAN2D(3, 64, 3, 4),
+    "patchgan2d_6ch_4layers": lambda: torch_ref.PatchGAN2D(6, 64, 4, 4),
+}
+
+
+def golden_inputs(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 3, c["size"], c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_network_restatement_matches_reference(name):
+    gold = NETS[name]
+    net = NET_BUILDERS[name]()
+    assert list(net.state_dict().keys()) == gold["state_dict_keys"]
+    assert sum(p.numel() for p in net.parameters()) == gold["n_params"]
+    net.load_state_dict(seeded_state_dict(net, gold["seed"]))
+    g = torch.Generator().manual_seed(gold["seed"])
+    x = (torch.rand(gold["x_shape"], generator=g) * 2 - 1).requires_grad_()
+    y = net(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    assert list(y.shape) == gold["y_shape"]
+    flat = y.detach().flatten()
+    assert torch.allclose(flat[gold["sample_idx"]], torch.tensor(gold["y_samples"]), atol=1e-6, rtol=1e-5)
+    assert abs(float(flat.double().abs().sum()) - gold["y_abs_sum"]) <= 1e-5 * gold["y_abs_sum"]
+    assert abs(float(x.grad.double().abs().sum()) - gold["x_grad_abs_sum"]) <= 1e-4 * gold["x_grad_abs_sum"]
+    for n, p in net.named_parameters():
+        ref = gold["param_grad_norms"][n]
+        assert abs(float(p.grad.norm()) - ref) <= 1e-4 * ref + 1e-7, n
+
+
+@pytest.mark.parametrize("name", ["c64_default", "c64_idt_ssim"])
+def test_cyclegan_step_restatement_matches_reference(name):
+    gold = STEPS[name]
+    c = gold["config"]
+    n_steps = c["steps"]
+    torch.manual_seed(c["seed"])
+    model = CycleGANStep(n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"], pool_size=c["pool_size"],
+                         lambda_identity=c["lambda_identity"], proportion_ssim=c["proportion_ssim"], seed=c["seed"])
+    random.seed(c["seed"])
+    for s in range(n_steps):
+        A, B = golden_inputs(c, s)
+        lrs = model.lrs()
+        losses, metrics = model.step(A, B)
+        g = gold["steps"][s]
+        for k, v in g["lrs"].items():
+            assert abs(lrs[k] - v) <= 1e-12, (s, k)
+        # identical arithmetic on the same torch build: tight; loosened slightly for thread-count differences
+        for k, v in g["losses"].items():
+            assert abs(losses[k] - v) <= 2e-4 * abs(v) + 1e-6, (s, k, losses[k], v)
+        for k, v in g["metrics"].items():
+            assert abs(metrics[k] - v) <= 2e-4 * abs(v) + 1e-5, (s, k, metrics[k], v)
+        model.update_learning_rate()
