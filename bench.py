@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of the CycleGAN ResNet-9 256x256 bf16 step (BASELINE.json configs[1]:
+horse2zebra hyper-parameters, batch 8 per GPU) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = set_input + optimize_parameters of ganslate_amd.nn.gans.unpaired.CycleGAN (what the reference's
+`t_comp` brackets, engines/trainer.py:56-60) on a synthetic batch already resident in HBM. One process per GPU;
+gradients are averaged over RCCL inside the step. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# algorithmic work (BASELINE.md §3 / SURVEY.md §8d): conv MACs x 2 of one CycleGAN step per image pair
+GFLOP_PER_IMAGE = 1289.9
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def make_conf(batch, size, n_iters):
+    from ganslate_amd.configs.config import Config
+    from ganslate_amd.configs.omegalite import OmegaConf
+    from ganslate_amd.configs.utils import init_config
+    y = OmegaConf.create({
+        "train": {
+            "output_dir": "/tmp/ganslate_amd_bench", "cuda": True, "batch_size": batch,
+            "n_iters": n_iters, "n_iters_decay": n_iters,
+            "dataset": {"_target_": "ganslate.data.SyntheticImageDataset", "final_size": [size, size]},
+            "gan": {
+                "_target_": "ganslate.nn.gans.unpaired.CycleGAN", "pool_size": 50,
+                "generator": {"_target_": "ganslate.nn.generators.Resnet2D", "n_residual_blocks": 9,
+                              "in_out_channels": {"AB": [3, 3]}},
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN2D", "n_layers": 3,
+                                  "in_channels": {"B": 3}},
+                # projects/horse2zebra/experiments/default.yaml:43-49
+                "optimizer": {"lambda_AB": 10.0, "lambda_BA": 10.0, "lambda_identity": 0, "proportion_ssim": 0,
+                              "lr_D": 0.0002, "lr_G": 0.0002},
+            },
+            "metrics": {"discriminator_evolution": True, "ssim": True},
+        }})
+    return init_config(y, Config)
+
+
+def cpu_baseline(size=256, steps=3):
+    """The reference step restated in stock torch fp32 (oracle/torch_ref.py) on the host cores: BASELINE config 1
+    shape (batch 1). Bounded sample: 1 warm-up + `steps` timed steps."""
+    import torch
+    from oracle.torch_ref import CycleGANStep
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)            # torch CPU convs stop scaling (and oversubscribe) far below 256 threads
+    torch.set_num_threads(threads)
+    model = CycleGANStep(seed=0)
+    g = torch.Generator().manual_seed(1234)
+    A = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    B = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    model.step(A, B)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.step(A, B)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/torch_ref.CycleGANStep (stock torch fp32), batch 1, {size}x{size}, 1 warm-up + "
+                      f"{steps} timed steps, {threads} threads of {cores} host cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ganslate_amd.utils import communication
+    from ganslate_amd.utils.builders import build_gan
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        communication.init_distributed()
+    dev = torch.device(f"cuda:{local_rank}")
+
+    torch.manual_seed(0)
+    model = build_gan(make_conf(args.batch, args.size, 10 ** 6))
+    g = torch.Generator().manual_seed(1234 + rank)
+    batch = {"A": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
+             "B": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)}
+
+    def step():
+        model.set_input(batch)
+        model.optimize_parameters()
+        model.update_learning_rate()
+
+    for _ in range(args.warmup):
+        step()
+
+    ops = model.networks["G_AB"].ops
+    timing = None
+    if not args.no_kernel_timing:
+        # HIP events around every launch of the dominant kernel (residual-block 3x3 conv, forward form) on the
+        # stream it is launched on (torch's current stream)
+        timing = ops.enable_kernel_timing(lambda g: g.T == 9 and g.Ci == 256 and g.Co == 256 and g.si == 1
+                                          and g.border == "reflect")
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    losses = {k: float(v) for k, v in model.losses.items() if v is not None}
+    assert all(v == v and abs(v) < 1e6 for v in losses.values()), f"non-finite losses: {losses}"
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / dt
+        out = {
+            "metric": "training images/sec, CycleGAN ResNet-9 256x256 bf16", "value": round(value, 2),
+            "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"horse2zebra CycleGAN ResNet-9 + PatchGAN-3, {args.size}x{args.size}, "
+                                   f"batch {args.batch} per GPU, lsgan, lambda 10/10, pool 50, Adam(2e-4, 0.5), "
+                                   "SSIM + D-output metrics on",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "step_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 1),
+            "step_mfma_frac": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+        }
+        if timing is not None:
+            n, ms = ops.kernel_timing_result()
+            hw = (args.size // 4) ** 2
+            flop = 2.0 * hw * args.batch * 256 * 2304           # 2*M*N*K of one launch
+            tf = flop / (ms * 1e-3) / 1e12 if n else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "kernel": "gconv_kernel<128,128,2,2> (3x3 256->256 reflect conv, M=%d N=256 K=2304)"
+                                         % (hw * args.batch),
+                               "launches_timed": n, "avg_ms": round(ms, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,31 +5,53 @@
 // autograd backward, including the adjoint of nn.ReflectionPad2d (the `fold`).
 #include "common.hpp"
 
-// ---- statistics finalize: partial [N][slots][2][C] -> mean_rstd [N][2][C] ---------------------------
-__global__ void inorm_finalize_kernel(const float* partial, int N, int slots, int C, float inv_hw, float eps,
-                                      float* mean_rstd) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * C) return;
-  const int n = idx / C, c = idx - n * C;
-  double s1 = 0.0, s2 = 0.0;
-  const float* pp = partial + (size_t)n * slots * 2 * C + c;
-  for (int s = 0; s < slots; ++s) {
-    s1 += (double)pp[(size_t)s * 2 * C];
-    s2 += (double)pp[(size_t)s * 2 * C + C];
+// ---- slot reduction: in [N][slots][K] -> out [N][K]; optional InstanceNorm finalize (K = 2C: sums | sumsq) ----
+// grid (ceil(K/64), N), 256 threads = 64 columns x 4 slot lanes
+__global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* out, int slots, int K, int finalize_c,
+                                                       float inv_hw, float eps) {
+  __shared__ double red[4][64];
+  __shared__ float tot[128];
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int col = tid & 63, lane = tid >> 6;
+  const float* src = in + (size_t)n * slots * K;
+  if (finalize_c == 0) {
+    const int k = blockIdx.x * 64 + col;
+    double s = 0.0;
+    if (k < K)
+      for (int sl = lane; sl < slots; sl += 4) s += (double)src[(size_t)sl * K + k];
+    red[lane][col] = s;
+    __syncthreads();
+    if (lane == 0 && k < K) out[(size_t)n * K + k] = (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+    return;
   }
-  const double mean = s1 * (double)inv_hw;
-  double var = s2 * (double)inv_hw - mean * mean;
-  if (var < 0.0) var = 0.0;
-  mean_rstd[(size_t)n * 2 * C + c] = (float)mean;
-  mean_rstd[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  // finalize: this block owns channels [c0, c0+64): needs the sum row and the sum-of-squares row
+  const int C = finalize_c;
+  const int c = blockIdx.x * 64 + col;
+  for (int half = 0; half < 2; ++half) {
+    double s = 0.0;
+    if (c < C)
+      for (int sl = lane; sl < slots; sl += 4) s += (double)src[(size_t)sl * K + half * C + c];
+    __syncthreads();
+    red[lane][col] = s;
+    __syncthreads();
+    if (lane == 0) tot[half * 64 + col] = (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+  }
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    const double mean = (double)tot[col] * (double)inv_hw;
+    double var = (double)tot[64 + col] * (double)inv_hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[(size_t)n * 2 * C + c] = (float)mean;
+    out[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 extern "C" int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
                                  float* mean_rstd, void* stream) {
   GS_REQUIRE(partial && mean_rstd && N > 0 && slots > 0 && C > 0 && hw > 0, "gs_inorm_finalize: bad argument");
-  const int total = N * C;
-  hipLaunchKernelGGL(inorm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), partial, N, slots, C, 1.0f / (float)hw, eps, mean_rstd);
+  hipLaunchKernelGGL(slot_sum_kernel, dim3((C + 63) / 64, N), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
+                     mean_rstd, slots, 2 * C, C, 1.0f / (float)hw, eps);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -119,17 +141,29 @@ __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const
   if (g2_n) add_bf8(f, g2_n[((size_t)ih * W + iw) * C8 + c8]);
 }
 
-// pass 1: per (n, pixel-chunk) partial sums of ghat and ghat*yhat  -> scratch [N][chunks][2][C]
+__device__ __forceinline__ void load8(float* f, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void unpack8(float* f, const uint4 v) {
+  f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+  f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+
+// pass 1: per (n, pixel-chunk, column group) partial sums of ghat and ghat*yhat  -> scratch [N][chunks][2][C]
+// 256 threads = COLS 8-channel columns x (256/COLS) pixel lanes; grid (chunks, N, ceil(C8/COLS))
+template <int COLS>
 __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
                                                                const float* mean_rstd, float* partial, int H, int W,
                                                                int C8, int fold, int mode, int act, float slope,
                                                                int pix_per_block, int chunks) {
-  __shared__ float red[256 * 16 / 4];  // reused per 8-channel column: [rows][16] -> sized for 64 rows
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[ROWS][COLS][17];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  const int cols = C8 < 64 ? C8 : 64;           // 8-channel columns handled per pass
-  const int rows = 256 / cols;                  // pixel lanes
-  const int col = tid % cols, row = tid / cols;
+  const int col = tid % COLS, row = tid / COLS;
+  const int c8 = blockIdx.z * COLS + col;
   const int HW = H * W;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
@@ -138,92 +172,91 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
   const uint4* g2_n = g2 ? g2 + (size_t)n * HW * C8 : nullptr;
   const uint4* y_n = y + (size_t)n * HW * C8;
   const float* mr = mean_rstd + (size_t)n * 2 * C8 * 8;
-  float* out = partial + ((size_t)n * chunks + blockIdx.x) * 2 * C8 * 8;
-  for (int cb = 0; cb < C8; cb += cols) {
-    const int c8 = cb + col;
-    float a1[8], a2[8];
+  float a1[8], a2[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a1[k] = a2[k] = 0.f;
-    if (row < rows && c8 < C8) {
-      float mu[8], rs[8];
+  for (int k = 0; k < 8; ++k) a1[k] = a2[k] = 0.f;
+  if (c8 < C8) {
+    float mu[8], rs[8];
+    load8(mu, mr + c8 * 8);
+    load8(rs, mr + C8 * 8 + c8 * 8);
+    for (int px = p0 + row; px < p1; px += ROWS) {
+      const int ih = px / W, iw = px - ih * W;
+      float g[8], yy[8];
+      load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
+      unpack8(yy, y_n[(size_t)px * C8 + c8]);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { mu[k] = mr[c8 * 8 + k]; rs[k] = mr[C8 * 8 + c8 * 8 + k]; }
-      for (int px = p0 + row; px < p1; px += rows) {
-        const int ih = px / W, iw = px - ih * W;
-        float g[8];
-        load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
-        const uint4 yv = y_n[(size_t)px * C8 + c8];
-        const float yy[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
-                             bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float yh = (yy[k] - mu[k]) * rs[k];
-          const float gh = g[k] * act_grad_from_out(yh, act, slope);
-          a1[k] += gh;
-          a2[k] += gh * yh;
-        }
+      for (int k = 0; k < 8; ++k) {
+        const float yh = (yy[k] - mu[k]) * rs[k];
+        const float gh = g[k] * act_grad_from_out(yh, act, slope);
+        a1[k] += gh;
+        a2[k] += gh * yh;
       }
     }
-    // reduce over `rows` pixel lanes through LDS, 4 floats at a time to bound LDS use (256*4 floats)
+  }
 #pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      __syncthreads();
+  for (int k = 0; k < 8; ++k) { red[row][col][k] = a1[k]; red[row][col][8 + k] = a2[k]; }
+  __syncthreads();
+  // COLS*16 outputs, summed over ROWS pixel lanes
+  for (int o = tid; o < COLS * 16; o += 256) {
+    const int cc = o >> 4, k = o & 15;
+    const int ch8 = blockIdx.z * COLS + cc;
+    if (ch8 < C8) {
+      float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float v = part < 2 ? a1[(part & 1) * 4 + k] : a2[(part & 1) * 4 + k];
-        red[tid * 4 + k] = v;
-      }
-      __syncthreads();
-      if (tid < cols * 4 && cb + tid / 4 < C8) {
-        const int cc = tid / 4, k = tid & 3;
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += red[(r * cols + cc) * 4 + k];
-        const int ch = (cb + cc) * 8 + (part & 1) * 4 + k;
-        out[(part < 2 ? 0 : C8 * 8) + ch] = s;
-      }
+      for (int r = 0; r < ROWS; ++r) sum += red[r][cc][k];
+      float* out = partial + ((size_t)n * chunks + blockIdx.x) * 2 * C8 * 8;
+      out[(k < 8 ? 0 : C8 * 8) + ch8 * 8 + (k & 7)] = sum;
     }
-    __syncthreads();
   }
 }
 
 // pass 2: dy = rstd * (ghat - S1/hw - yhat*S2/hw) ; optional gsum = folded gradient (before act')
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
                                                               const float* mean_rstd, const float* sums, uint4* dy,
-                                                              uint4* gsum, int H, int W, int C8, int fold, int mode,
-                                                              int act, float slope) {
+                                                              uint4* gsum, int H, int W, int C8, int c8_shift,
+                                                              int fold, int mode, int act, float slope) {
   const int n = blockIdx.y;
-  const int HW = H * W;
-  const long long per_img = (long long)HW * C8;
+  const unsigned HW = (unsigned)(H * W);
+  const unsigned per_img = HW * (unsigned)C8;
   const size_t pad_img = (size_t)(H + 2 * fold) * (W + 2 * fold) * C8;
   const uint4* gpad_n = gpad + (size_t)n * pad_img;
   const uint4* g2_n = g2 ? g2 + (size_t)n * per_img : nullptr;
   const uint4* y_n = y + (size_t)n * per_img;
+  uint4* dy_n = dy + (size_t)n * per_img;
+  uint4* gs_n = gsum ? gsum + (size_t)n * per_img : nullptr;
   const float inv_hw = 1.0f / (float)HW;
   const float* mr = mean_rstd ? mean_rstd + (size_t)n * 2 * C8 * 8 : nullptr;
   const float* sm = sums ? sums + (size_t)n * 2 * C8 * 8 : nullptr;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per_img;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int c8 = (int)(e % C8);
-    const int px = (int)(e / C8);
-    const int ih = px / W, iw = px - ih * W;
-    float g[8];
-    load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
-    if (gsum) {
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < per_img; e += gridDim.x * 256u) {
+    const unsigned px = c8_shift >= 0 ? (e >> c8_shift) : e / (unsigned)C8;
+    const int c8 = (int)(e - px * (unsigned)C8);
+    float g[8], yy[8], d[8];
+    if (fold == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = 0.f;
+      add_bf8(g, gpad_n[e]);
+      if (g2_n) add_bf8(g, g2_n[e]);
+    } else {
+      const int ih = (int)(px / (unsigned)W), iw = (int)(px - (unsigned)ih * (unsigned)W);
+      load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
+    }
+    if (gs_n) {
       uint4 o;
       o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]); o.z = pack_bf2(g[4], g[5]); o.w = pack_bf2(g[6], g[7]);
-      gsum[(size_t)n * per_img + e] = o;
+      gs_n[e] = o;
     }
-    const uint4 yv = y_n[e];
-    const float yy[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
-                         bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
-    float d[8];
+    unpack8(yy, y_n[e]);
     if (mr) {
+      float mu[8], rs[8], s1[8], s2[8];
+      load8(mu, mr + c8 * 8);
+      load8(rs, mr + C8 * 8 + c8 * 8);
+      load8(s1, sm + c8 * 8);
+      load8(s2, sm + C8 * 8 + c8 * 8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float rs = mr[C8 * 8 + c8 * 8 + k];
-        const float yh = (yy[k] - mr[c8 * 8 + k]) * rs;
+        const float yh = (yy[k] - mu[k]) * rs[k];
         const float gh = g[k] * act_grad_from_out(yh, act, slope);
-        d[k] = rs * (gh - sm[c8 * 8 + k] * inv_hw - yh * sm[C8 * 8 + c8 * 8 + k] * inv_hw);
+        d[k] = rs[k] * (gh - s1[k] * inv_hw - yh * s2[k] * inv_hw);
       }
     } else {
 #pragma unroll
@@ -231,21 +264,11 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
     }
     uint4 o;
     o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
-    dy[(size_t)n * per_img + e] = o;
+    dy_n[e] = o;
   }
 }
 
-// sums over chunks: scratch [N][chunks][2][C] -> [N][2][C] (stored behind the partials)
-__global__ void inorm_bwd_sum_kernel(const float* partial, float* sums, int N, int chunks, int C2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * C2) return;
-  const int n = idx / C2, c = idx - n * C2;
-  float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += partial[((size_t)n * chunks + k) * C2 + c];
-  sums[(size_t)n * C2 + c] = s;
-}
-
-static const int kBwdPixPerBlock = 512;
+static const int kBwdPixPerBlock = 128;
 
 extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C) {
   const int64_t chunks = ((int64_t)H * W + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
@@ -268,23 +291,29 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
     GS_REQUIRE(scratch, "gs_inorm_act_backward: scratch required with normalisation");
     const int chunks = (HW + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
     sums = scratch + (size_t)N * chunks * 2 * C;
-    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(chunks, N), dim3(256), 0, st,
-                       static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2),
-                       static_cast<const uint4*>(y), mean_rstd, scratch, H, W, C8, fold, fold_mode, act, slope,
-                       kBwdPixPerBlock, chunks);
+#define GS_LAUNCH_REDUCE(COLS)                                                                                   \
+  hipLaunchKernelGGL((inorm_bwd_reduce_kernel<COLS>), dim3(chunks, N, (C8 + COLS - 1) / COLS), dim3(256), 0, st, \
+                     static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y), \
+                     mean_rstd, scratch, H, W, C8, fold, fold_mode, act, slope, kBwdPixPerBlock, chunks)
+    if (C8 >= 32) GS_LAUNCH_REDUCE(32);
+    else if (C8 >= 8) GS_LAUNCH_REDUCE(8);
+    else GS_LAUNCH_REDUCE(1);
+#undef GS_LAUNCH_REDUCE
     GS_CHECK_HIP(hipGetLastError());
-    const int total = N * 2 * C;
-    hipLaunchKernelGGL(inorm_bwd_sum_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, sums, N, chunks,
-                       2 * C);
+    hipLaunchKernelGGL(slot_sum_kernel, dim3((2 * C + 63) / 64, N), dim3(256), 0, st, scratch, sums, chunks, 2 * C, 0,
+                       0.f, 0.f);
     GS_CHECK_HIP(hipGetLastError());
   }
   const long long per_img = (long long)HW * C8;
+  GS_REQUIRE(per_img < (1LL << 31), "gs_inorm_act_backward: image too large");
   long long bx = (per_img + 255) / 256;
-  if (bx > 2048) bx = 2048;
+  if (bx > 1024) bx = 1024;
+  int c8_shift = -1;
+  if ((C8 & (C8 - 1)) == 0) { c8_shift = 0; while ((1 << c8_shift) < C8) ++c8_shift; }
   hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)bx, N), dim3(256), 0, st,
                      static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y),
-                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), H, W, C8, fold, fold_mode,
-                     act, slope);
+                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), H, W, C8, c8_shift, fold,
+                     fold_mode, act, slope);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

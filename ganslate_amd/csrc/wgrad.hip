@@ -217,39 +217,54 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
 }
 
 // ---- bias gradient: db[c] += sum_pixels dy[pix][c] ---------------------------------------------------
-__global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy, long long pixels, int C, int cs,
+// 256 threads = COLS 8-channel columns x (256/COLS) pixel lanes, 16-B loads; grid (pixel chunks, column groups)
+template <int COLS>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy, long long pixels, int C8, int cs,
                                                         int co, float* db, int pix_per_block) {
-  // thread -> one channel; rows of pixels strided over the 256/C' thread groups
-  __shared__ float red[256];
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[ROWS][COLS][9];
   const int tid = threadIdx.x;
-  const int cpb = C < 256 ? C : 256;           // channels per block pass
-  const int groups = 256 / cpb;                // pixel lanes
-  const int c_in = tid % cpb, gidx = tid / cpb;
+  const int col = tid % COLS, row = tid / COLS;
+  const int c8 = blockIdx.y * COLS + col;
   const long long p0 = (long long)blockIdx.x * pix_per_block;
   const long long p1 = min(pixels, p0 + pix_per_block);
-  for (int cb = 0; cb < C; cb += cpb) {
-    const int c = cb + c_in;
-    float s = 0.f;
-    if (gidx < groups && c < C)
-      for (long long px = p0 + gidx; px < p1; px += groups) s += bf2f(dy[px * cs + co + c]);
-    red[tid] = s;
-    __syncthreads();
-    if (tid < cpb && cb + tid < C) {
-      float t = 0.f;
-      for (int g = 0; g < groups; ++g) t += red[g * cpb + tid];
-      unsafeAtomicAdd(db + cb + tid, t);
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = 0.f;
+  if (c8 < C8)
+    for (long long px = p0 + row; px < p1; px += ROWS) {
+      const uint4 v = *reinterpret_cast<const uint4*>(dy + px * cs + co + c8 * 8);
+      a[0] += bf_lo(v.x); a[1] += bf_hi(v.x); a[2] += bf_lo(v.y); a[3] += bf_hi(v.y);
+      a[4] += bf_lo(v.z); a[5] += bf_hi(v.z); a[6] += bf_lo(v.w); a[7] += bf_hi(v.w);
     }
-    __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[row][col][k] = a[k];
+  __syncthreads();
+  for (int o = tid; o < COLS * 8; o += 256) {
+    const int cc = o >> 3, k = o & 7;
+    const int ch8 = blockIdx.y * COLS + cc;
+    if (ch8 < C8) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) s += red[r][cc][k];
+      unsafeAtomicAdd(db + ch8 * 8 + k, s);
+    }
   }
 }
 
 extern "C" int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db,
                             void* stream) {
-  GS_REQUIRE(dy && db && pixels > 0 && C > 0, "gs_bias_grad: bad argument");
-  const int ppb = 2048;
-  const long long blocks = (pixels + ppb - 1) / ppb;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned short*>(dy), (long long)pixels, C, cs, co, db, ppb);
+  GS_REQUIRE(dy && db && pixels > 0 && C > 0 && (C & 7) == 0 && (cs & 7) == 0 && (co & 7) == 0,
+             "gs_bias_grad: bad argument (C, cs, co must be multiples of 8)");
+  const int C8 = C / 8;
+  int ppb = (int)((pixels + 1023) / 1024);
+  if (ppb < 64) ppb = 64;
+  const unsigned bx = (unsigned)((pixels + ppb - 1) / ppb);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned short* p = static_cast<const unsigned short*>(dy);
+  if (C8 >= 32) hipLaunchKernelGGL((bias_grad_kernel<32>), dim3(bx, (C8 + 31) / 32), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb);
+  else if (C8 >= 8) hipLaunchKernelGGL((bias_grad_kernel<8>), dim3(bx, (C8 + 7) / 8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb);
+  else hipLaunchKernelGGL((bias_grad_kernel<1>), dim3(bx, C8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -28,6 +28,19 @@ class HipOps:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         L.check(self.lib.gs_init(self.device.index or 0), "gs_init")
         self._desc_cache = {}
+        self._timing_filter, self._timing_events = None, []
+
+    # ---- per-kernel timing with HIP events on the launch stream (used by bench.py) ------------------
+    def enable_kernel_timing(self, gconv_filter):
+        self._timing_filter, self._timing_events = gconv_filter, []
+        return self._timing_events
+
+    def kernel_timing_result(self):
+        """(launches, average milliseconds) of the gconv launches selected by the filter"""
+        torch.cuda.synchronize()
+        ev = self._timing_events
+        ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        return len(ev), ms
 
     # ---- descriptors ------------------------------------------------------------------------------------
     def _gdesc(self, g: GConv, N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0):
@@ -58,8 +71,15 @@ class HipOps:
         out_cs = out_cs if out_cs is not None else out.shape[-1]
         d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0)
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
+        timed = self._timing_filter is not None and self._timing_filter(g)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(self.lib.gs_gconv_forward(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _stream()),
                 "gs_gconv_forward")
+        if timed:
+            e1.record()
+            self._timing_events.append((e0, e1))
 
     def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
         key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)
