@@ -65,7 +65,7 @@ def _net_case(hip_ops, build_native, shadow, x_shape, seed, grad_tol=0.15, grad_
     # (accumulation-order noise moves a few values across a bf16 rounding boundary, and from there across an
     #  activation kink, so even the emulation is only statistically equal; op-level tests are the tight ones)
     assert rel_l2(yh, yc) <= 2e-2, rel_l2(yh, yc)
-    assert rel_l2(gxh, gxc) <= 0.12, rel_l2(gxh, gxc)
+    assert rel_l2(gxh, gxc) <= grad_tol, rel_l2(gxh, gxc)
     # (b) vs the fp32 reference restatement
     assert rel_l2(yh, ya.detach()) <= 3e-2
     assert (ya.detach() - yh).abs().max().item() <= 0.12 * ya.abs().max().item()
@@ -73,7 +73,7 @@ def _net_case(hip_ops, build_native, shadow, x_shape, seed, grad_tol=0.15, grad_
     for n, p in shadow.named_parameters():
         if n.startswith("encoder.") or (n.endswith(".bias") and n[:-5] in normed):
             continue  # aliases / biases in front of an InstanceNorm (exactly-zero true gradient)
-        assert rel_l2(gh[n], gc[n]) <= 0.12, (n, rel_l2(gh[n], gc[n]))
+        assert rel_l2(gh[n], gc[n]) <= grad_tol, (n, rel_l2(gh[n], gc[n]))
         assert rel_l2(gh[n], p.grad) <= grad_tol and cosine(gh[n], p.grad) >= grad_cos, (n, rel_l2(gh[n], p.grad))
 
 
