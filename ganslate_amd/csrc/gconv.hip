@@ -15,6 +15,7 @@
 // the ds_read_b128 address. The im2col gather happens in that per-lane source address (reflect / replicate /
 // zero borders; out-of-range lanes read a zero page). Two LDS stages, one barrier per K-step of 64.
 #include "common.hpp"
+#include <cstdlib>
 
 struct GConvK {
   const char* in;
@@ -28,25 +29,35 @@ struct GConvK {
   gs_gconv_desc d;
 };
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
+template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
+__global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
+  constexpr int NW = WM * WN;           // waves per workgroup
   constexpr int WT = BN * 128;          // weight tile bytes per stage
   constexpr int XT = BM * 128;          // pixel tile bytes per stage
   constexpr int STAGE = WT + XT;
   constexpr int TI = BN / WN / 16;      // 16-channel tiles per wave
   constexpr int TJ = BM / WM / 16;      // 16-pixel tiles per wave
-  constexpr int NXI = BM / 32;          // pixel-tile DMA instructions per wave per stage
-  constexpr int NWI = (BN / 8 + 3) / 4; // weight-tile DMA instructions per wave per stage (upper bound)
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int NXI = BM / 8 / NW;      // pixel-tile DMA instructions per wave per stage
+  constexpr int NWI = (BN / 8 + NW - 1) / NW;  // weight-tile DMA instructions per wave per stage (upper bound)
+  constexpr bool W_UNIFORM = (BN / 8) % NW == 0;
+  constexpr int LOADS = NXI + NWI;      // DMA instructions per stage per wave (when W_UNIFORM)
+  static_assert(BM % (8 * NW) == 0, "pixel tile must split evenly over the waves");
+  static_assert(NSTAGE == 2 || (NSTAGE == 3 && W_UNIFORM), "3 stages need a uniform DMA count per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  short* taps = reinterpret_cast<short*>(smem + 2 * STAGE);
+  short* taps = reinterpret_cast<short*>(smem + NSTAGE * STAGE);
 
   const gs_gconv_desc& d = p.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
 
-  int b = blockIdx.x;
+  // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a contiguous run of
+  // logical tiles so the workgroups sharing a pixel tile / neighbouring halos also share an L2
+  int b;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
   const int nt = b % p.tiles_n;
   b /= p.tiles_n;
   const int mt = b % p.tiles_m;
@@ -62,7 +73,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
   bool xv[NXI];
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
-    const int row = (wave + 4 * i) * 8 + lrow;
+    const int row = (wave + NW * i) * 8 + lrow;
     const int m = mt * BM + row;
     xv[i] = m < HWc;
     const int ii = div_small(m, d.Wc, p.rcp_wc);
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
   int winc[NWI];  // 128 B per K-step for a real weight row, 0 for a masked row (stays on the zero page)
 #pragma unroll
   for (int i = 0; i < NWI; ++i) {
-    const int wi = wave + 4 * i;
+    const int wi = wave + NW * i;
     const int co = nt * BN + wi * 8 + lrow;
     const bool wv = co < d.w_rows;
     const char* real = p.w + ((size_t)co * d.Kp + chunk * 8) * 2;
@@ -84,14 +95,26 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
   }
   const int cmask = (1 << p.ci_shift) - 1;
 
+  // K order: for Ci >= 64 the K-steps walk taps fastest inside one 64-channel chunk, so the 9 (or 16, 49)
+  // shifted re-reads of an input chunk are back to back and hit L2; for Ci < 64 a K-step spans several taps
+  // and the natural (tap, channel) order of the pack is kept. `issue` is always called with ks increasing by 1.
+  const bool chunk_major = d.Ci >= 64;
+  int it_t = 0, it_c = 0;
   auto issue = [&](int ks, int buf) {
     char* sb = smem + buf * STAGE;
+    int q0;                                   // first 16-B k-group of this K-step inside a pack row
+    if (chunk_major) {
+      q0 = (it_t << p.ci_shift) + it_c * 8;
+      if (++it_t == d.T) { it_t = 0; ++it_c; }
+    } else {
+      q0 = ks * 8;
+    }
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
-      const int wi = wave + 4 * i;
-      if ((BN / 8) % 4 == 0 || wi < BN / 8) glds16(wsrc[i] + ks * winc[i], sb + wi * 1024);
+      const int wi = wave + NW * i;
+      if (W_UNIFORM || wi < BN / 8) glds16(wsrc[i] + q0 * (winc[i] >> 3), sb + wi * 1024);
     }
-    const int q = ks * 8 + chunk;
+    const int q = q0 + chunk;
     const int t = q >> p.ci_shift;
     const int c8 = q & cmask;
     const bool tv = t < d.T;
@@ -106,7 +129,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
       unsigned off = ((unsigned)(ih * d.Wi + iw) * (unsigned)d.in_cs + (unsigned)(c8 * 8)) * 2u;
       asm volatile("" : "+v"(off));  // keep the address math unconditional: select, don't branch
       const char* src = ok ? in_n + off : p.zero;
-      glds16(src, sb + WT + (wave + 4 * i) * 1024);
+      glds16(src, sb + WT + (wave + NW * i) * 1024);
     }
   };
 
@@ -123,13 +146,16 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
   const int nk = d.Kp >> 6;
 
   __syncthreads();  // taps visible
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (NSTAGE == 2) {
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+  }
 
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+  auto compute = [&](int cur) {
     const char* wb = smem + cur * STAGE + (wn * (BN / WN) + frow) * 128;
     const char* xb = smem + cur * STAGE + WT + (wm * (BM / WM) + frow) * 128;
 #pragma unroll
@@ -146,7 +172,57 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvK p) {
         for (int j = 0; j < TJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's share)
+  };
+
+  if constexpr (NSTAGE == 2) {
+    for (int ks = 0; ks < nk; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's share)
+      __syncthreads();
+    }
+  } else {
+    // 3-stage ring, DMA two K-steps ahead; one raw barrier per K-step; counted vmcnt keeps the younger stage in
+    // flight across the barrier (a __syncthreads() here would drain it: LDS-DMA counts as a pending LDS write)
+    int cur = 0, nxt2 = 2;
+    const int nk_run = VARIANT == 6 ? (nk < 2 ? nk : 2) : nk;   // ablation 6: prologue + epilogue only
+    for (int ks = 0; ks < nk_run; ++ks) {
+      if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (VARIANT == 7) {
+        // wave-group ping-pong: waves w and w+NW/2 share a SIMD; one half issues its LDS-DMA (slow to issue,
+        // ~100+ cycles per instruction) while the other half runs its MFMA cluster, then they swap
+        const bool second = wave >= NW / 2;
+        if (!second) compute(cur);
+        else if (ks + 2 < nk) issue(ks + 2, nxt2);
+        __builtin_amdgcn_s_barrier();
+        if (second) compute(cur);
+        else if (ks + 2 < nk) issue(ks + 2, nxt2);
+      } else if constexpr (VARIANT == 0) {
+        if (ks + 2 < nk) issue(ks + 2, nxt2);
+        compute(cur);
+      } else if constexpr (VARIANT == 1) {       // MFMAs first, DMA issue behind them
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < nk) issue(ks + 2, nxt2);
+      } else if constexpr (VARIANT == 3) {       // ablation: DMA only
+        if (ks + 2 < nk) issue(ks + 2, nxt2);
+      } else if constexpr (VARIANT == 4) {       // ablation: LDS reads + MFMA only
+        compute(cur);
+      } else if constexpr (VARIANT == 6) {
+        compute(cur);
+      } else {                                   // VARIANT 2: priority on the MFMA cluster
+        if (ks + 2 < nk) issue(ks + 2, nxt2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        compute(cur);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
     __syncthreads();
   }
 
@@ -223,18 +299,21 @@ struct TileCfg { int bm, bn; };
 TileCfg pick_tile(const gs_gconv_desc* d) {
   if (d->Co <= 16) return {256, 16};
   if (d->Co <= 64) return {128, 64};
+  // big tile (8 waves, 3 stages, 1 workgroup per CU) once it still fills the chip; else the 4-wave 128x128 tile
+  const long long big = (long long)d->N * (((long long)d->Hc * d->Wc + 255) / 256) * ((d->Co + 127) / 128);
+  if (big >= 192) return {256, 128};
   return {128, 128};
 }
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
 int launch(const GConvK& k, int blocks, hipStream_t st) {
-  constexpr int lds = 2 * (BM + BN) * 128 + GS_MAX_TAPS * 2;
+  constexpr int lds = NSTAGE * (BM + BN) * 128 + GS_MAX_TAPS * 2;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, NSTAGE, VARIANT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN>), dim3(blocks), dim3(256), lds, st, k);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, NSTAGE, VARIANT>), dim3(blocks), dim3(WM * WN * 64), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -273,7 +352,17 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (tc.bn == 16) return launch<256, 16, 4, 1>(k, (int)blocks, st);
-  if (tc.bn == 64) return launch<128, 64, 2, 2>(k, (int)blocks, st);
-  return launch<128, 128, 2, 2>(k, (int)blocks, st);
+  if (tc.bn == 16) return launch<256, 16, 4, 1, 2>(k, (int)blocks, st);
+  if (tc.bn == 64) return launch<128, 64, 2, 2, 2>(k, (int)blocks, st);
+  if (tc.bm == 256) {
+    static const int variant = getenv("GS_GCONV_VARIANT") ? atoi(getenv("GS_GCONV_VARIANT")) : 0;
+    if (variant == 1) return launch<256, 128, 4, 2, 3, 1>(k, (int)blocks, st);
+    if (variant == 2) return launch<256, 128, 4, 2, 3, 2>(k, (int)blocks, st);
+    if (variant == 3) return launch<256, 128, 4, 2, 3, 3>(k, (int)blocks, st);
+    if (variant == 4) return launch<256, 128, 4, 2, 3, 4>(k, (int)blocks, st);
+    if (variant == 6) return launch<256, 128, 4, 2, 3, 6>(k, (int)blocks, st);
+    if (variant == 7) return launch<256, 128, 4, 2, 3, 7>(k, (int)blocks, st);
+    return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);
+  }
+  return launch<128, 128, 2, 2, 2>(k, (int)blocks, st);
 }

@@ -18,7 +18,7 @@ struct WGradK {
   float* dw;
   const char* zero;
   int tiles_p, tiles_q, splits, chunk, q_shift;
-  float rcp_wa;
+  float rcp_wa, rcp_hw;
   gs_wgrad_desc d;
 };
 
@@ -26,14 +26,22 @@ struct WGradK {
 // over all 16 slots
 __device__ __forceinline__ int wg_swz(int R) { return ((R & 3) << 1) | (((R >> 3) & 1) << 3); }
 
-template <int WP, int WQ>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
-  constexpr int BP = 128, BQ = 128, BK = 64;
-  constexpr int AT = BK * BP * 2, GT = BK * BQ * 2, STAGE = AT + GT;  // 16 KiB + 16 KiB
+template <int BP, int BQ, int WP, int WQ>
+__global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
+  constexpr int NW = WP * WQ, BK = 64, NSTAGE = 3;
+  constexpr int ARB = BP * 2, GRB = BQ * 2;                  // row bytes of the two LDS tiles
+  constexpr int AT = BK * ARB, GT = BK * GRB, STAGE = AT + GT;
+  constexpr int ARI = 1024 / ARB, GRI = 1024 / GRB;          // rows per 1-KiB DMA instruction
+  constexpr int A_INSTR = BK / ARI;                          // DMA instructions of the dense tile per stage
+  constexpr int NAI = (A_INSTR + NW - 1) / NW, NGI = BK / GRI / NW;   // per wave per stage
+  constexpr int LOADS = NAI + NGI;                           // uniform over waves (surplus lanes hit a dummy)
   constexpr int TI = BP / WP / 16, TJ = BQ / WQ / 16;
-  static_assert(WP * WQ == 4, "4 waves");
+  constexpr int ASW = ARB / 16 - 1 < 15 ? ARB / 16 - 1 : 15; // swizzle mask: stay inside the row
+  static_assert((BK / GRI) % NW == 0, "gathered tile must split evenly over the waves");
+  static_assert(NAI == 1 || (A_INSTR % NW == 0 && (ARI * NW) % 16 == 0), "dense tile DMA layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  short* taps = reinterpret_cast<short*>(smem + 2 * STAGE);
+  short* taps = reinterpret_cast<short*>(smem + NSTAGE * STAGE);
+  char* dummy = smem + NSTAGE * STAGE + GS_MAX_TAPS * 2;     // 1 KiB sink for surplus DMA instructions
   const gs_wgrad_desc& d = p.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,51 +52,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
   b /= p.tiles_q;
   const int tp = b % p.tiles_p;
   b /= p.tiles_p;
-  const int sp = b % p.splits;
-  const int n = b / p.splits;
+  const int sp = b;                       // pixel range [k0, k1) of the batch-flattened pixel index
   const int HW = d.Ha * d.Wa;
   const int k0 = sp * p.chunk;
-  const int k1 = min(HW, k0 + p.chunk);
+  const int k1 = min(d.N * HW, k0 + p.chunk);
   if (k0 >= k1) return;
 
   if (tid < d.T) taps[tid] = (short)(((int)d.dh[tid] & 0xff) | ((int)d.dw_[tid] << 8));
+  __syncthreads();
 
-  // DMA: every wave-instruction moves 4 rows x 256 B; instruction k covers rows 4k..4k+3.
-  const int lrow = lane >> 4;   // row inside the instruction
-  const int slot = lane & 15;   // destination 16-B slot inside the row
-  const char* a_n = p.a + ((size_t)n * HW * d.a_cs + d.a_co) * 2;
-  const char* g_n = p.g + ((size_t)n * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
-  const int qmask = (1 << p.q_shift) - 1;
+  // ---- per-lane DMA bookkeeping: the 16-B chunk (and with it the tap / channel group) is fixed per lane ----
+  const char* a_n = p.a + (size_t)d.a_co * 2;
+  const char* g_n = p.g + (size_t)d.g_co * 2;
+  const unsigned g_img = (unsigned)(d.Hg * d.Wg);
+  const int a_row0 = ARI * wave + lane / (ARB / 16);         // row of this lane in its first A instruction
+  const int a_slot = lane % (ARB / 16);
+  const int a_chunk = a_slot ^ (wg_swz(a_row0) & ASW);       // swz is invariant under row += ARI*NW (multiple of 16)
+  const int a_pch = tp * BP + a_chunk * 8;
+  const bool a_cv = a_pch < d.P;
+  const int g_row0 = GRI * wave + lane / (GRB / 16);
+  const int g_slot = lane % (GRB / 16);
+  const int g_chunk = g_slot ^ wg_swz(g_row0);
+  const int g_col = tq * BQ + g_chunk * 8;                   // n' = t*Q + q
+  const int g_t = (g_col >> 3) >> p.q_shift;
+  const int g_q8 = (g_col >> 3) & ((1 << p.q_shift) - 1);
+  const bool g_tv = g_t < d.T;
+  const short tpv = taps[g_tv ? g_t : 0];
+  const int g_dh = (int)(signed char)(tpv & 0xff), g_dw = (int)tpv >> 8;
+  static_assert((GRI * NW) % 16 == 0, "row step must keep the swizzle invariant");
 
   auto issue = [&](int ks, int buf) {
     char* sb = smem + buf * STAGE;
+    const int mb = k0 + ks * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = wave + 4 * i;
-      const int R = k * 4 + lrow;
-      const int m = k0 + ks * BK + R;
-      const bool mv = m < k1;
-      const int chunk = slot ^ wg_swz(R);
-      // dense side
-      {
-        const int pch = tp * BP + chunk * 8;
-        const char* src = (mv && pch < d.P) ? a_n + ((size_t)m * d.a_cs + pch) * 2 : p.zero;
-        glds16(src, sb + k * 1024);
-      }
-      // gathered side
-      {
-        const int col = tq * BQ + chunk * 8;          // n' = t*Q + q
-        const int t = (col >> 3) >> p.q_shift;
-        const int q8 = (col >> 3) & qmask;
-        bool ok = mv && t < d.T;
-        const short tpv = taps[ok ? t : 0];
-        const int ii = div_small(m, d.Wa, p.rcp_wa);
-        const int jj = m - ii * d.Wa;
-        const int ih = border_index(ii * d.si + (int)(signed char)(tpv & 0xff), d.Hg, d.border, ok);
-        const int iw = border_index(jj * d.si + ((int)tpv >> 8), d.Wg, d.border, ok);
-        const char* src = ok ? g_n + ((size_t)(ih * d.Wg + iw) * d.g_cs + q8 * 8) * 2 : p.zero;
-        glds16(src, sb + AT + k * 1024);
-      }
+    for (int i = 0; i < NAI; ++i) {
+      const int R = a_row0 + i * ARI * NW;
+      const int m = mb + R;
+      unsigned off = ((unsigned)m * (unsigned)d.a_cs + (unsigned)a_pch) * 2u;
+      asm volatile("" : "+v"(off));
+      const bool real = A_INSTR % NW == 0 || wave + i * NW < A_INSTR;   // wave-uniform
+      const char* src = (real && m < k1 && a_cv) ? a_n + off : p.zero;
+      glds16(src, real ? sb + (wave + i * NW) * 1024 : dummy);
+    }
+#pragma unroll
+    for (int i = 0; i < NGI; ++i) {
+      const int R = g_row0 + i * GRI * NW;
+      const int m = mb + R;
+      bool ok = g_tv && m < k1;
+      const int nn = div_small(m, HW, p.rcp_hw);
+      const int rem = m - nn * HW;
+      const int ii = div_small(rem, d.Wa, p.rcp_wa);
+      const int jj = rem - ii * d.Wa;
+      const int ih = border_index(ii * d.si + g_dh, d.Hg, d.border, ok);
+      const int iw = border_index(jj * d.si + g_dw, d.Wg, d.border, ok);
+      unsigned off = (((unsigned)nn * g_img + (unsigned)(ih * d.Wg + iw)) * (unsigned)d.g_cs + (unsigned)(g_q8 * 8)) * 2u;
+      asm volatile("" : "+v"(off));
+      const char* src = ok ? g_n + off : p.zero;
+      glds16(src, sb + AT + (wave + i * NW) * 1024);
     }
   };
 
@@ -105,14 +125,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
   const int frr = (lane & 15) >> 2;    // pixel row inside a 4-row block
   const int fcc = lane & 3;            // 4-channel group inside the 16-channel tile
 
-  __syncthreads();
   issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (nk > 1) issue(1, 1);
 
+  int cur = 0, nxt2 = 2;
   for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+    if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ks + 2 < nk) issue(ks + 2, nxt2);
     const char* ab = smem + cur * STAGE;
     const char* gb = ab + AT;
 #pragma unroll
@@ -122,19 +143,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
       for (int h = 0; h < 2; ++h) {
         const int R = kk * 32 + fk * 8 + h * 4 + frr;
         const int sw = wg_swz(R);
-        const int rbase = R * 256 + (fcc & 1) * 8;
+        const int sub = (fcc & 1) * 8;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
           const int ch = (wp * (BP / WP) / 8) + i * 2 + (fcc >> 1);
           s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)GS_LDS(ab + rbase + ((ch ^ sw) << 4)));
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(ab + R * ARB + sub + ((ch ^ (sw & ASW)) << 4)));
           af[i][h * 4 + 0] = v[0]; af[i][h * 4 + 1] = v[1]; af[i][h * 4 + 2] = v[2]; af[i][h * 4 + 3] = v[3];
         }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int ch = (wq * (BQ / WQ) / 8) + j * 2 + (fcc >> 1);
           s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)GS_LDS(gb + rbase + ((ch ^ sw) << 4)));
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(gb + R * GRB + sub + ((ch ^ sw) << 4)));
           gf[j][h * 4 + 0] = v[0]; gf[j][h * 4 + 1] = v[1]; gf[j][h * 4 + 2] = v[2]; gf[j][h * 4 + 3] = v[3];
         }
       }
@@ -144,8 +165,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
         for (int j = 0; j < TJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
   }
 
   // ---- epilogue: C[p][n'] accumulated with fp32 atomics -------------------------------------------
@@ -168,6 +189,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradK p) {
   }
 }
 
+namespace {
+template <int BP, int BQ, int WP, int WQ>
+int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
+  k.tiles_p = (d->P + BP - 1) / BP;
+  k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
+  // split-K over the batch-flattened pixel index: one workgroup per CU is resident (144 KiB of LDS), so aim for
+  // a grid of (almost) exactly r * 256 workgroups with >= 16 K-steps each, preferring the smallest r
+  const long long M = (long long)d->N * d->Ha * d->Wa;
+  GS_REQUIRE(M < (1 << 24) && M * d->a_cs < (1LL << 31) && (long long)d->N * d->Hg * d->Wg * d->g_cs < (1LL << 31),
+             "gs_wgrad: tensor too large for 32-bit offsets");
+  const long long tiles = (long long)k.tiles_p * k.tiles_q;
+  const long long max_splits = (M + 1023) / 1024 > 0 ? (M + 1023) / 1024 : 1;
+  long long splits = 1;
+  double best = 1e30;
+  for (int r = 1; r <= 4; ++r) {
+    long long s = (256LL * r) / tiles;
+    if (s < 1) s = 1;
+    if (s > max_splits) s = max_splits;
+    const long long blocks = tiles * s;
+    const long long rounds = (blocks + 255) / 256;
+    const double cost = (double)rounds * ((double)M / (double)s + 512.0);   // K-steps per block + fixed overhead
+    if (cost < best) { best = cost; splits = s; }
+  }
+  int chunk = (int)((M + splits - 1) / splits);
+  chunk = (chunk + 63) / 64 * 64;
+  splits = (M + chunk - 1) / chunk;
+  k.splits = (int)splits;
+  k.chunk = chunk;
+  k.rcp_hw = 1.0f / (float)(d->Ha * d->Wa);
+  const long long blocks = tiles * splits;
+  GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_wgrad: bad grid %lld", blocks);
+  constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 2 + 1024;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
 extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream) {
   GS_REQUIRE(d && a && g && dw, "gs_wgrad: null argument");
   GS_REQUIRE(d->Q >= 8 && (d->Q & 7) == 0 && ((d->Q >> 3) & ((d->Q >> 3) - 1)) == 0,
@@ -176,44 +241,21 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
   GS_REQUIRE(d->T >= 1 && d->T <= GS_MAX_TAPS, "gs_wgrad: T=%d out of range", d->T);
   GS_REQUIRE((d->a_cs & 7) == 0 && (d->a_co & 7) == 0 && (d->g_cs & 7) == 0 && (d->g_co & 7) == 0,
              "gs_wgrad: channel strides/offsets must be multiples of 8");
-  GS_REQUIRE((long long)d->Ha * d->Wa < (1 << 24), "gs_wgrad: image too large");
   WGradK k;
   k.a = static_cast<const char*>(a);
   k.g = static_cast<const char*>(g);
   k.dw = dw;
   k.zero = static_cast<const char*>(gs_zero_page());
   GS_REQUIRE(k.zero, "gs_wgrad: library not initialised (call gs_init)");
-  k.tiles_p = (d->P + 127) / 128;
-  k.tiles_q = (d->T * d->Q + 127) / 128;
-  const int HW = d->Ha * d->Wa;
-  // enough workgroups to fill 256 CUs a few times over, but at least 4 K-steps per split
-  long long tiles = (long long)k.tiles_p * k.tiles_q * d->N;
-  int splits = (int)((1024 + tiles - 1) / tiles);
-  const int max_splits = (HW + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int chunk = (HW + splits - 1) / splits;
-  chunk = (chunk + 63) / 64 * 64;
-  splits = (HW + chunk - 1) / chunk;
-  k.splits = splits;
-  k.chunk = chunk;
   int sh = 0;
   while ((8 << sh) < d->Q) ++sh;
   k.q_shift = sh;
   k.rcp_wa = 1.0f / (float)d->Wa;
   k.d = *d;
-  const long long blocks = tiles * splits;
-  GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_wgrad: bad grid %lld", blocks);
-  constexpr int lds = 2 * (64 * 128 * 2 * 2) + GS_MAX_TAPS * 2;
-  static bool configured = false;
-  if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<2, 2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
-  }
-  hipLaunchKernelGGL((wgrad_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), k);
-  GS_CHECK_HIP(hipGetLastError());
-  return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d->P <= 16) return launch_wgrad<16, 256, 1, 8>(k, d, st);      // Cout 1/3 layers: skinny P
+  if (d->P <= 64) return launch_wgrad<64, 256, 1, 8>(k, d, st);
+  return launch_wgrad<128, 256, 2, 4>(k, d, st);
 }
 
 // ---- bias gradient: db[c] += sum_pixels dy[pix][c] ---------------------------------------------------

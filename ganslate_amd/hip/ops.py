@@ -60,8 +60,9 @@ class HipOps:
             return d
         return d[0]
 
-    def tile_m(self, g: GConv) -> int:
-        return self.lib.gs_tile_m(C.byref(self._gdesc(g, 1, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+    def tile_m(self, g: GConv, N: int) -> int:
+        """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
+        return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",

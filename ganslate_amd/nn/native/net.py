@@ -225,7 +225,7 @@ class NativeNet:
                 slots, offs = 0, []
                 for g in lw.fwd:
                     offs.append(slots)
-                    tm = ops.tile_m(g)
+                    tm = ops.tile_m(g, N)
                     slots += (g.Hc * g.Wc + tm - 1) // tm
                 part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=dev)
                 for g, o in zip(lw.fwd, offs):

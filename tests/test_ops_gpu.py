@@ -27,6 +27,11 @@ CONV_CASES = [
     (ConvSpec("conv", 256, 512, 4, 1, 1), 2, 18, 18),                        # K7 stride-1 k4 (ragged 17x17)
     (ConvSpec("conv", 512, 1, 4, 1, 1), 2, 17, 17),                          # K7 last (Cout 1 -> 8)
     (ConvSpec("convT", 64, 32, 4, 2, 1, 0), 1, 8, 8),                        # U-Net style k4 convT
+    # BASELINE-size layers: these select the 8-wave 256x128 / 3-stage tile configurations
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),    # K3 at cfg2 size (M=32768)
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 4, 128, 128),                        # K2 d128
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 4, 64, 64),                     # K4 u128
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 8, 64, 64),                         # PatchGAN conv3
 ]
 
 
@@ -64,19 +69,20 @@ def make_layer(spec, H, W, seed):
     return low, master, bias, fpack, dpack
 
 
-def stats_slots(ops, low, classes):
+def stats_slots(ops, low, classes, N):
     slots, offs = 0, []
     for g in classes:
         offs.append(slots)
-        slots += (g.Hc * g.Wc + ops.tile_m(g) - 1) // ops.tile_m(g)
+        slots += (g.Hc * g.Wc + ops.tile_m(g, N) - 1) // ops.tile_m(g, N)
     return slots, offs
 
 
 def run_forward(ops, dev, low, bias, fpack, xa, N, act="none"):
     spec = low.spec
     ya = torch.zeros(N, low.Ho, low.Wo, spec.cout_p, dtype=torch.bfloat16, device=dev)
-    slots, offs = stats_slots(ops, low, low.fwd)
-    part = torch.zeros(N * slots * 2 * spec.cout_p, dtype=torch.float32, device=dev)
+    slots, offs = stats_slots(ops, low, low.fwd, N)
+    # NaN-filled: every slot must be written by the kernel (a stale slot count shows up as NaN statistics)
+    part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
     for g, o in zip(low.fwd, offs):
         ops.gconv(g, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act=act, stats=part, stats_slots=slots,
                   stats_slot0=o)

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the hot kernels at BASELINE cfg2 layer shapes (run on the GPU box):
+    python tools/bench_kernels.py [--iters 50] [--only rb_fwd]
+Prints TFLOP/s per case measured with HIP events on the launch stream."""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from ganslate_amd.hip.ops import HipOps  # noqa: E402
+from ganslate_amd.nn.native.spec import ConvSpec, lower  # noqa: E402
+
+CASES = {
+    # name: (spec, N, H, W)
+    "rb": (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),
+    "d2": (ConvSpec("conv", 128, 256, 3, 2, 1), 8, 128, 128),
+    "d1": (ConvSpec("conv", 64, 128, 3, 2, 1), 8, 256, 256),
+    "u1": (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 8, 64, 64),
+    "stem": (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect"), 8, 256, 256),
+    "out": (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect"), 8, 256, 256),
+    "dc4": (ConvSpec("conv", 256, 512, 4, 1, 1), 8, 32, 32),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    ops = HipOps()
+    dev = ops.device
+    for name, (spec, N, H, W) in CASES.items():
+        low = lower(spec, H, W)
+        macs = N * low.Ho * low.Wo * spec.cout * spec.cin * spec.T if spec.kind == "conv" else \
+            N * H * W * spec.cout * spec.cin * spec.T
+        flop = 2.0 * macs
+        x = torch.randn(N, H, W, spec.cin_p, device=dev).to(torch.bfloat16)
+        gy = torch.randn(N, low.Ho, low.Wo, spec.cout_p, device=dev).to(torch.bfloat16)
+        fpack = (torch.randn(low.fwd_index.size + 64, device=dev) * 0.05).to(torch.bfloat16)
+        dpack = (torch.randn(low.dgrad_index.size + 64, device=dev) * 0.05).to(torch.bfloat16)
+        bias = torch.zeros(spec.cout_p, device=dev)
+        y = torch.empty(N, low.Ho, low.Wo, spec.cout_p, device=dev, dtype=torch.bfloat16)
+        f = low.dgrad_fold
+        gx = torch.empty(N, H + 2 * f, W + 2 * f, spec.cin_p, device=dev, dtype=torch.bfloat16)
+        dw = torch.zeros(spec.master_numel, device=dev)
+        slots, offs = 0, []
+        for g in low.fwd:
+            offs.append(slots)
+            slots += (g.Hc * g.Wc + ops.tile_m(g, N) - 1) // ops.tile_m(g, N)
+        part = torch.empty(N * slots * 2 * spec.cout_p, device=dev)
+        a, gt = (gy, x) if spec.kind == "conv" else (x, gy)
+
+        def fwd():
+            for g, o in zip(low.fwd, offs):
+                ops.gconv(g, x, fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
+
+        def dgrad():
+            for g in low.dgrad:
+                ops.gconv(g, gy, dpack, None, gx)
+
+        def wgrad():
+            ops.wgrad(low.wgrad, a, gt, dw)
+
+        for kind, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            tag = f"{name}_{kind}"
+            if args.only and args.only not in tag:
+                continue
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            print(f"{tag:12s} {ms * 1e3:9.1f} us  {flop / ms / 1e9:8.1f} TFLOP/s   ({flop / 1e9:.2f} GFLOP)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
