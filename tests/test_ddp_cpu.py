@@ -1,0 +1,92 @@
+"""Data-parallel path on CPU: 2 processes, gloo, oracle fp32 backend. Checks the identity the design relies on
+(SURVEY.md §8e): InstanceNorm is per-sample and every loss is a batch mean, so the all-reduced-and-averaged
+gradient of 2 ranks x batch 1 equals the single-process gradient on the concatenated batch of 2; and that the
+bucketed asynchronous all-reduce fires during the last backward pass and leaves all ranks with identical weights
+after the optimiser step."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+OVERRIDES = ["train.gan.generator.n_residual_blocks=2", "train.dataset.final_size=[32,32]", "train.gan.pool_size=0",
+             "train.metrics.ssim=False", "train.metrics.discriminator_evolution=False"]
+
+
+def _inputs(n):
+    g = torch.Generator().manual_seed(77)
+    return torch.rand(n, 3, 32, 32, generator=g) * 2 - 1, torch.rand(n, 3, 32, 32, generator=g) * 2 - 1
+
+
+def _build(batch, seed=5):
+    from ganslate_amd.nn.native import backend
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle.ops_ref import RefOps
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    conf = build_conf([f"config={ROOT / 'tests/configs/cyclegan_synthetic.yaml'}", f"train.batch_size={batch}",
+                       *OVERRIDES])
+    torch.manual_seed(seed)
+    return build_gan(conf)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), GANSLATE_DIST_BACKEND="gloo")
+    torch.set_num_threads(2)
+    from ganslate_amd.utils import communication
+    communication.init_distributed()
+    model = _build(1, seed=5 + rank)       # different init per rank: parallelize() must broadcast rank 0's weights
+    A, B = _inputs(world)
+    model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
+    # gradient of the generator objective, reduced over ranks
+    model.forward()
+    model.set_requires_grad([model.networks["D_B"], model.networks["D_A"]], False)
+    model.backward_G()
+    grads = {}
+    for name in ("G_AB", "G_BA"):
+        net = model.networks[name]
+        fired_async = len(net._reduce_handles) > 0
+        scale = net.finish_grad_reduction()
+        grads[name] = (net.master.grad.clone() * scale, fired_async)
+    # then a full step: weights must stay identical across ranks
+    model.optimizers["G"].zero_grad()
+    model.optimize_parameters()
+    weights = {n: net.master.detach().clone() for n, net in model.networks.items()}
+    torch.save({"grads": grads, "weights": weights}, Path(out_dir) / f"rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gradient_equals_single_process_batch_two(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    for name in r0["weights"]:
+        assert torch.equal(r0["weights"][name], r1["weights"][name]), f"{name}: ranks diverged after a step"
+    for name in ("G_AB", "G_BA"):
+        assert r0["grads"][name][1], "bucketed all-reduce did not start during the last backward pass"
+        assert torch.equal(r0["grads"][name][0], r1["grads"][name][0])
+    # single-process reference on the concatenated batch
+    os.environ.pop("WORLD_SIZE", None)
+    from ganslate_amd.nn.native import backend
+    single = _build(2, seed=5)             # rank 0's init
+    A, B = _inputs(2)
+    single.set_input({"A": A, "B": B})
+    single.forward()
+    single.set_requires_grad([single.networks["D_B"], single.networks["D_A"]], False)
+    single.backward_G()
+    try:
+        for name in ("G_AB", "G_BA"):
+            ref = single.networks[name].master.grad
+            got = r0["grads"][name][0]
+            scale = ref.abs().max().item()
+            assert (ref - got).abs().max().item() <= 1e-4 * scale, name
+    finally:
+        backend.set_ops(None)
