@@ -5,53 +5,60 @@
 // autograd backward, including the adjoint of nn.ReflectionPad2d (the `fold`).
 #include "common.hpp"
 
-// ---- slot reduction: in [N][slots][K] -> out [N][K]; optional InstanceNorm finalize (K = 2C: sums | sumsq) ----
-// grid (ceil(K/64), N), 256 threads = 64 columns x 4 slot lanes
-__global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* out, int slots, int K, int finalize_c,
-                                                       float inv_hw, float eps) {
-  __shared__ double red[4][64];
-  __shared__ float tot[128];
+// ---- slot reduction: in [N][slots][R][C] -> per (n, c) totals over the slots ---------------------------------------
+// grid (ceil(C/16), N), 256 threads = 16 channels x 16 slot lanes.
+//  R == 2 (forward): totals are (sum y, sum y^2)  -> out [N][2][C] = (mean, rstd)
+//  R == 3 (backward): totals are (sum ghat, sum ghat*yhat, sum yhat) -> out [N][3][C]; optionally the bias gradient of
+//           the conv in front of the norm, db[c] += sum_n -rstd * S2 * S3 / hw  (= sum_pixels dy, see norm backward)
+template <int R>
+__global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* out, int slots, int C, float inv_hw,
+                                                       float eps, const float* mean_rstd, float* db) {
+  __shared__ double red[16][17];
+  __shared__ float tot[R][16];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  const int col = tid & 63, lane = tid >> 6;
-  const float* src = in + (size_t)n * slots * K;
-  if (finalize_c == 0) {
-    const int k = blockIdx.x * 64 + col;
-    double s = 0.0;
-    if (k < K)
-      for (int sl = lane; sl < slots; sl += 4) s += (double)src[(size_t)sl * K + k];
-    red[lane][col] = s;
-    __syncthreads();
-    if (lane == 0 && k < K) out[(size_t)n * K + k] = (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]);
-    return;
-  }
-  // finalize: this block owns channels [c0, c0+64): needs the sum row and the sum-of-squares row
-  const int C = finalize_c;
-  const int c = blockIdx.x * 64 + col;
-  for (int half = 0; half < 2; ++half) {
+  const int col = tid & 15, lane = tid >> 4;
+  const int c = blockIdx.x * 16 + col;
+  const float* src = in + (size_t)n * slots * R * C;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
     double s = 0.0;
     if (c < C)
-      for (int sl = lane; sl < slots; sl += 4) s += (double)src[(size_t)sl * K + half * C + c];
+      for (int sl = lane; sl < slots; sl += 16) s += (double)src[((size_t)sl * R + r) * C + c];
     __syncthreads();
     red[lane][col] = s;
     __syncthreads();
-    if (lane == 0) tot[half * 64 + col] = (float)(red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+    if (lane == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) t += red[l][col];
+      tot[r][col] = (float)t;
+    }
   }
   __syncthreads();
   if (lane == 0 && c < C) {
-    const double mean = (double)tot[col] * (double)inv_hw;
-    double var = (double)tot[64 + col] * (double)inv_hw - mean * mean;
-    if (var < 0.0) var = 0.0;
-    out[(size_t)n * 2 * C + c] = (float)mean;
-    out[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (R == 2) {
+      const double mean = (double)tot[0][col] * (double)inv_hw;
+      double var = (double)tot[1][col] * (double)inv_hw - mean * mean;
+      if (var < 0.0) var = 0.0;
+      out[(size_t)n * 2 * C + c] = (float)mean;
+      out[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = tot[r][col];
+      if (db) {
+        const float rstd = mean_rstd[(size_t)n * 2 * C + C + c];
+        unsafeAtomicAdd(db + c, -rstd * tot[1][col] * tot[R - 1][col] * inv_hw);
+      }
+    }
   }
 }
 
 extern "C" int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
                                  float* mean_rstd, void* stream) {
   GS_REQUIRE(partial && mean_rstd && N > 0 && slots > 0 && C > 0 && hw > 0, "gs_inorm_finalize: bad argument");
-  hipLaunchKernelGGL(slot_sum_kernel, dim3((C + 63) / 64, N), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
-                     mean_rstd, slots, 2 * C, C, 1.0f / (float)hw, eps);
+  hipLaunchKernelGGL((slot_sum_kernel<2>), dim3((C + 15) / 16, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partial, mean_rstd, slots, C, 1.0f / (float)hw, eps, (const float*)nullptr, (float*)nullptr);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
                                                                int C8, int fold, int mode, int act, float slope,
                                                                int pix_per_block, int chunks) {
   constexpr int ROWS = 256 / COLS;
-  __shared__ float red[ROWS][COLS][17];
+  __shared__ float red[ROWS][COLS][25];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const int col = tid % COLS, row = tid / COLS;
@@ -172,9 +179,9 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
   const uint4* g2_n = g2 ? g2 + (size_t)n * HW * C8 : nullptr;
   const uint4* y_n = y + (size_t)n * HW * C8;
   const float* mr = mean_rstd + (size_t)n * 2 * C8 * 8;
-  float a1[8], a2[8];
+  float a1[8], a2[8], a3[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a1[k] = a2[k] = 0.f;
+  for (int k = 0; k < 8; ++k) a1[k] = a2[k] = a3[k] = 0.f;
   if (c8 < C8) {
     float mu[8], rs[8];
     load8(mu, mr + c8 * 8);
@@ -190,22 +197,23 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
         const float gh = g[k] * act_grad_from_out(yh, act, slope);
         a1[k] += gh;
         a2[k] += gh * yh;
+        a3[k] += yh;
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { red[row][col][k] = a1[k]; red[row][col][8 + k] = a2[k]; }
+  for (int k = 0; k < 8; ++k) { red[row][col][k] = a1[k]; red[row][col][8 + k] = a2[k]; red[row][col][16 + k] = a3[k]; }
   __syncthreads();
-  // COLS*16 outputs, summed over ROWS pixel lanes
-  for (int o = tid; o < COLS * 16; o += 256) {
-    const int cc = o >> 4, k = o & 15;
+  // COLS*24 outputs, summed over ROWS pixel lanes
+  for (int o = tid; o < COLS * 24; o += 256) {
+    const int cc = o / 24, k = o - cc * 24;
     const int ch8 = blockIdx.z * COLS + cc;
     if (ch8 < C8) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) sum += red[r][cc][k];
-      float* out = partial + ((size_t)n * chunks + blockIdx.x) * 2 * C8 * 8;
-      out[(k < 8 ? 0 : C8 * 8) + ch8 * 8 + (k & 7)] = sum;
+      float* out = partial + ((size_t)n * chunks + blockIdx.x) * 3 * C8 * 8;
+      out[(k >> 3) * C8 * 8 + ch8 * 8 + (k & 7)] = sum;
     }
   }
 }
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
   uint4* gs_n = gsum ? gsum + (size_t)n * per_img : nullptr;
   const float inv_hw = 1.0f / (float)HW;
   const float* mr = mean_rstd ? mean_rstd + (size_t)n * 2 * C8 * 8 : nullptr;
-  const float* sm = sums ? sums + (size_t)n * 2 * C8 * 8 : nullptr;
+  const float* sm = sums ? sums + (size_t)n * 3 * C8 * 8 : nullptr;
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < per_img; e += gridDim.x * 256u) {
     const unsigned px = c8_shift >= 0 ? (e >> c8_shift) : e / (unsigned)C8;
     const int c8 = (int)(e - px * (unsigned)C8);
@@ -268,15 +276,16 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
   }
 }
 
-static const int kBwdPixPerBlock = 128;
+static const int kBwdPixPerBlock = 64;
 
 extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C) {
   const int64_t chunks = ((int64_t)H * W + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
-  return (int64_t)N * (chunks + 1) * 2 * C;
+  return (int64_t)N * (chunks + 1) * 3 * C;
 }
 
 extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
-                                     void* dy, void* gsum, float* scratch, int32_t N, int32_t H, int32_t W,
+                                     void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t H,
+                                     int32_t W,
                                      int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
                                      void* stream) {
   GS_REQUIRE(g_pad && y && dy && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0,
@@ -290,7 +299,7 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   if (mean_rstd) {
     GS_REQUIRE(scratch, "gs_inorm_act_backward: scratch required with normalisation");
     const int chunks = (HW + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
-    sums = scratch + (size_t)N * chunks * 2 * C;
+    sums = scratch + (size_t)N * chunks * 3 * C;
 #define GS_LAUNCH_REDUCE(COLS)                                                                                   \
   hipLaunchKernelGGL((inorm_bwd_reduce_kernel<COLS>), dim3(chunks, N, (C8 + COLS - 1) / COLS), dim3(256), 0, st, \
                      static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y), \
@@ -300,8 +309,8 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
     GS_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(slot_sum_kernel, dim3((2 * C + 63) / 64, N), dim3(256), 0, st, scratch, sums, chunks, 2 * C, 0,
-                       0.f, 0.f);
+    hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, scratch, sums, chunks, C,
+                       1.0f / (float)HW, 0.f, mean_rstd, bias_grad);
     GS_CHECK_HIP(hipGetLastError());
   }
   const long long per_img = (long long)HW * C8;

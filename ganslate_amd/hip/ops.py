@@ -114,14 +114,14 @@ class HipOps:
                                               L.ACT[act], slope, _stream()), "gs_inorm_act_forward")
 
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
-                           slope=0.2):
+                           slope=0.2, bias_grad=None):
         N, H, W, Cc = y.shape
         scratch = None
         if mean_rstd is not None:
             n = self.lib.gs_inorm_backward_scratch_floats(N, H, W, Cc)
             scratch = torch.empty(n, dtype=torch.float32, device=y.device)
         L.check(self.lib.gs_inorm_act_backward(_ptr(g_pad), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(dy),
-                                               _ptr(gsum), _ptr(scratch), N, H, W, Cc, fold,
+                                               _ptr(gsum), _ptr(scratch), _ptr(bias_grad), N, H, W, Cc, fold,
                                                L.BORDER[fold_mode], L.ACT[act], slope, _stream()),
                 "gs_inorm_act_backward")
 

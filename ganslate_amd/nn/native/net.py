@@ -277,8 +277,10 @@ class NativeNet:
                 dy = torch.empty_like(x_out)
                 gsum = torch.empty_like(x_out) if (need_total and (fold > 0 or g2 is not None)) else None
                 if nd.norm:
+                    # the bias gradient of a conv in front of an InstanceNorm comes out of the norm's reduction sums
+                    db = grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
                     ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, act=nd.act,
-                                           slope=nd.slope)
+                                           slope=nd.slope, bias_grad=db)
                 else:
                     ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, act=nd.act, slope=nd.slope)
                 total = gsum if gsum is not None else g_pad
@@ -291,7 +293,7 @@ class NativeNet:
                 dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
                 a_t, g_t = (dy, s.acts[i]) if sp.kind == "conv" else (s.acts[i], dy)
                 ops.wgrad(lw.wgrad, a_t, g_t, dw)
-                if sp.bias:
+                if sp.bias and not nd.norm:
                     ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
                 self.grad_dirty = True
                 if final_pass:

@@ -98,9 +98,11 @@ int gs_inorm_act_forward(const void* y, const float* mean_rstd, const void* res,
  * (the data-gradient of a reflect/replicate-padded conv; fold=0 for a plain gradient) — the border is
  * folded back here (adjoint of ReflectionPad2d). g2 (optional, unpadded) is added (residual join).
  * Outputs dy (gradient w.r.t. the conv output y) and optionally gsum = fold(g_pad)+g2 (skip path).
- * If mean_rstd is NULL there is no norm: `y` then holds the activation OUTPUT and dy = g*act'(y). */
+ * If mean_rstd is NULL there is no norm: `y` then holds the activation OUTPUT and dy = g*act'(y).
+ * bias_grad (optional, norm only): db[c] += sum over pixels of dy — the gradient of the bias of the conv in front
+ * of the norm, obtained from the reduction sums (it is identically zero up to rounding, like the reference's). */
 int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
-                          void* dy, void* gsum, float* scratch, int32_t N, int32_t H, int32_t W,
+                          void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t H, int32_t W,
                           int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
                           void* stream);
 int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C);

@@ -139,7 +139,7 @@ class RefOps:
         x.copy_(v.to(x.dtype))
 
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
-                           slope=0.2):
+                           slope=0.2, bias_grad=None):
         N, H, W, Cc = y.shape
         g = _fold(g_pad.float(), H, W, fold, fold_mode)
         if g2 is not None:
@@ -155,7 +155,10 @@ class RefOps:
         gh = g * _act_grad_from_out(yh, act, slope)
         s1 = gh.mean((1, 2), keepdim=True)
         s2 = (gh * yh).mean((1, 2), keepdim=True)
-        dy.copy_((rstd * (gh - s1 - yh * s2)).to(dy.dtype))
+        d = rstd * (gh - s1 - yh * s2)
+        dy.copy_(d.to(dy.dtype))
+        if bias_grad is not None:      # sum over pixels of dy: identically zero up to rounding
+            bias_grad[:Cc] += d.sum((0, 1, 2))
 
     # ---- network boundary --------------------------------------------------------------------------------
     def image_to_act(self, img, act_t):

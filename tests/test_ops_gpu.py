@@ -183,7 +183,11 @@ def test_inorm_forward_backward(hip_ops, shape, act, res):
             ops.inorm_act_forward(yd, mr, r.to(dev) if res else None, x, act=act)
             dy = torch.empty_like(yd)
             gsum = torch.empty_like(yd) if res else None
-            ops.inorm_act_backward(gp.to(dev), g2.to(dev) if res else None, yd, mr, dy, gsum, fold=fold, act=act)
+            db = torch.zeros(C, dtype=torch.float32, device=dev)
+            ops.inorm_act_backward(gp.to(dev), g2.to(dev) if res else None, yd, mr, dy, gsum, fold=fold, act=act,
+                                   bias_grad=db)
+            # bias gradient in front of a norm is zero up to rounding: tiny next to the per-channel sum of |dy|
+            assert (db.cpu().abs() <= 1e-3 * dy.float().abs().sum((0, 1, 2)).cpu() + 1e-4).all()
             # no-norm variant: y holds the activation output
             dy2 = torch.empty_like(yd)
             ops.inorm_act_backward(gp.to(dev), None, x, None, dy2, None, fold=fold, act=act)
