@@ -26,6 +26,10 @@ struct GConvK {
   const char* zero;
   int tiles_m, tiles_n, ci_shift;
   float rcp_wc;
+  // taps factored into distinct row / column offsets (every lowering produces a product grid of taps)
+  int nh, nw;
+  signed char uh[16], uw[16];
+  unsigned char tap_h[GS_MAX_TAPS], tap_w[GS_MAX_TAPS];
   gs_gconv_desc d;
 };
 
@@ -63,23 +67,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
 
-  if (tid < d.T) taps[tid] = (short)(((int)d.dh[tid] & 0xff) | ((int)d.dw[tid] << 8));
+  if (tid < d.T) taps[tid] = (short)((int)p.tap_h[tid] | ((int)p.tap_w[tid] << 8));   // (row-table, column-table) index
 
   // ---- per-lane DMA bookkeeping -------------------------------------------------------------------
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;  // 16-B k-chunk fetched by this lane (swizzled source)
   const int HWc = d.Hc * d.Wc;
-  int xbh[NXI], xbw[NXI];
-  bool xv[NXI];
-#pragma unroll
-  for (int i = 0; i < NXI; ++i) {
-    const int row = (wave + NW * i) * 8 + lrow;
+  // Gather tables (built once per workgroup): tabh[h][row] = B(i*si+uh[h])*Wi and tabw[w][row] = B(j*si+uw[w]) for the
+  // distinct tap row/column offsets, GS_TAB_BAD for a masked row or a zero-padded tap. The K loop then needs two
+  // ds_reads + a multiply-add per DMA instruction instead of ~35 VALU of border / stride arithmetic (the loop was
+  // VALU-issue bound: 200 VALU per 32 MFMA).
+  constexpr unsigned GS_TAB_BAD = 0x8000u;
+  unsigned short* tabh = reinterpret_cast<unsigned short*>(smem + NSTAGE * STAGE + GS_MAX_TAPS * 2);
+  unsigned short* tabw = tabh + p.nh * BM;
+  for (int e = tid; e < BM * (p.nh + p.nw); e += NW * 64) {
+    const int k = e / BM, row = e - k * BM;
     const int m = mt * BM + row;
-    xv[i] = m < HWc;
+    bool ok = m < HWc;
     const int ii = div_small(m, d.Wc, p.rcp_wc);
     const int jj = m - ii * d.Wc;
-    xbh[i] = ii * d.si;
-    xbw[i] = jj * d.si;
+    unsigned v;
+    if (k < p.nh) v = (unsigned)border_index(ii * d.si + (int)p.uh[k], d.Hi, d.border, ok);
+    else v = (unsigned)border_index(jj * d.si + (int)p.uw[k - p.nh], d.Wi, d.border, ok);
+    tabh[e] = (unsigned short)(ok ? v : GS_TAB_BAD);
   }
   const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
   const char* wsrc[NWI];
@@ -118,15 +128,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int t = q >> p.ci_shift;
     const int c8 = q & cmask;
     const bool tv = t < d.T;
-    const short tp = taps[tv ? t : 0];
-    const int dh = (int)(signed char)(tp & 0xff);
-    const int dw = (int)tp >> 8;
+    const int tt = tv ? t : 0;
+    const int tp = taps[tt];
+    const unsigned short* hrow = tabh + (tp & 0xff) * BM + wave * 8 + lrow;
+    const unsigned short* wrow = tabw + (tp >> 8) * BM + wave * 8 + lrow;
+    const unsigned wi = (unsigned)d.Wi;
+    const unsigned cs2 = (unsigned)d.in_cs * 2u;
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      bool ok = tv && xv[i];
-      const int ih = border_index(xbh[i] + dh, d.Hi, d.border, ok);
-      const int iw = border_index(xbw[i] + dw, d.Wi, d.border, ok);
-      unsigned off = ((unsigned)(ih * d.Wi + iw) * (unsigned)d.in_cs + (unsigned)(c8 * 8)) * 2u;
+      const unsigned a = hrow[NW * 8 * i], bq = wrow[NW * 8 * i];
+      const bool ok = tv && !((a | bq) & GS_TAB_BAD);
+      unsigned off = (a * wi + bq) * cs2 + (unsigned)(c8 * 16);
       asm volatile("" : "+v"(off));  // keep the address math unconditional: select, don't branch
       const char* src = ok ? in_n + off : p.zero;
       glds16(src, sb + WT + (wave + NW * i) * 1024);
@@ -234,37 +246,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 
+  // The accumulators hold, per lane, 4 consecutive channels of one pixel. They are staged through a wave-private
+  // LDS slab [pixels of the wave][channels of the wave] so the global stores are 16 B per lane and a pixel's
+  // channel run is written as one contiguous line (the direct 8-B stores were store-issue bound).
+  constexpr int CW = BN / WN;                 // channels per wave
+  constexpr int PW = BM / WM;                 // pixels per wave
+  constexpr int SROW = CW * 2 + 16;           // padded slab row (bytes), keeps 16-B alignment
+  constexpr int RED_BYTES = WM * BN * 2 * 4;
+  char* slab = smem + ((RED_BYTES + 255) / 256) * 256 + wave * (PW * SROW);
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
-    const int m = mt * BM + wm * (BM / WM) + j * 16 + frow;
+    const int m = mt * BM + wm * PW + j * 16 + frow;
     const bool pv = m < HWc;
-    const int ii = div_small(m, d.Wc, p.rcp_wc);
-    const int jj = m - ii * d.Wc;
-    const size_t opix = ((size_t)n * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
-    char* orow = p.out + (opix * d.out_cs + d.out_co) * 2;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-      const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
-      if (co < d.Co) {
-        float v[4];
+      const int co = nt * BN + wn * CW + i * 16 + fk * 4;
+      float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][j][r] + (p.bias ? p.bias[co + r] : 0.f);
-          if (pv) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
-          v[r] = apply_act(v[r], d.act, d.slope);
-        }
-        if (pv) {
-          uint2 o;
-          o.x = pack_bf2(v[0], v[1]);
-          o.y = pack_bf2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(orow + co * 2) = o;
-        }
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + ((p.bias && co < d.Co) ? p.bias[co + r] : 0.f);
+        if (pv) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+        v[r] = apply_act(v[r], d.act, d.slope);
+      }
+      uint2 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(slab + (j * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int LPR = CW / 8;               // lanes per pixel row (16 B each)
+    constexpr int PPI = 64 / LPR;             // pixels per store instruction
+    const int sub = lane % LPR, prow = lane / LPR;
+    const int co = nt * BN + wn * CW + sub * 8;
+#pragma unroll
+    for (int it = 0; it < PW / PPI; ++it) {
+      const int pl = it * PPI + prow;
+      const int m = mt * BM + wm * PW + pl;
+      if (m < HWc && co < d.Co) {
+        const int ii = div_small(m, d.Wc, p.rcp_wc);
+        const int jj = m - ii * d.Wc;
+        const size_t opix = ((size_t)n * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+        const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
+        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
       }
     }
   }
 
   if (want_stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]; the stage buffers are dead after the loop
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2] in front of the store slabs
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -306,11 +337,12 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
 }
 template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
 int launch(const GConvK& k, int blocks, hipStream_t st) {
-  constexpr int lds = NSTAGE * (BM + BN) * 128 + GS_MAX_TAPS * 2;
+  const int lds = NSTAGE * (BM + BN) * 128 + GS_MAX_TAPS * 2 + BM * (k.nh + k.nw) * 2;
+  GS_REQUIRE(lds <= 160 * 1024, "gs_gconv_forward: gather tables do not fit in LDS (T=%d)", k.d.T);
   static bool configured = false;
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, NSTAGE, VARIANT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     configured = true;
   }
   hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, NSTAGE, VARIANT>), dim3(blocks), dim3(WM * WN * 64), lds, st, k);
@@ -329,9 +361,10 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   GS_REQUIRE((d->Co & 7) == 0 && d->Co > 0, "gs_gconv_forward: Co=%d must be a multiple of 8", d->Co);
   GS_REQUIRE(d->T >= 1 && d->T <= GS_MAX_TAPS, "gs_gconv_forward: T=%d out of range", d->T);
   GS_REQUIRE(d->Kp % 64 == 0 && d->Kp >= d->T * d->Ci, "gs_gconv_forward: bad Kp=%d", d->Kp);
-  GS_REQUIRE((d->in_cs & 7) == 0 && (d->in_co & 7) == 0 && (d->out_cs & 3) == 0 && (d->out_co & 3) == 0,
-             "gs_gconv_forward: channel strides/offsets must keep 16-B input / 8-B output alignment");
-  GS_REQUIRE((long long)d->Hc * d->Wc < (1 << 24), "gs_gconv_forward: class extent too large");
+  GS_REQUIRE((d->in_cs & 7) == 0 && (d->in_co & 7) == 0 && (d->out_cs & 7) == 0 && (d->out_co & 7) == 0,
+             "gs_gconv_forward: channel strides/offsets must be multiples of 8 (16-B accesses)");
+  GS_REQUIRE((long long)d->Hc * d->Wc < (1 << 24) && d->Hi < 32768 && d->Wi < 32768,
+             "gs_gconv_forward: class extent too large");
   GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward: stats requested without buffer");
   const TileCfg tc = pick_tile(d);
   GConvK k;
@@ -349,6 +382,16 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   k.ci_shift = sh;
   k.rcp_wc = 1.0f / (float)d->Wc;
   k.d = *d;
+  k.nh = k.nw = 0;
+  for (int t = 0; t < d->T; ++t) {
+    int h = 0, w = 0;
+    while (h < k.nh && k.uh[h] != d->dh[t]) ++h;
+    if (h == k.nh) { GS_REQUIRE(k.nh < 16, "gs_gconv_forward: more than 16 distinct tap rows"); k.uh[k.nh++] = d->dh[t]; }
+    while (w < k.nw && k.uw[w] != d->dw[t]) ++w;
+    if (w == k.nw) { GS_REQUIRE(k.nw < 16, "gs_gconv_forward: more than 16 distinct tap columns"); k.uw[k.nw++] = d->dw[t]; }
+    k.tap_h[t] = (unsigned char)h;
+    k.tap_w[t] = (unsigned char)w;
+  }
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
