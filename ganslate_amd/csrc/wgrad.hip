@@ -81,7 +81,18 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   const int g_dh = (int)(signed char)(tpv & 0xff), g_dw = (int)tpv >> 8;
   static_assert((GRI * NW) % 16 == 0, "row step must keep the swizzle invariant");
 
-  auto issue = [&](int ks, int buf) {
+  // pixel coordinates of this lane's gathered rows, advanced by BK pixels per K-step (no divisions in the loop)
+  int gn[NGI], gi[NGI], gj[NGI];
+#pragma unroll
+  for (int i = 0; i < NGI; ++i) {
+    const int m = k0 + g_row0 + i * GRI * NW;
+    gn[i] = div_small(m, HW, p.rcp_hw);
+    const int rem = m - gn[i] * HW;
+    gi[i] = div_small(rem, d.Wa, p.rcp_wa);
+    gj[i] = rem - gi[i] * d.Wa;
+  }
+
+  auto issue = [&](int ks, int buf) {      // always called with ks increasing by 1
     char* sb = smem + buf * STAGE;
     const int mb = k0 + ks * BK;
 #pragma unroll
@@ -99,10 +110,10 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
       const int R = g_row0 + i * GRI * NW;
       const int m = mb + R;
       bool ok = g_tv && m < k1;
-      const int nn = div_small(m, HW, p.rcp_hw);
-      const int rem = m - nn * HW;
-      const int ii = div_small(rem, d.Wa, p.rcp_wa);
-      const int jj = rem - ii * d.Wa;
+      const int nn = gn[i], ii = gi[i], jj = gj[i];
+      gj[i] += BK;
+      while (gj[i] >= d.Wa) { gj[i] -= d.Wa; ++gi[i]; }
+      while (gi[i] >= d.Ha) { gi[i] -= d.Ha; ++gn[i]; }
       const int ih = border_index(ii * d.si + g_dh, d.Hg, d.border, ok);
       const int iw = border_index(jj * d.si + g_dw, d.Wg, d.border, ok);
       unsigned off = (((unsigned)nn * g_img + (unsigned)(ih * d.Wg + iw)) * (unsigned)d.g_cs + (unsigned)(g_q8 * 8)) * 2u;
