@@ -276,6 +276,15 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
   }
 }
 
+// shared with norm_ex.hip
+int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, float inv_hw, const float* mean_rstd,
+                        float* db, hipStream_t st) {
+  hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
+                     mean_rstd, db);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static const int kBwdPixPerBlock = 64;
 
 extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C) {

@@ -27,6 +27,13 @@ class WGradDesc(C.Structure):
         ("dh", C.c_int8 * GS_MAX_TAPS), ("dw_", C.c_int8 * GS_MAX_TAPS)]
 
 
+class NormExDesc(C.Structure):
+    """Mirror of gs_norm_ex_desc."""
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "act1", "act2")] + [("slope", C.c_float)] + [
+        (n, C.c_int32) for n in ("x1_cs", "x1_co", "x2_cs", "x2_co", "g1_cs", "g1_co", "g2_cs", "g2_co")] + [
+        ("drop_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+
+
 _PROTOS = {
     "gs_init": (C.c_int, [C.c_int]),
     "gs_shutdown": (None, []),
@@ -44,6 +51,11 @@ _PROTOS = {
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "gs_inorm_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gs_norm_act_forward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "gs_norm_act_backward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_norm_backward_ex_scratch_floats": (C.c_int64, [C.POINTER(NormExDesc)]),
     "gs_image_to_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p]),
     "gs_act_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

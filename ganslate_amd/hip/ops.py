@@ -125,6 +125,37 @@ class HipOps:
                                                L.BORDER[fold_mode], L.ACT[act], slope, _stream()),
                 "gs_inorm_act_backward")
 
+    # ---- generalised norm / activation for skip-connection graphs (U-Net) ---------------------------------
+    def _norm_ex_desc(self, y, act1, act2, slope, drop_p, seed):
+        d = L.NormExDesc()
+        d.N, d.H, d.W, d.C = y.shape
+        d.act1, d.act2, d.slope = L.ACT[act1], L.ACT[act2], slope
+        d.drop_p, d.seed_lo, d.seed_hi = drop_p, seed & 0xffffffff, (seed >> 32) & 0xffffffff
+        return d
+
+    def norm_act_forward_ex(self, y, mean_rstd, x1, x2=None, act1="none", act2="none", slope=0.2, x1_co=0, x2_co=0,
+                            drop_p=0.0, seed=0):
+        d = self._norm_ex_desc(y, act1, act2, slope, drop_p, seed)
+        d.x1_cs, d.x1_co = x1.shape[-1], x1_co
+        if x2 is not None:
+            d.x2_cs, d.x2_co = x2.shape[-1], x2_co
+        L.check(self.lib.gs_norm_act_forward_ex(C.byref(d), _ptr(y), _ptr(mean_rstd), _ptr(x1), _ptr(x2), _stream()),
+                "gs_norm_act_forward_ex")
+
+    def norm_act_backward_ex(self, g1, g2, y, mean_rstd, dy, act1="none", act2="none", slope=0.2, g1_co=0, g2_co=0,
+                             drop_p=0.0, seed=0, bias_grad=None):
+        d = self._norm_ex_desc(y, act1, act2, slope, drop_p, seed)
+        d.g1_cs, d.g1_co = g1.shape[-1], g1_co
+        if g2 is not None:
+            d.g2_cs, d.g2_co = g2.shape[-1], g2_co
+        scratch = None
+        if mean_rstd is not None:
+            scratch = torch.empty(self.lib.gs_norm_backward_ex_scratch_floats(C.byref(d)), dtype=torch.float32,
+                                  device=y.device)
+        L.check(self.lib.gs_norm_act_backward_ex(C.byref(d), _ptr(g1), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(dy),
+                                                 _ptr(scratch), _ptr(bias_grad), _stream()),
+                "gs_norm_act_backward_ex")
+
     # ---- network boundary -----------------------------------------------------------------------------------
     def image_to_act(self, img, act_t):
         N, Cc, H, W = img.shape

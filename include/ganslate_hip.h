@@ -107,6 +107,28 @@ int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, cons
                           void* stream);
 int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C);
 
+/* Generalised form for skip-connection graphs (nn/generators/unet/unet2d.py:110-157): the normalised tensor is read
+ * through up to two activations (LeakyReLU by the next down-conv, ReLU by the up-conv on the skip half of
+ * torch.cat([x, y], 1)), outputs / gradient inputs are channel slices of wider concat buffers, and nn.Dropout(p) may sit
+ * between the norm and the consumer's activation (mask = counter-based hash of (seed, image, element)).
+ *   forward : v = drop(norm(y));  x1 = act1(v);  x2 = act2(v) (x2 optional)
+ *   backward: ghat = mask/(1-p) * (g1*act1'(yhat) + g2*act2'(yhat)) (g2 optional), dy as in gs_inorm_act_backward.
+ * mean_rstd == NULL: no norm, `y` holds a sign-preserving activation output. */
+typedef struct gs_norm_ex_desc {
+  int32_t N, H, W, C;
+  int32_t act1, act2;          /* GS_ACT_* */
+  float   slope;
+  int32_t x1_cs, x1_co, x2_cs, x2_co;      /* forward outputs: channel stride / offset (elements) */
+  int32_t g1_cs, g1_co, g2_cs, g2_co;      /* backward gradient inputs */
+  float   drop_p;              /* 0 = no dropout */
+  uint32_t seed_lo, seed_hi;
+} gs_norm_ex_desc;
+int gs_norm_act_forward_ex(const gs_norm_ex_desc* d, const void* y, const float* mean_rstd, void* x1, void* x2,
+                           void* stream);
+int gs_norm_act_backward_ex(const gs_norm_ex_desc* d, const void* g1, const void* g2, const void* y,
+                            const float* mean_rstd, void* dy, float* scratch, float* bias_grad, void* stream);
+int64_t gs_norm_backward_ex_scratch_floats(const gs_norm_ex_desc* d);
+
 /* ---- network boundary: NCHW fp32 images <-> NHWC bf16 activations ------------------------------- */
 /* x NCHW fp32 [N,C,H,W] -> act [N,H,W,Cp]  (set_input, cyclegan.py:84-90) */
 int gs_image_to_act(const float* img, void* act, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,

@@ -160,6 +160,62 @@ class RefOps:
         if bias_grad is not None:      # sum over pixels of dy: identically zero up to rounding
             bias_grad[:Cc] += d.sum((0, 1, 2))
 
+    # ---- generalised norm / activation for skip-connection graphs (U-Net) -------------------------------
+    @staticmethod
+    def _drop_scale(shape, drop_p, seed):
+        """same counter-based hash as ganslate_amd/csrc/norm_ex.hip (murmur3 finaliser), evaluated with int64"""
+        N, H, W, Cc = shape
+        if drop_p <= 0:
+            return torch.ones(shape)
+        M = 0xFFFFFFFF
+
+        def h32(x):
+            x = x & M
+            x = x ^ (x >> 16); x = (x * 0x85EBCA6B) & M
+            x = x ^ (x >> 13); x = (x * 0xC2B2AE35) & M
+            return x ^ (x >> 16)
+
+        idx = torch.arange(H * W * Cc, dtype=torch.int64).view(1, H, W, Cc)
+        n = torch.arange(1, N + 1, dtype=torch.int64).view(N, 1, 1, 1)
+        inner = h32(((seed & M) + 0x9E3779B9 * n) & M)
+        h = h32(idx ^ inner ^ ((seed >> 32) & M))
+        u = (h >> 8).float() * (1.0 / 16777216.0)
+        return torch.where(u >= drop_p, torch.full(shape, 1.0 / (1.0 - drop_p)), torch.zeros(shape))
+
+    def norm_act_forward_ex(self, y, mean_rstd, x1, x2=None, act1="none", act2="none", slope=0.2, x1_co=0, x2_co=0,
+                            drop_p=0.0, seed=0):
+        N, H, W, Cc = y.shape
+        v = y.float()
+        if mean_rstd is not None:
+            mr = mean_rstd.view(N, 2, Cc)
+            v = (v - mr[:, 0][:, None, None, :]) * mr[:, 1][:, None, None, :]
+        v = v * self._drop_scale(y.shape, drop_p, seed)
+        x1[..., x1_co:x1_co + Cc] = _act(v, act1, slope).to(x1.dtype)
+        if x2 is not None:
+            x2[..., x2_co:x2_co + Cc] = _act(v, act2, slope).to(x2.dtype)
+
+    def norm_act_backward_ex(self, g1, g2, y, mean_rstd, dy, act1="none", act2="none", slope=0.2, g1_co=0, g2_co=0,
+                             drop_p=0.0, seed=0, bias_grad=None):
+        N, H, W, Cc = y.shape
+        yh = y.float()
+        if mean_rstd is not None:
+            mr = mean_rstd.view(N, 2, Cc)
+            rstd = mr[:, 1][:, None, None, :]
+            yh = (yh - mr[:, 0][:, None, None, :]) * rstd
+        gh = g1[..., g1_co:g1_co + Cc].float() * _act_grad_from_out(yh, act1, slope)
+        if g2 is not None:
+            gh = gh + g2[..., g2_co:g2_co + Cc].float() * _act_grad_from_out(yh, act2, slope)
+        gh = gh * self._drop_scale(y.shape, drop_p, seed)
+        if mean_rstd is None:
+            dy.copy_(gh.to(dy.dtype))
+            return
+        s1 = gh.mean((1, 2), keepdim=True)
+        s2 = (gh * yh).mean((1, 2), keepdim=True)
+        d = rstd * (gh - s1 - yh * s2)
+        dy.copy_(d.to(dy.dtype))
+        if bias_grad is not None:
+            bias_grad[:Cc] += d.sum((0, 1, 2))
+
     # ---- network boundary --------------------------------------------------------------------------------
     def image_to_act(self, img, act_t):
         N, Cc, H, W = img.shape

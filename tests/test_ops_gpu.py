@@ -284,3 +284,42 @@ def test_adam_and_repack(hip_ops):
     close_f32(outs[1][2], outs[0][2], "v", rel=1e-6)
     assert outs[1][3].abs().max().item() == 0.0
     assert torch.equal(outs[1][4].cpu(), outs[0][4]), "repack must be bit-exact"
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (1, 16, 16, 256), (2, 5, 7, 8)])
+@pytest.mark.parametrize("norm", [True, False])
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_norm_ex_dual_activation_slices_dropout(hip_ops, shape, norm, drop_p):
+    """U-Net form: two activations of one normalised tensor into channel slices of concat buffers, dropout mask
+    regenerated in the backward pass, two gradient inputs with their own activation derivative."""
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(21)
+    y = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    g1 = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)               # from the next down-conv (LeakyReLU)
+    g2buf = torch.randn(N, H, W, 2 * C + 8, generator=g).to(torch.bfloat16)    # gradient of the concat buffer (ReLU)
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        yd = y.to(dev)
+        mr = None
+        if norm:
+            part = torch.zeros(N * 2 * C, dtype=torch.float32, device=dev)
+            pv = part.view(N, 1, 2, C)
+            pv[:, 0, 0] = yd.float().sum((1, 2)); pv[:, 0, 1] = (yd.float() ** 2).sum((1, 2))
+            mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+            ops.inorm_finalize(part, N, 1, C, H * W, mr)
+        x1 = torch.zeros(N, H, W, C, dtype=torch.bfloat16, device=dev)
+        cat = torch.full((N, H, W, 2 * C + 8), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.norm_act_forward_ex(yd, mr, x1, cat, act1="lrelu", act2="relu", x2_co=8, drop_p=drop_p, seed=99)
+        dy = torch.empty_like(yd)
+        db = torch.zeros(C, dtype=torch.float32, device=dev)
+        src = yd if norm else x1          # without a norm the stored tensor is the (sign-preserving) LeakyReLU output
+        ops.norm_act_backward_ex(g1.to(dev), g2buf.to(dev), src, mr, dy, act1="lrelu", act2="relu", g2_co=C,
+                                 drop_p=drop_p, seed=99, bias_grad=db if norm else None)
+        outs.append((x1, cat, dy))
+    assert torch.equal(outs[1][1].cpu()[..., :8], outs[0][1][..., :8]) and (outs[0][1][..., :8] == 7).all()
+    close_bf16(outs[1][0], outs[0][0], "x1 (lrelu)")
+    close_bf16(outs[1][1], outs[0][1], "x2 slice (relu)")
+    close_bf16(outs[1][2], outs[0][2], "dy")
+    if drop_p > 0:
+        kept = (outs[1][0].float().cpu() != 0).float().mean().item()
+        assert 0.4 < kept < 0.6, kept
