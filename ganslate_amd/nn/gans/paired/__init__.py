@@ -1,0 +1,1 @@
+from .pix2pix import Pix2PixConditionalGAN, Pix2PixConditionalGANConfig  # noqa: F401

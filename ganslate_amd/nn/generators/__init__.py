@@ -1,1 +1,2 @@
 from .resnet.resnet2d import Resnet2D, Resnet2DConfig  # noqa: F401
+from .unet.unet2d import Unet2D, Unet2DConfig  # noqa: F401

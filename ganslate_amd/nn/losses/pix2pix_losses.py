@@ -1,0 +1,11 @@
+"""lambda_pix2pix * L1(fake_B, real_B) on the fused L1 kernel (ganslate/nn/losses/pix2pix_losses.py:8-19)."""
+from .functional import l1_loss
+
+
+class Pix2PixLoss:
+
+    def __init__(self, conf):
+        self.lambda_pix2pix = conf.train.gan.optimizer.lambda_pix2pix
+
+    def __call__(self, fake_B, real_B):
+        return self.lambda_pix2pix * l1_loss(fake_B, real_B)

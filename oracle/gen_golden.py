@@ -22,7 +22,8 @@ sys.path.insert(2, str(ROOT))
 from omegaconf import DictConfig  # noqa: E402  (the stand-in)
 import ganslate.configs.base  # noqa: E402,F401
 from ganslate.nn.gans.unpaired.cyclegan import CycleGAN  # noqa: E402
-from ganslate.nn.generators import Resnet2D  # noqa: E402
+from ganslate.nn.generators import Resnet2D, Unet2D  # noqa: E402
+from ganslate.nn.gans.paired.pix2pix import Pix2PixConditionalGAN  # noqa: E402
 from ganslate.nn.discriminators import PatchGAN2D  # noqa: E402
 
 from oracle.torch_ref import seeded_state_dict  # noqa: E402
@@ -38,6 +39,65 @@ CASES = {
     "cfg1_256": dict(size=256, batch=1, steps=2, n_iters=100, n_iters_decay=100, pool_size=50,
                      lambda_identity=0.0, proportion_ssim=0.0, seed=13),
 }
+
+
+PIX2PIX_CASES = {
+    # cityscapes pix2pix yaml hyper-parameters (projects/cityscapes_label2photo/experiments/pix2pix.yaml:25-48:
+    # PatchGAN n_layers 4 on 6 channels, lambda 30, lr_D 1e-4) with a narrow U-Net and no dropout -> deterministic
+    "p2p_64x128": dict(size=[64, 128], batch=2, steps=6, n_iters=4, n_iters_decay=4, num_downs=5, ngf=16,
+                       use_dropout=False, n_layers=4, lambda_pix2pix=30.0, seed=31),
+    # cfg3 network shape (num_downs 7, 256x512) at reduced width, batch 1
+    "p2p_cfg3_shape": dict(size=[256, 512], batch=1, steps=2, n_iters=100, n_iters_decay=100, num_downs=7, ngf=16,
+                           use_dropout=False, n_layers=4, lambda_pix2pix=30.0, seed=32),
+}
+
+
+def make_pix2pix_conf(c):
+    return DictConfig({
+        "mode": "train",
+        "train": {
+            "output_dir": "/tmp/ganslate_ref_out", "cuda": False, "mixed_precision": False, "opt_level": "O1",
+            "batch_size": c["batch"], "n_iters": c["n_iters"], "n_iters_decay": c["n_iters_decay"],
+            "checkpointing": {"load_iter": None, "freq": 10 ** 9, "start_after": 0, "load_optimizers": True},
+            "metrics": {"discriminator_evolution": True, "ssim": False},
+            "gan": {
+                "_target_": "ganslate.nn.gans.paired.Pix2PixConditionalGAN", "norm_type": "instance",
+                "weight_init_type": "normal", "weight_init_gain": 0.02,
+                "generator": {"_target_": "ganslate.nn.generators.Unet2D", "num_downs": c["num_downs"],
+                              "ngf": c["ngf"], "use_dropout": c["use_dropout"],
+                              "in_out_channels": {"AB": [3, 3], "BA": [3, 3]}},
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN2D", "ndf": 64,
+                                  "n_layers": c["n_layers"], "kernel_size": [4, 4], "in_channels": {"B": 6, "A": 6}},
+                "optimizer": {"adversarial_loss_type": "lsgan", "beta1": 0.5, "beta2": 0.999, "lr_D": 0.0001,
+                              "lr_G": 0.0002, "lambda_pix2pix": c["lambda_pix2pix"]},
+            },
+        },
+    })
+
+
+def p2p_inputs(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 3, *c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+def run_pix2pix_case(name, c):
+    torch.manual_seed(c["seed"])
+    model = Pix2PixConditionalGAN(make_pix2pix_conf(c))
+    for k, (n, net) in enumerate(model.networks.items()):
+        net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+    rec = []
+    for s in range(c["steps"]):
+        A, B = p2p_inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        rec.append({"lrs": {k: float(v) for k, v in lrs.items()},
+                    "losses": {k: float(v) for k, v in losses.items() if v is not None},
+                    "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
+        model.update_learning_rate()
+        print(name, s, rec[-1]["losses"], flush=True)
+    return {"config": c, "steps": rec}
 
 
 def make_conf(c):
@@ -124,7 +184,13 @@ def main():
         "patchgan2d_64": net_case("patchgan2d_64", PatchGAN2D(3, 64, 3, 4, "instance"), (2, 3, 64, 64), 23),
         "patchgan2d_6ch_4layers": net_case("p", PatchGAN2D(6, 64, 4, 4, "instance"), (1, 6, 96, 128), 24),
     }
+    nets["unet2d_5downs"] = net_case("u5", Unet2D(3, 3, 5, "instance", ngf=16), (2, 3, 32, 64), 25)
+    nets["unet2d_7downs"] = net_case("u7", Unet2D(3, 3, 7, "instance", ngf=8), (1, 3, 128, 256), 26)
     (out / "nets.json").write_text(json.dumps(nets, indent=1))
+    p2p = {name: run_pix2pix_case(name, c) for name, c in PIX2PIX_CASES.items()}
+    (out / "pix2pix_steps.json").write_text(json.dumps(p2p, indent=1))
+    if "--only-new" in sys.argv:
+        return
     steps = {name: run_case(name, c) for name, c in CASES.items()}
     (out / "cyclegan_steps.json").write_text(json.dumps(steps, indent=1))
 

@@ -74,6 +74,47 @@ class PatchGAN2D(nn.Module):
         return self.model(x)
 
 
+class _UnetBlock(nn.Module):
+    """ganslate/nn/generators/unet/unet2d.py:80-157 restated"""
+
+    def __init__(self, outer, inner, in_ch=None, sub=None, outermost=False, innermost=False, dropout=False):
+        super().__init__()
+        self.outermost = outermost
+        in_ch = outer if in_ch is None else in_ch
+        down = nn.Conv2d(in_ch, inner, 4, 2, 1)
+        if outermost:
+            mods = [down, sub, nn.ReLU(), nn.ConvTranspose2d(inner * 2, outer, 4, 2, 1), nn.Tanh()]
+        elif innermost:
+            mods = [nn.LeakyReLU(0.2), down, nn.ReLU(), nn.ConvTranspose2d(inner, outer, 4, 2, 1),
+                    nn.InstanceNorm2d(outer)]
+        else:
+            mods = [nn.LeakyReLU(0.2), down, nn.InstanceNorm2d(inner), sub, nn.ReLU(),
+                    nn.ConvTranspose2d(inner * 2, outer, 4, 2, 1), nn.InstanceNorm2d(outer)]
+            if dropout:
+                mods.append(nn.Dropout(0.5))
+        self.model = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.model(x) if self.outermost else torch.cat([x, self.model(x)], 1)
+
+
+class Unet2D(nn.Module):
+    """ganslate/nn/generators/unet/unet2d.py:17-76 restated"""
+
+    def __init__(self, in_channels, out_channels, num_downs=7, ngf=64, use_dropout=False):
+        super().__init__()
+        blk = _UnetBlock(ngf * 8, ngf * 8, innermost=True)
+        for _ in range(num_downs - 5):
+            blk = _UnetBlock(ngf * 8, ngf * 8, sub=blk, dropout=use_dropout)
+        blk = _UnetBlock(ngf * 4, ngf * 8, sub=blk)
+        blk = _UnetBlock(ngf * 2, ngf * 4, sub=blk)
+        blk = _UnetBlock(ngf, ngf * 2, sub=blk)
+        self.model = _UnetBlock(out_channels, ngf, in_ch=in_channels, sub=blk, outermost=True)
+
+    def forward(self, x):
+        return self.model(x)
+
+
 def seeded_state_dict(module: nn.Module, seed: int, gain=0.02, bias_gain=0.01):
     """Deterministic weights independent of module construction order / torch's default init RNG use:
     every tensor of the state_dict (in key order, aliases share one draw) ~ N(0, gain) (biases N(0, bias_gain))
@@ -205,6 +246,51 @@ class CycleGANStep:
     def update_learning_rate(self):
         for s in self.sched:
             s.step()
+
+    def lrs(self):
+        return {"lr_G": self.opt_G.param_groups[0]["lr"], "lr_D": self.opt_D.param_groups[0]["lr"]}
+
+
+class Pix2PixStep:
+    """fp32 restatement of Pix2PixConditionalGAN.optimize_parameters (ganslate/nn/gans/paired/pix2pix.py:76-152):
+    G then D; D sees cat([real_A, fake_B], 1); loss_G = LSGAN(D(A, G(A)), 1) + lambda * L1(G(A), B)."""
+
+    def __init__(self, num_downs=7, ngf=64, use_dropout=False, n_layers=3, lr_G=2e-4, lr_D=1e-4, beta1=0.5,
+                 beta2=0.999, lambda_pix2pix=100.0, adv="lsgan", n_iters=100, n_iters_decay=100, seed=0):
+        self.nets = OrderedDict(G=Unet2D(3, 3, num_downs, ngf, use_dropout), D=PatchGAN2D(6, 64, n_layers))
+        for k, (name, net) in enumerate(self.nets.items()):
+            net.load_state_dict(seeded_state_dict(net, seed + k))
+        self.lam, self.adv = lambda_pix2pix, adv
+        self.opt_G = torch.optim.Adam(self.nets["G"].parameters(), lr=lr_G, betas=(beta1, beta2))
+        self.opt_D = torch.optim.Adam(self.nets["D"].parameters(), lr=lr_D, betas=(beta1, beta2))
+        rule = lambda it: 1.0 - max(0, it + 1 - n_iters) / float(n_iters_decay + 1)
+        self.sched = [torch.optim.lr_scheduler.LambdaLR(o, rule) for o in (self.opt_G, self.opt_D)]
+
+    def step(self, real_A, real_B):
+        G, Dn = self.nets["G"], self.nets["D"]
+        losses, metrics = {}, {}
+        fake_B = G(real_A)
+        for p in Dn.parameters():
+            p.requires_grad = False
+        self.opt_G.zero_grad(set_to_none=True)
+        losses["G"] = adversarial_loss(Dn(torch.cat([real_A, fake_B], 1)), True, self.adv)
+        losses["pix2pix"] = self.lam * (fake_B - real_B).abs().mean()
+        (losses["G"] + losses["pix2pix"]).backward()
+        self.opt_G.step()
+        for p in Dn.parameters():
+            p.requires_grad = True
+        self.opt_D.zero_grad(set_to_none=True)
+        pred_real = Dn(torch.cat([real_A, real_B], 1))
+        pred_fake = Dn(torch.cat([real_A, fake_B.detach()], 1))
+        losses["D"] = adversarial_loss(pred_real, True, self.adv) + adversarial_loss(pred_fake, False, self.adv)
+        losses["D"].backward()
+        metrics["D_real"], metrics["D_fake"] = pred_real.detach().mean(), pred_fake.detach().mean()
+        self.opt_D.step()
+        return {k: float(v.detach()) for k, v in losses.items()}, {k: float(v) for k, v in metrics.items()}
+
+    def update_learning_rate(self):
+        for s_ in self.sched:
+            s_.step()
 
     def lrs(self):
         return {"lr_G": self.opt_G.param_groups[0]["lr"], "lr_D": self.opt_D.param_groups[0]["lr"]}

