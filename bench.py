@@ -25,6 +25,30 @@ GFLOP_PER_IMAGE = 1289.9
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def make_pix2pix_conf(batch, n_iters):
+    """BASELINE configs[2]: cityscapes_label2photo pix2pix.yaml:25-48 — Unet2D(num_downs 7, ngf 128, dropout) +
+    PatchGAN2D(n_layers 4, 6 ch), 256x512 (a parity-test workload, measured with --workload pix2pix)"""
+    from ganslate_amd.configs.config import Config
+    from ganslate_amd.configs.omegalite import OmegaConf
+    from ganslate_amd.configs.utils import init_config
+    y = OmegaConf.create({
+        "train": {
+            "output_dir": "/tmp/ganslate_amd_bench", "cuda": True, "batch_size": batch,
+            "n_iters": n_iters, "n_iters_decay": n_iters,
+            "dataset": {"_target_": "ganslate.data.SyntheticImageDataset", "final_size": [256, 512]},
+            "gan": {
+                "_target_": "ganslate.nn.gans.paired.Pix2PixConditionalGAN",
+                "generator": {"_target_": "ganslate.nn.generators.Unet2D", "num_downs": 7, "ngf": 128,
+                              "use_dropout": True, "in_out_channels": {"AB": [3, 3]}},
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN2D", "n_layers": 4,
+                                  "in_channels": {"B": 6}},
+                "optimizer": {"lr_D": 0.0001, "lr_G": 0.0002, "lambda_pix2pix": 30.0},
+            },
+            "metrics": {"discriminator_evolution": True},
+        }})
+    return init_config(y, Config)
+
+
 def make_conf(batch, size, n_iters):
     from ganslate_amd.configs.config import Config
     from ganslate_amd.configs.omegalite import OmegaConf
@@ -78,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix"],
+                    help="cyclegan = the headline (BASELINE configs[1]); pix2pix = configs[2] (batch 1, 256x512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -97,10 +123,17 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
 
     torch.manual_seed(0)
-    model = build_gan(make_conf(args.batch, args.size, 10 ** 6))
     g = torch.Generator().manual_seed(1234 + rank)
-    batch = {"A": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
-             "B": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev)}
+    if args.workload == "pix2pix":
+        args.no_cpu_baseline = args.no_kernel_timing = True
+        if args.batch == 8:
+            args.batch = 1
+        model = build_gan(make_pix2pix_conf(args.batch, 10 ** 6))
+        shape = (args.batch, 3, 256, 512)
+    else:
+        model = build_gan(make_conf(args.batch, args.size, 10 ** 6))
+        shape = (args.batch, 3, args.size, args.size)
+    batch = {"A": (torch.rand(shape, generator=g) * 2 - 1).to(dev), "B": (torch.rand(shape, generator=g) * 2 - 1).to(dev)}
 
     def step():
         model.set_input(batch)
@@ -110,7 +143,7 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    ops = model.networks["G_AB"].ops
+    ops = next(iter(model.networks.values())).ops
     timing = None
     if not args.no_kernel_timing:
         # HIP events around every launch of the dominant kernel (residual-block 3x3 conv, forward form) on the
@@ -138,7 +171,16 @@ def main():
     losses = {k: float(v) for k, v in model.losses.items() if v is not None}
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), f"non-finite losses: {losses}"
 
-    if rank == 0:
+    if rank == 0 and args.workload == "pix2pix":
+        value = args.batch * world * args.steps / dt
+        print(json.dumps({"metric": "training images/sec, Pix2Pix U-Net(7,128)+PatchGAN-4 256x512 bf16",
+                          "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "synthetic", "config": {"workload": "cityscapes pix2pix (BASELINE configs[2])",
+                                                          "global_batch": args.batch * world},
+                          "step_tflops": round(value * 371.5 / 1e3, 1)}), flush=True)
+    elif rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
         out = {
