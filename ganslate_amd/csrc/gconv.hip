@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     // 3-stage ring, DMA two K-steps ahead; one raw barrier per K-step; counted vmcnt keeps the younger stage in
     // flight across the barrier (a __syncthreads() here would drain it: LDS-DMA counts as a pending LDS write)
     int cur = 0, nxt2 = 2;
-    const int nk_run = VARIANT == 6 ? (nk < 2 ? nk : 2) : nk;   // ablation 6: prologue + epilogue only
+    const int nk_run = (VARIANT == 6 || VARIANT == 8) ? (nk < 2 ? nk : 2) : nk;   // ablations 6/8: no main loop
     for (int ks = 0; ks < nk_run; ++ks) {
       if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         if (ks + 2 < nk) issue(ks + 2, nxt2);
       } else if constexpr (VARIANT == 4) {       // ablation: LDS reads + MFMA only
         compute(cur);
-      } else if constexpr (VARIANT == 6) {
+      } else if constexpr (VARIANT == 6 || VARIANT == 8) {
         compute(cur);
       } else {                                   // VARIANT 2: priority on the MFMA cluster
         if (ks + 2 < nk) issue(ks + 2, nxt2);
@@ -238,8 +238,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     __syncthreads();
   }
 
+  if constexpr (VARIANT == 8) { if (acc[0][0][0] == 12345.678f) p.out[0] = 1; return; }
   // ---- epilogue: bias, InstanceNorm partial statistics, activation, bf16 NHWC store -----------------
-  const bool want_stats = d.stats_slots > 0;
+  const bool want_stats = d.stats_slots > 0 && VARIANT != 10;
   float s1[TI][4], s2[TI][4];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         const int jj = m - ii * d.Wc;
         const size_t opix = ((size_t)n * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
         const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
-        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
+        if (VARIANT != 9 || val.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
       }
     }
   }
@@ -332,7 +333,13 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
   if (d->Co <= 64) return {128, 64};
   // big tile (8 waves, 3 stages, 1 workgroup per CU) once it still fills the chip; else the 4-wave 128x128 tile
   const long long big = (long long)d->N * (((long long)d->Hc * d->Wc + 255) / 256) * ((d->Co + 127) / 128);
-  if (big >= 192) return {256, 128};
+  if (big >= 192) {
+    // one workgroup per CU is resident: if the 256-pixel tiling needs a second, mostly empty round of workgroups
+    // but 320-pixel tiles fit in one round, the larger tile wins (e.g. the 66x66 padded-domain data gradients)
+    const long long big320 = (long long)d->N * (((long long)d->Hc * d->Wc + 319) / 320) * ((d->Co + 127) / 128);
+    if (big > 256 && big <= 512 && big320 <= 256) return {320, 128};
+    return {256, 128};
+  }
   return {128, 128};
 }
 template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
@@ -397,6 +404,7 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tc.bn == 16) return launch<256, 16, 4, 1, 2>(k, (int)blocks, st);
   if (tc.bn == 64) return launch<128, 64, 2, 2, 2>(k, (int)blocks, st);
+  if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, (int)blocks, st);
   if (tc.bm == 256) {
     static const int variant = getenv("GS_GCONV_VARIANT") ? atoi(getenv("GS_GCONV_VARIANT")) : 0;
     if (variant == 1) return launch<256, 128, 4, 2, 3, 1>(k, (int)blocks, st);
@@ -405,7 +413,15 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
     if (variant == 4) return launch<256, 128, 4, 2, 3, 4>(k, (int)blocks, st);
     if (variant == 6) return launch<256, 128, 4, 2, 3, 6>(k, (int)blocks, st);
     if (variant == 7) return launch<256, 128, 4, 2, 3, 7>(k, (int)blocks, st);
-    return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);
+    if (variant == 8) return launch<256, 128, 4, 2, 3, 8>(k, (int)blocks, st);
+    if (variant == 9) return launch<256, 128, 4, 2, 3, 9>(k, (int)blocks, st);
+    if (variant == 13) return launch<256, 128, 8, 2, 3, 0>(k, (int)blocks, st);   // 16 waves
+    if (variant == 14) return launch<256, 128, 4, 4, 3, 0>(k, (int)blocks, st);   // 16 waves
+    if (variant == 11) return launch<256, 128, 2, 2, 3, 0>(k, (int)blocks, st);   // 4 waves, 128x64 per wave
+    if (variant == 12) return launch<256, 128, 4, 1, 3, 0>(k, (int)blocks, st);   // 4 waves, 64 px x 128 co per wave
+    if (variant == 10) return launch<256, 128, 4, 2, 3, 10>(k, (int)blocks, st);
+    if (variant == 15) return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);       // 8 waves
+    return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);                            // 16 waves: best measured
   }
   return launch<128, 128, 2, 2, 2>(k, (int)blocks, st);
 }

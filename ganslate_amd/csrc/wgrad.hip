@@ -11,6 +11,7 @@
 // ds_read_b64_tr_b16 from [64 pixels][128 channels] tiles staged by LDS-DMA. The pixel range of every image
 // is split over workgroups (split-K); partial tiles are accumulated with fp32 atomics.
 #include "common.hpp"
+#include <cstdlib>
 
 struct WGradK {
   const char* a;
@@ -266,7 +267,9 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (d->P <= 16) return launch_wgrad<16, 256, 1, 8>(k, d, st);      // Cout 1/3 layers: skinny P
   if (d->P <= 64) return launch_wgrad<64, 256, 1, 8>(k, d, st);
-  return launch_wgrad<128, 256, 2, 4>(k, d, st);
+  static const int variant = getenv("GS_WGRAD_VARIANT") ? atoi(getenv("GS_WGRAD_VARIANT")) : 0;
+  if (variant == 1) return launch_wgrad<128, 256, 2, 4>(k, d, st);   // 8 waves
+  return launch_wgrad<128, 256, 4, 4>(k, d, st);                      // 16 waves: best measured
 }
 
 // ---- bias gradient: db[c] += sum_pixels dy[pix][c] ---------------------------------------------------
