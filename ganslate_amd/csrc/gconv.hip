@@ -402,8 +402,10 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (tc.bn == 16) return launch<256, 16, 4, 1, 2>(k, (int)blocks, st);
-  if (tc.bn == 64) return launch<128, 64, 2, 2, 2>(k, (int)blocks, st);
+  // wave counts per tile picked by measurement (tools/bench_kernels.py): more waves hide the LDS-DMA issue latency
+  if (tc.bn == 16) return launch<256, 16, 8, 1, 2>(k, (int)blocks, st);
+  if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, (int)blocks, st);
+  if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
   if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, (int)blocks, st);
   if (tc.bm == 256) {
     static const int variant = getenv("GS_GCONV_VARIANT") ? atoi(getenv("GS_GCONV_VARIANT")) : 0;
@@ -423,5 +425,5 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
     if (variant == 15) return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);       // 8 waves
     return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);                            // 16 waves: best measured
   }
-  return launch<128, 128, 2, 2, 2>(k, (int)blocks, st);
+  return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
 }
