@@ -27,7 +27,7 @@ struct WGradK {
 // over all 16 slots
 __device__ __forceinline__ int wg_swz(int R) { return ((R & 3) << 1) | (((R >> 3) & 1) << 3); }
 
-template <int BP, int BQ, int WP, int WQ>
+template <int BP, int BQ, int WP, int WQ, int VARIANT = 0>
 __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   constexpr int NW = WP * WQ, BK = 64, NSTAGE = 3;
   constexpr int ARB = BP * 2, GRB = BQ * 2;                  // row bytes of the two LDS tiles
@@ -131,11 +131,29 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int wp = wave / WQ, wq = wave % WQ;
-  const int nk = (k1 - k0 + BK - 1) / BK;
+  const int nk = VARIANT == 3 ? 2 : (k1 - k0 + BK - 1) / BK;
   // transpose-read geometry: lane supplies the address of 4 consecutive channels of one pixel row
   const int fk = lane >> 4;            // 8-pixel block inside a 32-deep MFMA step
   const int frr = (lane & 15) >> 2;    // pixel row inside a 4-row block
   const int fcc = lane & 3;            // 4-channel group inside the 16-channel tile
+
+  // per-lane LDS byte offsets of the transpose reads, hoisted out of the K loop: the swizzle term of row
+  // R = kk*32 + fk*8 + h*4 + frr only depends on (frr, fk&1), so (kk, h) enter as compile-time row offsets
+  int aoff[TI], goff[TJ];
+  {
+    const int sw = wg_swz(fk * 8 + frr);
+    const int sub = (fcc & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int ch = (wp * (BP / WP) / 8) + i * 2 + (fcc >> 1);
+      aoff[i] = (fk * 8 + frr) * ARB + sub + ((ch ^ (sw & ASW)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int ch = (wq * (BQ / WQ) / 8) + j * 2 + (fcc >> 1);
+      goff[j] = (fk * 8 + frr) * GRB + sub + ((ch ^ sw) << 4);
+    }
+  }
 
   issue(0, 0);
   if (nk > 1) issue(1, 1);
@@ -150,32 +168,25 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     const char* gb = ab + AT;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[TI], gf[TJ];
+      uint2 ah[TI][2], gh[TJ][2];   // two 64-bit transpose reads = one 8-element MFMA fragment
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int R = kk * 32 + fk * 8 + h * 4 + frr;
-        const int sw = wg_swz(R);
-        const int sub = (fcc & 1) * 8;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          const int ch = (wp * (BP / WP) / 8) + i * 2 + (fcc >> 1);
-          s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)GS_LDS(ab + R * ARB + sub + ((ch ^ (sw & ASW)) << 4)));
-          af[i][h * 4 + 0] = v[0]; af[i][h * 4 + 1] = v[1]; af[i][h * 4 + 2] = v[2]; af[i][h * 4 + 3] = v[3];
-        }
+        for (int i = 0; i < TI; ++i)
+          ah[i][h] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(ab + aoff[i] + (kk * 32 + h * 4) * ARB)));
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const int ch = (wq * (BQ / WQ) / 8) + j * 2 + (fcc >> 1);
-          s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)GS_LDS(gb + R * GRB + sub + ((ch ^ sw) << 4)));
-          gf[j][h * 4 + 0] = v[0]; gf[j][h * 4 + 1] = v[1]; gf[j][h * 4 + 2] = v[2]; gf[j][h * 4 + 3] = v[3];
-        }
+        for (int j = 0; j < TJ; ++j)
+          gh[j][h] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(gb + goff[j] + (kk * 32 + h * 4) * GRB)));
       }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, uint4{ah[i][0].x, ah[i][0].y, ah[i][1].x, ah[i][1].y}),
+              __builtin_bit_cast(bf16x8, uint4{gh[j][0].x, gh[j][0].y, gh[j][1].x, gh[j][1].y}), acc[i][j], 0, 0, 0);
     }
     cur = cur == 2 ? 0 : cur + 1;
     nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int col = tq * BQ + wq * (BQ / WQ) + j * 16 + frow;
-          if (col < TQ) unsafeAtomicAdd(row + col, acc[i][j][r]);
+          if (col < TQ && (VARIANT != 2 || acc[i][j][r] == 1234.5f)) unsafeAtomicAdd(row + col, acc[i][j][r]);
         }
       }
     }
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
 }
 
 namespace {
-template <int BP, int BQ, int WP, int WQ>
+template <int BP, int BQ, int WP, int WQ, int VARIANT = 0>
 int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   k.tiles_p = (d->P + BP - 1) / BP;
   k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
@@ -235,11 +246,11 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 2 + 1024;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ, VARIANT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
+  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ, VARIANT>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -269,6 +280,8 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
   if (d->P <= 64) return launch_wgrad<64, 256, 1, 8>(k, d, st);
   static const int variant = getenv("GS_WGRAD_VARIANT") ? atoi(getenv("GS_WGRAD_VARIANT")) : 0;
   if (variant == 1) return launch_wgrad<128, 256, 2, 4>(k, d, st);   // 8 waves
+  if (variant == 2) return launch_wgrad<128, 256, 4, 4, 2>(k, d, st);   // ablation: no atomics
+  if (variant == 3) return launch_wgrad<128, 256, 4, 4, 3>(k, d, st);   // ablation: 2 K-steps only
   return launch_wgrad<128, 256, 4, 4>(k, d, st);                      // 16 waves: best measured
 }
 
