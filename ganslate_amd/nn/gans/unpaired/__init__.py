@@ -1,1 +1,2 @@
+from .cut import CUT, CUTConfig  # noqa: F401
 from .cyclegan import CycleGAN, CycleGANConfig  # noqa: F401

@@ -45,4 +45,51 @@ class Resnet2D(NativeNet):
         nodes.append(Node(ConvSpec("conv", feats, out_channels, 7, 1, 3, pad_mode="reflect", bias=use_bias), False,
                           "none", name=f"model.{17 + n}"))
         self.encoder_nodes = 3 + 2 * n              # nodes that make up the reference's `encoder`
+        self.n_residual_blocks = n
         super().__init__(nodes, in_channels, out_channels, out_act="tanh")
+
+    # ---- feature taps for CUT (ganslate/nn/gans/unpaired/cut.py:297-312 walks `self.encoder` module by module) ----
+    def encoder_len(self):
+        return 10 + self.n_residual_blocks
+
+    def encoder_tap(self, e):
+        """encoder module index -> ("pad", None) | ("y", node) | ("x", node), channels.
+        The reference appends the module OUTPUT; outputs of InstanceNorm modules are later overwritten in place by the
+        following nn.ReLU(inplace=True), so taps on 2/5/8 observe the activated tensor (same as 3/6/9)."""
+        assert 0 <= e < self.encoder_len(), f"encoder has {self.encoder_len()} layers"
+        if e == 0:
+            return ("pad", None), self.in_channels
+        if e < 10:
+            node, sub = (e - 1) // 3, (e - 1) % 3
+            return (("y" if sub == 0 else "x"), node), self.nodes[node].spec.cout
+        node = 3 + 2 * (e - 10) + 1
+        return ("x", node), self.nodes[node].spec.cout
+
+    def extract_patch_features(self, x, layers, ids):
+        """features of `layers` sampled at pixel ids (one LongTensor per layer) -> list of [N, P, C] fp32"""
+        import torch.nn.functional as F
+        taps, where = [], []
+        for e in layers:
+            tap, _ = self.encoder_tap(e)
+            where.append(tap)
+            if tap[0] != "pad":
+                taps.append(tap)
+        native = iter(self.forward_taps(x, taps, [i for i, t in zip(ids, where) if t[0] != "pad"])) if taps else iter(())
+        out = []
+        for tap, pid in zip(where, ids):
+            if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output: plain indexing of the boundary image
+                xp = F.pad(x.float(), (3, 3, 3, 3), mode="reflect")
+                out.append(xp.permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :])
+            else:
+                out.append(next(native))
+        return out
+
+    def tap_extent(self, e, H, W):
+        """number of pixels of encoder layer e for an H x W input"""
+        if e == 0:
+            return (H + 6) * (W + 6)
+        if e < 4:
+            return H * W
+        if e < 7:
+            return (H // 2) * (W // 2)
+        return (H // 4) * (W // 4)

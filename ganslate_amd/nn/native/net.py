@@ -66,7 +66,7 @@ class NativeNet:
         self._dist = None
         self._fw_pending = 0
         self._reduce_handles = []
-        self._reduced = False
+        self._reduced_buckets = set()
         self.grad_dirty = False
 
     # ---- torch.nn.Module-like surface used by BaseGAN ----------------------------------------------------------
@@ -207,7 +207,14 @@ class NativeNet:
             return out
         return _NetFn.apply(x, self._token, self)
 
-    def _forward(self, x, save):
+    def forward_taps(self, x, taps, ids):
+        """sampled features of intermediate nodes: taps = [("x"|"y", node)], ids = [LongTensor[P]] (pixel indices);
+        returns a tuple of [N, P, C] fp32 tensors that autograd can differentiate into the network"""
+        x = x.contiguous().float()
+        return _TapFn.apply(x, self._token, self, tuple(taps), tuple(ids))
+
+    def _forward(self, x, save, stop=None):
+        """stop = index of the last node to run (encoder-only passes of CUT, cut.py:297-312); None = whole net"""
         ops, dev = self.ops, self.device
         N, _, H, W = x.shape
         lows = self._lowered(H, W)
@@ -217,6 +224,8 @@ class NativeNet:
         ops.image_to_act(x, a)
         acts, ys, mrs = [a], [], []
         for i, (nd, lw) in enumerate(zip(self.nodes, lows)):
+            if stop is not None and i > stop:
+                break
             sp = nd.spec
             bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
             fpack = pk["fpack"][pk["f_off"][i]:]
@@ -243,9 +252,11 @@ class NativeNet:
                     ops.gconv(g, acts[-1], fpack, bias, y, act=nd.act, slope=nd.slope)
                 ys.append(None); mrs.append(None)
                 acts.append(y)
-        lw = lows[-1]
-        out = torch.empty(N, self.out_channels, lw.Ho, lw.Wo, dtype=torch.float32, device=dev)
-        ops.act_to_image(acts[-1], out, act=self.out_act)
+        out = None
+        if stop is None:
+            lw = lows[-1]
+            out = torch.empty(N, self.out_channels, lw.Ho, lw.Wo, dtype=torch.float32, device=dev)
+            ops.act_to_image(acts[-1], out, act=self.out_act)
         if not save:
             return out, None
         s = _Saved()
@@ -253,7 +264,11 @@ class NativeNet:
         return out, s
 
     # ---- backward ---------------------------------------------------------------------------------------------------------
-    def _backward(self, s: _Saved, g_img, need_input_grad: bool, want_w: bool):
+    def _backward(self, s: _Saved, g_img, need_input_grad: bool, want_w: bool, start=None, inj_x=None, inj_y=None):
+        """g_img = gradient of the output image, or None for a partial pass that starts at node `start` and is driven
+        only by injected gradients: inj_x[i] / inj_y[i] = dense gradients w.r.t. the output / raw conv output of
+        node i (feature taps of CUT's PatchNCE loss)."""
+        inj_x, inj_y = inj_x or {}, inj_y or {}
         ops, dev = self.ops, self.device
         nodes, lows, N = self.nodes, s.lows, s.N
         if self.master.grad is None:
@@ -261,14 +276,22 @@ class NativeNet:
         H, W = s.x_img.shape[2], s.x_img.shape[3]
         pk = self._get_packs(H, W)
         grad = self.master.grad
-        last = len(nodes) - 1
-        ga = torch.empty_like(s.acts[-1])
-        ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
-        pending = (ga, 0, None)       # gradient w.r.t. the output of node i: (tensor on padded domain, fold, extra)
+        last = len(nodes) - 1 if start is None else start
+        pending = None                # gradient w.r.t. the output of node i: (tensor on padded domain, fold, extra)
+        if g_img is not None:
+            ga = torch.empty_like(s.acts[-1])
+            ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
+            pending = (ga, 0, None)
         skip: Dict[int, torch.Tensor] = {}
         final_pass = want_w and self._dist is not None and self._fw_pending == 0
         for i in range(last, -1, -1):
             nd, lw, sp = nodes[i], lows[i], nodes[i].spec
+            if i in inj_x:            # tapped feature gradient joins the gradient of this node's output
+                if pending is None:
+                    pending = (inj_x[i], 0, None)
+                else:
+                    f0 = pending[1]
+                    pending[0][:, f0:f0 + lw.Ho, f0:f0 + lw.Wo, :] += inj_x[i]   # the pad adjoint is linear
             g_pad, fold, g2 = pending
             x_out = s.acts[i + 1]
             # ---- gradient w.r.t. the conv output y ---------------------------------------------------------------
@@ -288,6 +311,8 @@ class NativeNet:
                 dy, total = g_pad, g_pad
             if need_total:
                 skip[nd.res] = total
+            if i in inj_y:
+                dy = dy + inj_y[i]
             # ---- parameter gradients ---------------------------------------------------------------------------------
             if want_w:
                 dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
@@ -306,7 +331,8 @@ class NativeNet:
                 for g in lw.dgrad:
                     ops.gconv(g, dy, dpack, None, gx)
                 pending = (gx, f, skip.pop(i - 1, None))
-            s.acts[i + 1] = None  # release as we go
+            if start is None:
+                s.acts[i + 1] = None  # release as we go
         if not need_input_grad:
             return None
         gx, f, _ = pending
@@ -341,24 +367,69 @@ class NativeNet:
         s, e = rng
         h = dist.all_reduce(self.master.grad[s:e], op=dist.ReduceOp.SUM, group=self._dist, async_op=True)
         self._reduce_handles.append(h)
-        if i == 0:
-            self._reduced = True
+        self._reduced_buckets.add(i)
 
     def finish_grad_reduction(self) -> float:
         """Called by the optimiser before the update. Returns the factor the summed gradient must be scaled by."""
         if self._dist is None:
             return 1.0
         import torch.distributed as dist
-        if not self._reduced and self.grad_dirty:
-            # backward passes did not line up with forward passes (custom recipe): reduce the whole buffer now
-            self._reduce_handles.append(
-                dist.all_reduce(self.master.grad, op=dist.ReduceOp.SUM, group=self._dist, async_op=True))
+        if self.grad_dirty:
+            # buckets the last backward pass did not reach (partial encoder passes, custom recipes) go now
+            for i, s, e in self._buckets:
+                if i not in self._reduced_buckets:
+                    self._reduce_handles.append(dist.all_reduce(self.master.grad[s:e], op=dist.ReduceOp.SUM,
+                                                                group=self._dist, async_op=True))
         for h in self._reduce_handles:
             h.wait()          # stream-level wait on GPU backends; no host sync
         self._reduce_handles = []
-        self._reduced = False
+        self._reduced_buckets = set()
         self._fw_pending = 0
         return 1.0 / dist.get_world_size(self._dist)
+
+
+class _TapFn(torch.autograd.Function):
+    """Encoder-only pass returning sampled feature patches [N, P, C] (fp32) of several nodes as one autograd node:
+    forward gathers rows of the NHWC activations (a patch is one pixel's channel vector), backward scatters the patch
+    gradients back and runs the partial backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, token, net, taps, ids):
+        stop = max(node for _, node in taps)
+        _, saved = net._forward(x.detach(), save=True, stop=stop)
+        ctx.net, ctx.saved, ctx.taps, ctx.ids, ctx.stop = net, saved, taps, ids, stop
+        ctx.need_x = ctx.needs_input_grad[0]
+        ctx.want_w = net.requires_grad
+        if ctx.want_w:
+            net._fw_pending += 1
+        outs = []
+        N = x.shape[0]
+        for (kind, node), pid in zip(taps, ids):
+            src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
+            c = net.nodes[node].spec.cout
+            outs.append(src.view(N, -1, src.shape[-1])[:, pid, :c].float())
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        net, s = ctx.net, ctx.saved
+        if ctx.want_w:
+            net._fw_pending -= 1
+        inj = {"x": {}, "y": {}}
+        N = s.N
+        for (kind, node), pid, g in zip(ctx.taps, ctx.ids, grads):
+            if g is None:
+                continue
+            src = s.ys[node] if kind == "y" else s.acts[node + 1]
+            dense = inj[kind].get(node)
+            if dense is None:
+                dense = torch.zeros_like(src)
+                inj[kind][node] = dense
+            c = net.nodes[node].spec.cout
+            dense.view(N, -1, src.shape[-1])[:, pid, :c] += g.to(dense.dtype)
+        gx = net._backward(s, None, ctx.need_x, ctx.want_w, start=ctx.stop, inj_x=inj["x"], inj_y=inj["y"])
+        ctx.saved = None
+        return gx, None, None, None, None
 
 
 class _NetFn(torch.autograd.Function):

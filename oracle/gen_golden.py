@@ -24,6 +24,7 @@ import ganslate.configs.base  # noqa: E402,F401
 from ganslate.nn.gans.unpaired.cyclegan import CycleGAN  # noqa: E402
 from ganslate.nn.generators import Resnet2D, Unet2D  # noqa: E402
 from ganslate.nn.gans.paired.pix2pix import Pix2PixConditionalGAN  # noqa: E402
+from ganslate.nn.gans.unpaired.cut import CUT  # noqa: E402
 from ganslate.nn.discriminators import PatchGAN2D  # noqa: E402
 
 from oracle.torch_ref import seeded_state_dict  # noqa: E402
@@ -95,6 +96,46 @@ def run_pix2pix_case(name, c):
         rec.append({"lrs": {k: float(v) for k, v in lrs.items()},
                     "losses": {k: float(v) for k, v in losses.items() if v is not None},
                     "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
+        model.update_learning_rate()
+        print(name, s, rec[-1]["losses"], flush=True)
+    return {"config": c, "steps": rec}
+
+
+CUT_CASES = {
+    # CUT defaults (cut.py:16-40): nce_layers (0,4,8,12,16), 256 patches, T 0.07, lambda_nce_idt 0.5; horse2zebra lrs
+    "cut_64": dict(size=64, batch=2, steps=4, n_iters=100, n_iters_decay=100, num_patches=256, seed=41),
+}
+
+
+def make_cut_conf(c):
+    conf = make_conf(dict(c, pool_size=0, lambda_identity=0.0, proportion_ssim=0.0))
+    gan = conf.train.gan
+    gan["_target_"] = "ganslate.nn.gans.unpaired.CUT"
+    gan["nce_layers"] = [0, 4, 8, 12, 16]
+    gan["mlp_nc"] = 256
+    gan["num_patches"] = c["num_patches"]
+    gan["use_equivariance_flip"] = False
+    gan.generator["in_channels"] = 3      # the key cut.py:83 reads; absent from the v1 schema
+    gan["optimizer"] = DictConfig({"adversarial_loss_type": "lsgan", "beta1": 0.5, "beta2": 0.999, "lr_D": 0.0002,
+                                   "lr_G": 0.0002, "lambda_adv": 1, "lambda_nce": 1, "lambda_nce_idt": 0.5,
+                                   "nce_T": 0.07})
+    return conf
+
+
+def run_cut_case(name, c):
+    torch.manual_seed(c["seed"])
+    model = CUT(make_cut_conf(c))
+    for k, (n, net) in enumerate(model.networks.items()):
+        net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+    rec = []
+    for s in range(c["steps"]):
+        A, B = inputs(c, s)
+        torch.manual_seed(1000 + s)          # pins the torch.randperm patch ids of this step
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        rec.append({"lrs": {k: float(v) for k, v in lrs.items()},
+                    "losses": {k: float(v) for k, v in losses.items() if v is not None}})
         model.update_learning_rate()
         print(name, s, rec[-1]["losses"], flush=True)
     return {"config": c, "steps": rec}
@@ -189,6 +230,8 @@ def main():
     (out / "nets.json").write_text(json.dumps(nets, indent=1))
     p2p = {name: run_pix2pix_case(name, c) for name, c in PIX2PIX_CASES.items()}
     (out / "pix2pix_steps.json").write_text(json.dumps(p2p, indent=1))
+    cut = {name: run_cut_case(name, c) for name, c in CUT_CASES.items()}
+    (out / "cut_steps.json").write_text(json.dumps(cut, indent=1))
     if "--only-new" in sys.argv:
         return
     steps = {name: run_case(name, c) for name, c in CASES.items()}

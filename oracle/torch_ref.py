@@ -294,3 +294,114 @@ class Pix2PixStep:
 
     def lrs(self):
         return {"lr_G": self.opt_G.param_groups[0]["lr"], "lr_D": self.opt_D.param_groups[0]["lr"]}
+
+
+class _PatchMLP(nn.Module):
+    """FeaturePatchMLP restated (ganslate/nn/gans/unpaired/cut.py:229-294): same module names (mlps.N.0 / mlps.N.2)"""
+
+    def __init__(self, channels, num_patches=256, nc=256):
+        super().__init__()
+        self.num_patches = num_patches
+        self.mlps = nn.ModuleList(nn.Sequential(nn.Linear(c, nc), nn.ReLU(), nn.Linear(nc, nc)) for c in channels)
+
+    def forward(self, feats, patch_ids=None):
+        out, ids = [], []
+        for i, feat in enumerate(feats):
+            feat = feat.permute(0, 2, 3, 1).flatten(1, 2)
+            if patch_ids is not None:
+                pid = patch_ids[i]
+            else:
+                pid = torch.randperm(feat.shape[1], device=feat.device)
+                pid = pid[:int(min(self.num_patches, len(pid)))]
+            f = self.mlps[i](feat[:, pid, :].flatten(0, 1))
+            f = f.div(f.pow(2).sum(1, keepdim=True).pow(0.5) + 1e-7)
+            out.append(f)
+            ids.append(pid)
+        return out, ids
+
+
+def patch_nce(feat_q, feat_k, batch, T=0.07):
+    """PatchNCELoss.forward restated (ganslate/nn/losses/cut_losses.py:14-43)"""
+    dim = feat_q.shape[1]
+    feat_k = feat_k.detach()
+    l_pos = torch.bmm(feat_q.view(-1, 1, dim), feat_k.view(-1, dim, 1)).view(-1, 1)
+    q, k = feat_q.view(batch, -1, dim), feat_k.view(batch, -1, dim)
+    n = q.size(1)
+    l_neg = torch.bmm(q, k.transpose(2, 1))
+    l_neg.masked_fill_(torch.eye(n, dtype=torch.bool)[None], -10.0)
+    out = torch.cat((l_pos, l_neg.view(-1, n)), 1) / T
+    return nn.functional.cross_entropy(out, torch.zeros(out.size(0), dtype=torch.long), reduction="none")
+
+
+class CUTStep:
+    """fp32 restatement of CUT.optimize_parameters (ganslate/nn/gans/unpaired/cut.py:113-226): D first, then G + mlp;
+    NCE over encoder features of layers (0, 4, 8, 12, 16) with 256 random patches per level; identity NCE weighted
+    by lambda_nce_idt."""
+
+    def __init__(self, batch, n_blocks=9, nce_layers=(0, 4, 8, 12, 16), num_patches=256, mlp_nc=256, lr=2e-4,
+                 beta1=0.5, beta2=0.999, lambda_adv=1.0, lambda_nce=1.0, lambda_nce_idt=0.5, nce_T=0.07,
+                 n_iters=100, n_iters_decay=100, seed=0):
+        self.G, self.D = Resnet2D(3, 3, n_blocks), PatchGAN2D(3, 64, 3)
+        self.layers, self.batch, self.T = list(nce_layers), batch, nce_T
+        with torch.no_grad():
+            f, ch = torch.zeros(1, 3, 64, 64), []
+            for i, layer in enumerate(self.G.encoder):
+                f = layer(f)
+                if i in self.layers:
+                    ch.append(f.shape[1])
+        self.mlp = _PatchMLP(ch, num_patches, mlp_nc)
+        self.nets = OrderedDict(G=self.G, D=self.D, mlp=self.mlp)
+        for k, (name, net) in enumerate(self.nets.items()):
+            net.load_state_dict(seeded_state_dict(net, seed + k))
+        self.lam = (lambda_adv, lambda_nce, lambda_nce_idt)
+        self.opts = OrderedDict(G=torch.optim.Adam(self.G.parameters(), lr=lr, betas=(beta1, beta2)),
+                                D=torch.optim.Adam(self.D.parameters(), lr=lr, betas=(beta1, beta2)),
+                                mlp=torch.optim.Adam(self.mlp.parameters(), lr=lr, betas=(beta1, beta2)))
+        rule = lambda it: 1.0 - max(0, it + 1 - n_iters) / float(n_iters_decay + 1)
+        self.sched = [torch.optim.lr_scheduler.LambdaLR(o, rule) for o in self.opts.values()]
+
+    def _features(self, x):
+        feats, f = [], x
+        for i, layer in enumerate(self.G.encoder):
+            f = layer(f)
+            if i in self.layers:
+                feats.append(f)
+        return feats
+
+    def _nce(self, source, target):
+        sp, ids = self.mlp(self._features(source))
+        tp, _ = self.mlp(self._features(target), ids)
+        loss = 0
+        for t, s_ in zip(tp, sp):
+            loss = loss + (patch_nce(t, s_, self.batch, self.T) * self.lam[1]).mean()
+        return loss / len(self.layers)
+
+    def step(self, real_A, real_B):
+        lam_adv, lam_nce, lam_idt = self.lam
+        losses = {}
+        fake_B = self.G(real_A)
+        idt_B = self.G(real_B) if lam_idt > 0 else None
+        for p in self.D.parameters():
+            p.requires_grad = True
+        self.opts["D"].zero_grad(set_to_none=True)
+        losses["D"] = adversarial_loss(self.D(real_B), True) + adversarial_loss(self.D(fake_B.detach()), False)
+        losses["D"].backward()
+        self.opts["D"].step()
+        for p in self.D.parameters():
+            p.requires_grad = False
+        self.opts["G"].zero_grad(set_to_none=True)
+        self.opts["mlp"].zero_grad(set_to_none=True)
+        losses["G"] = adversarial_loss(self.D(fake_B), True) * lam_adv
+        nce = self._nce(real_A, fake_B)
+        losses["NCE"] = nce
+        if lam_idt > 0:
+            losses["NCE_idt"] = lam_idt * self._nce(real_B, idt_B)
+            nce = (1 - lam_idt) * nce + losses["NCE_idt"]
+        (losses["G"] + nce).backward()
+        self.opts["G"].step()
+        self.opts["mlp"].step()
+        return {k: float(v.detach()) for k, v in losses.items()}
+
+    def update_learning_rate(self):
+        for s_ in self.sched:
+            s_.step()

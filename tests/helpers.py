@@ -95,3 +95,49 @@ def run_product_pix2pix_steps(model, c, n_steps):
                     "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
         model.update_learning_rate()
     return out
+
+
+# ---- CUT -------------------------------------------------------------------------------------------------------------
+CUT_CONF = Path(__file__).parent / "configs" / "cut_synthetic.yaml"
+
+
+def load_golden_cut():
+    return json.loads((GOLD / "cut_steps.json").read_text())
+
+
+def build_product_cut(c, extra=()):
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle import torch_ref
+    conf = build_conf([f"config={CUT_CONF}", f"train.batch_size={c['batch']}", f"train.n_iters={c['n_iters']}",
+                       f"train.n_iters_decay={c['n_iters_decay']}", f"train.gan.num_patches={c['num_patches']}",
+                       *extra])
+    torch.manual_seed(c["seed"])
+    model = build_gan(conf)
+    ref = torch_ref.CUTStep(c["batch"], num_patches=c["num_patches"], seed=c["seed"])
+    for k, name in enumerate(["G", "D", "mlp"]):
+        model.networks[name].load_state_dict(torch_ref.seeded_state_dict(ref.nets[name], c["seed"] + k))
+    # patch ids drawn on the CPU generator (as the reference does on CPU), whatever the device
+    G = model.networks["G"]
+
+    def sample(H, W):
+        ids = []
+        for e in model.nce_layers:
+            pid = torch.randperm(G.tap_extent(e, H, W))
+            ids.append(pid[:int(min(model.num_patches, len(pid)))].to(model.device))
+        return ids
+
+    model.sample_patch_ids = sample
+    return model
+
+
+def run_product_cut_steps(model, c, n_steps):
+    out = []
+    for s in range(n_steps):
+        A, B = golden_inputs(c, s)
+        torch.manual_seed(1000 + s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        out.append({"lrs": dict(lrs), "losses": {k: float(v.detach()) for k, v in losses.items() if v is not None}})
+        model.update_learning_rate()
+    return out

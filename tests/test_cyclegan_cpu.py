@@ -57,3 +57,19 @@ def test_pix2pix_product_step_matches_reference_golden_fp32(fp32_oracle_backend)
         if s == 0:
             for k, v in g["metrics"].items():
                 assert got[s]["metrics"][k] == pytest.approx(v, rel=1e-4, abs=1e-5), (s, k)
+
+
+def test_cut_product_step_matches_reference_golden_fp32(fp32_oracle_backend):
+    """CUT recipe: encoder-only partial passes with feature taps gathered from / scattered into the executor's NHWC
+    activations, MLP + PatchNCE, D-then-G order — against the real reference's golden losses."""
+    from .helpers import build_product_cut, load_golden_cut, run_product_cut_steps
+    gold = load_golden_cut()["cut_64"]
+    c = gold["config"]
+    got = run_product_cut_steps(build_product_cut(c), c, 2)
+    for s in range(2):
+        g = gold["steps"][s]
+        assert got[s]["lrs"] == pytest.approx(g["lrs"], abs=1e-12)
+        assert set(got[s]["losses"]) == set(g["losses"])
+        for k, v in g["losses"].items():
+            tol = 2e-4 if s == 0 else (0.02 if k.startswith("NCE") else 0.10)
+            assert got[s]["losses"][k] == pytest.approx(v, rel=tol), (s, k, got[s]["losses"][k], v)

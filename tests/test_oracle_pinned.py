@@ -96,3 +96,19 @@ def test_pix2pix_step_restatement_matches_reference(name):
         for k, v in g["metrics"].items():
             assert abs(metrics[k] - v) <= 2e-4 * abs(v) + 1e-5, (s, k, metrics[k], v)
         model.update_learning_rate()
+
+
+def test_cut_step_restatement_matches_reference():
+    from oracle.torch_ref import CUTStep
+    from .helpers import load_golden_cut
+    gold = load_golden_cut()["cut_64"]
+    c = gold["config"]
+    model = CUTStep(c["batch"], num_patches=c["num_patches"], n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"],
+                    seed=c["seed"])
+    for s in range(c["steps"]):
+        A, B = golden_inputs(c, s)
+        torch.manual_seed(1000 + s)
+        losses = model.step(A, B)
+        for k, v in gold["steps"][s]["losses"].items():
+            assert abs(losses[k] - v) <= 3e-4 * abs(v) + 1e-6, (s, k, losses[k], v)
+        model.update_learning_rate()
