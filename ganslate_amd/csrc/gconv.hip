@@ -1,12 +1,15 @@
 // Generalised convolution as an implicit GEMM on the gfx950 matrix cores.
 //
-//   out[n, i*so+py, j*so+px, co] = act(bias[co] + sum_t sum_ci in[n, B(i*si+dh[t]), B(j*si+dw[t]), ci] * w[co][t*Ci+ci])
+//   out[n, z*so+pz, i*so+py, j*so+px, co] =
+//       act(bias[co] + sum_t sum_ci in[n, B(z*si+dd[t]), B(i*si+dh[t]), B(j*si+dw[t]), ci] * w[co][t*Ci+ci])
 //
-// One kernel covers Conv2d forward (any stride), the data-gradient of stride-1 convs, and — one launch per
-// output parity class — ConvTranspose2d(stride 2) forward and the data-gradient of stride-2 convs.
+// One kernel covers Conv2d/Conv3d forward (any stride), the data-gradient of stride-1 convs, and — one launch per
+// output parity class — ConvTranspose2d/3d(stride 2) forward and the data-gradient of stride-2 convs.
 // Replaces the cuDNN/MIOpen calls behind nn.Conv2d / nn.ConvTranspose2d in
 // ganslate/nn/generators/resnet/resnet2d.py:25,35,52-57,65,80-87 and
-// ganslate/nn/discriminators/patchgan/patchgan2d.py:29,36-62 (forward) and their autograd backward.
+// ganslate/nn/discriminators/patchgan/patchgan2d.py:29,36-62 (forward) and their autograd backward, and their
+// 3-D twins (resnet3d.py:25-64,78-84, patchgan3d.py:28-60). A 2-D tensor is a volume of depth 1: the (depth, row)
+// pair is one "row" of the gather tables, so the K loop is the same for both.
 //
 // GEMM view: D[co][pixel] = W[co][k] * X[pixel][k]^T, k = (tap, ci). Weights are the MFMA A operand so each
 // lane ends up with 4 consecutive output channels of one pixel (8-byte NHWC stores).
@@ -25,10 +28,10 @@ struct GConvK {
   float* stats;
   const char* zero;
   int tiles_m, tiles_n, ci_shift;
-  float rcp_wc;
-  // taps factored into distinct row / column offsets (every lowering produces a product grid of taps)
+  float rcp_wc, rcp_hc;
+  // taps factored into distinct (depth, row) / column offsets (every lowering produces a product grid of taps)
   int nh, nw;
-  signed char uh[16], uw[16];
+  signed char ud[64], uh[64], uw[16];
   unsigned char tap_h[GS_MAX_TAPS], tap_w[GS_MAX_TAPS];
   gs_gconv_desc d;
 };
@@ -67,14 +70,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
 
-  if (tid < d.T) taps[tid] = (short)((int)p.tap_h[tid] | ((int)p.tap_w[tid] << 8));   // (row-table, column-table) index
+  for (int t = tid; t < d.T; t += NW * 64)
+    taps[t] = (short)((int)p.tap_h[t] | ((int)p.tap_w[t] << 8));   // (row-table, column-table) index
 
   // ---- per-lane DMA bookkeeping -------------------------------------------------------------------
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;  // 16-B k-chunk fetched by this lane (swizzled source)
-  const int HWc = d.Hc * d.Wc;
-  // Gather tables (built once per workgroup): tabh[h][row] = B(i*si+uh[h])*Wi and tabw[w][row] = B(j*si+uw[w]) for the
-  // distinct tap row/column offsets, GS_TAB_BAD for a masked row or a zero-padded tap. The K loop then needs two
+  const int HWc = d.Dc * d.Hc * d.Wc;
+  // Gather tables (built once per workgroup): tabh[h][row] = B(z*si+ud[h])*Hi + B(i*si+uh[h]) and
+  // tabw[w][row] = B(j*si+uw[w]) for the distinct tap (depth,row) / column offsets, GS_TAB_BAD for a masked row or a zero-padded tap. The K loop then needs two
   // ds_reads + a multiply-add per DMA instruction instead of ~35 VALU of border / stride arithmetic (the loop was
   // VALU-issue bound: 200 VALU per 32 MFMA).
   constexpr unsigned GS_TAB_BAD = 0x8000u;
@@ -84,14 +88,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int k = e / BM, row = e - k * BM;
     const int m = mt * BM + row;
     bool ok = m < HWc;
-    const int ii = div_small(m, d.Wc, p.rcp_wc);
-    const int jj = m - ii * d.Wc;
+    const int zi = div_small(m, d.Wc, p.rcp_wc);
+    const int jj = m - zi * d.Wc;
+    const int zz = div_small(zi, d.Hc, p.rcp_hc);
+    const int ii = zi - zz * d.Hc;
     unsigned v;
-    if (k < p.nh) v = (unsigned)border_index(ii * d.si + (int)p.uh[k], d.Hi, d.border, ok);
-    else v = (unsigned)border_index(jj * d.si + (int)p.uw[k - p.nh], d.Wi, d.border, ok);
+    if (k < p.nh) {
+      const int iz = border_index(zz * d.si + (int)p.ud[k], d.Di, d.border, ok);
+      v = (unsigned)(iz * d.Hi + border_index(ii * d.si + (int)p.uh[k], d.Hi, d.border, ok));
+    } else {
+      v = (unsigned)border_index(jj * d.si + (int)p.uw[k - p.nh], d.Wi, d.border, ok);
+    }
     tabh[e] = (unsigned short)(ok ? v : GS_TAB_BAD);
   }
-  const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+  const char* in_n = p.in + ((size_t)n * d.Di * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
   const char* wsrc[NWI];
   int winc[NWI];  // 128 B per K-step for a real weight row, 0 for a masked row (stays on the zero page)
 #pragma unroll
@@ -286,9 +296,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       const int pl = it * PPI + prow;
       const int m = mt * BM + wm * PW + pl;
       if (m < HWc && co < d.Co) {
-        const int ii = div_small(m, d.Wc, p.rcp_wc);
-        const int jj = m - ii * d.Wc;
-        const size_t opix = ((size_t)n * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+        const int zi = div_small(m, d.Wc, p.rcp_wc);
+        const int jj = m - zi * d.Wc;
+        const int zz = div_small(zi, d.Hc, p.rcp_hc);
+        const int ii = zi - zz * d.Hc;
+        const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
         const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
         if (VARIANT != 9 || val.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
       }
@@ -332,11 +344,12 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
   if (d->Co <= 16) return {256, 16};
   if (d->Co <= 64) return {128, 64};
   // big tile (8 waves, 3 stages, 1 workgroup per CU) once it still fills the chip; else the 4-wave 128x128 tile
-  const long long big = (long long)d->N * (((long long)d->Hc * d->Wc + 255) / 256) * ((d->Co + 127) / 128);
+  const long long pix = (long long)d->Dc * d->Hc * d->Wc;
+  const long long big = (long long)d->N * ((pix + 255) / 256) * ((d->Co + 127) / 128);
   if (big >= 192) {
     // one workgroup per CU is resident: if the 256-pixel tiling needs a second, mostly empty round of workgroups
     // but 320-pixel tiles fit in one round, the larger tile wins (e.g. the 66x66 padded-domain data gradients)
-    const long long big320 = (long long)d->N * (((long long)d->Hc * d->Wc + 319) / 320) * ((d->Co + 127) / 128);
+    const long long big320 = (long long)d->N * ((pix + 319) / 320) * ((d->Co + 127) / 128);
     if (big > 256 && big <= 512 && big320 <= 256) return {320, 128};
     return {256, 128};
   }
@@ -370,7 +383,9 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   GS_REQUIRE(d->Kp % 64 == 0 && d->Kp >= d->T * d->Ci, "gs_gconv_forward: bad Kp=%d", d->Kp);
   GS_REQUIRE((d->in_cs & 7) == 0 && (d->in_co & 7) == 0 && (d->out_cs & 7) == 0 && (d->out_co & 7) == 0,
              "gs_gconv_forward: channel strides/offsets must be multiples of 8 (16-B accesses)");
-  GS_REQUIRE((long long)d->Hc * d->Wc < (1 << 24) && d->Hi < 32768 && d->Wi < 32768,
+  GS_REQUIRE(d->Di >= 1 && d->Do >= 1 && d->Dc >= 1, "gs_gconv_forward: depths must be >= 1 (1 for 2-D tensors)");
+  GS_REQUIRE((long long)d->Dc * d->Hc * d->Wc < (1 << 24) && (long long)d->Di * d->Hi < 32768 && d->Wi < 32768 &&
+                 (long long)d->Di * d->Hi * d->Wi * d->in_cs * 2 < (1LL << 32),
              "gs_gconv_forward: class extent too large");
   GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward: stats requested without buffer");
   const TileCfg tc = pick_tile(d);
@@ -382,18 +397,23 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   k.stats = stats;
   k.zero = static_cast<const char*>(gs_zero_page());
   GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
-  k.tiles_m = (d->Hc * d->Wc + tc.bm - 1) / tc.bm;
+  k.tiles_m = (d->Dc * d->Hc * d->Wc + tc.bm - 1) / tc.bm;
   k.tiles_n = (d->Co + tc.bn - 1) / tc.bn;
   int sh = 0;
   while ((8 << sh) < d->Ci) ++sh;
   k.ci_shift = sh;
   k.rcp_wc = 1.0f / (float)d->Wc;
+  k.rcp_hc = 1.0f / (float)d->Hc;
   k.d = *d;
   k.nh = k.nw = 0;
   for (int t = 0; t < d->T; ++t) {
     int h = 0, w = 0;
-    while (h < k.nh && k.uh[h] != d->dh[t]) ++h;
-    if (h == k.nh) { GS_REQUIRE(k.nh < 16, "gs_gconv_forward: more than 16 distinct tap rows"); k.uh[k.nh++] = d->dh[t]; }
+    while (h < k.nh && (k.uh[h] != d->dh[t] || k.ud[h] != d->dd[t])) ++h;
+    if (h == k.nh) {
+      GS_REQUIRE(k.nh < 64, "gs_gconv_forward: more than 64 distinct tap (depth,row) pairs");
+      k.ud[k.nh] = d->dd[t];
+      k.uh[k.nh++] = d->dh[t];
+    }
     while (w < k.nw && k.uw[w] != d->dw[t]) ++w;
     if (w == k.nw) { GS_REQUIRE(k.nw < 16, "gs_gconv_forward: more than 16 distinct tap columns"); k.uw[k.nw++] = d->dw[t]; }
     k.tap_h[t] = (unsigned char)h;

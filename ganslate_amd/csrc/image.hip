@@ -56,27 +56,44 @@ __global__ __launch_bounds__(256) void act_to_image_bwd_kernel(const float* g_im
   }
 }
 
-__global__ __launch_bounds__(256) void image_to_act_bwd_kernel(const unsigned short* g_pad, float* g_img, int C, int H,
-                                                               int W, int Cp, int fold, int accumulate) {
-  const int n = blockIdx.y;
-  const int Hp = H + 2 * fold, Wp = W + 2 * fold;
-  const unsigned short* gp = g_pad + (size_t)n * Hp * Wp * Cp;
-  float* out = g_img + (size_t)n * C * H * W;
-  const long long hw = (long long)H * W;
-  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
-    const int ih = (int)(p / W), iw = (int)(p - (long long)ih * W);
-    int hs[3], ws[3], nh = 1, nw = 1;
-    hs[0] = ih + fold; ws[0] = iw + fold;
-    if (fold > 0) {
-      if (ih >= 1 && ih <= fold) hs[nh++] = fold - ih;
-      if (ih >= H - 1 - fold && ih <= H - 2) hs[nh++] = fold + 2 * (H - 1) - ih;
-      if (iw >= 1 && iw <= fold) ws[nw++] = fold - iw;
-      if (iw >= W - 1 - fold && iw <= W - 2) ws[nw++] = fold + 2 * (W - 1) - iw;
+// sources of the pad adjoint along one axis (reflect: <= 3, replicate: border cell + its p pad cells, p <= 3)
+__device__ __forceinline__ int img_fold_sources(int* idx, int x, int n, int p, int mode) {
+  int cnt = 1;
+  idx[0] = x + p;
+  if (p > 0) {
+    if (mode == GS_BORDER_REFLECT) {
+      if (x >= 1 && x <= p) idx[cnt++] = p - x;
+      if (x >= n - 1 - p && x <= n - 2) idx[cnt++] = p + 2 * (n - 1) - x;
+    } else {
+      if (x == 0) for (int k = 0; k < p; ++k) idx[cnt++] = k;
+      if (x == n - 1) for (int k = 1; k <= p; ++k) idx[cnt++] = n - 1 + p + k;
     }
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void image_to_act_bwd_kernel(const unsigned short* g_pad, float* g_img, int C, int D,
+                                                               int H, int W, int Cp, int fold, int mode,
+                                                               int accumulate) {
+  const int n = blockIdx.y;
+  const int fd = D > 1 ? fold : 0;
+  const int Dp = D + 2 * fd, Hp = H + 2 * fold, Wp = W + 2 * fold;
+  const unsigned short* gp = g_pad + (size_t)n * Dp * Hp * Wp * Cp;
+  const long long hw = (long long)D * H * W;
+  float* out = g_img + (size_t)n * C * hw;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    const long long zi = p / W;
+    const int iw = (int)(p - zi * W);
+    const int iz = (int)(zi / H), ih = (int)(zi - (long long)iz * H);
+    int ds[8], hs[8], ws[8];
+    const int nd = img_fold_sources(ds, iz, D, fd, mode);
+    const int nh = img_fold_sources(hs, ih, H, fold, mode);
+    const int nw = img_fold_sources(ws, iw, W, fold, mode);
     for (int c = 0; c < C; ++c) {
       float s = 0.f;
-      for (int a = 0; a < nh; ++a)
-        for (int b = 0; b < nw; ++b) s += bf2f(gp[((size_t)hs[a] * Wp + ws[b]) * Cp + c]);
+      for (int e = 0; e < nd; ++e)
+        for (int a = 0; a < nh; ++a)
+          for (int b = 0; b < nw; ++b) s += bf2f(gp[(((size_t)ds[e] * Hp + hs[a]) * Wp + ws[b]) * Cp + c]);
       if (accumulate) out[(size_t)c * hw + p] += s; else out[(size_t)c * hw + p] = s;
     }
   }
@@ -120,14 +137,15 @@ extern "C" int gs_act_to_image_backward(const float* g_img, const float* out_img
   return 0;
 }
 
-extern "C" int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t H, int32_t W,
-                                        int32_t Cp, int32_t fold, int32_t fold_mode, int32_t accumulate,
+extern "C" int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t D, int32_t H,
+                                        int32_t W, int32_t Cp, int32_t fold, int32_t fold_mode, int32_t accumulate,
                                         void* stream) {
-  GS_REQUIRE(g_pad && g_img && N > 0 && C > 0 && Cp >= C, "gs_image_to_act_backward: bad argument");
-  GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT, "gs_image_to_act_backward: only reflect fold implemented");
-  const long long hw = (long long)H * W;
+  GS_REQUIRE(g_pad && g_img && N > 0 && C > 0 && Cp >= C && D > 0, "gs_image_to_act_backward: bad argument");
+  GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT || (fold_mode == GS_BORDER_REPLICATE && fold <= 3),
+             "gs_image_to_act_backward: fold must be reflect, or replicate with fold <= 3");
+  const long long hw = (long long)D * H * W;
   hipLaunchKernelGGL(image_to_act_bwd_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned short*>(g_pad), g_img, C, H, W, Cp, fold, accumulate);
+                     static_cast<const unsigned short*>(g_pad), g_img, C, D, H, W, Cp, fold, fold_mode, accumulate);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

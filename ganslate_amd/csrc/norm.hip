@@ -111,7 +111,8 @@ extern "C" int gs_inorm_act_forward(const void* y, const float* mean_rstd, const
 
 // ---- backward ------------------------------------------------------------------------------------------
 // folded gradient: g(n, ih, iw, c8) = sum over the padded-domain positions that the padding maps to (ih, iw)
-struct FoldIdx { int idx[3]; int cnt; };
+// (reflect: up to 3 sources; replicate: the border cell collects its `p` pad cells — needs p <= 3)
+struct FoldIdx { int idx[8]; int cnt; };
 __device__ __forceinline__ FoldIdx fold_sources(int x, int n, int p, int mode) {
   FoldIdx f;
   f.idx[0] = x + p;
@@ -121,7 +122,8 @@ __device__ __forceinline__ FoldIdx fold_sources(int x, int n, int p, int mode) {
       if (x >= 1 && x <= p) f.idx[f.cnt++] = p - x;
       if (x >= n - 1 - p && x <= n - 2) f.idx[f.cnt++] = p + 2 * (n - 1) - x;
     } else if (mode == GS_BORDER_REPLICATE) {
-      // handled by the caller through a loop (all p pad cells map to the border); not used in 2-D nets
+      if (x == 0) for (int k = 0; k < p; ++k) f.idx[f.cnt++] = k;
+      if (x == n - 1) for (int k = 1; k <= p; ++k) f.idx[f.cnt++] = n - 1 + p + k;
     }
   }
   return f;
@@ -132,20 +134,29 @@ __device__ __forceinline__ void add_bf8(float* f, const uint4 v) {
   f[4] += bf_lo(v.z); f[5] += bf_hi(v.z); f[6] += bf_lo(v.w); f[7] += bf_hi(v.w);
 }
 
-__device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const uint4* g2_n, int ih, int iw, int H,
+// px = (iz*H + ih)*W + iw is the unpadded pixel index; the depth axis is only padded when D > 1
+__device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const uint4* g2_n, int px, int D, int H,
                                             int W, int C8, int c8, int fold, int mode) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) f[k] = 0.f;
   if (fold == 0) {
-    add_bf8(f, gpad_n[((size_t)ih * W + iw) * C8 + c8]);
+    add_bf8(f, gpad_n[(size_t)px * C8 + c8]);
   } else {
-    const int Wp = W + 2 * fold;
+    const int zi = px / W, iw = px - zi * W;
+    const int iz = zi / H, ih = zi - iz * H;
+    const int Wp = W + 2 * fold, Hp = H + 2 * fold;
+    const FoldIdx fd = fold_sources(iz, D, D > 1 ? fold : 0, mode);
     const FoldIdx fh = fold_sources(ih, H, fold, mode);
     const FoldIdx fw = fold_sources(iw, W, fold, mode);
-    for (int a = 0; a < fh.cnt; ++a)
-      for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.idx[a] * Wp + fw.idx[b]) * C8 + c8]);
+    for (int c = 0; c < fd.cnt; ++c)
+      for (int a = 0; a < fh.cnt; ++a)
+        for (int b = 0; b < fw.cnt; ++b)
+          add_bf8(f, gpad_n[(((size_t)fd.idx[c] * Hp + fh.idx[a]) * Wp + fw.idx[b]) * C8 + c8]);
   }
-  if (g2_n) add_bf8(f, g2_n[((size_t)ih * W + iw) * C8 + c8]);
+  if (g2_n) add_bf8(f, g2_n[(size_t)px * C8 + c8]);
+}
+__device__ __forceinline__ size_t padded_pixels(int D, int H, int W, int fold) {
+  return (size_t)(D > 1 ? D + 2 * fold : D) * (H + 2 * fold) * (W + 2 * fold);
 }
 
 __device__ __forceinline__ void load8(float* f, const float* p) {
@@ -162,19 +173,19 @@ __device__ __forceinline__ void unpack8(float* f, const uint4 v) {
 // 256 threads = COLS 8-channel columns x (256/COLS) pixel lanes; grid (chunks, N, ceil(C8/COLS))
 template <int COLS>
 __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
-                                                               const float* mean_rstd, float* partial, int H, int W,
-                                                               int C8, int fold, int mode, int act, float slope,
-                                                               int pix_per_block, int chunks) {
+                                                               const float* mean_rstd, float* partial, int D, int H,
+                                                               int W, int C8, int fold, int mode, int act,
+                                                               float slope, int pix_per_block, int chunks) {
   constexpr int ROWS = 256 / COLS;
   __shared__ float red[ROWS][COLS][25];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const int col = tid % COLS, row = tid / COLS;
   const int c8 = blockIdx.z * COLS + col;
-  const int HW = H * W;
+  const int HW = D * H * W;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
-  const size_t pad_img = (size_t)(H + 2 * fold) * (W + 2 * fold) * C8;
+  const size_t pad_img = padded_pixels(D, H, W, fold) * C8;
   const uint4* gpad_n = gpad + (size_t)n * pad_img;
   const uint4* g2_n = g2 ? g2 + (size_t)n * HW * C8 : nullptr;
   const uint4* y_n = y + (size_t)n * HW * C8;
@@ -187,9 +198,8 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
     load8(mu, mr + c8 * 8);
     load8(rs, mr + C8 * 8 + c8 * 8);
     for (int px = p0 + row; px < p1; px += ROWS) {
-      const int ih = px / W, iw = px - ih * W;
       float g[8], yy[8];
-      load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
+      load_folded(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold, mode);
       unpack8(yy, y_n[(size_t)px * C8 + c8]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -221,12 +231,13 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
 // pass 2: dy = rstd * (ghat - S1/hw - yhat*S2/hw) ; optional gsum = folded gradient (before act')
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
                                                               const float* mean_rstd, const float* sums, uint4* dy,
-                                                              uint4* gsum, int H, int W, int C8, int c8_shift,
-                                                              int fold, int mode, int act, float slope) {
+                                                              uint4* gsum, int D, int H, int W, int C8,
+                                                              int c8_shift, int fold, int mode, int act,
+                                                              float slope) {
   const int n = blockIdx.y;
-  const unsigned HW = (unsigned)(H * W);
+  const unsigned HW = (unsigned)(D * H * W);
   const unsigned per_img = HW * (unsigned)C8;
-  const size_t pad_img = (size_t)(H + 2 * fold) * (W + 2 * fold) * C8;
+  const size_t pad_img = padded_pixels(D, H, W, fold) * C8;
   const uint4* gpad_n = gpad + (size_t)n * pad_img;
   const uint4* g2_n = g2 ? g2 + (size_t)n * per_img : nullptr;
   const uint4* y_n = y + (size_t)n * per_img;
@@ -245,8 +256,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
       add_bf8(g, gpad_n[e]);
       if (g2_n) add_bf8(g, g2_n[e]);
     } else {
-      const int ih = (int)(px / (unsigned)W), iw = (int)(px - (unsigned)ih * (unsigned)W);
-      load_folded(g, gpad_n, g2_n, ih, iw, H, W, C8, c8, fold, mode);
+      load_folded(g, gpad_n, g2_n, (int)px, D, H, W, C8, c8, fold, mode);
     }
     if (gs_n) {
       uint4 o;
@@ -285,25 +295,35 @@ int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, fl
   return 0;
 }
 
-static const int kBwdPixPerBlock = 64;
+// pixels per block of the reduction pass: 64 for 2-D sized maps, more for volumes so that the second-level sum
+// stays at <= 4096 slots per image
+static int bwd_pix_per_block(long long pixels) {
+  long long ppb = (pixels + 4095) / 4096;
+  return ppb < 64 ? 64 : (int)((ppb + 63) / 64 * 64);
+}
 
-extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C) {
-  const int64_t chunks = ((int64_t)H * W + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
+extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t D, int32_t H, int32_t W, int32_t C) {
+  const int64_t pixels = (int64_t)D * H * W;
+  const int64_t ppb = bwd_pix_per_block(pixels);
+  const int64_t chunks = (pixels + ppb - 1) / ppb;
   return (int64_t)N * (chunks + 1) * 3 * C;
 }
 
 extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
-                                     void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t H,
-                                     int32_t W,
-                                     int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
-                                     void* stream) {
-  GS_REQUIRE(g_pad && y && dy && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0,
+                                     void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t D,
+                                     int32_t H, int32_t W, int32_t C, int32_t fold, int32_t fold_mode, int32_t act,
+                                     float slope, void* stream) {
+  GS_REQUIRE(g_pad && y && dy && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0,
              "gs_inorm_act_backward: bad argument");
-  GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT, "gs_inorm_act_backward: only reflect fold implemented");
-  GS_REQUIRE(fold == 0 || (H > 2 * fold && W > 2 * fold), "gs_inorm_act_backward: fold larger than image");
+  GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT || (fold_mode == GS_BORDER_REPLICATE && fold <= 3),
+             "gs_inorm_act_backward: fold must be reflect, or replicate with fold <= 3");
+  GS_REQUIRE(fold == 0 || fold_mode != GS_BORDER_REFLECT || (H > 2 * fold && W > 2 * fold && (D == 1 || D > 2 * fold)),
+             "gs_inorm_act_backward: fold larger than image");
+  GS_REQUIRE((long long)D * H * W < (1LL << 31), "gs_inorm_act_backward: image too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int C8 = C / 8;
-  const int HW = H * W;
+  const int HW = D * H * W;
+  const int kBwdPixPerBlock = bwd_pix_per_block(HW);
   float* sums = nullptr;
   if (mean_rstd) {
     GS_REQUIRE(scratch, "gs_inorm_act_backward: scratch required with normalisation");
@@ -312,7 +332,7 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
 #define GS_LAUNCH_REDUCE(COLS)                                                                                   \
   hipLaunchKernelGGL((inorm_bwd_reduce_kernel<COLS>), dim3(chunks, N, (C8 + COLS - 1) / COLS), dim3(256), 0, st, \
                      static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y), \
-                     mean_rstd, scratch, H, W, C8, fold, fold_mode, act, slope, kBwdPixPerBlock, chunks)
+                     mean_rstd, scratch, D, H, W, C8, fold, fold_mode, act, slope, kBwdPixPerBlock, chunks)
     if (C8 >= 32) GS_LAUNCH_REDUCE(32);
     else if (C8 >= 8) GS_LAUNCH_REDUCE(8);
     else GS_LAUNCH_REDUCE(1);
@@ -330,7 +350,7 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   if ((C8 & (C8 - 1)) == 0) { c8_shift = 0; while ((1 << c8_shift) < C8) ++c8_shift; }
   hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)bx, N), dim3(256), 0, st,
                      static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y),
-                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), H, W, C8, c8_shift, fold,
+                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), D, H, W, C8, c8_shift, fold,
                      fold_mode, act, slope);
   GS_CHECK_HIP(hipGetLastError());
   return 0;

@@ -1,10 +1,10 @@
 // Weight gradient of the generalised convolution family on the gfx950 matrix cores:
 //
-//   dw[p][t*Q+q] += sum_{n,i,j} a[n,i,j,p] * g[n, B(i*si+dh[t]), B(j*si+dw[t]), q]
+//   dw[p][t*Q+q] += sum_{n,z,i,j} a[n,z,i,j,p] * g[n, B(z*si+dd[t]), B(i*si+dh[t]), B(j*si+dw[t]), q]
 //
-// `a` is the dense side (dY for Conv2d, X for ConvTranspose2d), `g` the gathered side. Replaces the
+// `a` is the dense side (dY for Conv, X for ConvTranspose), `g` the gathered side. Replaces the
 // autograd weight-gradient kernels behind loss.backward() (ganslate/nn/gans/base.py:170) for every conv of
-// resnet2d.py / patchgan2d.py.
+// resnet2d.py / patchgan2d.py and their 3-D twins resnet3d.py / patchgan3d.py (2-D = depth 1).
 //
 // GEMM view: C[p][n'] = A[m][p]^T * G[m][n'], contraction over pixels m. Both operands are pixel-major in
 // memory (NHWC), so MFMA fragments (8 consecutive k per lane) are read with the LDS transpose read
@@ -19,7 +19,7 @@ struct WGradK {
   float* dw;
   const char* zero;
   int tiles_p, tiles_q, splits, chunk, q_shift;
-  float rcp_wa, rcp_hw;
+  float rcp_wa, rcp_hw, rcp_da;
   gs_wgrad_desc d;
 };
 
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   static_assert((BK / GRI) % NW == 0, "gathered tile must split evenly over the waves");
   static_assert(NAI == 1 || (A_INSTR % NW == 0 && (ARI * NW) % 16 == 0), "dense tile DMA layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  short* taps = reinterpret_cast<short*>(smem + NSTAGE * STAGE);
-  char* dummy = smem + NSTAGE * STAGE + GS_MAX_TAPS * 2;     // 1 KiB sink for surplus DMA instructions
+  int* taps = reinterpret_cast<int*>(smem + NSTAGE * STAGE);
+  char* dummy = smem + NSTAGE * STAGE + GS_MAX_TAPS * 4;     // 1 KiB sink for surplus DMA instructions
   const gs_wgrad_desc& d = p.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,16 +56,17 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   const int sp = b;                       // pixel range [k0, k1) of the batch-flattened pixel index
   const int HW = d.Ha * d.Wa;
   const int k0 = sp * p.chunk;
-  const int k1 = min(d.N * HW, k0 + p.chunk);
+  const int k1 = min(d.N * d.Da * HW, k0 + p.chunk);
   if (k0 >= k1) return;
 
-  if (tid < d.T) taps[tid] = (short)(((int)d.dh[tid] & 0xff) | ((int)d.dw_[tid] << 8));
+  for (int t = tid; t < d.T; t += NW * 64)
+    taps[t] = ((int)d.dh[t] & 0xff) | (((int)d.dw_[t] & 0xff) << 8) | ((int)d.dd[t] << 16);
   __syncthreads();
 
   // ---- per-lane DMA bookkeeping: the 16-B chunk (and with it the tap / channel group) is fixed per lane ----
   const char* a_n = p.a + (size_t)d.a_co * 2;
   const char* g_n = p.g + (size_t)d.g_co * 2;
-  const unsigned g_img = (unsigned)(d.Hg * d.Wg);
+  const unsigned g_img = (unsigned)(d.Dg * d.Hg * d.Wg);
   const int a_row0 = ARI * wave + lane / (ARB / 16);         // row of this lane in its first A instruction
   const int a_slot = lane % (ARB / 16);
   const int a_chunk = a_slot ^ (wg_swz(a_row0) & ASW);       // swz is invariant under row += ARI*NW (multiple of 16)
@@ -78,19 +79,21 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   const int g_t = (g_col >> 3) >> p.q_shift;
   const int g_q8 = (g_col >> 3) & ((1 << p.q_shift) - 1);
   const bool g_tv = g_t < d.T;
-  const short tpv = taps[g_tv ? g_t : 0];
-  const int g_dh = (int)(signed char)(tpv & 0xff), g_dw = (int)tpv >> 8;
+  const int tpv = taps[g_tv ? g_t : 0];
+  const int g_dh = (int)(signed char)(tpv & 0xff), g_dw = (int)(signed char)((tpv >> 8) & 0xff), g_dd = tpv >> 16;
   static_assert((GRI * NW) % 16 == 0, "row step must keep the swizzle invariant");
 
   // pixel coordinates of this lane's gathered rows, advanced by BK pixels per K-step (no divisions in the loop)
-  int gn[NGI], gi[NGI], gj[NGI];
+  int gn[NGI], gz[NGI], gi[NGI], gj[NGI];
 #pragma unroll
   for (int i = 0; i < NGI; ++i) {
     const int m = k0 + g_row0 + i * GRI * NW;
-    gn[i] = div_small(m, HW, p.rcp_hw);
-    const int rem = m - gn[i] * HW;
+    const int nz = div_small(m, HW, p.rcp_hw);          // (image, depth) combined
+    const int rem = m - nz * HW;
     gi[i] = div_small(rem, d.Wa, p.rcp_wa);
     gj[i] = rem - gi[i] * d.Wa;
+    gn[i] = div_small(nz, d.Da, p.rcp_da);
+    gz[i] = nz - gn[i] * d.Da;
   }
 
   auto issue = [&](int ks, int buf) {      // always called with ks increasing by 1
@@ -111,13 +114,15 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
       const int R = g_row0 + i * GRI * NW;
       const int m = mb + R;
       bool ok = g_tv && m < k1;
-      const int nn = gn[i], ii = gi[i], jj = gj[i];
+      const int nn = gn[i], zz = gz[i], ii = gi[i], jj = gj[i];
       gj[i] += BK;
       while (gj[i] >= d.Wa) { gj[i] -= d.Wa; ++gi[i]; }
-      while (gi[i] >= d.Ha) { gi[i] -= d.Ha; ++gn[i]; }
+      while (gi[i] >= d.Ha) { gi[i] -= d.Ha; ++gz[i]; }
+      while (gz[i] >= d.Da) { gz[i] -= d.Da; ++gn[i]; }
+      const int iz = border_index(zz * d.si + g_dd, d.Dg, d.border, ok);
       const int ih = border_index(ii * d.si + g_dh, d.Hg, d.border, ok);
       const int iw = border_index(jj * d.si + g_dw, d.Wg, d.border, ok);
-      unsigned off = (((unsigned)nn * g_img + (unsigned)(ih * d.Wg + iw)) * (unsigned)d.g_cs + (unsigned)(g_q8 * 8)) * 2u;
+      unsigned off = (((unsigned)nn * g_img + (unsigned)((iz * d.Hg + ih) * d.Wg + iw)) * (unsigned)d.g_cs + (unsigned)(g_q8 * 8)) * 2u;
       asm volatile("" : "+v"(off));
       const char* src = ok ? g_n + off : p.zero;
       glds16(src, sb + AT + (wave + i * NW) * 1024);
@@ -219,8 +224,8 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
   // split-K over the batch-flattened pixel index: one workgroup per CU is resident (144 KiB of LDS), so aim for
   // a grid of (almost) exactly r * 256 workgroups with >= 16 K-steps each, preferring the smallest r
-  const long long M = (long long)d->N * d->Ha * d->Wa;
-  GS_REQUIRE(M < (1 << 24) && M * d->a_cs < (1LL << 31) && (long long)d->N * d->Hg * d->Wg * d->g_cs < (1LL << 31),
+  const long long M = (long long)d->N * d->Da * d->Ha * d->Wa;
+  GS_REQUIRE(M < (1 << 24) && M * d->a_cs < (1LL << 31) && (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31),
              "gs_wgrad: tensor too large for 32-bit offsets");
   const long long tiles = (long long)k.tiles_p * k.tiles_q;
   const long long max_splits = (M + 1023) / 1024 > 0 ? (M + 1023) / 1024 : 1;
@@ -243,7 +248,7 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   k.rcp_hw = 1.0f / (float)(d->Ha * d->Wa);
   const long long blocks = tiles * splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_wgrad: bad grid %lld", blocks);
-  constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 2 + 1024;
+  constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 4 + 1024;
   static bool configured = false;
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ, VARIANT>),
@@ -274,6 +279,8 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
   while ((8 << sh) < d->Q) ++sh;
   k.q_shift = sh;
   k.rcp_wa = 1.0f / (float)d->Wa;
+  k.rcp_da = 1.0f / (float)d->Da;
+  GS_REQUIRE(d->Da >= 1 && d->Dg >= 1, "gs_wgrad: depths must be >= 1 (1 for 2-D tensors)");
   k.d = *d;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (d->P <= 16) return launch_wgrad<16, 256, 1, 8>(k, d, st);      // Cout 1/3 layers: skinny P

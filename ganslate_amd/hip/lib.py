@@ -6,7 +6,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-GS_MAX_TAPS = 128
+GS_MAX_TAPS = 352
 BORDER = {"zero": 0, "reflect": 1, "replicate": 2}
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 
@@ -14,17 +14,18 @@ ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 class GConvDesc(C.Structure):
     """Mirror of gs_gconv_desc (include/ganslate_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
-        "N", "Hi", "Wi", "Ci", "in_cs", "in_co", "Ho", "Wo", "Co", "out_cs", "out_co", "Hc", "Wc",
+        "N", "Hi", "Wi", "Ci", "Di", "Do", "Dc", "pz", "in_cs", "in_co", "Ho", "Wo", "Co", "out_cs", "out_co", "Hc", "Wc",
         "so", "py", "px", "si", "T", "Kp", "w_rows", "border", "act")] + [
         ("slope", C.c_float), ("stats_slots", C.c_int32), ("stats_slot0", C.c_int32),
-        ("dh", C.c_int8 * GS_MAX_TAPS), ("dw", C.c_int8 * GS_MAX_TAPS)]
+        ("dh", C.c_int8 * GS_MAX_TAPS), ("dw", C.c_int8 * GS_MAX_TAPS), ("dd", C.c_int8 * GS_MAX_TAPS)]
 
 
 class WGradDesc(C.Structure):
     """Mirror of gs_wgrad_desc."""
     _fields_ = [(n, C.c_int32) for n in (
-        "N", "Ha", "Wa", "P", "a_cs", "a_co", "Hg", "Wg", "Q", "g_cs", "g_co", "si", "T", "border", "dw_ld")] + [
-        ("dh", C.c_int8 * GS_MAX_TAPS), ("dw_", C.c_int8 * GS_MAX_TAPS)]
+        "N", "Ha", "Wa", "P", "a_cs", "a_co", "Hg", "Wg", "Q", "g_cs", "g_co", "Da", "Dg", "si", "T", "border",
+        "dw_ld")] + [
+        ("dh", C.c_int8 * GS_MAX_TAPS), ("dw_", C.c_int8 * GS_MAX_TAPS), ("dd", C.c_int8 * GS_MAX_TAPS)]
 
 
 class NormExDesc(C.Structure):
@@ -49,8 +50,8 @@ _PROTOS = {
                                        C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "gs_inorm_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                        C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
-    "gs_inorm_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "gs_inorm_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gs_norm_act_forward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
     "gs_norm_act_backward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -63,7 +64,7 @@ _PROTOS = {
     "gs_act_to_image_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_image_to_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                           C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_mse_const": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_l1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -49,13 +49,14 @@ class HipOps:
         if d is None:
             d = L.GConvDesc()
             d.N, d.Hi, d.Wi, d.Ci, d.in_cs, d.in_co = N, g.Hi, g.Wi, g.Ci, in_cs, in_co
+            d.Di, d.Do, d.Dc, d.pz = g.Di, g.Do, g.Dc, g.pz
             d.Ho, d.Wo, d.Co, d.out_cs, d.out_co = g.Ho, g.Wo, g.Co, out_cs, out_co
             d.Hc, d.Wc, d.so, d.py, d.px, d.si = g.Hc, g.Wc, g.so, g.py, g.px, g.si
             d.T, d.Kp, d.w_rows = g.T, g.Kp, g.w_rows
             d.border, d.act, d.slope = L.BORDER[g.border], L.ACT[act], slope
             d.stats_slots, d.stats_slot0 = stats_slots, stats_slot0
-            for i, (a, b) in enumerate(zip(g.dh, g.dw)):
-                d.dh[i], d.dw[i] = a, b
+            for i, (a, b, c) in enumerate(zip(g.dh, g.dw, g.dd)):
+                d.dh[i], d.dw[i], d.dd[i] = a, b, c
             self._desc_cache[key] = (d, g)   # keep g alive so id() stays unique
             return d
         return d[0]
@@ -88,12 +89,13 @@ class HipOps:
         if ent is None:
             d = L.WGradDesc()
             d.N, d.Ha, d.Wa, d.P = a.shape[0], w.Ha, w.Wa, w.P
+            d.Da, d.Dg = w.Da, w.Dg
             d.a_cs, d.a_co = (a_cs if a_cs is not None else a.shape[-1]), a_co
             d.Hg, d.Wg, d.Q = w.Hg, w.Wg, w.Q
             d.g_cs, d.g_co = (g_cs if g_cs is not None else g.shape[-1]), g_co
             d.si, d.T, d.border, d.dw_ld = w.si, w.T, L.BORDER[w.border], w.T * w.Q
-            for i, (p, q) in enumerate(zip(w.dh, w.dw)):
-                d.dh[i], d.dw_[i] = p, q
+            for i, (p, q, r) in enumerate(zip(w.dh, w.dw, w.dd)):
+                d.dh[i], d.dw_[i], d.dd[i] = p, q, r
             ent = (d, w)
             self._desc_cache[key] = ent
         L.check(self.lib.gs_wgrad(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(dw), _stream()), "gs_wgrad")
@@ -109,19 +111,20 @@ class HipOps:
                 "gs_inorm_finalize")
 
     def inorm_act_forward(self, y, mean_rstd, res, x, act="none", slope=0.2):
-        N, H, W, Cc = y.shape
-        L.check(self.lib.gs_inorm_act_forward(_ptr(y), _ptr(mean_rstd), _ptr(res), _ptr(x), N, H * W, Cc,
+        N, Cc = y.shape[0], y.shape[-1]
+        L.check(self.lib.gs_inorm_act_forward(_ptr(y), _ptr(mean_rstd), _ptr(res), _ptr(x), N,
+                                              y.numel() // (N * Cc), Cc,
                                               L.ACT[act], slope, _stream()), "gs_inorm_act_forward")
 
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
                            slope=0.2, bias_grad=None):
-        N, H, W, Cc = y.shape
+        N, D, H, W, Cc = y.shape if y.dim() == 5 else (y.shape[0], 1) + tuple(y.shape[1:])
         scratch = None
         if mean_rstd is not None:
-            n = self.lib.gs_inorm_backward_scratch_floats(N, H, W, Cc)
+            n = self.lib.gs_inorm_backward_scratch_floats(N, D, H, W, Cc)
             scratch = torch.empty(n, dtype=torch.float32, device=y.device)
         L.check(self.lib.gs_inorm_act_backward(_ptr(g_pad), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(dy),
-                                               _ptr(gsum), _ptr(scratch), _ptr(bias_grad), N, H, W, Cc, fold,
+                                               _ptr(gsum), _ptr(scratch), _ptr(bias_grad), N, D, H, W, Cc, fold,
                                                L.BORDER[fold_mode], L.ACT[act], slope, _stream()),
                 "gs_inorm_act_backward")
 
@@ -157,25 +160,32 @@ class HipOps:
                 "gs_norm_act_backward_ex")
 
     # ---- network boundary -----------------------------------------------------------------------------------
+    @staticmethod
+    def _img_dims(img):
+        """(N, C, rows, W) of an NCHW image or NCDHW volume: the layout-only kernels see a volume as D*H rows"""
+        N, Cc = img.shape[0], img.shape[1]
+        return N, Cc, img.numel() // (N * Cc * img.shape[-1]), img.shape[-1]
+
     def image_to_act(self, img, act_t):
-        N, Cc, H, W = img.shape
+        N, Cc, H, W = self._img_dims(img)
         L.check(self.lib.gs_image_to_act(_ptr(img), _ptr(act_t), N, Cc, H, W, act_t.shape[-1], _stream()),
                 "gs_image_to_act")
 
     def act_to_image(self, act_t, img, act="none"):
-        N, Cc, H, W = img.shape
+        N, Cc, H, W = self._img_dims(img)
         L.check(self.lib.gs_act_to_image(_ptr(act_t), _ptr(img), N, Cc, H, W, act_t.shape[-1], L.ACT[act],
                                          _stream()), "gs_act_to_image")
 
     def act_to_image_backward(self, g_img, out_img, g_act, act="none"):
-        N, Cc, H, W = g_img.shape
+        N, Cc, H, W = self._img_dims(g_img)
         L.check(self.lib.gs_act_to_image_backward(_ptr(g_img), _ptr(out_img), _ptr(g_act), N, Cc, H, W,
                                                   g_act.shape[-1], L.ACT[act], _stream()),
                 "gs_act_to_image_backward")
 
     def image_to_act_backward(self, g_pad, g_img, fold=0, fold_mode="reflect", accumulate=False):
-        N, Cc, H, W = g_img.shape
-        L.check(self.lib.gs_image_to_act_backward(_ptr(g_pad), _ptr(g_img), N, Cc, H, W, g_pad.shape[-1], fold,
+        N, Cc = g_img.shape[0], g_img.shape[1]
+        D, H, W = g_img.shape[2:] if g_img.dim() == 5 else (1,) + tuple(g_img.shape[2:])
+        L.check(self.lib.gs_image_to_act_backward(_ptr(g_pad), _ptr(g_img), N, Cc, D, H, W, g_pad.shape[-1], fold,
                                                   L.BORDER[fold_mode], int(accumulate), _stream()),
                 "gs_image_to_act_backward")
 

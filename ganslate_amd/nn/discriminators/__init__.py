@@ -1,1 +1,2 @@
 from .patchgan.patchgan2d import PatchGAN2D, PatchGAN2DConfig  # noqa: F401
+from .patchgan.patchgan3d import PatchGAN3D, PatchGAN3DConfig  # noqa: F401

@@ -17,24 +17,30 @@ class PatchGAN2DConfig(configs.base.BaseDiscriminatorConfig):
     kernel_size: Tuple[int] = (4, 4)
 
 
+def patchgan_nodes(in_channels, ndf, n_layers, kernel_size, use_bias, dims=2):
+    """layer list shared by PatchGAN2D (patchgan2d.py:24-63) and PatchGAN3D (patchgan3d.py:24-61)"""
+    ks = list(kernel_size) if not isinstance(kernel_size, int) else [kernel_size] * dims
+    assert len(set(ks)) == 1 and len(ks) == dims, "square / cubic kernels only"
+    kw = int(ks[0])
+    conv = lambda *a, **k: ConvSpec(*a, dims=dims, **k)
+    nodes = [Node(conv("conv", in_channels, ndf, kw, 2, 1), False, "lrelu", name="model.0")]
+    idx, mult = 2, 1
+    for n in range(1, n_layers):
+        prev, mult = mult, min(2 ** n, 8)
+        nodes.append(Node(conv("conv", ndf * prev, ndf * mult, kw, 2, 1, bias=use_bias), True, "lrelu",
+                          name=f"model.{idx}"))
+        idx += 3
+    prev, mult = mult, min(2 ** n_layers, 8)
+    nodes.append(Node(conv("conv", ndf * prev, ndf * mult, kw, 1, 1, bias=use_bias), True, "lrelu",
+                      name=f"model.{idx}"))
+    idx += 3
+    nodes.append(Node(conv("conv", ndf * mult, 1, kw, 1, 1), False, "none", name=f"model.{idx}"))
+    return nodes
+
+
 class PatchGAN2D(NativeNet):
 
     def __init__(self, in_channels, ndf, n_layers, kernel_size, norm_type):
         require_instance_norm(norm_type)
-        use_bias = is_bias_before_norm(norm_type)
-        ks = list(kernel_size) if not isinstance(kernel_size, int) else [kernel_size, kernel_size]
-        assert len(set(ks)) == 1, "square kernels only"
-        kw = int(ks[0])
-        nodes = [Node(ConvSpec("conv", in_channels, ndf, kw, 2, 1), False, "lrelu", name="model.0")]
-        idx, mult = 2, 1
-        for n in range(1, n_layers):
-            prev, mult = mult, min(2 ** n, 8)
-            nodes.append(Node(ConvSpec("conv", ndf * prev, ndf * mult, kw, 2, 1, bias=use_bias), True, "lrelu",
-                              name=f"model.{idx}"))
-            idx += 3
-        prev, mult = mult, min(2 ** n_layers, 8)
-        nodes.append(Node(ConvSpec("conv", ndf * prev, ndf * mult, kw, 1, 1, bias=use_bias), True, "lrelu",
-                          name=f"model.{idx}"))
-        idx += 3
-        nodes.append(Node(ConvSpec("conv", ndf * mult, 1, kw, 1, 1), False, "none", name=f"model.{idx}"))
+        nodes = patchgan_nodes(in_channels, ndf, n_layers, kernel_size, is_bias_before_norm(norm_type), dims=2)
         super().__init__(nodes, in_channels, 1, out_act="none")

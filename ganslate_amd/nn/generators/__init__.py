@@ -1,2 +1,3 @@
 from .resnet.resnet2d import Resnet2D, Resnet2DConfig  # noqa: F401
 from .unet.unet2d import Unet2D, Unet2DConfig  # noqa: F401
+from .resnet.resnet3d import Resnet3D, Resnet3DConfig  # noqa: F401

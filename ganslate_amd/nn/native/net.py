@@ -48,6 +48,7 @@ class NativeNet:
         self.in_channels, self.out_channels, self.out_act = in_channels, out_channels, out_act
         assert nodes[0].spec.cin == in_channels and nodes[-1].spec.cout == out_channels
         assert not nodes[-1].norm, "last node feeds the image boundary directly"
+        self.dims = nodes[0].spec.dims          # 2 = NCHW images, 3 = NCDHW volumes
         # ---- flat parameter layout: [w_0 | b_0 | w_1 | b_1 | ...] ------------------------------------------
         self.w_off, self.b_off, off = [], [], 0
         for nd in nodes:
@@ -151,24 +152,24 @@ class NativeNet:
         self._packs_dirty = True
 
     # ---- lowering / packs (per input size) -----------------------------------------------------------------------
-    def _lowered(self, H, W) -> List[Lowered]:
-        key = (H, W)
+    def _lowered(self, *sizes) -> List[Lowered]:
+        key = tuple(sizes)
         if key not in self._low_cache:
-            lows, h, w = [], H, W
+            lows, cur = [], key
             for nd in self.nodes:
-                lw = lower(nd.spec, h, w)
+                lw = lower(nd.spec, *cur)
                 lows.append(lw)
-                h, w = lw.Ho, lw.Wo
+                cur = lw.out_dims
             self._low_cache[key] = lows
         return self._low_cache[key]
 
-    def _get_packs(self, H, W):
+    def _get_packs(self, *sizes):
         """bf16 packs are size-independent except for the parity-class split, which only depends on the spec;
-        one pack set per (H, W) key keeps the bookkeeping trivial (a net sees one or two sizes in practice)."""
-        key = (H, W)
+        one pack set per input-size key keeps the bookkeeping trivial (a net sees one or two sizes in practice)."""
+        key = tuple(sizes)
         pk = self._packs.get(key)
         if pk is None:
-            lows = self._lowered(H, W)
+            lows = self._lowered(*sizes)
             f_idx, d_idx, f_off, d_off = [], [], [], []
             fo = do = 0
             for i, lw in enumerate(lows):
@@ -199,7 +200,8 @@ class NativeNet:
 
     # ---- forward ----------------------------------------------------------------------------------------------------------
     def forward(self, x):
-        assert x.dim() == 4 and x.shape[1] == self.in_channels, f"expected N x {self.in_channels} x H x W"
+        assert x.dim() == 2 + self.dims and x.shape[1] == self.in_channels, \
+            f"expected N x {self.in_channels} x {'D x ' if self.dims == 3 else ''}H x W"
         x = x.contiguous().float()
         record = torch.is_grad_enabled() and (x.requires_grad or self.requires_grad)
         if not record:
@@ -216,11 +218,11 @@ class NativeNet:
     def _forward(self, x, save, stop=None):
         """stop = index of the last node to run (encoder-only passes of CUT, cut.py:297-312); None = whole net"""
         ops, dev = self.ops, self.device
-        N, _, H, W = x.shape
-        lows = self._lowered(H, W)
-        pk = self._get_packs(H, W)
+        N, sizes = x.shape[0], tuple(x.shape[2:])
+        lows = self._lowered(*sizes)
+        pk = self._get_packs(*sizes)
         m = self.master.detach()
-        a = torch.empty(N, H, W, self.nodes[0].spec.cin_p, dtype=self.ops.act_dtype, device=dev)
+        a = torch.empty(N, *sizes, self.nodes[0].spec.cin_p, dtype=self.ops.act_dtype, device=dev)
         ops.image_to_act(x, a)
         acts, ys, mrs = [a], [], []
         for i, (nd, lw) in enumerate(zip(self.nodes, lows)):
@@ -229,18 +231,18 @@ class NativeNet:
             sp = nd.spec
             bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
             fpack = pk["fpack"][pk["f_off"][i]:]
-            y = torch.empty(N, lw.Ho, lw.Wo, sp.cout_p, dtype=self.ops.act_dtype, device=dev)
+            y = torch.empty(N, *lw.out_dims, sp.cout_p, dtype=self.ops.act_dtype, device=dev)
             if nd.norm:
                 slots, offs = 0, []
                 for g in lw.fwd:
                     offs.append(slots)
                     tm = ops.tile_m(g, N)
-                    slots += (g.Hc * g.Wc + tm - 1) // tm
+                    slots += (g.pixels + tm - 1) // tm
                 part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=dev)
                 for g, o in zip(lw.fwd, offs):
                     ops.gconv(g, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
                 mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=dev)
-                ops.inorm_finalize(part, N, slots, sp.cout_p, lw.Ho * lw.Wo, mr)
+                ops.inorm_finalize(part, N, slots, sp.cout_p, lw.out_pixels, mr)
                 xo = torch.empty_like(y)
                 res = acts[nd.res + 1] if nd.res is not None else None
                 ops.inorm_act_forward(y, mr, res, xo, act=nd.act, slope=nd.slope)
@@ -255,7 +257,7 @@ class NativeNet:
         out = None
         if stop is None:
             lw = lows[-1]
-            out = torch.empty(N, self.out_channels, lw.Ho, lw.Wo, dtype=torch.float32, device=dev)
+            out = torch.empty(N, self.out_channels, *lw.out_dims, dtype=torch.float32, device=dev)
             ops.act_to_image(acts[-1], out, act=self.out_act)
         if not save:
             return out, None
@@ -273,26 +275,27 @@ class NativeNet:
         nodes, lows, N = self.nodes, s.lows, s.N
         if self.master.grad is None:
             self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        H, W = s.x_img.shape[2], s.x_img.shape[3]
-        pk = self._get_packs(H, W)
+        pk = self._get_packs(*s.x_img.shape[2:])
         grad = self.master.grad
         last = len(nodes) - 1 if start is None else start
-        pending = None                # gradient w.r.t. the output of node i: (tensor on padded domain, fold, extra)
+        # gradient w.r.t. the output of node i: (tensor on padded domain, fold, extra, pad mode of the fold)
+        pending = None
         if g_img is not None:
             ga = torch.empty_like(s.acts[-1])
             ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
-            pending = (ga, 0, None)
+            pending = (ga, 0, None, "reflect")
         skip: Dict[int, torch.Tensor] = {}
         final_pass = want_w and self._dist is not None and self._fw_pending == 0
         for i in range(last, -1, -1):
             nd, lw, sp = nodes[i], lows[i], nodes[i].spec
             if i in inj_x:            # tapped feature gradient joins the gradient of this node's output
                 if pending is None:
-                    pending = (inj_x[i], 0, None)
+                    pending = (inj_x[i], 0, None, "reflect")
                 else:
                     f0 = pending[1]
-                    pending[0][:, f0:f0 + lw.Ho, f0:f0 + lw.Wo, :] += inj_x[i]   # the pad adjoint is linear
-            g_pad, fold, g2 = pending
+                    inner = (slice(None),) + tuple(slice(f0, f0 + n) for n in lw.out_dims)
+                    pending[0][inner] += inj_x[i]   # the pad adjoint is linear
+            g_pad, fold, g2, fmode = pending
             x_out = s.acts[i + 1]
             # ---- gradient w.r.t. the conv output y ---------------------------------------------------------------
             need_total = nd.res is not None
@@ -302,10 +305,11 @@ class NativeNet:
                 if nd.norm:
                     # the bias gradient of a conv in front of an InstanceNorm comes out of the norm's reduction sums
                     db = grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
-                    ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, act=nd.act,
-                                           slope=nd.slope, bias_grad=db)
+                    ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, fold_mode=fmode,
+                                           act=nd.act, slope=nd.slope, bias_grad=db)
                 else:
-                    ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, act=nd.act, slope=nd.slope)
+                    ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, fold_mode=fmode, act=nd.act,
+                                           slope=nd.slope)
                 total = gsum if gsum is not None else g_pad
             else:
                 dy, total = g_pad, g_pad
@@ -326,18 +330,18 @@ class NativeNet:
             # ---- data gradient ------------------------------------------------------------------------------------------
             if i > 0 or need_input_grad:
                 f = lw.dgrad_fold
-                gx = torch.empty(N, lw.Hi + 2 * f, lw.Wi + 2 * f, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
+                gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
                 dpack = pk["dpack"][pk["d_off"][i]:]
                 for g in lw.dgrad:
                     ops.gconv(g, dy, dpack, None, gx)
-                pending = (gx, f, skip.pop(i - 1, None))
+                pending = (gx, f, skip.pop(i - 1, None), sp.pad_mode if f else "reflect")
             if start is None:
                 s.acts[i + 1] = None  # release as we go
         if not need_input_grad:
             return None
-        gx, f, _ = pending
+        gx, f, _, fmode = pending
         g_in = torch.empty_like(s.x_img)
-        ops.image_to_act_backward(gx, g_in, fold=f)
+        ops.image_to_act_backward(gx, g_in, fold=f, fold_mode=fmode)
         return g_in
 
     # ---- data parallelism (reference: DistributedDataParallel per network, base.py:172-189) -------------

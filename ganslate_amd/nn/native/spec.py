@@ -1,4 +1,4 @@
-"""Lowering of nn.Conv2d / nn.ConvTranspose2d (forward, data-gradient, weight-gradient) onto the
+"""Lowering of nn.Conv2d/3d and nn.ConvTranspose2d/3d (forward, data-gradient, weight-gradient) onto the
 "generalised convolution" the HIP kernels implement (include/ganslate_hip.h: gs_gconv_desc / gs_wgrad_desc).
 
 Master weights live in the OTI layout [P][T][Q]:
@@ -10,7 +10,8 @@ the master by a gather (`pack index`, -1 = zero).
 
 Reference semantics restated here: ganslate/nn/generators/resnet/resnet2d.py:24-25,35,52-57,65,80-87 and
 ganslate/nn/discriminators/patchgan/patchgan2d.py:29,36-62 (layer hyper-parameters), torch.nn.Conv2d /
-ConvTranspose2d arithmetic.
+ConvTranspose2d arithmetic; the 3-D twins ganslate/nn/generators/resnet/resnet3d.py:24-64,78-84 and
+ganslate/nn/discriminators/patchgan/patchgan3d.py:28-60 lower through the same code with a real depth axis.
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -28,23 +29,24 @@ def roundup(x: int, m: int) -> int:
 
 @dataclass
 class ConvSpec:
-    """One convolution layer of the reference network."""
+    """One convolution layer of the reference network (nn.Conv2d/3d or nn.ConvTranspose2d/3d)."""
     kind: str                     # "conv" | "convT"
     cin: int
     cout: int
-    k: int                        # square kernels only (all hot-path layers are square)
+    k: int                        # cubic/square kernels only (all hot-path layers are)
     stride: int = 1
     pad: int = 0
-    out_pad: int = 0              # ConvTranspose2d output_padding
+    out_pad: int = 0              # ConvTranspose output_padding
     pad_mode: str = "zero"        # "zero" | "reflect" | "replicate" (explicit pad layer folded into the conv)
     bias: bool = True
+    dims: int = 2                 # 2 = Conv2d family, 3 = Conv3d family (resnet3d.py, patchgan3d.py)
 
     @property
     def cin_p(self): return pad8(self.cin)
     @property
     def cout_p(self): return pad8(self.cout)
     @property
-    def T(self): return self.k * self.k
+    def T(self): return self.k ** self.dims
     @property
     def P(self): return self.cout_p if self.kind == "conv" else self.cin_p
     @property
@@ -52,19 +54,21 @@ class ConvSpec:
     @property
     def master_numel(self): return self.P * self.T * self.Q
 
-    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+    def out_size(self, x: int) -> int:
         if self.kind == "conv":
-            f = lambda x: (x + 2 * self.pad - self.k) // self.stride + 1
-        else:
-            f = lambda x: (x - 1) * self.stride - 2 * self.pad + self.k + self.out_pad
-        return f(H), f(W)
+            return (x + 2 * self.pad - self.k) // self.stride + 1
+        return (x - 1) * self.stride - 2 * self.pad + self.k + self.out_pad
+
+    def out_hw(self, *sizes) -> Tuple[int, ...]:
+        return tuple(self.out_size(x) for x in sizes)
 
     # ---- torch <-> master layout ---------------------------------------------------------------
     def torch_weight_shape(self):
-        return (self.cout, self.cin, self.k, self.k) if self.kind == "conv" else (self.cin, self.cout, self.k, self.k)
+        io = (self.cout, self.cin) if self.kind == "conv" else (self.cin, self.cout)
+        return io + (self.k,) * self.dims
 
     def master_from_torch(self, w):
-        """torch weight (OIHW for conv, IOHW for convT) -> padded OTI master (numpy or torch)."""
+        """torch weight (OI[D]HW for conv, IO[D]HW for convT) -> padded OTI master (numpy or torch)."""
         import torch
         p, q = w.shape[0], w.shape[1]
         m = torch.zeros(self.P, self.T, self.Q, dtype=torch.float32, device=w.device)
@@ -73,12 +77,14 @@ class ConvSpec:
 
     def torch_from_master(self, m):
         p, q = (self.cout, self.cin) if self.kind == "conv" else (self.cin, self.cout)
-        return m.reshape(self.P, self.T, self.Q)[:p, :, :q].permute(0, 2, 1).reshape(p, q, self.k, self.k).contiguous()
+        return m.reshape(self.P, self.T, self.Q)[:p, :, :q].permute(0, 2, 1).reshape(
+            (p, q) + (self.k,) * self.dims).contiguous()
 
 
 @dataclass
 class GConv:
-    """One class of the generalised convolution (mirrors gs_gconv_desc, minus the batch/IO strides)."""
+    """One class of the generalised convolution (mirrors gs_gconv_desc, minus the batch/IO strides).
+    A 2-D layer is the depth-1 case (Di = Do = Dc = 1, pz = 0, dd = 0)."""
     Hi: int; Wi: int; Ci: int
     Ho: int; Wo: int; Co: int
     Hc: int; Wc: int
@@ -87,11 +93,22 @@ class GConv:
     border: str
     pack_offset: int = 0          # element offset of this class's [w_rows][Kp] block in the layer's pack
     w_rows: int = 0
+    Di: int = 1
+    Do: int = 1
+    Dc: int = 1
+    pz: int = 0
+    dd: Optional[List[int]] = None
+
+    def __post_init__(self):
+        if self.dd is None:
+            self.dd = [0] * len(self.dh)
 
     @property
     def T(self): return len(self.dh)
     @property
     def Kp(self): return roundup(self.T * self.Ci, 64)
+    @property
+    def pixels(self): return self.Dc * self.Hc * self.Wc
 
 
 @dataclass
@@ -101,6 +118,13 @@ class WGrad:
     si: int
     dh: List[int]; dw: List[int]
     border: str
+    Da: int = 1
+    Dg: int = 1
+    dd: Optional[List[int]] = None
+
+    def __post_init__(self):
+        if self.dd is None:
+            self.dd = [0] * len(self.dh)
 
     @property
     def T(self): return len(self.dh)
@@ -117,6 +141,19 @@ class Lowered:
     dgrad_index: Optional[np.ndarray] = None
     dgrad_fold: int = 0                           # dgrad output is padded by this much (reflect/replicate)
     wgrad: Optional[WGrad] = None
+    Di: int = 1
+    Do: int = 1
+
+    @property
+    def in_dims(self): return (self.Hi, self.Wi) if self.spec.dims == 2 else (self.Di, self.Hi, self.Wi)
+    @property
+    def out_dims(self): return (self.Ho, self.Wo) if self.spec.dims == 2 else (self.Do, self.Ho, self.Wo)
+    @property
+    def out_pixels(self): return self.Do * self.Ho * self.Wo
+    @property
+    def dgrad_dims(self):
+        """extent of the data-gradient tensor (the padded domain when the pad adjoint is left to the consumer)"""
+        return tuple(x + 2 * self.dgrad_fold for x in self.in_dims)
 
 
 def _pack_index(rows: int, taps_master: List[int], chan: int, master_idx) -> np.ndarray:
@@ -131,66 +168,85 @@ def _pack_index(rows: int, taps_master: List[int], chan: int, master_idx) -> np.
     return idx
 
 
-def lower(spec: ConvSpec, Hi: int, Wi: int) -> Lowered:
+def lower(spec: ConvSpec, *sizes) -> Lowered:
+    """sizes = (H, W) for dims == 2, (D, H, W) for dims == 3. Every axis follows the same 1-D rule; a 2-D layer gets
+    a dummy depth axis (extent 1, kernel 1, no padding)."""
+    assert len(sizes) == spec.dims, f"expected {spec.dims} spatial sizes, got {sizes}"
     k, s, p = spec.k, spec.stride, spec.pad
     T, P, Q = spec.T, spec.P, spec.Q
-    Ho, Wo = spec.out_hw(Hi, Wi)
-    low = Lowered(spec, Hi, Wi, Ho, Wo)
-    taps = [(r, c) for r in range(k) for c in range(k)]
+    real = (spec.dims == 3, True, True)
+    ins = ((1,) + tuple(sizes)) if spec.dims == 2 else tuple(sizes)
+    ka = tuple(k if r else 1 for r in real)               # kernel extent per axis
+    pa = tuple(p if r else 0 for r in real)               # padding per axis
+    outs = tuple(spec.out_size(x) if r else 1 for x, r in zip(ins, real))
+    Di, Hi, Wi = ins
+    Do, Ho, Wo = outs
+    low = Lowered(spec, Hi, Wi, Ho, Wo, Di=Di, Do=Do)
+    taps = [(a, b, c) for a in range(ka[0]) for b in range(ka[1]) for c in range(ka[2])]   # master tap order
+    off = lambda f: ([f(t[0], 0) for t in taps], [f(t[1], 1) for t in taps], [f(t[2], 2) for t in taps])
     m_conv = lambda row, t, ch: (row * T + t) * Q + ch      # master[row][t][ch]   (row = P index)
     m_tr = lambda row, t, ch: (ch * T + t) * Q + row        # master[ch][t][row]   (transposed roles)
 
-    def parity_classes(Hout, Wout, rows, chan, midx, in_h, in_w):
+    def gconv(i3, ci, o3, co, c3, so, ph, si, offs, border, pack_off, rows):
+        dd, dh, dw = offs
+        return GConv(i3[1], i3[2], ci, o3[1], o3[2], co, c3[1], c3[2], so, ph[1], ph[2], si, dh, dw, border,
+                     pack_off, rows, Di=i3[0], Do=o3[0], Dc=c3[0], pz=ph[0], dd=dd)
+
+    def parity_classes(out3, rows, chan, midx, in3):
         """stride-2 'transposed' gather: out[2i+py] = sum_{r:(py+p-r) even} in[i + (py+p-r)/2] * W[r]"""
-        classes, tables, off = [], [], 0
-        for py in range(2):
-            for px in range(2):
-                th = [(r, (py + p - r) // 2) for r in range(k) if (py + p - r) % 2 == 0]
-                tw = [(c, (px + p - c) // 2) for c in range(k) if (px + p - c) % 2 == 0]
-                Hc, Wc = (Hout - py + 1) // 2, (Wout - px + 1) // 2
-                if not th or not tw or Hc <= 0 or Wc <= 0:
-                    continue
-                tm = [r * k + c for r, _ in th for c, _ in tw]
-                g = GConv(in_h, in_w, chan, Hout, Wout, rows, Hc, Wc, 2, py, px, 1,
-                          [d for _, d in th for _ in tw], [d for _ in th for _, d in tw], "zero", off, rows)
-                tab = _pack_index(rows, tm, chan, midx)
-                classes.append(g); tables.append(tab.reshape(-1)); off += tab.size
+        classes, tables, poff = [], [], 0
+        axis_taps = lambda a, ph: [(r, (ph + pa[a] - r) // 2) for r in range(ka[a]) if (ph + pa[a] - r) % 2 == 0]
+        for pz in (range(2) if real[0] else range(1)):
+            for py in range(2):
+                for px in range(2):
+                    ph = (pz, py, px)
+                    at = [axis_taps(a, ph[a]) for a in range(3)]
+                    c3 = tuple((out3[a] - ph[a] + 1) // 2 if real[a] else 1 for a in range(3))
+                    if any(not t for t in at) or any(c <= 0 for c in c3):
+                        continue
+                    combos = [(a, b, c) for a in at[0] for b in at[1] for c in at[2]]
+                    tm = [(a[0] * ka[1] + b[0]) * ka[2] + c[0] for a, b, c in combos]
+                    offs = ([a[1] for a, _, _ in combos], [b[1] for _, b, _ in combos], [c[1] for _, _, c in combos])
+                    g = gconv(in3, chan, out3, rows, c3, 2, ph, 1, offs, "zero", poff, rows)
+                    tab = _pack_index(rows, tm, chan, midx)
+                    classes.append(g); tables.append(tab.reshape(-1)); poff += tab.size
         return classes, np.concatenate(tables)
 
     if spec.kind == "conv":
         assert s in (1, 2), "stride 1 or 2"
         # forward: out[i] = sum_r in[B(i*s + r - p)] W[r]
-        low.fwd = [GConv(Hi, Wi, spec.cin_p, Ho, Wo, spec.cout_p, Ho, Wo, 1, 0, 0, s,
-                         [r - p for r, _ in taps], [c - p for _, c in taps], spec.pad_mode, 0, spec.cout_p)]
+        fwd_offs = off(lambda r, a: r - pa[a])
+        low.fwd = [gconv(ins, spec.cin_p, outs, spec.cout_p, outs, 1, (0, 0, 0), s, fwd_offs, spec.pad_mode, 0,
+                         spec.cout_p)]
         low.fwd_index = _pack_index(spec.cout_p, list(range(T)), spec.cin_p, m_conv).reshape(-1)
         if s == 1:
             if spec.pad_mode == "zero":
                 # dX[ih] = sum_r dY[ih + p - r] W[:, r]^T
-                low.dgrad = [GConv(Ho, Wo, spec.cout_p, Hi, Wi, spec.cin_p, Hi, Wi, 1, 0, 0, 1,
-                                   [p - r for r, _ in taps], [p - c for _, c in taps], "zero", 0, spec.cin_p)]
+                low.dgrad = [gconv(outs, spec.cout_p, ins, spec.cin_p, ins, 1, (0, 0, 0), 1,
+                                   off(lambda r, a: pa[a] - r), "zero", 0, spec.cin_p)]
             else:
                 # gradient on the padded domain; the pad adjoint ("fold") is applied by the consumer
-                Hp, Wp = Hi + 2 * p, Wi + 2 * p
-                low.dgrad = [GConv(Ho, Wo, spec.cout_p, Hp, Wp, spec.cin_p, Hp, Wp, 1, 0, 0, 1,
-                                   [-r for r, _ in taps], [-c for _, c in taps], "zero", 0, spec.cin_p)]
+                pad3 = tuple(x + 2 * q for x, q in zip(ins, pa))
+                low.dgrad = [gconv(outs, spec.cout_p, pad3, spec.cin_p, pad3, 1, (0, 0, 0), 1,
+                                   off(lambda r, a: -r), "zero", 0, spec.cin_p)]
                 low.dgrad_fold = p
             low.dgrad_index = _pack_index(spec.cin_p, list(range(T)), spec.cout_p, m_tr).reshape(-1)
         else:
             assert spec.pad_mode == "zero", "strided convs use zero padding in the reference nets"
-            low.dgrad, low.dgrad_index = parity_classes(Hi, Wi, spec.cin_p, spec.cout_p, m_tr, Ho, Wo)
-        low.wgrad = WGrad(Ho, Wo, spec.cout_p, Hi, Wi, spec.cin_p, s,
-                          [r - p for r, _ in taps], [c - p for _, c in taps], spec.pad_mode)
+            low.dgrad, low.dgrad_index = parity_classes(ins, spec.cin_p, spec.cout_p, m_tr, outs)
+        dd, dh, dw = fwd_offs
+        low.wgrad = WGrad(Ho, Wo, spec.cout_p, Hi, Wi, spec.cin_p, s, dh, dw, spec.pad_mode, Da=Do, Dg=Di, dd=dd)
     else:
-        assert s == 2 and spec.pad_mode == "zero", "ConvTranspose2d: stride 2, zero padding"
+        assert s == 2 and spec.pad_mode == "zero", "ConvTranspose: stride 2, zero padding"
         # forward = parity classes; pack[co][t*cin+ci] = master[ci][t][co]
-        low.fwd, low.fwd_index = parity_classes(Ho, Wo, spec.cout_p, spec.cin_p, m_tr, Hi, Wi)
+        low.fwd, low.fwd_index = parity_classes(outs, spec.cout_p, spec.cin_p, m_tr, ins)
         # dgrad: dX[i] = sum_r dY[2i - p + r] W[:, r]  -> strided gather, master used as is
-        low.dgrad = [GConv(Ho, Wo, spec.cout_p, Hi, Wi, spec.cin_p, Hi, Wi, 1, 0, 0, 2,
-                           [r - p for r, _ in taps], [c - p for _, c in taps], "zero", 0, spec.cin_p)]
+        offs = off(lambda r, a: r - pa[a])
+        low.dgrad = [gconv(outs, spec.cout_p, ins, spec.cin_p, ins, 1, (0, 0, 0), 2, offs, "zero", 0, spec.cin_p)]
         low.dgrad_index = _pack_index(spec.cin_p, list(range(T)), spec.cout_p, m_conv).reshape(-1)
         # wgrad: dense = X, gathered = dY at (2i - p + r)
-        low.wgrad = WGrad(Hi, Wi, spec.cin_p, Ho, Wo, spec.cout_p, 2,
-                          [r - p for r, _ in taps], [c - p for _, c in taps], "zero")
+        dd, dh, dw = offs
+        low.wgrad = WGrad(Hi, Wi, spec.cin_p, Ho, Wo, spec.cout_p, 2, dh, dw, "zero", Da=Di, Dg=Do, dd=dd)
     low.fwd_index = low.fwd_index.astype(np.int32)
     low.dgrad_index = low.dgrad_index.astype(np.int32)
     return low

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GS_MAX_TAPS 128
+#define GS_MAX_TAPS 352   /* 7x7x7 = 343 taps of the 3-D stem / output convs (resnet3d.py:25,64) */
 
 /* border handling of the gathered operand (reference: nn.ReflectionPad2d resnet2d.py:24,
  * nn.ReplicationPad3d resnet3d.py:15, Conv2d(padding=1) zero padding resnet2d.py:35) */
@@ -37,13 +37,15 @@ enum { GS_BORDER_ZERO = 0, GS_BORDER_REFLECT = 1, GS_BORDER_REPLICATE = 2 };
 enum { GS_ACT_NONE = 0, GS_ACT_RELU = 1, GS_ACT_LRELU = 2, GS_ACT_TANH = 3 };
 
 /* One "generalised convolution" class:
- *   out[n, i*so+py, j*so+px, co] = bias[co] + sum_{t<T} sum_{ci<Ci}
- *        in[n, B(i*si+dh[t]), B(j*si+dw[t]), ci] * w[co][t*Ci+ci]          (i<Hc, j<Wc)
- * With so=1 it is nn.Conv2d forward (stride si) or the data-gradient of a stride-1 conv; with so=2 it
- * is one output-parity class of nn.ConvTranspose2d(stride=2) forward or of the data-gradient of a
- * stride-2 conv. B() applies `border`. */
+ *   out[n, z*so+pz, i*so+py, j*so+px, co] = bias[co] + sum_{t<T} sum_{ci<Ci}
+ *        in[n, B(z*si+dd[t]), B(i*si+dh[t]), B(j*si+dw[t]), ci] * w[co][t*Ci+ci]     (z<Dc, i<Hc, j<Wc)
+ * With so=1 it is nn.Conv2d/Conv3d forward (stride si) or the data-gradient of a stride-1 conv; with so=2
+ * it is one output-parity class of nn.ConvTranspose2d/3d(stride=2) forward or of the data-gradient of a
+ * stride-2 conv. B() applies `border`. 2-D tensors are the depth-1 case (Di=Do=Dc=1, pz=0, dd[]=0);
+ * volumes are NDHWC (resnet3d.py:25-64, patchgan3d.py:28-60). Di*Hi must stay below 32768. */
 typedef struct gs_gconv_desc {
   int32_t N, Hi, Wi, Ci;       /* gathered input: logical dims; Ci multiple of 8, Ci/8 a power of two */
+  int32_t Di, Do, Dc, pz;      /* depth of the input / output / class and the depth phase (1,1,1,0 in 2-D) */
   int32_t in_cs, in_co;        /* input channel stride / channel offset in elements (concat views) */
   int32_t Ho, Wo, Co;          /* full output dims; Co = number of channels written, multiple of 8 */
   int32_t out_cs, out_co;      /* output channel stride / offset */
@@ -59,18 +61,21 @@ typedef struct gs_gconv_desc {
   int32_t stats_slot0;         /* first slot this class writes; it writes ceil(Hc*Wc/tile_m) slots */
   int8_t  dh[GS_MAX_TAPS];
   int8_t  dw[GS_MAX_TAPS];
+  int8_t  dd[GS_MAX_TAPS];
 } gs_gconv_desc;
 
 /* Weight-gradient of the same family:
- *   dw[p][t*Q+q] += sum_{n,i,j} a[n,i,j,p] * g[n, B(i*si+dh[t]), B(j*si+dw[t]), q]
- * (`a` is the dense side: dY for Conv, X for ConvTranspose; `g` the gathered side). */
+ *   dw[p][t*Q+q] += sum_{n,z,i,j} a[n,z,i,j,p] * g[n, B(z*si+dd[t]), B(i*si+dh[t]), B(j*si+dw[t]), q]
+ * (`a` is the dense side: dY for Conv, X for ConvTranspose; `g` the gathered side; Da=Dg=1 in 2-D). */
 typedef struct gs_wgrad_desc {
   int32_t N, Ha, Wa, P, a_cs, a_co;
   int32_t Hg, Wg, Q, g_cs, g_co;    /* Q multiple of 8, Q/8 a power of two */
+  int32_t Da, Dg;
   int32_t si, T, border;
   int32_t dw_ld;                    /* leading dimension of dw rows = T*Q */
   int8_t  dh[GS_MAX_TAPS];
   int8_t  dw_[GS_MAX_TAPS];
+  int8_t  dd[GS_MAX_TAPS];
 } gs_wgrad_desc;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -94,18 +99,19 @@ int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C,
 /* x = act((y-mean)*rstd) [+ res]   (resnet2d.py:26-27, 83-84, 87, 93) */
 int gs_inorm_act_forward(const void* y, const float* mean_rstd, const void* res, void* x, int32_t N,
                          int64_t hw, int32_t C, int32_t act, float slope, void* stream);
-/* Backward of the above. g_pad is the incoming gradient on a domain padded by `fold` on each side
- * (the data-gradient of a reflect/replicate-padded conv; fold=0 for a plain gradient) — the border is
- * folded back here (adjoint of ReflectionPad2d). g2 (optional, unpadded) is added (residual join).
+/* Backward of the above. g_pad is the incoming gradient on a domain padded by `fold` on each side of every
+ * spatial axis with extent > 1 (the data-gradient of a reflect/replicate-padded conv; fold=0 for a plain gradient)
+ * — the border is folded back here (adjoint of nn.ReflectionPad2d resnet2d.py:24 / nn.ReplicationPad3d
+ * resnet3d.py:24,78). D = 1 for 2-D tensors. g2 (optional, unpadded) is added (residual join).
  * Outputs dy (gradient w.r.t. the conv output y) and optionally gsum = fold(g_pad)+g2 (skip path).
  * If mean_rstd is NULL there is no norm: `y` then holds the activation OUTPUT and dy = g*act'(y).
  * bias_grad (optional, norm only): db[c] += sum over pixels of dy — the gradient of the bias of the conv in front
  * of the norm, obtained from the reduction sums (it is identically zero up to rounding, like the reference's). */
 int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
-                          void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t H, int32_t W,
-                          int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
+                          void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t D, int32_t H,
+                          int32_t W, int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
                           void* stream);
-int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t H, int32_t W, int32_t C);
+int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t D, int32_t H, int32_t W, int32_t C);
 
 /* Generalised form for skip-connection graphs (nn/generators/unet/unet2d.py:110-157): the normalised tensor is read
  * through up to two activations (LeakyReLU by the next down-conv, ReLU by the up-conv on the skip half of
@@ -140,8 +146,9 @@ int gs_act_to_image(const void* act, float* img, int32_t N, int32_t C, int32_t H
 int gs_act_to_image_backward(const float* g_img, const float* out_img, void* g_act, int32_t N, int32_t C,
                              int32_t H, int32_t W, int32_t Cp, int32_t act_kind, void* stream);
 /* gradient of gs_image_to_act composed with the first conv's padding fold: g_pad act (padded by fold)
- * -> NCHW fp32 image gradient; accumulate != 0 adds into g_img */
-int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t H, int32_t W,
+ * -> NC(D)HW fp32 image gradient; accumulate != 0 adds into g_img. The other three boundary functions are
+ * layout-only: a volume goes through them with H := D*H. */
+int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                              int32_t Cp, int32_t fold, int32_t fold_mode, int32_t accumulate, void* stream);
 
 /* ---- losses (fp32, on the boundary images / discriminator maps) --------------------------------- */

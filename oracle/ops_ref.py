@@ -52,18 +52,24 @@ def _act_grad_from_out(o, act, slope):
     return torch.ones_like(o)
 
 
-def _fold(gpad, H, W, fold, mode="reflect"):
-    """adjoint of ReflectionPad2d(fold) on an NHWC tensor padded by `fold`"""
+def _v5(t):
+    """channels-last activation viewed as [N, D, H, W, C] (a 2-D tensor is the depth-1 volume)"""
+    return t if t.dim() == 5 else t.unsqueeze(1)
+
+
+def _fold(gpad, dims, fold, mode="reflect"):
+    """adjoint of ReflectionPad2d / ReplicationPad3d(fold) (resnet2d.py:24, resnet3d.py:24) on a channels-last
+    tensor padded by `fold` along every spatial axis; dims = unpadded spatial extents"""
     if fold == 0:
         return gpad
-    assert mode == "reflect"
-    N, Hp, Wp, C = gpad.shape
-    out = torch.zeros(N, H, W, C, dtype=gpad.dtype)
-    ih, _ = _border(torch.arange(Hp) - fold, H, "reflect")
-    iw, _ = _border(torch.arange(Wp) - fold, W, "reflect")
-    tmp = torch.zeros(N, H, Wp, C, dtype=gpad.dtype)
-    tmp.index_add_(1, ih, gpad)
-    out.index_add_(2, iw, tmp)
+    out = gpad
+    for ax, n in enumerate(dims, start=1):
+        src, _ = _border(torch.arange(n + 2 * fold) - fold, n, mode)
+        shape = list(out.shape)
+        shape[ax] = n
+        nxt = torch.zeros(shape, dtype=out.dtype)
+        nxt.index_add_(ax, src, out)
+        out = nxt
     return out
 
 
@@ -83,39 +89,46 @@ class RefOps:
     def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
               stats=None, stats_slots=0, stats_slot0=0):
         N = x.shape[0]
-        xin = x[..., in_co:in_co + g.Ci].float()
+        xin = _v5(x)[..., in_co:in_co + g.Ci].float()
         Wt = wpack[g.pack_offset:g.pack_offset + g.w_rows * g.Kp].view(g.w_rows, g.Kp).float()
         Wt = Wt[:g.Co, :g.T * g.Ci].reshape(g.Co, g.T, g.Ci)
+        z = torch.arange(g.Dc) * g.si
         i = torch.arange(g.Hc) * g.si
         j = torch.arange(g.Wc) * g.si
-        acc = torch.zeros(N, g.Hc, g.Wc, g.Co)
+        acc = torch.zeros(N, g.Dc, g.Hc, g.Wc, g.Co)
         for t in range(g.T):
+            iz, okz = _border(z + g.dd[t], g.Di, g.border)
             ih, okh = _border(i + g.dh[t], g.Hi, g.border)
             iw, okw = _border(j + g.dw[t], g.Wi, g.border)
-            patch = xin[:, ih][:, :, iw] * (okh[:, None] & okw[None, :]).float()[None, :, :, None]
+            ok = (okz[:, None, None] & okh[None, :, None] & okw[None, None, :]).float()
+            patch = xin[:, iz][:, :, ih][:, :, :, iw] * ok[None, :, :, :, None]
             acc += patch @ Wt[:, t, :].t()
         if bias is not None:
             acc += bias[:g.Co].float()
         if stats_slots > 0:
             sv = stats.view(N, stats_slots, 2, g.Co)
-            sv[:, stats_slot0, 0] = acc.sum((1, 2))
-            sv[:, stats_slot0, 1] = (acc * acc).sum((1, 2))
+            sv[:, stats_slot0, 0] = acc.sum((1, 2, 3))
+            sv[:, stats_slot0, 1] = (acc * acc).sum((1, 2, 3))
         acc = _act(acc, act, slope)
+        oz = torch.arange(g.Dc) * g.so + g.pz
         oh = torch.arange(g.Hc) * g.so + g.py
         ow = torch.arange(g.Wc) * g.so + g.px
-        out[:, oh[:, None], ow[None, :], out_co:out_co + g.Co] = acc.to(out.dtype)
+        _v5(out)[:, oz[:, None, None], oh[None, :, None], ow[None, None, :], out_co:out_co + g.Co] = acc.to(out.dtype)
 
     def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
-        av = a[..., a_co:a_co + w.P].float()
-        gv = g[..., g_co:g_co + w.Q].float()
+        av = _v5(a)[..., a_co:a_co + w.P].float()
+        gv = _v5(g)[..., g_co:g_co + w.Q].float()
+        z = torch.arange(w.Da) * w.si
         i = torch.arange(w.Ha) * w.si
         j = torch.arange(w.Wa) * w.si
         d = dw.view(w.P, w.T, w.Q)
         for t in range(w.T):
+            iz, okz = _border(z + w.dd[t], w.Dg, w.border)
             ih, okh = _border(i + w.dh[t], w.Hg, w.border)
             iw, okw = _border(j + w.dw[t], w.Wg, w.border)
-            patch = gv[:, ih][:, :, iw] * (okh[:, None] & okw[None, :]).float()[None, :, :, None]
-            d[:, t, :] += torch.einsum("nijp,nijq->pq", av, patch)
+            ok = (okz[:, None, None] & okh[None, :, None] & okw[None, None, :]).float()
+            patch = gv[:, iz][:, :, ih][:, :, :, iw] * ok[None, :, :, :, None]
+            d[:, t, :] += torch.einsum("nzijp,nzijq->pq", av, patch)
 
     def bias_grad(self, dy, C_, db, *, cs=None, co=0):
         db[:C_] += dy[..., co:co + C_].float().reshape(-1, C_).sum(0)
@@ -130,9 +143,10 @@ class RefOps:
         mr[:, 1] = (1.0 / torch.sqrt(var + eps)).float()
 
     def inorm_act_forward(self, y, mean_rstd, res, x, act="none", slope=0.2):
-        N, H, W, Cc = y.shape
+        N, Cc = y.shape[0], y.shape[-1]
+        bc = (N,) + (1,) * (y.dim() - 2) + (Cc,)
         mr = mean_rstd.view(N, 2, Cc)
-        v = (y.float() - mr[:, 0][:, None, None, :]) * mr[:, 1][:, None, None, :]
+        v = (y.float() - mr[:, 0].reshape(bc)) * mr[:, 1].reshape(bc)
         v = _act(v, act, slope)
         if res is not None:
             v = v + res.float()
@@ -140,8 +154,10 @@ class RefOps:
 
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
                            slope=0.2, bias_grad=None):
-        N, H, W, Cc = y.shape
-        g = _fold(g_pad.float(), H, W, fold, fold_mode)
+        N, Cc = y.shape[0], y.shape[-1]
+        sp = tuple(range(1, y.dim() - 1))
+        bc = (N,) + (1,) * (y.dim() - 2) + (Cc,)
+        g = _fold(g_pad.float(), y.shape[1:-1], fold, fold_mode)
         if g2 is not None:
             g = g + g2.float()
         if gsum is not None:
@@ -150,15 +166,15 @@ class RefOps:
             dy.copy_((g * _act_grad_from_out(y.float(), act, slope)).to(dy.dtype))
             return
         mr = mean_rstd.view(N, 2, Cc)
-        rstd = mr[:, 1][:, None, None, :]
-        yh = (y.float() - mr[:, 0][:, None, None, :]) * rstd
+        rstd = mr[:, 1].reshape(bc)
+        yh = (y.float() - mr[:, 0].reshape(bc)) * rstd
         gh = g * _act_grad_from_out(yh, act, slope)
-        s1 = gh.mean((1, 2), keepdim=True)
-        s2 = (gh * yh).mean((1, 2), keepdim=True)
+        s1 = gh.mean(sp, keepdim=True)
+        s2 = (gh * yh).mean(sp, keepdim=True)
         d = rstd * (gh - s1 - yh * s2)
         dy.copy_(d.to(dy.dtype))
         if bias_grad is not None:      # sum over pixels of dy: identically zero up to rounding
-            bias_grad[:Cc] += d.sum((0, 1, 2))
+            bias_grad[:Cc] += d.reshape(-1, Cc).sum(0)
 
     # ---- generalised norm / activation for skip-connection graphs (U-Net) -------------------------------
     @staticmethod
@@ -218,13 +234,13 @@ class RefOps:
 
     # ---- network boundary --------------------------------------------------------------------------------
     def image_to_act(self, img, act_t):
-        N, Cc, H, W = img.shape
+        Cc = img.shape[1]
         act_t.zero_()
-        act_t[..., :Cc] = img.permute(0, 2, 3, 1).to(act_t.dtype)
+        act_t[..., :Cc] = img.movedim(1, -1).to(act_t.dtype)
 
     def act_to_image(self, act_t, img, act="none"):
         Cc = img.shape[1]
-        img.copy_(_act(act_t[..., :Cc].float(), act, 0.0).permute(0, 3, 1, 2))
+        img.copy_(_act(act_t[..., :Cc].float(), act, 0.0).movedim(-1, 1))
 
     def act_to_image_backward(self, g_img, out_img, g_act, act="none"):
         Cc = g_img.shape[1]
@@ -232,11 +248,11 @@ class RefOps:
         if act != "none":
             g = g * _act_grad_from_out(out_img, act, 0.0)
         g_act.zero_()
-        g_act[..., :Cc] = g.permute(0, 2, 3, 1).to(g_act.dtype)
+        g_act[..., :Cc] = g.movedim(1, -1).to(g_act.dtype)
 
     def image_to_act_backward(self, g_pad, g_img, fold=0, fold_mode="reflect", accumulate=False):
-        N, Cc, H, W = g_img.shape
-        g = _fold(g_pad.float(), H, W, fold, fold_mode)[..., :Cc].permute(0, 3, 1, 2)
+        Cc = g_img.shape[1]
+        g = _fold(g_pad.float(), g_img.shape[2:], fold, fold_mode)[..., :Cc].movedim(-1, 1)
         if accumulate:
             g_img += g
         else:

@@ -3,6 +3,7 @@
 Network- and step-level CPU restatement of the reference hot path in plain torch fp32 (torch.nn + autograd):
   * Resnet2D            ganslate/nn/generators/resnet/resnet2d.py:14-93
   * PatchGAN2D          ganslate/nn/discriminators/patchgan/patchgan2d.py:17-66
+  * Resnet3D/PatchGAN3D ganslate/nn/generators/resnet/resnet3d.py:14-92, .../patchgan/patchgan3d.py:17-65
   * AdversarialLoss     ganslate/nn/losses/adversarial_loss.py:7-98 (lsgan / vanilla / wgangp)
   * CycleGAN losses     ganslate/nn/losses/cyclegan_losses.py:7-101
   * ImagePool           ganslate/data/utils/image_pool.py:5-60
@@ -68,6 +69,61 @@ class PatchGAN2D(nn.Module):
         prev, mult = mult, min(2 ** n_layers, 8)
         seq += [nn.Conv2d(ndf * prev, ndf * mult, kw, 1, 1), nn.InstanceNorm2d(ndf * mult), nn.LeakyReLU(0.2, True)]
         seq += [nn.Conv2d(ndf * mult, 1, kw, 1, 1)]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _Residual3D(nn.Module):
+    """ganslate/nn/generators/resnet/resnet3d.py:70-92 restated"""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.conv_block = nn.Sequential(
+            nn.ReplicationPad3d(1), nn.Conv3d(ch, ch, 3), nn.InstanceNorm3d(ch), nn.ReLU(True),
+            nn.ReplicationPad3d(1), nn.Conv3d(ch, ch, 3), nn.InstanceNorm3d(ch))
+
+    def forward(self, x):
+        return x + self.conv_block(x)
+
+
+class Resnet3D(nn.Module):
+    """ganslate/nn/generators/resnet/resnet3d.py:14-67 restated (replication padding, no `encoder` alias)"""
+
+    def __init__(self, in_channels, out_channels, n_residual_blocks=9):
+        super().__init__()
+        layers = [nn.ReplicationPad3d(3), nn.Conv3d(in_channels, 64, 7), nn.InstanceNorm3d(64), nn.ReLU(True)]
+        ch = 64
+        for _ in range(2):
+            layers += [nn.Conv3d(ch, ch * 2, 3, stride=2, padding=1), nn.InstanceNorm3d(ch * 2), nn.ReLU(True)]
+            ch *= 2
+        layers += [_Residual3D(ch) for _ in range(n_residual_blocks)]
+        for _ in range(2):
+            layers += [nn.ConvTranspose3d(ch, ch // 2, 3, stride=2, padding=1, output_padding=1),
+                       nn.InstanceNorm3d(ch // 2), nn.ReLU(True)]
+            ch //= 2
+        layers += [nn.ReplicationPad3d(3), nn.Conv3d(64, out_channels, 7), nn.Tanh()]
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class PatchGAN3D(nn.Module):
+    """ganslate/nn/discriminators/patchgan/patchgan3d.py:17-65 restated"""
+
+    def __init__(self, in_channels, ndf=64, n_layers=3, kernel_size=4):
+        super().__init__()
+        kw = kernel_size
+        seq = [nn.Conv3d(in_channels, ndf, kw, 2, 1), nn.LeakyReLU(0.2, True)]
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            seq += [nn.Conv3d(ndf * prev, ndf * mult, kw, 2, 1), nn.InstanceNorm3d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        prev, mult = mult, min(2 ** n_layers, 8)
+        seq += [nn.Conv3d(ndf * prev, ndf * mult, kw, 1, 1), nn.InstanceNorm3d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        seq += [nn.Conv3d(ndf * mult, 1, kw, 1, 1)]
         self.model = nn.Sequential(*seq)
 
     def forward(self, x):

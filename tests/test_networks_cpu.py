@@ -69,6 +69,17 @@ def test_patchgan2d_forward_backward(fp32_oracle_backend, in_ch, n_layers, hw):
              (2, in_ch, *hw), 33)
 
 
+def test_resnet3d_forward_backward(fp32_oracle_backend):
+    """3-D twin: replication padding (fold of the padded-domain gradients), 27-tap convs, 8 parity classes"""
+    from ganslate_amd.nn.generators import Resnet3D
+    _compare(Resnet3D(1, 1, "instance", 2), torch_ref.Resnet3D(1, 1, 2), (1, 1, 8, 12, 16), 41)
+
+
+def test_patchgan3d_forward_backward(fp32_oracle_backend):
+    from ganslate_amd.nn.discriminators import PatchGAN3D
+    _compare(PatchGAN3D(1, 16, 2, (4, 4, 4), "instance"), torch_ref.PatchGAN3D(1, 16, 2, 4), (2, 1, 16, 24, 16), 42)
+
+
 def test_frozen_network_gets_no_weight_gradients(fp32_oracle_backend):
     """set_requires_grad(D, False) during the G step: input gradient flows, parameter gradients do not (K20)"""
     from ganslate_amd.nn.discriminators import PatchGAN2D

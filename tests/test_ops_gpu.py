@@ -32,12 +32,23 @@ CONV_CASES = [
     (ConvSpec("conv", 64, 128, 3, 2, 1), 4, 128, 128),                        # K2 d128
     (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 4, 64, 64),                     # K4 u128
     (ConvSpec("conv", 128, 256, 4, 2, 1), 8, 64, 64),                         # PatchGAN conv3
+    # 3-D twins (resnet3d.py / patchgan3d.py): (spec, N, D, H, W)
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 8, 8, 8),      # residual conv
+    (ConvSpec("conv", 1, 64, 7, 1, 3, pad_mode="replicate", dims=3), 1, 12, 10, 16),      # stem: 343 taps, Cin 1 -> 8
+    (ConvSpec("conv", 64, 128, 3, 2, 1, dims=3), 1, 16, 16, 16),                          # down-sampling
+    (ConvSpec("conv", 128, 256, 3, 2, 1, dims=3), 1, 9, 11, 13),                          # odd sizes
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1, dims=3), 1, 6, 8, 8),                        # up-sampling, 8 classes
+    (ConvSpec("conv", 64, 1, 7, 1, 3, pad_mode="replicate", dims=3), 1, 12, 12, 12),      # output conv (K = 21952)
+    (ConvSpec("conv", 1, 64, 4, 2, 1, dims=3), 2, 16, 16, 16),                            # PatchGAN3D first
+    (ConvSpec("conv", 128, 256, 4, 1, 1, dims=3), 1, 10, 10, 10),                         # stride-1 k4 (ragged 9^3)
+    (ConvSpec("conv", 256, 1, 4, 1, 1, dims=3), 2, 7, 7, 7),                              # last (Cout 1 -> 8)
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),   # BASELINE cfg5 RB size
 ]
 
 
 def _ids(c):
-    s, N, H, W = c
-    return f"{s.kind}{s.k}s{s.stride}{s.pad_mode}-{s.cin}x{s.cout}-{N}x{H}x{W}"
+    s, N, sizes = c[0], c[1], c[2:]
+    return f"{s.kind}{s.k}s{s.stride}{s.pad_mode}-{s.cin}x{s.cout}-{N}x" + "x".join(map(str, sizes))
 
 
 def close_bf16(got, ref, what):
@@ -54,9 +65,9 @@ def close_f32(got, ref, what, rel=2e-3):
     assert err <= rel * scale + 1e-6, f"{what}: max err {err} vs scale {scale}"
 
 
-def make_layer(spec, H, W, seed):
+def make_layer(spec, sizes, seed):
     g = torch.Generator().manual_seed(seed)
-    low = lower(spec, H, W)
+    low = lower(spec, *sizes)
     w = torch.randn(spec.torch_weight_shape(), generator=g) * 0.05
     master = spec.master_from_torch(w)
     bias = torch.zeros(spec.cout_p)
@@ -73,13 +84,13 @@ def stats_slots(ops, low, classes, N):
     slots, offs = 0, []
     for g in classes:
         offs.append(slots)
-        slots += (g.Hc * g.Wc + ops.tile_m(g, N) - 1) // ops.tile_m(g, N)
+        slots += (g.pixels + ops.tile_m(g, N) - 1) // ops.tile_m(g, N)
     return slots, offs
 
 
 def run_forward(ops, dev, low, bias, fpack, xa, N, act="none"):
     spec = low.spec
-    ya = torch.zeros(N, low.Ho, low.Wo, spec.cout_p, dtype=torch.bfloat16, device=dev)
+    ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
     slots, offs = stats_slots(ops, low, low.fwd, N)
     # NaN-filled: every slot must be written by the kernel (a stale slot count shows up as NaN statistics)
     part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
@@ -87,17 +98,17 @@ def run_forward(ops, dev, low, bias, fpack, xa, N, act="none"):
         ops.gconv(g, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act=act, stats=part, stats_slots=slots,
                   stats_slot0=o)
     mr = torch.empty(N * 2 * spec.cout_p, dtype=torch.float32, device=dev)
-    ops.inorm_finalize(part, N, slots, spec.cout_p, low.Ho * low.Wo, mr)
+    ops.inorm_finalize(part, N, slots, spec.cout_p, low.out_pixels, mr)
     return ya, mr
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=_ids)
 def test_gconv_forward_stats(hip_ops, case):
-    spec, N, H, W = case
-    low, master, bias, fpack, dpack = make_layer(spec, H, W, 1)
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 1)
     g = torch.Generator().manual_seed(2)
-    xa = torch.zeros(N, H, W, spec.cin_p, dtype=torch.bfloat16)
-    xa[..., :spec.cin] = torch.randn(N, H, W, spec.cin, generator=g).to(torch.bfloat16)
+    xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
+    xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
     y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N)
     y_hip, mr_hip = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N)
     torch.cuda.synchronize()
@@ -111,7 +122,7 @@ def test_gconv_forward_stats(hip_ops, case):
 @pytest.mark.parametrize("act", ["lrelu", "relu", "tanh"])
 def test_gconv_epilogue_activation(hip_ops, act):
     spec, N, H, W = ConvSpec("conv", 3, 64, 4, 2, 1), 2, 32, 32
-    low, master, bias, fpack, dpack = make_layer(spec, H, W, 3)
+    low, master, bias, fpack, dpack = make_layer(spec, (H, W), 3)
     xa = torch.zeros(N, H, W, spec.cin_p, dtype=torch.bfloat16)
     xa[..., :3] = torch.randn(N, H, W, 3, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16)
     y_ref, _ = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N, act=act)
@@ -121,15 +132,14 @@ def test_gconv_epilogue_activation(hip_ops, act):
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=_ids)
 def test_dgrad(hip_ops, case):
-    spec, N, H, W = case
-    low, master, bias, fpack, dpack = make_layer(spec, H, W, 5)
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 5)
     g = torch.Generator().manual_seed(6)
-    gy = torch.zeros(N, low.Ho, low.Wo, spec.cout_p, dtype=torch.bfloat16)
-    gy[..., :spec.cout] = torch.randn(N, low.Ho, low.Wo, spec.cout, generator=g).to(torch.bfloat16)
-    f = low.dgrad_fold
+    gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., :spec.cout] = torch.randn(N, *low.out_dims, spec.cout, generator=g).to(torch.bfloat16)
     outs = []
     for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
-        gx = torch.zeros(N, H + 2 * f, W + 2 * f, spec.cin_p, dtype=torch.bfloat16, device=dev)
+        gx = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16, device=dev)
         for gc in low.dgrad:
             ops.gconv(gc, gy.to(dev), dpack.to(dev), None, gx)
         outs.append(gx)
@@ -138,13 +148,13 @@ def test_dgrad(hip_ops, case):
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=_ids)
 def test_wgrad_and_bias_grad(hip_ops, case):
-    spec, N, H, W = case
-    low = lower(spec, H, W)
+    spec, N, sizes = case[0], case[1], case[2:]
+    low = lower(spec, *sizes)
     g = torch.Generator().manual_seed(7)
-    xa = torch.zeros(N, H, W, spec.cin_p, dtype=torch.bfloat16)
-    xa[..., :spec.cin] = torch.randn(N, H, W, spec.cin, generator=g).to(torch.bfloat16)
-    gy = torch.zeros(N, low.Ho, low.Wo, spec.cout_p, dtype=torch.bfloat16)
-    gy[..., :spec.cout] = torch.randn(N, low.Ho, low.Wo, spec.cout, generator=g).to(torch.bfloat16)
+    xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
+    xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
+    gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., :spec.cout] = torch.randn(N, *low.out_dims, spec.cout, generator=g).to(torch.bfloat16)
     a, gt = (gy, xa) if spec.kind == "conv" else (xa, gy)
     res = []
     for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
@@ -198,6 +208,59 @@ def test_inorm_forward_backward(hip_ops, shape, act, res):
             close_bf16(outs[1][2], outs[0][2], "gsum")
         close_bf16(outs[1][3], outs[0][3], "act bwd")
         close_f32(outs[1][4], outs[0][4], "mean/rstd", rel=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 9, 10, 64), (2, 5, 7, 6, 256), (1, 20, 24, 28, 8)])
+@pytest.mark.parametrize("act", ["relu", "none"])
+def test_inorm_backward_3d_replicate_fold(hip_ops, shape, act):
+    """InstanceNorm3d backward with the nn.ReplicationPad3d adjoint folded in (resnet3d.py:24,78-84)"""
+    N, D, H, W, C = shape
+    g = torch.Generator().manual_seed(18)
+    y = (torch.randn(N, D, H, W, C, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    for fold in (0, 1, 3):
+        gp = torch.randn(N, D + 2 * fold, H + 2 * fold, W + 2 * fold, C, generator=g).to(torch.bfloat16)
+        g2 = torch.randn(N, D, H, W, C, generator=g).to(torch.bfloat16)
+        outs = []
+        for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+            yd = y.to(dev)
+            part = torch.zeros(N * 2 * C, dtype=torch.float32, device=dev)
+            pv = part.view(N, 1, 2, C)
+            pv[:, 0, 0] = yd.float().sum((1, 2, 3))
+            pv[:, 0, 1] = (yd.float() ** 2).sum((1, 2, 3))
+            mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+            ops.inorm_finalize(part, N, 1, C, D * H * W, mr)
+            x = torch.empty_like(yd)
+            ops.inorm_act_forward(yd, mr, g2.to(dev), x, act=act)
+            dy, gsum = torch.empty_like(yd), torch.empty_like(yd)
+            ops.inorm_act_backward(gp.to(dev), g2.to(dev), yd, mr, dy, gsum, fold=fold, fold_mode="replicate", act=act)
+            outs.append((x, dy, gsum))
+        close_bf16(outs[1][0], outs[0][0], "inorm3d fwd")
+        close_bf16(outs[1][1], outs[0][1], f"inorm3d bwd fold={fold}")
+        close_bf16(outs[1][2], outs[0][2], f"gsum fold={fold}")
+
+
+def test_image_boundary_3d(hip_ops):
+    N, C, Cp, D, H, W = 2, 1, 8, 6, 10, 12
+    g = torch.Generator().manual_seed(19)
+    img = torch.rand(N, C, D, H, W, generator=g) * 2 - 1
+    gimg = torch.randn(N, C, D, H, W, generator=g)
+    for fold in (0, 3):
+        gpad = torch.randn(N, D + 2 * fold, H + 2 * fold, W + 2 * fold, Cp, generator=g).to(torch.bfloat16)
+        outs = []
+        for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+            a = torch.empty(N, D, H, W, Cp, dtype=torch.bfloat16, device=dev)
+            ops.image_to_act(img.to(dev), a)
+            o = torch.empty(N, C, D, H, W, device=dev)
+            ops.act_to_image(a, o, act="tanh")
+            ga = torch.empty(N, D, H, W, Cp, dtype=torch.bfloat16, device=dev)
+            ops.act_to_image_backward(gimg.to(dev), o, ga, act="tanh")
+            gi = torch.ones(N, C, D, H, W, device=dev)
+            ops.image_to_act_backward(gpad.to(dev), gi, fold=fold, fold_mode="replicate", accumulate=True)
+            outs.append((a, o, ga, gi))
+        assert torch.equal(outs[1][0].cpu(), outs[0][0]), "image_to_act must be bit-exact"
+        close_f32(outs[1][1], outs[0][1], "act_to_image tanh", rel=1e-5)
+        close_bf16(outs[1][2], outs[0][2], "act_to_image bwd")
+        close_f32(outs[1][3], outs[0][3], "image_to_act bwd", rel=1e-5)
 
 
 @pytest.mark.parametrize("C,Cp", [(3, 8), (1, 8), (6, 8)])
