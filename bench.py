@@ -49,6 +49,32 @@ def make_pix2pix_conf(batch, n_iters):
     return init_config(y, Config)
 
 
+def make_volume_conf(batch, size, n_iters):
+    """BASELINE configs[4] shape family (3-D CycleGAN on 128^3 single-channel patches, conv3d implicit GEMM) with the
+    reference's Resnet3D(9 blocks) + PatchGAN3D(3 layers) (33.2 TFLOP per pair)"""
+    from ganslate_amd.configs.config import Config
+    from ganslate_amd.configs.omegalite import OmegaConf
+    from ganslate_amd.configs.utils import init_config
+    y = OmegaConf.create({
+        "train": {
+            "output_dir": "/tmp/ganslate_amd_bench", "cuda": True, "batch_size": batch,
+            "n_iters": n_iters, "n_iters_decay": n_iters,
+            "dataset": {"_target_": "ganslate.data.SyntheticImageDataset", "image_channels": 1,
+                        "final_size": [size, size, size]},
+            "gan": {
+                "_target_": "ganslate.nn.gans.unpaired.CycleGAN", "pool_size": 50,
+                "generator": {"_target_": "ganslate.nn.generators.Resnet3D", "n_residual_blocks": 9,
+                              "in_out_channels": {"AB": [1, 1]}},
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN3D", "n_layers": 3,
+                                  "in_channels": {"B": 1}},
+                "optimizer": {"lambda_AB": 10.0, "lambda_BA": 10.0, "lambda_identity": 0, "proportion_ssim": 0,
+                              "lr_D": 0.0002, "lr_G": 0.0002},
+            },
+            "metrics": {"discriminator_evolution": True, "ssim": False},
+        }})
+    return init_config(y, Config)
+
+
 def make_conf(batch, size, n_iters):
     from ganslate_amd.configs.config import Config
     from ganslate_amd.configs.omegalite import OmegaConf
@@ -102,8 +128,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix"],
-                    help="cyclegan = the headline (BASELINE configs[1]); pix2pix = configs[2] (batch 1, 256x512)")
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cyclegan3d"],
+                    help="cyclegan = the headline (BASELINE configs[1]); pix2pix = configs[2] (batch 1, 256x512); "
+                         "cyclegan3d = 3-D CycleGAN on 128^3 volumes (configs[4] shape, batch 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -130,6 +157,14 @@ def main():
             args.batch = 1
         model = build_gan(make_pix2pix_conf(args.batch, 10 ** 6))
         shape = (args.batch, 3, 256, 512)
+    elif args.workload == "cyclegan3d":
+        args.no_cpu_baseline = True
+        if args.batch == 8:
+            args.batch = 1
+        if args.size == 256:
+            args.size = 128
+        model = build_gan(make_volume_conf(args.batch, args.size, 10 ** 6))
+        shape = (args.batch, 1, args.size, args.size, args.size)
     else:
         model = build_gan(make_conf(args.batch, args.size, 10 ** 6))
         shape = (args.batch, 3, args.size, args.size)
@@ -148,8 +183,9 @@ def main():
     if not args.no_kernel_timing:
         # HIP events around every launch of the dominant kernel (residual-block 3x3 conv, forward form) on the
         # stream it is launched on (torch's current stream)
-        timing = ops.enable_kernel_timing(lambda g: g.T == 9 and g.Ci == 256 and g.Co == 256 and g.si == 1
-                                          and g.border == "reflect")
+        rb_taps, rb_border = (27, "replicate") if args.workload == "cyclegan3d" else (9, "reflect")
+        timing = ops.enable_kernel_timing(lambda g: g.T == rb_taps and g.Ci == 256 and g.Co == 256 and g.si == 1
+                                          and g.border == rb_border)
 
     torch.cuda.synchronize()
     if world > 1:
@@ -168,7 +204,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    losses = {k: float(v) for k, v in model.losses.items() if v is not None}
+    losses = {k: float(v.detach()) for k, v in model.losses.items() if v is not None}
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), f"non-finite losses: {losses}"
 
     if rank == 0 and args.workload == "pix2pix":
@@ -180,6 +216,30 @@ def main():
                           "data": "synthetic", "config": {"workload": "cityscapes pix2pix (BASELINE configs[2])",
                                                           "global_batch": args.batch * world},
                           "step_tflops": round(value * 371.5 / 1e3, 1)}), flush=True)
+    elif rank == 0 and args.workload == "cyclegan3d":
+        value = args.batch * world * args.steps / dt
+        tflop_per_pair = 33.2 * (args.size / 128.0) ** 3          # SURVEY.md §8 row a15 at 128^3
+        out = {"metric": "training volumes/sec, 3-D CycleGAN Resnet3D-9 + PatchGAN3D-3 bf16",
+               "value": round(value, 4), "unit": "vol/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic",
+               "config": {"workload": f"3-D CycleGAN {args.size}^3 single-channel patches (BASELINE configs[4] "
+                                      "shape), Resnet3D 9 blocks + PatchGAN3D 3 layers, lsgan, lambda 10/10",
+                          "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+               "step_tflops": round(value * tflop_per_pair, 1),
+               "step_mfma_frac": round(value * tflop_per_pair / (PEAK_BF16_TFLOPS * world), 4)}
+        if timing is not None:
+            n, ms = ops.kernel_timing_result()
+            vox = (args.size // 4) ** 3
+            flop = 2.0 * vox * args.batch * 256 * 6912
+            tf = flop / (ms * 1e-3) / 1e12 if n else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "kernel": "gconv_kernel (3x3x3 256->256 replicate conv, M=%d N=256 K=6912)"
+                                         % (vox * args.batch),
+                               "launches_timed": n, "avg_ms": round(ms, 4)}
+        print(json.dumps(out), flush=True)
     elif rank == 0:
         images = args.batch * world * args.steps
         value = images / dt

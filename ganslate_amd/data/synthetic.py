@@ -15,7 +15,7 @@ class SyntheticImageDatasetConfig(configs.base.BaseDatasetConfig):
     root: str = ""
     num_workers: int = 0
     image_channels: int = 3
-    final_size: Tuple[int, int] = field(default_factory=lambda: [256, 256])
+    final_size: Tuple[int, ...] = field(default_factory=lambda: [256, 256])
     length: int = 1024
     seed: int = 1234
 
@@ -24,7 +24,7 @@ class SyntheticImageDataset(Dataset):
 
     def __init__(self, conf):
         d = conf[conf.mode].dataset
-        self.shape = (d.image_channels, int(d.final_size[0]), int(d.final_size[1]))
+        self.shape = (d.image_channels, *(int(v) for v in d.final_size))   # (H, W) images or (D, H, W) volumes
         self.length, self.seed = d.length, d.seed
 
     def __getitem__(self, index):

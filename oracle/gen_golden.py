@@ -216,9 +216,80 @@ def net_case(name, net, x_shape, seed):
     }
 
 
+# ---- 3-D (BASELINE configs[4] shape family: Resnet3D-class generator + PatchGAN3D on single-channel volumes) --------
+CASES_3D = {
+    # CycleGAN hyper-parameters of the horse2zebra yaml on 1-channel volumes; Resnet3D(9 blocks) + PatchGAN3D(2 layers)
+    "v32_default": dict(size=[32, 32, 32], batch=1, steps=4, n_iters=100, n_iters_decay=100, pool_size=50,
+                        lambda_identity=0.0, proportion_ssim=0.0, n_residual_blocks=9, d_layers=2, seed=51),
+    # anisotropic patch, identity loss on, batch 2
+    "v16x24x32_idt": dict(size=[16, 24, 32], batch=2, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
+                          lambda_identity=0.5, proportion_ssim=0.0, n_residual_blocks=3, d_layers=2, seed=52),
+}
+
+
+def make_conf_3d(c):
+    conf = make_conf(c)
+    conf.train.metrics["ssim"] = False
+    gan = conf.train.gan
+    gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Resnet3D",
+                                   "n_residual_blocks": c["n_residual_blocks"],
+                                   "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
+    gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
+                                       "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                       "in_channels": {"B": 1, "A": 1}})
+    return conf
+
+
+def inputs_3d(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 1, *c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+def run_case_3d(name, c):
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    model = CycleGAN(make_conf_3d(c))
+    for k, (n, net) in enumerate(model.networks.items()):
+        net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+    random.seed(c["seed"])
+    rec = []
+    for s in range(c["steps"]):
+        A, B = inputs_3d(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        rec.append({
+            "lrs": {k: float(v) for k, v in lrs.items()},
+            "losses": {k: float(v) for k, v in losses.items() if v is not None},
+            "metrics": {k: float(v) for k, v in metrics.items() if v is not None},
+        })
+        model.update_learning_rate()
+        print(name, s, rec[-1]["losses"], flush=True)
+    norms = {n: float(torch.sqrt(sum((p.detach() ** 2).sum() for p in net.parameters())))
+             for n, net in model.networks.items()}
+    return {"config": c, "steps": rec, "final_param_norms": norms}
+
+
+def main_3d(out):
+    from ganslate.nn.generators import Resnet3D
+    from ganslate.nn.discriminators import PatchGAN3D
+    vol = {
+        "nets": {
+            "resnet3d_16x24x32_3blocks": net_case("r3", Resnet3D(1, 1, "instance", 3), (1, 1, 16, 24, 32), 61),
+            "patchgan3d_32_3layers": net_case("p3", PatchGAN3D(1, 64, 3, 4, "instance"), (2, 1, 32, 32, 32), 62),
+            "patchgan3d_2ch_2layers": net_case("p2", PatchGAN3D(2, 64, 2, 4, "instance"), (1, 2, 16, 24, 20), 63),
+        },
+        "steps": {name: run_case_3d(name, c) for name, c in CASES_3D.items()},
+    }
+    (out / "volumes.json").write_text(json.dumps(vol, indent=1))
+
+
 def main():
     out = ROOT / "tests" / "golden"
     out.mkdir(parents=True, exist_ok=True)
+    if "--only-3d" in sys.argv:
+        return main_3d(out)
     nets = {
         "resnet2d_64": net_case("resnet2d_64", Resnet2D(3, 3, "instance", 9), (2, 3, 64, 64), 21),
         "resnet2d_40x56_3blocks": net_case("r", Resnet2D(3, 3, "instance", 3), (1, 3, 40, 56), 22),
@@ -232,6 +303,7 @@ def main():
     (out / "pix2pix_steps.json").write_text(json.dumps(p2p, indent=1))
     cut = {name: run_cut_case(name, c) for name, c in CUT_CASES.items()}
     (out / "cut_steps.json").write_text(json.dumps(cut, indent=1))
+    main_3d(out)
     if "--only-new" in sys.argv:
         return
     steps = {name: run_case(name, c) for name, c in CASES.items()}

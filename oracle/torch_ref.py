@@ -235,9 +235,10 @@ class CycleGANStep:
     def __init__(self, in_ch=3, out_ch=3, n_blocks=9, ndf=64, n_layers=3, lr_G=2e-4, lr_D=2e-4, beta1=0.5,
                  beta2=0.999, lambda_AB=10.0, lambda_BA=10.0, lambda_identity=0.0, proportion_ssim=0.0,
                  pool_size=50, adv="lsgan", n_iters=100, n_iters_decay=100, metrics_ssim=True, metrics_D=True,
-                 seed=0):
-        self.nets = OrderedDict(G_AB=Resnet2D(in_ch, out_ch, n_blocks), G_BA=Resnet2D(out_ch, in_ch, n_blocks),
-                                D_B=PatchGAN2D(out_ch, ndf, n_layers), D_A=PatchGAN2D(in_ch, ndf, n_layers))
+                 seed=0, dims=2):
+        G, D = (Resnet2D, PatchGAN2D) if dims == 2 else (Resnet3D, PatchGAN3D)
+        self.nets = OrderedDict(G_AB=G(in_ch, out_ch, n_blocks), G_BA=G(out_ch, in_ch, n_blocks),
+                                D_B=D(out_ch, ndf, n_layers), D_A=D(in_ch, ndf, n_layers))
         for k, (name, net) in enumerate(self.nets.items()):
             net.load_state_dict(seeded_state_dict(net, seed + k))
         self.hp = dict(lambda_AB=lambda_AB, lambda_BA=lambda_BA, lambda_identity=lambda_identity,

@@ -51,6 +51,53 @@ def run_product_steps(model, c, n_steps):
     return out
 
 
+# ---- volumes (Resnet3D + PatchGAN3D) ------------------------------------------------------------------------------------
+VOL_CONF = Path(__file__).parent / "configs" / "cyclegan3d_synthetic.yaml"
+
+
+def load_golden_volumes():
+    return json.loads((GOLD / "volumes.json").read_text())
+
+
+def volume_inputs(c, step):
+    g = torch.Generator().manual_seed(c["seed"] * 100 + step)
+    shape = (c["batch"], 1, *c["size"])
+    return torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+
+
+def build_product_cyclegan3d(c, extra=()):
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle import torch_ref
+    conf = build_conf([f"config={VOL_CONF}", f"train.batch_size={c['batch']}", f"train.n_iters={c['n_iters']}",
+                       f"train.n_iters_decay={c['n_iters_decay']}", f"train.gan.pool_size={c['pool_size']}",
+                       f"train.gan.generator.n_residual_blocks={c['n_residual_blocks']}",
+                       f"train.gan.discriminator.n_layers={c['d_layers']}",
+                       f"train.gan.optimizer.lambda_identity={c['lambda_identity']}", *extra])
+    torch.manual_seed(c["seed"])
+    model = build_gan(conf)
+    G = lambda: torch_ref.Resnet3D(1, 1, c["n_residual_blocks"])
+    D = lambda: torch_ref.PatchGAN3D(1, 64, c["d_layers"])
+    shadow = {"G_AB": G(), "G_BA": G(), "D_B": D(), "D_A": D()}
+    for k, name in enumerate(["G_AB", "G_BA", "D_B", "D_A"]):
+        model.networks[name].load_state_dict(torch_ref.seeded_state_dict(shadow[name], c["seed"] + k))
+    random.seed(c["seed"])
+    return model
+
+
+def run_product_volume_steps(model, c, n_steps):
+    out = []
+    for s in range(n_steps):
+        A, B = volume_inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        lrs, losses, visuals, metrics = model.get_loggable_data()
+        out.append({"lrs": dict(lrs),
+                    "losses": {k: float(v.detach()) for k, v in losses.items() if v is not None},
+                    "metrics": {k: float(v) for k, v in metrics.items() if v is not None}})
+        model.update_learning_rate()
+    return out
+
+
 # ---- pix2pix ---------------------------------------------------------------------------------------------------------
 P2P_CONF = Path(__file__).parent / "configs" / "pix2pix_synthetic.yaml"
 

@@ -40,6 +40,26 @@ def test_product_step_matches_reference_golden_fp32(fp32_oracle_backend, name, n
             assert got[s]["metrics"][k] == pytest.approx(v, rel=tol, abs=2e-2 if s else 1e-5), (s, k)
 
 
+@pytest.mark.parametrize("name,n_steps", [("v16x24x32_idt", 2)])
+def test_product_volume_step_matches_reference_golden_fp32(fp32_oracle_backend, name, n_steps):
+    """CycleGAN with Resnet3D + PatchGAN3D (replicate-pad fold, 27/64/343-tap 3-D lowering, 8 parity classes) on the
+    fp32 oracle backend against the golden losses of the real reference"""
+    from .helpers import build_product_cyclegan3d, load_golden_volumes, run_product_volume_steps
+    gold = load_golden_volumes()["steps"][name]
+    c = gold["config"]
+    model = build_product_cyclegan3d(c)
+    got = run_product_volume_steps(model, c, n_steps)
+    for s in range(n_steps):
+        g = gold["steps"][s]
+        assert set(got[s]["losses"]) == set(g["losses"])
+        tol_adv, tol_cyc = (1e-4, 1e-4) if s == 0 else (0.10, 0.02)
+        for k, v in g["losses"].items():
+            tol = tol_cyc if k.startswith(("cycle", "idt")) else tol_adv
+            assert got[s]["losses"][k] == pytest.approx(v, rel=tol, abs=1e-5), (s, k)
+        for k, v in g["metrics"].items():
+            assert got[s]["metrics"][k] == pytest.approx(v, rel=1e-4 if s == 0 else 0.25, abs=1e-5 if s == 0 else 2e-2)
+
+
 def test_pix2pix_product_step_matches_reference_golden_fp32(fp32_oracle_backend):
     """Pix2PixConditionalGAN + Unet2D executor (skip concat by channel slices, dual-activation norm backward) on the
     fp32 oracle backend against the real reference's golden losses."""

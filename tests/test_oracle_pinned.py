@@ -13,6 +13,8 @@ from oracle.torch_ref import CycleGANStep, seeded_state_dict
 GOLD = Path(__file__).parent / "golden"
 NETS = json.loads((GOLD / "nets.json").read_text())
 STEPS = json.loads((GOLD / "cyclegan_steps.json").read_text())
+VOLUMES = json.loads((GOLD / "volumes.json").read_text())
+NETS = dict(NETS, **VOLUMES["nets"])
 
 NET_BUILDERS = {
     "resnet2d_64": lambda: torch_ref.Resnet2D(3, 3, 9),
@@ -21,6 +23,9 @@ NET_BUILDERS = {
     "patchgan2d_6ch_4layers": lambda: torch_ref.PatchGAN2D(6, 64, 4, 4),
     "unet2d_5downs": lambda: torch_ref.Unet2D(3, 3, 5, 16),
     "unet2d_7downs": lambda: torch_ref.Unet2D(3, 3, 7, 8),
+    "resnet3d_16x24x32_3blocks": lambda: torch_ref.Resnet3D(1, 1, 3),
+    "patchgan3d_32_3layers": lambda: torch_ref.PatchGAN3D(1, 64, 3, 4),
+    "patchgan3d_2ch_2layers": lambda: torch_ref.PatchGAN3D(2, 64, 2, 4),
 }
 
 
@@ -72,6 +77,29 @@ def test_cyclegan_step_restatement_matches_reference(name):
         for k, v in g["losses"].items():
             assert abs(losses[k] - v) <= 2e-4 * abs(v) + 1e-6, (s, k, losses[k], v)
         for k, v in g["metrics"].items():
+            assert abs(metrics[k] - v) <= 2e-4 * abs(v) + 1e-5, (s, k, metrics[k], v)
+        model.update_learning_rate()
+
+
+@pytest.mark.parametrize("name", list(VOLUMES["steps"]))
+def test_cyclegan3d_step_restatement_matches_reference(name):
+    """CycleGAN on volumes with the reference's Resnet3D + PatchGAN3D (resnet3d.py:14-92, patchgan3d.py:17-65)"""
+    gold = VOLUMES["steps"][name]
+    c = gold["config"]
+    torch.manual_seed(c["seed"])
+    model = CycleGANStep(in_ch=1, out_ch=1, n_blocks=c["n_residual_blocks"], n_layers=c["d_layers"],
+                         n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"], pool_size=c["pool_size"],
+                         lambda_identity=c["lambda_identity"], proportion_ssim=0.0, metrics_ssim=False,
+                         seed=c["seed"], dims=3)
+    random.seed(c["seed"])
+    for s in range(c["steps"]):
+        g = torch.Generator().manual_seed(c["seed"] * 100 + s)
+        shape = (c["batch"], 1, *c["size"])
+        A, B = torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+        losses, metrics = model.step(A, B)
+        for k, v in gold["steps"][s]["losses"].items():
+            assert abs(losses[k] - v) <= 2e-4 * abs(v) + 1e-6, (s, k, losses[k], v)
+        for k, v in gold["steps"][s]["metrics"].items():
             assert abs(metrics[k] - v) <= 2e-4 * abs(v) + 1e-5, (s, k, metrics[k], v)
         model.update_learning_rate()
 
