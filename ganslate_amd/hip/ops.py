@@ -131,7 +131,8 @@ class HipOps:
     # ---- generalised norm / activation for skip-connection graphs (U-Net) ---------------------------------
     def _norm_ex_desc(self, y, act1, act2, slope, drop_p, seed):
         d = L.NormExDesc()
-        d.N, d.H, d.W, d.C = y.shape
+        d.N, d.W, d.C = y.shape[0], y.shape[-2], y.shape[-1]       # geometry-free kernels: a volume is D*H rows
+        d.H = y.numel() // (d.N * d.W * d.C)
         d.act1, d.act2, d.slope = L.ACT[act1], L.ACT[act2], slope
         d.drop_p, d.seed_lo, d.seed_hi = drop_p, seed & 0xffffffff, (seed >> 32) & 0xffffffff
         return d

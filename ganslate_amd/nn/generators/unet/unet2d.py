@@ -33,9 +33,11 @@ class _Saved:
 
 
 class Unet2D(NativeNet):
+    dims = 2          # Unet3D (unet3d.py:17-156) is the same graph on Conv3d / ConvTranspose3d / InstanceNorm3d
 
     def __init__(self, in_channels, out_channels, num_downs, norm_type, ngf=64, use_dropout=False):
         require_instance_norm(norm_type)
+        dims = type(self).dims
         use_bias = is_bias_before_norm(norm_type)
         assert num_downs >= 5, "Unet2D needs num_downs >= 5 (unet2d.py:36-66)"
         assert ngf % 8 == 0, "ngf must be a multiple of 8"
@@ -52,12 +54,12 @@ class Unet2D(NativeNet):
         up_name = lambda k: prefix[k] + (".3" if k in (1, D) else ".5")
         nodes = []
         for k in range(1, D + 1):
-            nodes.append(Node(ConvSpec("conv", self.c[k - 1], self.c[k], 4, 2, 1, bias=use_bias),
+            nodes.append(Node(ConvSpec("conv", self.c[k - 1], self.c[k], 4, 2, 1, bias=use_bias, dims=dims),
                               norm=(1 < k < D), act="lrelu", name=down_name(k)))
         for k in range(D, 0, -1):
             cin = self.c[k] if k == D else 2 * self.c[k]
             cout = out_channels if k == 1 else self.c[k - 1]
-            nodes.append(Node(ConvSpec("convT", cin, cout, 4, 2, 1, 0, bias=True if k == 1 else use_bias),
+            nodes.append(Node(ConvSpec("convT", cin, cout, 4, 2, 1, 0, bias=True if k == 1 else use_bias, dims=dims),
                               norm=(k > 1), act="none", name=up_name(k)))
         super().__init__(nodes, in_channels, out_channels, out_act="tanh")
 
@@ -67,15 +69,15 @@ class Unet2D(NativeNet):
     def _up(self, k):
         return 2 * self.D - k
 
-    def _lowered(self, H, W):
-        key = (H, W)
+    def _lowered(self, *sizes):
+        key = tuple(sizes)
         if key not in self._low_cache:
             D = self.D
-            assert H % (1 << D) == 0 and W % (1 << D) == 0, f"input {H}x{W} must be divisible by 2^{D}"
+            assert all(x % (1 << D) == 0 for x in key), f"input {key} must be divisible by 2^{D}"
             lows = [None] * (2 * D)
             for k in range(1, D + 1):
-                lows[self._down(k)] = lower(self.nodes[self._down(k)].spec, H >> (k - 1), W >> (k - 1))
-                lows[self._up(k)] = lower(self.nodes[self._up(k)].spec, H >> k, W >> k)
+                lows[self._down(k)] = lower(self.nodes[self._down(k)].spec, *(x >> (k - 1) for x in key))
+                lows[self._up(k)] = lower(self.nodes[self._up(k)].spec, *(x >> k for x in key))
             self._low_cache[key] = lows
         return self._low_cache[key]
 
@@ -94,50 +96,50 @@ class Unet2D(NativeNet):
         for g in lw.fwd:
             offs.append(slots)
             tm = ops.tile_m(g, N)
-            slots += (g.Hc * g.Wc + tm - 1) // tm
+            slots += (g.pixels + tm - 1) // tm
         part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
         for g, o in zip(lw.fwd, offs):
             ops.gconv(g, x, fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
         mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
-        ops.inorm_finalize(part, N, slots, sp.cout_p, lw.Ho * lw.Wo, mr)
+        ops.inorm_finalize(part, N, slots, sp.cout_p, lw.out_pixels, mr)
         return mr
 
-    def _new(self, N, H, W, C):
-        return torch.empty(N, H, W, C, dtype=self.ops.act_dtype, device=self.device)
+    def _new(self, N, sizes, C):
+        return torch.empty(N, *sizes, C, dtype=self.ops.act_dtype, device=self.device)
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def _forward(self, x, save):
         ops, D, c = self.ops, self.D, self.c
-        N, _, H, W = x.shape
-        lows, pk = self._lowered(H, W), self._get_packs(H, W)
+        N, sizes = x.shape[0], tuple(x.shape[2:])
+        lows, pk = self._lowered(*sizes), self._get_packs(*sizes)
         s = _Saved()
-        s.x_img, s.N, s.H, s.W, s.lows = x, N, H, W, lows
+        s.x_img, s.N, s.sizes, s.lows = x, N, sizes, lows
         s.seed = random.getrandbits(62) if (self.training and self.dropout_levels) else 0
-        a0 = self._new(N, H, W, self.nodes[0].spec.cin_p)
+        a0 = self._new(N, sizes, self.nodes[0].spec.cin_p)
         ops.image_to_act(x, a0)
         s.L = {0: a0}          # L[k]: LeakyReLU(h_k), the input of down_{k+1}
         s.cat, s.yd, s.mrd, s.yu, s.mru = {}, {}, {}, {}, {}
         for k in range(1, D + 1):
             i, lw = self._down(k), lows[self._down(k)]
-            hk, wk = H >> k, W >> k
+            sk = tuple(x >> k for x in sizes)
             if k < D:
-                s.cat[k] = self._new(N, hk, wk, 2 * c[k])
+                s.cat[k] = self._new(N, sk, 2 * c[k])
             if k == 1:            # conv + bias, no norm; LeakyReLU in the epilogue, ReLU copy into the concat buffer
-                s.L[1] = self._new(N, hk, wk, c[1])
+                s.L[1] = self._new(N, sk, c[1])
                 self._conv(i, lw, pk, s.L[0], s.L[1], act="lrelu")
                 ops.norm_act_forward_ex(s.L[1], None, s.cat[1], None, act1="relu")
             elif k < D:
-                s.yd[k] = self._new(N, hk, wk, c[k])
+                s.yd[k] = self._new(N, sk, c[k])
                 s.mrd[k] = self._conv(i, lw, pk, s.L[k - 1], s.yd[k], stats=True)
-                s.L[k] = self._new(N, hk, wk, c[k])
+                s.L[k] = self._new(N, sk, c[k])
                 ops.norm_act_forward_ex(s.yd[k], s.mrd[k], s.L[k], s.cat[k], act1="lrelu", act2="relu")
             else:                 # innermost: no norm; its only consumer is up_D through ReLU
-                s.R = self._new(N, hk, wk, c[D])
+                s.R = self._new(N, sk, c[D])
                 self._conv(i, lw, pk, s.L[D - 1], s.R, act="relu")
         for k in range(D, 0, -1):
             i, lw = self._up(k), lows[self._up(k)]
             xin = s.R if k == D else s.cat[k]
-            y = self._new(N, H >> (k - 1), W >> (k - 1), self.nodes[i].spec.cout_p)
+            y = self._new(N, tuple(x >> (k - 1) for x in sizes), self.nodes[i].spec.cout_p)
             if k > 1:
                 s.yu[k] = y
                 s.mru[k] = self._conv(i, lw, pk, xin, y, stats=True)
@@ -147,7 +149,7 @@ class Unet2D(NativeNet):
             else:
                 self._conv(i, lw, pk, xin, y)
                 s.y1 = y
-        out = torch.empty(N, self.out_channels, H, W, dtype=torch.float32, device=self.device)
+        out = torch.empty(N, self.out_channels, *sizes, dtype=torch.float32, device=self.device)
         ops.act_to_image(s.y1, out, act="tanh")
         s.out_img = out
         return out, (s if save else None)
@@ -163,7 +165,7 @@ class Unet2D(NativeNet):
 
     def _dgrad(self, i, lw, pk, dy, N):
         sp = self.nodes[i].spec
-        gx = self._new(N, lw.Hi, lw.Wi, sp.cin_p)
+        gx = self._new(N, lw.in_dims, sp.cin_p)
         dpack = pk["dpack"][pk["d_off"][i]:]
         for g in lw.dgrad:
             self.ops.gconv(g, dy, dpack, None, gx)
@@ -171,7 +173,7 @@ class Unet2D(NativeNet):
 
     def _backward(self, s, g_img, need_input_grad, want_w):
         ops, D, c, N = self.ops, self.D, self.c, s.N
-        lows, pk = s.lows, self._get_packs(s.H, s.W)
+        lows, pk = s.lows, self._get_packs(*s.sizes)
         if self.master.grad is None:
             self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         grad = self.master.grad

@@ -272,13 +272,14 @@ def run_case_3d(name, c):
 
 
 def main_3d(out):
-    from ganslate.nn.generators import Resnet3D
+    from ganslate.nn.generators import Resnet3D, Unet3D
     from ganslate.nn.discriminators import PatchGAN3D
     vol = {
         "nets": {
             "resnet3d_16x24x32_3blocks": net_case("r3", Resnet3D(1, 1, "instance", 3), (1, 1, 16, 24, 32), 61),
             "patchgan3d_32_3layers": net_case("p3", PatchGAN3D(1, 64, 3, 4, "instance"), (2, 1, 32, 32, 32), 62),
             "patchgan3d_2ch_2layers": net_case("p2", PatchGAN3D(2, 64, 2, 4, "instance"), (1, 2, 16, 24, 20), 63),
+            "unet3d_5downs": net_case("u3", Unet3D(1, 1, 5, "instance", ngf=8), (1, 1, 32, 32, 64), 64),
         },
         "steps": {name: run_case_3d(name, c) for name, c in CASES_3D.items()},
     }

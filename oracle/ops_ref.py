@@ -200,6 +200,8 @@ class RefOps:
 
     def norm_act_forward_ex(self, y, mean_rstd, x1, x2=None, act1="none", act2="none", slope=0.2, x1_co=0, x2_co=0,
                             drop_p=0.0, seed=0):
+        flat = lambda t: t if t is None or t.dim() == 4 else t.view(t.shape[0], -1, t.shape[-2], t.shape[-1])
+        y, x1, x2 = flat(y), flat(x1), flat(x2)        # geometry-free: a volume is D*H rows
         N, H, W, Cc = y.shape
         v = y.float()
         if mean_rstd is not None:
@@ -212,6 +214,8 @@ class RefOps:
 
     def norm_act_backward_ex(self, g1, g2, y, mean_rstd, dy, act1="none", act2="none", slope=0.2, g1_co=0, g2_co=0,
                              drop_p=0.0, seed=0, bias_grad=None):
+        flat = lambda t: t if t is None or t.dim() == 4 else t.view(t.shape[0], -1, t.shape[-2], t.shape[-1])
+        g1, g2, y, dy = flat(g1), flat(g2), flat(y), flat(dy)
         N, H, W, Cc = y.shape
         yh = y.float()
         if mean_rstd is not None:

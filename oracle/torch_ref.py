@@ -171,6 +171,47 @@ class Unet2D(nn.Module):
         return self.model(x)
 
 
+class _UnetBlock3D(nn.Module):
+    """ganslate/nn/generators/unet/unet3d.py:75-156 restated"""
+
+    def __init__(self, outer, inner, in_ch=None, sub=None, outermost=False, innermost=False, dropout=False):
+        super().__init__()
+        self.outermost = outermost
+        in_ch = outer if in_ch is None else in_ch
+        down = nn.Conv3d(in_ch, inner, 4, 2, 1)
+        if outermost:
+            mods = [down, sub, nn.ReLU(), nn.ConvTranspose3d(inner * 2, outer, 4, 2, 1), nn.Tanh()]
+        elif innermost:
+            mods = [nn.LeakyReLU(0.2), down, nn.ReLU(), nn.ConvTranspose3d(inner, outer, 4, 2, 1),
+                    nn.InstanceNorm3d(outer)]
+        else:
+            mods = [nn.LeakyReLU(0.2), down, nn.InstanceNorm3d(inner), sub, nn.ReLU(),
+                    nn.ConvTranspose3d(inner * 2, outer, 4, 2, 1), nn.InstanceNorm3d(outer)]
+            if dropout:
+                mods.append(nn.Dropout(0.5))
+        self.model = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.model(x) if self.outermost else torch.cat([x, self.model(x)], 1)
+
+
+class Unet3D(nn.Module):
+    """ganslate/nn/generators/unet/unet3d.py:17-72 restated"""
+
+    def __init__(self, in_channels, out_channels, num_downs=7, ngf=64, use_dropout=False):
+        super().__init__()
+        blk = _UnetBlock3D(ngf * 8, ngf * 8, innermost=True)
+        for _ in range(num_downs - 5):
+            blk = _UnetBlock3D(ngf * 8, ngf * 8, sub=blk, dropout=use_dropout)
+        blk = _UnetBlock3D(ngf * 4, ngf * 8, sub=blk)
+        blk = _UnetBlock3D(ngf * 2, ngf * 4, sub=blk)
+        blk = _UnetBlock3D(ngf, ngf * 2, sub=blk)
+        self.model = _UnetBlock3D(out_channels, ngf, in_ch=in_channels, sub=blk, outermost=True)
+
+    def forward(self, x):
+        return self.model(x)
+
+
 def seeded_state_dict(module: nn.Module, seed: int, gain=0.02, bias_gain=0.01):
     """Deterministic weights independent of module construction order / torch's default init RNG use:
     every tensor of the state_dict (in key order, aliases share one draw) ~ N(0, gain) (biases N(0, bias_gain))

@@ -80,6 +80,12 @@ def test_patchgan3d_forward_backward(fp32_oracle_backend):
     _compare(PatchGAN3D(1, 16, 2, (4, 4, 4), "instance"), torch_ref.PatchGAN3D(1, 16, 2, 4), (2, 1, 16, 24, 16), 42)
 
 
+def test_unet3d_forward_backward(fp32_oracle_backend):
+    """Unet3D (unet3d.py:17-156): k4 s2 Conv3d / ConvTranspose3d (8 parity classes), skip concat, 5 levels"""
+    from ganslate_amd.nn.generators import Unet3D
+    _compare(Unet3D(1, 1, 5, "instance", ngf=8), torch_ref.Unet3D(1, 1, 5, 8), (1, 1, 32, 32, 64), 43)
+
+
 def test_frozen_network_gets_no_weight_gradients(fp32_oracle_backend):
     """set_requires_grad(D, False) during the G step: input gradient flows, parameter gradients do not (K20)"""
     from ganslate_amd.nn.discriminators import PatchGAN2D

@@ -26,6 +26,7 @@ NET_BUILDERS = {
     "resnet3d_16x24x32_3blocks": lambda: torch_ref.Resnet3D(1, 1, 3),
     "patchgan3d_32_3layers": lambda: torch_ref.PatchGAN3D(1, 64, 3, 4),
     "patchgan3d_2ch_2layers": lambda: torch_ref.PatchGAN3D(2, 64, 2, 4),
+    "unet3d_5downs": lambda: torch_ref.Unet3D(1, 1, 5, 8),
 }
 
 

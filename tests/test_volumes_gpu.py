@@ -28,6 +28,12 @@ def test_patchgan3d_hip_vs_oracle(hip_ops, in_ch, n_layers, dhw):
               torch_ref.PatchGAN3D(in_ch, 64, n_layers, 4), (1, in_ch, *dhw), 72)
 
 
+def test_unet3d_hip_vs_oracle(hip_ops):
+    from ganslate_amd.nn.generators import Unet3D
+    _net_case(hip_ops, lambda: Unet3D(1, 1, 5, "instance", ngf=16), torch_ref.Unet3D(1, 1, 5, 16),
+              (1, 1, 32, 32, 64), 73, grad_tol=0.30, grad_cos=0.95)
+
+
 def test_resnet3d_matches_reference_golden(hip_ops):
     from ganslate_amd.nn.generators import Resnet3D
     gold = load_golden_volumes()["nets"]["resnet3d_16x24x32_3blocks"]
