@@ -301,8 +301,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         const int zz = div_small(zi, d.Hc, p.rcp_hc);
         const int ii = zi - zz * d.Hc;
         const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
-        const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
-        if (VARIANT != 9 || val.x == 0x12345678u) *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
+        uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
+        uint4* dst = reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2);
+        if (d.accumulate) {
+          const uint4 old = *dst;
+          val.x = pack_bf2(bf_lo(val.x) + bf_lo(old.x), bf_hi(val.x) + bf_hi(old.x));
+          val.y = pack_bf2(bf_lo(val.y) + bf_lo(old.y), bf_hi(val.y) + bf_hi(old.y));
+          val.z = pack_bf2(bf_lo(val.z) + bf_lo(old.z), bf_hi(val.z) + bf_hi(old.z));
+          val.w = pack_bf2(bf_lo(val.w) + bf_lo(old.w), bf_hi(val.w) + bf_hi(old.w));
+        }
+        if (VARIANT != 9 || val.x == 0x12345678u) *dst = val;
       }
     }
   }
@@ -388,6 +396,8 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
                  (long long)d->Di * d->Hi * d->Wi * d->in_cs * 2 < (1LL << 32),
              "gs_gconv_forward: class extent too large");
   GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward: stats requested without buffer");
+  GS_REQUIRE(!d->accumulate || (d->stats_slots == 0 && d->act == GS_ACT_NONE && !bias),
+             "gs_gconv_forward: accumulate excludes bias, activation and statistics");
   const TileCfg tc = pick_tile(d);
   GConvK k;
   k.in = static_cast<const char*>(in);

@@ -16,7 +16,7 @@ class GConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "Hi", "Wi", "Ci", "Di", "Do", "Dc", "pz", "in_cs", "in_co", "Ho", "Wo", "Co", "out_cs", "out_co", "Hc", "Wc",
         "so", "py", "px", "si", "T", "Kp", "w_rows", "border", "act")] + [
-        ("slope", C.c_float), ("stats_slots", C.c_int32), ("stats_slot0", C.c_int32),
+        ("slope", C.c_float), ("stats_slots", C.c_int32), ("stats_slot0", C.c_int32), ("accumulate", C.c_int32),
         ("dh", C.c_int8 * GS_MAX_TAPS), ("dw", C.c_int8 * GS_MAX_TAPS), ("dd", C.c_int8 * GS_MAX_TAPS)]
 
 
@@ -33,6 +33,13 @@ class NormExDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "act1", "act2")] + [("slope", C.c_float)] + [
         (n, C.c_int32) for n in ("x1_cs", "x1_co", "x2_cs", "x2_co", "g1_cs", "g1_co", "g2_cs", "g2_co")] + [
         ("drop_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+
+
+class PNormDesc(C.Structure):
+    """Mirror of gs_pnorm_desc."""
+    _fields_ = [("pixels", C.c_int64)] + [(n, C.c_int32) for n in (
+        "N", "C", "y_cs", "y_co", "res_mode", "res_cs", "res_co", "res_mod", "out_cs", "out_co", "g_cs", "g_co",
+        "g2_cs", "g2_co", "dy_cs", "dy_co", "gres_cs", "gres_co")]
 
 
 _PROTOS = {
@@ -57,6 +64,14 @@ _PROTOS = {
     "gs_norm_act_backward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_norm_backward_ex_scratch_floats": (C.c_int64, [C.POINTER(NormExDesc)]),
+    "gs_pnorm_forward": (C.c_int, [C.POINTER(PNormDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "gs_pnorm_backward": (C.c_int, [C.POINTER(PNormDesc)] + [C.c_void_p] * 12),
+    "gs_pnorm_backward_scratch_floats": (C.c_int64, [C.POINTER(PNormDesc)]),
+    "gs_add_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                               C.c_int32, C.c_void_p]),
+    "gs_repeat_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int64, C.c_void_p]),
     "gs_image_to_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p]),
     "gs_act_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -43,8 +43,8 @@ class HipOps:
         return len(ev), ms
 
     # ---- descriptors ------------------------------------------------------------------------------------
-    def _gdesc(self, g: GConv, N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0):
-        key = (id(g), N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0)
+    def _gdesc(self, g: GConv, N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0, accumulate=False):
+        key = (id(g), N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0, accumulate)
         d = self._desc_cache.get(key)
         if d is None:
             d = L.GConvDesc()
@@ -54,7 +54,7 @@ class HipOps:
             d.Hc, d.Wc, d.so, d.py, d.px, d.si = g.Hc, g.Wc, g.so, g.py, g.px, g.si
             d.T, d.Kp, d.w_rows = g.T, g.Kp, g.w_rows
             d.border, d.act, d.slope = L.BORDER[g.border], L.ACT[act], slope
-            d.stats_slots, d.stats_slot0 = stats_slots, stats_slot0
+            d.stats_slots, d.stats_slot0, d.accumulate = stats_slots, stats_slot0, int(accumulate)
             for i, (a, b, c) in enumerate(zip(g.dh, g.dw, g.dd)):
                 d.dh[i], d.dw[i], d.dd[i] = a, b, c
             self._desc_cache[key] = (d, g)   # keep g alive so id() stays unique
@@ -67,11 +67,11 @@ class HipOps:
 
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
-              slope=0.2, stats=None, stats_slots=0, stats_slot0=0):
+              slope=0.2, stats=None, stats_slots=0, stats_slot0=0, accumulate=False):
         N = x.shape[0]
         in_cs = in_cs if in_cs is not None else x.shape[-1]
         out_cs = out_cs if out_cs is not None else out.shape[-1]
-        d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0)
+        d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0, accumulate)
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
         timed = self._timing_filter is not None and self._timing_filter(g)
         if timed:
@@ -159,6 +159,52 @@ class HipOps:
         L.check(self.lib.gs_norm_act_backward_ex(C.byref(d), _ptr(g1), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(dy),
                                                  _ptr(scratch), _ptr(bias_grad), _stream()),
                 "gs_norm_act_backward_ex")
+
+    # ---- V-Net elementwise family (InstanceNorm3d -> [+res] -> PReLU -> [+res]) on channel slices ----------------
+    @staticmethod
+    def _pdesc(y, C_, y_co, res, res_mode, res_mod, res_co):
+        d = L.PNormDesc()
+        d.N, d.C = y.shape[0], C_
+        d.pixels = y.numel() // (y.shape[0] * y.shape[-1])
+        d.y_cs, d.y_co = y.shape[-1], y_co
+        d.res_mode, d.res_mod = res_mode, res_mod
+        if res is not None:
+            d.res_cs, d.res_co = res.shape[-1], res_co
+        return d
+
+    def pnorm_forward(self, y, mean_rstd, out, *, C, slope=None, res=None, res_mode=0, res_mod=0, y_co=0, res_co=0,
+                      out_co=0):
+        d = self._pdesc(y, C, y_co, res, res_mode, res_mod, res_co)
+        d.out_cs, d.out_co = out.shape[-1], out_co
+        L.check(self.lib.gs_pnorm_forward(L.C.byref(d), _ptr(y), _ptr(mean_rstd), _ptr(res), _ptr(slope), _ptr(out),
+                                          _stream()), "gs_pnorm_forward")
+
+    def pnorm_backward(self, g, y, mean_rstd, dy, *, C, slope=None, dslope=None, g2=None, res=None, res_mode=0,
+                       res_mod=0, gres=None, bias_grad=None, g_co=0, g2_co=0, y_co=0, res_co=0, dy_co=0, gres_co=0):
+        d = self._pdesc(y, C, y_co, res, res_mode, res_mod, res_co)
+        d.g_cs, d.g_co = g.shape[-1], g_co
+        if g2 is not None:
+            d.g2_cs, d.g2_co = g2.shape[-1], g2_co
+        d.dy_cs, d.dy_co = dy.shape[-1], dy_co
+        if gres is not None:
+            d.gres_cs, d.gres_co = gres.shape[-1], gres_co
+        scratch = None
+        if mean_rstd is not None or (slope is not None and dslope is not None):
+            scratch = torch.empty(self.lib.gs_pnorm_backward_scratch_floats(L.C.byref(d)), dtype=torch.float32,
+                                  device=y.device)
+        L.check(self.lib.gs_pnorm_backward(L.C.byref(d), _ptr(g), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(res),
+                                           _ptr(slope), _ptr(dy), _ptr(gres), _ptr(dslope), _ptr(bias_grad),
+                                           _ptr(scratch), _stream()), "gs_pnorm_backward")
+
+    def add_views(self, dst, src, C, dst_co=0, src_co=0, accumulate=True):
+        pixels = dst.numel() // dst.shape[-1]
+        L.check(self.lib.gs_add_views(_ptr(dst), dst.shape[-1], dst_co, _ptr(src), src.shape[-1], src_co, pixels, C,
+                                      int(accumulate), _stream()), "gs_add_views")
+
+    def repeat_backward(self, g, g_img, C, g_co=0):
+        N, Cin = g_img.shape[0], g_img.shape[1]
+        L.check(self.lib.gs_repeat_backward(_ptr(g), g.shape[-1], g_co, _ptr(g_img), N, Cin, C,
+                                            g_img.numel() // (N * Cin), _stream()), "gs_repeat_backward")
 
     # ---- network boundary -----------------------------------------------------------------------------------
     @staticmethod

@@ -1,0 +1,366 @@
+"""Vnet3D generator (partially-invertible V-Net) on the HIP kernels — constructor, channel plan, block order, bias rule
+and state_dict names of ganslate/nn/generators/vnet/vnet3d.py:27-267 with ganslate/nn/invertible.py:8-48:
+
+  InputBlock : out1 = PReLU(IN(conv5(x)) + x.repeat(c / in_channels))                               (vnet3d.py:155-168)
+  DownBlock i: down = PReLU(IN(conv k2 s2 (C -> 2C)));  out = PReLU(core(down) + down)               (vnet3d.py:171-202)
+  UpBlock i  : up = PReLU(IN(convT k2 s2 (Cin -> Cout/2)));  xcat = cat(up, skip);  out = PReLU(core(xcat) + xcat)
+  core       : n additive couplings on channel halves, y1 = x1 + F(x2), y2 = x2 + G(y1), F = G-shaped
+               PReLU(IN(conv5(h -> h)))  (memcnn.AdditiveCoupling; `disable=True` wrapper = plain autograd, the
+               brats yaml's use_memory_saving=False / use_inverse=False, invertible.py:15-19)
+  OutBlock   : tanh(conv1(PReLU(IN(conv5(x)))))                                                    (vnet3d.py:245-259)
+
+Execution: a coupling never splits or concatenates — convs read / write channel slices of the 2h-channel block
+buffers (in_co / out_co of gs_gconv_desc), the norm + PReLU + residual chain is one kernel per half
+(gs_pnorm_forward), and in the backward pass the gradient buffer of [y1|y2] is turned into the gradient of [x1|x2] in
+place by data-gradient launches that accumulate into a slice (gs_gconv_desc.accumulate). PReLU slopes live in the flat
+master buffer behind the conv weights (`Extra`), their gradients come out of the norm-backward reductions."""
+from dataclasses import dataclass
+from typing import Tuple
+
+import torch
+
+from .... import configs
+from ...native.net import Extra, NativeNet, Node
+from ...native.spec import ConvSpec, lower
+from ...utils import is_bias_before_norm, require_instance_norm
+
+
+@dataclass
+class Vnet3DConfig(configs.base.BaseGeneratorConfig):
+    """Partially-invertible V-Net generator."""
+    use_memory_saving: bool = False
+    use_inverse: bool = False
+    first_layer_channels: int = 16
+    down_blocks: Tuple[int] = (1, 2, 3, 2)
+    up_blocks: Tuple[int] = (2, 2, 1, 1)
+    is_separable: bool = False
+
+
+class _Saved:
+    pass
+
+
+class _Block:
+    """bookkeeping of one Down/Up block: node indices and PReLU names"""
+
+    def __init__(self):
+        self.conv = None            # strided conv / transposed conv node
+        self.conv_slope = None
+        self.couplings = []         # [(node_F, slope_F, node_G, slope_G)]
+        self.tail_slope = None
+        self.C = 0                  # channels of the block (2h)
+        self.level = 0              # resolution level of the block's tensors (0 = input resolution)
+
+
+class Vnet3D(NativeNet):
+    dims = 3
+
+    def __init__(self, in_channels, out_channels, norm_type, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
+                 up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True, is_separable=False):
+        require_instance_norm(norm_type)
+        if use_inverse:
+            raise NotImplementedError("Vnet3D(use_inverse=True) builds the RevGAN inverse path, which is outside the "
+                                      "training-step scope; the shipped configs use use_inverse: False")
+        if is_separable:
+            raise NotImplementedError("separable convolutions are not implemented")
+        if first_layer_channels % in_channels:
+            raise ValueError("`first_layer_channels` has to be divisible by `in_channels`.")
+        if len(down_blocks) != len(up_blocks):
+            raise ValueError("Number of `down_blocks` and `up_blocks` has to be equal.")
+        c = first_layer_channels
+        assert c >= 8 and (c & (c - 1)) == 0, "first_layer_channels must be a power of two >= 8 (16-byte channel slices)"
+        use_bias = is_bias_before_norm(norm_type)
+        dims = type(self).dims
+        L = self.L = len(down_blocks)
+        self.c = c
+        conv = lambda *a, **k: ConvSpec(*a, dims=dims, **k)
+        nodes, extras = [], []
+
+        def add_conv(spec, norm, name, aliases=()):
+            nodes.append(Node(spec, norm, "none", name=name, aliases=tuple(aliases)))
+            return len(nodes) - 1
+
+        def add_slope(name, size, aliases=()):
+            extras.append(Extra(name, size, 0.25, tuple(aliases)))
+            return name
+
+        enc = lambda i, rest: (f"encoder.{i}.{rest}",)       # `encoder` = [in_ab] + downs (vnet3d.py:88)
+        self.n_in = add_conv(conv("conv", in_channels, c, 5, 1, 2, bias=use_bias), True, "in_ab.conv1",
+                             enc(0, "conv1"))
+        self.s_in = add_slope("in_ab.relu.weight", c, enc(0, "relu.weight"))
+
+        def couplings(blk, prefix, h, n, alias_prefix=None):
+            for j in range(n):
+                ent = []
+                for fn in ("Fm", "Gm"):
+                    base = f"{prefix}.core.sequence.{j}.invertible_block._fn.{fn}"
+                    al = (lambda r: (f"{alias_prefix}.core.sequence.{j}.invertible_block._fn.{fn}.{r}",)) \
+                        if alias_prefix else (lambda r: ())
+                    ent.append(add_conv(conv("conv", h, h, 5, 1, 2, bias=use_bias), True, base + ".0", al("0")))
+                    ent.append(add_slope(base + ".2.weight", h, al("2.weight")))
+                blk.couplings.append(tuple(ent))
+
+        self.downs = []
+        for i, n in enumerate(down_blocks):
+            blk = _Block()
+            cin = c * 2 ** i
+            blk.C, blk.level = 2 * cin, i + 1
+            blk.conv = add_conv(conv("conv", cin, 2 * cin, 2, 2, 0, bias=use_bias), True,
+                                f"downs.{i}.down_conv_ab.0", enc(i + 1, "down_conv_ab.0"))
+            blk.conv_slope = add_slope(f"downs.{i}.down_conv_ab.2.weight", 2 * cin, enc(i + 1, "down_conv_ab.2.weight"))
+            couplings(blk, f"downs.{i}", cin, n, f"encoder.{i + 1}")
+            blk.tail_slope = add_slope(f"downs.{i}.relu.weight", 2 * cin, enc(i + 1, "relu.weight"))
+            self.downs.append(blk)
+        ucf = [2 * 2 ** i for i in reversed(range(L))]
+        self.ups = []
+        for i, n in enumerate(up_blocks):
+            blk = _Block()
+            cin, cout = (c * ucf[0], c * ucf[0]) if i == 0 else (c * ucf[i - 1], c * ucf[i])
+            blk.C, blk.level, blk.cin = cout, L - 1 - i, cin
+            blk.conv = add_conv(conv("convT", cin, cout // 2, 2, 2, 0, 0, bias=use_bias), True,
+                                f"ups.{i}.up_conv_ab.0")
+            blk.conv_slope = add_slope(f"ups.{i}.up_conv_ab.2.weight", cout // 2)
+            couplings(blk, f"ups.{i}", cout // 2, n)
+            blk.tail_slope = add_slope(f"ups.{i}.relu.weight", cout)
+            self.ups.append(blk)
+        self.n_o1 = add_conv(conv("conv", 2 * c, 2 * c, 5, 1, 2, bias=use_bias), True, "out_ab.conv1")
+        self.s_o1 = add_slope("out_ab.relu1.weight", 2 * c)
+        self.n_o2 = add_conv(conv("conv", 2 * c, out_channels, 1, 1, 0), False, "out_ab.conv2")
+        super().__init__(nodes, in_channels, out_channels, out_act="tanh", extras=extras)
+
+    # ---- lowering: every node at the resolution level it runs at -------------------------------------------------
+    def _lowered(self, *sizes):
+        key = tuple(sizes)
+        if key not in self._low_cache:
+            assert all(x % (1 << self.L) == 0 for x in key), f"input {key} must be divisible by 2^{self.L}"
+            lv = lambda k: tuple(x >> k for x in key)
+            lows = [None] * len(self.nodes)
+            lows[self.n_in] = lower(self.nodes[self.n_in].spec, *key)
+            for blk in self.downs:
+                lows[blk.conv] = lower(self.nodes[blk.conv].spec, *lv(blk.level - 1))
+                for nf, _, ng, _ in blk.couplings:
+                    lows[nf] = lower(self.nodes[nf].spec, *lv(blk.level))
+                    lows[ng] = lower(self.nodes[ng].spec, *lv(blk.level))
+            for blk in self.ups:
+                lows[blk.conv] = lower(self.nodes[blk.conv].spec, *lv(blk.level + 1))
+                for nf, _, ng, _ in blk.couplings:
+                    lows[nf] = lower(self.nodes[nf].spec, *lv(blk.level))
+                    lows[ng] = lower(self.nodes[ng].spec, *lv(blk.level))
+            lows[self.n_o1] = lower(self.nodes[self.n_o1].spec, *key)
+            lows[self.n_o2] = lower(self.nodes[self.n_o2].spec, *key)
+            self._low_cache[key] = lows
+        return self._low_cache[key]
+
+    # ---- helpers -------------------------------------------------------------------------------------------------------
+    def _new(self, N, sizes, C):
+        return torch.empty(N, *sizes, C, dtype=self.ops.act_dtype, device=self.device)
+
+    def _conv(self, s, i, x, in_co=0, stats=True, out=None):
+        """raw output of node i (+ mean/rstd of its InstanceNorm) reading channels [in_co, in_co + cin) of x"""
+        ops, sp, lw, N = self.ops, self.nodes[i].spec, s.lows[i], s.N
+        m = self.master.detach()
+        bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
+        fpack = s.pk["fpack"][s.pk["f_off"][i]:]
+        y = out if out is not None else self._new(N, lw.out_dims, sp.cout_p)
+        if not stats:
+            for g in lw.fwd:
+                ops.gconv(g, x, fpack, bias, y, in_co=in_co)
+            return y, None
+        slots, offs = 0, []
+        for g in lw.fwd:
+            offs.append(slots)
+            tm = ops.tile_m(g, N)
+            slots += (g.pixels + tm - 1) // tm
+        part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
+        for g, o in zip(lw.fwd, offs):
+            ops.gconv(g, x, fpack, bias, y, in_co=in_co, stats=part, stats_slots=slots, stats_slot0=o)
+        mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
+        ops.inorm_finalize(part, N, slots, sp.cout_p, lw.out_pixels, mr)
+        return y, mr
+
+    def _slope(self, name, grad=False):
+        return self.extra(name, grad=grad)
+
+    # ---- forward -----------------------------------------------------------------------------------------------------
+    def _couplings_forward(self, s, blk, X):
+        """X [.., 2h] -> core(X); saves what the backward pass needs"""
+        ops, h = self.ops, blk.C // 2
+        saved = []
+        for nf, sf, ng, sg in blk.couplings:
+            Y = self._new(s.N, X.shape[1:-1], blk.C)
+            ya, mra = self._conv(s, nf, X, in_co=h)                         # F reads x2
+            ops.pnorm_forward(ya, mra, Y, C=h, slope=self._slope(sf), res=X, res_mode=2, res_co=0, out_co=0)
+            yb, mrb = self._conv(s, ng, Y, in_co=0)                         # G reads y1
+            ops.pnorm_forward(yb, mrb, Y, C=h, slope=self._slope(sg), res=X, res_mode=2, res_co=h, out_co=h)
+            saved.append((X, Y, ya, mra, yb, mrb))
+            X = Y
+        return X, saved
+
+    def _forward(self, x, save, stop=None):
+        assert stop is None, "feature taps are not implemented for Vnet3D"
+        ops, c, L = self.ops, self.c, self.L
+        N, sizes = x.shape[0], tuple(x.shape[2:])
+        s = _Saved()
+        s.x_img, s.N, s.sizes = x, N, sizes
+        s.lows, s.pk = self._lowered(*sizes), self._get_packs(*sizes)
+        lv = lambda k: tuple(v >> k for v in sizes)
+        a0 = self._new(N, sizes, self.nodes[0].spec.cin_p)
+        ops.image_to_act(x, a0)
+        s.a0 = a0
+        # InputBlock
+        s.y_in, s.mr_in = self._conv(s, self.n_in, a0)
+        out1 = self._new(N, sizes, c)
+        ops.pnorm_forward(s.y_in, s.mr_in, out1, C=c, slope=self._slope(self.s_in), res=a0, res_mode=1,
+                          res_mod=self.in_channels)
+        s.out1 = out1
+        # DownBlocks
+        s.down = []
+        cur = out1
+        for blk in self.downs:
+            rec = _Saved()
+            rec.x_in = cur
+            rec.y, rec.mr = self._conv(s, blk.conv, cur)
+            rec.D0 = self._new(N, lv(blk.level), blk.C)
+            ops.pnorm_forward(rec.y, rec.mr, rec.D0, C=blk.C, slope=self._slope(blk.conv_slope))
+            rec.Xn, rec.coup = self._couplings_forward(s, blk, rec.D0)
+            rec.out = self._new(N, lv(blk.level), blk.C)
+            ops.pnorm_forward(rec.Xn, None, rec.out, C=blk.C, slope=self._slope(blk.tail_slope), res=rec.D0, res_mode=1)
+            s.down.append(rec)
+            cur = rec.out
+        # UpBlocks
+        s.up = []
+        skips = [s.down[L - 2 - i].out if i < L - 1 else out1 for i in range(L)]
+        for i, blk in enumerate(self.ups):
+            rec = _Saved()
+            rec.x_in = cur
+            h = blk.C // 2
+            rec.y, rec.mr = self._conv(s, blk.conv, cur)
+            rec.D0 = self._new(N, lv(blk.level), blk.C)                      # xcat = [up | skip]
+            ops.pnorm_forward(rec.y, rec.mr, rec.D0, C=h, slope=self._slope(blk.conv_slope), out_co=0)
+            ops.add_views(rec.D0, skips[i], h, dst_co=h, src_co=0, accumulate=False)
+            rec.Xn, rec.coup = self._couplings_forward(s, blk, rec.D0)
+            rec.out = self._new(N, lv(blk.level), blk.C)
+            ops.pnorm_forward(rec.Xn, None, rec.out, C=blk.C, slope=self._slope(blk.tail_slope), res=rec.D0, res_mode=1)
+            s.up.append(rec)
+            cur = rec.out
+        # OutBlock
+        s.o_in = cur
+        s.y_o1, s.mr_o1 = self._conv(s, self.n_o1, cur)
+        s.t = self._new(N, sizes, 2 * c)
+        ops.pnorm_forward(s.y_o1, s.mr_o1, s.t, C=2 * c, slope=self._slope(self.s_o1))
+        s.z, _ = self._conv(s, self.n_o2, s.t, stats=False)
+        out = torch.empty(N, self.out_channels, *sizes, dtype=torch.float32, device=self.device)
+        ops.act_to_image(s.z, out, act="tanh")
+        s.out_img = out
+        return out, (s if save else None)
+
+    # ---- backward ----------------------------------------------------------------------------------------------------
+    def _wgrad(self, s, i, x_in, dy, x_co=0):
+        """parameter gradients of node i: dense side / gathered side by layer kind; x_in may be a channel slice"""
+        ops, sp, lw, grad = self.ops, self.nodes[i].spec, s.lows[i], self.master.grad
+        dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
+        if sp.kind == "conv":
+            ops.wgrad(lw.wgrad, dy, x_in, dw, g_co=x_co)
+        else:
+            ops.wgrad(lw.wgrad, x_in, dy, dw, a_co=x_co)
+        self.grad_dirty = True
+
+    def _bias_slice(self, i, want_w):
+        sp = self.nodes[i].spec
+        return self.master.grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
+
+    def _dgrad(self, s, i, dy, out=None, out_co=0, accumulate=False):
+        sp, lw = self.nodes[i].spec, s.lows[i]
+        gx = out if out is not None else self._new(s.N, lw.in_dims, sp.cin_p)
+        dpack = s.pk["dpack"][s.pk["d_off"][i]:]
+        for g in lw.dgrad:
+            self.ops.gconv(g, dy, dpack, None, gx, out_co=out_co, accumulate=accumulate)
+        return gx
+
+    def _block_backward(self, s, blk, rec, g, g2, g2_co, want_w):
+        """gradient w.r.t. the block output (g [+ g2 slice]) -> total gradient w.r.t. D0 (= down, or xcat)"""
+        ops, h = self.ops, blk.C // 2
+        dsl = (lambda name: self._slope(name, grad=True)) if want_w else (lambda name: None)
+        gu = torch.empty_like(rec.out)
+        ops.pnorm_backward(g, rec.Xn, None, gu, C=blk.C, slope=self._slope(blk.tail_slope), dslope=dsl(blk.tail_slope),
+                           g2=g2, g2_co=g2_co, res=rec.D0, res_mode=1)
+        G = gu.clone()                                   # becomes the gradient w.r.t. core's input, in place
+        for (nf, sf, ng, sg), (X, Y, ya, mra, yb, mrb) in zip(reversed(blk.couplings), reversed(rec.coup)):
+            # y2 = x2 + G(y1): gradient of G's conv output from the y2 half, its data gradient joins the y1 half
+            dyb = torch.empty_like(yb)
+            ops.pnorm_backward(G, yb, mrb, dyb, C=h, slope=self._slope(sg), dslope=dsl(sg), g_co=h,
+                               bias_grad=self._bias_slice(ng, want_w))
+            if want_w:
+                self._wgrad(s, ng, Y, dyb, x_co=0)
+            self._dgrad(s, ng, dyb, out=G, out_co=0, accumulate=True)
+            # y1 = x1 + F(x2)
+            dya = torch.empty_like(ya)
+            ops.pnorm_backward(G, ya, mra, dya, C=h, slope=self._slope(sf), dslope=dsl(sf), g_co=0,
+                               bias_grad=self._bias_slice(nf, want_w))
+            if want_w:
+                self._wgrad(s, nf, X, dya, x_co=h)
+            self._dgrad(s, nf, dya, out=G, out_co=h, accumulate=True)
+        ops.add_views(G, gu, blk.C, accumulate=True)     # out = core(D0) + D0
+        return G
+
+    def _backward(self, s, g_img, need_input_grad, want_w, start=None, inj_x=None, inj_y=None):
+        assert start is None and not inj_x and not inj_y, "feature taps are not implemented for Vnet3D"
+        ops, c, L, N = self.ops, self.c, self.L, s.N
+        if self.master.grad is None:
+            self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        grad = self.master.grad
+        dsl = (lambda name: self._slope(name, grad=True)) if want_w else (lambda name: None)
+        # OutBlock
+        gz = torch.empty_like(s.z)
+        ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, gz, act="tanh")
+        if want_w:
+            self._wgrad(s, self.n_o2, s.t, gz)
+            sp = self.nodes[self.n_o2].spec
+            ops.bias_grad(gz, sp.cout_p, grad[self.b_off[self.n_o2]:self.b_off[self.n_o2] + sp.cout_p])
+        gt = self._dgrad(s, self.n_o2, gz)
+        dy = torch.empty_like(s.y_o1)
+        ops.pnorm_backward(gt, s.y_o1, s.mr_o1, dy, C=2 * c, slope=self._slope(self.s_o1), dslope=dsl(self.s_o1),
+                           bias_grad=self._bias_slice(self.n_o1, want_w))
+        if want_w:
+            self._wgrad(s, self.n_o1, s.o_in, dy)
+        g_cur = self._dgrad(s, self.n_o1, dy)            # gradient w.r.t. the last UpBlock's output
+        # UpBlocks, last first; skip gradients are slices of the blocks' xcat gradients
+        skip_grad = {}                                   # forward skip index -> (tensor, channel offset)
+        for i in range(L - 1, -1, -1):
+            blk, rec = self.ups[i], s.up[i]
+            h = blk.C // 2
+            G = self._block_backward(s, blk, rec, g_cur, None, 0, want_w)
+            skip_grad[i] = (G, h)
+            dy = torch.empty_like(rec.y)
+            ops.pnorm_backward(G, rec.y, rec.mr, dy, C=h, slope=self._slope(blk.conv_slope),
+                               dslope=dsl(blk.conv_slope), g_co=0, bias_grad=self._bias_slice(blk.conv, want_w))
+            if want_w:
+                self._wgrad(s, blk.conv, rec.x_in, dy)
+            g_cur = self._dgrad(s, blk.conv, dy)         # w.r.t. the previous UpBlock's output / the last DownBlock's
+        # DownBlocks, deepest first: output k also fed UpBlock L-1-k as its skip (k < L-1)
+        for k in range(L - 1, -1, -1):
+            blk, rec = self.downs[k], s.down[k]
+            g2, g2_co = skip_grad[L - 2 - k] if k < L - 1 else (None, 0)
+            G = self._block_backward(s, blk, rec, g_cur, g2, g2_co, want_w)
+            dy = torch.empty_like(rec.y)
+            ops.pnorm_backward(G, rec.y, rec.mr, dy, C=blk.C, slope=self._slope(blk.conv_slope),
+                               dslope=dsl(blk.conv_slope), bias_grad=self._bias_slice(blk.conv, want_w))
+            if want_w:
+                self._wgrad(s, blk.conv, rec.x_in, dy)
+            g_cur = self._dgrad(s, blk.conv, dy)
+        # InputBlock: out1 also was the skip of the last UpBlock
+        g2, g2_co = skip_grad[L - 1]
+        dy = torch.empty_like(s.y_in)
+        gres = torch.empty_like(s.y_in) if need_input_grad else None
+        ops.pnorm_backward(g_cur, s.y_in, s.mr_in, dy, C=c, slope=self._slope(self.s_in), dslope=dsl(self.s_in),
+                           g2=g2, g2_co=g2_co, res=s.a0, res_mode=1, res_mod=self.in_channels, gres=gres,
+                           bias_grad=self._bias_slice(self.n_in, want_w))
+        if want_w:
+            self._wgrad(s, self.n_in, s.a0, dy)
+        if not need_input_grad:
+            return None
+        gx = self._dgrad(s, self.n_in, dy)
+        g_in = torch.empty_like(s.x_img)
+        ops.image_to_act_backward(gx, g_in, fold=0)
+        ops.repeat_backward(gres, g_in, c)               # adjoint of x.repeat (vnet3d.py:165-166)
+        return g_in

@@ -34,6 +34,15 @@ class Node:
     aliases: Tuple[str, ...] = ()  # additional state_dict prefixes holding the same tensors
 
 
+@dataclass
+class Extra:
+    """A non-conv parameter vector kept in the flat master buffer after the conv layers (nn.PReLU slopes)."""
+    name: str                    # state_dict key, e.g. "in_ab.relu.weight"
+    size: int
+    init: float = 0.25           # nn.PReLU default; ganslate's init_weights leaves it alone (nn/utils.py:13-36)
+    aliases: Tuple[str, ...] = ()
+
+
 class _Saved:
     __slots__ = ("x_img", "acts", "ys", "mrs", "out_img", "lows", "N")
 
@@ -41,7 +50,8 @@ class _Saved:
 class NativeNet:
     """Hand-written fwd/bwd of a conv network over an ops backend (HIP in production)."""
 
-    def __init__(self, nodes: List[Node], in_channels: int, out_channels: int, out_act: str = "none", ops=None):
+    def __init__(self, nodes: List[Node], in_channels: int, out_channels: int, out_act: str = "none", ops=None,
+                 extras: Optional[List[Extra]] = None):
         self.ops = ops if ops is not None else get_ops()
         self.device = self.ops.device
         self.nodes = nodes
@@ -54,6 +64,11 @@ class NativeNet:
         for nd in nodes:
             self.w_off.append(off); off += nd.spec.master_numel
             self.b_off.append(off); off += nd.spec.cout_p
+        self.extras = list(extras or [])
+        self.x_off = {}
+        for ex in self.extras:
+            self.x_off[ex.name] = off
+            off += (ex.size + 7) // 8 * 8
         self.numel = off
         self.master = torch.nn.Parameter(torch.zeros(off, dtype=torch.float32, device=self.device))
         self.master.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
@@ -110,9 +125,17 @@ class NativeNet:
             else:
                 raise NotImplementedError(f"initialization method `{init_type}` is not implemented")
             flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
+        for ex in self.extras:
+            flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = ex.init
         with torch.no_grad():
             self.master.copy_(flat.to(self.device))
         self._packs_dirty = True
+
+    def extra(self, name, grad=False):
+        """view of an extra parameter vector (padded to 8) in the master / gradient buffer"""
+        o = self.x_off[name]
+        n = (next(e.size for e in self.extras if e.name == name) + 7) // 8 * 8
+        return (self.master.grad if grad else self.master.detach())[o:o + n]
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """torch-layout tensors under the reference's module names (incl. aliases such as encoder.N == model.N)."""
@@ -125,6 +148,10 @@ class NativeNet:
                 sd[f"{prefix}.weight"] = w
                 if nd.spec.bias:
                     sd[f"{prefix}.bias"] = b
+        for ex in self.extras:
+            v = m[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+            for key in (ex.name,) + tuple(ex.aliases):
+                sd[key] = v
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -135,6 +162,8 @@ class NativeNet:
             flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
             if nd.spec.bias and f"{nd.name}.bias" in sd:
                 flat[self.b_off[i]:self.b_off[i] + nd.spec.cout] = sd[f"{nd.name}.bias"].detach().float().cpu()
+        for ex in self.extras:
+            flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = sd[ex.name].detach().float().cpu().reshape(-1)
         with torch.no_grad():
             self.master.copy_(flat.to(self.device))
         self._packs_dirty = True
@@ -146,6 +175,8 @@ class NativeNet:
         for i, nd in enumerate(self.nodes):
             sd[f"{nd.name}.weight"] = nd.spec.torch_from_master(g[self.w_off[i]:self.w_off[i] + nd.spec.master_numel])
             sd[f"{nd.name}.bias"] = g[self.b_off[i]:self.b_off[i] + nd.spec.cout].clone()
+        for ex in self.extras:
+            sd[ex.name] = g[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
         return sd
 
     def mark_packs_dirty(self):

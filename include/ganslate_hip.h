@@ -58,7 +58,9 @@ typedef struct gs_gconv_desc {
   int32_t act;                 /* GS_ACT_* applied in the epilogue (after bias) */
   float   slope;               /* LeakyReLU slope */
   int32_t stats_slots;         /* partial-stat slots per image in `stats` (0 = no stats) */
-  int32_t stats_slot0;         /* first slot this class writes; it writes ceil(Hc*Wc/tile_m) slots */
+  int32_t stats_slot0;         /* first slot this class writes; it writes ceil(Dc*Hc*Wc/tile_m) slots */
+  int32_t accumulate;          /* != 0: out += result (bf16 read-modify-write; the gradient joins of the additive
+                                * coupling blocks, ganslate/nn/invertible.py:8-48); no bias/activation/stats then */
   int8_t  dh[GS_MAX_TAPS];
   int8_t  dw[GS_MAX_TAPS];
   int8_t  dd[GS_MAX_TAPS];
@@ -134,6 +136,37 @@ int gs_norm_act_forward_ex(const gs_norm_ex_desc* d, const void* y, const float*
 int gs_norm_act_backward_ex(const gs_norm_ex_desc* d, const void* g1, const void* g2, const void* y,
                             const float* mean_rstd, void* dy, float* scratch, float* bias_grad, void* stream);
 int64_t gs_norm_backward_ex_scratch_floats(const gs_norm_ex_desc* d);
+
+/* ---- V-Net elementwise family (nn/generators/vnet/vnet3d.py:155-267; memcnn.AdditiveCoupling via nn/invertible.py) ----
+ * InstanceNorm3d(affine=False) -> [+ residual] -> nn.PReLU(C) -> [+ residual] on channel slices, and its backward incl.
+ * the gradient of the learnable slope:
+ *   forward : u = norm(y) (mean_rstd == NULL: u = y);  res_mode 1: u += res;  v = u > 0 ? u : slope[c]*u (slope == NULL:
+ *             v = u);  res_mode 2: v += res;  out = v
+ *   backward: gt = g (+ g2);  gu = gt*(u > 0 ? 1 : slope[c]);  dslope[c] += sum gt*min(u, 0);  gres = gu (optional);
+ *             dy = rstd*(gu - mean gu - yhat*mean(gu*yhat)) (no norm: dy = gu);  bias_grad[c] += sum over pixels of dy
+ * res_mod > 0: channel c reads residual channel c % res_mod (InputBlock's x.repeat, vnet3d.py:162-167). */
+typedef struct gs_pnorm_desc {
+  int64_t pixels;                           /* D*H*W of one image */
+  int32_t N, C;                             /* C multiple of 8 */
+  int32_t y_cs, y_co;                       /* channel stride / offset (elements) of every operand view */
+  int32_t res_mode, res_cs, res_co, res_mod;
+  int32_t out_cs, out_co;
+  int32_t g_cs, g_co, g2_cs, g2_co;
+  int32_t dy_cs, dy_co, gres_cs, gres_co;
+} gs_pnorm_desc;
+int gs_pnorm_forward(const gs_pnorm_desc* d, const void* y, const float* mean_rstd, const void* res, const float* slope,
+                     void* out, void* stream);
+int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const void* g2, const void* y, const float* mean_rstd,
+                      const void* res, const float* slope, void* dy, void* gres, float* dslope, float* bias_grad,
+                      float* scratch, void* stream);
+int64_t gs_pnorm_backward_scratch_floats(const gs_pnorm_desc* d);
+/* dst[view] = src[view] (accumulate == 0) or dst[view] += src[view]: gradient joins (out + down, torch.cat skip halves,
+ * vnet3d.py:198-200,239-243) */
+int gs_add_views(void* dst, int32_t dst_cs, int32_t dst_co, const void* src, int32_t src_cs, int32_t src_co,
+                 int64_t pixels, int32_t C, int32_t accumulate, void* stream);
+/* adjoint of x.repeat(1, C/Cin, 1, 1, 1): g_img[n][c0][pix] += sum over c = c0 (mod Cin) of g[pix][c] */
+int gs_repeat_backward(const void* g, int32_t g_cs, int32_t g_co, float* g_img, int32_t N, int32_t Cin, int32_t C,
+                       int64_t pixels, void* stream);
 
 /* ---- network boundary: NCHW fp32 images <-> NHWC bf16 activations ------------------------------- */
 /* x NCHW fp32 [N,C,H,W] -> act [N,H,W,Cp]  (set_input, cyclegan.py:84-90) */

@@ -224,6 +224,11 @@ CASES_3D = {
     # anisotropic patch, identity loss on, batch 2
     "v16x24x32_idt": dict(size=[16, 24, 32], batch=2, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
                           lambda_identity=0.5, proportion_ssim=0.0, n_residual_blocks=3, d_layers=2, seed=52),
+    # brats yaml networks: Vnet3D(16; down 2,2,3; up 3,3,3) + PatchGAN3D(2 layers), lr_G 4e-4 is the CUT yaml's; the
+    # cyclegan yaml keeps the defaults
+    "vnet_16x32x32": dict(size=[16, 32, 32], batch=1, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
+                          lambda_identity=0.0, proportion_ssim=0.0, d_layers=2, seed=53,
+                          vnet=dict(first_layer_channels=16, down_blocks=[2, 2, 3], up_blocks=[3, 3, 3])),
 }
 
 
@@ -231,9 +236,16 @@ def make_conf_3d(c):
     conf = make_conf(c)
     conf.train.metrics["ssim"] = False
     gan = conf.train.gan
-    gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Resnet3D",
-                                   "n_residual_blocks": c["n_residual_blocks"],
-                                   "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
+    if "vnet" in c:
+        # brats yaml generator (projects/brats_mri_sequence_translation/experiments/*.yaml): Vnet3D, no memory saving
+        gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet3D", "use_memory_saving": False,
+                                       "use_inverse": False, "first_layer_channels": c["vnet"]["first_layer_channels"],
+                                       "down_blocks": c["vnet"]["down_blocks"], "up_blocks": c["vnet"]["up_blocks"],
+                                       "is_separable": False, "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
+    else:
+        gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Resnet3D",
+                                       "n_residual_blocks": c["n_residual_blocks"],
+                                       "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
     gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
                                        "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
                                        "in_channels": {"B": 1, "A": 1}})
@@ -272,13 +284,17 @@ def run_case_3d(name, c):
 
 
 def main_3d(out):
-    from ganslate.nn.generators import Resnet3D, Unet3D
+    from ganslate.nn.generators import Resnet3D, Unet3D, Vnet3D
     from ganslate.nn.discriminators import PatchGAN3D
     vol = {
         "nets": {
             "resnet3d_16x24x32_3blocks": net_case("r3", Resnet3D(1, 1, "instance", 3), (1, 1, 16, 24, 32), 61),
             "patchgan3d_32_3layers": net_case("p3", PatchGAN3D(1, 64, 3, 4, "instance"), (2, 1, 32, 32, 32), 62),
             "patchgan3d_2ch_2layers": net_case("p2", PatchGAN3D(2, 64, 2, 4, "instance"), (1, 2, 16, 24, 20), 63),
+            "vnet3d_brats_blocks": net_case("v3", Vnet3D(1, 1, "instance", 16, (2, 2, 3), (3, 3, 3), False, False),
+                                            (1, 1, 16, 24, 32), 65),
+            "vnet3d_2ch_small": net_case("v2", Vnet3D(2, 1, "instance", 8, (1, 2), (2, 1), False, False),
+                                         (2, 2, 8, 12, 16), 66),
             "unet3d_5downs": net_case("u3", Unet3D(1, 1, 5, "instance", ngf=8), (1, 1, 32, 32, 64), 64),
         },
         "steps": {name: run_case_3d(name, c) for name, c in CASES_3D.items()},

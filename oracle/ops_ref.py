@@ -87,7 +87,7 @@ class RefOps:
 
     # ---- convolution family ---------------------------------------------------------------------------
     def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
-              stats=None, stats_slots=0, stats_slot0=0):
+              stats=None, stats_slots=0, stats_slot0=0, accumulate=False):
         N = x.shape[0]
         xin = _v5(x)[..., in_co:in_co + g.Ci].float()
         Wt = wpack[g.pack_offset:g.pack_offset + g.w_rows * g.Kp].view(g.w_rows, g.Kp).float()
@@ -113,7 +113,10 @@ class RefOps:
         oz = torch.arange(g.Dc) * g.so + g.pz
         oh = torch.arange(g.Hc) * g.so + g.py
         ow = torch.arange(g.Wc) * g.so + g.px
-        _v5(out)[:, oz[:, None, None], oh[None, :, None], ow[None, None, :], out_co:out_co + g.Co] = acc.to(out.dtype)
+        idx = (slice(None), oz[:, None, None], oh[None, :, None], ow[None, None, :], slice(out_co, out_co + g.Co))
+        if accumulate:      # bf16 read-modify-write like the kernel epilogue
+            acc = acc.to(out.dtype).float() + _v5(out)[idx].float()
+        _v5(out)[idx] = acc.to(out.dtype)
 
     def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
         av = _v5(a)[..., a_co:a_co + w.P].float()
@@ -235,6 +238,69 @@ class RefOps:
         dy.copy_(d.to(dy.dtype))
         if bias_grad is not None:
             bias_grad[:Cc] += d.sum((0, 1, 2))
+
+    # ---- V-Net elementwise family: IN3d -> [+res] -> PReLU(C) -> [+res] (vnet3d.py:155-267, invertible.py:8-48) --------
+    @staticmethod
+    def _p_preact(y, mean_rstd, res, res_mode, res_mod, C_, y_co, res_co):
+        N = y.shape[0]
+        bc = (N,) + (1,) * (y.dim() - 2) + (C_,)
+        yh = y[..., y_co:y_co + C_].float()
+        if mean_rstd is not None:
+            mr = mean_rstd.view(N, 2, C_)
+            yh = (yh - mr[:, 0].reshape(bc)) * mr[:, 1].reshape(bc)
+        r = None
+        if res is not None:
+            if res_mod > 0:
+                r = res[..., res_co + (torch.arange(C_) % res_mod)].float()
+            else:
+                r = res[..., res_co:res_co + C_].float()
+        u = yh + r if res_mode == 1 else yh
+        return yh, u, r
+
+    def pnorm_forward(self, y, mean_rstd, out, *, C, slope=None, res=None, res_mode=0, res_mod=0, y_co=0, res_co=0,
+                      out_co=0):
+        yh, u, r = self._p_preact(y, mean_rstd, res, res_mode, res_mod, C, y_co, res_co)
+        v = torch.where(u > 0, u, u * slope[:C]) if slope is not None else u
+        if res_mode == 2:
+            v = v + r
+        out[..., out_co:out_co + C] = v.to(out.dtype)
+
+    def pnorm_backward(self, g, y, mean_rstd, dy, *, C, slope=None, dslope=None, g2=None, res=None, res_mode=0,
+                       res_mod=0, gres=None, bias_grad=None, g_co=0, g2_co=0, y_co=0, res_co=0, dy_co=0, gres_co=0):
+        yh, u, _ = self._p_preact(y, mean_rstd, res, res_mode, res_mod, C, y_co, res_co)
+        gt = g[..., g_co:g_co + C].float()
+        if g2 is not None:
+            gt = gt + g2[..., g2_co:g2_co + C].float()
+        if slope is not None:
+            gu = torch.where(u > 0, gt, gt * slope[:C])
+            if dslope is not None:
+                dslope[:C] += torch.where(u > 0, torch.zeros_like(u), gt * u).reshape(-1, C).sum(0)
+        else:
+            gu = gt
+        if gres is not None:
+            gres[..., gres_co:gres_co + C] = gu.to(gres.dtype)
+        if mean_rstd is None:
+            dy[..., dy_co:dy_co + C] = gu.to(dy.dtype)
+            return
+        N = y.shape[0]
+        sp = tuple(range(1, y.dim() - 1))
+        rstd = mean_rstd.view(N, 2, C)[:, 1].reshape((N,) + (1,) * (y.dim() - 2) + (C,))
+        d = rstd * (gu - gu.mean(sp, keepdim=True) - yh * (gu * yh).mean(sp, keepdim=True))
+        dy[..., dy_co:dy_co + C] = d.to(dy.dtype)
+        if bias_grad is not None:
+            bias_grad[:C] += d.reshape(-1, C).sum(0)
+
+    def add_views(self, dst, src, C, dst_co=0, src_co=0, accumulate=True):
+        v = src[..., src_co:src_co + C].float()
+        if accumulate:
+            v = v + dst[..., dst_co:dst_co + C].float()
+        dst[..., dst_co:dst_co + C] = v.to(dst.dtype)
+
+    def repeat_backward(self, g, g_img, C, g_co=0):
+        Cin = g_img.shape[1]
+        gv = g[..., g_co:g_co + C].float()
+        for c0 in range(Cin):
+            g_img[:, c0] += gv[..., c0::Cin].sum(-1)
 
     # ---- network boundary --------------------------------------------------------------------------------
     def image_to_act(self, img, act_t):

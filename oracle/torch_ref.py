@@ -212,6 +212,129 @@ class Unet3D(nn.Module):
         return self.model(x)
 
 
+# ---- Vnet3D (ganslate/nn/generators/vnet/vnet3d.py:27-267 + ganslate/nn/invertible.py:8-48) --------------------------
+# memcnn (third-party, unpinned in the reference: setup.cfg:31, absent from the container) is restated from its
+# published algorithm: AdditiveCoupling splits channels in two halves, y1 = x1 + Fm(x2), y2 = x2 + Gm(y1), Gm a deep
+# copy of Fm; InvertibleModuleWrapper(disable=True) is a plain call. Module names follow memcnn's (`_fn`, `Fm`, `Gm`).
+class _AdditiveCoupling(nn.Module):
+    def __init__(self, Fm, Gm):
+        super().__init__()
+        self.Fm, self.Gm = Fm, Gm
+
+    def forward(self, x):
+        x1, x2 = torch.chunk(x, 2, dim=1)
+        y1 = x1 + self.Fm(x2)
+        y2 = x2 + self.Gm(y1)
+        return torch.cat([y1, y2], dim=1)
+
+
+class _Wrapper(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self._fn = fn
+
+    def forward(self, x):
+        return self._fn(x)
+
+
+class _InvertibleBlock(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        mk = lambda: nn.Sequential(nn.Conv3d(h, h, 5, padding=2), nn.InstanceNorm3d(h), nn.PReLU(h))
+        self.invertible_block = _Wrapper(_AdditiveCoupling(mk(), mk()))
+
+    def forward(self, x):
+        return self.invertible_block(x)
+
+
+class _InvertibleSequence(nn.Module):
+    def __init__(self, h, n):
+        super().__init__()
+        self.sequence = nn.Sequential(*[_InvertibleBlock(h) for _ in range(n)])
+
+    def forward(self, x):
+        return self.sequence(x)
+
+
+class _VInput(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.n_repeats = cout // cin
+        self.conv1 = nn.Conv3d(cin, cout, 5, padding=2)
+        self.bn1 = nn.InstanceNorm3d(cout)
+        self.relu = nn.PReLU(cout)
+
+    def forward(self, x):
+        return self.relu(self.bn1(self.conv1(x)) + x.repeat(1, self.n_repeats, 1, 1, 1))
+
+
+class _VDown(nn.Module):
+    def __init__(self, cin, n):
+        super().__init__()
+        cout = 2 * cin
+        self.down_conv_ab = nn.Sequential(nn.Conv3d(cin, cout, 2, stride=2), nn.InstanceNorm3d(cout), nn.PReLU(cout))
+        self.core = _InvertibleSequence(cout // 2, n)
+        self.relu = nn.PReLU(cout)
+
+    def forward(self, x):
+        down = self.down_conv_ab(x)
+        return self.relu(self.core(down) + down)
+
+
+class _VUp(nn.Module):
+    def __init__(self, cin, cout, n):
+        super().__init__()
+        self.up_conv_ab = nn.Sequential(nn.ConvTranspose3d(cin, cout // 2, 2, stride=2), nn.InstanceNorm3d(cout // 2),
+                                        nn.PReLU(cout // 2))
+        self.core = _InvertibleSequence(cout // 2, n)
+        self.relu = nn.PReLU(cout)
+
+    def forward(self, x, skip):
+        xcat = torch.cat((self.up_conv_ab(x), skip), 1)
+        return self.relu(self.core(xcat) + xcat)
+
+
+class _VOut(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv3d(cin, cin, 5, padding=2)
+        self.bn1 = nn.InstanceNorm3d(cin)
+        self.relu1 = nn.PReLU(cin)
+        self.conv2 = nn.Conv3d(cin, cout, 1)
+
+    def forward(self, x):
+        return torch.tanh(self.conv2(self.relu1(self.bn1(self.conv1(x)))))
+
+
+class Vnet3D(nn.Module):
+    """use_inverse=False, use_memory_saving=False, is_separable=False (the brats yaml's settings)"""
+
+    def __init__(self, in_channels, out_channels, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
+                 up_blocks=(2, 2, 1, 1)):
+        super().__init__()
+        c = first_layer_channels
+        self.in_ab = _VInput(in_channels, c)
+        self.out_ab = _VOut(2 * c, out_channels)
+        self.downs = nn.ModuleList([_VDown(c * 2 ** i, n) for i, n in enumerate(down_blocks)])
+        self.encoder = nn.ModuleList([self.in_ab]).extend(self.downs)
+        ucf = [2 * 2 ** i for i in reversed(range(len(down_blocks)))]
+        ups = [_VUp(c * ucf[0], c * ucf[0], up_blocks[0])]
+        for i, n in enumerate(up_blocks[1:]):
+            ups.append(_VUp(c * ucf[i], c * ucf[i + 1], n))
+        self.ups = nn.ModuleList(ups)
+
+    def forward(self, x):
+        out1 = self.in_ab(x)
+        downs = []
+        for i, d in enumerate(self.downs):
+            downs.append(d(out1 if i == 0 else downs[-1]))
+        rev = list(reversed(downs))
+        out = rev[0]
+        for i, up in enumerate(self.ups):
+            out = up(out, out1 if i == len(self.ups) - 1 else rev[i + 1])
+        return self.out_ab(out)
+
+
 def seeded_state_dict(module: nn.Module, seed: int, gain=0.02, bias_gain=0.01):
     """Deterministic weights independent of module construction order / torch's default init RNG use:
     every tensor of the state_dict (in key order, aliases share one draw) ~ N(0, gain) (biases N(0, bias_gain))
@@ -276,8 +399,11 @@ class CycleGANStep:
     def __init__(self, in_ch=3, out_ch=3, n_blocks=9, ndf=64, n_layers=3, lr_G=2e-4, lr_D=2e-4, beta1=0.5,
                  beta2=0.999, lambda_AB=10.0, lambda_BA=10.0, lambda_identity=0.0, proportion_ssim=0.0,
                  pool_size=50, adv="lsgan", n_iters=100, n_iters_decay=100, metrics_ssim=True, metrics_D=True,
-                 seed=0, dims=2):
+                 seed=0, dims=2, vnet=None):
         G, D = (Resnet2D, PatchGAN2D) if dims == 2 else (Resnet3D, PatchGAN3D)
+        if vnet is not None:          # brats yaml generator: Vnet3D(first_layer_channels, down_blocks, up_blocks)
+            G = lambda i, o, _n: Vnet3D(i, o, vnet["first_layer_channels"], tuple(vnet["down_blocks"]),
+                                        tuple(vnet["up_blocks"]))
         self.nets = OrderedDict(G_AB=G(in_ch, out_ch, n_blocks), G_BA=G(out_ch, in_ch, n_blocks),
                                 D_B=D(out_ch, ndf, n_layers), D_A=D(in_ch, ndf, n_layers))
         for k, (name, net) in enumerate(self.nets.items()):

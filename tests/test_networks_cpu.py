@@ -86,6 +86,20 @@ def test_unet3d_forward_backward(fp32_oracle_backend):
     _compare(Unet3D(1, 1, 5, "instance", ngf=8), torch_ref.Unet3D(1, 1, 5, 8), (1, 1, 32, 32, 64), 43)
 
 
+def test_vnet3d_forward_backward(fp32_oracle_backend):
+    """Vnet3D (vnet3d.py:27-267): additive couplings on channel slices with in-place gradient joins, PReLU slope
+    gradients, k2 s2 down / transposed convs, channel-repeat input residual"""
+    from ganslate_amd.nn.generators import Vnet3D
+    native = Vnet3D(1, 1, "instance", 8, (1, 2), (2, 1), use_memory_saving=False, use_inverse=False)
+    _compare(native, torch_ref.Vnet3D(1, 1, 8, (1, 2), (2, 1)), (2, 1, 8, 12, 16), 44)
+
+
+def test_vnet3d_two_input_channels(fp32_oracle_backend):
+    from ganslate_amd.nn.generators import Vnet3D
+    native = Vnet3D(2, 1, "instance", 8, (1,), (1,), use_memory_saving=False, use_inverse=False)
+    _compare(native, torch_ref.Vnet3D(2, 1, 8, (1,), (1,)), (1, 2, 8, 8, 8), 45)
+
+
 def test_frozen_network_gets_no_weight_gradients(fp32_oracle_backend):
     """set_requires_grad(D, False) during the G step: input gradient flows, parameter gradients do not (K20)"""
     from ganslate_amd.nn.discriminators import PatchGAN2D

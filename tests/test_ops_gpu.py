@@ -263,6 +263,80 @@ def test_image_boundary_3d(hip_ops):
         close_f32(outs[1][3], outs[0][3], "image_to_act bwd", rel=1e-5)
 
 
+@pytest.mark.parametrize("norm", [True, False])
+@pytest.mark.parametrize("res_mode,res_mod", [(0, 0), (1, 0), (2, 0), (1, 2)])
+def test_pnorm_forward_backward(hip_ops, norm, res_mode, res_mod):
+    """IN3d -> [+res] -> PReLU(C) -> [+res] on channel slices, slope gradient, gres (vnet3d.py:155-267)"""
+    N, sp, C, Cb = 2, (6, 7, 9), 16, 48           # operands are 16-channel slices of 48-channel buffers
+    g = torch.Generator().manual_seed(20)
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    ybuf = (rnd(N, *sp, Cb) * 2 + 0.3).to(torch.bfloat16)
+    res = rnd(N, *sp, 8 if res_mod else Cb).to(torch.bfloat16)
+    gbuf, g2buf = rnd(N, *sp, Cb).to(torch.bfloat16), rnd(N, *sp, Cb).to(torch.bfloat16)
+    slope = rnd(C) * 0.3
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        y = ybuf.to(dev)
+        mr = None
+        if norm:
+            yv = y[..., 16:32].float()
+            part = torch.stack([yv.sum((1, 2, 3)), (yv * yv).sum((1, 2, 3))], 1).reshape(-1).contiguous()
+            mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+            ops.inorm_finalize(part, N, 1, C, sp[0] * sp[1] * sp[2], mr)
+        kw = dict(C=C, slope=slope.to(dev), res=res.to(dev) if res_mode else None, res_mode=res_mode,
+                  res_mod=res_mod, y_co=16, res_co=0 if res_mod else 32)
+        out = torch.zeros(N, *sp, Cb, dtype=torch.bfloat16, device=dev)
+        ops.pnorm_forward(y, mr, out, out_co=8, **kw)
+        dy = torch.zeros(N, *sp, 32, dtype=torch.bfloat16, device=dev)
+        gres = torch.zeros(N, *sp, 24, dtype=torch.bfloat16, device=dev)
+        dslope = torch.full((C,), 0.5, device=dev)
+        db = torch.zeros(C, device=dev)
+        ops.pnorm_backward(gbuf.to(dev), y, mr, dy, g2=g2buf.to(dev), dslope=dslope, gres=gres, bias_grad=db,
+                           g_co=0, g2_co=24, dy_co=16, gres_co=8, **kw)
+        outs.append((out, dy, gres, dslope, db))
+    close_bf16(outs[1][0], outs[0][0], "pnorm fwd")
+    close_bf16(outs[1][1], outs[0][1], "pnorm dy")
+    close_bf16(outs[1][2], outs[0][2], "pnorm gres")
+    close_f32(outs[1][3], outs[0][3], "dslope", rel=3e-3)
+    if norm:   # the bias gradient in front of a norm is zero up to rounding on both sides
+        assert outs[1][4].abs().max().item() <= 1e-2 * outs[0][1].float().abs().sum().item() / C
+
+
+def test_gconv_accumulate_into_slice(hip_ops):
+    """data gradient accumulated into one half of a coupling block's gradient buffer (invertible.py:8-48)"""
+    spec, N, sizes = ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, (8, 8, 12)
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 21)
+    g = torch.Generator().manual_seed(22)
+    gy = torch.randn(N, *sizes, 16, generator=g).to(torch.bfloat16)
+    base = torch.randn(N, *sizes, 32, generator=g).to(torch.bfloat16)
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        G = base.clone().to(dev)
+        for gc in low.dgrad:
+            ops.gconv(gc, gy.to(dev), dpack.to(dev), None, G, out_co=16, accumulate=True)
+        outs.append(G)
+    assert torch.equal(outs[1][..., :16].cpu(), base[..., :16]), "the other half must be untouched"
+    close_bf16(outs[1], outs[0], "accumulated dgrad")
+
+
+def test_add_views_and_repeat_backward(hip_ops):
+    g = torch.Generator().manual_seed(23)
+    N, sp = 2, (4, 6, 5)
+    a = torch.randn(N, *sp, 32, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, *sp, 16, generator=g).to(torch.bfloat16)
+    gimg = torch.randn(N, 2, *sp, generator=g)
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        d1, d2 = a.clone().to(dev), a.clone().to(dev)
+        ops.add_views(d1, b.to(dev), 8, dst_co=16, src_co=8, accumulate=True)
+        ops.add_views(d2, b.to(dev), 16, dst_co=0, src_co=0, accumulate=False)
+        gi = gimg.clone().to(dev)
+        ops.repeat_backward(a.to(dev), gi, 16, g_co=8)
+        outs.append((d1, d2, gi))
+    assert torch.equal(outs[1][0].cpu(), outs[0][0]) and torch.equal(outs[1][1].cpu(), outs[0][1])
+    close_f32(outs[1][2], outs[0][2], "repeat backward", rel=1e-5)
+
+
 @pytest.mark.parametrize("C,Cp", [(3, 8), (1, 8), (6, 8)])
 def test_image_boundary(hip_ops, C, Cp):
     N, H, W = 2, 20, 24

@@ -27,6 +27,8 @@ NET_BUILDERS = {
     "patchgan3d_32_3layers": lambda: torch_ref.PatchGAN3D(1, 64, 3, 4),
     "patchgan3d_2ch_2layers": lambda: torch_ref.PatchGAN3D(2, 64, 2, 4),
     "unet3d_5downs": lambda: torch_ref.Unet3D(1, 1, 5, 8),
+    "vnet3d_brats_blocks": lambda: torch_ref.Vnet3D(1, 1, 16, (2, 2, 3), (3, 3, 3)),
+    "vnet3d_2ch_small": lambda: torch_ref.Vnet3D(2, 1, 8, (1, 2), (2, 1)),
 }
 
 
@@ -88,7 +90,8 @@ def test_cyclegan3d_step_restatement_matches_reference(name):
     gold = VOLUMES["steps"][name]
     c = gold["config"]
     torch.manual_seed(c["seed"])
-    model = CycleGANStep(in_ch=1, out_ch=1, n_blocks=c["n_residual_blocks"], n_layers=c["d_layers"],
+    model = CycleGANStep(in_ch=1, out_ch=1, n_blocks=c.get("n_residual_blocks", 0), n_layers=c["d_layers"],
+                         vnet=c.get("vnet"),
                          n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"], pool_size=c["pool_size"],
                          lambda_identity=c["lambda_identity"], proportion_ssim=0.0, metrics_ssim=False,
                          seed=c["seed"], dims=3)

@@ -34,6 +34,14 @@ def test_unet3d_hip_vs_oracle(hip_ops):
               (1, 1, 32, 32, 64), 73, grad_tol=0.30, grad_cos=0.95)
 
 
+@pytest.mark.parametrize("cin,c,downs,ups,dhw", [(1, 16, (2, 2, 3), (3, 3, 3), (16, 24, 32)),
+                                                 (2, 8, (1, 2), (2, 1), (16, 24, 32))])
+def test_vnet3d_hip_vs_oracle(hip_ops, cin, c, downs, ups, dhw):
+    from ganslate_amd.nn.generators import Vnet3D
+    _net_case(hip_ops, lambda: Vnet3D(cin, 1, "instance", c, downs, ups, use_memory_saving=False, use_inverse=False),
+              torch_ref.Vnet3D(cin, 1, c, downs, ups), (1, cin, *dhw), 74, grad_tol=0.30, grad_cos=0.95)
+
+
 def test_resnet3d_matches_reference_golden(hip_ops):
     from ganslate_amd.nn.generators import Resnet3D
     gold = load_golden_volumes()["nets"]["resnet3d_16x24x32_3blocks"]
@@ -48,7 +56,7 @@ def test_resnet3d_matches_reference_golden(hip_ops):
     assert abs(y.double().abs().sum().item() - gold["y_abs_sum"]) <= 2e-2 * gold["y_abs_sum"]
 
 
-@pytest.mark.parametrize("name", ["v32_default", "v16x24x32_idt"])
+@pytest.mark.parametrize("name", ["v32_default", "v16x24x32_idt", "vnet_16x32x32"])
 def test_volume_training_step_matches_reference_golden(hip_ops, name):
     gold = load_golden_volumes()["steps"][name]
     c = gold["config"]
