@@ -49,7 +49,7 @@ def make_pix2pix_conf(batch, n_iters):
     return init_config(y, Config)
 
 
-def make_volume_conf(batch, size, n_iters):
+def make_volume_conf(batch, size, n_iters, generator="resnet"):
     """BASELINE configs[4] shape family (3-D CycleGAN on 128^3 single-channel patches, conv3d implicit GEMM) with the
     reference's Resnet3D(9 blocks) + PatchGAN3D(3 layers) (33.2 TFLOP per pair)"""
     from ganslate_amd.configs.config import Config
@@ -63,10 +63,14 @@ def make_volume_conf(batch, size, n_iters):
                         "final_size": [size, size, size]},
             "gan": {
                 "_target_": "ganslate.nn.gans.unpaired.CycleGAN", "pool_size": 50,
-                "generator": {"_target_": "ganslate.nn.generators.Resnet3D", "n_residual_blocks": 9,
-                              "in_out_channels": {"AB": [1, 1]}},
-                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN3D", "n_layers": 3,
-                                  "in_channels": {"B": 1}},
+                # vnet: the brats yaml networks (projects/brats_mri_sequence_translation/experiments/cyclegan.yaml)
+                "generator": ({"_target_": "ganslate.nn.generators.Vnet3D", "use_memory_saving": False,
+                               "use_inverse": False, "down_blocks": [2, 2, 3], "up_blocks": [3, 3, 3],
+                               "in_out_channels": {"AB": [1, 1]}} if generator == "vnet" else
+                              {"_target_": "ganslate.nn.generators.Resnet3D", "n_residual_blocks": 9,
+                               "in_out_channels": {"AB": [1, 1]}}),
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN3D",
+                                  "n_layers": 2 if generator == "vnet" else 3, "in_channels": {"B": 1}},
                 "optimizer": {"lambda_AB": 10.0, "lambda_BA": 10.0, "lambda_identity": 0, "proportion_ssim": 0,
                               "lr_D": 0.0002, "lr_G": 0.0002},
             },
@@ -128,9 +132,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cyclegan3d"],
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cyclegan3d", "brats"],
                     help="cyclegan = the headline (BASELINE configs[1]); pix2pix = configs[2] (batch 1, 256x512); "
-                         "cyclegan3d = 3-D CycleGAN on 128^3 volumes (configs[4] shape, batch 1)")
+                         "cyclegan3d = 3-D CycleGAN on 128^3 volumes with Resnet3D (configs[4] shape, batch 1); "
+                         "brats = configs[4] with the brats yaml's own networks (Vnet3D + PatchGAN3D-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -157,13 +162,16 @@ def main():
             args.batch = 1
         model = build_gan(make_pix2pix_conf(args.batch, 10 ** 6))
         shape = (args.batch, 3, 256, 512)
-    elif args.workload == "cyclegan3d":
+    elif args.workload in ("cyclegan3d", "brats"):
         args.no_cpu_baseline = True
+        if args.workload == "brats":
+            args.no_kernel_timing = True
         if args.batch == 8:
             args.batch = 1
         if args.size == 256:
             args.size = 128
-        model = build_gan(make_volume_conf(args.batch, args.size, 10 ** 6))
+        model = build_gan(make_volume_conf(args.batch, args.size, 10 ** 6,
+                                           "vnet" if args.workload == "brats" else "resnet"))
         shape = (args.batch, 1, args.size, args.size, args.size)
     else:
         model = build_gan(make_conf(args.batch, args.size, 10 ** 6))
@@ -216,16 +224,19 @@ def main():
                           "data": "synthetic", "config": {"workload": "cityscapes pix2pix (BASELINE configs[2])",
                                                           "global_batch": args.batch * world},
                           "step_tflops": round(value * 371.5 / 1e3, 1)}), flush=True)
-    elif rank == 0 and args.workload == "cyclegan3d":
+    elif rank == 0 and args.workload in ("cyclegan3d", "brats"):
         value = args.batch * world * args.steps / dt
-        tflop_per_pair = 33.2 * (args.size / 128.0) ** 3          # SURVEY.md §8 row a15 at 128^3
-        out = {"metric": "training volumes/sec, 3-D CycleGAN Resnet3D-9 + PatchGAN3D-3 bf16",
+        vnet = args.workload == "brats"
+        # SURVEY.md §8 rows a15 / a16 at 128^3
+        tflop_per_pair = (27.7 if vnet else 33.2) * (args.size / 128.0) ** 3
+        nets = "Vnet3D(16; 2,2,3 / 3,3,3) + PatchGAN3D-2" if vnet else "Resnet3D-9 + PatchGAN3D-3"
+        out = {"metric": f"training volumes/sec, 3-D CycleGAN {nets} bf16",
                "value": round(value, 4), "unit": "vol/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic",
                "config": {"workload": f"3-D CycleGAN {args.size}^3 single-channel patches (BASELINE configs[4] "
-                                      "shape), Resnet3D 9 blocks + PatchGAN3D 3 layers, lsgan, lambda 10/10",
+                                      f"shape), {nets}, lsgan, lambda 10/10",
                           "global_batch": args.batch * world, "parallelism": f"dp{world}"},
                "step_tflops": round(value * tflop_per_pair, 1),
                "step_mfma_frac": round(value * tflop_per_pair / (PEAK_BF16_TFLOPS * world), 4)}

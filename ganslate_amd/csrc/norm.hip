@@ -6,32 +6,34 @@
 #include "common.hpp"
 
 // ---- slot reduction: in [N][slots][R][C] -> per (n, c) totals over the slots ---------------------------------------
-// grid (ceil(C/16), N), 256 threads = 16 channels x 16 slot lanes.
+// grid (ceil(C/CH), N), 256 threads = CH channels x 256/CH slot lanes (CH = 16, or 4 for narrow layers whose volumes
+// produce thousands of slots: more workgroups and shorter serial chains).
 //  R == 2 (forward): totals are (sum y, sum y^2)  -> out [N][2][C] = (mean, rstd)
 //  R == 3 (backward): totals are (sum ghat, sum ghat*yhat, sum yhat) -> out [N][3][C]; optionally the bias gradient of
 //           the conv in front of the norm, db[c] += sum_n -rstd * S2 * S3 / hw  (= sum_pixels dy, see norm backward)
-template <int R>
+template <int R, int CH = 16>
 __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* out, int slots, int C, float inv_hw,
                                                        float eps, const float* mean_rstd, float* db) {
-  __shared__ double red[16][17];
-  __shared__ float tot[R][16];
+  constexpr int LANES = 256 / CH;
+  __shared__ double red[LANES][CH + 1];
+  __shared__ float tot[R][CH];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  const int col = tid & 15, lane = tid >> 4;
-  const int c = blockIdx.x * 16 + col;
+  const int col = tid % CH, lane = tid / CH;
+  const int c = blockIdx.x * CH + col;
   const float* src = in + (size_t)n * slots * R * C;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
     if (c < C)
-      for (int sl = lane; sl < slots; sl += 16) s += (double)src[((size_t)sl * R + r) * C + c];
+      for (int sl = lane; sl < slots; sl += LANES) s += (double)src[((size_t)sl * R + r) * C + c];
     __syncthreads();
     red[lane][col] = s;
     __syncthreads();
     if (lane == 0) {
       double t = 0.0;
 #pragma unroll
-      for (int l = 0; l < 16; ++l) t += red[l][col];
+      for (int l = 0; l < LANES; ++l) t += red[l][col];
       tot[r][col] = (float)t;
     }
   }
@@ -57,8 +59,12 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
 extern "C" int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
                                  float* mean_rstd, void* stream) {
   GS_REQUIRE(partial && mean_rstd && N > 0 && slots > 0 && C > 0 && hw > 0, "gs_inorm_finalize: bad argument");
-  hipLaunchKernelGGL((slot_sum_kernel<2>), dim3((C + 15) / 16, N), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     partial, mean_rstd, slots, C, 1.0f / (float)hw, eps, (const float*)nullptr, (float*)nullptr);
+  if (C < 128 && slots > 256)
+    hipLaunchKernelGGL((slot_sum_kernel<2, 4>), dim3((C + 3) / 4, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       partial, mean_rstd, slots, C, 1.0f / (float)hw, eps, (const float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((slot_sum_kernel<2>), dim3((C + 15) / 16, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       partial, mean_rstd, slots, C, 1.0f / (float)hw, eps, (const float*)nullptr, (float*)nullptr);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -289,8 +295,12 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
 // shared with norm_ex.hip
 int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, float inv_hw, const float* mean_rstd,
                         float* db, hipStream_t st) {
-  hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
-                     mean_rstd, db);
+  if (C < 128 && slots > 256)
+    hipLaunchKernelGGL((slot_sum_kernel<3, 4>), dim3((C + 3) / 4, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
+                       mean_rstd, db);
+  else
+    hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
+                       mean_rstd, db);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -338,9 +348,7 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
     GS_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, scratch, sums, chunks, C,
-                       1.0f / (float)HW, 0.f, mean_rstd, bias_grad);
-    GS_CHECK_HIP(hipGetLastError());
+    if (int rc = gs_launch_slot_sum3(scratch, sums, N, chunks, C, 1.0f / (float)HW, mean_rstd, bias_grad, st)) return rc;
   }
   const long long per_img = (long long)HW * C8;
   GS_REQUIRE(per_img < (1LL << 31), "gs_inorm_act_backward: image too large");

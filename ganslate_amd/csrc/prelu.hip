@@ -174,27 +174,29 @@ __global__ __launch_bounds__(256) void pnorm_bwd_reduce_kernel(const PNormK p, c
 
 // pass 2: per (n, c) totals over the chunks -> sums [N][4][C]; parameter gradients:
 //   dslope[c] += S4;  bias_grad[c] += -rstd*S2*S3/hw (sum over pixels of dy, the bias of the conv in front of the norm)
+template <int CH>
 __global__ __launch_bounds__(256) void pnorm_bwd_finalize_kernel(const float* partial, float* sums, int chunks, int C,
                                                                  float inv_hw, const float* mean_rstd, float* dslope,
                                                                  float* db) {
-  __shared__ double red[16][17];
-  __shared__ float tot[4][16];
+  constexpr int LANES = 256 / CH;
+  __shared__ double red[LANES][CH + 1];
+  __shared__ float tot[4][CH];
   const int n = blockIdx.y, tid = threadIdx.x;
-  const int col = tid & 15, lane = tid >> 4;
-  const int c = blockIdx.x * 16 + col;
+  const int col = tid % CH, lane = tid / CH;
+  const int c = blockIdx.x * CH + col;
   const float* src = partial + (size_t)n * chunks * 4 * C;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     double s = 0.0;
     if (c < C)
-      for (int sl = lane; sl < chunks; sl += 16) s += (double)src[((size_t)sl * 4 + r) * C + c];
+      for (int sl = lane; sl < chunks; sl += LANES) s += (double)src[((size_t)sl * 4 + r) * C + c];
     __syncthreads();
     red[lane][col] = s;
     __syncthreads();
     if (lane == 0) {
       double t = 0.0;
 #pragma unroll
-      for (int l = 0; l < 16; ++l) t += red[l][col];
+      for (int l = 0; l < LANES; ++l) t += red[l][col];
       tot[r][col] = (float)t;
     }
   }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void pnorm_bwd_apply_kernel(const PNormK p, co
 }
 
 static int pn_pix_per_block(long long pixels) {
-  long long ppb = (pixels + 4095) / 4096;
+  long long ppb = (pixels + 2047) / 2048;
   return ppb < 64 ? 64 : (int)((ppb + 63) / 64 * 64);
 }
 
@@ -311,8 +313,12 @@ extern "C" int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const vo
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
     GS_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(pnorm_bwd_finalize_kernel, dim3((d->C + 15) / 16, d->N), dim3(256), 0, st, scratch, sums, chunks,
-                       d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
+    if (d->C < 128 && chunks > 256)
+      hipLaunchKernelGGL((pnorm_bwd_finalize_kernel<4>), dim3((d->C + 3) / 4, d->N), dim3(256), 0, st, scratch, sums,
+                         chunks, d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
+    else
+      hipLaunchKernelGGL((pnorm_bwd_finalize_kernel<16>), dim3((d->C + 15) / 16, d->N), dim3(256), 0, st, scratch, sums,
+                         chunks, d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
     GS_CHECK_HIP(hipGetLastError());
   }
   long long bx = ((long long)k.HW * k.C8 + 255) / 256;
