@@ -202,6 +202,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_dt = time.perf_counter() - t0          # time the host needed to enqueue the K steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -263,6 +264,7 @@ def main():
                                    f"batch {args.batch} per GPU, lsgan, lambda 10/10, pool 50, Adam(2e-4, 0.5), "
                                    "SSIM + D-output metrics on",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
             "step_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 1),
             "step_mfma_frac": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }

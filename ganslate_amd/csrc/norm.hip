@@ -117,22 +117,22 @@ extern "C" int gs_inorm_act_forward(const void* y, const float* mean_rstd, const
 
 // ---- backward ------------------------------------------------------------------------------------------
 // folded gradient: g(n, ih, iw, c8) = sum over the padded-domain positions that the padding maps to (ih, iw)
-// (reflect: up to 3 sources; replicate: the border cell collects its `p` pad cells — needs p <= 3)
-struct FoldIdx { int idx[8]; int cnt; };
-__device__ __forceinline__ FoldIdx fold_sources(int x, int n, int p, int mode) {
+// reflect: up to 3 source positions per axis; replicate: one contiguous range per axis (the border cell collects its
+// `p` pad cells). Kept as two code paths so the index lists stay in registers.
+struct FoldIdx { int idx[3]; int cnt; };
+__device__ __forceinline__ FoldIdx fold_sources(int x, int n, int p) {
   FoldIdx f;
   f.idx[0] = x + p;
   f.cnt = 1;
   if (p > 0) {
-    if (mode == GS_BORDER_REFLECT) {
-      if (x >= 1 && x <= p) f.idx[f.cnt++] = p - x;
-      if (x >= n - 1 - p && x <= n - 2) f.idx[f.cnt++] = p + 2 * (n - 1) - x;
-    } else if (mode == GS_BORDER_REPLICATE) {
-      if (x == 0) for (int k = 0; k < p; ++k) f.idx[f.cnt++] = k;
-      if (x == n - 1) for (int k = 1; k <= p; ++k) f.idx[f.cnt++] = n - 1 + p + k;
-    }
+    if (x >= 1 && x <= p) f.idx[f.cnt++] = p - x;
+    if (x >= n - 1 - p && x <= n - 2) f.idx[f.cnt++] = p + 2 * (n - 1) - x;
   }
   return f;
+}
+__device__ __forceinline__ void fold_range(int x, int n, int p, int& lo, int& hi) {   // replicate
+  lo = x == 0 ? 0 : x + p;
+  hi = x == n - 1 ? n - 1 + 2 * p : x + p;
 }
 
 __device__ __forceinline__ void add_bf8(float* f, const uint4 v) {
@@ -141,23 +141,41 @@ __device__ __forceinline__ void add_bf8(float* f, const uint4 v) {
 }
 
 // px = (iz*H + ih)*W + iw is the unpadded pixel index; the depth axis is only padded when D > 1
+// FM (compile-time fold mode): 0 = no fold, 1 = reflect 2-D, 2 = reflect 3-D, 3 = replicate
+template <int FM>
 __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const uint4* g2_n, int px, int D, int H,
-                                            int W, int C8, int c8, int fold, int mode) {
+                                            int W, int C8, int c8, int fold) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) f[k] = 0.f;
-  if (fold == 0) {
+  if constexpr (FM == 0) {
     add_bf8(f, gpad_n[(size_t)px * C8 + c8]);
   } else {
     const int zi = px / W, iw = px - zi * W;
-    const int iz = zi / H, ih = zi - iz * H;
     const int Wp = W + 2 * fold, Hp = H + 2 * fold;
-    const FoldIdx fd = fold_sources(iz, D, D > 1 ? fold : 0, mode);
-    const FoldIdx fh = fold_sources(ih, H, fold, mode);
-    const FoldIdx fw = fold_sources(iw, W, fold, mode);
-    for (int c = 0; c < fd.cnt; ++c)
+    if constexpr (FM == 1) {                            // the 2-D nets (nn.ReflectionPad2d)
+      const FoldIdx fh = fold_sources(zi, H, fold);
+      const FoldIdx fw = fold_sources(iw, W, fold);
       for (int a = 0; a < fh.cnt; ++a)
-        for (int b = 0; b < fw.cnt; ++b)
-          add_bf8(f, gpad_n[(((size_t)fd.idx[c] * Hp + fh.idx[a]) * Wp + fw.idx[b]) * C8 + c8]);
+        for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.idx[a] * Wp + fw.idx[b]) * C8 + c8]);
+    } else if constexpr (FM == 2) {
+      const int iz = zi / H, ih = zi - iz * H;
+      const FoldIdx fd = fold_sources(iz, D, fold);
+      const FoldIdx fh = fold_sources(ih, H, fold);
+      const FoldIdx fw = fold_sources(iw, W, fold);
+      for (int c = 0; c < fd.cnt; ++c)
+        for (int a = 0; a < fh.cnt; ++a)
+          for (int b = 0; b < fw.cnt; ++b)
+            add_bf8(f, gpad_n[(((size_t)fd.idx[c] * Hp + fh.idx[a]) * Wp + fw.idx[b]) * C8 + c8]);
+    } else {                                            // replicate (nn.ReplicationPad3d)
+      const int iz = zi / H, ih = zi - iz * H;
+      int d0, d1, h0, h1, w0, w1;
+      fold_range(iz, D, D > 1 ? fold : 0, d0, d1);
+      fold_range(ih, H, fold, h0, h1);
+      fold_range(iw, W, fold, w0, w1);
+      for (int c = d0; c <= d1; ++c)
+        for (int a = h0; a <= h1; ++a)
+          for (int b = w0; b <= w1; ++b) add_bf8(f, gpad_n[(((size_t)c * Hp + a) * Wp + b) * C8 + c8]);
+    }
   }
   if (g2_n) add_bf8(f, g2_n[(size_t)px * C8 + c8]);
 }
@@ -177,7 +195,7 @@ __device__ __forceinline__ void unpack8(float* f, const uint4 v) {
 
 // pass 1: per (n, pixel-chunk, column group) partial sums of ghat and ghat*yhat  -> scratch [N][chunks][2][C]
 // 256 threads = COLS 8-channel columns x (256/COLS) pixel lanes; grid (chunks, N, ceil(C8/COLS))
-template <int COLS>
+template <int COLS, int FM>
 __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
                                                                const float* mean_rstd, float* partial, int D, int H,
                                                                int W, int C8, int fold, int mode, int act,
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
     load8(rs, mr + C8 * 8 + c8 * 8);
     for (int px = p0 + row; px < p1; px += ROWS) {
       float g[8], yy[8];
-      load_folded(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold, mode);
+      load_folded<FM>(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold);
       unpack8(yy, y_n[(size_t)px * C8 + c8]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
 }
 
 // pass 2: dy = rstd * (ghat - S1/hw - yhat*S2/hw) ; optional gsum = folded gradient (before act')
+template <int FM>
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
                                                               const float* mean_rstd, const float* sums, uint4* dy,
                                                               uint4* gsum, int D, int H, int W, int C8,
@@ -256,13 +275,13 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
     const unsigned px = c8_shift >= 0 ? (e >> c8_shift) : e / (unsigned)C8;
     const int c8 = (int)(e - px * (unsigned)C8);
     float g[8], yy[8], d[8];
-    if (fold == 0) {
+    if constexpr (FM == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) g[k] = 0.f;
       add_bf8(g, gpad_n[e]);
       if (g2_n) add_bf8(g, g2_n[e]);
     } else {
-      load_folded(g, gpad_n, g2_n, (int)px, D, H, W, C8, c8, fold, mode);
+      load_folded<FM>(g, gpad_n, g2_n, (int)px, D, H, W, C8, c8, fold);
     }
     if (gs_n) {
       uint4 o;
@@ -334,19 +353,29 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   const int C8 = C / 8;
   const int HW = D * H * W;
   const int kBwdPixPerBlock = bwd_pix_per_block(HW);
+  // compile-time fold mode of the kernels: 0 none, 1 reflect 2-D, 2 reflect 3-D, 3 replicate
+  const int fm = fold == 0 ? 0 : (fold_mode == GS_BORDER_REFLECT ? (D == 1 ? 1 : 2) : 3);
   float* sums = nullptr;
   if (mean_rstd) {
     GS_REQUIRE(scratch, "gs_inorm_act_backward: scratch required with normalisation");
     const int chunks = (HW + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
     sums = scratch + (size_t)N * chunks * 3 * C;
-#define GS_LAUNCH_REDUCE(COLS)                                                                                   \
-  hipLaunchKernelGGL((inorm_bwd_reduce_kernel<COLS>), dim3(chunks, N, (C8 + COLS - 1) / COLS), dim3(256), 0, st, \
-                     static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y), \
+#define GS_LAUNCH_REDUCE2(COLS, FM)                                                                                   \
+  hipLaunchKernelGGL((inorm_bwd_reduce_kernel<COLS, FM>), dim3(chunks, N, (C8 + COLS - 1) / COLS), dim3(256), 0, st, \
+                     static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y),     \
                      mean_rstd, scratch, D, H, W, C8, fold, fold_mode, act, slope, kBwdPixPerBlock, chunks)
+#define GS_LAUNCH_REDUCE(COLS)                                        \
+  do {                                                                \
+    if (fm == 0) GS_LAUNCH_REDUCE2(COLS, 0);                          \
+    else if (fm == 1) GS_LAUNCH_REDUCE2(COLS, 1);                     \
+    else if (fm == 2) GS_LAUNCH_REDUCE2(COLS, 2);                     \
+    else GS_LAUNCH_REDUCE2(COLS, 3);                                  \
+  } while (0)
     if (C8 >= 32) GS_LAUNCH_REDUCE(32);
     else if (C8 >= 8) GS_LAUNCH_REDUCE(8);
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
+#undef GS_LAUNCH_REDUCE2
     GS_CHECK_HIP(hipGetLastError());
     if (int rc = gs_launch_slot_sum3(scratch, sums, N, chunks, C, 1.0f / (float)HW, mean_rstd, bias_grad, st)) return rc;
   }
@@ -356,10 +385,16 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   if (bx > 1024) bx = 1024;
   int c8_shift = -1;
   if ((C8 & (C8 - 1)) == 0) { c8_shift = 0; while ((1 << c8_shift) < C8) ++c8_shift; }
-  hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)bx, N), dim3(256), 0, st,
-                     static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y),
-                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), D, H, W, C8, c8_shift, fold,
-                     fold_mode, act, slope);
+#define GS_LAUNCH_APPLY(FM)                                                                                        \
+  hipLaunchKernelGGL((inorm_bwd_apply_kernel<FM>), dim3((unsigned)bx, N), dim3(256), 0, st,                         \
+                     static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y), \
+                     mean_rstd, sums, static_cast<uint4*>(dy), static_cast<uint4*>(gsum), D, H, W, C8, c8_shift,    \
+                     fold, fold_mode, act, slope)
+  if (fm == 0) GS_LAUNCH_APPLY(0);
+  else if (fm == 1) GS_LAUNCH_APPLY(1);
+  else if (fm == 2) GS_LAUNCH_APPLY(2);
+  else GS_LAUNCH_APPLY(3);
+#undef GS_LAUNCH_APPLY
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -27,7 +27,7 @@ struct WGradK {
 // over all 16 slots
 __device__ __forceinline__ int wg_swz(int R) { return ((R & 3) << 1) | (((R >> 3) & 1) << 3); }
 
-template <int BP, int BQ, int WP, int WQ, int VARIANT = 0>
+template <int BP, int BQ, int WP, int WQ, int VARIANT = 0, bool VOL = true>
 __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   constexpr int NW = WP * WQ, BK = 64, NSTAGE = 3;
   constexpr int ARB = BP * 2, GRB = BQ * 2;                  // row bytes of the two LDS tiles
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     const int rem = m - nz * HW;
     gi[i] = div_small(rem, d.Wa, p.rcp_wa);
     gj[i] = rem - gi[i] * d.Wa;
-    gn[i] = div_small(nz, d.Da, p.rcp_da);
-    gz[i] = nz - gn[i] * d.Da;
+    gn[i] = VOL ? div_small(nz, d.Da, p.rcp_da) : nz;
+    gz[i] = VOL ? nz - gn[i] * d.Da : 0;
   }
 
   auto issue = [&](int ks, int buf) {      // always called with ks increasing by 1
@@ -117,9 +117,14 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
       const int nn = gn[i], zz = gz[i], ii = gi[i], jj = gj[i];
       gj[i] += BK;
       while (gj[i] >= d.Wa) { gj[i] -= d.Wa; ++gi[i]; }
-      while (gi[i] >= d.Ha) { gi[i] -= d.Ha; ++gz[i]; }
-      while (gz[i] >= d.Da) { gz[i] -= d.Da; ++gn[i]; }
-      const int iz = border_index(zz * d.si + g_dd, d.Dg, d.border, ok);
+      int iz = 0;
+      if constexpr (VOL) {
+        while (gi[i] >= d.Ha) { gi[i] -= d.Ha; ++gz[i]; }
+        while (gz[i] >= d.Da) { gz[i] -= d.Da; ++gn[i]; }
+        iz = border_index(zz * d.si + g_dd, d.Dg, d.border, ok);
+      } else {
+        while (gi[i] >= d.Ha) { gi[i] -= d.Ha; ++gn[i]; }
+      }
       const int ih = border_index(ii * d.si + g_dh, d.Hg, d.border, ok);
       const int iw = border_index(jj * d.si + g_dw, d.Wg, d.border, ok);
       unsigned off = (((unsigned)nn * g_img + (unsigned)((iz * d.Hg + ih) * d.Wg + iw)) * (unsigned)d.g_cs + (unsigned)(g_q8 * 8)) * 2u;
@@ -218,8 +223,8 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
 }
 
 namespace {
-template <int BP, int BQ, int WP, int WQ, int VARIANT = 0>
-int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
+template <int BP, int BQ, int WP, int WQ, int VARIANT = 0, bool VOL = true>
+int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   k.tiles_p = (d->P + BP - 1) / BP;
   k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
   // split-K over the batch-flattened pixel index: one workgroup per CU is resident (144 KiB of LDS), so aim for
@@ -251,13 +256,19 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 4 + 1024;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ, VARIANT>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ, VARIANT, VOL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ, VARIANT>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
+  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ, VARIANT, VOL>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
+}
+template <int BP, int BQ, int WP, int WQ, int VARIANT = 0>
+int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
+  // depth-1 tensors (the 2-D nets) run the instantiation without the depth bookkeeping in the K loop
+  if (d->Da == 1 && d->Dg == 1) return launch_wgrad_impl<BP, BQ, WP, WQ, VARIANT, false>(k, d, st);
+  return launch_wgrad_impl<BP, BQ, WP, WQ, VARIANT, true>(k, d, st);
 }
 }  // namespace
 
