@@ -80,6 +80,13 @@ _PROTOS = {
                                            C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_image_to_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_image_unfold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_image_unfold_backward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 11 + [C.c_void_p]),
+    "gs_shiftadd_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_shiftadd_to_image_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_mse_const": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_l1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

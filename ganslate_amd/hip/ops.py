@@ -236,6 +236,30 @@ class HipOps:
                                                   L.BORDER[fold_mode], int(accumulate), _stream()),
                 "gs_image_to_act_backward")
 
+    # ---- W-fold boundary transforms of the k7 stem / last layer (csrc/wfold.hip) ---------------------------------
+    def image_unfold(self, img, act_t, k, p, border):
+        N, Cc, rows, W = self._img_dims(img)
+        L.check(self.lib.gs_image_unfold(_ptr(img), _ptr(act_t), N, Cc, rows, W, act_t.shape[-1], k, p,
+                                         L.BORDER[border], _stream()), "gs_image_unfold")
+
+    def image_unfold_backward(self, g, g_img, k, p, fold, border, accumulate=False):
+        N, Cc = g_img.shape[0], g_img.shape[1]
+        D, H, W = g_img.shape[2:] if g_img.dim() == 5 else (1,) + tuple(g_img.shape[2:])
+        L.check(self.lib.gs_image_unfold_backward(_ptr(g), _ptr(g_img), N, Cc, D, H, W, g.shape[-1], k, p, fold,
+                                                  L.BORDER[border], int(accumulate), _stream()),
+                "gs_image_unfold_backward")
+
+    def shiftadd_to_image(self, z, bias, img, k, act="none"):
+        N, Cc, rows, W = self._img_dims(img)
+        L.check(self.lib.gs_shiftadd_to_image(_ptr(z), _ptr(bias), _ptr(img), N, Cc, rows, W, z.shape[-1], k,
+                                              L.ACT[act], _stream()), "gs_shiftadd_to_image")
+
+    def shiftadd_to_image_backward(self, g_img, out_img, gz, k, act="none"):
+        N, Cc, rows, W = self._img_dims(g_img)
+        L.check(self.lib.gs_shiftadd_to_image_backward(_ptr(g_img), _ptr(out_img), _ptr(gz), N, Cc, rows, W,
+                                                       gz.shape[-1], k, L.ACT[act], _stream()),
+                "gs_shiftadd_to_image_backward")
+
     # ---- losses ---------------------------------------------------------------------------------------------
     def mse_const(self, x, target, loss=None, grad=None, grad_scale=None):
         L.check(self.lib.gs_mse_const(_ptr(x), x.numel(), float(target), _ptr(loss), _ptr(grad), _ptr(grad_scale),

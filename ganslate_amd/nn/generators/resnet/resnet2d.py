@@ -2,6 +2,7 @@
 names as ganslate/nn/generators/resnet/resnet2d.py:14-93:
 c7s1-64, d128, d256, n x R256, u128, u64, c7s1-out, tanh; ReflectionPad before the k7 and residual convs;
 InstanceNorm2d(affine=False) + ReLU; ConvTranspose2d(3, s2, p1, op1) up-sampling (always biased)."""
+import os
 from dataclasses import dataclass
 
 from .... import configs
@@ -15,13 +16,19 @@ class Resnet2DConfig(configs.base.BaseGeneratorConfig):
     n_residual_blocks: int = 9
 
 
-def resnet_nodes(in_channels, out_channels, use_bias, n, dims=2):
+def resnet_nodes(in_channels, out_channels, use_bias, n, dims=2, wfold=None):
     """layer list shared by Resnet2D (reflect padding, `encoder` alias — resnet2d.py:24,46,80) and Resnet3D
     (replicate padding, no `encoder` — resnet3d.py:15,24,78)"""
     pad_mode = "reflect" if dims == 2 else "replicate"
     enc = (lambda *names: tuple(names)) if dims == 2 else (lambda *names: ())
     conv = lambda *a, **k: ConvSpec(*a, dims=dims, **k)
-    nodes = [Node(conv("conv", in_channels, 64, 7, 1, 3, pad_mode=pad_mode, bias=use_bias), True, "relu",
+    # the k7 convs at the image boundary have 1-3 channels on one side: their W taps are folded into the channel axis
+    # so the 16-wide matrix tile is not mostly padding (csrc/wfold.hip); GS_WFOLD=0 keeps the plain lowering (A/B runs)
+    if wfold is None:
+        wfold = os.environ.get("GS_WFOLD", "1") != "0"
+    wf_in = "in" if (wfold and 7 * in_channels <= 32) else ""
+    wf_out = "out" if (wfold and 7 * out_channels <= 32) else ""
+    nodes = [Node(conv("conv", in_channels, 64, 7, 1, 3, pad_mode=pad_mode, bias=use_bias, wfold=wf_in), True, "relu",
                   name="model.1", aliases=enc("encoder.1"))]
     feats = 64
     for d in range(2):
@@ -41,8 +48,8 @@ def resnet_nodes(in_channels, out_channels, use_bias, n, dims=2):
         idx = 10 + n + 3 * u
         nodes.append(Node(conv("convT", feats, feats // 2, 3, 2, 1, 1), True, "relu", name=f"model.{idx}"))
         feats //= 2
-    nodes.append(Node(conv("conv", feats, out_channels, 7, 1, 3, pad_mode=pad_mode, bias=use_bias), False,
-                      "none", name=f"model.{17 + n}"))
+    nodes.append(Node(conv("conv", feats, out_channels, 7, 1, 3, pad_mode=pad_mode, bias=use_bias, wfold=wf_out),
+                      False, "none", name=f"model.{17 + n}"))
     return nodes
 
 

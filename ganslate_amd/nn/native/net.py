@@ -59,6 +59,9 @@ class NativeNet:
         assert nodes[0].spec.cin == in_channels and nodes[-1].spec.cout == out_channels
         assert not nodes[-1].norm, "last node feeds the image boundary directly"
         self.dims = nodes[0].spec.dims          # 2 = NCHW images, 3 = NCDHW volumes
+        for i, nd in enumerate(nodes):           # W-folded convs only exist at the image boundary (csrc/wfold.hip)
+            assert nd.spec.wfold in ("", "in", "out") and (nd.spec.wfold != "in" or i == 0) and \
+                (nd.spec.wfold != "out" or i == len(nodes) - 1), "W-fold: 'in' on the first, 'out' on the last layer"
         # ---- flat parameter layout: [w_0 | b_0 | w_1 | b_1 | ...] ------------------------------------------
         self.w_off, self.b_off, off = [], [], 0
         for nd in nodes:
@@ -253,8 +256,12 @@ class NativeNet:
         lows = self._lowered(*sizes)
         pk = self._get_packs(*sizes)
         m = self.master.detach()
-        a = torch.empty(N, *sizes, self.nodes[0].spec.cin_p, dtype=self.ops.act_dtype, device=dev)
-        ops.image_to_act(x, a)
+        sp0 = self.nodes[0].spec
+        a = torch.empty(N, *sizes, sp0.cin_p, dtype=self.ops.act_dtype, device=dev)
+        if sp0.wfold == "in":      # the W taps of the stem become channels while the image is converted
+            ops.image_unfold(x, a, sp0.k, sp0.pad, sp0.pad_mode)
+        else:
+            ops.image_to_act(x, a)
         acts, ys, mrs = [a], [], []
         for i, (nd, lw) in enumerate(zip(self.nodes, lows)):
             if stop is not None and i > stop:
@@ -281,15 +288,22 @@ class NativeNet:
                 acts.append(xo)
             else:
                 assert nd.res is None
+                wf_out = sp.wfold == "out"     # bias and activation move behind the shift-add
                 for g in lw.fwd:
-                    ops.gconv(g, acts[-1], fpack, bias, y, act=nd.act, slope=nd.slope)
+                    ops.gconv(g, acts[-1], fpack, None if wf_out else bias, y, act="none" if wf_out else nd.act,
+                              slope=nd.slope)
                 ys.append(None); mrs.append(None)
                 acts.append(y)
         out = None
         if stop is None:
-            lw = lows[-1]
-            out = torch.empty(N, self.out_channels, *lw.out_dims, dtype=torch.float32, device=dev)
-            ops.act_to_image(acts[-1], out, act=self.out_act)
+            lw, spl = lows[-1], self.nodes[-1].spec
+            if spl.wfold == "out":
+                out = torch.empty(N, self.out_channels, *spl.out_hw(*lw.in_dims), dtype=torch.float32, device=dev)
+                ops.shiftadd_to_image(acts[-1], m[self.b_off[-1]:self.b_off[-1] + spl.cout_p], out, spl.k,
+                                      act=self.out_act)
+            else:
+                out = torch.empty(N, self.out_channels, *lw.out_dims, dtype=torch.float32, device=dev)
+                ops.act_to_image(acts[-1], out, act=self.out_act)
         if not save:
             return out, None
         s = _Saved()
@@ -313,7 +327,11 @@ class NativeNet:
         pending = None
         if g_img is not None:
             ga = torch.empty_like(s.acts[-1])
-            ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
+            if nodes[-1].spec.wfold == "out":
+                ops.shiftadd_to_image_backward(g_img.contiguous().float(), s.out_img, ga, nodes[-1].spec.k,
+                                               act=self.out_act)
+            else:
+                ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
             pending = (ga, 0, None, "reflect")
         skip: Dict[int, torch.Tensor] = {}
         final_pass = want_w and self._dist is not None and self._fw_pending == 0
@@ -354,7 +372,12 @@ class NativeNet:
                 a_t, g_t = (dy, s.acts[i]) if sp.kind == "conv" else (s.acts[i], dy)
                 ops.wgrad(lw.wgrad, a_t, g_t, dw)
                 if sp.bias and not nd.norm:
-                    ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
+                    if sp.wfold == "out":   # channels [0, cout) of dy are the dw = 0 slice = the plain output gradient
+                        tmp = torch.zeros(sp.cout_p, dtype=torch.float32, device=dev)
+                        ops.bias_grad(dy, sp.cout_p, tmp)
+                        grad[self.b_off[i]:self.b_off[i] + sp.cout] += tmp[:sp.cout]
+                    else:
+                        ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
                 self.grad_dirty = True
                 if final_pass:
                     self._maybe_reduce_bucket(i)
@@ -372,7 +395,11 @@ class NativeNet:
             return None
         gx, f, _, fmode = pending
         g_in = torch.empty_like(s.x_img)
-        ops.image_to_act_backward(gx, g_in, fold=f, fold_mode=fmode)
+        sp0 = nodes[0].spec
+        if sp0.wfold == "in":
+            ops.image_unfold_backward(gx, g_in, sp0.k, sp0.pad, f, sp0.pad_mode)
+        else:
+            ops.image_to_act_backward(gx, g_in, fold=f, fold_mode=fmode)
         return g_in
 
     # ---- data parallelism (reference: DistributedDataParallel per network, base.py:172-189) -------------

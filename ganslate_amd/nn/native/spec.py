@@ -27,6 +27,14 @@ def roundup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def pad8pow2(c: int) -> int:
+    """smallest 8 * 2^j >= c (the gathered-channel constraint of the conv kernels)"""
+    v = 8
+    while v < c:
+        v *= 2
+    return v
+
+
 @dataclass
 class ConvSpec:
     """One convolution layer of the reference network (nn.Conv2d/3d or nn.ConvTranspose2d/3d)."""
@@ -40,13 +48,20 @@ class ConvSpec:
     pad_mode: str = "zero"        # "zero" | "reflect" | "replicate" (explicit pad layer folded into the conv)
     bias: bool = True
     dims: int = 2                 # 2 = Conv2d family, 3 = Conv3d family (resnet3d.py, patchgan3d.py)
+    # "W-fold" (stride-1 convs with very few channels on one side, i.e. the k7 stem / last layer of the ResNets): the
+    # taps of the W axis become channels, the conv that runs has a k x [k x] 1 kernel.
+    #   "in" : input channels (dw, ci) = k*cin, produced by gs_image_unfold
+    #   "out": output channels (dw, co) = k*cout on a W + 2*pad wide domain, reduced by gs_shiftadd_to_image
+    wfold: str = ""
 
     @property
-    def cin_p(self): return pad8(self.cin)
+    def cin_p(self): return pad8pow2(self.k * self.cin) if self.wfold == "in" else pad8(self.cin)
     @property
-    def cout_p(self): return pad8(self.cout)
+    def cout_p(self): return pad8pow2(self.k * self.cout) if self.wfold == "out" else pad8(self.cout)
     @property
-    def T(self): return self.k ** self.dims
+    def kw(self): return 1 if self.wfold else self.k
+    @property
+    def T(self): return self.k ** (self.dims - 1) * self.kw
     @property
     def P(self): return self.cout_p if self.kind == "conv" else self.cin_p
     @property
@@ -72,13 +87,23 @@ class ConvSpec:
         import torch
         p, q = w.shape[0], w.shape[1]
         m = torch.zeros(self.P, self.T, self.Q, dtype=torch.float32, device=w.device)
-        m[:p, :, :q] = w.reshape(p, q, self.T).permute(0, 2, 1)
+        if self.wfold == "in":       # [co][ci][t'][dw] -> [co][t'][dw*cin + ci]
+            m[:p, :, :self.k * q] = w.reshape(p, q, self.T, self.k).permute(0, 2, 3, 1).reshape(p, self.T, self.k * q)
+        elif self.wfold == "out":    # [co][ci][t'][dw] -> [dw*cout + co][t'][ci]
+            m[:self.k * p, :, :q] = w.reshape(p, q, self.T, self.k).permute(3, 0, 2, 1).reshape(self.k * p, self.T, q)
+        else:
+            m[:p, :, :q] = w.reshape(p, q, self.T).permute(0, 2, 1)
         return m
 
     def torch_from_master(self, m):
         p, q = (self.cout, self.cin) if self.kind == "conv" else (self.cin, self.cout)
-        return m.reshape(self.P, self.T, self.Q)[:p, :, :q].permute(0, 2, 1).reshape(
-            (p, q) + (self.k,) * self.dims).contiguous()
+        m = m.reshape(self.P, self.T, self.Q)
+        shape = (p, q) + (self.k,) * self.dims
+        if self.wfold == "in":
+            return m[:p, :, :self.k * q].reshape(p, self.T, self.k, q).permute(0, 3, 1, 2).reshape(shape).contiguous()
+        if self.wfold == "out":
+            return m[:self.k * p, :, :q].reshape(self.k, p, self.T, q).permute(1, 3, 2, 0).reshape(shape).contiguous()
+        return m[:p, :, :q].permute(0, 2, 1).reshape(shape).contiguous()
 
 
 @dataclass
@@ -143,6 +168,7 @@ class Lowered:
     wgrad: Optional[WGrad] = None
     Di: int = 1
     Do: int = 1
+    dgrad_dims3: Optional[Tuple[int, int, int]] = None   # (D, H, W) extent of the data-gradient tensor
 
     @property
     def in_dims(self): return (self.Hi, self.Wi) if self.spec.dims == 2 else (self.Di, self.Hi, self.Wi)
@@ -153,6 +179,8 @@ class Lowered:
     @property
     def dgrad_dims(self):
         """extent of the data-gradient tensor (the padded domain when the pad adjoint is left to the consumer)"""
+        if self.dgrad_dims3 is not None:
+            return self.dgrad_dims3 if self.spec.dims == 3 else self.dgrad_dims3[1:]
         return tuple(x + 2 * self.dgrad_fold for x in self.in_dims)
 
 
@@ -174,11 +202,21 @@ def lower(spec: ConvSpec, *sizes) -> Lowered:
     assert len(sizes) == spec.dims, f"expected {spec.dims} spatial sizes, got {sizes}"
     k, s, p = spec.k, spec.stride, spec.pad
     T, P, Q = spec.T, spec.P, spec.Q
+    wf = spec.wfold
+    assert not wf or (spec.kind == "conv" and s == 1), "W-fold applies to stride-1 convolutions"
     real = (spec.dims == 3, True, True)
     ins = ((1,) + tuple(sizes)) if spec.dims == 2 else tuple(sizes)
     ka = tuple(k if r else 1 for r in real)               # kernel extent per axis
     pa = tuple(p if r else 0 for r in real)               # padding per axis
+    woff = 0                                              # constant W offset of every tap of a W-folded conv
+    if wf:
+        ka, pa = ka[:2] + (1,), pa[:2] + (0,)
+        woff = -p if wf == "out" else 0
     outs = tuple(spec.out_size(x) if r else 1 for x, r in zip(ins, real))
+    if wf == "in":
+        outs = outs[:2] + (ins[2],)                       # the unfold already applied the W border
+    elif wf == "out":
+        outs = outs[:2] + (ins[2] + 2 * p,)               # all W + 2p shifted partial rows, reduced by the shift-add
     Di, Hi, Wi = ins
     Do, Ho, Wo = outs
     low = Lowered(spec, Hi, Wi, Ho, Wo, Di=Di, Do=Do)
@@ -215,7 +253,7 @@ def lower(spec: ConvSpec, *sizes) -> Lowered:
     if spec.kind == "conv":
         assert s in (1, 2), "stride 1 or 2"
         # forward: out[i] = sum_r in[B(i*s + r - p)] W[r]
-        fwd_offs = off(lambda r, a: r - pa[a])
+        fwd_offs = off(lambda r, a: r - pa[a] + (woff if a == 2 else 0))
         low.fwd = [gconv(ins, spec.cin_p, outs, spec.cout_p, outs, 1, (0, 0, 0), s, fwd_offs, spec.pad_mode, 0,
                          spec.cout_p)]
         low.fwd_index = _pack_index(spec.cout_p, list(range(T)), spec.cin_p, m_conv).reshape(-1)
@@ -223,10 +261,12 @@ def lower(spec: ConvSpec, *sizes) -> Lowered:
             if spec.pad_mode == "zero":
                 # dX[ih] = sum_r dY[ih + p - r] W[:, r]^T
                 low.dgrad = [gconv(outs, spec.cout_p, ins, spec.cin_p, ins, 1, (0, 0, 0), 1,
-                                   off(lambda r, a: pa[a] - r), "zero", 0, spec.cin_p)]
+                                   off(lambda r, a: pa[a] - r - (woff if a == 2 else 0)), "zero", 0, spec.cin_p)]
             else:
                 # gradient on the padded domain; the pad adjoint ("fold") is applied by the consumer
-                pad3 = tuple(x + 2 * q for x, q in zip(ins, pa))
+                # (W-fold "in": W is not padded, the unfold adjoint handles it; "out": W is padded like the other axes)
+                pad3 = tuple(x + 2 * q for x, q in zip(ins, pa[:2] + (p if wf == "out" else pa[2],)))
+                low.dgrad_dims3 = pad3
                 low.dgrad = [gconv(outs, spec.cout_p, pad3, spec.cin_p, pad3, 1, (0, 0, 0), 1,
                                    off(lambda r, a: -r), "zero", 0, spec.cin_p)]
                 low.dgrad_fold = p

@@ -184,6 +184,25 @@ int gs_act_to_image_backward(const float* g_img, const float* out_img, void* g_a
 int gs_image_to_act_backward(const void* g_pad, float* g_img, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
                              int32_t Cp, int32_t fold, int32_t fold_mode, int32_t accumulate, void* stream);
 
+/* ---- "W-fold" of the k7 boundary convolutions (resnet2d.py:24-25,64-65; resnet3d.py:24-25,64) --------------------
+ * A conv with 1-3 input (stem) or output (last layer) channels wastes the 16-wide matrix tile, so the taps of the W
+ * axis are moved into the channel axis and the conv itself runs with a k x [k x] 1 kernel through gs_gconv_forward /
+ * gs_wgrad; these are the boundary transforms and their adjoints. `rows` = D*H of a volume (or H of an image).
+ *   unfold   : act[n, r, j][dw*C + c] = img[n][c][r][B(j + dw - p)], channels >= k*C zero (fused NCHW fp32 -> NHWC bf16)
+ *   shift-add: img[n][co][r][j] = act(bias[co] + sum_dw z[n, r, j + dw][dw*Co + co]),  z is W + k - 1 wide */
+int gs_image_unfold(const float* img, void* act, int32_t N, int32_t C, int64_t rows, int32_t W, int32_t Qp, int32_t k,
+                    int32_t p, int32_t border, void* stream);
+/* adjoint of gs_image_unfold composed with the (depth, row) padding fold of the stem conv: g is the data gradient of the
+ * transformed conv on the domain padded by `fold` along depth (D > 1) and rows, W unpadded */
+int gs_image_unfold_backward(const void* g, float* g_img, int32_t N, int32_t C, int32_t D, int32_t H, int32_t W,
+                             int32_t Qp, int32_t k, int32_t p, int32_t fold, int32_t border, int32_t accumulate,
+                             void* stream);
+int gs_shiftadd_to_image(const void* z, const float* bias, float* img, int32_t N, int32_t Co, int64_t rows, int32_t W,
+                         int32_t Pp, int32_t k, int32_t act_kind, void* stream);
+/* gz[n, r, j'][dw*Co + co] = g_img[n][co][r][j' - dw] * act'(out) (zero outside [0, W)), channels >= k*Co zero */
+int gs_shiftadd_to_image_backward(const float* g_img, const float* out_img, void* gz, int32_t N, int32_t Co,
+                                  int64_t rows, int32_t W, int32_t Pp, int32_t k, int32_t act_kind, void* stream);
+
 /* ---- losses (fp32, on the boundary images / discriminator maps) --------------------------------- */
 /* loss[0] = mean((x-target)^2); if grad != NULL: grad = grad_scale * 2*(x-target)/n
  * (nn.MSELoss vs expanded constant, adversarial_loss.py:28-29,60-62) */

@@ -328,6 +328,56 @@ class RefOps:
         else:
             g_img.copy_(g)
 
+    # ---- W-fold boundary transforms (csrc/wfold.hip) -----------------------------------------------------------------
+    def image_unfold(self, img, act_t, k, p, border):
+        Cc, W = img.shape[1], img.shape[-1]
+        act_t.zero_()
+        xl = img.movedim(1, -1)                                   # [N, ..., W, C]
+        for dw in range(k):
+            j, ok = _border(torch.arange(W) + dw - p, W, border)
+            v = xl.index_select(-2, j) * ok.float()[:, None]
+            act_t[..., dw * Cc:(dw + 1) * Cc] = v.to(act_t.dtype)
+
+    def image_unfold_backward(self, g, g_img, k, p, fold, border, accumulate=False):
+        Cc, W = g_img.shape[1], g_img.shape[-1]
+        gf = g.float()
+        # (depth, row) padding adjoint on every spatial axis but W
+        sp = g_img.shape[2:]
+        for ax, n in enumerate(sp[:-1], start=1):
+            if fold == 0 or (len(sp) == 3 and ax == 1 and n == 1):
+                continue
+            src, _ = _border(torch.arange(n + 2 * fold) - fold, n, border)
+            shape = list(gf.shape); shape[ax] = n
+            nxt = torch.zeros(shape); nxt.index_add_(ax, src, gf); gf = nxt
+        out = torch.zeros(*g_img.shape[:1], *sp, Cc)             # channels-last
+        for dw in range(k):
+            j, ok = _border(torch.arange(W) + dw - p, W, border)
+            out.index_add_(out.dim() - 2, j, gf[..., dw * Cc:(dw + 1) * Cc] * ok.float()[:, None])
+        out = out.movedim(-1, 1)
+        if accumulate:
+            g_img += out
+        else:
+            g_img.copy_(out)
+
+    def shiftadd_to_image(self, z, bias, img, k, act="none"):
+        Co, W = img.shape[1], img.shape[-1]
+        acc = torch.zeros(*img.shape[:1], *img.shape[2:], Co)
+        for dw in range(k):
+            acc += z[..., dw:dw + W, dw * Co:(dw + 1) * Co].float()
+        if bias is not None:
+            acc += bias[:Co].float()
+        img.copy_(_act(acc, act, 0.0).movedim(-1, 1))
+
+    def shiftadd_to_image_backward(self, g_img, out_img, gz, k, act="none"):
+        Co, W = g_img.shape[1], g_img.shape[-1]
+        g = g_img
+        if act != "none":
+            g = g * _act_grad_from_out(out_img, act, 0.0)
+        gl = g.movedim(1, -1)
+        gz.zero_()
+        for dw in range(k):
+            gz[..., dw:dw + W, dw * Co:(dw + 1) * Co] = gl.to(gz.dtype)
+
     # ---- losses -----------------------------------------------------------------------------------------
     def mse_const(self, x, target, loss=None, grad=None, grad_scale=None):
         if loss is not None:

@@ -90,6 +90,79 @@ def test_lowering_matches_torch(spec, size):
     assert torch.allclose(db[:spec.cout], b.grad, atol=2e-3, rtol=1e-4)
 
 
+WFOLD_SPECS = [
+    (ConvSpec("conv", 3, 12, 7, 1, 3, pad_mode="reflect", wfold="in"), (10, 12)),              # resnet2d.py:24-25
+    (ConvSpec("conv", 12, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), (10, 12)),             # resnet2d.py:64-65
+    (ConvSpec("conv", 1, 6, 7, 1, 3, pad_mode="replicate", dims=3, wfold="in"), (8, 6, 10)),   # resnet3d.py:24-25
+    (ConvSpec("conv", 6, 1, 7, 1, 3, pad_mode="replicate", dims=3, wfold="out"), (7, 9, 8)),   # resnet3d.py:64
+    (ConvSpec("conv", 2, 5, 5, 1, 2, dims=3, wfold="in"), (6, 7, 8)),                          # zero padding
+    (ConvSpec("conv", 5, 2, 5, 1, 2, dims=3, wfold="out"), (6, 7, 8)),
+]
+
+
+@pytest.mark.parametrize("spec,size", WFOLD_SPECS, ids=lambda v: _ID(v) + v.wfold if isinstance(v, ConvSpec) else None)
+def test_wfold_lowering_matches_torch(spec, size):
+    """W taps folded into channels (csrc/wfold.hip): unfold / shift-add boundary transforms + the k x [k x] 1 conv
+    reproduce the plain convolution and all of its gradients"""
+    torch.manual_seed(1)
+    ops = RefOps(act_dtype=torch.float32)
+    N = 2
+    x = torch.randn(N, spec.cin, *size, requires_grad=True)
+    w = torch.randn(spec.torch_weight_shape(), requires_grad=True) * 0.2
+    w.retain_grad()
+    b = torch.randn(spec.cout, requires_grad=True)
+    y = torch_forward(spec, x, w, b)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+
+    low = lower(spec, *size)
+    master = spec.master_from_torch(w.detach())
+    assert torch.equal(spec.torch_from_master(master), w.detach())
+    fpack = torch.empty(low.fwd_index.size, dtype=torch.float32)
+    ops.repack(master, torch.from_numpy(low.fwd_index), fpack)
+    dpack = torch.empty(low.dgrad_index.size, dtype=torch.float32)
+    ops.repack(master, torch.from_numpy(low.dgrad_index), dpack)
+    bias = torch.zeros(spec.cout_p); bias[:spec.cout] = b.detach()
+    f = low.dgrad_fold
+
+    if spec.wfold == "in":
+        xa = torch.full((N, *size, spec.cin_p), float("nan"))
+        ops.image_unfold(x.detach(), xa, spec.k, spec.pad, spec.pad_mode)
+        ya = torch.full((N, *low.out_dims, spec.cout_p), float("nan"))
+        for g in low.fwd:
+            ops.gconv(g, xa, fpack, bias, ya)
+        assert torch.allclose(ya[..., :spec.cout].movedim(-1, 1), y.detach(), atol=1e-4, rtol=1e-4)
+        gya = torch.zeros(N, *low.out_dims, spec.cout_p); ops.image_to_act(gy, gya)
+        gxa = torch.full((N, *low.dgrad_dims, spec.cin_p), float("nan"))
+        for g in low.dgrad:
+            ops.gconv(g, gya, dpack, None, gxa)
+        gimg = torch.empty_like(x.detach())
+        ops.image_unfold_backward(gxa, gimg, spec.k, spec.pad, f, spec.pad_mode)
+        assert torch.allclose(gimg, x.grad, atol=1e-4, rtol=1e-4)
+        db = torch.zeros(spec.cout_p); ops.bias_grad(gya, spec.cout_p, db)
+    else:
+        xa = torch.zeros(N, *size, spec.cin_p); ops.image_to_act(x.detach(), xa)
+        za = torch.full((N, *low.out_dims, spec.cout_p), float("nan"))
+        assert low.out_dims[-1] == size[-1] + 2 * spec.pad
+        for g in low.fwd:
+            ops.gconv(g, xa, fpack, None, za)
+        img = torch.empty_like(y.detach())
+        ops.shiftadd_to_image(za, bias, img, spec.k)
+        assert torch.allclose(img, y.detach(), atol=1e-4, rtol=1e-4)
+        gya = torch.full((N, *low.out_dims, spec.cout_p), float("nan"))
+        ops.shiftadd_to_image_backward(gy, None, gya, spec.k)
+        gxa = torch.full((N, *low.dgrad_dims, spec.cin_p), float("nan"))
+        for g in low.dgrad:
+            ops.gconv(g, gya, dpack, None, gxa)
+        gx = _fold(gxa, size, f, spec.pad_mode)[..., :spec.cin].movedim(-1, 1)
+        assert torch.allclose(gx, x.grad, atol=1e-4, rtol=1e-4)
+        db = torch.zeros(spec.cout_p); ops.bias_grad(gya, spec.cout_p, db)   # first `cout` entries = the dw = 0 slice
+    dw = torch.zeros(spec.P, spec.T, spec.Q)
+    ops.wgrad(low.wgrad, gya, xa, dw)
+    assert torch.allclose(spec.torch_from_master(dw), w.grad, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(db[:spec.cout], b.grad, atol=2e-3, rtol=1e-4)
+
+
 def test_master_roundtrip():
     for spec in SPECS + SPECS_3D:
         w = torch.randn(spec.torch_weight_shape())

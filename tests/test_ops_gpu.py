@@ -362,6 +362,38 @@ def test_image_boundary(hip_ops, C, Cp):
         close_f32(outs[1][3], outs[0][3], "image_to_act bwd", rel=1e-5)
 
 
+@pytest.mark.parametrize("dims,C,Qp,border", [(2, 3, 32, "reflect"), (3, 1, 8, "replicate"), (3, 2, 16, "zero")])
+def test_wfold_boundary_transforms(hip_ops, dims, C, Qp, border):
+    """unfold / shift-add and their adjoints (csrc/wfold.hip) against the oracle"""
+    N, k, p = 2, 7, 3
+    sp = (12, 15) if dims == 2 else (5, 8, 9)
+    g = torch.Generator().manual_seed(24)
+    img = torch.rand(N, C, *sp, generator=g) * 2 - 1
+    gimg = torch.randn(N, C, *sp, generator=g)
+    Pp = Qp
+    zsp = sp[:-1] + (sp[-1] + 2 * p,)
+    z = torch.randn(N, *zsp, Pp, generator=g).to(torch.bfloat16)
+    bias = torch.randn(Pp, generator=g)
+    for fold in ((0,) if border == "zero" else (0, p)):   # zero padding never leaves a fold to the consumer
+        gsp = tuple(v + 2 * fold for v in sp[:-1]) + (sp[-1],)
+        gun = torch.randn(N, *gsp, Qp, generator=g).to(torch.bfloat16)
+        outs = []
+        for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+            a = torch.full((N, *sp, Qp), 7.0, dtype=torch.bfloat16, device=dev)
+            ops.image_unfold(img.to(dev), a, k, p, border)
+            gi = torch.ones(N, C, *sp, device=dev)
+            ops.image_unfold_backward(gun.to(dev), gi, k, p, fold, border, accumulate=True)
+            o = torch.empty(N, C, *sp, device=dev)
+            ops.shiftadd_to_image(z.to(dev), bias.to(dev), o, k, act="tanh")
+            gz = torch.full((N, *zsp, Pp), 7.0, dtype=torch.bfloat16, device=dev)
+            ops.shiftadd_to_image_backward(gimg.to(dev), o, gz, k, act="tanh")
+            outs.append((a, gi, o, gz))
+        assert torch.equal(outs[1][0].cpu(), outs[0][0]), "unfold must be bit-exact"
+        close_f32(outs[1][1], outs[0][1], "unfold backward", rel=1e-5)
+        close_f32(outs[1][2], outs[0][2], "shift-add", rel=1e-5)
+        close_bf16(outs[1][3], outs[0][3], "shift-add backward")
+
+
 def test_losses_and_metrics(hip_ops):
     g = torch.Generator().manual_seed(10)
     a = torch.rand(8, 3, 64, 64, generator=g) * 2 - 1
