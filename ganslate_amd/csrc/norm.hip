@@ -4,6 +4,7 @@
 // (ganslate/nn/utils.py:53-59; resnet2d.py:26-27,36-37,83-87,93; patchgan2d.py:45-46,58-59) and their
 // autograd backward, including the adjoint of nn.ReflectionPad2d (the `fold`).
 #include "common.hpp"
+#include <cstdlib>
 
 // ---- slot reduction: in [N][slots][R][C] -> per (n, c) totals over the slots ---------------------------------------
 // grid (ceil(C/CH), N), 256 threads = CH channels x 256/CH slot lanes (CH = 16, or 4 for narrow layers whose volumes
@@ -221,7 +222,28 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const uint4* gpad
     float mu[8], rs[8];
     load8(mu, mr + c8 * 8);
     load8(rs, mr + C8 * 8 + c8 * 8);
-    for (int px = p0 + row; px < p1; px += ROWS) {
+    // two pixels per iteration: twice the loads in flight per lane (the kernel is latency-bound at 8 waves per CU)
+    int px = p0 + row;
+    for (; px + ROWS < p1; px += 2 * ROWS) {
+      float g[8], yy[8], g_b[8], yy_b[8];
+      const uint4 ya = y_n[(size_t)px * C8 + c8];
+      const uint4 yb = y_n[(size_t)(px + ROWS) * C8 + c8];
+      load_folded<FM>(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold);
+      load_folded<FM>(g_b, gpad_n, g2_n, px + ROWS, D, H, W, C8, c8, fold);
+      unpack8(yy, ya);
+      unpack8(yy_b, yb);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float yh = (yy[k] - mu[k]) * rs[k];
+        const float gh = g[k] * act_grad_from_out(yh, act, slope);
+        const float yh2 = (yy_b[k] - mu[k]) * rs[k];
+        const float gh2 = g_b[k] * act_grad_from_out(yh2, act, slope);
+        a1[k] += gh + gh2;
+        a2[k] += gh * yh + gh2 * yh2;
+        a3[k] += yh + yh2;
+      }
+    }
+    for (; px < p1; px += ROWS) {
       float g[8], yy[8];
       load_folded<FM>(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold);
       unpack8(yy, y_n[(size_t)px * C8 + c8]);
@@ -327,6 +349,8 @@ int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, fl
 // pixels per block of the reduction pass: 64 for 2-D sized maps, more for volumes so that the second-level sum
 // stays at <= 4096 slots per image
 static int bwd_pix_per_block(long long pixels) {
+  static const int forced = getenv("GS_BWD_PPB") ? atoi(getenv("GS_BWD_PPB")) : 0;   // tuning aid
+  if (forced > 0) return forced;
   long long ppb = (pixels + 4095) / 4096;
   return ppb < 64 ? 64 : (int)((ppb + 63) / 64 * 64);
 }
