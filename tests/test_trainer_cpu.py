@@ -1,0 +1,65 @@
+"""engines.Trainer (ganslate/engines/trainer.py:11-112) driven through init_engine with a YAML,
+on the CPU oracle backend: iteration range, logging cadence, LR schedule, checkpoint cadence and resume."""
+import copy
+from pathlib import Path
+
+import pytest
+import torch
+
+from ganslate_amd.nn.native import backend
+from oracle.ops_ref import RefOps
+
+CONF = Path(__file__).parent / "configs" / "cyclegan_synthetic.yaml"
+
+
+@pytest.fixture()
+def fp32_oracle_backend():
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    yield
+    backend.set_ops(None)
+
+
+def _args(out_dir, *extra):
+    return [f"config={CONF}", "train.cuda=false", f"train.output_dir={out_dir}", "train.batch_size=1",
+            "train.n_iters=3", "train.n_iters_decay=2", "train.dataset.final_size=[32,32]", "train.seed=7",
+            "train.gan.generator.n_residual_blocks=1", "train.metrics.ssim=false",
+            "train.checkpointing.freq=2", "train.logging.freq=1", *extra]
+
+
+def test_trainer_runs_logs_checkpoints_and_resumes(fp32_oracle_backend, tmp_path):
+    from ganslate_amd.engines import init_engine
+    tr = init_engine("train", _args(tmp_path))
+    assert list(tr.iters) == [1, 2, 3, 4, 5]                       # range(1, 1 + n_iters + n_iters_decay)
+    tr.run()
+    assert [h[0] for h in tr.history] == [1, 2, 3, 4, 5]
+    for _, losses, metrics in tr.history:
+        assert set(losses) == {"G_AB", "G_BA", "D_A", "D_B", "cycle_A", "cycle_B"}
+        assert all(v == v and abs(v) < 1e4 for v in losses.values())
+        assert {"D_A_real", "D_A_fake", "D_B_real", "D_B_fake"} <= set(metrics)
+    # linear decay after n_iters (nn/utils.py:83-99): factor 1 - max(0, it + 1 - n_iters) / (n_iters_decay + 1); the
+    # scheduler has stepped 5 times -> 1 - 3/3
+    assert tr.model.optimizers["G"].param_groups[0]["lr"] == pytest.approx(0.0, abs=1e-12)
+    assert [h[0] for h in tr.history][-1] == 5
+    ckpts = sorted(p.name for p in (tmp_path / "checkpoints").iterdir())
+    assert ckpts == ["2.pth", "4.pth"]                             # freq 2, rank 0
+    ck = torch.load(tmp_path / "checkpoints" / "4.pth", map_location="cpu")
+    assert {"G_AB", "G_BA", "D_A", "D_B", "optimizer_G", "optimizer_D"} <= set(ck)
+    assert "model.1.weight" in ck["G_AB"] and "encoder.1.weight" in ck["G_AB"]   # reference key names
+
+    # resume from iteration 4: weights of the checkpoint, iteration range continues at 5
+    tr2 = init_engine("train", _args(tmp_path, "train.checkpointing.load_iter=4"))
+    assert list(tr2.iters) == [5]
+    sd = tr2.model.networks["G_AB"].state_dict()
+    assert torch.equal(sd["model.1.weight"].cpu(), ck["G_AB"]["model.1.weight"])
+    tr2.run()
+    assert [h[0] for h in tr2.history] == [5]
+
+
+def test_trainer_is_deterministic_for_a_seed(fp32_oracle_backend, tmp_path):
+    from ganslate_amd.engines import init_engine
+    runs = []
+    for k in range(2):
+        tr = init_engine("train", _args(tmp_path / f"r{k}", "train.n_iters=2", "train.n_iters_decay=0"))
+        tr.run()
+        runs.append(copy.deepcopy(tr.history))
+    assert runs[0] == runs[1]
