@@ -130,3 +130,44 @@ def test_cut_two_ranks_stay_in_sync(tmp_path):
     r0, r1 = (torch.load(tmp_path / f"cut_rank{r}.pt") for r in range(world))
     for name in r0:
         assert torch.equal(r0[name], r1[name]), f"{name}: ranks diverged"
+
+
+def _vnet_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), GANSLATE_DIST_BACKEND="gloo")
+    torch.set_num_threads(2)
+    from ganslate_amd.nn.native import backend
+    from ganslate_amd.utils import communication
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle.ops_ref import RefOps
+    communication.init_distributed()
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    # the brats yaml's networks (BASELINE configs[4]: 3-D CycleGAN, DDP) at a small width / patch
+    conf = build_conf([f"config={ROOT / 'tests/configs/cyclegan_vnet_synthetic.yaml'}", "train.batch_size=1",
+                       "train.gan.generator.first_layer_channels=8", "train.gan.generator.down_blocks=[1,1]",
+                       "train.gan.generator.up_blocks=[1,1]", "train.gan.pool_size=0",
+                       "train.dataset.final_size=[16,16,16]"])
+    torch.manual_seed(11 + rank)
+    model = build_gan(conf)
+    g = torch.Generator().manual_seed(78)
+    A, B = torch.rand(world, 1, 16, 16, 16, generator=g) * 2 - 1, torch.rand(world, 1, 16, 16, 16, generator=g) * 2 - 1
+    for step in range(2):
+        model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
+        model.optimize_parameters()
+    weights = {n: net.master.detach().clone() for n, net in model.networks.items()}
+    torch.save(weights, Path(out_dir) / f"vnet_rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_vnet3d_cyclegan_two_ranks_stay_in_sync(tmp_path):
+    """3-D CycleGAN with Vnet3D + PatchGAN3D under data parallelism (BASELINE configs[4]): conv weights AND the PReLU
+    slopes stored behind them in the flat buffer are averaged; all ranks end every step with identical parameters."""
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_vnet_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"vnet_rank{r}.pt") for r in range(world))
+    for name in r0:
+        assert torch.equal(r0[name], r1[name]), f"{name}: ranks diverged"
