@@ -379,7 +379,21 @@ int launch(const GConvK& k, int blocks, hipStream_t st) {
 }
 }  // namespace
 
+// hconv.hip: halo-resident kernel for narrow stride-1 layers
+int gs_hconv_slots(const gs_gconv_desc* d);
+int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
+                 void* stream, int* handled);
+
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
+
+extern "C" int gs_gconv_stat_slots(const gs_gconv_desc* d) {
+  if (!d || d->Dc < 1 || d->Hc < 1 || d->Wc < 1) return 0;
+  const int hs = gs_hconv_slots(d);
+  if (hs) return hs;
+  const long long pix = (long long)d->Dc * d->Hc * d->Wc;
+  const int bm = pick_tile(d).bm;
+  return (int)((pix + bm - 1) / bm);
+}
 
 extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                                 void* out, float* stats, void* stream) {
@@ -398,6 +412,11 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward: stats requested without buffer");
   GS_REQUIRE(!d->accumulate || (d->stats_slots == 0 && d->act == GS_ACT_NONE && !bias),
              "gs_gconv_forward: accumulate excludes bias, activation and statistics");
+  {
+    int handled = 0;
+    if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
+    if (handled) return 0;
+  }
   const TileCfg tc = pick_tile(d);
   GConvK k;
   k.in = static_cast<const char*>(in);

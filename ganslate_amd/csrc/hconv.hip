@@ -1,0 +1,276 @@
+// Halo-resident convolution for narrow layers (stride 1, <= 64 channels on both sides, many taps): the k5 convs of
+// Vnet3D's additive couplings / input / output blocks (ganslate/nn/generators/vnet/vnet3d.py:161,252,262-267) and the
+// W-folded k7 boundary convs of the ResNets.
+//
+// The im2col-style gather of gconv.hip re-reads every input voxel once per tap from L2 (125x for a 5x5x5 kernel): with
+// 16-32 channels those layers are L2-bandwidth bound at a few percent of the matrix peak. Here a workgroup owns a box
+// of 256 output voxels (4x8x8, or 1x16x16 for images), stages the input box + halo for up to 32 channels in LDS ONCE
+// (LDS-DMA, border handling in the per-lane source address) and runs all taps out of it: the MFMA B operand of a tap is
+// a ds_read_b128 at (voxel + tap offset), the A operand (weights, tiny and shared by every workgroup) is read straight
+// from L2 in fragment layout. HBM/L2 traffic drops from taps x input to ~1.7 x input; the loop is LDS-read bound.
+//   D[co][voxel] += W[co][(tap, ci)] * X[voxel + off(tap)][ci],  v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+// Same epilogue contract as gconv_kernel: bias, per-workgroup InstanceNorm partial sums (one slot per box), activation,
+// optional accumulate-into (additive-coupling gradient joins), channel-slice output views.
+#include "common.hpp"
+#include <cstdlib>
+
+struct HConvK {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  float* stats;
+  const char* zero;
+  int BD, BH, BW;        // output box
+  int HD, HH, HW;        // halo box = output box + tap range
+  int dmin, hmin, wmin;  // smallest tap offset per axis
+  int nbd, nbh, nbw;     // boxes per axis
+  int chunks;            // Ci / CC
+  int cc_shift;          // log2(CC)
+  gs_gconv_desc d;
+};
+
+template <int TI, int CC>
+__global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
+  constexpr int PP = CC / 8;                      // 16-B pieces per voxel
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* toff = reinterpret_cast<int*>(smem);                        // [GS_MAX_TAPS] halo-linear tap offsets
+  float* red = reinterpret_cast<float*>(smem + GS_MAX_TAPS * 4);   // [4 waves][64 channels][2]
+  char* halo = smem + GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4;
+  const gs_gconv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int b = blockIdx.x;
+  const int bx = b % p.nbw; b /= p.nbw;
+  const int by = b % p.nbh; b /= p.nbh;
+  const int bz = b % p.nbd;
+  const int n = b / p.nbd;
+  const int box = (bz * p.nbh + by) * p.nbw + bx;
+  const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
+
+  for (int t = tid; t < d.T; t += 256)
+    toff[t] = (((int)d.dd[t] - p.dmin) * p.HH + ((int)d.dh[t] - p.hmin)) * p.HW + ((int)d.dw[t] - p.wmin);
+
+  const int row = lane & 15, kg = lane >> 4;
+  int pbase[4];
+  bool pval[4];
+  size_t opix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pl = wave * 64 + j * 16 + row;
+    const int lz = pl / (p.BH * p.BW), rem = pl - lz * (p.BH * p.BW);
+    const int ly = rem / p.BW, lx = rem - ly * p.BW;
+    pbase[j] = (lz * p.HH + ly) * p.HW + lx;
+    const int oz = oz0 + lz, oy = oy0 + ly, ox = ox0 + lx;
+    pval[j] = oz < d.Do && oy < d.Ho && ox < d.Wo;
+    opix[j] = (((size_t)n * d.Do + oz) * d.Ho + oy) * d.Wo + ox;
+  }
+
+  f32x4 acc[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int HV = p.HD * p.HH * p.HW;
+  const int pieces = HV * PP;
+  const int hhw = p.HH * p.HW;
+  const char* in_n = p.in + ((size_t)n * d.Di * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+  const int nsteps = (d.T * CC + 31) >> 5;
+  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u});
+
+  for (int chunk = 0; chunk < p.chunks; ++chunk) {
+    __syncthreads();   // tap table visible / the previous chunk's reads are done
+    // ---- stage the input box + halo of this channel chunk: one 16-B piece per lane per LDS-DMA instruction ----
+    for (int q0 = wave * 64; q0 < pieces; q0 += 256) {
+      const int q = q0 + lane;
+      const int v = q / PP, part = q - v * PP;
+      const int hz = v / hhw, r2 = v - hz * hhw;
+      const int hy = r2 / p.HW, hx = r2 - hy * p.HW;
+      bool ok = q < pieces;
+      // boxes hanging over the image edge ask for positions even a reflection cannot map: clamp (those voxels only
+      // feed masked output pixels)
+      int iz = border_index(oz0 + hz + p.dmin, d.Di, d.border, ok);
+      int iy = border_index(oy0 + hy + p.hmin, d.Hi, d.border, ok);
+      int ix = border_index(ox0 + hx + p.wmin, d.Wi, d.border, ok);
+      iz = min(max(iz, 0), d.Di - 1);
+      iy = min(max(iy, 0), d.Hi - 1);
+      ix = min(max(ix, 0), d.Wi - 1);
+      unsigned off = ((unsigned)((iz * d.Hi + iy) * d.Wi + ix) * (unsigned)d.in_cs + (unsigned)(chunk * CC + part * 8)) * 2u;
+      asm volatile("" : "+v"(off));
+      const char* src = ok ? in_n + off : p.zero;
+      glds16(src, halo + (size_t)q0 * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- all taps out of LDS: K-step of 32 = 32/CC taps x CC channels (or a fraction of a tap for CC = 32) -----
+    for (int s = 0; s < nsteps; ++s) {
+      const int kk = s * 32 + kg * 8;
+      const int tap = kk >> p.cc_shift, c0 = kk & (CC - 1);
+      const bool valid = tap < d.T;
+      const int tp = valid ? tap : 0;
+      bf16x8 wf[TI], xf[4];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int co = i * 16 + row;
+        const bool wv = valid && co < d.w_rows;
+        const char* a = p.w + ((size_t)co * d.Kp + tp * d.Ci + chunk * CC + c0) * 2;
+        wf[i] = wv ? *reinterpret_cast<const bf16x8*>(a) : zero8;
+      }
+      const int vo = toff[tp];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(halo + ((size_t)(pbase[j] + vo) * CC + c0) * 2);
+        xf[j] = valid ? x : zero8;
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: bias, partial statistics (one slot per box), activation, [accumulate], 8-B NHWC stores ----------
+  const bool want_stats = d.stats_slots > 0;
+  float s1[TI][4], s2[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = i * 16 + kg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + ((p.bias && co < d.Co) ? p.bias[co + r] : 0.f);
+        if (pval[j]) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+        v[r] = apply_act(v[r], d.act, d.slope);
+      }
+      if (pval[j] && co < d.Co) {
+        uint2* dst = reinterpret_cast<uint2*>(p.out + (opix[j] * d.out_cs + d.out_co + co) * 2);
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        if (d.accumulate) {   // bf16 read-modify-write, same rounding points as gconv_kernel
+          const uint2 old = *dst;
+          o.x = pack_bf2(bf_lo(o.x) + bf_lo(old.x), bf_hi(o.x) + bf_hi(old.x));
+          o.y = pack_bf2(bf_lo(o.y) + bf_lo(old.y), bf_hi(o.y) + bf_hi(old.y));
+        }
+        *dst = o;
+      }
+    }
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[i][r], q = s2[i][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        if (row == 0) {
+          const int c = i * 16 + kg * 4 + r;
+          red[(wave * 64 + c) * 2 + 0] = a;
+          red[(wave * 64 + c) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < d.Co) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+      float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + box) * 2) * d.Co;
+      sp[tid] = a;
+      sp[d.Co + tid] = q;
+    }
+  }
+}
+
+namespace {
+struct HPlan {
+  bool ok;
+  int BD, BH, BW, HD, HH, HW, dmin, hmin, wmin, nbd, nbh, nbw, CC, TI, lds;
+};
+
+HPlan plan(const gs_gconv_desc* d) {
+  HPlan h{};
+  static const bool enabled = !(getenv("GS_HCONV") && atoi(getenv("GS_HCONV")) == 0);
+  if (!enabled) return h;
+  if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 64 || d->T < 9) return h;
+  if (d->Dc != d->Do || d->Hc != d->Ho || d->Wc != d->Wo || d->pz || d->py || d->px) return h;
+  int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
+  for (int t = 0; t < d->T; ++t) {
+    const int o[3] = {d->dd[t], d->dh[t], d->dw[t]};
+    for (int a = 0; a < 3; ++a) { if (o[a] < lo[a]) lo[a] = o[a]; if (o[a] > hi[a]) hi[a] = o[a]; }
+  }
+  if (d->Do > 1) { h.BD = 4; h.BH = 8; h.BW = 8; } else { h.BD = 1; h.BH = 16; h.BW = 16; }
+  h.HD = h.BD + hi[0] - lo[0]; h.HH = h.BH + hi[1] - lo[1]; h.HW = h.BW + hi[2] - lo[2];
+  h.dmin = lo[0]; h.hmin = lo[1]; h.wmin = lo[2];
+  h.nbd = (d->Do + h.BD - 1) / h.BD; h.nbh = (d->Ho + h.BH - 1) / h.BH; h.nbw = (d->Wo + h.BW - 1) / h.BW;
+  h.CC = d->Ci < 32 ? d->Ci : 32;
+  h.TI = d->Co <= 16 ? 1 : (d->Co <= 32 ? 2 : 4);
+  const long long hv = (long long)h.HD * h.HH * h.HW;
+  const long long halo_bytes = (hv * h.CC * 2 + 1023) / 1024 * 1024 + 1024;
+  h.lds = GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4 + (int)halo_bytes;
+  // two workgroups per CU must fit, so a workgroup's staging overlaps the other's tap loop
+  if (h.lds > 80 * 1024) return h;
+  h.ok = true;
+  return h;
+}
+
+template <int TI, int CC>
+int launch_h(const HConvK& k, int blocks, int lds, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<TI, CC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    configured = true;
+  }
+  hipLaunchKernelGGL((hconv_kernel<TI, CC>), dim3(blocks), dim3(256), lds, st, k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+// number of partial-statistics slots per image this class writes if it runs on the halo kernel, 0 if it does not
+int gs_hconv_slots(const gs_gconv_desc* d) {
+  const HPlan h = plan(d);
+  return h.ok ? h.nbd * h.nbh * h.nbw : 0;
+}
+
+// returns 0 and sets *handled when the layer ran here; *handled = 0 -> the caller falls back to gconv_kernel
+int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
+                 void* stream, int* handled) {
+  *handled = 0;
+  const HPlan h = plan(d);
+  if (!h.ok) return 0;
+  HConvK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_pack);
+  k.bias = bias;
+  k.out = static_cast<char*>(out);
+  k.stats = stats;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
+  k.BD = h.BD; k.BH = h.BH; k.BW = h.BW; k.HD = h.HD; k.HH = h.HH; k.HW = h.HW;
+  k.dmin = h.dmin; k.hmin = h.hmin; k.wmin = h.wmin; k.nbd = h.nbd; k.nbh = h.nbh; k.nbw = h.nbw;
+  k.chunks = d->Ci / h.CC;
+  k.cc_shift = h.CC == 8 ? 3 : (h.CC == 16 ? 4 : 5);
+  k.d = *d;
+  const long long blocks = (long long)d->N * h.nbd * h.nbh * h.nbw;
+  GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  *handled = 1;
+#define GS_H(TI_, CC_) if (h.TI == TI_ && h.CC == CC_) return launch_h<TI_, CC_>(k, (int)blocks, h.lds, st)
+  GS_H(1, 8); GS_H(1, 16); GS_H(1, 32);
+  GS_H(2, 8); GS_H(2, 16); GS_H(2, 32);
+  GS_H(4, 8); GS_H(4, 16); GS_H(4, 32);
+#undef GS_H
+  *handled = 0;
+  return 0;
+}

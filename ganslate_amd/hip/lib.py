@@ -47,6 +47,7 @@ _PROTOS = {
     "gs_shutdown": (None, []),
     "gs_last_error": (C.c_char_p, []),
     "gs_tile_m": (C.c_int, [C.POINTER(GConvDesc)]),
+    "gs_gconv_stat_slots": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "gs_wgrad": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

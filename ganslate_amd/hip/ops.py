@@ -65,6 +65,10 @@ class HipOps:
         """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
         return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
+    def stat_slots(self, g: GConv, N: int) -> int:
+        """partial-statistics slots per image the kernel writes for this class at batch N"""
+        return self.lib.gs_gconv_stat_slots(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
               slope=0.2, stats=None, stats_slots=0, stats_slot0=0, accumulate=False):

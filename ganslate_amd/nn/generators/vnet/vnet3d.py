@@ -169,8 +169,7 @@ class Vnet3D(NativeNet):
         slots, offs = 0, []
         for g in lw.fwd:
             offs.append(slots)
-            tm = ops.tile_m(g, N)
-            slots += (g.pixels + tm - 1) // tm
+            slots += ops.stat_slots(g, N)
         part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
         for g, o in zip(lw.fwd, offs):
             ops.gconv(g, x, fpack, bias, y, in_co=in_co, stats=part, stats_slots=slots, stats_slot0=o)

@@ -84,7 +84,10 @@ typedef struct gs_wgrad_desc {
 int gs_init(int device);                 /* torch.cuda.set_device + lazy cuDNN handle (base.py:84-91) */
 void gs_shutdown(void);
 const char* gs_last_error(void);
-int gs_tile_m(const gs_gconv_desc* d);   /* pixel-tile height the kernel will use (stats slot count) */
+int gs_tile_m(const gs_gconv_desc* d);   /* pixel-tile height of the im2col kernel for this class */
+/* number of partial-statistics slots per image gs_gconv_forward writes for this class (pixel tiles of the im2col
+ * kernel, or output boxes of the halo-resident kernel narrow stride-1 layers run on): size `stats` with it */
+int gs_gconv_stat_slots(const gs_gconv_desc* d);
 
 /* ---- convolution family (torch.nn.Conv2d / ConvTranspose2d forward + autograd backward) --------- */
 /* resnet2d.py:25,35,52-57,65,80-87; patchgan2d.py:29,36-62; backward via loss.backward() base.py:170 */

@@ -85,6 +85,9 @@ class RefOps:
     def tile_m(self, g, N=1):
         return 1 << 30  # one statistics slot per class
 
+    def stat_slots(self, g, N=1):
+        return 1
+
     # ---- convolution family ---------------------------------------------------------------------------
     def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
               stats=None, stats_slots=0, stats_slot0=0, accumulate=False):

@@ -43,6 +43,16 @@ CONV_CASES = [
     (ConvSpec("conv", 128, 256, 4, 1, 1, dims=3), 1, 10, 10, 10),                         # stride-1 k4 (ragged 9^3)
     (ConvSpec("conv", 256, 1, 4, 1, 1, dims=3), 2, 7, 7, 7),                              # last (Cout 1 -> 8)
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),   # BASELINE cfg5 RB size
+    # narrow stride-1 layers -> halo-resident kernel (hconv.hip): Vnet3D k5 convs, W-folded k7 boundary convs
+    (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 2, 12, 16, 24),                           # coupling conv, h = 16
+    (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 9, 11, 13),                            # ragged boxes, h = 32
+    (ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, 8, 8, 8),                              # two channel chunks
+    (ConvSpec("conv", 1, 16, 5, 1, 2, dims=3), 1, 16, 16, 16),                            # Vnet3D input conv
+    (ConvSpec("conv", 32, 32, 5, 1, 2), 2, 20, 36),                                       # 2-D boxes of 16x16
+    (ConvSpec("conv", 1, 64, 7, 1, 3, pad_mode="replicate", dims=3, wfold="in"), 1, 12, 10, 16),
+    (ConvSpec("conv", 64, 1, 7, 1, 3, pad_mode="replicate", dims=3, wfold="out"), 1, 12, 12, 12),
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 40, 56),
+    (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 32, 32),
 ]
 
 
@@ -84,7 +94,7 @@ def stats_slots(ops, low, classes, N):
     slots, offs = 0, []
     for g in classes:
         offs.append(slots)
-        slots += (g.pixels + ops.tile_m(g, N) - 1) // ops.tile_m(g, N)
+        slots += ops.stat_slots(g, N)
     return slots, offs
 
 

@@ -48,7 +48,7 @@ def main():
         slots, offs = 0, []
         for g in low.fwd:
             offs.append(slots)
-            slots += (g.pixels + ops.tile_m(g, N) - 1) // ops.tile_m(g, N)
+            slots += ops.stat_slots(g, N)
         part = torch.empty(N * slots * 2 * spec.cout_p, device=dev)
         a, gt = (gy, x) if spec.kind == "conv" else (x, gy)
 
