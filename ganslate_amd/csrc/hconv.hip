@@ -4,10 +4,10 @@
 //
 // The im2col-style gather of gconv.hip re-reads every input voxel once per tap from L2 (125x for a 5x5x5 kernel): with
 // 16-32 channels those layers are L2-bandwidth bound at a few percent of the matrix peak. Here a workgroup owns a box
-// of 256 output voxels (4x8x8, or 1x16x16 for images), stages the input box + halo for up to 32 channels in LDS ONCE
+// of 256 output voxels (4x8x8, or 1x16x16 for images), stages the input box + halo for 16 channels in LDS ONCE
 // (LDS-DMA, border handling in the per-lane source address) and runs all taps out of it: the MFMA B operand of a tap is
-// a ds_read_b128 at (voxel + tap offset), the A operand (weights, tiny and shared by every workgroup) is read straight
-// from L2 in fragment layout. HBM/L2 traffic drops from taps x input to ~1.7 x input; the loop is LDS-read bound.
+// a ds_read_b128 at (voxel + tap offset); the weights stream through a double-buffered LDS stage of 8 K-steps, fetched
+// one stage ahead. HBM/L2 traffic drops from taps x input to ~1.7 x input; the loop is LDS-read bound.
 //   D[co][voxel] += W[co][(tap, ci)] * X[voxel + off(tap)][ci],  v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 // Same epilogue contract as gconv_kernel: bias, per-workgroup InstanceNorm partial sums (one slot per box), activation,
 // optional accumulate-into (additive-coupling gradient joins), channel-slice output views.
@@ -30,13 +30,23 @@ struct HConvK {
   gs_gconv_desc d;
 };
 
+// LDS map: [tap offsets GS_MAX_TAPS*4][stats scratch 2 KiB][2 weight stages][halo]
+//   weight stage: TI*16 rows (output channels) x 8 K-steps x 32 k, row pitch 33 pieces of 16 B (528 B: the pad piece
+//   spreads the 16 rows of a fragment read over all banks); filled by LDS-DMA, lane q -> (row q/33, piece q%33)
 template <int TI, int CC>
 __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
   constexpr int PP = CC / 8;                      // 16-B pieces per voxel
+  constexpr int SK = 8;                           // K-steps per weight stage
+  constexpr int WROWS = TI * 16;
+  constexpr int WPIECES = WROWS * 33;
+  constexpr int WINSTR = (WPIECES + 63) / 64;     // LDS-DMA instructions per stage
+  constexpr int WSTAGE = WINSTR * 1024;           // bytes per stage
+  constexpr int WPW = (WINSTR + 3) / 4;           // instructions per wave per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* toff = reinterpret_cast<int*>(smem);                        // [GS_MAX_TAPS] halo-linear tap offsets
   float* red = reinterpret_cast<float*>(smem + GS_MAX_TAPS * 4);   // [4 waves][64 channels][2]
-  char* halo = smem + GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4;
+  char* wst = smem + GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4;
+  char* halo = wst + 2 * WSTAGE;
   const gs_gconv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,7 +88,26 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
   const int hhw = p.HH * p.HW;
   const char* in_n = p.in + ((size_t)n * d.Di * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
   const int nsteps = (d.T * CC + 31) >> 5;
-  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u});
+  const int nstages = (nsteps + SK - 1) / SK;
+
+  // weight stage g of channel chunk `chunk` -> LDS buffer `buf` (every wave issues WPW instructions)
+  auto issue_w = [&](int g, int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int inst = wave * WPW + i;               // wave-uniform
+      if (inst < WINSTR) {
+        const int q = inst * 64 + lane;
+        const int r = q / 33, pc = q - r * 33;
+        const int kk = g * (SK * 32) + pc * 8;
+        const int tap = kk >> p.cc_shift, c0 = kk & (CC - 1);
+        const bool ok = pc < 32 && r < WROWS && r < d.w_rows && tap < d.T;
+        unsigned off = ((unsigned)r * (unsigned)d.Kp + (unsigned)(tap * d.Ci + chunk * CC + c0)) * 2u;
+        asm volatile("" : "+v"(off));
+        const char* src = ok ? p.w + off : p.zero;
+        glds16(src, wst + buf * WSTAGE + inst * 1024);
+      }
+    }
+  };
 
   for (int chunk = 0; chunk < p.chunks; ++chunk) {
     __syncthreads();   // tap table visible / the previous chunk's reads are done
@@ -102,33 +131,33 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
       const char* src = ok ? in_n + off : p.zero;
       glds16(src, halo + (size_t)q0 * 16);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    issue_w(0, chunk, 0);
 
-    // ---- all taps out of LDS: K-step of 32 = 32/CC taps x CC channels (or a fraction of a tap for CC = 32) -----
-    for (int s = 0; s < nsteps; ++s) {
-      const int kk = s * 32 + kg * 8;
-      const int tap = kk >> p.cc_shift, c0 = kk & (CC - 1);
-      const bool valid = tap < d.T;
-      const int tp = valid ? tap : 0;
-      bf16x8 wf[TI], xf[4];
+    // ---- all taps out of LDS; weights arrive one stage (8 K-steps of 32) ahead -------------------------------
+    for (int g = 0; g < nstages; ++g) {
+      const int buf = g & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage g (and, for g == 0, the halo) landed
+      __syncthreads();                                   // ... for every wave; stage g-1 fully consumed
+      if (g + 1 < nstages) issue_w(g + 1, chunk, buf ^ 1);
+      const char* wb = wst + buf * WSTAGE;
 #pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const int co = i * 16 + row;
-        const bool wv = valid && co < d.w_rows;
-        const char* a = p.w + ((size_t)co * d.Kp + tp * d.Ci + chunk * CC + c0) * 2;
-        wf[i] = wv ? *reinterpret_cast<const bf16x8*>(a) : zero8;
+      for (int u = 0; u < SK; ++u) {
+        const int kk = (g * SK + u) * 32 + kg * 8;
+        const int tap = kk >> p.cc_shift, c0 = kk & (CC - 1);
+        const int vo = toff[tap < d.T ? tap : 0];        // past the last tap the weights are zero: any finite B
+        bf16x8 wf[TI], xf[4];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          wf[i] = *reinterpret_cast<const bf16x8*>(wb + (i * 16 + row) * 528 + (u * 4 + kg) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          xf[j] = *reinterpret_cast<const bf16x8*>(halo + ((size_t)(pbase[j] + vo) * CC + c0) * 2);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
       }
-      const int vo = toff[tp];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(halo + ((size_t)(pbase[j] + vo) * CC + c0) * 2);
-        xf[j] = valid ? x : zero8;
-      }
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -201,7 +230,7 @@ HPlan plan(const gs_gconv_desc* d) {
   HPlan h{};
   static const bool enabled = !(getenv("GS_HCONV") && atoi(getenv("GS_HCONV")) == 0);
   if (!enabled) return h;
-  if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 64 || d->T < 9) return h;
+  if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 32 || d->T < 9) return h;
   if (d->Dc != d->Do || d->Hc != d->Ho || d->Wc != d->Wo || d->pz || d->py || d->px) return h;
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
   for (int t = 0; t < d->T; ++t) {
@@ -212,13 +241,14 @@ HPlan plan(const gs_gconv_desc* d) {
   h.HD = h.BD + hi[0] - lo[0]; h.HH = h.BH + hi[1] - lo[1]; h.HW = h.BW + hi[2] - lo[2];
   h.dmin = lo[0]; h.hmin = lo[1]; h.wmin = lo[2];
   h.nbd = (d->Do + h.BD - 1) / h.BD; h.nbh = (d->Ho + h.BH - 1) / h.BH; h.nbw = (d->Wo + h.BW - 1) / h.BW;
-  h.CC = d->Ci < 32 ? d->Ci : 32;
+  h.CC = d->Ci < 16 ? d->Ci : 16;
   h.TI = d->Co <= 16 ? 1 : (d->Co <= 32 ? 2 : 4);
   const long long hv = (long long)h.HD * h.HH * h.HW;
   const long long halo_bytes = (hv * h.CC * 2 + 1023) / 1024 * 1024 + 1024;
-  h.lds = GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4 + (int)halo_bytes;
+  const int wstage = (h.TI * 16 * 33 + 63) / 64 * 1024;
+  h.lds = GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4 + 2 * wstage + (int)halo_bytes;
   // two workgroups per CU must fit, so a workgroup's staging overlaps the other's tap loop
-  if (h.lds > 80 * 1024) return h;
+  if (h.lds > 110 * 1024) return h;
   h.ok = true;
   return h;
 }
@@ -228,7 +258,7 @@ int launch_h(const HConvK& k, int blocks, int lds, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<TI, CC>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
     configured = true;
   }
   hipLaunchKernelGGL((hconv_kernel<TI, CC>), dim3(blocks), dim3(256), lds, st, k);
@@ -260,16 +290,16 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
   k.BD = h.BD; k.BH = h.BH; k.BW = h.BW; k.HD = h.HD; k.HH = h.HH; k.HW = h.HW;
   k.dmin = h.dmin; k.hmin = h.hmin; k.wmin = h.wmin; k.nbd = h.nbd; k.nbh = h.nbh; k.nbw = h.nbw;
   k.chunks = d->Ci / h.CC;
-  k.cc_shift = h.CC == 8 ? 3 : (h.CC == 16 ? 4 : 5);
+  k.cc_shift = h.CC == 8 ? 3 : 4;
   k.d = *d;
   const long long blocks = (long long)d->N * h.nbd * h.nbh * h.nbw;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   *handled = 1;
 #define GS_H(TI_, CC_) if (h.TI == TI_ && h.CC == CC_) return launch_h<TI_, CC_>(k, (int)blocks, h.lds, st)
-  GS_H(1, 8); GS_H(1, 16); GS_H(1, 32);
-  GS_H(2, 8); GS_H(2, 16); GS_H(2, 32);
-  GS_H(4, 8); GS_H(4, 16); GS_H(4, 32);
+  GS_H(1, 8); GS_H(1, 16);
+  GS_H(2, 8); GS_H(2, 16);
+  GS_H(4, 8); GS_H(4, 16);
 #undef GS_H
   *handled = 0;
   return 0;
