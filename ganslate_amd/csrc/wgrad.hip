@@ -272,6 +272,9 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
 }
 }  // namespace
 
+// hwgrad.hip: halo-resident kernel for narrow stride-1 layers
+int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream, int* handled);
+
 extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream) {
   GS_REQUIRE(d && a && g && dw, "gs_wgrad: null argument");
   GS_REQUIRE(d->Q >= 8 && (d->Q & 7) == 0 && ((d->Q >> 3) & ((d->Q >> 3) - 1)) == 0,
@@ -280,6 +283,11 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
   GS_REQUIRE(d->T >= 1 && d->T <= GS_MAX_TAPS, "gs_wgrad: T=%d out of range", d->T);
   GS_REQUIRE((d->a_cs & 7) == 0 && (d->a_co & 7) == 0 && (d->g_cs & 7) == 0 && (d->g_co & 7) == 0,
              "gs_wgrad: channel strides/offsets must be multiples of 8");
+  {
+    int handled = 0;
+    if (int rc = gs_hwgrad_try(d, a, g, dw, stream, &handled)) return rc;
+    if (handled) return 0;
+  }
   WGradK k;
   k.a = static_cast<const char*>(a);
   k.g = static_cast<const char*>(g);

@@ -21,6 +21,11 @@ CASES = {
     "stem": (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect"), 8, 256, 256),
     "out": (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect"), 8, 256, 256),
     "dc4": (ConvSpec("conv", 256, 512, 4, 1, 1), 8, 32, 32),
+    # 3-D: Resnet3D residual conv at 128^3 / 4, Vnet3D coupling convs (halo-resident kernel)
+    "rb3": (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),
+    "v16": (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 128, 128, 128),
+    "v32": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 64, 64, 64),
+    "v64": (ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, 32, 32, 32),
 }
 
 
@@ -31,19 +36,24 @@ def main():
     args = ap.parse_args()
     ops = HipOps()
     dev = ops.device
-    for name, (spec, N, H, W) in CASES.items():
-        low = lower(spec, H, W)
-        macs = N * low.Ho * low.Wo * spec.cout * spec.cin * spec.T if spec.kind == "conv" else \
-            N * H * W * spec.cout * spec.cin * spec.T
+    for name, case in CASES.items():
+        spec, N, sizes = case[0], case[1], case[2:]
+        if args.only and not any(args.only in f"{name}_{k}" for k in ("fwd", "dgrad", "wgrad")):
+            continue
+        low = lower(spec, *sizes)
+        in_px = 1
+        for v in sizes:
+            in_px *= v
+        macs = N * low.out_pixels * spec.cout * spec.cin * spec.T if spec.kind == "conv" else \
+            N * in_px * spec.cout * spec.cin * spec.T
         flop = 2.0 * macs
-        x = torch.randn(N, H, W, spec.cin_p, device=dev).to(torch.bfloat16)
-        gy = torch.randn(N, low.Ho, low.Wo, spec.cout_p, device=dev).to(torch.bfloat16)
+        x = torch.randn(N, *sizes, spec.cin_p, device=dev).to(torch.bfloat16)
+        gy = torch.randn(N, *low.out_dims, spec.cout_p, device=dev).to(torch.bfloat16)
         fpack = (torch.randn(low.fwd_index.size + 64, device=dev) * 0.05).to(torch.bfloat16)
         dpack = (torch.randn(low.dgrad_index.size + 64, device=dev) * 0.05).to(torch.bfloat16)
         bias = torch.zeros(spec.cout_p, device=dev)
-        y = torch.empty(N, low.Ho, low.Wo, spec.cout_p, device=dev, dtype=torch.bfloat16)
-        f = low.dgrad_fold
-        gx = torch.empty(N, H + 2 * f, W + 2 * f, spec.cin_p, device=dev, dtype=torch.bfloat16)
+        y = torch.empty(N, *low.out_dims, spec.cout_p, device=dev, dtype=torch.bfloat16)
+        gx = torch.empty(N, *low.dgrad_dims, spec.cin_p, device=dev, dtype=torch.bfloat16)
         dw = torch.zeros(spec.master_numel, device=dev)
         slots, offs = 0, []
         for g in low.fwd:
