@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  const int co0 = blockIdx.y * WROWS;             // output-channel group of this workgroup
   int b = blockIdx.x;
   const int bx = b % p.nbw; b /= p.nbw;
   const int by = b % p.nbh; b /= p.nbh;
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
         const int r = q / 33, pc = q - r * 33;
         const int kk = g * (SK * 32) + pc * 8;
         const int tap = kk >> p.cc_shift, c0 = kk & (CC - 1);
-        const bool ok = pc < 32 && r < WROWS && r < d.w_rows && tap < d.T;
-        unsigned off = ((unsigned)r * (unsigned)d.Kp + (unsigned)(tap * d.Ci + chunk * CC + c0)) * 2u;
+        const bool ok = pc < 32 && r < WROWS && co0 + r < d.w_rows && tap < d.T;
+        unsigned off = ((unsigned)(co0 + r) * (unsigned)d.Kp + (unsigned)(tap * d.Ci + chunk * CC + c0)) * 2u;
         asm volatile("" : "+v"(off));
         const char* src = ok ? p.w + off : p.zero;
         glds16(src, wst + buf * WSTAGE + inst * 1024);
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
     for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
-    const int co = i * 16 + kg * 4;
+    const int co = co0 + i * 16 + kg * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v[4];
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
         }
       }
     __syncthreads();
-    if (tid < d.Co) {
+    if (tid < WROWS && co0 + tid < d.Co) {
       float a = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { a += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
       float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + box) * 2) * d.Co;
-      sp[tid] = a;
-      sp[d.Co + tid] = q;
+      sp[co0 + tid] = a;
+      sp[d.Co + co0 + tid] = q;
     }
   }
 }
@@ -223,14 +224,15 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
 namespace {
 struct HPlan {
   bool ok;
-  int BD, BH, BW, HD, HH, HW, dmin, hmin, wmin, nbd, nbh, nbw, CC, TI, lds;
+  int BD, BH, BW, HD, HH, HW, dmin, hmin, wmin, nbd, nbh, nbw, CC, TI, cog, lds;
 };
 
 HPlan plan(const gs_gconv_desc* d) {
   HPlan h{};
   static const bool enabled = !(getenv("GS_HCONV") && atoi(getenv("GS_HCONV")) == 0);
   if (!enabled) return h;
-  if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 32 || d->T < 9) return h;
+  if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 64 || d->T < 9) return h;
+  if (d->Ci > 32 && d->Co > 16) return h;          // wide on both sides: the im2col kernel is the better fit (measured)
   if (d->Dc != d->Do || d->Hc != d->Ho || d->Wc != d->Wo || d->pz || d->py || d->px) return h;
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
   for (int t = 0; t < d->T; ++t) {
@@ -242,7 +244,8 @@ HPlan plan(const gs_gconv_desc* d) {
   h.dmin = lo[0]; h.hmin = lo[1]; h.wmin = lo[2];
   h.nbd = (d->Do + h.BD - 1) / h.BD; h.nbh = (d->Ho + h.BH - 1) / h.BH; h.nbw = (d->Wo + h.BW - 1) / h.BW;
   h.CC = d->Ci < 16 ? d->Ci : 16;
-  h.TI = d->Co <= 16 ? 1 : (d->Co <= 32 ? 2 : 4);
+  h.TI = d->Co <= 16 ? 1 : 2;                      // 16 or 32 output channels per workgroup,
+  h.cog = (d->Co + h.TI * 16 - 1) / (h.TI * 16);   // wider layers split over blockIdx.y (each stages its own halo)
   const long long hv = (long long)h.HD * h.HH * h.HW;
   const long long halo_bytes = (hv * h.CC * 2 + 1023) / 1024 * 1024 + 1024;
   const int wstage = (h.TI * 16 * 33 + 63) / 64 * 1024;
@@ -254,14 +257,14 @@ HPlan plan(const gs_gconv_desc* d) {
 }
 
 template <int TI, int CC>
-int launch_h(const HConvK& k, int blocks, int lds, hipStream_t st) {
+int launch_h(const HConvK& k, int blocks, int cog, int lds, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<TI, CC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
     configured = true;
   }
-  hipLaunchKernelGGL((hconv_kernel<TI, CC>), dim3(blocks), dim3(256), lds, st, k);
+  hipLaunchKernelGGL((hconv_kernel<TI, CC>), dim3(blocks, cog), dim3(256), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -296,10 +299,9 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   *handled = 1;
-#define GS_H(TI_, CC_) if (h.TI == TI_ && h.CC == CC_) return launch_h<TI_, CC_>(k, (int)blocks, h.lds, st)
+#define GS_H(TI_, CC_) if (h.TI == TI_ && h.CC == CC_) return launch_h<TI_, CC_>(k, (int)blocks, h.cog, h.lds, st)
   GS_H(1, 8); GS_H(1, 16);
   GS_H(2, 8); GS_H(2, 16);
-  GS_H(4, 8); GS_H(4, 16);
 #undef GS_H
   *handled = 0;
   return 0;
