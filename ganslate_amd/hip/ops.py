@@ -12,7 +12,14 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """torch's current HIP stream as a raw handle. torch.cuda.current_stream() costs ~8 us of Python per call, which at
+    ~1100 launches per step was half of the host's enqueue time; the C accessor is ~0.3 us."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
