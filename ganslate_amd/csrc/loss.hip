@@ -191,13 +191,7 @@ __global__ void ssim_final_kernel(const float* partial, int n, float scale, floa
   if (threadIdx.x == 0) out[0] = (float)(sh[0] * (double)scale);
 }
 
-extern "C" int64_t gs_ssim_scratch_floats(int32_t NC, int32_t H, int32_t W) {
-  const int64_t th = (H - 10 + SSIM_TH - 1) / SSIM_TH, tw = (W - 10 + SSIM_TW - 1) / SSIM_TW;
-  return (int64_t)NC * th * tw;
-}
-extern "C" int gs_ssim_distance(const float* x, const float* y, int32_t NC, int32_t H, int32_t W, float* out,
-                                float* scratch, void* stream) {
-  GS_REQUIRE(x && y && out && scratch && NC > 0 && H > 10 && W > 10, "gs_ssim_distance: bad argument");
+static int ssim_init_gauss() {
   static bool init = false;
   if (!init) {
     // fp32 restatement of _fspecial_gauss_1d(11, 1.5) (ssim.py:22-40)
@@ -207,12 +201,170 @@ extern "C" int gs_ssim_distance(const float* x, const float* y, int32_t NC, int3
     GS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)));
     init = true;
   }
+  return 0;
+}
+
+extern "C" int64_t gs_ssim_scratch_floats(int32_t NC, int32_t H, int32_t W) {
+  const int64_t th = (H - 10 + SSIM_TH - 1) / SSIM_TH, tw = (W - 10 + SSIM_TW - 1) / SSIM_TW;
+  return (int64_t)NC * th * tw;
+}
+extern "C" int gs_ssim_distance(const float* x, const float* y, int32_t NC, int32_t H, int32_t W, float* out,
+                                float* scratch, void* stream) {
+  GS_REQUIRE(x && y && out && scratch && NC > 0 && H > 10 && W > 10, "gs_ssim_distance: bad argument");
+  if (int rc = ssim_init_gauss()) return rc;
   const int th = (H - 10 + SSIM_TH - 1) / SSIM_TH, tw = (W - 10 + SSIM_TW - 1) / SSIM_TW;
   const int blocks = NC * th * tw;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(ssim_kernel, dim3(blocks), dim3(256), 0, st, x, y, H, W, tw, th, scratch);
   const double cnt = (double)NC * (H - 10) * (W - 10);
   hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, (float)(1.0 / cnt), out);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// ---- SSIM distance: gradient w.r.t. the second image (the distance is symmetric, swap the arguments for the first) ----
+// L = mean(D), D = sqrt(relu(2 - S1 - S2)) with mu1 = b(X), mu2 = b(Y), e11 = b(XX), e22 = b(YY), e12 = b(XY) (b = the
+// separable 11-tap Gaussian, valid region). Per output pixel o, with gD = -dL/(2 D n):
+//   G0 = gD * (dS1/dmu2 - mu1 * dS2/ds12 - 2 mu2 * dS2/ds2),  G1 = gD * dS2/ds12,  G2 = gD * dS2/ds2
+//   dS1/dmu2 = (2 mu1 B1 - 2 mu2 A1) / B1^2,  dS2/ds12 = 2 / B2,  dS2/ds2 = -A2 / B2^2   (S1 = A1/B1, S2 = A2/B2)
+// and dL/dY(p) = 1/2 * ( bT(G0)(p) + X(p) bT(G1)(p) + 2 Y(p) bT(G2)(p) ) with bT the transposed (full) Gaussian; the 1/2 is
+// the (y + 1)/2 input mapping (nn/losses/utils/ssim.py:65-99 differentiated; cyclegan_losses.py:78-90 uses it as a loss).
+__global__ __launch_bounds__(256) void ssim_grad_maps_kernel(const float* x, const float* y, int H, int W, int tiles_w,
+                                                             int tiles_h, const float* grad_scale, float inv_cnt,
+                                                             float* maps, size_t map_stride) {
+  __shared__ float sx[SSIM_TH + 10][SSIM_TW + 10];
+  __shared__ float sy[SSIM_TH + 10][SSIM_TW + 10];
+  __shared__ float hz[5][SSIM_TH + 10][SSIM_TW];
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w;
+  const int th = b % tiles_h; const int plane = b / tiles_h;
+  const int Ho = H - 10, Wo = W - 10;
+  const int oh0 = th * SSIM_TH, ow0 = tw * SSIM_TW;
+  const float* xp = x + (size_t)plane * H * W;
+  const float* yp = y + (size_t)plane * H * W;
+  for (int e = threadIdx.x; e < (SSIM_TH + 10) * (SSIM_TW + 10); e += 256) {
+    const int r = e / (SSIM_TW + 10), c = e % (SSIM_TW + 10);
+    const int ih = oh0 + r, iw = ow0 + c;
+    float a = 0.f, bb = 0.f;
+    if (ih < H && iw < W) { a = (xp[(size_t)ih * W + iw] + 1.f) * 0.5f; bb = (yp[(size_t)ih * W + iw] + 1.f) * 0.5f; }
+    sx[r][c] = a; sy[r][c] = bb;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < (SSIM_TH + 10) * SSIM_TW; e += 256) {
+    const int r = e / SSIM_TW, c = e % SSIM_TW;
+    float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = c_gauss[k], a = sx[r][c + k], bb = sy[r][c + k];
+      m1 += g * a; m2 += g * bb; xx += g * a * a; yy += g * bb * bb; xy += g * a * bb;
+    }
+    hz[0][r][c] = m1; hz[1][r][c] = m2; hz[2][r][c] = xx; hz[3][r][c] = yy; hz[4][r][c] = xy;
+  }
+  __syncthreads();
+  const float up = (grad_scale ? grad_scale[0] : 1.f) * inv_cnt;
+  float* mp = maps + (size_t)plane * Ho * Wo;
+  for (int e = threadIdx.x; e < SSIM_TH * SSIM_TW; e += 256) {
+    const int r = e / SSIM_TW, c = e % SSIM_TW;
+    if (oh0 + r < Ho && ow0 + c < Wo) {
+      float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float g = c_gauss[k];
+        m1 += g * hz[0][r + k][c]; m2 += g * hz[1][r + k][c]; xx += g * hz[2][r + k][c];
+        yy += g * hz[3][r + k][c]; xy += g * hz[4][r + k][c];
+      }
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float s1sq = xx - m1 * m1, s2sq = yy - m2 * m2, s12 = xy - m1 * m2;
+      const float A1 = 2.f * m1 * m2 + C1, B1 = m1 * m1 + m2 * m2 + C1;
+      const float A2 = 2.f * s12 + C2, B2 = s1sq + s2sq + C2;
+      const float S = 2.f - (A1 / B1 + A2 / B2);
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+      if (S > 0.f) {
+        const float gD = -up / (2.f * sqrtf(S));
+        const float dS1 = (2.f * m1 * B1 - 2.f * m2 * A1) / (B1 * B1);
+        const float dS2_12 = 2.f / B2, dS2_2 = -A2 / (B2 * B2);
+        g0 = gD * (dS1 - m1 * dS2_12 - 2.f * m2 * dS2_2);
+        g1 = gD * dS2_12;
+        g2 = gD * dS2_2;
+      }
+      const size_t o = (size_t)(oh0 + r) * Wo + (ow0 + c);
+      mp[o] = g0; mp[map_stride + o] = g1; mp[2 * map_stride + o] = g2;
+    }
+  }
+}
+
+// transposed separable Gaussian of the three maps + combination with X, Y: one workgroup = 16x32 input pixels
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* x, const float* y, const float* maps,
+                                                       size_t map_stride, int H, int W, int tiles_w, int tiles_h,
+                                                       float* grad_y) {
+  __shared__ float sm[3][SSIM_TH + 10][SSIM_TW + 10];
+  __shared__ float hz[3][SSIM_TH + 10][SSIM_TW];
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w;
+  const int th = b % tiles_h; const int plane = b / tiles_h;
+  const int Ho = H - 10, Wo = W - 10;
+  const int ph0 = th * SSIM_TH, pw0 = tw * SSIM_TW;
+  const float* mp = maps + (size_t)plane * Ho * Wo;
+  // output-pixel window [ph0 - 10, ph0 + TH) x [pw0 - 10, pw0 + TW), zero outside the valid map
+  for (int e = threadIdx.x; e < (SSIM_TH + 10) * (SSIM_TW + 10); e += 256) {
+    const int r = e / (SSIM_TW + 10), c = e % (SSIM_TW + 10);
+    const int oh = ph0 - 10 + r, ow = pw0 - 10 + c;
+    const bool ok = oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+    const size_t o = ok ? (size_t)oh * Wo + ow : 0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) sm[m][r][c] = ok ? mp[m * map_stride + o] : 0.f;
+  }
+  __syncthreads();
+  // horizontal: t[r][c] = sum_k w[k] * G[.., pw - k]  ->  window column (c + 10 - k)
+  for (int e = threadIdx.x; e < (SSIM_TH + 10) * SSIM_TW; e += 256) {
+    const int r = e / SSIM_TW, c = e % SSIM_TW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = c_gauss[k];
+      a0 += g * sm[0][r][c + 10 - k]; a1 += g * sm[1][r][c + 10 - k]; a2 += g * sm[2][r][c + 10 - k];
+    }
+    hz[0][r][c] = a0; hz[1][r][c] = a1; hz[2][r][c] = a2;
+  }
+  __syncthreads();
+  const float* xp = x + (size_t)plane * H * W;
+  const float* yp = y + (size_t)plane * H * W;
+  float* gp = grad_y + (size_t)plane * H * W;
+  for (int e = threadIdx.x; e < SSIM_TH * SSIM_TW; e += 256) {
+    const int r = e / SSIM_TW, c = e % SSIM_TW;
+    const int ph = ph0 + r, pw = pw0 + c;
+    if (ph < H && pw < W) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float g = c_gauss[k];
+        a0 += g * hz[0][r + 10 - k][c]; a1 += g * hz[1][r + 10 - k][c]; a2 += g * hz[2][r + 10 - k][c];
+      }
+      const size_t i = (size_t)ph * W + pw;
+      const float X = (xp[i] + 1.f) * 0.5f, Y = (yp[i] + 1.f) * 0.5f;
+      gp[i] = 0.5f * (a0 + X * a1 + 2.f * Y * a2);
+    }
+  }
+}
+
+extern "C" int64_t gs_ssim_backward_scratch_floats(int32_t NC, int32_t H, int32_t W) {
+  return 3 * (int64_t)NC * (H - 10) * (W - 10);
+}
+
+extern "C" int gs_ssim_distance_backward(const float* x, const float* y, int32_t NC, int32_t H, int32_t W,
+                                         const float* grad_scale, float* grad_y, float* scratch, void* stream) {
+  GS_REQUIRE(x && y && grad_y && scratch && NC > 0 && H > 10 && W > 10, "gs_ssim_distance_backward: bad argument");
+  if (int rc = ssim_init_gauss()) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int Ho = H - 10, Wo = W - 10;
+  const size_t map_stride = (size_t)NC * Ho * Wo;
+  const int th = (Ho + SSIM_TH - 1) / SSIM_TH, tw = (Wo + SSIM_TW - 1) / SSIM_TW;
+  hipLaunchKernelGGL(ssim_grad_maps_kernel, dim3(NC * th * tw), dim3(256), 0, st, x, y, H, W, tw, th, grad_scale,
+                     (float)(1.0 / ((double)NC * Ho * Wo)), scratch, map_stride);
+  const int th2 = (H + SSIM_TH - 1) / SSIM_TH, tw2 = (W + SSIM_TW - 1) / SSIM_TW;
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3(NC * th2 * tw2), dim3(256), 0, st, x, y, scratch, map_stride, H, W, tw2, th2,
+                     grad_y);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -301,3 +301,10 @@ class HipOps:
     def repack(self, master, index, pack):
         L.check(self.lib.gs_repack_bf16(_ptr(master), _ptr(index), _ptr(pack), pack.numel(), _stream()),
                 "gs_repack_bf16")
+
+    def ssim_distance_backward(self, x, y, grad_y, grad_scale=None):
+        NC = x.numel() // (x.shape[-1] * x.shape[-2])
+        H, W = x.shape[-2], x.shape[-1]
+        scratch = torch.empty(self.lib.gs_ssim_backward_scratch_floats(NC, H, W), dtype=torch.float32, device=x.device)
+        L.check(self.lib.gs_ssim_distance_backward(_ptr(x), _ptr(y), NC, H, W, _ptr(grad_scale), _ptr(grad_y),
+                                                   _ptr(scratch), _stream()), "gs_ssim_distance_backward")

@@ -64,24 +64,33 @@ def ssim_distance_nograd(x, y):
     return out
 
 
+class _SSIMDistance(torch.autograd.Function):
+    """SSIM distance as a loss term: fused forward (gs_ssim_distance) and hand-written backward
+    (gs_ssim_distance_backward: gradient maps + transposed separable Gaussian); the distance is symmetric, so the
+    gradient w.r.t. the first image is the same kernel with the arguments swapped."""
+
+    @staticmethod
+    def forward(ctx, X, Y):
+        X, Y = X.contiguous(), Y.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=X.device)
+        get_ops().ssim_distance(X, Y, out)
+        ctx.save_for_backward(X, Y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, Y = ctx.saved_tensors
+        g = g.contiguous().float()
+        gx = gy = None
+        if ctx.needs_input_grad[1]:
+            gy = torch.empty_like(Y)
+            get_ops().ssim_distance_backward(X, Y, gy, grad_scale=g)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(X)
+            get_ops().ssim_distance_backward(Y, X, gx, grad_scale=g)
+        return gx, gy
+
+
 def ssim_distance_autograd(X, Y):
-    """Differentiable SSIM distance for `proportion_ssim > 0` (cyclegan_losses.py:78-90). The backward of the
-    fused SSIM kernel is not written yet, so the loss form is composed from torch device ops."""
-    import torch.nn.functional as F
-    X, Y = (X + 1) / 2, (Y + 1) / 2
-    if X.ndim == 5:
-        X, Y = X.reshape(-1, *X.shape[2:]), Y.reshape(-1, *Y.shape[2:])
-    ch = X.shape[1]
-    coords = torch.arange(11, dtype=torch.float32, device=X.device) - 5
-    g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
-    g = (g / g.sum()).view(1, 1, 1, 11).repeat(ch, 1, 1, 1)
-
-    def blur(t):
-        return F.conv2d(F.conv2d(t, g, groups=ch), g.transpose(2, 3), groups=ch)
-
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    mu1, mu2 = blur(X), blur(Y)
-    s1, s2, s12 = blur(X * X) - mu1 ** 2, blur(Y * Y) - mu2 ** 2, blur(X * Y) - mu1 * mu2
-    S1 = (2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)
-    S2 = (2 * s12 + C2) / (s1 + s2 + C2)
-    return torch.sqrt(torch.relu(2 - (S1 + S2))).mean()
+    """Differentiable SSIM distance for `proportion_ssim > 0` (cyclegan_losses.py:78-90; SSIMLoss on (x+1)/2)."""
+    return _SSIMDistance.apply(X.float(), Y.float())

@@ -222,6 +222,11 @@ int gs_mean(const float* x, int64_t n, float* out, void* stream);
 int gs_ssim_distance(const float* x, const float* y, int32_t NC, int32_t H, int32_t W, float* out,
                      float* scratch, void* stream);
 int64_t gs_ssim_scratch_floats(int32_t NC, int32_t H, int32_t W);
+/* gradient of gs_ssim_distance w.r.t. y (the distance is symmetric: swap x and y for the other one), scaled by the
+ * upstream scalar grad_scale[0] (device pointer, NULL = 1): the SSIM-weighted cycle loss, cyclegan_losses.py:78-90 */
+int gs_ssim_distance_backward(const float* x, const float* y, int32_t NC, int32_t H, int32_t W,
+                              const float* grad_scale, float* grad_y, float* scratch, void* stream);
+int64_t gs_ssim_backward_scratch_floats(int32_t NC, int32_t H, int32_t W);
 
 /* ---- optimiser (torch.optim.Adam betas=(0.5,0.999) eps=1e-8, cyclegan.py:81-82) ------------------ */
 /* hyper (host pointer to 6 floats): lr, beta1, beta2, eps, bias_correction1, sqrt(bias_correction2).

@@ -402,6 +402,14 @@ class RefOps:
     def ssim_distance(self, x, y, out):
         out.copy_(ssim_distance(x, y))
 
+    def ssim_distance_backward(self, x, y, grad_y, grad_scale=None):
+        """gradient of the SSIM distance w.r.t. y by differentiating the restatement with autograd"""
+        yy = y.detach().clone().requires_grad_()
+        with torch.enable_grad():
+            d = ssim_distance(x.detach(), yy)
+        (g,) = torch.autograd.grad(d, yy)
+        grad_y.copy_(g * (grad_scale if grad_scale is not None else 1.0))
+
     # ---- optimiser ---------------------------------------------------------------------------------------
     def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, zero_grad=True):
         gi = g * grad_scale

@@ -427,6 +427,24 @@ def test_losses_and_metrics(hip_ops):
     close_f32(outs[1][2], outs[0][2], "mse grad", rel=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 1, 37, 53), (1, 2, 6, 40, 44)])
+def test_ssim_distance_backward(hip_ops, shape):
+    """hand-written gradient of the SSIM distance (gradient maps + transposed separable Gaussian) against autograd of
+    the oracle restatement (nn/losses/utils/ssim.py:65-99 as a loss, cyclegan_losses.py:78-90)"""
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(shape, generator=g) * 2 - 1
+    y = (x * 0.6 + (torch.rand(shape, generator=g) * 2 - 1) * 0.4)
+    scale = torch.tensor(1.7)
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        gy, gx = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
+        ops.ssim_distance_backward(x.to(dev), y.to(dev), gy, grad_scale=scale.to(dev))
+        ops.ssim_distance_backward(y.to(dev), x.to(dev), gx, grad_scale=scale.to(dev))     # symmetric: d/dx
+        outs.append((gy, gx))
+    close_f32(outs[1][0], outs[0][0], "ssim grad y", rel=2e-3)
+    close_f32(outs[1][1], outs[0][1], "ssim grad x", rel=2e-3)
+
+
 def test_losses_repeatable(hip_ops):
     """the fixed-order last-block reduction must give bit-identical results run to run"""
     x = torch.randn(3_000_000, generator=torch.Generator().manual_seed(11)).to(hip_ops.device)
