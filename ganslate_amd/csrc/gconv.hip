@@ -196,7 +196,54 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     }
   };
 
-  if constexpr (NSTAGE == 2) {
+  // fragment load / MFMA halves of a K-step (kk = 0, 1) for the software-pipelined 3-stage loop
+  auto load_frags = [&](int buf, int kk, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
+    const char* wb = smem + buf * STAGE + (wn * (BN / WN) + frow) * 128;
+    const char* xb = smem + buf * STAGE + WT + (wm * (BM / WM) + frow) * 128;
+    const int coff = ((kk * 4 + fk) ^ swz) << 4;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + coff);
+  };
+  auto mfma_frags = [&](const bf16x8 (&wf)[TI], const bf16x8 (&xf)[TJ]) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+
+  if constexpr (NSTAGE == 3 && VARIANT == 0) {
+    // Software-pipelined ring: the LDS reads of the next half K-step are in flight while the matrix pipe works on the
+    // current one, across the barrier too (the plain loop below had every wave read right after the barrier and only
+    // then start its MFMAs: LDS and matrix phases alternated instead of overlapping). DMA runs up to 3 stages ahead:
+    // stage ks+3 goes into the buffer of stage ks as soon as every wave's reads of it have returned.
+    if (nk > 2) issue(2, 2);
+    const int pend0 = (nk > 2 ? 2 : (nk > 1 ? 1 : 0)) * LOADS;
+    if (pend0 == 2 * LOADS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (pend0 == LOADS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 wa[TI], xa[TJ], wb2[TI], xb2[TJ];
+    load_frags(0, 0, wa, xa);
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+      load_frags(cur, 1, wb2, xb2);
+      mfma_frags(wa, xa);
+      if (ks + 1 < nk) {
+        if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // stage ks+1 landed everywhere; nobody still reads stage ks
+        if (ks + 3 < nk) issue(ks + 3, cur);
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        load_frags(nxt, 0, wa, xa);
+        cur = nxt;
+      }
+      mfma_frags(wb2, xb2);
+    }
+    __syncthreads();
+  } else if constexpr (NSTAGE == 2) {
     for (int ks = 0; ks < nk; ++ks) {
       const int cur = ks & 1;
       if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
@@ -222,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         __builtin_amdgcn_s_barrier();
         if (second) compute(cur);
         else if (ks + 2 < nk) issue(ks + 2, nxt2);
-      } else if constexpr (VARIANT == 0) {
+      } else if constexpr (VARIANT == 0 || VARIANT == 16) {   // 16: the plain (not software-pipelined) loop, for A/B runs
         if (ks + 2 < nk) issue(ks + 2, nxt2);
         compute(cur);
       } else if constexpr (VARIANT == 1) {       // MFMAs first, DMA issue behind them
@@ -472,6 +519,7 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
     if (variant == 12) return launch<256, 128, 4, 1, 3, 0>(k, (int)blocks, st);   // 4 waves, 64 px x 128 co per wave
     if (variant == 10) return launch<256, 128, 4, 2, 3, 10>(k, (int)blocks, st);
     if (variant == 15) return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);       // 8 waves
+    if (variant == 16) return launch<256, 128, 4, 4, 3, 16>(k, (int)blocks, st);   // 16 waves, plain loop
     return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);                            // 16 waves: best measured
   }
   return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
