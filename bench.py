@@ -79,6 +79,31 @@ def make_volume_conf(batch, size, n_iters, generator="resnet"):
     return init_config(y, Config)
 
 
+def make_cut_conf(batch, size, n_iters):
+    """BASELINE configs[3]: horse2zebra CUT (PatchNCE) — ResNet-9 + PatchGAN-3 + the patch-feature MLP with the
+    reference defaults (cut.py:16-40: nce_layers 0,4,8,12,16; 256 patches; lambda_nce_idt 0.5) and the horse2zebra
+    learning rates"""
+    from ganslate_amd.configs.config import Config
+    from ganslate_amd.configs.omegalite import OmegaConf
+    from ganslate_amd.configs.utils import init_config
+    y = OmegaConf.create({
+        "train": {
+            "output_dir": "/tmp/ganslate_amd_bench", "cuda": True, "batch_size": batch,
+            "n_iters": n_iters, "n_iters_decay": n_iters,
+            "dataset": {"_target_": "ganslate.data.SyntheticImageDataset", "final_size": [size, size]},
+            "gan": {
+                "_target_": "ganslate.nn.gans.unpaired.CUT",
+                "generator": {"_target_": "ganslate.nn.generators.Resnet2D", "n_residual_blocks": 9,
+                              "in_out_channels": {"AB": [3, 3]}},
+                "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN2D", "n_layers": 3,
+                                  "in_channels": {"B": 3}},
+                "optimizer": {"lr_D": 0.0002, "lr_G": 0.0002},
+            },
+            "metrics": {"discriminator_evolution": True},
+        }})
+    return init_config(y, Config)
+
+
 def make_conf(batch, size, n_iters):
     from ganslate_amd.configs.config import Config
     from ganslate_amd.configs.omegalite import OmegaConf
@@ -132,8 +157,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cyclegan3d", "brats"],
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cut", "cyclegan3d", "brats"],
                     help="cyclegan = the headline (BASELINE configs[1]); pix2pix = configs[2] (batch 1, 256x512); "
+                         "cut = configs[3] (PatchNCE, batch 8, 256x256); "
                          "cyclegan3d = 3-D CycleGAN on 128^3 volumes with Resnet3D (configs[4] shape, batch 1); "
                          "brats = configs[4] with the brats yaml's own networks (Vnet3D + PatchGAN3D-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,6 +188,10 @@ def main():
             args.batch = 1
         model = build_gan(make_pix2pix_conf(args.batch, 10 ** 6))
         shape = (args.batch, 3, 256, 512)
+    elif args.workload == "cut":
+        args.no_cpu_baseline = args.no_kernel_timing = True
+        model = build_gan(make_cut_conf(args.batch, args.size, 10 ** 6))
+        shape = (args.batch, 3, args.size, args.size)
     elif args.workload in ("cyclegan3d", "brats"):
         args.no_cpu_baseline = True
         if args.workload == "brats":
@@ -225,6 +255,16 @@ def main():
                           "data": "synthetic", "config": {"workload": "cityscapes pix2pix (BASELINE configs[2])",
                                                           "global_batch": args.batch * world},
                           "step_tflops": round(value * 371.5 / 1e3, 1)}), flush=True)
+    elif rank == 0 and args.workload == "cut":
+        value = args.batch * world * args.steps / dt
+        print(json.dumps({"metric": "training images/sec, CUT ResNet-9 + PatchGAN-3 + PatchNCE 256x256 bf16",
+                          "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "synthetic",
+                          "config": {"workload": f"horse2zebra CUT (BASELINE configs[3]), {args.size}x{args.size}, "
+                                                 f"batch {args.batch} per GPU, nce_layers 0/4/8/12/16, 256 patches",
+                                     "global_batch": args.batch * world, "parallelism": f"dp{world}"}}), flush=True)
     elif rank == 0 and args.workload in ("cyclegan3d", "brats"):
         value = args.batch * world * args.steps / dt
         vnet = args.workload == "brats"
