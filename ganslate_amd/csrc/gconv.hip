@@ -164,6 +164,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 15;           // row inside a 16-row fragment
   const int fk = lane >> 4;             // k-chunk (8 bf16) inside a 32-deep MFMA step
+  // this lane's bias values, fetched now so their latency hides under the K loop (as 16 dependent loads in the
+  // epilogue they cost ~6 us of the 52 us residual-conv launch)
+  f32x4 bia[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
+    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int swz = lane & 7;             // == row & 7 for every fragment row of this lane
   const int nk = d.Kp >> 6;
 
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     // 3-stage ring, DMA two K-steps ahead; one raw barrier per K-step; counted vmcnt keeps the younger stage in
     // flight across the barrier (a __syncthreads() here would drain it: LDS-DMA counts as a pending LDS write)
     int cur = 0, nxt2 = 2;
-    const int nk_run = (VARIANT == 6 || VARIANT == 8) ? (nk < 2 ? nk : 2) : nk;   // ablations 6/8: no main loop
+    const int nk_run = (VARIANT == 6 || VARIANT == 8 || VARIANT == 17 || VARIANT == 18) ? (nk < 2 ? nk : 2) : nk;   // ablations: no main loop
     for (int ks = 0; ks < nk_run; ++ks) {
       if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         if (ks + 2 < nk) issue(ks + 2, nxt2);
       } else if constexpr (VARIANT == 4) {       // ablation: LDS reads + MFMA only
         compute(cur);
-      } else if constexpr (VARIANT == 6 || VARIANT == 8) {
+      } else if constexpr (VARIANT == 6 || VARIANT == 8 || VARIANT == 17 || VARIANT == 18) {
         compute(cur);
       } else {                                   // VARIANT 2: priority on the MFMA cluster
         if (ks + 2 < nk) issue(ks + 2, nxt2);
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][j][r] + ((p.bias && co < d.Co) ? p.bias[co + r] : 0.f);
+        v[r] = acc[i][j][r] + bia[i][r];
         if (pv) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
         v[r] = apply_act(v[r], d.act, d.slope);
       }
@@ -333,7 +341,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     }
   }
   __syncthreads();
-  {
+  if constexpr (VARIANT == 17) { if (s1[0][0] == 12345.678f) p.out[0] = 1; return; }   // ablation: slab only
+  if constexpr (VARIANT != 18) {
     constexpr int LPR = CW / 8;               // lanes per pixel row (16 B each)
     constexpr int PPI = 64 / LPR;             // pixels per store instruction
     const int sub = lane % LPR, prow = lane / LPR;
@@ -520,6 +529,8 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
     if (variant == 10) return launch<256, 128, 4, 2, 3, 10>(k, (int)blocks, st);
     if (variant == 15) return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);       // 8 waves
     if (variant == 16) return launch<256, 128, 4, 4, 3, 16>(k, (int)blocks, st);   // 16 waves, plain loop
+    if (variant == 17) return launch<256, 128, 4, 2, 3, 17>(k, (int)blocks, st);   // ablation: epilogue = slab only
+    if (variant == 18) return launch<256, 128, 4, 2, 3, 18>(k, (int)blocks, st);   // ablation: epilogue = slab + stats
     return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);                            // 16 waves: best measured
   }
   return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
