@@ -33,6 +33,8 @@ struct GConvK {
   int nh, nw;
   signed char ud[64], uh[64], uw[16];
   unsigned char tap_h[GS_MAX_TAPS], tap_w[GS_MAX_TAPS];
+  gs_gconv_fuse f;             // f.partial != nullptr: first pass of the consumer's InstanceNorm backward in the epilogue
+  int fuse_slots;
   gs_gconv_desc d;
 };
 
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   constexpr int CW = BN / WN;                 // channels per wave
   constexpr int PW = BM / WM;                 // pixels per wave
   constexpr int SROW = CW * 2 + 16;           // padded slab row (bytes), keeps 16-B alignment
-  constexpr int RED_BYTES = WM * BN * 2 * 4;
+  constexpr int RED_BYTES = WM * BN * 3 * 4;  // [WM][BN][2] statistics, or [WM][BN][3] fused norm-backward sums
   char* slab = smem + ((RED_BYTES + 255) / 256) * 256 + wave * (PW * SROW);
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
@@ -347,6 +349,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     constexpr int PPI = 64 / LPR;             // pixels per store instruction
     const int sub = lane % LPR, prow = lane / LPR;
     const int co = nt * BN + wn * CW + sub * 8;
+    // fused first pass of the consumer's InstanceNorm backward (gs_gconv_forward_fused): sums over this tile of
+    // ghat = (g + g2) * act'(yhat), ghat * yhat, yhat, with yhat taken at the pixel the padding folds this one onto
+    const bool fuse = p.f.partial != nullptr;
+    float fa1[8], fa2[8], fa3[8], fmu[8], frs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fa1[k] = fa2[k] = fa3[k] = fmu[k] = frs[k] = 0.f;
+    if (fuse && co < d.Co) {
+      const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { fmu[k] = mr[co + k]; frs[k] = mr[d.Co + co + k]; }
+    }
 #pragma unroll
     for (int it = 0; it < PW / PPI; ++it) {
       const int pl = it * PPI + prow;
@@ -359,6 +372,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
         uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
         uint4* dst = reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2);
+        if (fuse) {
+          const int fd = p.f.Dy > 1 ? p.f.fold : 0;
+          const int uz = zz - fd, uy = ii - p.f.fold, ux = jj - p.f.fold;
+          const bool interior = (unsigned)uz < (unsigned)p.f.Dy && (unsigned)uy < (unsigned)p.f.Hy &&
+                                (unsigned)ux < (unsigned)p.f.Wy;
+          bool okd = true;
+          int yz = border_index(uz, p.f.Dy, p.f.fold_mode, okd);
+          int yy = border_index(uy, p.f.Hy, p.f.fold_mode, okd);
+          int yx = border_index(ux, p.f.Wy, p.f.fold_mode, okd);
+          yz = min(max(yz, 0), p.f.Dy - 1); yy = min(max(yy, 0), p.f.Hy - 1); yx = min(max(yx, 0), p.f.Wy - 1);
+          const size_t ypix = (((size_t)n * p.f.Dy + yz) * p.f.Hy + yy) * p.f.Wy + yx;
+          const uint4 yv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.y) + (ypix * d.Co + co) * 2);
+          float g[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y),
+                        bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
+          const float yr[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
+                               bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
+          if (interior && p.f.g2) {
+            const uint4 gv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.g2) + (ypix * d.Co + co) * 2);
+            g[0] += bf_lo(gv.x); g[1] += bf_hi(gv.x); g[2] += bf_lo(gv.y); g[3] += bf_hi(gv.y);
+            g[4] += bf_lo(gv.z); g[5] += bf_hi(gv.z); g[6] += bf_lo(gv.w); g[7] += bf_hi(gv.w);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float yh = (yr[k] - fmu[k]) * frs[k];
+            const float gh = g[k] * act_grad_from_out(yh, p.f.act, p.f.slope);
+            fa1[k] += gh;
+            fa2[k] += gh * yh;
+            fa3[k] += interior ? yh : 0.f;
+          }
+        }
         if (d.accumulate) {
           const uint4 old = *dst;
           val.x = pack_bf2(bf_lo(val.x) + bf_lo(old.x), bf_hi(val.x) + bf_hi(old.x));
@@ -367,6 +410,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
           val.w = pack_bf2(bf_lo(val.w) + bf_lo(old.w), bf_hi(val.w) + bf_hi(old.w));
         }
         if (VARIANT != 9 || val.x == 0x12345678u) *dst = val;
+      }
+    }
+    if (fuse) {
+      // lanes sharing `sub` hold different pixels of the same 8 channels: butterfly over the pixel bits, then across
+      // the pixel waves through LDS; one slot per pixel tile, no atomics (same contract as the statistics slots)
+      float* red3 = reinterpret_cast<float*>(smem);   // [WM][BN][3]
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          fa1[k] += __shfl_xor(fa1[k], o, 64);
+          fa2[k] += __shfl_xor(fa2[k], o, 64);
+          fa3[k] += __shfl_xor(fa3[k], o, 64);
+        }
+      }
+      if (prow == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int cl = wn * CW + sub * 8 + k;
+          red3[(wm * BN + cl) * 3 + 0] = fa1[k];
+          red3[(wm * BN + cl) * 3 + 1] = fa2[k];
+          red3[(wm * BN + cl) * 3 + 2] = fa3[k];
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const int c = nt * BN + tid;
+        if (c < d.Co) {
+          float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) {
+            t0 += red3[(w * BN + tid) * 3]; t1 += red3[(w * BN + tid) * 3 + 1]; t2 += red3[(w * BN + tid) * 3 + 2];
+          }
+          float* sp = p.f.partial + ((size_t)n * p.fuse_slots + mt) * 3 * d.Co;
+          sp[c] = t0; sp[d.Co + c] = t1; sp[2 * d.Co + c] = t2;
+        }
       }
     }
   }
@@ -451,8 +530,28 @@ extern "C" int gs_gconv_stat_slots(const gs_gconv_desc* d) {
   return (int)((pix + bm - 1) / bm);
 }
 
+static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                              float* stats, const gs_gconv_fuse* fuse, void* stream);
+
 extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                                 void* out, float* stats, void* stream) {
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, nullptr, stream);
+}
+
+extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                                      void* out, float* stats, const gs_gconv_fuse* fuse, void* stream) {
+  GS_REQUIRE(d && fuse && fuse->y && fuse->mean_rstd && fuse->partial, "gs_gconv_forward_fused: null argument");
+  GS_REQUIRE(d->so == 1 && d->si == 1 && !d->accumulate && d->stats_slots == 0 && d->act == GS_ACT_NONE &&
+                 d->out_cs == d->Co && d->out_co == 0,
+             "gs_gconv_forward_fused: only plain stride-1 data-gradient launches with a dense output can be fused");
+  const int fd = fuse->Dy > 1 ? fuse->fold : 0;
+  GS_REQUIRE(d->Do == fuse->Dy + 2 * fd && d->Ho == fuse->Hy + 2 * fuse->fold && d->Wo == fuse->Wy + 2 * fuse->fold,
+             "gs_gconv_forward_fused: output domain must be the norm's domain padded by `fold`");
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, stream);
+}
+
+static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                              float* stats, const gs_gconv_fuse* fuse, void* stream) {
   GS_REQUIRE(d && in && w_pack && out, "gs_gconv_forward: null argument");
   GS_REQUIRE(d->Ci >= 8 && (d->Ci & 7) == 0 && ((d->Ci >> 3) & ((d->Ci >> 3) - 1)) == 0,
              "gs_gconv_forward: Ci=%d must be 8*2^k", d->Ci);
@@ -468,13 +567,15 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
   GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward: stats requested without buffer");
   GS_REQUIRE(!d->accumulate || (d->stats_slots == 0 && d->act == GS_ACT_NONE && !bias),
              "gs_gconv_forward: accumulate excludes bias, activation and statistics");
-  {
+  if (!fuse) {
     int handled = 0;
     if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
     if (handled) return 0;
   }
   const TileCfg tc = pick_tile(d);
   GConvK k;
+  if (fuse) k.f = *fuse; else k.f = gs_gconv_fuse{};
+  k.fuse_slots = (int)(((long long)d->Dc * d->Hc * d->Wc + tc.bm - 1) / tc.bm);
   k.in = static_cast<const char*>(in);
   k.w = static_cast<const char*>(w_pack);
   k.bias = bias;

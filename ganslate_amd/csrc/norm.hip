@@ -365,7 +365,7 @@ extern "C" int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t D, int32_
 extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
                                      void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t D,
                                      int32_t H, int32_t W, int32_t C, int32_t fold, int32_t fold_mode, int32_t act,
-                                     float slope, void* stream) {
+                                     float slope, int32_t pre_slots, void* stream) {
   GS_REQUIRE(g_pad && y && dy && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0,
              "gs_inorm_act_backward: bad argument");
   GS_REQUIRE(fold == 0 || fold_mode == GS_BORDER_REFLECT || (fold_mode == GS_BORDER_REPLICATE && fold <= 3),
@@ -382,8 +382,9 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   float* sums = nullptr;
   if (mean_rstd) {
     GS_REQUIRE(scratch, "gs_inorm_act_backward: scratch required with normalisation");
-    const int chunks = (HW + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
+    const int chunks = pre_slots > 0 ? pre_slots : (HW + kBwdPixPerBlock - 1) / kBwdPixPerBlock;
     sums = scratch + (size_t)N * chunks * 3 * C;
+    if (pre_slots <= 0) {
 #define GS_LAUNCH_REDUCE2(COLS, FM)                                                                                   \
   hipLaunchKernelGGL((inorm_bwd_reduce_kernel<COLS, FM>), dim3(chunks, N, (C8 + COLS - 1) / COLS), dim3(256), 0, st, \
                      static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2), static_cast<const uint4*>(y),     \
@@ -401,6 +402,7 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
 #undef GS_LAUNCH_REDUCE
 #undef GS_LAUNCH_REDUCE2
     GS_CHECK_HIP(hipGetLastError());
+    }
     if (int rc = gs_launch_slot_sum3(scratch, sums, N, chunks, C, 1.0f / (float)HW, mean_rstd, bias_grad, st)) return rc;
   }
   const long long per_img = (long long)HW * C8;

@@ -35,6 +35,12 @@ class NormExDesc(C.Structure):
         ("drop_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
 
 
+class GConvFuse(C.Structure):
+    """Mirror of gs_gconv_fuse."""
+    _fields_ = [("y", C.c_void_p), ("mean_rstd", C.c_void_p), ("g2", C.c_void_p), ("partial", C.c_void_p)] + [
+        (n, C.c_int32) for n in ("Dy", "Hy", "Wy", "fold", "fold_mode", "act")] + [("slope", C.c_float)]
+
+
 class PNormDesc(C.Structure):
     """Mirror of gs_pnorm_desc."""
     _fields_ = [("pixels", C.c_int64)] + [(n, C.c_int32) for n in (
@@ -50,6 +56,8 @@ _PROTOS = {
     "gs_gconv_stat_slots": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "gs_gconv_forward_fused": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.POINTER(GConvFuse), C.c_void_p]),
     "gs_wgrad": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_bias_grad": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_inorm_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float,
@@ -58,7 +66,7 @@ _PROTOS = {
                                        C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "gs_inorm_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "gs_inorm_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gs_norm_act_forward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/ganslate_hip.h). Every call enqueues on torch's current
 stream; tensors are device tensors owned by the caller. No fallback: a missing library raises in lib.load()."""
 import ctypes as C
+import os
 
 import torch
 
@@ -72,18 +73,38 @@ class HipOps:
         """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
         return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
+    def fused_norm_plan(self, g: GConv, N: int, C_: int):
+        """(slots, scratch) for fusing the reduction pass of the consumer's InstanceNorm backward into the data-gradient
+        launch of class g, or None when this backend / layer shape does not fuse (narrow layers run on the halo kernel)"""
+        if g.so != 1 or g.si != 1 or g.Co <= 64 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
+            return None
+        tm = self.tile_m(g, N)
+        slots = (g.pixels + tm - 1) // tm
+        return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
+
     def stat_slots(self, g: GConv, N: int) -> int:
         """partial-statistics slots per image the kernel writes for this class at batch N"""
         return self.lib.gs_gconv_stat_slots(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
-              slope=0.2, stats=None, stats_slots=0, stats_slot0=0, accumulate=False):
+              slope=0.2, stats=None, stats_slots=0, stats_slot0=0, accumulate=False, fuse=None):
         N = x.shape[0]
         in_cs = in_cs if in_cs is not None else x.shape[-1]
         out_cs = out_cs if out_cs is not None else out.shape[-1]
         d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0, accumulate)
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
+        if fuse is not None:     # data gradient + first pass of the consumer's InstanceNorm backward (fused_norm_plan)
+            f = L.GConvFuse()
+            f.y, f.mean_rstd, f.partial = fuse["y"].data_ptr(), fuse["mean_rstd"].data_ptr(), fuse["partial"].data_ptr()
+            f.g2 = fuse["g2"].data_ptr() if fuse.get("g2") is not None else None
+            yd = fuse["y"].shape[1:-1]
+            f.Dy, f.Hy, f.Wy = (1,) + tuple(yd) if len(yd) == 2 else tuple(yd)
+            f.fold, f.fold_mode, f.act, f.slope = fuse["fold"], L.BORDER[fuse["fold_mode"]], L.ACT[fuse["act"]], \
+                float(fuse.get("slope", 0.2))
+            L.check(self.lib.gs_gconv_forward_fused(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats),
+                                                    C.byref(f), _stream()), "gs_gconv_forward_fused")
+            return
         timed = self._timing_filter is not None and self._timing_filter(g)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -128,15 +149,17 @@ class HipOps:
                                               L.ACT[act], slope, _stream()), "gs_inorm_act_forward")
 
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
-                           slope=0.2, bias_grad=None):
+                           slope=0.2, bias_grad=None, pre=None):
         N, D, H, W, Cc = y.shape if y.dim() == 5 else (y.shape[0], 1) + tuple(y.shape[1:])
-        scratch = None
-        if mean_rstd is not None:
+        scratch, pre_slots = None, 0
+        if pre is not None:          # reduction pass already done by the fused data-gradient launch
+            pre_slots, scratch = pre
+        elif mean_rstd is not None:
             n = self.lib.gs_inorm_backward_scratch_floats(N, D, H, W, Cc)
             scratch = torch.empty(n, dtype=torch.float32, device=y.device)
         L.check(self.lib.gs_inorm_act_backward(_ptr(g_pad), _ptr(g2), _ptr(y), _ptr(mean_rstd), _ptr(dy),
                                                _ptr(gsum), _ptr(scratch), _ptr(bias_grad), N, D, H, W, Cc, fold,
-                                               L.BORDER[fold_mode], L.ACT[act], slope, _stream()),
+                                               L.BORDER[fold_mode], L.ACT[act], slope, pre_slots, _stream()),
                 "gs_inorm_act_backward")
 
     # ---- generalised norm / activation for skip-connection graphs (U-Net) ---------------------------------

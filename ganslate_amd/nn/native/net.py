@@ -343,7 +343,8 @@ class NativeNet:
                     f0 = pending[1]
                     inner = (slice(None),) + tuple(slice(f0, f0 + n) for n in lw.out_dims)
                     pending[0][inner] += inj_x[i]   # the pad adjoint is linear
-            g_pad, fold, g2, fmode = pending
+            g_pad, fold, g2, fmode = pending[:4]
+            pre = pending[4] if len(pending) > 4 else None
             x_out = s.acts[i + 1]
             # ---- gradient w.r.t. the conv output y ---------------------------------------------------------------
             need_total = nd.res is not None
@@ -354,7 +355,7 @@ class NativeNet:
                     # the bias gradient of a conv in front of an InstanceNorm comes out of the norm's reduction sums
                     db = grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
                     ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, fold_mode=fmode,
-                                           act=nd.act, slope=nd.slope, bias_grad=db)
+                                           act=nd.act, slope=nd.slope, bias_grad=db, pre=pre)
                 else:
                     ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, fold_mode=fmode, act=nd.act,
                                            slope=nd.slope)
@@ -385,14 +386,27 @@ class NativeNet:
                 f = lw.dgrad_fold
                 gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
                 dpack = pk["dpack"][pk["d_off"][i]:]
-                for g in lw.dgrad:
-                    ops.gconv(g, dy, dpack, None, gx)
-                pending = (gx, f, skip.pop(i - 1, None), sp.pad_mode if f else "reflect")
+                g2n = skip.pop(i - 1, None)
+                fmode_n = sp.pad_mode if f else "reflect"
+                # the reduction pass of the previous layer's InstanceNorm backward rides in this launch's epilogue
+                # (wide stride-1 layers; not when a tapped feature gradient is still to be added to gx)
+                plan = None
+                if i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 1 and (i - 1) not in inj_x:
+                    plan = ops.fused_norm_plan(lw.dgrad[0], N, sp.cin_p)
+                if plan is not None:
+                    ops.gconv(lw.dgrad[0], dy, dpack, None, gx,
+                              fuse={"y": s.ys[i - 1], "mean_rstd": s.mrs[i - 1], "g2": g2n, "partial": plan[1], "fold": f,
+                                    "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope})
+                    pending = (gx, f, g2n, fmode_n, plan)
+                else:
+                    for g in lw.dgrad:
+                        ops.gconv(g, dy, dpack, None, gx)
+                    pending = (gx, f, g2n, fmode_n)
             if start is None:
                 s.acts[i + 1] = None  # release as we go
         if not need_input_grad:
             return None
-        gx, f, _, fmode = pending
+        gx, f, _, fmode = pending[:4]
         g_in = torch.empty_like(s.x_img)
         sp0 = nodes[0].spec
         if sp0.wfold == "in":

@@ -93,6 +93,23 @@ int gs_gconv_stat_slots(const gs_gconv_desc* d);
 /* resnet2d.py:25,35,52-57,65,80-87; patchgan2d.py:29,36-62; backward via loss.backward() base.py:170 */
 int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                      void* out, float* stats, void* stream);
+/* Data-gradient launch of a stride-1 conv with the first pass of the consumer's InstanceNorm backward fused into its
+ * epilogue: while the tile of the (padded-domain) gradient g is stored, the per-tile sums of ghat = (fold(g) + g2) *
+ * act'(yhat), ghat * yhat and yhat over the pixels of the tile are written to partial[N][slots][3][C] (slots =
+ * gs_gconv_stat_slots(d)), exactly what the reduction pass of gs_inorm_act_backward would produce — pass that buffer to it
+ * as `scratch` with pre_slots = slots. y / mean_rstd: raw output and statistics of the conv in front of that norm on the
+ * unpadded domain Dy x Hy x Wy; the launch's output domain is that domain padded by `fold` (resnet2d.py:80-87 backward). */
+typedef struct gs_gconv_fuse {
+  const void* y;
+  const float* mean_rstd;
+  const void* g2;              /* optional residual-join gradient on the unpadded domain */
+  float* partial;
+  int32_t Dy, Hy, Wy;
+  int32_t fold, fold_mode, act;
+  float slope;
+} gs_gconv_fuse;
+int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                           float* stats, const gs_gconv_fuse* fuse, void* stream);
 int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream);
 /* db[c] += sum over pixels of dy[pix, c]  (bias gradient of any conv) */
 int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, void* stream);
@@ -115,7 +132,9 @@ int gs_inorm_act_forward(const void* y, const float* mean_rstd, const void* res,
 int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, const float* mean_rstd,
                           void* dy, void* gsum, float* scratch, float* bias_grad, int32_t N, int32_t D, int32_t H,
                           int32_t W, int32_t C, int32_t fold, int32_t fold_mode, int32_t act, float slope,
-                          void* stream);
+                          int32_t pre_slots, void* stream);
+/* pre_slots > 0: `scratch` already holds the partial sums [N][pre_slots][3][C] (written by gs_gconv_forward_fused)
+ * followed by room for the [N][3][C] totals; the reduction pass is skipped. */
 int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t D, int32_t H, int32_t W, int32_t C);
 
 /* Generalised form for skip-connection graphs (nn/generators/unet/unet2d.py:110-157): the normalised tensor is read

@@ -177,6 +177,52 @@ def test_wgrad_and_bias_grad(hip_ops, case):
     close_f32(res[1][1], res[0][1], "bias grad")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 2, 16, 16),
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),                       # 320-pixel tiles
+    (ConvSpec("conv", 128, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 6, 10, 12),
+    (ConvSpec("conv", 128, 128, 4, 1, 1), 2, 19, 23),                                          # zero padding: no fold
+], ids=_ids)
+@pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none")])
+def test_dgrad_with_fused_norm_reduction(hip_ops, case, with_g2, act):
+    """gs_gconv_forward_fused: the data gradient is unchanged and the per-tile sums written by its epilogue make
+    gs_inorm_act_backward(pre_slots) produce the same dy as its own reduction pass"""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 25)
+    g = torch.Generator().manual_seed(26)
+    C = spec.cin_p
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16)
+    y = (torch.randn(N, *sizes, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16)          # raw output of the previous conv
+    g2 = torch.randn(N, *sizes, C, generator=g).to(torch.bfloat16) if with_g2 else None
+    f, gc = low.dgrad_fold, low.dgrad[0]
+    res = {}
+    for name, ops, dev in (("ref", RefOps(), "cpu"), ("hip", hip_ops, hip_ops.device)):
+        yd = y.to(dev)
+        sp_axes = tuple(range(1, yd.dim() - 1))
+        part = torch.stack([yd.float().sum(sp_axes), (yd.float() ** 2).sum(sp_axes)], 1).reshape(-1).contiguous()
+        mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+        ops.inorm_finalize(part, N, 1, C, yd.numel() // (N * C), mr)
+        plan = ops.fused_norm_plan(gc, N, C)
+        assert plan is not None
+        gx = torch.zeros(N, *low.dgrad_dims, C, dtype=torch.bfloat16, device=dev)
+        ops.gconv(gc, gy.to(dev), dpack.to(dev), None, gx,
+                  fuse={"y": yd, "mean_rstd": mr, "g2": None if g2 is None else g2.to(dev), "partial": plan[1], "fold": f,
+                        "fold_mode": spec.pad_mode if f else "reflect", "act": act, "slope": 0.2})
+        gx_plain = torch.zeros_like(gx)
+        ops.gconv(gc, gy.to(dev), dpack.to(dev), None, gx_plain)
+        dy_pre, dy_own = torch.empty_like(yd), torch.empty_like(yd)
+        kw = dict(fold=f, fold_mode=spec.pad_mode if f else "reflect", act=act)
+        ops.inorm_act_backward(gx, None if g2 is None else g2.to(dev), yd, mr, dy_pre, None, pre=plan, **kw)
+        ops.inorm_act_backward(gx, None if g2 is None else g2.to(dev), yd, mr, dy_own, None, **kw)
+        sums = plan[1][:N * plan[0] * 3 * C].view(N, plan[0], 3, C).sum(1)
+        res[name] = (gx, gx_plain, dy_pre, dy_own, sums)
+    assert torch.equal(res["hip"][0], res["hip"][1]), "fusion must not change the data gradient"
+    close_bf16(res["hip"][0], res["ref"][0], "dgrad")
+    close_f32(res["hip"][4], res["ref"][4], "fused partial sums", rel=3e-3)
+    close_bf16(res["hip"][2], res["hip"][3].cpu(), "dy from fused sums vs own reduction")
+    close_bf16(res["hip"][2], res["ref"][3], "dy vs oracle")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 256), (2, 17, 13, 64), (1, 32, 32, 8), (1, 5, 7, 512)])
 @pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
 @pytest.mark.parametrize("res", [False, True])
