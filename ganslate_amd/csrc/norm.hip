@@ -293,10 +293,22 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
   const float inv_hw = 1.0f / (float)HW;
   const float* mr = mean_rstd ? mean_rstd + (size_t)n * 2 * C8 * 8 : nullptr;
   const float* sm = sums ? sums + (size_t)n * 3 * C8 * 8 : nullptr;
+  // a thread keeps its channel group across iterations whenever the grid stride is a multiple of C8 (every power-of-two
+  // channel count): the four per-channel vectors are then fetched once, not once per element
+  int c8h = -1;
+  float mu[8], rs[8], s1[8], s2[8];
+#pragma unroll 2
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < per_img; e += gridDim.x * 256u) {
     const unsigned px = c8_shift >= 0 ? (e >> c8_shift) : e / (unsigned)C8;
     const int c8 = (int)(e - px * (unsigned)C8);
     float g[8], yy[8], d[8];
+    if (mr && c8 != c8h) {
+      load8(mu, mr + c8 * 8);
+      load8(rs, mr + C8 * 8 + c8 * 8);
+      load8(s1, sm + c8 * 8);
+      load8(s2, sm + C8 * 8 + c8 * 8);
+      c8h = c8;
+    }
     if constexpr (FM == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) g[k] = 0.f;
@@ -312,11 +324,6 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
     }
     unpack8(yy, y_n[e]);
     if (mr) {
-      float mu[8], rs[8], s1[8], s2[8];
-      load8(mu, mr + c8 * 8);
-      load8(rs, mr + C8 * 8 + c8 * 8);
-      load8(s1, sm + c8 * 8);
-      load8(s2, sm + C8 * 8 + c8 * 8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float yh = (yy[k] - mu[k]) * rs[k];
@@ -407,8 +414,10 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   }
   const long long per_img = (long long)HW * C8;
   GS_REQUIRE(per_img < (1LL << 31), "gs_inorm_act_backward: image too large");
-  long long bx = (per_img + 255) / 256;
+  static const int apply_u = getenv("GS_APPLY_U") ? atoi(getenv("GS_APPLY_U")) : 4;   // elements per thread
+  long long bx = (per_img + 256LL * apply_u - 1) / (256LL * apply_u);
   if (bx > 1024) bx = 1024;
+  if (bx < 1) bx = 1;
   int c8_shift = -1;
   if ((C8 & (C8 - 1)) == 0) { c8_shift = 0; while ((1 << c8_shift) < C8) ++c8_shift; }
 #define GS_LAUNCH_APPLY(FM)                                                                                        \
