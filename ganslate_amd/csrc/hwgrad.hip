@@ -107,6 +107,9 @@ __global__ __launch_bounds__(512) void hwgrad_kernel(const HWGradK p) {
     __syncthreads();
 
     if (ntaps > 0) {
+      int tbv[TPW];                                // tap offsets of this wave (tap 0 stands in for the ones past T:
+#pragma unroll                                     // no branch in the loop, their accumulators are dropped at the end)
+      for (int t = 0; t < TPW; ++t) tbv[t] = toff[wave * TPW + (t < ntaps ? t : 0)];
 #pragma unroll 1
       for (int ks = 0; ks < 8; ++ks) {             // 8 K-steps of 32 pixels = 4 box rows of 8
         // dense fragments (shared by every tap of this wave): rows = channels, k = the 8 pixels of box row ks*4+fk
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(512) void hwgrad_kernel(const HWGradK p) {
         const int rb = (lz * p.HH + ly) * p.HW + lx0 + frr;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          if (t < ntaps) {                         // wave-uniform
-            const char* gp = halo + ((size_t)(rb + toff[wave * TPW + t]) * 16 + fcc * 4) * 2;
+          {
+            const char* gp = halo + ((size_t)(rb + tbv[t]) * 16 + fcc * 4) * 2;
             const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4*)GS_LDS(gp)));
             const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -159,6 +162,204 @@ __global__ __launch_bounds__(512) void hwgrad_kernel(const HWGradK p) {
   }
 }
 
+// ---- wide layers with few taps (the 3x3 residual convs: P, Q multiples of 64, T <= 9) -------------------------------------
+// Same staging, different work split: a workgroup owns a 64 x 64 block of (p, q) for ALL taps; its 8 waves each own a
+// 32 x 16 sub-block (two dense fragments, one gathered fragment per tap -> 2 + 2T transpose reads per 2T MFMAs, against
+// 24 reads per 16 MFMAs in wgrad_kernel) and keep T x 2 accumulators in registers across the workgroup's boxes. Boxes are
+// double-buffered: the LDS-DMA of the next box (32 KiB dense tile + 41 KiB halo) runs under the MFMAs of the current one.
+// LDS-DMA traffic per MAC is ~3x below wgrad_kernel's (the gathered operand is staged once for 9 taps).
+// 32-B slot swizzle of a 128-B row v: spreads the 8 (row, k-block) patches a 32-lane transpose read touches over all
+// 64 banks (brute-forced over every alignment: 1 access per bank for the dense tile and the 2-D halo)
+__device__ __forceinline__ int hw_swz(int v) { return ((v >> 1) ^ ((v >> 3) << 1)) & 3; }
+
+template <int TMAX>
+__global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
+  constexpr int APITCH = 128;                      // 64 channels of the dense tile
+  constexpr int ABYTES = 256 * APITCH;             // 32 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* toff = reinterpret_cast<int*>(smem);        // [TMAX]
+  const gs_wgrad_desc& d = p.d;
+  const int HV = p.HD * p.HH * p.HW, hhw = p.HH * p.HW;
+  constexpr int GPITCH = 144;                      // halo voxel pitch: 128 B of channels + 16 B pad (9 pieces), so the
+                                                   // per-tap read address is rowbase(ks) + tapbase(t): one add, no swizzle
+  const int hbytes = (HV * GPITCH + 1023) / 1024 * 1024 + 1024;
+  char* bufs = smem + 256;
+  auto at_of = [&](int b) { return bufs + (size_t)b * (ABYTES + hbytes); };
+  auto halo_of = [&](int b) { return bufs + (size_t)b * (ABYTES + hbytes) + ABYTES; };
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ptiles = d.P / 64;
+  const int pt = blockIdx.y % ptiles, qt = blockIdx.y / ptiles;
+  const int wp = wave >> 2, wq = wave & 3;         // 32-row half of p, 16-column quarter of q
+  for (int t = tid; t < d.T; t += 512)
+    toff[t] = ((((int)d.dd[t] - p.dmin) * p.HH + ((int)d.dh[t] - p.hmin)) * p.HW + ((int)d.dw_[t] - p.wmin)) * GPITCH;
+  __syncthreads();
+  int tb[TMAX];                                    // tap byte offsets inside the halo, in registers for the whole kernel
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) tb[t] = toff[t < d.T ? t : 0];
+
+  f32x4 acc[TMAX][2];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int fk = lane >> 4, frr = (lane & 15) >> 2, fcc = lane & 3;
+  const int hpieces = HV * 9;
+
+  // Each thread stages the same pieces of every box: decode them once (the integer divisions of a per-box decode were
+  // 3/4 of the kernel's VALU work and made it issue-bound).
+  constexpr int NA = 4;                                  // dense pieces per thread: 2048 / 512
+  constexpr int NHMAX = 8;                               // halo pieces per thread (<= 4096 pieces)
+  int a_rel[NA], a_lz[NA], a_ly[NA], a_lx[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = i * 512 + wave * 64 + lane;
+    const int px = q >> 3, part = q & 7;
+    a_lz[i] = px / (p.BH * p.BW);
+    const int rem = px - a_lz[i] * (p.BH * p.BW);
+    a_ly[i] = rem / p.BW;
+    a_lx[i] = rem - a_ly[i] * p.BW;
+    const int spart = part ^ (hw_swz(px) << 1);          // LDS piece `part` of row px holds source piece spart
+    a_rel[i] = ((a_lz[i] * d.Ha + a_ly[i]) * d.Wa + a_lx[i]) * d.a_cs + pt * 64 + spart * 8;
+  }
+  int h_z[NHMAX], h_y[NHMAX], h_x[NHMAX], h_c[NHMAX];
+#pragma unroll
+  for (int i = 0; i < NHMAX; ++i) {
+    const int q = i * 512 + wave * 64 + lane;
+    const int v = q / 9, part = q - v * 9;               // piece 8 of a voxel is the pad
+    const int hz = v / hhw, r2 = v - hz * hhw;
+    const int hy = r2 / p.HW;
+    h_z[i] = hz + p.dmin; h_y[i] = hy + p.hmin; h_x[i] = r2 - hy * p.HW + p.wmin;
+    h_c[i] = (q < hpieces && part < 8) ? qt * 64 + part * 8 : -1;
+  }
+
+  auto issue_box = [&](int box, int b) {
+    int bb = box;
+    const int bx = bb % p.nbw; bb /= p.nbw;
+    const int by = bb % p.nbh; bb /= p.nbh;
+    const int bz = bb % p.nbd;
+    const int n = bb / p.nbd;
+    const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
+    char* at = at_of(b);
+    char* halo = halo_of(b);
+    const size_t pix0 = (((size_t)n * d.Da + oz0) * d.Ha + oy0) * d.Wa + ox0;
+    const char* a_n = p.a + (pix0 * d.a_cs + d.a_co) * 2;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const bool ok = oz0 + a_lz[i] < d.Da && oy0 + a_ly[i] < d.Ha && ox0 + a_lx[i] < d.Wa;
+      const char* src = ok ? a_n + (size_t)a_rel[i] * 2 : p.zero;
+      glds16(src, at + (size_t)(i * 512 + wave * 64) * 16);
+    }
+    const char* g_n = p.g + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+#pragma unroll
+    for (int i = 0; i < NHMAX; ++i) {
+      if (i * 512 + wave * 64 < hpieces) {               // wave-uniform: whole 64-piece instructions inside the halo
+        bool ok = h_c[i] >= 0;
+        int iz = border_index(oz0 + h_z[i], d.Dg, d.border, ok);
+        int iy = border_index(oy0 + h_y[i], d.Hg, d.border, ok);
+        int ix = border_index(ox0 + h_x[i], d.Wg, d.border, ok);
+        iz = min(max(iz, 0), d.Dg - 1);
+        iy = min(max(iy, 0), d.Hg - 1);
+        ix = min(max(ix, 0), d.Wg - 1);
+        unsigned off = ((unsigned)((iz * d.Hg + iy) * d.Wg + ix) * (unsigned)d.g_cs + (unsigned)h_c[i]) * 2u;
+        asm volatile("" : "+v"(off));
+        const char* src = ok ? g_n + off : p.zero;
+        glds16(src, halo + (size_t)(i * 512 + wave * 64) * 16);
+      }
+    }
+  };
+  // dense-tile byte offsets of this lane's transpose reads inside a K-step (the swizzle only looks at row bits 1..3,
+  // which a K-step offset of 32 rows does not touch)
+  int aoff[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = fk * 8 + h * 4 + frr;
+      aoff[i][h] = r * APITCH + (((wp * 2 + i) ^ hw_swz(r)) << 5) + fcc * 8;
+    }
+  // halo row base of this lane's 8-pixel run, per K-step
+  int rbk[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int px0 = (ks * 4 + fk) * 8;
+    const int lz = px0 / (p.BH * p.BW), rem = px0 - lz * (p.BH * p.BW);
+    const int ly = rem / p.BW, lx0 = rem - ly * p.BW;
+    rbk[ks] = ((lz * p.HH + ly) * p.HW + lx0 + frr) * GPITCH + wq * 32 + fcc * 8;   // byte offset incl. this lane's columns
+  }
+
+  int cur = 0;
+  int box = blockIdx.x;
+  if (box < p.nboxes) issue_box(box, 0);
+  for (; box < p.nboxes; box += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this box landed (nothing else is outstanding)
+    __syncthreads();                                     // ... for every wave; the other buffer is fully consumed
+    if (box + (int)gridDim.x < p.nboxes && p.tgroups != 3) issue_box(box + gridDim.x, cur ^ 1);
+    if (p.tgroups == 2) { cur ^= 1; continue; }          // ablation: staging only
+    // address-space-3 base pointers once per box: per-read addresses are then 32-bit adds (a generic -> LDS cast per
+    // read was a third of the loop's VALU work)
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* at3 = (lds_char*)GS_LDS(at_of(cur));
+    lds_char* halo3 = (lds_char*)GS_LDS(halo_of(cur));
+    auto tr64 = [](lds_char* a) {
+      return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a));
+    };
+    // fragments of K-step ks: 2 dense + T gathered (T == TMAX, host dispatch)
+    auto load_frags = [&](int ks, bf16x8 (&af)[2], bf16x8 (&gf)[TMAX]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint2 lo = tr64(at3 + aoff[i][0] + ks * (32 * APITCH));
+        const uint2 hi = tr64(at3 + aoff[i][1] + ks * (32 * APITCH));
+        af[i] = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        lds_char* g0 = halo3 + rbk[ks] + tb[t];
+        const uint2 lo = tr64(g0);
+        const uint2 hi = tr64(g0 + 4 * GPITCH);
+        gf[t] = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+      }
+    };
+    auto mma = [&](const bf16x8 (&af)[2], const bf16x8 (&gf)[TMAX]) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[t], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[t], acc[t][1], 0, 0, 0);
+      }
+    };
+    // software pipeline over the 8 K-steps: the 22 transpose reads of step ks+1 are issued before the 18 MFMAs of
+    // step ks (the compiler otherwise emits read-wait-MFMA per tap and the LDS latency is exposed 72 times per box)
+    bf16x8 afA[2], gfA[TMAX], afB[2], gfB[TMAX];
+    load_frags(0, afA, gfA);
+#pragma unroll
+    for (int ks = 0; ks < 8; ks += 2) {
+      load_frags(ks + 1, afB, gfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(afA, gfA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < 8) load_frags(ks + 2, afA, gfA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(afB, gfB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur ^= 1;
+  }
+
+  const int col = lane & 15;
+  const int q = qt * 64 + wq * 16 + col;
+  if (p.tgroups == 1 && acc[0][0][0] != 12345.678f) return;   // ablation: no atomics
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t < d.T) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = pt * 64 + wp * 32 + i * 16 + fk * 4 + r;
+          unsafeAtomicAdd(p.dw + (size_t)pp * d.dw_ld + t * d.Q + q, acc[t][i][r]);
+        }
+    }
+  }
+}
+
 namespace {
 template <int TI, int TPW>
 int launch_hw(const HWGradK& k, dim3 grid, int lds, hipStream_t st) {
@@ -178,6 +379,51 @@ int launch_hw(const HWGradK& k, dim3 grid, int lds, hipStream_t st) {
 int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream, int* handled) {
   *handled = 0;
   static const bool enabled = !(getenv("GS_HWGRAD") && atoi(getenv("GS_HWGRAD")) == 0);
+  static const bool wide_enabled = !(getenv("GS_HWGRAD_WIDE") && atoi(getenv("GS_HWGRAD_WIDE")) == 0);
+  if (enabled && wide_enabled && d->si == 1 && d->T == 9 && d->P % 64 == 0 && d->Q % 64 == 0 && d->P >= 64 &&
+      d->Q >= 64 && d->Da == 1) {
+    int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
+    for (int t = 0; t < d->T; ++t) {
+      const int o[3] = {d->dd[t], d->dh[t], d->dw_[t]};
+      for (int ax = 0; ax < 3; ++ax) { if (o[ax] < lo[ax]) lo[ax] = o[ax]; if (o[ax] > hi[ax]) hi[ax] = o[ax]; }
+    }
+    HWGradK k;
+    k.BD = 1; k.BH = 16; k.BW = 16;
+    k.HD = k.BD + hi[0] - lo[0]; k.HH = k.BH + hi[1] - lo[1]; k.HW = k.BW + hi[2] - lo[2];
+    k.dmin = lo[0]; k.hmin = lo[1]; k.wmin = lo[2];
+    k.nbd = 1; k.nbh = (d->Ha + k.BH - 1) / k.BH; k.nbw = (d->Wa + k.BW - 1) / k.BW;
+    const long long nboxes = (long long)d->N * k.nbh * k.nbw;
+    const long long hv = (long long)k.HD * k.HH * k.HW;
+    const int hbytes = (int)((hv * 144 + 1023) / 1024 * 1024 + 1024);
+    const int lds = 256 + 2 * (256 * 128 + hbytes);
+    const int tiles = (d->P / 64) * (d->Q / 64);
+    if (lds <= 160 * 1024 && hv * 9 <= 4096 && nboxes >= 4 && nboxes < (1LL << 31) && tiles <= 65535 &&
+        (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31)) {
+      k.nboxes = (int)nboxes;
+      k.qchunks = k.phalves = 1;
+      k.tgroups = getenv("GS_HWW_ABL") ? atoi(getenv("GS_HWW_ABL")) : 0;   // 0 = normal; 1/2/3 = ablations
+      k.a = static_cast<const char*>(a);
+      k.g = static_cast<const char*>(g);
+      k.dw = dw;
+      k.zero = static_cast<const char*>(gs_zero_page());
+      GS_REQUIRE(k.zero, "gs_wgrad: library not initialised (call gs_init)");
+      k.d = *d;
+      long long groups = 256 / tiles;                    // one workgroup per CU
+      if (groups < 1) groups = 1;
+      if (groups > nboxes) groups = nboxes;
+      static bool configured = false;
+      if (!configured) {
+        GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_wide_kernel<9>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+      }
+      *handled = 1;
+      hipLaunchKernelGGL((hwgrad_wide_kernel<9>), dim3((unsigned)groups, (unsigned)tiles), dim3(512), lds,
+                         static_cast<hipStream_t>(stream), k);
+      GS_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   if (!enabled || d->si != 1 || d->P > 64 || d->Q > 64 || d->T < 9) return 0;
   if (d->Q > 32 && d->P > 16) return 0;            // wide on both sides: the im2col kernel is the better fit (measured)
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
