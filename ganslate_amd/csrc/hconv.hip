@@ -141,23 +141,42 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
       __syncthreads();                                   // ... for every wave; stage g-1 fully consumed
       if (g + 1 < nstages) issue_w(g + 1, chunk, buf ^ 1);
       const char* wb = wst + buf * WSTAGE;
+      // tap offsets of the stage's 8 K-steps first, then a hand-pipelined loop: the 4 + TI fragment reads of step
+      // u+1 are issued before the 4*TI MFMAs of step u (left to itself the compiler emits read-wait-MFMA per fragment)
+      int vo[SK];
 #pragma unroll
       for (int u = 0; u < SK; ++u) {
-        const int kk = (g * SK + u) * 32 + kg * 8;
-        const int tap = kk >> p.cc_shift, c0 = kk & (CC - 1);
-        const int vo = toff[tap < d.T ? tap : 0];        // past the last tap the weights are zero: any finite B
-        bf16x8 wf[TI], xf[4];
+        const int tap = ((g * SK + u) * 32 + kg * 8) >> p.cc_shift;
+        vo[u] = toff[tap < d.T ? tap : 0];               // past the last tap the weights are zero: any finite B
+      }
+      const int c0 = (kg * 8) & (CC - 1);                // 32 % CC == 0: this lane's channel offset is step-invariant
+      auto load_frags = [&](int u, bf16x8 (&wf)[TI], bf16x8 (&xf)[4]) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
           wf[i] = *reinterpret_cast<const bf16x8*>(wb + (i * 16 + row) * 528 + (u * 4 + kg) * 16);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          xf[j] = *reinterpret_cast<const bf16x8*>(halo + ((size_t)(pbase[j] + vo) * CC + c0) * 2);
+          xf[j] = *reinterpret_cast<const bf16x8*>(halo + ((size_t)(pbase[j] + vo[u]) * CC + c0) * 2);
+      };
+      auto mma = [&](const bf16x8 (&wf)[TI], const bf16x8 (&xf)[4]) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      };
+      bf16x8 wA[TI], xA[4], wB[TI], xB[4];
+      load_frags(0, wA, xA);
+#pragma unroll
+      for (int u = 0; u < SK; u += 2) {
+        load_frags(u + 1, wB, xB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wA, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < SK) load_frags(u + 2, wA, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wB, xB);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
