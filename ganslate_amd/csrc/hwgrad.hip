@@ -17,6 +17,9 @@
 struct HWGradK {
   const char* a;
   const char* g;
+  const char* a2;          // optional second (dense, gathered) pair of the same layer: boxes >= nboxes1 come from it
+  const char* g2;          // (two backward passes through a network merged into one launch, gs_wgrad_pair)
+  int nboxes1;
   float* dw;
   const char* zero;
   int BD, BH, BW;        // pixel box
@@ -236,19 +239,21 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
     const int bx = bb % p.nbw; bb /= p.nbw;
     const int by = bb % p.nbh; bb /= p.nbh;
     const int bz = bb % p.nbd;
-    const int n = bb / p.nbd;
+    int n = bb / p.nbd;
+    if (box >= p.nboxes1) n -= d.N;                      // image index inside the second pair
     const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
     char* at = at_of(b);
     char* halo = halo_of(b);
+    const bool second = box >= p.nboxes1;                // wave-uniform
     const size_t pix0 = (((size_t)n * d.Da + oz0) * d.Ha + oy0) * d.Wa + ox0;
-    const char* a_n = p.a + (pix0 * d.a_cs + d.a_co) * 2;
+    const char* a_n = (second ? p.a2 : p.a) + (pix0 * d.a_cs + d.a_co) * 2;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const bool ok = oz0 + a_lz[i] < d.Da && oy0 + a_ly[i] < d.Ha && ox0 + a_lx[i] < d.Wa;
       const char* src = ok ? a_n + (size_t)a_rel[i] * 2 : p.zero;
       glds16(src, at + (size_t)(i * 512 + wave * 64) * 16);
     }
-    const char* g_n = p.g + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+    const char* g_n = (second ? p.g2 : p.g) + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
 #pragma unroll
     for (int i = 0; i < NHMAX; ++i) {
       if (i * 512 + wave * 64 < hpieces) {               // wave-uniform: whole 64-piece instructions inside the halo
@@ -376,7 +381,16 @@ int launch_hw(const HWGradK& k, dim3 grid, int lds, hipStream_t st) {
 }  // namespace
 
 // returns 0 and sets *handled when the layer ran here; *handled = 0 -> the caller falls back to wgrad_kernel
+int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
+                   void* stream, int* handled);
+
 int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream, int* handled) {
+  return gs_hwgrad_try2(d, a, g, nullptr, nullptr, dw, stream, handled);
+}
+
+// a2/g2 != nullptr: a second operand pair of the same layer (only the wide kernel merges; otherwise *handled stays 0)
+int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
+                   void* stream, int* handled) {
   *handled = 0;
   static const bool enabled = !(getenv("GS_HWGRAD") && atoi(getenv("GS_HWGRAD")) == 0);
   static const bool wide_enabled = !(getenv("GS_HWGRAD_WIDE") && atoi(getenv("GS_HWGRAD_WIDE")) == 0);
@@ -392,7 +406,8 @@ int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* d
     k.HD = k.BD + hi[0] - lo[0]; k.HH = k.BH + hi[1] - lo[1]; k.HW = k.BW + hi[2] - lo[2];
     k.dmin = lo[0]; k.hmin = lo[1]; k.wmin = lo[2];
     k.nbd = 1; k.nbh = (d->Ha + k.BH - 1) / k.BH; k.nbw = (d->Wa + k.BW - 1) / k.BW;
-    const long long nboxes = (long long)d->N * k.nbh * k.nbw;
+    const long long nboxes1 = (long long)d->N * k.nbh * k.nbw;
+    const long long nboxes = a2 ? 2 * nboxes1 : nboxes1;
     const long long hv = (long long)k.HD * k.HH * k.HW;
     const int hbytes = (int)((hv * 144 + 1023) / 1024 * 1024 + 1024);
     const int lds = 256 + 2 * (256 * 128 + hbytes);
@@ -400,6 +415,9 @@ int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* d
     if (lds <= 160 * 1024 && hv * 9 <= 4096 && nboxes >= 4 && nboxes < (1LL << 31) && tiles <= 65535 &&
         (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31)) {
       k.nboxes = (int)nboxes;
+      k.nboxes1 = (int)nboxes1;
+      k.a2 = static_cast<const char*>(a2);
+      k.g2 = static_cast<const char*>(g2);
       k.qchunks = k.phalves = 1;
       k.tgroups = getenv("GS_HWW_ABL") ? atoi(getenv("GS_HWW_ABL")) : 0;   // 0 = normal; 1/2/3 = ablations
       k.a = static_cast<const char*>(a);
@@ -424,6 +442,7 @@ int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* d
       return 0;
     }
   }
+  if (a2) return 0;                                // only the wide kernel merges two passes
   if (!enabled || d->si != 1 || d->P > 64 || d->Q > 64 || d->T < 9) return 0;
   if (d->Q > 32 && d->P > 16) return 0;            // wide on both sides: the im2col kernel is the better fit (measured)
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
@@ -448,6 +467,8 @@ int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* d
   if (lds > 96 * 1024) return 0;
   if ((long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs >= (1LL << 31)) return 0;
   k.nboxes = (int)nboxes;
+  k.nboxes1 = (int)nboxes;
+  k.a2 = k.g2 = nullptr;
   k.a = static_cast<const char*>(a);
   k.g = static_cast<const char*>(g);
   k.dw = dw;

@@ -272,8 +272,24 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
 }
 }  // namespace
 
-// hwgrad.hip: halo-resident kernel for narrow stride-1 layers
+// hwgrad.hip: halo-resident kernels for narrow stride-1 layers and the wide 3x3 layers
 int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream, int* handled);
+int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
+                   void* stream, int* handled);
+
+extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream);
+
+// dw += wgrad(a1, g1) + wgrad(a2, g2) for two operand pairs of the SAME layer and shapes (the two backward passes a
+// network sees per step): one launch where the kernel can merge them (fixed costs and atomics paid once), else two
+extern "C" int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2,
+                             float* dw, void* stream) {
+  GS_REQUIRE(d && a1 && g1 && a2 && g2 && dw, "gs_wgrad_pair: null argument");
+  int handled = 0;
+  if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, stream, &handled)) return rc;
+  if (handled) return 0;
+  if (int rc = gs_wgrad(d, a1, g1, dw, stream)) return rc;
+  return gs_wgrad(d, a2, g2, dw, stream);
+}
 
 extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream) {
   GS_REQUIRE(d && a && g && dw, "gs_wgrad: null argument");

@@ -115,7 +115,13 @@ class HipOps:
             e1.record()
             self._timing_events.append((e0, e1))
 
-    def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
+    @staticmethod
+    def can_merge_wgrad(w: WGrad) -> bool:
+        """two backward passes of this layer can share one launch (the wide halo kernel's eligibility, hwgrad.hip)"""
+        return (w.T == 9 and w.si == 1 and w.P % 64 == 0 and w.Q % 64 == 0 and w.Da == 1
+                and os.environ.get("GS_WGRAD_PAIR", "1") != "0")
+
+    def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
         key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)
         ent = self._desc_cache.get(key)
         if ent is None:
@@ -130,6 +136,10 @@ class HipOps:
                 d.dh[i], d.dw_[i], d.dd[i] = p, q, r
             ent = (d, w)
             self._desc_cache[key] = ent
+        if pair is not None:      # (a2, g2): the same layer's operands from another backward pass, one launch
+            L.check(self.lib.gs_wgrad_pair(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(pair[0]), _ptr(pair[1]), _ptr(dw),
+                                           _stream()), "gs_wgrad_pair")
+            return
         L.check(self.lib.gs_wgrad(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(dw), _stream()), "gs_wgrad")
 
     def bias_grad(self, dy, C_, db, *, cs=None, co=0):

@@ -87,6 +87,7 @@ class NativeNet:
         self._reduce_handles = []
         self._reduced_buckets = set()
         self.grad_dirty = False
+        self._deferred = {}          # node -> (wgrad desc, dense, gathered) held back for a merged launch
 
     # ---- torch.nn.Module-like surface used by BaseGAN ----------------------------------------------------------
     def parameters(self):
@@ -334,6 +335,9 @@ class NativeNet:
             pending = (ga, 0, None, "reflect")
         skip: Dict[int, torch.Tensor] = {}
         final_pass = want_w and self._dist is not None and self._fw_pending == 0
+        # another recorded forward of this net still awaits its backward (G_AB(real_A) and G_AB(fake_A) in one step):
+        # hold the weight gradients of mergeable layers back and issue both passes as one launch then
+        more_passes = want_w and self._fw_pending > 0 and start is None
         for i in range(last, -1, -1):
             nd, lw, sp = nodes[i], lows[i], nodes[i].spec
             if i in inj_x:            # tapped feature gradient joins the gradient of this node's output
@@ -370,7 +374,16 @@ class NativeNet:
             if want_w:
                 dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
                 a_t, g_t = (dy, s.acts[i]) if sp.kind == "conv" else (s.acts[i], dy)
-                ops.wgrad(lw.wgrad, a_t, g_t, dw)
+                held = self._deferred.pop(i, None)
+                if held is not None and (held[0] is not lw.wgrad or held[1].shape != a_t.shape):
+                    ops.wgrad(held[0], held[1], held[2], dw)      # other input size: cannot share a launch
+                    held = None
+                if held is not None:
+                    ops.wgrad(lw.wgrad, a_t, g_t, dw, pair=(held[1], held[2]))
+                elif more_passes and ops.can_merge_wgrad(lw.wgrad):
+                    self._deferred[i] = (lw.wgrad, a_t, g_t)
+                else:
+                    ops.wgrad(lw.wgrad, a_t, g_t, dw)
                 if sp.bias and not nd.norm:
                     if sp.wfold == "out":   # channels [0, cout) of dy are the dw = 0 slice = the plain output gradient
                         tmp = torch.zeros(sp.cout_p, dtype=torch.float32, device=dev)
@@ -444,8 +457,16 @@ class NativeNet:
         self._reduce_handles.append(h)
         self._reduced_buckets.add(i)
 
+    def flush_deferred_wgrads(self):
+        """weight gradients held back for a merged launch whose partner pass never came"""
+        for i, (wd, a_t, g_t) in sorted(self._deferred.items()):
+            sp = self.nodes[i].spec
+            self.ops.wgrad(wd, a_t, g_t, self.master.grad[self.w_off[i]:self.w_off[i] + sp.master_numel])
+        self._deferred = {}
+
     def finish_grad_reduction(self) -> float:
         """Called by the optimiser before the update. Returns the factor the summed gradient must be scaled by."""
+        self.flush_deferred_wgrads()
         if self._dist is None:
             return 1.0
         import torch.distributed as dist

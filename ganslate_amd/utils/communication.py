@@ -15,7 +15,9 @@ def init_distributed():
             if backend == "nccl":
                 torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
             if not dist.is_initialized():
-                dist.init_process_group(backend=backend, init_method="env://")
+                import datetime
+                dist.init_process_group(backend=backend, init_method="env://",
+                                        timeout=datetime.timedelta(minutes=10))
             synchronize()
         else:
             raise ValueError("Distributed ON but but running single process.")

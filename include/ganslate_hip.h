@@ -111,6 +111,10 @@ typedef struct gs_gconv_fuse {
 int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
                            float* stats, const gs_gconv_fuse* fuse, void* stream);
 int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream);
+/* dw += wgrad(a1, g1) + wgrad(a2, g2): two operand pairs of the same layer and shapes — the two backward passes a
+ * generator sees per step (cyclegan.py:139-150: G_AB(real_A) and G_AB(fake_A)) — in one launch where possible */
+int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
+                  void* stream);
 /* db[c] += sum over pixels of dy[pix, c]  (bias gradient of any conv) */
 int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, void* stream);
 

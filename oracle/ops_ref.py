@@ -139,7 +139,13 @@ class RefOps:
             part[:, 0, 1] = (gh * yh).reshape(N, -1, Cc).sum(1)
             part[:, 0, 2] = yh.reshape(N, -1, Cc).sum(1)
 
-    def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0):
+    @staticmethod
+    def can_merge_wgrad(w):
+        return w.T == 9 and w.si == 1 and w.P % 64 == 0 and w.Q % 64 == 0 and w.Da == 1
+
+    def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
+        if pair is not None:
+            self.wgrad(w, pair[0], pair[1], dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co)
         av = _v5(a)[..., a_co:a_co + w.P].float()
         gv = _v5(g)[..., g_co:g_co + w.Q].float()
         z = torch.arange(w.Da) * w.si

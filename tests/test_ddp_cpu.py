@@ -13,6 +13,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    """a port nobody listens on right now (fixed offsets collided with sockets lingering from an earlier test)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 OVERRIDES = ["train.gan.generator.n_residual_blocks=2", "train.dataset.final_size=[32,32]", "train.gan.pool_size=0",
              "train.metrics.ssim=False", "train.metrics.discriminator_evolution=False"]
 
@@ -62,10 +70,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 def test_two_rank_gradient_equals_single_process_batch_two(tmp_path):
     world = 2
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
     for name in r0["weights"]:
@@ -120,12 +128,12 @@ def _cut_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 def test_cut_two_ranks_stay_in_sync(tmp_path):
     """CUT's encoder-only partial passes leave the upper gradient buckets to the catch-up reduction; generator,
     discriminator and mlp must still end every step identical on all ranks."""
     world = 2
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_cut_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"cut_rank{r}.pt") for r in range(world))
     for name in r0:
@@ -161,12 +169,12 @@ def _vnet_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 def test_vnet3d_cyclegan_two_ranks_stay_in_sync(tmp_path):
     """3-D CycleGAN with Vnet3D + PatchGAN3D under data parallelism (BASELINE configs[4]): conv weights AND the PReLU
     slopes stored behind them in the flat buffer are averaged; all ranks end every step with identical parameters."""
     world = 2
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_vnet_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"vnet_rank{r}.pt") for r in range(world))
     for name in r0:
