@@ -518,6 +518,10 @@ int launch(const GConvK& k, int blocks, hipStream_t st) {
 int gs_hconv_slots(const gs_gconv_desc* d);
 int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
                  void* stream, int* handled);
+// hconvw.hip: halo-resident forward kernel for the wide 3x3 stride-1 layers
+int gs_hconvw_slots(const gs_gconv_desc* d);
+int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
+                  void* stream, int* handled);
 
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
 
@@ -525,6 +529,8 @@ extern "C" int gs_gconv_stat_slots(const gs_gconv_desc* d) {
   if (!d || d->Dc < 1 || d->Hc < 1 || d->Wc < 1) return 0;
   const int hs = gs_hconv_slots(d);
   if (hs) return hs;
+  const int ws = gs_hconvw_slots(d);
+  if (ws) return ws;
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const int bm = pick_tile(d).bm;
   return (int)((pix + bm - 1) / bm);
@@ -570,6 +576,8 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
   if (!fuse) {
     int handled = 0;
     if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
+    if (handled) return 0;
+    if (int rc = gs_hconvw_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
     if (handled) return 0;
   }
   const TileCfg tc = pick_tile(d);

@@ -1,0 +1,287 @@
+// Halo-resident forward kernel for the WIDE 3x3 stride-1 layers (the residual-block convs, Cin a multiple of 64,
+// Cout a multiple of 128, image sides multiples of 16): ganslate/nn/generators/resnet/resnet2d.py:80-87.
+//
+// gconv_kernel's loop is bound by the LDS: per K-step it takes 48 KiB of LDS-DMA writes (16 KiB weights + 32 KiB of
+// gathered pixels) and the fragment reads. The pixels of the 9 taps of a 64-channel chunk are the same
+// 18x18 halo box read at 9 offsets, so this kernel stages that box ONCE per chunk (47 KiB, double-buffered, border
+// handling resolved once per workgroup in the per-lane source offsets) and streams only the weights per K-step:
+// 16 + 47/9 = 21 KiB of DMA per K-step instead of 48. The MFMA B operand of tap t is a ds_read_b128 at
+// rowbase(j) + tapoff(t); a 144-byte voxel pitch makes 16 consecutive voxels cover all 64 banks.
+// Tile 256 pixels (one 16x16 box) x 128 output channels, 16 waves as 4 x 4, 3-stage weight ring, same epilogue
+// contract as gconv_kernel (bias, one statistics slot per box, activation, dense or sliced output).
+#include "common.hpp"
+#include <cstdlib>
+
+struct HConvWK {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  float* stats;
+  const char* zero;
+  int tiles_m, tiles_n, nbw;   // boxes per image, channel tiles, boxes per row
+  int hh, hw, hmin, wmin;      // halo extent and smallest tap offsets
+  int chunks;                  // Ci / 64
+  gs_gconv_desc d;
+};
+
+template <int T>
+__global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
+  constexpr int BM = 256, BN = 128, WM = 4, WN = 4, NW = 16;
+  constexpr int WT = BN * 128;                   // weight stage: 128 rows x 64 k
+  constexpr int HP = 144;                        // halo voxel pitch (9 pieces of 16 B: 8 channels-pieces + 1 pad)
+  constexpr int HBUF = 3 * 1024 * 16;            // 3 LDS-DMA instructions of 1024 lanes per buffer (>= 18*18*9 pieces)
+  constexpr int HPW = 3;                         // halo DMA instructions per wave per chunk
+  constexpr int TI = 2, TJ = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wring = smem;                            // 3 x 16 KiB
+  char* hbuf = smem + 3 * WT;                    // 2 x 48 KiB
+  const gs_gconv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int b;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int nt = b % p.tiles_n;
+  b /= p.tiles_n;
+  const int mt = b % p.tiles_m;
+  const int n = b / p.tiles_m;
+  const int oy0 = (mt / p.nbw) * 16, ox0 = (mt % p.nbw) * 16;
+
+  // ---- halo pieces of this thread (box-invariant, resolved once): source byte offset of channel chunk 0, or -1 ----
+  const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+  const int hpieces = p.hh * p.hw * 9;
+  int hsrc[HPW];
+#pragma unroll
+  for (int i = 0; i < HPW; ++i) {
+    const int q = i * 1024 + tid;
+    const int v = q / 9, part = q - v * 9;
+    const int hy = v / p.hw, hx = v - hy * p.hw;
+    bool ok = q < hpieces && part < 8;
+    int iy = border_index(oy0 + hy + p.hmin, d.Hi, d.border, ok);
+    int ix = border_index(ox0 + hx + p.wmin, d.Wi, d.border, ok);
+    iy = min(max(iy, 0), d.Hi - 1);
+    ix = min(max(ix, 0), d.Wi - 1);
+    hsrc[i] = ok ? ((iy * d.Wi + ix) * d.in_cs + part * 8) * 2 : -1;
+  }
+  auto issue_halo = [&](int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      unsigned off = (unsigned)hsrc[i] + (unsigned)chunk * 128u;
+      asm volatile("" : "+v"(off));
+      const char* src = hsrc[i] >= 0 ? in_n + off : p.zero;
+      glds16(src, hbuf + buf * HBUF + (i * 1024 + wave * 64) * 16);
+    }
+  };
+  // ---- weight stage: one LDS-DMA instruction per wave (128 rows x 8 pieces), rows swizzled like gconv_kernel ----
+  const int lrow = lane >> 3;
+  const int wchunk = (lane & 7) ^ lrow;
+  const int wco = nt * BN + wave * 8 + lrow;
+  const bool wv = wco < d.w_rows;
+  const char* wsrc = wv ? p.w + ((size_t)wco * d.Kp + wchunk * 8) * 2 : p.zero;
+  const int winc = wv ? 16 : 0;                  // bytes per 8-k piece step
+  auto issue_w = [&](int c, int t, int buf) {
+    const int q0 = (t * (d.Ci >> 3)) + c * 8;    // first 8-k piece of this K-step inside a pack row (tap-major pack)
+    glds16(wsrc + (size_t)q0 * winc, wring + buf * WT + wave * 1024);
+  };
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 15, fk = lane >> 4, swz = lane & 7;
+  int rowb[TJ];                                  // halo byte offset of this lane's pixel in box row wm*4+j, k-chunk fk
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) rowb[j] = ((wm * 4 + j) * p.hw + frow) * HP + fk * 16;
+  int tb[T];                                     // tap byte offsets inside the halo
+#pragma unroll
+  for (int t = 0; t < T; ++t) tb[t] = (((int)d.dh[t] - p.hmin) * p.hw + ((int)d.dw[t] - p.wmin)) * HP;
+
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bia[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
+    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- main loop: chunks x taps; weights 2 K-steps ahead in a 3-stage ring, halo one chunk ahead ----------------
+  const int nk = p.chunks * T;
+  issue_halo(0, 0);
+  issue_w(0, 0, 0);
+  if (nk > 1) issue_w(T > 1 ? 0 : 1, T > 1 ? 1 : 0, 1);
+  int stage = 0;
+  for (int c = 0; c < p.chunks; ++c) {
+    const char* hb = hbuf + (c & 1) * HBUF;
+    const bool more_chunks = c + 1 < p.chunks;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int ks = c * T + t;
+      // in-order completion: leave only the DMAs younger than this step's weights in flight
+      if (ks + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (t == 1 && more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + 1) : "memory");   // + next halo
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t == 0 && more_chunks) issue_halo(c + 1, (c + 1) & 1);
+      if (ks + 2 < nk) {
+        const int t2 = t + 2 < T ? t + 2 : t + 2 - T;
+        const int c2 = t + 2 < T ? c : c + 1;
+        issue_w(c2, t2, stage >= 1 ? stage - 1 : 2);   // ring slot (stage + 2) % 3
+      }
+      const char* wb = wring + stage * WT + (wn * 32 + frow) * 128;
+      const char* xb = hb + tb[t];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((kk * 4 + fk) ^ swz) << 4;
+        bf16x8 wf[TI], xf[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + rowb[j] + kk * 64);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: bias, partial statistics (slot = box), activation, LDS-staged coalesced NHWC stores ------------
+  const bool want_stats = d.stats_slots > 0;
+  float s1[TI][4], s2[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+  constexpr int CW = 32, PW = 64, SROW = CW * 2 + 16;
+  constexpr int RED_BYTES = WM * BN * 2 * 4;
+  char* slab = smem + ((RED_BYTES + 255) / 256) * 256 + wave * (PW * SROW);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + bia[i][r];
+        s1[i][r] += v[r];
+        s2[i][r] += v[r] * v[r];
+        v[r] = apply_act(v[r], d.act, d.slope);
+      }
+      uint2 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(slab + (j * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int LPR = CW / 8, PPI = 64 / LPR;   // 4 lanes per pixel, 16 pixels per store instruction
+    const int sub = lane % LPR, prow = lane / LPR;
+    const int co = nt * BN + wn * CW + sub * 8;
+#pragma unroll
+    for (int it = 0; it < PW / PPI; ++it) {
+      const int pl = it * PPI + prow;             // pixel inside the wave's 4 box rows
+      const int ly = wm * 4 + (pl >> 4), lx = pl & 15;
+      if (co < d.Co) {
+        const size_t opix = ((size_t)n * d.Ho + (oy0 + ly)) * d.Wo + (ox0 + lx);
+        const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
+        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
+      }
+    }
+  }
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[i][r], q = s2[i][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        if (frow == 0) {
+          const int cl = wn * CW + i * 16 + fk * 4 + r;
+          red[(wm * BN + cl) * 2 + 0] = a;
+          red[(wm * BN + cl) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = nt * BN + tid;
+      if (co < d.Co) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+        sp[co] = a;
+        sp[d.Co + co] = q;
+      }
+    }
+  }
+}
+
+static bool hconvw_eligible(const gs_gconv_desc* d, int* lo) {
+  static const bool enabled = !(getenv("GS_HCONV_WIDE") && atoi(getenv("GS_HCONV_WIDE")) == 0);
+  if (!enabled || d->si != 1 || d->so != 1 || d->T != 9 || d->Ci % 64 != 0 || d->Co % 128 != 0 || d->accumulate) return false;
+  if (d->Di != 1 || d->Do != 1 || d->Dc != 1 || d->Hc != d->Ho || d->Wc != d->Wo || d->py || d->px || d->pz) return false;
+  if (d->Ho % 16 != 0 || d->Wo % 16 != 0) return false;
+  int hi[2] = {-128, -128};
+  lo[0] = lo[1] = 127;
+  for (int t = 0; t < d->T; ++t) {
+    if (d->dd[t] != 0) return false;
+    const int o[2] = {d->dh[t], d->dw[t]};
+    for (int a = 0; a < 2; ++a) { if (o[a] < lo[a]) lo[a] = o[a]; if (o[a] > hi[a]) hi[a] = o[a]; }
+  }
+  if (hi[0] - lo[0] != 2 || hi[1] - lo[1] != 2) return false;    // 18 x 18 halo
+  const long long blocks = (long long)d->N * (d->Ho / 16) * (d->Wo / 16) * (d->Co / 128);
+  if (blocks < 192 || blocks >= (1LL << 31)) return false;        // small grids: the 128-pixel tiles fill the chip better
+  if ((long long)d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 31)) return false;
+  return true;
+}
+
+// partial-statistics slots per image when the layer runs here (one per 16x16 box), 0 when it does not
+int gs_hconvw_slots(const gs_gconv_desc* d) {
+  int lo[2];
+  return hconvw_eligible(d, lo) ? (d->Ho / 16) * (d->Wo / 16) : 0;
+}
+
+// returns 0 and sets *handled when the layer ran here
+int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                  float* stats, void* stream, int* handled) {
+  *handled = 0;
+  int lo[2];
+  if (!hconvw_eligible(d, lo)) return 0;
+  const long long blocks = (long long)d->N * (d->Ho / 16) * (d->Wo / 16) * (d->Co / 128);
+  HConvWK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_pack);
+  k.bias = bias;
+  k.out = static_cast<char*>(out);
+  k.stats = stats;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
+  k.tiles_m = (d->Ho / 16) * (d->Wo / 16);
+  k.tiles_n = d->Co / 128;
+  k.nbw = d->Wo / 16;
+  k.hh = 18; k.hw = 18; k.hmin = lo[0]; k.wmin = lo[1];
+  k.chunks = d->Ci / 64;
+  k.d = *d;
+  const int lds = 3 * 128 * 128 + 2 * 3 * 1024 * 16;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  *handled = 1;
+  hipLaunchKernelGGL((hconvw_kernel<9>), dim3((unsigned)blocks), dim3(1024), lds, static_cast<hipStream_t>(stream), k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
