@@ -29,13 +29,19 @@ template <int T>
 __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   constexpr int BM = 256, BN = 128, WM = 4, WN = 4, NW = 16;
   constexpr int WT = BN * 128;                   // weight stage: 128 rows x 64 k
-  constexpr int HP = 144;                        // halo voxel pitch (9 pieces of 16 B: 8 channels-pieces + 1 pad)
-  constexpr int HBUF = 3 * 1024 * 16;            // 3 LDS-DMA instructions of 1024 lanes per buffer (>= 18*18*9 pieces)
-  constexpr int HPW = 3;                         // halo DMA instructions per wave per chunk
+  constexpr int HP = 160;                        // halo voxel pitch: 8 channel pieces of 16 B + 2 pad pieces. 40 banks: the
+                                                 // 16 lanes of every ds_read_b128 lane group land on 16 distinct 4-bank
+                                                 // slots (144 B left the k-chunk-1 lanes on the k-chunk-0 lanes' banks)
+  constexpr int HPIECES = 18 * 18 * 10;          // 3240
+  constexpr int HINSTR = (HPIECES + 63) / 64;    // 51 wave-instructions of 64 pieces
+  constexpr int HBUF = HINSTR * 1024;            // 52224 B per buffer
+  constexpr int HPW = 4;                         // halo DMA instructions per wave per chunk (uniform: surplus ones
+                                                 // copy the zero page into a 1-KiB sink so vmcnt counts stay equal)
   constexpr int TI = 2, TJ = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wring = smem;                            // 3 x 16 KiB
-  char* hbuf = smem + 3 * WT;                    // 2 x 48 KiB
+  char* hbuf = smem + 3 * WT;                    // 2 x 51 KiB
+  char* sink = hbuf + 2 * HBUF;                  // 1 KiB
   const gs_gconv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,14 +59,13 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
 
   // ---- halo pieces of this thread (box-invariant, resolved once): source byte offset of channel chunk 0, or -1 ----
   const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
-  const int hpieces = p.hh * p.hw * 9;
   int hsrc[HPW];
 #pragma unroll
   for (int i = 0; i < HPW; ++i) {
-    const int q = i * 1024 + tid;
-    const int v = q / 9, part = q - v * 9;
+    const int q = (i * NW + wave) * 64 + lane;   // wave-instruction i*16+wave covers pieces [inst*64, inst*64+64)
+    const int v = q / 10, part = q - v * 10;
     const int hy = v / p.hw, hx = v - hy * p.hw;
-    bool ok = q < hpieces && part < 8;
+    bool ok = q < HPIECES && part < 8;
     int iy = border_index(oy0 + hy + p.hmin, d.Hi, d.border, ok);
     int ix = border_index(ox0 + hx + p.wmin, d.Wi, d.border, ok);
     iy = min(max(iy, 0), d.Hi - 1);
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       unsigned off = (unsigned)hsrc[i] + (unsigned)chunk * 128u;
       asm volatile("" : "+v"(off));
       const char* src = hsrc[i] >= 0 ? in_n + off : p.zero;
-      glds16(src, hbuf + buf * HBUF + (i * 1024 + wave * 64) * 16);
+      const int inst = i * NW + wave;
+      glds16(src, inst < HINSTR ? hbuf + buf * HBUF + inst * 1024 : sink);
     }
   };
   // ---- weight stage: one LDS-DMA instruction per wave (128 rows x 8 pieces), rows swizzled like gconv_kernel ----
@@ -109,46 +115,66 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- main loop: chunks x taps; weights 2 K-steps ahead in a 3-stage ring, halo one chunk ahead ----------------
+  // ---- main loop: chunks x taps, software-pipelined over half K-steps --------------------------------------------
+  // Weights run 3 K-steps ahead in a 3-slot ring, halo boxes 2 chunks ahead in 2 buffers. Inside a K-step the fragment
+  // reads of the second half are issued before the MFMAs of the first, and the reads of the NEXT step's first half
+  // (after the one barrier per K-step) before the MFMAs of the second: LDS latency hides under the matrix pipe.
   const int nk = p.chunks * T;
+  auto load_frags = [&](const char* wb, const char* xb, int kk, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
+    const int coff = ((kk * 4 + fk) ^ swz) << 4;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + rowb[j] + kk * 64);
+  };
+  auto mma = [&](const bf16x8 (&wf)[TI], const bf16x8 (&xf)[TJ]) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+  auto ct_of = [&](int ks, int& c, int& t) { c = ks / T; t = ks - c * T; };
   issue_halo(0, 0);
-  issue_w(0, 0, 0);
-  if (nk > 1) issue_w(T > 1 ? 0 : 1, T > 1 ? 1 : 0, 1);
+  if (p.chunks > 1) issue_halo(1, 1);
+#pragma unroll
+  for (int s0 = 0; s0 < 3; ++s0)
+    if (s0 < nk) { int c0, t0; ct_of(s0, c0, t0); issue_w(c0, t0, s0); }
+  // halo 0 (and, in order, halo 1) and weights 0 landed; weights 1, 2 may still fly
+  if (nk >= 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wA[TI], xA[TJ], wB[TI], xB[TJ];
+  load_frags(wring + (wn * 32 + frow) * 128, hbuf + tb[0], 0, wA, xA);
   int stage = 0;
   for (int c = 0; c < p.chunks; ++c) {
     const char* hb = hbuf + (c & 1) * HBUF;
-    const bool more_chunks = c + 1 < p.chunks;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int ks = c * T + t;
-      // in-order completion: leave only the DMAs younger than this step's weights in flight
-      if (ks + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (t == 1 && more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + 1) : "memory");   // + next halo
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (t == 0 && more_chunks) issue_halo(c + 1, (c + 1) & 1);
-      if (ks + 2 < nk) {
-        const int t2 = t + 2 < T ? t + 2 : t + 2 - T;
-        const int c2 = t + 2 < T ? c : c + 1;
-        issue_w(c2, t2, stage >= 1 ? stage - 1 : 2);   // ring slot (stage + 2) % 3
-      }
       const char* wb = wring + stage * WT + (wn * 32 + frow) * 128;
-      const char* xb = hb + tb[t];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int coff = ((kk * 4 + fk) ^ swz) << 4;
-        bf16x8 wf[TI], xf[TJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + rowb[j] + kk * 64);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      load_frags(wb, hb + tb[t], 1, wB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wA, xA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < nk) {
+        // weights ks+1 landed, this wave's reads of slot `stage` (and, at t == T-1, of this chunk's halo) returned
+        if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (t == 0 && c >= 1 && c + 1 < p.chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(HPW + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t == T - 1 && c + 2 < p.chunks) issue_halo(c + 2, c & 1);
+        if (ks + 3 < nk) { int c3, t3; ct_of(ks + 3, c3, t3); issue_w(c3, t3, stage); }
+        const int nstage = stage == 2 ? 0 : stage + 1;
+        const char* nwb = wring + nstage * WT + (wn * 32 + frow) * 128;
+        const char* nxb = (t == T - 1) ? hbuf + ((c + 1) & 1) * HBUF + tb[0] : hb + tb[t + 1 < T ? t + 1 : 0];
+        load_frags(nwb, nxb, 0, wA, xA);
+        stage = nstage;
       }
-      stage = stage == 2 ? 0 : stage + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wB, xB);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();
@@ -273,7 +299,7 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.hh = 18; k.hw = 18; k.hmin = lo[0]; k.wmin = lo[1];
   k.chunks = d->Ci / 64;
   k.d = *d;
-  const int lds = 3 * 128 * 128 + 2 * 3 * 1024 * 16;
+  const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
   static bool configured = false;
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9>),
