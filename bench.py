@@ -315,7 +315,7 @@ def main():
             tf = flop / (ms * 1e-3) / 1e12 if n else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                               "kernel": "gconv_kernel<256,128,4,4,3> (3x3 256->256 reflect conv, M=%d N=256 K=2304)"
+                               "kernel": "hconvw_kernel<9> (3x3 256->256 reflect conv, halo-resident, M=%d N=256 K=2304)"
                                          % (hw * args.batch),
                                "launches_timed": n, "avg_ms": round(ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
