@@ -151,13 +151,20 @@ __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const
   if constexpr (FM == 0) {
     add_bf8(f, gpad_n[(size_t)px * C8 + c8]);
   } else {
-    const int zi = px / W, iw = px - zi * W;
+    const int zi = div_small(px, W, 1.0f / (float)W), iw = px - zi * W;
     const int Wp = W + 2 * fold, Hp = H + 2 * fold;
     if constexpr (FM == 1) {                            // the 2-D nets (nn.ReflectionPad2d)
-      const FoldIdx fh = fold_sources(zi, H, fold);
-      const FoldIdx fw = fold_sources(iw, W, fold);
-      for (int a = 0; a < fh.cnt; ++a)
-        for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.idx[a] * Wp + fw.idx[b]) * C8 + c8]);
+      // only rows / columns 1..fold and n-1-fold..n-2 collect reflected copies: everything else is one load
+      const bool plain = (zi < 1 || zi > fold) && (zi < H - 1 - fold || zi > H - 2) &&
+                         (iw < 1 || iw > fold) && (iw < W - 1 - fold || iw > W - 2);
+      if (plain) {
+        add_bf8(f, gpad_n[((size_t)(zi + fold) * Wp + (iw + fold)) * C8 + c8]);
+      } else {
+        const FoldIdx fh = fold_sources(zi, H, fold);
+        const FoldIdx fw = fold_sources(iw, W, fold);
+        for (int a = 0; a < fh.cnt; ++a)
+          for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.idx[a] * Wp + fw.idx[b]) * C8 + c8]);
+      }
     } else if constexpr (FM == 2) {
       const int iz = zi / H, ih = zi - iz * H;
       const FoldIdx fd = fold_sources(iz, D, fold);
