@@ -166,14 +166,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 15;           // row inside a 16-row fragment
   const int fk = lane >> 4;             // k-chunk (8 bf16) inside a 32-deep MFMA step
-  // this lane's bias values, fetched now so their latency hides under the K loop (as 16 dependent loads in the
-  // epilogue they cost ~6 us of the 52 us residual-conv launch)
-  f32x4 bia[TI];
-#pragma unroll
-  for (int i = 0; i < TI; ++i) {
-    const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
-    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+
   const int swz = lane & 7;             // == row & 7 for every fragment row of this lane
   const int nk = d.Kp >> 6;
 
@@ -224,7 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   };
 
-  if constexpr (NSTAGE == 3 && VARIANT == 0) {
+  if constexpr (NSTAGE == 3 && VARIANT == 19) {   // measured: -2 % at best, and its extra live fragments spill at 16 waves
     // Software-pipelined ring: the LDS reads of the next half K-step are in flight while the matrix pipe works on the
     // current one, across the barrier too (the plain loop below had every wave read right after the barrier and only
     // then start its MFMAs: LDS and matrix phases alternated instead of overlapping). DMA runs up to 3 stages ahead:
@@ -306,6 +299,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   }
 
   if constexpr (VARIANT == 8) { if (acc[0][0][0] == 12345.678f) p.out[0] = 1; return; }
+  // this lane's bias values as TI vector loads issued back to back (one exposed latency; as 4*TI dependent scalar loads
+  // inside the loops below they cost ~6 us per launch, and fetched before the K loop they cost registers in it)
+  f32x4 bia[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
+    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // ---- epilogue: bias, InstanceNorm partial statistics, activation, bf16 NHWC store -----------------
   const bool want_stats = d.stats_slots > 0 && VARIANT != 10;
   float s1[TI][4], s2[TI][4];
@@ -342,7 +343,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       *reinterpret_cast<uint2*>(slab + (j * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
     }
   }
+  // per-wave statistics to LDS before the store loop, so the s1/s2 registers are dead inside it
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2] in front of the store slabs
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[i][r], q = s2[i][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        if (frow == 0) {
+          const int cl = wn * (BN / WN) + i * 16 + fk * 4 + r;
+          red[(wm * BN + cl) * 2 + 0] = a;
+          red[(wm * BN + cl) * 2 + 1] = q;
+        }
+      }
+  }
   __syncthreads();
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(smem);
+    if (tid < BN) {
+      const int co = nt * BN + tid;
+      if (co < d.Co) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+        sp[co] = a;
+        sp[d.Co + co] = q;
+      }
+    }
+  }
   if constexpr (VARIANT == 17) { if (s1[0][0] == 12345.678f) p.out[0] = 1; return; }   // ablation: slab only
   if constexpr (VARIANT != 18) {
     constexpr int LPR = CW / 8;               // lanes per pixel row (16 B each)
@@ -450,34 +482,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     }
   }
 
-  if (want_stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2] in front of the store slabs
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[i][r], q = s2[i][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
-        if (frow == 0) {
-          const int cl = wn * (BN / WN) + i * 16 + fk * 4 + r;
-          red[(wm * BN + cl) * 2 + 0] = a;
-          red[(wm * BN + cl) * 2 + 1] = q;
-        }
-      }
-    __syncthreads();
-    if (tid < BN) {
-      const int co = nt * BN + tid;
-      if (co < d.Co) {
-        float a = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
-        sp[co] = a;
-        sp[d.Co + co] = q;
-      }
-    }
-  }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -637,7 +641,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     if (variant == 12) return launch<256, 128, 4, 1, 3, 0>(k, (int)blocks, st);   // 4 waves, 64 px x 128 co per wave
     if (variant == 10) return launch<256, 128, 4, 2, 3, 10>(k, (int)blocks, st);
     if (variant == 15) return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);       // 8 waves
-    if (variant == 16) return launch<256, 128, 4, 4, 3, 16>(k, (int)blocks, st);   // 16 waves, plain loop
+    if (variant == 19) return launch<256, 128, 4, 4, 3, 19>(k, (int)blocks, st);   // 16 waves, software-pipelined loop
     if (variant == 17) return launch<256, 128, 4, 2, 3, 17>(k, (int)blocks, st);   // ablation: epilogue = slab only
     if (variant == 18) return launch<256, 128, 4, 2, 3, 18>(k, (int)blocks, st);   // ablation: epilogue = slab + stats
     return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);                            // 16 waves: best measured

@@ -108,12 +108,6 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bia[TI];
-#pragma unroll
-  for (int i = 0; i < TI; ++i) {
-    const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
-    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 
   // ---- main loop: chunks x taps, software-pipelined over half K-steps --------------------------------------------
   // Weights run 3 K-steps ahead in a 3-slot ring, halo boxes 2 chunks ahead in 2 buffers. Inside a K-step the fragment
@@ -176,6 +170,12 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       mma(wB, xB);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  f32x4 bia[TI];                                // loaded after the loop: inside it they would spill (128-VGPR cap)
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
+    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
 

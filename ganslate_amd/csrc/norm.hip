@@ -120,14 +120,23 @@ extern "C" int gs_inorm_act_forward(const void* y, const float* mean_rstd, const
 // folded gradient: g(n, ih, iw, c8) = sum over the padded-domain positions that the padding maps to (ih, iw)
 // reflect: up to 3 source positions per axis; replicate: one contiguous range per axis (the border cell collects its
 // `p` pad cells). Kept as two code paths so the index lists stay in registers.
-struct FoldIdx { int idx[3]; int cnt; };
+// (scalars + selects, not an indexed array: a dynamically indexed idx[3] went to scratch memory and made the fold
+// variants of both backward kernels 2.5x slower than the plain ones)
+struct FoldIdx {
+  int i0, i1, i2, cnt;
+  __device__ __forceinline__ int at(int a) const { return a == 0 ? i0 : (a == 1 ? i1 : i2); }
+};
 __device__ __forceinline__ FoldIdx fold_sources(int x, int n, int p) {
   FoldIdx f;
-  f.idx[0] = x + p;
+  f.i0 = x + p;
+  f.i1 = f.i2 = 0;
   f.cnt = 1;
   if (p > 0) {
-    if (x >= 1 && x <= p) f.idx[f.cnt++] = p - x;
-    if (x >= n - 1 - p && x <= n - 2) f.idx[f.cnt++] = p + 2 * (n - 1) - x;
+    const bool lo = x >= 1 && x <= p, hi = x >= n - 1 - p && x <= n - 2;
+    const int e1 = p - x, e2 = p + 2 * (n - 1) - x;
+    f.i1 = lo ? e1 : e2;
+    f.i2 = e2;
+    f.cnt = 1 + (lo ? 1 : 0) + (hi ? 1 : 0);
   }
   return f;
 }
@@ -163,7 +172,7 @@ __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const
         const FoldIdx fh = fold_sources(zi, H, fold);
         const FoldIdx fw = fold_sources(iw, W, fold);
         for (int a = 0; a < fh.cnt; ++a)
-          for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.idx[a] * Wp + fw.idx[b]) * C8 + c8]);
+          for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.at(a) * Wp + fw.at(b)) * C8 + c8]);
       }
     } else if constexpr (FM == 2) {
       const int iz = zi / H, ih = zi - iz * H;
@@ -173,7 +182,7 @@ __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const
       for (int c = 0; c < fd.cnt; ++c)
         for (int a = 0; a < fh.cnt; ++a)
           for (int b = 0; b < fw.cnt; ++b)
-            add_bf8(f, gpad_n[(((size_t)fd.idx[c] * Hp + fh.idx[a]) * Wp + fw.idx[b]) * C8 + c8]);
+            add_bf8(f, gpad_n[(((size_t)fd.at(c) * Hp + fh.at(a)) * Wp + fw.at(b)) * C8 + c8]);
     } else {                                            // replicate (nn.ReplicationPad3d)
       const int iz = zi / H, ih = zi - iz * H;
       int d0, d1, h0, h1, w0, w1;

@@ -29,10 +29,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rotate", type=int, default=8, help="distinct tensor sets cycled through (cold-ish caches)")
+    ap.add_argument("--size", type=int, default=64)
     args = ap.parse_args()
     ops = HipOps()
     dev = ops.device
-    N, H, W, C = 8, 64, 64, 256
+    N, H, W, C = 8, args.size, args.size, 256
     R = args.rotate
     mk = lambda *shape: [torch.randn(*shape, device=dev).to(torch.bfloat16) for _ in range(R)]
     y, x, res = mk(N, H, W, C), mk(N, H, W, C), mk(N, H, W, C)
