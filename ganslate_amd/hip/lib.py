@@ -109,6 +109,9 @@ _PROTOS = {
     "gs_ssim_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float),
                                C.c_float, C.c_int32, C.c_void_p]),
+    "gs_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_float, C.c_int32, C.c_void_p]),
+    "gs_pool_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "gs_repack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 

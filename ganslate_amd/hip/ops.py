@@ -43,6 +43,9 @@ class HipOps:
         self._timing_filter, self._timing_events = gconv_filter, []
         return self._timing_events
 
+    def disable_kernel_timing(self):
+        self._timing_filter = None
+
     def kernel_timing_result(self):
         """(launches, average milliseconds) of the gconv launches selected by the filter"""
         torch.cuda.synchronize()
@@ -330,6 +333,17 @@ class HipOps:
         hyper = (C.c_float * 6)(lr, beta1, beta2, eps, bc1, bc2_sqrt)
         L.check(self.lib.gs_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), hyper, float(grad_scale),
                                       int(zero_grad), _stream()), "gs_adam_step")
+
+    def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True):
+        """hyper_dev: device float32[6] = lr, beta1, beta2, eps, 1-beta1^t, sqrt(1-beta2^t) (see NativeAdam.prepare)"""
+        L.check(self.lib.gs_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev),
+                                          float(grad_scale), int(zero_grad), _stream()), "gs_adam_step_dev")
+
+    def pool_query(self, pool, images, out, code_dev):
+        B = images.shape[0]
+        nbytes = images[0].numel() * images.element_size()
+        L.check(self.lib.gs_pool_query(_ptr(pool), _ptr(images), _ptr(out), _ptr(code_dev), B, nbytes, _stream()),
+                "gs_pool_query")
 
     def repack(self, master, index, pack):
         L.check(self.lib.gs_repack_bf16(_ptr(master), _ptr(index), _ptr(pack), pack.numel(), _stream()),

@@ -24,6 +24,7 @@ class Pix2PixConditionalGANConfig(configs.base.BaseGANConfig):
 
 
 class Pix2PixConditionalGAN(BaseGAN):
+    graph_capturable = True      # fixed launch sequence, no image pool
 
     def __init__(self, conf):
         super().__init__(conf)

@@ -30,6 +30,7 @@ class CycleGANConfig(configs.base.BaseGANConfig):
 
 
 class CycleGAN(BaseGAN):
+    graph_capturable = True      # fixed launch sequence: the pools' coin flips and Adam's scalars live in device memory
 
     def __init__(self, conf):
         super().__init__(conf)
@@ -44,6 +45,9 @@ class CycleGAN(BaseGAN):
             self.fake_A_pool = ImagePool(conf.train.gan.pool_size)
             self.fake_B_pool = ImagePool(conf.train.gan.pool_size)
         self.setup()
+
+    def _step_pools(self):
+        return [self.fake_B_pool, self.fake_A_pool]      # backward_D("D_B") runs first
 
     def init_criterions(self):
         self.criterion_adv = AdversarialLoss(self.conf.train.gan.optimizer.adversarial_loss_type).to(self.device)

@@ -14,27 +14,61 @@ class NativeAdam(torch.optim.Optimizer):
             if getattr(p, "_owner_net", None) is None:
                 raise TypeError("NativeAdam only optimises the flat master parameters of NativeNet instances")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.external_prepare = False
+
+    def prepare(self):
+        """Host side of one update: advance the step counters and upload the step-dependent scalars (learning rate from
+        the scheduler, bias corrections) to each parameter's device hyper vector. `step()` calls it itself unless a
+        captured step owns the launches (external_prepare), in which case the caller prepares before every replay."""
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                if "hyper" not in st:
+                    st["hyper"] = torch.zeros(6, dtype=torch.float32, device=p.device)
+                st["step"] += 1
+                t = st["step"]
+                st["hyper"].copy_(torch.tensor([group["lr"], b1, b2, group["eps"], 1.0 - b1 ** t,
+                                                (1.0 - b2 ** t) ** 0.5], dtype=torch.float64).float())
 
     @torch.no_grad()
     def step(self, closure=None):
         ops = get_ops()
+        if not self.external_prepare:
+            self.prepare()
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
                 net = p._owner_net
                 if p.grad is None:
                     continue
                 scale = net.finish_grad_reduction()
                 st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                ops.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                              st["step"], grad_scale=scale, zero_grad=True)
+                ops.adam_step_dev(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["hyper"], grad_scale=scale,
+                                  zero_grad=True)
                 net.grad_dirty = False
                 net.mark_packs_dirty()
+
+    def state_dict(self):
+        sd = super().state_dict()       # the hyper vectors are derived state: rebuilt by the next prepare()
+        sd["state"] = {k: {kk: vv for kk, vv in st.items() if kk != "hyper"} for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """moments are loaded INTO the existing device buffers (a captured step keeps their addresses)"""
+        old = {p: dict(st) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)
+        for p, st_old in old.items():
+            st_new = self.state[p]
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st_old and k in st_new:
+                    st_old[k].copy_(st_new[k])
+                    st_new[k] = st_old[k]
+            if "hyper" in st_old:
+                st_new["hyper"] = st_old["hyper"]
 
     def zero_grad(self, set_to_none=True):
         """The update kernel already cleared the gradient it consumed; only buffers written since are cleared."""

@@ -256,6 +256,16 @@ int64_t gs_ssim_backward_scratch_floats(int32_t NC, int32_t H, int32_t W);
  * grad_scale multiplies the gradient (1/world_size after an all-reduce SUM). zero_grad != 0 clears g. */
 int gs_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_host,
                  float grad_scale, int32_t zero_grad, void* stream);
+/* Same update with `hyper` (same 6 floats) in DEVICE memory, so a captured hipGraph of the step can be replayed while
+ * the host refreshes the learning rate and bias corrections between replays. */
+int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                     float grad_scale, int32_t zero_grad, void* stream);
+/* ImagePool.query (ganslate/data/utils/image_pool.py:31-60) with the host's coin flips uploaded as code_dev[B]:
+ * < 0 pass image b through; slot: store image b in `slot`, return it (pool filling); slot | 0x40000000: return the
+ * image stored in `slot`, store image b there. Images of a batch are handled in order (same-slot draws chain like the
+ * reference's loop). pool = [slots][image_bytes], images/out = [B][image_bytes], image_bytes % 16 == 0. */
+int gs_pool_query(void* pool, const void* images, void* out, const int32_t* code_dev, int32_t B,
+                  int64_t image_bytes, void* stream);
 /* pack[e] = bf16(master[index[e]]) (index < 0 -> 0): refresh the bf16 forward/dgrad weight packs */
 int gs_repack_bf16(const float* master, const int32_t* index, void* pack, int64_t n, void* stream);
 

@@ -450,6 +450,31 @@ class RefOps:
         if zero_grad:
             g.zero_()
 
+    def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True):
+        """hyper_dev = float32[6]: lr, beta1, beta2, eps, 1-beta1^t, sqrt(1-beta2^t) — the update of adam_step with the
+        scalars taken from the tensor (they were rounded to fp32 when it was written, like the kernel's arguments)"""
+        lr, beta1, beta2, eps, bc1, bc2s = (float(h) for h in hyper_dev.tolist())
+        gi = g * grad_scale
+        m.lerp_(gi, 1 - beta1)
+        v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+        p.addcdiv_(m, (v.sqrt() / bc2s).add_(eps), value=-lr / bc1)
+        if zero_grad:
+            g.zero_()
+
+    def pool_query(self, pool, images, out, code_dev):
+        """ganslate/data/utils/image_pool.py:31-60 with the coin flips given as codes (see gs_pool_query)"""
+        for b, c in enumerate(code_dev.tolist()):
+            img = images[b].clone()
+            if c < 0:
+                out[b] = img
+            elif c & 0x40000000:
+                slot = c & 0x3fffffff
+                out[b] = pool[slot]
+                pool[slot] = img
+            else:
+                pool[c] = img
+                out[b] = img
+
     def repack(self, master, index, pack):
         idx = index.long()
         vals = master.reshape(-1)[idx.clamp_min(0)]

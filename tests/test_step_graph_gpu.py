@@ -1,0 +1,145 @@
+"""The captured training step (BaseGAN._graph_step): a CycleGAN whose iterations run as hipGraph replays must follow the
+same trajectory as one that enqueues every launch from the host — same losses, same weights, same image-pool contents —
+with the pools' coin flips and Adam's step-dependent scalars living in device memory. Plus the two kernels that made the
+step capturable (gs_pool_query, gs_adam_step_dev) against the op-level oracle."""
+import random
+
+import pytest
+import torch
+
+from oracle.ops_ref import RefOps
+from tests.helpers import build_product_cyclegan, golden_inputs, load_golden_steps
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, c, n_steps):
+    random.seed(c["seed"])
+    out = []
+    for s in range(n_steps):
+        A, B = golden_inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        _, losses, visuals, metrics = model.get_loggable_data()
+        torch.cuda.synchronize()
+        out.append(({k: float(v.detach()) for k, v in losses.items() if v is not None},
+                    {k: float(v) for k, v in metrics.items() if v is not None},
+                    visuals["fake_B"].detach().float().cpu().clone()))
+        model.update_learning_rate()
+    return out
+
+
+def _pair(c, extra, n_steps):
+    eager = build_product_cyclegan(c, extra)
+    eager.step_graph_enabled = False
+    want = _run(eager, c, n_steps)
+    graphed = build_product_cyclegan(c, extra)
+    assert graphed.step_graph_enabled
+    got = _run(graphed, c, n_steps)
+    assert graphed._graph is not None, "the step was never captured"
+    return eager, graphed, want, got
+
+
+@pytest.mark.parametrize("pool_size,extra", [(3, ()), (50, ("train.gan.optimizer.lambda_identity=0.5",
+                                                           "train.gan.optimizer.proportion_ssim=0.84"))])
+def test_graph_replays_reproduce_eager_steps_with_frozen_weights(hip_ops, pool_size, extra):
+    """learning rate 0: every iteration's losses depend only on its inputs and the image pools' state, so replayed and
+    launch-by-launch iterations must agree tightly (no chaotic amplification of the split-K atomics' rounding order)"""
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    c["pool_size"] = pool_size          # 3: the pool is full after two iterations, swaps and same-slot draws follow
+    n_steps = 8
+    frozen = ("train.gan.optimizer.lr_G=0.0", "train.gan.optimizer.lr_D=0.0")
+    eager, graphed, want, got = _pair(c, tuple(extra) + frozen, n_steps)
+    for s in range(n_steps):
+        for k, v in want[s][0].items():
+            assert got[s][0][k] == pytest.approx(v, rel=1e-4, abs=1e-6), (s, k)
+        for k, v in want[s][1].items():
+            assert got[s][1][k] == pytest.approx(v, rel=1e-4, abs=1e-6), (s, k)
+        assert torch.equal(got[s][2], want[s][2]), s          # forward kernels are deterministic
+    for pa, pb in ((eager.fake_A_pool, graphed.fake_A_pool), (eager.fake_B_pool, graphed.fake_B_pool)):
+        assert pa.num_imgs == pb.num_imgs and torch.equal(pa.images, pb.images)
+
+
+def test_graph_replays_follow_the_eager_trajectory(hip_ops):
+    """With weights moving, the split-K atomics' rounding order makes two launch-by-launch runs drift apart too (Adam
+    turns it into +-lr steps from the third iteration on); a replayed run must stay within that run-to-run scatter."""
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    c["pool_size"] = 3
+    n_steps = 8
+    eager, graphed, want, got = _pair(c, (), n_steps)
+    again = build_product_cyclegan(c, ())
+    again.step_graph_enabled = False
+    noise = _run(again, c, n_steps)
+    for s in range(n_steps):
+        img_scatter = (noise[s][2] - want[s][2]).abs().max().item()
+        assert (got[s][2] - want[s][2]).abs().max().item() <= 3 * img_scatter + (1e-6 if s < 2 else 2e-2), s
+        for k, v in want[s][0].items():
+            scatter = abs(noise[s][0][k] - v)
+            assert abs(got[s][0][k] - v) <= 4 * scatter + (1e-5 if s < 2 else 2e-2) * abs(v) + 1e-6, (s, k)
+    for name in eager.networks:
+        a, b = eager.networks[name].master.detach(), graphed.networks[name].master.detach()
+        n = again.networks[name].master.detach()
+        assert (a - b).norm().item() <= 2 * (a - n).norm().item() + 1e-3 * a.norm().item(), name
+    for oa, ob in zip(eager.optimizers.values(), graphed.optimizers.values()):
+        assert [st["step"] for st in oa.state.values()] == [st["step"] for st in ob.state.values()] == \
+            [n_steps] * len(oa.state)
+        for group in ob.param_groups:          # the device scalars the replayed update reads are those of step n
+            for p in group["params"]:
+                want_h = torch.tensor([group["lr"], 0.5, 0.999, 1e-8, 1 - 0.5 ** n_steps,
+                                       (1 - 0.999 ** n_steps) ** 0.5], dtype=torch.float64).float()
+                assert torch.equal(ob.state[p]["hyper"].cpu(), want_h)
+
+
+def test_graph_falls_back_for_another_batch_size(hip_ops):
+    """a ragged last batch runs launch by launch and the next full batch replays again"""
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    model = build_product_cyclegan(c)
+    random.seed(1)
+    for s, batch in enumerate([2, 2, 2, 1, 2]):
+        A, B = golden_inputs(c, s)
+        model.set_input({"A": A[:batch], "B": B[:batch]})
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        assert model.visuals["fake_B"].shape[0] == batch
+        assert all(float(v.detach()) == float(v.detach()) for v in model.losses.values() if v is not None)
+    assert model._graph is not None
+    assert [st["step"] for st in model.optimizers["G"].state.values()] == [5, 5]
+
+
+def test_pool_query_kernel(hip_ops):
+    g = torch.Generator().manual_seed(0)
+    B, slots = 5, 4
+    pool0 = torch.rand((slots, 3, 8, 8), generator=g)
+    imgs = torch.rand((B, 3, 8, 8), generator=g)
+    code = torch.tensor([1, -1, 2 | 0x40000000, 2 | 0x40000000, 0 | 0x40000000], dtype=torch.int32)
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        pool, x, out = pool0.clone().to(dev), imgs.to(dev), torch.empty_like(imgs).to(dev)
+        ops.pool_query(pool, x, out, code.to(dev))
+        outs.append((pool.cpu(), out.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[1][1][3], imgs[2])       # the second draw of slot 2 returns the image the first one stored
+
+
+def test_adam_dev_matches_host_scalars(hip_ops):
+    g = torch.Generator().manual_seed(1)
+    n = 50_001
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-2
+    dev = hip_ops.device
+    res = []
+    for variant in ("host", "dev", "ref"):
+        ops = RefOps() if variant == "ref" else hip_ops
+        d = "cpu" if variant == "ref" else dev
+        p, gr, m, v = p0.clone().to(d), g0.clone().to(d), torch.zeros(n, device=d), torch.zeros(n, device=d)
+        for t in (1, 2, 3):
+            gr.copy_(g0.to(d) * t)
+            if variant == "host":
+                ops.adam_step(p, gr, m, v, 2e-4, 0.5, 0.999, 1e-8, t, grad_scale=0.5)
+            else:
+                hyper = torch.tensor([2e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** t, (1 - 0.999 ** t) ** 0.5],
+                                     dtype=torch.float64).float().to(d)
+                ops.adam_step_dev(p, gr, m, v, hyper, grad_scale=0.5)
+        res.append((p.cpu(), m.cpu(), v.cpu(), gr.cpu()))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), "device-scalar Adam must be bit-identical"
+    assert (res[1][0] - res[2][0]).abs().max().item() <= 1e-6 * res[2][0].abs().max().item()
+    assert res[1][3].abs().max().item() == 0.0
