@@ -3,11 +3,20 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace {
 char g_err[512] = "";
 void* g_zero = nullptr;      // 256-byte zero page: source of masked LDS-DMA lanes
-float* g_reduce_ws = nullptr;  // 1024 partials + 1 arrival counter for the loss reductions
+// Loss reductions: 1024 partials + 1 arrival counter per workspace. Launches on one stream are ordered and share a
+// workspace; launches on different streams may overlap (the discriminator pass runs beside the generators' backward),
+// so every stream that ever launched a reduction owns one of GS_WS_SLOTS workspaces.
+constexpr int GS_WS_SLOTS = 16;
+constexpr int GS_WS_FLOATS = 1040;
+float* g_reduce_ws = nullptr;
+void* g_ws_stream[GS_WS_SLOTS] = {};
+int g_ws_used = 0;
+std::mutex g_ws_mutex;
 }  // namespace
 
 void gs_set_error(const char* fmt, ...) {
@@ -17,7 +26,17 @@ void gs_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const void* gs_zero_page() { return g_zero; }
-float* gs_reduce_workspace() { return g_reduce_ws; }
+float* gs_reduce_workspace(void* stream) {
+  if (!g_reduce_ws) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  for (int i = 0; i < g_ws_used; ++i)
+    if (g_ws_stream[i] == stream) return g_reduce_ws + (size_t)i * GS_WS_FLOATS;
+  if (g_ws_used < GS_WS_SLOTS) {
+    g_ws_stream[g_ws_used] = stream;
+    return g_reduce_ws + (size_t)(g_ws_used++) * GS_WS_FLOATS;
+  }
+  return g_reduce_ws + (size_t)((reinterpret_cast<uintptr_t>(stream) >> 4) % GS_WS_SLOTS) * GS_WS_FLOATS;
+}
 
 extern "C" const char* gs_last_error(void) { return g_err; }
 
@@ -28,8 +47,8 @@ extern "C" int gs_init(int device) {
     GS_CHECK_HIP(hipMemset(g_zero, 0, 256));
   }
   if (!g_reduce_ws) {
-    GS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_reduce_ws), 1040 * sizeof(float)));
-    GS_CHECK_HIP(hipMemset(g_reduce_ws, 0, 1040 * sizeof(float)));
+    GS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_reduce_ws), GS_WS_SLOTS * GS_WS_FLOATS * sizeof(float)));
+    GS_CHECK_HIP(hipMemset(g_reduce_ws, 0, GS_WS_SLOTS * GS_WS_FLOATS * sizeof(float)));
   }
   hipDeviceProp_t prop;
   GS_CHECK_HIP(hipGetDeviceProperties(&prop, device));
@@ -40,5 +59,5 @@ extern "C" int gs_init(int device) {
 
 extern "C" void gs_shutdown(void) {
   if (g_zero) { (void)hipFree(g_zero); g_zero = nullptr; }
-  if (g_reduce_ws) { (void)hipFree(g_reduce_ws); g_reduce_ws = nullptr; }
+  if (g_reduce_ws) { (void)hipFree(g_reduce_ws); g_reduce_ws = nullptr; g_ws_used = 0; }
 }

@@ -5,7 +5,7 @@
 // utils/metrics/train_metrics.py:27-33 and SSIMLoss (nn/losses/utils/ssim.py:65-99).
 #include "common.hpp"
 
-float* gs_reduce_workspace();   // >= 1024 floats + 1 counter (api.hip)
+float* gs_reduce_workspace(void* stream);   // 1024 floats + 1 counter, one per launching stream (api.hip)
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
   v = wave_sum(v);
@@ -92,7 +92,7 @@ static inline unsigned red_blocks(long long n) {
 extern "C" int gs_mse_const(const float* x, int64_t n, float target, float* loss, float* grad,
                             const float* grad_scale, void* stream) {
   GS_REQUIRE(x && n > 0 && (loss || grad), "gs_mse_const: bad argument");
-  float* ws = gs_reduce_workspace();
+  float* ws = gs_reduce_workspace(stream);
   GS_REQUIRE(ws, "gs_mse_const: library not initialised (call gs_init)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (loss) hipLaunchKernelGGL(mse_const_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, ws, loss);
@@ -103,7 +103,7 @@ extern "C" int gs_mse_const(const float* x, int64_t n, float target, float* loss
 extern "C" int gs_l1(const float* a, const float* b, int64_t n, float* loss, float* grad_a, const float* grad_scale,
                      void* stream) {
   GS_REQUIRE(a && b && n > 0 && (loss || grad_a), "gs_l1: bad argument");
-  float* ws = gs_reduce_workspace();
+  float* ws = gs_reduce_workspace(stream);
   GS_REQUIRE(ws, "gs_l1: library not initialised (call gs_init)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (loss) hipLaunchKernelGGL(l1_kernel, dim3(red_blocks(n)), dim3(256), 0, st, a, b, (long long)n, ws, loss);
@@ -113,7 +113,7 @@ extern "C" int gs_l1(const float* a, const float* b, int64_t n, float* loss, flo
 }
 extern "C" int gs_mean(const float* x, int64_t n, float* out, void* stream) {
   GS_REQUIRE(x && out && n > 0, "gs_mean: bad argument");
-  float* ws = gs_reduce_workspace();
+  float* ws = gs_reduce_workspace(stream);
   GS_REQUIRE(ws, "gs_mean: library not initialised (call gs_init)");
   hipLaunchKernelGGL(mean_kernel, dim3(red_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)n, ws, out);
   GS_CHECK_HIP(hipGetLastError());

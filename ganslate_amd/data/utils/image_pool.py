@@ -42,7 +42,9 @@ class ImagePool:
                 code.append(-1)
         self._pending = torch.tensor(code, dtype=torch.int32)
         if batch in self._codes:
-            self._codes[batch].copy_(self._pending)
+            dst = self._codes[batch]
+            # pinned + non_blocking: a pageable upload would make the host wait for everything enqueued so far
+            dst.copy_(self._pending.pin_memory() if dst.is_cuda else self._pending, non_blocking=True)
 
     def apply(self, images):
         images = images.detach().contiguous()

@@ -105,6 +105,38 @@ class BaseGAN(ABC):
         if self.is_train:
             self._init_step_graph()
 
+    # ---- second launch stream -------------------------------------------------------------
+    # The discriminators' update of an iteration only needs the forward pass' images and the discriminator weights the
+    # generator loss has already read, so its launches can run beside the generators' backward pass instead of after
+    # it: same arithmetic, same host order, another HIP stream. Recipes mark the point from which the side work may
+    # start (fork_side_work), wrap it (side_work) and join before the discriminator optimiser step.
+    def _side_stream_enabled(self):
+        from ..native.backend import get_ops
+        return (os.environ.get("GS_SIDE_STREAM", "1") != "0" and self.device.type == "cuda"
+                and getattr(get_ops(), "name", "") == "hip" and int(os.environ.get("WORLD_SIZE", 1)) == 1)
+
+    def fork_side_work(self):
+        """everything launched so far on the current stream happens-before the next side_work() block"""
+        if not self._side_stream_enabled():
+            return
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        self._fork_event = torch.cuda.Event()
+        self._fork_event.record()
+
+    def side_work(self):
+        import contextlib
+        if getattr(self, "_fork_event", None) is None:
+            return contextlib.nullcontext()
+        self._side_stream.wait_event(self._fork_event)
+        self._side_busy = True
+        return torch.cuda.stream(self._side_stream)
+
+    def join_side_work(self):
+        if getattr(self, "_side_busy", False):
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+            self._side_busy, self._fork_event = False, None
+
     # ---- captured training step -------------------------------------------------------------------------------
     def _init_step_graph(self):
         """Decide whether iterations run as graph replays. Off for data-parallel runs (the bucketed all-reduce is

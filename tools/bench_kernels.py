@@ -20,6 +20,10 @@ CASES = {
     "u1": (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 8, 64, 64),
     "stem": (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect"), 8, 256, 256),
     "out": (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect"), 8, 256, 256),
+    # the same boundary convs as the step runs them: W taps folded into channels (csrc/wfold.hip), 7 H taps left
+    "stemw": (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 8, 256, 256),
+    "outw": (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 8, 256, 256),
+    "u2": (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 8, 128, 128),
     "dc4": (ConvSpec("conv", 256, 512, 4, 1, 1), 8, 32, 32),
     # 3-D: Resnet3D residual conv at 128^3 / 4, Vnet3D coupling convs (halo-resident kernel)
     "rb3": (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),
