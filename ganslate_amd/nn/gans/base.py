@@ -14,7 +14,7 @@ from pathlib import Path
 
 import torch
 
-from ...utils import communication, io
+from ...utils import communication, io, streams
 from ...utils.builders import build_D, build_G
 from ...utils.metrics import TrainingMetrics
 from ..utils import get_scheduler
@@ -110,32 +110,41 @@ class BaseGAN(ABC):
     # generator loss has already read, so its launches can run beside the generators' backward pass instead of after
     # it: same arithmetic, same host order, another HIP stream. Recipes mark the point from which the side work may
     # start (fork_side_work), wrap it (side_work) and join before the discriminator optimiser step.
-    def _side_stream_enabled(self):
+    def _side_stream_enabled(self, name):
         from ..native.backend import get_ops
-        return (os.environ.get("GS_SIDE_STREAM", "1") != "0" and self.device.type == "cuda"
+        want = os.environ.get("GS_SIDE_STREAM", "1")        # "0": none, "1": all, or a comma list of names
+        return ((want == "1" or name in want.split(",")) and self.device.type == "cuda"
                 and getattr(get_ops(), "name", "") == "hip" and int(os.environ.get("WORLD_SIZE", 1)) == 1)
 
-    def fork_side_work(self):
-        """everything launched so far on the current stream happens-before the next side_work() block"""
-        if not self._side_stream_enabled():
+    def fork_side_work(self, name="D"):
+        """everything launched so far on the current stream happens-before the next side_work(name) block"""
+        if not self._side_stream_enabled(name):
             return
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        self._fork_event = torch.cuda.Event()
-        self._fork_event.record()
+        if not hasattr(self, "_side"):
+            self._side = {}
+        st = self._side.setdefault(name, {"stream": torch.cuda.Stream(device=self.device), "fork": None, "busy": False})
+        st["fork"] = streams.new_event()
+        st["fork"].record()
 
-    def side_work(self):
+    def side_work(self, name="D"):
         import contextlib
-        if getattr(self, "_fork_event", None) is None:
+        st = getattr(self, "_side", {}).get(name)
+        if st is None or st["fork"] is None:
             return contextlib.nullcontext()
-        self._side_stream.wait_event(self._fork_event)
-        self._side_busy = True
-        return torch.cuda.stream(self._side_stream)
+        st["stream"].wait_event(st["fork"])
+        st["busy"] = True
+        return torch.cuda.stream(st["stream"])
 
-    def join_side_work(self):
-        if getattr(self, "_side_busy", False):
-            torch.cuda.current_stream().wait_stream(self._side_stream)
-            self._side_busy, self._fork_event = False, None
+    def join_side_work(self, name="D", last=True):
+        """the current stream waits for the side stream. last=False keeps the fork alive: autograd runs the backward of
+        what was launched in side_work(name) on that stream again, and since the networks accumulate their parameter
+        gradients themselves (no AccumulateGrad leaves) the engine does not join it — the recipe joins once more after
+        its backward()."""
+        st = getattr(self, "_side", {}).get(name)
+        if st is not None and st["busy"]:
+            streams.wait_stream(torch.cuda.current_stream(), st["stream"])
+            if last:
+                st["busy"], st["fork"] = False, None
 
     # ---- captured training step -------------------------------------------------------------------------------
     def _init_step_graph(self):
@@ -208,10 +217,12 @@ class BaseGAN(ABC):
                 self._eager_step()
         except Exception as e:      # a recipe with a host-dependent launch sequence: stay eager, loudly
             self._graph_broken = True
+            streams.release_events()
             self._set_external_host_state(False)
             torch.cuda.synchronize()
             raise RuntimeError(f"{type(self).__name__}: the training step could not be captured into a hipGraph "
                                f"({e}); set GS_STEP_GRAPH=0 to run it launch by launch") from e
+        streams.release_events()
         self._graph, self._graph_shapes = graph, self._input_shapes()
         self._graph_out = (dict(self.visuals), dict(self.losses), dict(self.metrics))
         graph.replay()

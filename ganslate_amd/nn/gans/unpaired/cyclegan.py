@@ -85,15 +85,26 @@ class CycleGAN(BaseGAN):
         self.optimizers["D"].step()
 
     def forward(self):
+        """The two translation cycles A -> B -> A and B -> A -> B are independent until the losses: the second one is
+        launched on its own stream (BaseGAN.side_work; autograd then runs its backward there too). Host order, and
+        with it the autograd graph, is the reference's (cyclegan.py:109-124)."""
         real_A, real_B = self.visuals["real_A"], self.visuals["real_B"]
+        for net in (self.networks["G_AB"], self.networks["G_BA"]):
+            net.refresh_packs(real_A)          # weight packs are shared by both streams: refresh them before the fork
+            net.multi_stream_passes = True     # ... and their backward passes are ordered per network (NativeNet)
+        use_idt = self.criterion_G.is_using_identity()
+        idt_B, idt_A = None, None
+        self.fork_side_work("cycle_B")
         fake_B = self.networks["G_AB"](real_A)
         rec_A = self.networks["G_BA"](fake_B)
-        fake_A = self.networks["G_BA"](real_B)
-        rec_B = self.networks["G_AB"](fake_A)
-        idt_B, idt_A = None, None
-        if self.criterion_G.is_using_identity():
-            idt_B = self.networks["G_AB"](real_B)
+        with self.side_work("cycle_B"):
+            fake_A = self.networks["G_BA"](real_B)
+            rec_B = self.networks["G_AB"](fake_A)
+            if use_idt:
+                idt_B = self.networks["G_AB"](real_B)
+        if use_idt:
             idt_A = self.networks["G_BA"](real_A)
+        self.join_side_work("cycle_B", last=False)
         self.visuals.update({"fake_B": fake_B, "rec_A": rec_A, "idt_A": idt_A,
                              "fake_A": fake_A, "rec_B": rec_B, "idt_B": idt_B})
 
@@ -123,6 +134,7 @@ class CycleGAN(BaseGAN):
         self.losses.update(losses_G)
         combined_loss_G = sum(losses_G.values()) + self.losses["G_AB"] + self.losses["G_BA"]
         self.backward(loss=combined_loss_G, optimizer=self.optimizers["G"], loss_id=0)
+        self.join_side_work("cycle_B")      # the second cycle's backward ran on its own stream (see forward)
 
     def infer(self, input, direction="AB"):
         assert direction in ["AB", "BA"], "Specify which generator direction, AB or BA, to use."

@@ -23,6 +23,10 @@ from .backend import get_ops
 from .spec import ConvSpec, Lowered, lower
 
 
+import os
+_BWD_ORDER = os.environ.get("GS_BWD_ORDER", "1") != "0"
+
+
 @dataclass
 class Node:
     spec: ConvSpec
@@ -88,6 +92,7 @@ class NativeNet:
         self._reduced_buckets = set()
         self.grad_dirty = False
         self._deferred = {}          # node -> (wgrad desc, dense, gathered) held back for a merged launch
+        self.multi_stream_passes = False   # set by a recipe that runs passes of this network on several streams
 
     # ---- torch.nn.Module-like surface used by BaseGAN ----------------------------------------------------------
     def parameters(self):
@@ -185,6 +190,32 @@ class NativeNet:
 
     def mark_packs_dirty(self):
         self._packs_dirty = True
+
+    def refresh_packs(self, x):
+        """bring the bf16 packs for inputs shaped like x up to date now (on the current stream), so that passes launched
+        on several streams afterwards only read them"""
+        self._get_packs(*tuple(x.shape[2:]))
+
+    # Passes of one network that run on different streams (the two cycles of a CycleGAN step) accumulate into the same
+    # gradient buffer and hand operands to each other for merged weight-gradient launches: a backward pass starts after
+    # the previous backward pass of the SAME network has finished, whatever stream that ran on. Only networks a recipe
+    # marks (multi_stream_passes) pay for the events.
+    def _order_backward_begin(self):
+        if self.device.type == "cuda" and _BWD_ORDER and self.multi_stream_passes:
+            ev = getattr(self, "_bwd_done", None)
+            # An event from before a stream capture began (or from inside one that has ended) orders nothing here: the
+            # capture's own begin / end already does. A pass on the stream the previous one ran on is ordered by the
+            # stream itself (and a captured side stream waiting on its own event crashes hipStreamEndCapture, ROCm 7.2).
+            if ev is not None and ev[1] == torch.cuda.is_current_stream_capturing() and \
+                    ev[2] != torch.cuda.current_stream():
+                torch.cuda.current_stream().wait_event(ev[0])
+
+    def _order_backward_end(self):
+        if self.device.type == "cuda" and _BWD_ORDER and self.multi_stream_passes:
+            from ...utils.streams import new_event
+            ev = new_event()
+            ev.record()
+            self._bwd_done = (ev, torch.cuda.is_current_stream_capturing(), torch.cuda.current_stream())
 
     # ---- lowering / packs (per input size) -----------------------------------------------------------------------
     def _lowered(self, *sizes) -> List[Lowered]:
@@ -379,6 +410,9 @@ class NativeNet:
                     ops.wgrad(held[0], held[1], held[2], dw)      # other input size: cannot share a launch
                     held = None
                 if held is not None:
+                    if dev.type == "cuda":      # the other pass may have run (and allocated) on another stream
+                        held[1].record_stream(torch.cuda.current_stream())
+                        held[2].record_stream(torch.cuda.current_stream())
                     ops.wgrad(lw.wgrad, a_t, g_t, dw, pair=(held[1], held[2]))
                 elif more_passes and ops.can_merge_wgrad(lw.wgrad):
                     self._deferred[i] = (lw.wgrad, a_t, g_t)
@@ -523,7 +557,11 @@ class _TapFn(torch.autograd.Function):
                 inj[kind][node] = dense
             c = net.nodes[node].spec.cout
             dense.view(N, -1, src.shape[-1])[:, pid, :c] += g.to(dense.dtype)
+        if ctx.want_w:      # passes that write parameter gradients are ordered per network
+            net._order_backward_begin()
         gx = net._backward(s, None, ctx.need_x, ctx.want_w, start=ctx.stop, inj_x=inj["x"], inj_y=inj["y"])
+        if ctx.want_w:
+            net._order_backward_end()
         ctx.saved = None
         return gx, None, None, None, None
 
@@ -546,6 +584,12 @@ class _NetFn(torch.autograd.Function):
         net = ctx.net
         if ctx.want_w:
             net._fw_pending -= 1
+        if ctx.want_w:      # passes that write parameter gradients are ordered per network
+            net._order_backward_begin()
+        if g.is_cuda:           # the incoming gradient may come from another stream's allocator pool
+            g.record_stream(torch.cuda.current_stream())
         gx = net._backward(ctx.saved, g, ctx.need_x, ctx.want_w)
+        if ctx.want_w:
+            net._order_backward_end()
         ctx.saved = None
         return gx, None, None
