@@ -178,6 +178,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         communication.init_distributed()
+    elif os.environ.get("GS_FORCE_DDP") == "1":       # the data-parallel code path with a 1-rank RCCL group
+        os.environ.setdefault("LOCAL_RANK", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1)
     dev = torch.device(f"cuda:{local_rank}")
 
     torch.manual_seed(0)
@@ -334,7 +337,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

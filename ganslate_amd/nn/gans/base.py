@@ -28,6 +28,7 @@ class BaseGAN(ABC):
     # launches of a CycleGAN step cost the host ~20-25 ms to enqueue one by one but only ~15 ms to execute.
     graph_capturable = False
     input_visuals = ("real_A", "real_B")
+    side_stream_names = ()       # streams the recipe forks work onto (created up front, outside any capture)
 
     def __init__(self, conf):
         self.logger = logging.getLogger("ganslate_amd")
@@ -100,8 +101,8 @@ class BaseGAN(ABC):
                 raise ValueError("When inferring there should be only one network initialized - generator.")
         if self.conf[self.conf.mode].checkpointing.load_iter:
             self.load_networks(self.conf[self.conf.mode].checkpointing.load_iter)
-        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
-            self.parallelize_networks()
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1 or os.environ.get("GS_FORCE_DDP") == "1":
+            self.parallelize_networks()      # GS_FORCE_DDP: the data-parallel path with a 1-rank group (tests)
         if self.is_train:
             self._init_step_graph()
 
@@ -113,8 +114,12 @@ class BaseGAN(ABC):
     def _side_stream_enabled(self, name):
         from ..native.backend import get_ops
         want = os.environ.get("GS_SIDE_STREAM", "1")        # "0": none, "1": all, or a comma list of names
-        return ((want == "1" or name in want.split(",")) and self.device.type == "cuda"
-                and getattr(get_ops(), "name", "") == "hip" and int(os.environ.get("WORLD_SIZE", 1)) == 1)
+        if not ((want == "1" or name in want.split(",")) and self.device.type == "cuda"
+                and getattr(get_ops(), "name", "") == "hip"):
+            return False
+        # data parallel: only inside a captured step, where the gradient all-reduce happens between the graphs; a
+        # launch-by-launch iteration issues its bucketed all-reduces from inside backward and stays on one stream
+        return not self._data_parallel_nets() or torch.cuda.is_current_stream_capturing()
 
     def fork_side_work(self, name="D"):
         """everything launched so far on the current stream happens-before the next side_work(name) block"""
@@ -122,7 +127,9 @@ class BaseGAN(ABC):
             return
         if not hasattr(self, "_side"):
             self._side = {}
-        st = self._side.setdefault(name, {"stream": torch.cuda.Stream(device=self.device), "fork": None, "busy": False})
+        if name not in self._side:
+            self._side[name] = {"stream": torch.cuda.Stream(device=self.device), "fork": None, "busy": False}
+        st = self._side[name]
         st["fork"] = streams.new_event()
         st["fork"].record()
 
@@ -148,17 +155,23 @@ class BaseGAN(ABC):
 
     # ---- captured training step -------------------------------------------------------------------------------
     def _init_step_graph(self):
-        """Decide whether iterations run as graph replays. Off for data-parallel runs (the bucketed all-reduce is
-        issued from the host as gradients become ready), for backends without streams (the CPU test oracle) and with
-        GS_STEP_GRAPH=0."""
+        """Decide whether iterations run as graph replays. Off for backends without streams (the CPU test oracle) and
+        with GS_STEP_GRAPH=0. Data-parallel runs replay two graphs per iteration with the gradient all-reduce between
+        them (see _capture_step)."""
         from ..native.backend import get_ops
         self._graph, self._graph_shapes, self._graph_calls, self._graph_broken = None, None, 0, False
+        self._graph_update = None
         self.step_graph_enabled = (self.graph_capturable and os.environ.get("GS_STEP_GRAPH", "1") != "0"
-                                   and int(os.environ.get("WORLD_SIZE", 1)) == 1
                                    and getattr(get_ops(), "name", "") == "hip" and self.device.type == "cuda")
+        if self.device.type == "cuda":
+            self._side = {n: {"stream": torch.cuda.Stream(device=self.device), "fork": None, "busy": False}
+                          for n in self.side_stream_names}
         if self.step_graph_enabled:
             self._eager_set_input, self._eager_step = self.set_input, self.optimize_parameters
             self.set_input, self.optimize_parameters = self._graph_set_input, self._graph_step
+
+    def _data_parallel_nets(self):
+        return [net for net in self.networks.values() if getattr(net, "_dist", None) is not None]
 
     def _step_pools(self):
         """ImagePools in the order optimize_parameters queries them (their coin flips are drawn before a replay)"""
@@ -195,7 +208,7 @@ class BaseGAN(ABC):
         self._graph_calls += 1
         if self._graph is not None and self._input_shapes() == self._graph_shapes and self.step_graph_enabled:
             self._prepare_host_state()
-            self._graph.replay()
+            self._replay()
             self.visuals.update(self._graph_out[0]); self.losses.update(self._graph_out[1])
             self.metrics.update(self._graph_out[2])
             return
@@ -204,17 +217,47 @@ class BaseGAN(ABC):
         self._set_external_host_state(False)
         self._eager_step()
 
+    def _replay(self):
+        self._graph.replay()
+        if self._graph_update is not None:       # data parallel: sum the flat gradients, then the optimiser launches
+            import torch.distributed as dist
+            for net in self._reduced_nets:
+                dist.all_reduce(net.master.grad, op=dist.ReduceOp.SUM, group=net._dist)
+            self._graph_update.replay()
+
     def _capture_step(self):
-        """record this iteration's launches (capture does not execute them), then run it as the first replay"""
+        """Record this iteration's launches (capture does not execute them), then run it as the first replay.
+
+        Data-parallel runs: collectives stay outside the graphs. The optimisers' step() calls made by the recipe are held
+        back while the first graph records forward, backward and everything else; the flat gradient of every network is
+        then all-reduced launch by launch (one collective per network, RCCL's own stream), and a second graph holds the
+        held-back Adam launches (the 1/world factor is folded into them). Nothing in an iteration reads the updated
+        weights before its end, so moving the updates behind the last backward pass changes no arithmetic."""
         self._static_inputs = {n: self.visuals[n].clone() for n in self.input_visuals}
         self.visuals.update(self._static_inputs)
         self._set_external_host_state(True)
         self._prepare_host_state()
+        dp_nets = self._data_parallel_nets()
+        pending = [] if dp_nets else None
+        for optim in self.optimizers.values():
+            optim.deferred_to = pending
+        for net in dp_nets:
+            net.external_reduce = True
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph, update = torch.cuda.CUDAGraph(), None
         try:
-            with torch.cuda.graph(graph):
+            # data parallel: RCCL's watchdog thread may poll events of earlier collectives while this thread captures;
+            # only this thread's calls are policed then
+            mode = "thread_local" if dp_nets else "global"
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 self._eager_step()
+                for net in dp_nets:
+                    net.flush_deferred_wgrads()
+            if dp_nets:
+                update = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(update, capture_error_mode=mode):
+                    for optim in pending:
+                        optim.launch()
         except Exception as e:      # a recipe with a host-dependent launch sequence: stay eager, loudly
             self._graph_broken = True
             streams.release_events()
@@ -222,10 +265,16 @@ class BaseGAN(ABC):
             torch.cuda.synchronize()
             raise RuntimeError(f"{type(self).__name__}: the training step could not be captured into a hipGraph "
                                f"({e}); set GS_STEP_GRAPH=0 to run it launch by launch") from e
+        finally:
+            for optim in self.optimizers.values():
+                optim.deferred_to = None
+            for net in dp_nets:
+                net.external_reduce = False
         streams.release_events()
-        self._graph, self._graph_shapes = graph, self._input_shapes()
+        self._graph, self._graph_update, self._graph_shapes = graph, update, self._input_shapes()
+        self._reduced_nets = dp_nets
         self._graph_out = (dict(self.visuals), dict(self.losses), dict(self.metrics))
-        graph.replay()
+        self._replay()
 
     def backward(self, loss, optimizer, retain_graph=False, loss_id=0):
         loss.backward(retain_graph=retain_graph)

@@ -31,6 +31,7 @@ class CycleGANConfig(configs.base.BaseGANConfig):
 
 class CycleGAN(BaseGAN):
     graph_capturable = True      # fixed launch sequence: the pools' coin flips and Adam's scalars live in device memory
+    side_stream_names = ("cycle_B", "D")
 
     def __init__(self, conf):
         super().__init__(conf)

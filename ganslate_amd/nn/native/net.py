@@ -93,6 +93,7 @@ class NativeNet:
         self.grad_dirty = False
         self._deferred = {}          # node -> (wgrad desc, dense, gathered) held back for a merged launch
         self.multi_stream_passes = False   # set by a recipe that runs passes of this network on several streams
+        self.external_reduce = False       # data-parallel gradients are reduced by the caller (BaseGAN graph runner)
 
     # ---- torch.nn.Module-like surface used by BaseGAN ----------------------------------------------------------
     def parameters(self):
@@ -365,7 +366,7 @@ class NativeNet:
                 ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
             pending = (ga, 0, None, "reflect")
         skip: Dict[int, torch.Tensor] = {}
-        final_pass = want_w and self._dist is not None and self._fw_pending == 0
+        final_pass = want_w and self._dist is not None and self._fw_pending == 0 and not self.external_reduce
         # another recorded forward of this net still awaits its backward (G_AB(real_A) and G_AB(fake_A) in one step):
         # hold the weight gradients of mergeable layers back and issue both passes as one launch then
         more_passes = want_w and self._fw_pending > 0 and start is None
@@ -503,6 +504,10 @@ class NativeNet:
         self.flush_deferred_wgrads()
         if self._dist is None:
             return 1.0
+        if self.external_reduce:       # a captured step: the runner all-reduces the flat gradient between its graphs
+            import torch.distributed as dist
+            self._fw_pending = 0
+            return 1.0 / dist.get_world_size(self._dist)
         import torch.distributed as dist
         if self.grad_dirty:
             # buckets the last backward pass did not reach (partial encoder passes, custom recipes) go now

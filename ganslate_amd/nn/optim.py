@@ -15,6 +15,7 @@ class NativeAdam(torch.optim.Optimizer):
                 raise TypeError("NativeAdam only optimises the flat master parameters of NativeNet instances")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self.external_prepare = False
+        self.deferred_to = None
 
     def prepare(self):
         """Host side of one update: advance the step counters and upload the step-dependent scalars (learning rate from
@@ -40,9 +41,16 @@ class NativeAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        ops = get_ops()
+        if self.deferred_to is not None:     # a data-parallel captured step: the update is launched after the all-reduce
+            self.deferred_to.append(self)
+            return
         if not self.external_prepare:
             self.prepare()
+        self.launch()
+
+    @torch.no_grad()
+    def launch(self):
+        ops = get_ops()
         for group in self.param_groups:
             for p in group["params"]:
                 net = p._owner_net
