@@ -243,17 +243,24 @@ def main():
     if not args.no_kernel_timing:
         # HIP events around every launch of the dominant kernel (residual-block 3x3 conv, forward form) on the stream it
         # is launched on (torch's current stream). A replayed hipGraph cannot hold event records, so when the timed
-        # region ran as graph replays the events are taken in a few launch-by-launch steps of the same workload right
-        # after it (same kernels, same arguments); profiles/ holds the rocprofv3 average of the replayed launches.
+        # region ran as graph replays the events are taken in a few launch-by-launch, single-stream steps of the same
+        # workload right after it (same kernels, same arguments, no other stream sharing the chip — which is also how
+        # rocprofv3's kernel trace runs them; profiles/ holds its average for the same kernel).
         rb_taps, rb_border = (27, "replicate") if args.workload == "cyclegan3d" else (9, "reflect")
         timing = ops.enable_kernel_timing(lambda g: g.T == rb_taps and g.Ci == 256 and g.Co == 256 and g.si == 1
                                           and g.border == rb_border)
         if graphed:
             model.step_graph_enabled = False
+        side = os.environ.get("GS_SIDE_STREAM")
+        os.environ["GS_SIDE_STREAM"] = "0"       # one stream: a launch's duration is its own, not a share of the chip
         for _ in range(min(args.steps, 5)):
             step()
         torch.cuda.synchronize()
         ops.disable_kernel_timing()
+        if side is None:
+            del os.environ["GS_SIDE_STREAM"]
+        else:
+            os.environ["GS_SIDE_STREAM"] = side
         if graphed:
             model.step_graph_enabled = True
 
@@ -332,7 +339,7 @@ def main():
                                "kernel": "hconvw_kernel<9> (3x3 256->256 reflect conv, halo-resident, M=%d N=256 K=2304)"
                                          % (hw * args.batch),
                                "launches_timed": n, "avg_ms": round(ms, 4),
-                               "timed_in": "%d launch-by-launch steps right after the timed region%s"
+                               "timed_in": "%d launch-by-launch single-stream steps right after the timed region%s"
                                            % (min(args.steps, 5), " (which ran as hipGraph replays)" if graphed else "")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)

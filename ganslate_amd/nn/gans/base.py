@@ -21,7 +21,7 @@ from ..utils import get_scheduler
 
 
 class BaseGAN(ABC):
-    # ---- captured training step (no counterpart in the reference; DESIGN.md §5.3) ---------------------------
+    # ---- captured training step (no counterpart in the reference; DESIGN.md §4.8) ---------------------------
     # A recipe whose optimize_parameters enqueues the same launch sequence every iteration sets graph_capturable and
     # names the visuals that set_input fills. The second call of optimize_parameters is then captured into a hipGraph
     # (torch.cuda.CUDAGraph on the launch stream) and every later iteration is one graph launch: the ~500 kernel
@@ -106,7 +106,7 @@ class BaseGAN(ABC):
         if self.is_train:
             self._init_step_graph()
 
-    # ---- second launch stream (DESIGN.md §5.4) -------------------------------------------------------------
+    # ---- second launch stream (DESIGN.md §4.8) -------------------------------------------------------------
     # The discriminators' update of an iteration only needs the forward pass' images and the discriminator weights the
     # generator loss has already read, so its launches can run beside the generators' backward pass instead of after
     # it: same arithmetic, same host order, another HIP stream. Recipes mark the point from which the side work may

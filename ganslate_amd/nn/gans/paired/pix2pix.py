@@ -25,6 +25,7 @@ class Pix2PixConditionalGANConfig(configs.base.BaseGANConfig):
 
 class Pix2PixConditionalGAN(BaseGAN):
     graph_capturable = True      # fixed launch sequence, no image pool
+    side_stream_names = ("D",)
 
     def __init__(self, conf):
         super().__init__(conf)
@@ -58,13 +59,16 @@ class Pix2PixConditionalGAN(BaseGAN):
         # ------------------------ D ------------------------
         self.set_requires_grad(self.networks["D"], True)
         self.optimizers["D"].zero_grad(set_to_none=True)
-        self.backward_D()
-        self.metrics.update(self.training_metrics.compute_metrics_D("D", self.pred_real, self.pred_fake))
+        with self.side_work():       # launched beside the generator's backward pass (BaseGAN.fork_side_work)
+            self.backward_D()
+            self.metrics.update(self.training_metrics.compute_metrics_D("D", self.pred_real, self.pred_fake))
+        self.join_side_work()
         self.optimizers["D"].step()
 
     def backward_G(self):
         real_A, real_B, fake_B = self.visuals["real_A"], self.visuals["real_B"], self.visuals["fake_B"]
         pred = self.networks["D"](torch.cat([real_A, fake_B], dim=1))
+        self.fork_side_work()        # the discriminator's own update needs nothing that is launched after this point
         self.losses["G"] = self.criterion_adv(pred, target_is_real=True)
         self.losses["pix2pix"] = self.criterion_pix2pix(fake_B, real_B)
         combined_loss_G = self.losses["G"] + self.losses["pix2pix"]
