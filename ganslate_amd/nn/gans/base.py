@@ -233,6 +233,8 @@ class BaseGAN(ABC):
         then all-reduced launch by launch (one collective per network, RCCL's own stream), and a second graph holds the
         held-back Adam launches (the 1/world factor is folded into them). Nothing in an iteration reads the updated
         weights before its end, so moving the updates behind the last backward pass changes no arithmetic."""
+        self.logger.info("capturing the training step into a hipGraph (GS_STEP_GRAPH=0 runs it launch by launch, "
+                         "GS_SIDE_STREAM=0 on one stream)")
         self._static_inputs = {n: self.visuals[n].clone() for n in self.input_visuals}
         self.visuals.update(self._static_inputs)
         self._set_external_host_state(True)
