@@ -35,6 +35,12 @@ struct GConvK {
   unsigned char tap_h[GS_MAX_TAPS], tap_w[GS_MAX_TAPS];
   gs_gconv_fuse f;             // f.partial != nullptr: first pass of the consumer's InstanceNorm backward in the epilogue
   int fuse_slots;
+  // split-K (few output tiles, long K: the deep U-Net / PatchGAN-tail layers): workgroup (tile, sp) runs K-steps
+  // [sp*nk/splits, (sp+1)*nk/splits) and writes raw fp32 sums to partial[sp][output pixel][Co]; gconv_splitk_finalize
+  // adds them up and applies the usual epilogue
+  int splits;
+  float* partial;
+  long long split_stride;      // floats per split = N * Do*Ho*Wo * Co
   gs_gconv_desc d;
 };
 
@@ -67,6 +73,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
     b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
+  const int sp = b % p.splits;
+  b /= p.splits;
   const int nt = b % p.tiles_n;
   b /= p.tiles_n;
   const int mt = b % p.tiles_m;
@@ -121,7 +129,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   // shifted re-reads of an input chunk are back to back and hit L2; for Ci < 64 a K-step spans several taps
   // and the natural (tap, channel) order of the pack is kept. `issue` is always called with ks increasing by 1.
   const bool chunk_major = d.Ci >= 64;
-  int it_t = 0, it_c = 0;
+  const int nk = d.Kp >> 6;
+  const int ks_begin = (int)((long long)sp * nk / p.splits), ks_end = (int)((long long)(sp + 1) * nk / p.splits);
+  int it_t = ks_begin % d.T, it_c = ks_begin / d.T;     // (tap, chunk) of the first K-step (chunk-major order)
   auto issue = [&](int ks, int buf) {
     char* sb = smem + buf * STAGE;
     int q0;                                   // first 16-B k-group of this K-step inside a pack row
@@ -168,11 +178,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int fk = lane >> 4;             // k-chunk (8 bf16) inside a 32-deep MFMA step
 
   const int swz = lane & 7;             // == row & 7 for every fragment row of this lane
-  const int nk = d.Kp >> 6;
 
   __syncthreads();  // taps visible
   if constexpr (NSTAGE == 2) {
-    issue(0, 0);
+    issue(ks_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {
@@ -247,9 +256,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     }
     __syncthreads();
   } else if constexpr (NSTAGE == 2) {
-    for (int ks = 0; ks < nk; ++ks) {
-      const int cur = ks & 1;
-      if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const int cur = (ks - ks_begin) & 1;
+      if (ks + 1 < ks_end) issue(ks + 1, cur ^ 1);
       compute(cur);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's share)
       __syncthreads();
@@ -299,6 +308,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   }
 
   if constexpr (VARIANT == 8) { if (acc[0][0][0] == 12345.678f) p.out[0] = 1; return; }
+  if constexpr (NSTAGE == 2) {
+    if (p.splits > 1) {       // raw partial sums, dense [output pixel][Co] per split; the epilogue runs in the finalize pass
+      float* part = p.partial + (size_t)sp * p.split_stride;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int m = mt * BM + wm * (BM / WM) + j * 16 + frow;
+        if (m >= HWc) continue;
+        const int zi = div_small(m, d.Wc, p.rcp_wc);
+        const int jj = m - zi * d.Wc;
+        const int zz = div_small(zi, d.Hc, p.rcp_hc);
+        const int ii = zi - zz * d.Hc;
+        const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
+          if (co < d.Co) *reinterpret_cast<f32x4*>(part + opix * d.Co + co) = acc[i][j];
+        }
+      }
+      return;
+    }
+  }
   // this lane's bias values as TI vector loads issued back to back (one exposed latency; as 4*TI dependent scalar loads
   // inside the loops below they cost ~6 us per launch, and fetched before the K loop they cost registers in it)
   f32x4 bia[TI];
@@ -484,6 +514,76 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
 
 }
 
+// ---- split-K finalize: out = act(bias + sum_sp partial[sp]) as bf16, plus the partial statistics of the pixel tile ----
+struct SplitFinK {
+  const float* partial;
+  const float* bias;
+  char* out;
+  float* stats;
+  long long split_stride;
+  int splits, tiles_m, bm;
+  float rcp_wc, rcp_hc;
+  gs_gconv_desc d;
+};
+
+__global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitFinK p) {
+  const gs_gconv_desc& d = p.d;
+  const int cgroups = (d.Co + 63) / 64;
+  int b = blockIdx.x;
+  const int cg = b % cgroups;
+  b /= cgroups;
+  const int mt = b % p.tiles_m;
+  const int n = b / p.tiles_m;
+  const int tx = threadIdx.x & 15, py = threadIdx.x >> 4;
+  const int co = cg * 64 + tx * 4;
+  const bool cv = co < d.Co;
+  const int HWc = d.Dc * d.Hc * d.Wc;
+  f32x4 bia = (cv && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int pl = py; pl < p.bm; pl += 16) {
+    const int m = mt * p.bm + pl;
+    if (m >= HWc || !cv) continue;
+    const int zi = div_small(m, d.Wc, p.rcp_wc);
+    const int jj = m - zi * d.Wc;
+    const int zz = div_small(zi, d.Hc, p.rcp_hc);
+    const int ii = zi - zz * d.Hc;
+    const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+    f32x4 v = bia;
+    const float* src = p.partial + opix * d.Co + co;
+    for (int sp = 0; sp < p.splits; ++sp) {      // fixed order: reproducible
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)sp * p.split_stride);
+      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[r] += v[r];
+      s2[r] += v[r] * v[r];
+      o[r] = apply_act(v[r], d.act, d.slope);
+    }
+    uint2 pk;
+    pk.x = pack_bf2(o[0], o[1]);
+    pk.y = pack_bf2(o[2], o[3]);
+    *reinterpret_cast<uint2*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = pk;
+  }
+  if (d.stats_slots > 0) {
+    __shared__ float red[16][64][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[py][tx * 4 + r][0] = s1[r]; red[py][tx * 4 + r][1] = s2[r]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int c = cg * 64 + threadIdx.x;
+      if (c < d.Co) {
+        float a = 0.f, q = 0.f;
+        for (int y = 0; y < 16; ++y) { a += red[y][threadIdx.x][0]; q += red[y][threadIdx.x][1]; }
+        float* spt = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+        spt[c] = a;
+        spt[d.Co + c] = q;
+      }
+    }
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 namespace {
 struct TileCfg { int bm, bn; };
@@ -502,6 +602,23 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
   }
   return {128, 128};
 }
+// Split-K plan: layers whose output tiles cannot fill the chip but whose K loop is long (U-Net bottleneck convs with
+// 2..128 pixels and K = 16*1024, the PatchGAN 512->1 tail) are latency-bound on a handful of workgroups that each
+// stream megabytes of weights through a 2-stage ring; splitting K spreads that stream over all CUs. Returns 1 = no split.
+int splitk_plan(const gs_gconv_desc* d, const TileCfg& tc, bool fused) {
+  static const bool enabled = !(getenv("GS_SPLITK") && atoi(getenv("GS_SPLITK")) == 0);
+  if (!enabled || fused || d->accumulate || (tc.bm != 128 && tc.bn != 16)) return 1;
+  const long long pix = (long long)d->Dc * d->Hc * d->Wc;
+  const long long blocks = (long long)d->N * ((pix + tc.bm - 1) / tc.bm) * ((d->Co + tc.bn - 1) / tc.bn);
+  const int nk = d->Kp >> 6;
+  if (blocks > 64 || nk < 16) return 1;
+  long long splits = 256 / blocks;
+  if (splits > nk / 4) splits = nk / 4;
+  const long long out_floats = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
+  while (splits > 1 && splits * out_floats > (64LL << 20)) --splits;     // <= 256 MiB of partial sums
+  return splits < 2 ? 1 : (int)splits;
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
 int launch(const GConvK& k, int blocks, hipStream_t st) {
   const int lds = NSTAGE * (BM + BN) * 128 + GS_MAX_TAPS * 2 + BM * (k.nh + k.nw) * 2;
@@ -541,11 +658,25 @@ extern "C" int gs_gconv_stat_slots(const gs_gconv_desc* d) {
 }
 
 static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
-                              float* stats, const gs_gconv_fuse* fuse, void* stream);
+                              float* stats, const gs_gconv_fuse* fuse, float* ws, int64_t ws_floats, void* stream);
 
 extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                                 void* out, float* stats, void* stream) {
-  return gconv_forward_impl(d, in, w_pack, bias, out, stats, nullptr, stream);
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, nullptr, nullptr, 0, stream);
+}
+
+// floats of workspace gs_gconv_forward_ws wants for this launch (0: the launch does not split K)
+extern "C" int64_t gs_gconv_splitk_ws_floats(const gs_gconv_desc* d) {
+  if (!d || d->Dc < 1 || d->Hc < 1 || d->Wc < 1 || d->Co < 1) return 0;
+  if (gs_hconv_slots(d) || gs_hconvw_slots(d)) return 0;
+  const TileCfg tc = pick_tile(d);
+  const int splits = splitk_plan(d, tc, false);
+  return splits > 1 ? (int64_t)splits * d->N * d->Do * d->Ho * d->Wo * d->Co : 0;
+}
+
+extern "C" int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                                   void* out, float* stats, float* ws, int64_t ws_floats, void* stream) {
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, nullptr, ws, ws_floats, stream);
 }
 
 extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
@@ -557,11 +688,11 @@ extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, co
   const int fd = fuse->Dy > 1 ? fuse->fold : 0;
   GS_REQUIRE(d->Do == fuse->Dy + 2 * fd && d->Ho == fuse->Hy + 2 * fuse->fold && d->Wo == fuse->Wy + 2 * fuse->fold,
              "gs_gconv_forward_fused: output domain must be the norm's domain padded by `fold`");
-  return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, stream);
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, nullptr, 0, stream);
 }
 
 static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
-                              float* stats, const gs_gconv_fuse* fuse, void* stream) {
+                              float* stats, const gs_gconv_fuse* fuse, float* ws, int64_t ws_floats, void* stream) {
   GS_REQUIRE(d && in && w_pack && out, "gs_gconv_forward: null argument");
   GS_REQUIRE(d->Ci >= 8 && (d->Ci & 7) == 0 && ((d->Ci >> 3) & ((d->Ci >> 3) - 1)) == 0,
              "gs_gconv_forward: Ci=%d must be 8*2^k", d->Ci);
@@ -617,9 +748,29 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     k.tap_h[t] = (unsigned char)h;
     k.tap_w[t] = (unsigned char)w;
   }
-  const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
+  k.splits = 1;
+  k.partial = nullptr;
+  k.split_stride = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
+  if (ws) {
+    const int splits = splitk_plan(d, tc, fuse != nullptr);
+    if (splits > 1 && ws_floats >= (int64_t)splits * k.split_stride) { k.splits = splits; k.partial = ws; }
+  }
+  const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n * k.splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (k.splits > 1) {
+    int rc = tc.bn == 16 ? launch<256, 16, 8, 1, 2>(k, (int)blocks, st)
+           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
+    if (rc) return rc;
+    SplitFinK f;
+    f.partial = ws; f.bias = bias; f.out = static_cast<char*>(out); f.stats = stats;
+    f.split_stride = k.split_stride; f.splits = k.splits; f.tiles_m = k.tiles_m; f.bm = tc.bm;
+    f.rcp_wc = k.rcp_wc; f.rcp_hc = k.rcp_hc; f.d = *d;
+    const int fblocks = d->N * k.tiles_m * ((d->Co + 63) / 64);
+    hipLaunchKernelGGL(gconv_splitk_finalize_kernel, dim3(fblocks), dim3(256), 0, st, f);
+    GS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   // wave counts per tile picked by measurement (tools/bench_kernels.py): more waves hide the LDS-DMA issue latency
   if (tc.bn == 16) return launch<256, 16, 8, 1, 2>(k, (int)blocks, st);
   if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, (int)blocks, st);

@@ -72,6 +72,15 @@ class HipOps:
             return d
         return d[0]
 
+    def _splitk_floats(self, d) -> int:
+        """workspace floats the split-K form of this launch wants (0: no split); cached per descriptor"""
+        key = ("splitk", id(d))
+        n = self._desc_cache.get(key)
+        if n is None:
+            n = int(self.lib.gs_gconv_splitk_ws_floats(C.byref(d)))
+            self._desc_cache[key] = n
+        return n
+
     def tile_m(self, g: GConv, N: int) -> int:
         """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
         return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
@@ -112,8 +121,14 @@ class HipOps:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(self.lib.gs_gconv_forward(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _stream()),
-                "gs_gconv_forward")
+        nws = self._splitk_floats(d)
+        if nws:      # few output tiles, long K: split-K with a per-launch workspace (stream-safe through the allocator)
+            ws = torch.empty(nws, dtype=torch.float32, device=self.device)
+            L.check(self.lib.gs_gconv_forward_ws(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _ptr(ws),
+                                                 nws, _stream()), "gs_gconv_forward_ws")
+        else:
+            L.check(self.lib.gs_gconv_forward(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _stream()),
+                    "gs_gconv_forward")
         if timed:
             e1.record()
             self._timing_events.append((e0, e1))

@@ -102,7 +102,15 @@ int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack,
 typedef struct gs_gconv_fuse {
   const void* y;
   const float* mean_rstd;
-  const void* g2;              /* optional residual-join gradient on the unpadded domain */
+  const void* g2;              /* Same launch with a caller-owned fp32 workspace for split-K: layers with few output tiles and a long K loop (U-Net
+ * bottleneck convs, the PatchGAN 512->1 tail) run their K range split over the chip and a second pass sums the partial
+ * results and applies bias / statistics / activation. gs_gconv_splitk_ws_floats(d) is the workspace the launch wants
+ * (0: it does not split; gs_gconv_forward_ws then equals gs_gconv_forward). Results match gs_gconv_forward up to the
+ * fp32 summation order. */
+int64_t gs_gconv_splitk_ws_floats(const gs_gconv_desc* d);
+int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                        void* out, float* stats, float* ws, int64_t ws_floats, void* stream);
+/* optional residual-join gradient on the unpadded domain */
   float* partial;
   int32_t Dy, Hy, Wy;
   int32_t fold, fold_mode, act;

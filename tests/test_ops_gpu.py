@@ -27,6 +27,10 @@ CONV_CASES = [
     (ConvSpec("conv", 256, 512, 4, 1, 1), 2, 18, 18),                        # K7 stride-1 k4 (ragged 17x17)
     (ConvSpec("conv", 512, 1, 4, 1, 1), 2, 17, 17),                          # K7 last (Cout 1 -> 8)
     (ConvSpec("convT", 64, 32, 4, 2, 1, 0), 1, 8, 8),                        # U-Net style k4 convT
+    # U-Net bottleneck: a handful of pixels, K = 16 * 512 -> split-K launches (gs_gconv_forward_ws) + finalize pass
+    (ConvSpec("conv", 512, 512, 4, 2, 1), 1, 4, 8),
+    (ConvSpec("conv", 512, 512, 4, 2, 1), 1, 2, 4),                          # 1 x 2 output pixels
+    (ConvSpec("convT", 512, 256, 4, 2, 1, 0), 1, 2, 4),
     # BASELINE-size layers: these select the 8-wave 256x128 / 3-stage tile configurations
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),    # K3 at cfg2 size (M=32768)
     (ConvSpec("conv", 64, 128, 3, 2, 1), 4, 128, 128),                        # K2 d128
@@ -216,7 +220,8 @@ def test_dgrad_with_fused_norm_reduction(hip_ops, case, with_g2, act):
         ops.inorm_act_backward(gx, None if g2 is None else g2.to(dev), yd, mr, dy_own, None, **kw)
         sums = plan[1][:N * plan[0] * 3 * C].view(N, plan[0], 3, C).sum(1)
         res[name] = (gx, gx_plain, dy_pre, dy_own, sums)
-    assert torch.equal(res["hip"][0], res["hip"][1]), "fusion must not change the data gradient"
+    # same arithmetic up to the fp32 summation order (a small plain launch may run split-K, the fused one never does)
+    close_bf16(res["hip"][0], res["hip"][1].cpu(), "fusion must not change the data gradient")
     close_bf16(res["hip"][0], res["ref"][0], "dgrad")
     close_f32(res["hip"][4], res["ref"][4], "fused partial sums", rel=3e-3)
     close_bf16(res["hip"][2], res["hip"][3].cpu(), "dy from fused sums vs own reduction")
