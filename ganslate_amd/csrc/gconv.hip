@@ -526,21 +526,24 @@ struct SplitFinK {
   gs_gconv_desc d;
 };
 
+// Workgroup = (image, pixel tile, 16 output channels): 64 pixel lanes x 4 channel quads, so even a 2-pixel layer with 1024
+// channels spreads its 32-way sum over 64 workgroups (the first version used 64-channel groups and 16 pixel lanes: 583 us
+// for 128 pixels x 1024 channels x 32 splits on 32 workgroups).
 __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitFinK p) {
   const gs_gconv_desc& d = p.d;
-  const int cgroups = (d.Co + 63) / 64;
+  const int cgroups = (d.Co + 15) / 16;
   int b = blockIdx.x;
   const int cg = b % cgroups;
   b /= cgroups;
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
-  const int tx = threadIdx.x & 15, py = threadIdx.x >> 4;
-  const int co = cg * 64 + tx * 4;
+  const int tx = threadIdx.x & 3, py = threadIdx.x >> 2;     // channel quad, pixel lane (0..63)
+  const int co = cg * 16 + tx * 4;
   const bool cv = co < d.Co;
   const int HWc = d.Dc * d.Hc * d.Wc;
   f32x4 bia = (cv && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int pl = py; pl < p.bm; pl += 16) {
+  for (int pl = py; pl < p.bm; pl += 64) {
     const int m = mt * p.bm + pl;
     if (m >= HWc || !cv) continue;
     const int zi = div_small(m, d.Wc, p.rcp_wc);
@@ -567,15 +570,15 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
     *reinterpret_cast<uint2*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = pk;
   }
   if (d.stats_slots > 0) {
-    __shared__ float red[16][64][2];
+    __shared__ float red[64][16][2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { red[py][tx * 4 + r][0] = s1[r]; red[py][tx * 4 + r][1] = s2[r]; }
     __syncthreads();
-    if (threadIdx.x < 64) {
-      const int c = cg * 64 + threadIdx.x;
+    if (threadIdx.x < 16) {
+      const int c = cg * 16 + threadIdx.x;
       if (c < d.Co) {
         float a = 0.f, q = 0.f;
-        for (int y = 0; y < 16; ++y) { a += red[y][threadIdx.x][0]; q += red[y][threadIdx.x][1]; }
+        for (int y = 0; y < 64; ++y) { a += red[y][threadIdx.x][0]; q += red[y][threadIdx.x][1]; }
         float* spt = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
         spt[c] = a;
         spt[d.Co + c] = q;
@@ -612,7 +615,8 @@ int splitk_plan(const gs_gconv_desc* d, const TileCfg& tc, bool fused) {
   const long long blocks = (long long)d->N * ((pix + tc.bm - 1) / tc.bm) * ((d->Co + tc.bn - 1) / tc.bn);
   const int nk = d->Kp >> 6;
   if (blocks > 64 || nk < 16) return 1;
-  long long splits = 256 / blocks;
+  static const int target = getenv("GS_SPLITK_TARGET") ? atoi(getenv("GS_SPLITK_TARGET")) : 256;
+  long long splits = target / blocks;
   if (splits > nk / 4) splits = nk / 4;
   const long long out_floats = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
   while (splits > 1 && splits * out_floats > (64LL << 20)) --splits;     // <= 256 MiB of partial sums
@@ -766,7 +770,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     f.partial = ws; f.bias = bias; f.out = static_cast<char*>(out); f.stats = stats;
     f.split_stride = k.split_stride; f.splits = k.splits; f.tiles_m = k.tiles_m; f.bm = tc.bm;
     f.rcp_wc = k.rcp_wc; f.rcp_hc = k.rcp_hc; f.d = *d;
-    const int fblocks = d->N * k.tiles_m * ((d->Co + 63) / 64);
+    const int fblocks = d->N * k.tiles_m * ((d->Co + 15) / 16);
     hipLaunchKernelGGL(gconv_splitk_finalize_kernel, dim3(fblocks), dim3(256), 0, st, f);
     GS_CHECK_HIP(hipGetLastError());
     return 0;
