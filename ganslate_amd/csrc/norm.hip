@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
 extern "C" int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
                                  float* mean_rstd, void* stream) {
   GS_REQUIRE(partial && mean_rstd && N > 0 && slots > 0 && C > 0 && hw > 0, "gs_inorm_finalize: bad argument");
-  if (C < 128 && slots > 256)
+  if (slots > 256 && (long long)N * ((C + 15) / 16) < 128)      // few workgroups, long slot loops: 4x the workgroups
     hipLaunchKernelGGL((slot_sum_kernel<2, 4>), dim3((C + 3) / 4, N), dim3(256), 0, static_cast<hipStream_t>(stream),
                        partial, mean_rstd, slots, C, 1.0f / (float)hw, eps, (const float*)nullptr, (float*)nullptr);
   else
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
 // shared with norm_ex.hip
 int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, float inv_hw, const float* mean_rstd,
                         float* db, hipStream_t st) {
-  if (C < 128 && slots > 256)
+  if (slots > 256 && (long long)N * ((C + 15) / 16) < 128)      // few workgroups, long slot loops: 4x the workgroups
     hipLaunchKernelGGL((slot_sum_kernel<3, 4>), dim3((C + 3) / 4, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
                        mean_rstd, db);
   else

@@ -85,10 +85,13 @@ class HipOps:
         """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
         return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
-    def fused_norm_plan(self, g: GConv, N: int, C_: int):
+    def fused_norm_plan(self, g: GConv, N: int, C_: int, force: bool = False):
         """(slots, scratch) for fusing the reduction pass of the consumer's InstanceNorm backward into the data-gradient
         launch of class g, or None when this backend / layer shape does not fuse (narrow layers run on the halo kernel)"""
         if g.so != 1 or g.si != 1 or g.Co <= 64 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
+            return None
+        d = self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
+        if self._splitk_floats(d) and not force:   # few output tiles, long K: split-K wins over the fused epilogue
             return None
         tm = self.tile_m(g, N)
         slots = (g.pixels + tm - 1) // tm
