@@ -614,7 +614,8 @@ int splitk_plan(const gs_gconv_desc* d, const TileCfg& tc, bool fused) {
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)d->N * ((pix + tc.bm - 1) / tc.bm) * ((d->Co + tc.bn - 1) / tc.bn);
   const int nk = d->Kp >> 6;
-  if (blocks > 64 || nk < 16) return 1;
+  static const int max_blocks = getenv("GS_SPLITK_MAXB") ? atoi(getenv("GS_SPLITK_MAXB")) : 128;
+  if (blocks > max_blocks || nk < 16) return 1;
   static const int target = getenv("GS_SPLITK_TARGET") ? atoi(getenv("GS_SPLITK_TARGET")) : 256;
   long long splits = target / blocks;
   if (splits > nk / 4) splits = nk / 4;

@@ -31,11 +31,23 @@ __device__ __forceinline__ void finish_reduction(float partial, float* ws, float
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  if (last && threadIdx.x == 0) {
+  if (last) {
+    // all 256 threads of the last workgroup: thread t adds partials t, t+256, ... in index order, then a fixed-shape
+    // tree over the threads — the same association every run (one thread walking up to 1024 partials cost 90 us)
+    __shared__ double tree[256];
     double s = 0.0;
-    for (unsigned i = 0; i < gridDim.x; ++i) s += (double)__hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[0] = (float)(s * (double)scale);
-    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+      s += (double)__hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tree[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) tree[threadIdx.x] += tree[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out[0] = (float)(tree[0] * (double)scale);
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
