@@ -25,9 +25,11 @@ struct HConvWK {
   gs_gconv_desc d;
 };
 
-template <int T>
-__global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
-  constexpr int BM = 256, BN = 128, WM = 4, WN = 4, NW = 16;
+// NW = 16: waves as 4 x 4, 64 pixels x 32 channels each; NW = 8: 4 x 2, 64 x 64 each (a third fewer fragment reads per
+// MFMA — the loop is bound by LDS reads — for half the latency hiding)
+template <int T, int NW = 16>
+__global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
+  constexpr int BM = 256, BN = 128, WM = 4, WN = NW / 4;
   constexpr int WT = BN * 128;                   // weight stage: 128 rows x 64 k
   constexpr int HP = 160;                        // halo voxel pitch: 8 channel pieces of 16 B + 2 pad pieces. 40 banks: the
                                                  // 16 lanes of every ds_read_b128 lane group land on 16 distinct 4-bank
@@ -35,9 +37,11 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   constexpr int HPIECES = 18 * 18 * 10;          // 3240
   constexpr int HINSTR = (HPIECES + 63) / 64;    // 51 wave-instructions of 64 pieces
   constexpr int HBUF = HINSTR * 1024;            // 52224 B per buffer
-  constexpr int HPW = 4;                         // halo DMA instructions per wave per chunk (uniform: surplus ones
+  constexpr int HPW = (HINSTR + NW - 1) / NW;    // halo DMA instructions per wave per chunk (uniform: surplus ones
                                                  // copy the zero page into a 1-KiB sink so vmcnt counts stay equal)
-  constexpr int TI = 2, TJ = 4;
+  constexpr int WPI = 16 / NW;                   // weight DMA instructions per wave per K-step (8 rows each)
+  constexpr int TI = BN / WN / 16, TJ = 4;
+  constexpr int CWV = TI * 16;                   // output channels per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wring = smem;                            // 3 x 16 KiB
   char* hbuf = smem + 3 * WT;                    // 2 x 51 KiB
@@ -85,13 +89,19 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   // ---- weight stage: one LDS-DMA instruction per wave (128 rows x 8 pieces), rows swizzled like gconv_kernel ----
   const int lrow = lane >> 3;
   const int wchunk = (lane & 7) ^ lrow;
-  const int wco = nt * BN + wave * 8 + lrow;
-  const bool wv = wco < d.w_rows;
-  const char* wsrc = wv ? p.w + ((size_t)wco * d.Kp + wchunk * 8) * 2 : p.zero;
-  const int winc = wv ? 16 : 0;                  // bytes per 8-k piece step
+  const char* wsrc[WPI];
+  int winc[WPI];                                 // bytes per 8-k piece step
+#pragma unroll
+  for (int i = 0; i < WPI; ++i) {
+    const int wco = nt * BN + (wave * WPI + i) * 8 + lrow;
+    const bool wv = wco < d.w_rows;
+    wsrc[i] = wv ? p.w + ((size_t)wco * d.Kp + wchunk * 8) * 2 : p.zero;
+    winc[i] = wv ? 16 : 0;
+  }
   auto issue_w = [&](int c, int t, int buf) {
     const int q0 = (t * (d.Ci >> 3)) + c * 8;    // first 8-k piece of this K-step inside a pack row (tap-major pack)
-    glds16(wsrc + (size_t)q0 * winc, wring + buf * WT + wave * 1024);
+#pragma unroll
+    for (int i = 0; i < WPI; ++i) glds16(wsrc[i] + (size_t)q0 * winc[i], wring + buf * WT + (wave * WPI + i) * 1024);
   };
 
   const int wm = wave / WN, wn = wave % WN;
@@ -135,19 +145,19 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   for (int s0 = 0; s0 < 3; ++s0)
     if (s0 < nk) { int c0, t0; ct_of(s0, c0, t0); issue_w(c0, t0, s0); }
   // halo 0 (and, in order, halo 1) and weights 0 landed; weights 1, 2 may still fly
-  if (nk >= 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (nk == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPI) : "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   bf16x8 wA[TI], xA[TJ], wB[TI], xB[TJ];
-  load_frags(wring + (wn * 32 + frow) * 128, hbuf + tb[0], 0, wA, xA);
+  load_frags(wring + (wn * CWV + frow) * 128, hbuf + tb[0], 0, wA, xA);
   int stage = 0;
   for (int c = 0; c < p.chunks; ++c) {
     const char* hb = hbuf + (c & 1) * HBUF;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int ks = c * T + t;
-      const char* wb = wring + stage * WT + (wn * 32 + frow) * 128;
+      const char* wb = wring + stage * WT + (wn * CWV + frow) * 128;
       load_frags(wb, hb + tb[t], 1, wB, xB);
       __builtin_amdgcn_sched_barrier(0);
       mma(wA, xA);
@@ -155,13 +165,13 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       if (ks + 1 < nk) {
         // weights ks+1 landed, this wave's reads of slot `stage` (and, at t == T-1, of this chunk's halo) returned
         if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (t == 0 && c >= 1 && c + 1 < p.chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(HPW + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else if (t == 0 && c >= 1 && c + 1 < p.chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(HPW + WPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPI) : "memory");
         __builtin_amdgcn_s_barrier();
         if (t == T - 1 && c + 2 < p.chunks) issue_halo(c + 2, c & 1);
         if (ks + 3 < nk) { int c3, t3; ct_of(ks + 3, c3, t3); issue_w(c3, t3, stage); }
         const int nstage = stage == 2 ? 0 : stage + 1;
-        const char* nwb = wring + nstage * WT + (wn * 32 + frow) * 128;
+        const char* nwb = wring + nstage * WT + (wn * CWV + frow) * 128;
         const char* nxb = (t == T - 1) ? hbuf + ((c + 1) & 1) * HBUF + tb[0] : hb + tb[t + 1 < T ? t + 1 : 0];
         load_frags(nwb, nxb, 0, wA, xA);
         stage = nstage;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   f32x4 bia[TI];                                // loaded after the loop: inside it they would spill (128-VGPR cap)
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
-    const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
+    const int co = nt * BN + wn * CWV + i * 16 + fk * 4;
     bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
-  constexpr int CW = 32, PW = 64, SROW = CW * 2 + 16;
+  constexpr int CW = CWV, PW = 64, SROW = CW * 2 + 16;
   constexpr int RED_BYTES = WM * BN * 2 * 4;
   char* slab = smem + ((RED_BYTES + 255) / 256) * 256 + wave * (PW * SROW);
 #pragma unroll
@@ -300,14 +310,20 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.chunks = d->Ci / 64;
   k.d = *d;
   const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
+  static const int nw = getenv("GS_HCONVW_NW") ? atoi(getenv("GS_HCONVW_NW")) : 16;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 16>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
   *handled = 1;
-  hipLaunchKernelGGL((hconvw_kernel<9>), dim3((unsigned)blocks), dim3(1024), lds, static_cast<hipStream_t>(stream), k);
+  if (nw == 8)
+    hipLaunchKernelGGL((hconvw_kernel<9, 8>), dim3((unsigned)blocks), dim3(512), lds, static_cast<hipStream_t>(stream), k);
+  else
+    hipLaunchKernelGGL((hconvw_kernel<9, 16>), dim3((unsigned)blocks), dim3(1024), lds, static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
