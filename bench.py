@@ -23,6 +23,7 @@ sys.path.insert(0, str(ROOT))
 # algorithmic work (BASELINE.md §3 / SURVEY.md §8d): conv MACs x 2 of one CycleGAN step per image pair
 GFLOP_PER_IMAGE = 1289.9
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+HCONVW_HBM_BYTES = 43.7e6    # measured, see profiles/r01_hconvw_hbm_pmc.txt
 
 
 def make_pix2pix_conf(batch, n_iters):
@@ -335,7 +336,12 @@ def main():
             flop = 2.0 * hw * args.batch * 256 * 2304           # 2*M*N*K of one launch
             tf = flop / (ms * 1e-3) / 1e12 if n else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                               # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (bench.py
+                               # cannot run the profiler on itself): profiles/r01_hconvw_hbm_pmc.txt
+                               "traffic": HCONVW_HBM_BYTES if (args.batch == 8 and args.size == 256) else None,
+                               "traffic_source": "profiles/r01_hconvw_hbm_pmc.txt (2 x FETCH_SIZE + WRITE_SIZE, separate "
+                                                 "rocprofv3 --pmc passes; algorithmic 34.8e6)",
                                "kernel": "hconvw_kernel<9> (3x3 256->256 reflect conv, halo-resident, M=%d N=256 K=2304)"
                                          % (hw * args.batch),
                                "launches_timed": n, "avg_ms": round(ms, 4),
