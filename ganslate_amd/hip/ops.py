@@ -367,6 +367,11 @@ class HipOps:
         L.check(self.lib.gs_repack_bf16(_ptr(master), _ptr(index), _ptr(pack), pack.numel(), _stream()),
                 "gs_repack_bf16")
 
+    def repack_tiled(self, master, index, pack, rows, kp):
+        """one [rows][kp] pack segment whose master indices run along the rows (see NativeNet._get_packs)"""
+        L.check(self.lib.gs_repack_bf16_tiled(_ptr(master), _ptr(index), _ptr(pack), rows, kp, _stream()),
+                "gs_repack_bf16_tiled")
+
     def ssim_distance_backward(self, x, y, grad_y, grad_scale=None):
         NC = x.numel() // (x.shape[-1] * x.shape[-2])
         H, W = x.shape[-2], x.shape[-1]

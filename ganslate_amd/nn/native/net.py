@@ -230,6 +230,33 @@ class NativeNet:
             self._low_cache[key] = lows
         return self._low_cache[key]
 
+    @staticmethod
+    def _repack_plan(lows, idx, offs, which, min_tiled=1 << 20):
+        """[(start, numel, rows, kp)] covering a network's pack: rows > 0 marks a [rows][kp] class segment whose master
+        indices are consecutive along the ROWS (the transposed packs: data-gradient pack of a conv, forward pack of a
+        transposed conv) and that is large enough for the tiled refresh to pay; everything else is merged into runs for
+        the element-wise kernel (rows = 0)."""
+        plan, run_start, pos = [], 0, 0
+        for i, lw in enumerate(lows):
+            flat = idx[i].reshape(-1)
+            for g in getattr(lw, which):
+                start, n = g.pack_offset, g.w_rows * g.Kp
+                tiled = False
+                if n >= min_tiled and g.w_rows >= 64:
+                    t = flat[start:start + n].reshape(g.w_rows, g.Kp)[:64, :256]
+                    ok = (t[1:] >= 0) & (t[:-1] >= 0)
+                    tiled = bool(ok.any()) and float(((t[1:] == t[:-1] + 1) & ok).sum()) > 0.9 * float(ok.sum())
+                if tiled:
+                    a = offs[i] + start
+                    if a > run_start:
+                        plan.append((run_start, a - run_start, 0, 0))
+                    plan.append((a, n, g.w_rows, g.Kp))
+                    run_start = a + n
+            pos = offs[i] + flat.size
+        if pos > run_start:
+            plan.append((run_start, pos - run_start, 0, 0))
+        return plan
+
     def _get_packs(self, *sizes):
         """bf16 packs are size-independent except for the parity-class split, which only depends on the spec;
         one pack set per input-size key keeps the bookkeeping trivial (a net sees one or two sizes in practice)."""
@@ -245,6 +272,8 @@ class NativeNet:
                 f_idx.append(fi); d_idx.append(di); f_off.append(fo); d_off.append(do)
                 fo += fi.size; do += di.size
             pk = {
+                "f_plan": self._repack_plan(lows, f_idx, f_off, "fwd"),
+                "d_plan": self._repack_plan(lows, d_idx, d_off, "dgrad"),
                 "f_index": torch.from_numpy(np.concatenate(f_idx).astype(np.int32)).to(self.device),
                 "d_index": torch.from_numpy(np.concatenate(d_idx).astype(np.int32)).to(self.device),
                 "f_off": f_off, "d_off": d_off,
@@ -260,8 +289,13 @@ class NativeNet:
             self._packs_dirty = False
         if not pk["fresh"]:
             m = self.master.detach()
-            self.ops.repack(m, pk["f_index"], pk["fpack"][:pk["f_index"].numel()])
-            self.ops.repack(m, pk["d_index"], pk["dpack"][:pk["d_index"].numel()])
+            for which in ("f", "d"):
+                index, pack = pk[which + "_index"], pk[which + "pack"]
+                for start, n, rows, kp in pk[which + "_plan"]:
+                    if rows:         # a large transposed segment: tiled through LDS
+                        self.ops.repack_tiled(m, index[start:start + n], pack[start:start + n], rows, kp)
+                    else:
+                        self.ops.repack(m, index[start:start + n], pack[start:start + n])
             pk["fresh"] = True
         return pk
 

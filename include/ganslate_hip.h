@@ -277,6 +277,10 @@ int gs_pool_query(void* pool, const void* images, void* out, const int32_t* code
 /* pack[e] = bf16(master[index[e]]) (index < 0 -> 0): refresh the bf16 forward/dgrad weight packs */
 int gs_repack_bf16(const float* master, const int32_t* index, void* pack, int64_t n, void* stream);
 
+/* Same refresh for one [rows][kp] pack segment whose master indices run along the rows (transposed packs): 64 x 64
+ * tiles through LDS so that both the master reads and the pack writes are contiguous. Results are identical. */
+int gs_repack_bf16_tiled(const float* master, const int32_t* index, void* pack, int32_t rows, int32_t kp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -480,6 +480,10 @@ class RefOps:
         vals = master.reshape(-1)[idx.clamp_min(0)]
         pack.copy_(torch.where(idx >= 0, vals, torch.zeros_like(vals)).to(pack.dtype))
 
+    def repack_tiled(self, master, index, pack, rows, kp):
+        """same refresh for one [rows][kp] segment (the HIP side only changes the access order)"""
+        self.repack(master, index, pack)
+
 
 def ssim_distance(X, Y):
     """Restatement of SSIMLoss.forward (ganslate/nn/losses/utils/ssim.py:65-99) on inputs in [-1, 1]

@@ -571,3 +571,28 @@ def test_norm_ex_dual_activation_slices_dropout(hip_ops, shape, norm, drop_p):
     if drop_p > 0:
         kept = (outs[1][0].float().cpu() != 0).float().mean().item()
         assert 0.4 < kept < 0.6, kept
+
+
+def test_tiled_repack_matches_elementwise(hip_ops):
+    """NativeNet refreshes large transposed pack segments (data-gradient pack of a conv, forward pack of a transposed
+    conv) with gs_repack_bf16_tiled: the packs must be bit-identical to the element-wise refresh of the whole pack"""
+    from ganslate_amd.nn.native.net import NativeNet, Node
+    nodes = [Node(ConvSpec("conv", 8, 512, 4, 2, 1), norm=True, act="lrelu", name="a"),
+             Node(ConvSpec("conv", 512, 512, 4, 2, 1), norm=True, act="relu", name="b"),
+             Node(ConvSpec("convT", 512, 512, 4, 2, 1, 0), norm=True, act="relu", name="c"),
+             Node(ConvSpec("convT", 512, 8, 4, 2, 1, 0), norm=False, act="none", name="d")]
+    net = NativeNet(nodes, 8, 8, ops=hip_ops)
+    torch.manual_seed(3)
+    net.init_weights("normal", 0.02)
+    x = torch.zeros(1, 8, 16, 16, device=hip_ops.device)
+    net.refresh_packs(x)
+    pk = net._packs[(16, 16)]
+    assert any(rows for _, _, rows, _ in pk["f_plan"]) and any(rows for _, _, rows, _ in pk["d_plan"])
+    for which in ("f", "d"):
+        plan = pk[which + "_plan"]
+        n = pk[which + "_index"].numel()
+        assert plan[0][0] == 0 and plan[-1][0] + plan[-1][1] == n
+        assert all(a[0] + a[1] == b[0] for a, b in zip(plan, plan[1:]))          # contiguous cover
+        ref = torch.empty(n, dtype=torch.bfloat16, device=hip_ops.device)
+        hip_ops.repack(net.master.detach(), pk[which + "_index"], ref)
+        assert torch.equal(ref, pk[which + "pack"][:n]), which
