@@ -175,7 +175,7 @@ __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const
           for (int b = 0; b < fw.cnt; ++b) add_bf8(f, gpad_n[((size_t)fh.at(a) * Wp + fw.at(b)) * C8 + c8]);
       }
     } else if constexpr (FM == 2) {
-      const int iz = zi / H, ih = zi - iz * H;
+      const int iz = div_small(zi, H, 1.0f / (float)H), ih = zi - iz * H;
       const FoldIdx fd = fold_sources(iz, D, fold);
       const FoldIdx fh = fold_sources(ih, H, fold);
       const FoldIdx fw = fold_sources(iw, W, fold);
@@ -184,14 +184,21 @@ __device__ __forceinline__ void load_folded(float* f, const uint4* gpad_n, const
           for (int b = 0; b < fw.cnt; ++b)
             add_bf8(f, gpad_n[(((size_t)fd.at(c) * Hp + fh.at(a)) * Wp + fw.at(b)) * C8 + c8]);
     } else {                                            // replicate (nn.ReplicationPad3d)
-      const int iz = zi / H, ih = zi - iz * H;
-      int d0, d1, h0, h1, w0, w1;
-      fold_range(iz, D, D > 1 ? fold : 0, d0, d1);
-      fold_range(ih, H, fold, h0, h1);
-      fold_range(iw, W, fold, w0, w1);
-      for (int c = d0; c <= d1; ++c)
-        for (int a = h0; a <= h1; ++a)
-          for (int b = w0; b <= w1; ++b) add_bf8(f, gpad_n[(((size_t)c * Hp + a) * Wp + b) * C8 + c8]);
+      const int iz = div_small(zi, H, 1.0f / (float)H), ih = zi - iz * H;
+      const int fd = D > 1 ? fold : 0;
+      // only the first and last voxel of an axis collect the replicated border: everything else is one load
+      const bool plain = (D == 1 || (iz > 0 && iz < D - 1)) && ih > 0 && ih < H - 1 && iw > 0 && iw < W - 1;
+      if (plain) {
+        add_bf8(f, gpad_n[(((size_t)(iz + fd) * Hp + (ih + fold)) * Wp + (iw + fold)) * C8 + c8]);
+      } else {
+        int d0, d1, h0, h1, w0, w1;
+        fold_range(iz, D, fd, d0, d1);
+        fold_range(ih, H, fold, h0, h1);
+        fold_range(iw, W, fold, w0, w1);
+        for (int c = d0; c <= d1; ++c)
+          for (int a = h0; a <= h1; ++a)
+            for (int b = w0; b <= w1; ++b) add_bf8(f, gpad_n[(((size_t)c * Hp + a) * Wp + b) * C8 + c8]);
+      }
     }
   }
   if (g2_n) add_bf8(f, g2_n[(size_t)px * C8 + c8]);

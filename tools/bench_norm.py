@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rotate", type=int, default=8, help="distinct tensor sets cycled through (cold-ish caches)")
     ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--vol", type=int, default=0, help="3-D cases at N=1, vol^3, C=256 (replicate fold) instead of the 2-D ones")
     args = ap.parse_args()
     ops = HipOps()
     dev = ops.device
@@ -55,6 +56,20 @@ def main():
         "bwd fold1+g2+gsum": (lambda i: ops.inorm_act_backward(gpad[i], g2[i], y[i], mr, dy[i], gsum[i], fold=1, act="none"), 5 * mb * 2 - 3 * mb),
         "bwd nofold": (lambda i: ops.inorm_act_backward(g0[i], None, y[i], mr, dy[i], None, fold=0, act="relu"), 5 * mb),
     }
+    if args.vol:       # the 3-D residual-block shape (Resnet3D at 128^3 / 4): replicate fold
+        V = args.vol
+        N = 1
+        y, dy = mk(N, V, V, V, C), mk(N, V, V, V, C)
+        gpad, g0 = mk(N, V + 2, V + 2, V + 2, C), mk(N, V, V, V, C)
+        part = torch.stack([y[0].float().sum((1, 2, 3)), (y[0].float() ** 2).sum((1, 2, 3))], 1).reshape(-1).contiguous()
+        mr = torch.empty(N * 2 * C, device=dev)
+        ops.inorm_finalize(part, N, 1, C, V ** 3, mr)
+        mb = N * V ** 3 * C * 2 / 1e6
+        cases = {
+            "3d bwd replicate fold": (lambda i: ops.inorm_act_backward(gpad[i], None, y[i], mr, dy[i], None, fold=1,
+                                                                       fold_mode="replicate", act="relu"), 5 * mb),
+            "3d bwd nofold": (lambda i: ops.inorm_act_backward(g0[i], None, y[i], mr, dy[i], None, fold=0, act="relu"), 5 * mb),
+        }
     for name, (fn, traffic_mb) in cases.items():
         us = timeit(lambda: fn(nxt()), args.iters)
         print(f"{name:22s} {us:8.1f} us   {traffic_mb / us * 1e3 / 1e3:6.2f} TB/s algorithmic ({traffic_mb:.0f} MB)", flush=True)
