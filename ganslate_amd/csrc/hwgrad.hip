@@ -394,8 +394,37 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
   *handled = 0;
   static const bool enabled = !(getenv("GS_HWGRAD") && atoi(getenv("GS_HWGRAD")) == 0);
   static const bool wide_enabled = !(getenv("GS_HWGRAD_WIDE") && atoi(getenv("GS_HWGRAD_WIDE")) == 0);
+  static const bool planes_enabled = !(getenv("GS_HWGRAD_PLANES") && atoi(getenv("GS_HWGRAD_PLANES")) == 0);
+  // 3x3x3 layers of volumes (Resnet3D residual convs): the 27 taps are three depth planes of 9, and a plane is the 2-D
+  // problem over (image, slice) pairs with the gathered operand read from slice z + dd (border rule applied in depth):
+  // three launches of the wide kernel, each writing its own 9 tap rows of dw
+  if (enabled && wide_enabled && planes_enabled && d->si == 1 && d->T == 27 && d->Da > 1 && d->P % 64 == 0 &&
+      d->Q % 64 == 0 && d->P >= 64 && d->Q >= 64) {
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; ++k)
+      for (int t = 0; t < 9; ++t) {
+        ok = ok && d->dd[9 * k + t] == d->dd[9 * k] && d->dh[9 * k + t] == d->dh[t] && d->dw_[9 * k + t] == d->dw_[t];
+      }
+    if (ok) {
+      for (int k = 0; k < 3; ++k) {
+        gs_wgrad_desc sub = *d;
+        sub.T = 9;
+        for (int t = 0; t < 9; ++t) { sub.dd[t] = d->dd[9 * k + t]; sub.dh[t] = d->dh[9 * k + t]; sub.dw_[t] = d->dw_[9 * k + t]; }
+        int h = 0;
+        if (int rc = gs_hwgrad_try2(&sub, a, g, a2, g2, dw + (size_t)9 * k * d->Q, stream, &h)) return rc;
+        if (!h) {
+          GS_REQUIRE(k == 0, "gs_wgrad: depth plane %d of a 27-tap layer was refused after plane 0 ran", k);
+          return 0;                                  // not eligible after all: the caller falls back for all 27 taps
+        }
+      }
+      *handled = 1;
+      return 0;
+    }
+  }
+  int dlo = 127, dhi = -128;
+  for (int t = 0; t < d->T; ++t) { if (d->dd[t] < dlo) dlo = d->dd[t]; if (d->dd[t] > dhi) dhi = d->dd[t]; }
   if (enabled && wide_enabled && d->si == 1 && d->T == 9 && d->P % 64 == 0 && d->Q % 64 == 0 && d->P >= 64 &&
-      d->Q >= 64 && d->Da == 1) {
+      d->Q >= 64 && (d->Da == 1 || (dlo == dhi && planes_enabled))) {
     int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
     for (int t = 0; t < d->T; ++t) {
       const int o[3] = {d->dd[t], d->dh[t], d->dw_[t]};
@@ -405,8 +434,8 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     k.BD = 1; k.BH = 16; k.BW = 16;
     k.HD = k.BD + hi[0] - lo[0]; k.HH = k.BH + hi[1] - lo[1]; k.HW = k.BW + hi[2] - lo[2];
     k.dmin = lo[0]; k.hmin = lo[1]; k.wmin = lo[2];
-    k.nbd = 1; k.nbh = (d->Ha + k.BH - 1) / k.BH; k.nbw = (d->Wa + k.BW - 1) / k.BW;
-    const long long nboxes1 = (long long)d->N * k.nbh * k.nbw;
+    k.nbd = d->Da; k.nbh = (d->Ha + k.BH - 1) / k.BH; k.nbw = (d->Wa + k.BW - 1) / k.BW;   // BD = 1: a box per slice
+    const long long nboxes1 = (long long)d->N * k.nbd * k.nbh * k.nbw;
     const long long nboxes = a2 ? 2 * nboxes1 : nboxes1;
     const long long hv = (long long)k.HD * k.HH * k.HW;
     const int hbytes = (int)((hv * 144 + 1023) / 1024 * 1024 + 1024);

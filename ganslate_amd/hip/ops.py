@@ -139,8 +139,14 @@ class HipOps:
     @staticmethod
     def can_merge_wgrad(w: WGrad) -> bool:
         """two backward passes of this layer can share one launch (the wide halo kernel's eligibility, hwgrad.hip)"""
-        return (w.T == 9 and w.si == 1 and w.P % 64 == 0 and w.Q % 64 == 0 and w.Da == 1
-                and os.environ.get("GS_WGRAD_PAIR", "1") != "0")
+        if w.si != 1 or w.P % 64 or w.Q % 64 or os.environ.get("GS_WGRAD_PAIR", "1") == "0":
+            return False
+        if w.T == 9 and w.Da == 1:
+            return True
+        # 3x3x3 layers of volumes run as three depth planes of the same kernel (hwgrad.hip)
+        return (w.T == 27 and w.Da > 1 and os.environ.get("GS_HWGRAD_PLANES", "1") != "0"
+                and all(w.dd[9 * k + t] == w.dd[9 * k] and w.dh[9 * k + t] == w.dh[t] and w.dw[9 * k + t] == w.dw[t]
+                        for k in range(3) for t in range(9)))
 
     def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
         key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)

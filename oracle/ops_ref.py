@@ -141,7 +141,13 @@ class RefOps:
 
     @staticmethod
     def can_merge_wgrad(w):
-        return w.T == 9 and w.si == 1 and w.P % 64 == 0 and w.Q % 64 == 0 and w.Da == 1
+        if w.si != 1 or w.P % 64 or w.Q % 64:
+            return False
+        if w.T == 9 and w.Da == 1:
+            return True
+        return (w.T == 27 and w.Da > 1 and
+                all(w.dd[9 * k + t] == w.dd[9 * k] and w.dh[9 * k + t] == w.dh[t] and w.dw[9 * k + t] == w.dw[t]
+                    for k in range(3) for t in range(9)))
 
     def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
         if pair is not None:
