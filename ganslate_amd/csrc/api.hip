@@ -35,7 +35,10 @@ float* gs_reduce_workspace(void* stream) {
     g_ws_stream[g_ws_used] = stream;
     return g_reduce_ws + (size_t)(g_ws_used++) * GS_WS_FLOATS;
   }
-  return g_reduce_ws + (size_t)((reinterpret_cast<uintptr_t>(stream) >> 4) % GS_WS_SLOTS) * GS_WS_FLOATS;
+  // more launching streams than workspaces: two live streams would share partial sums, so refuse instead of aliasing
+  gs_set_error("loss reductions were launched from more than %d streams of this process; raise GS_WS_SLOTS (api.hip)",
+               GS_WS_SLOTS);
+  return nullptr;
 }
 
 extern "C" const char* gs_last_error(void) { return g_err; }

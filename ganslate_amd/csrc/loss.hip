@@ -105,7 +105,7 @@ extern "C" int gs_mse_const(const float* x, int64_t n, float target, float* loss
                             const float* grad_scale, void* stream) {
   GS_REQUIRE(x && n > 0 && (loss || grad), "gs_mse_const: bad argument");
   float* ws = gs_reduce_workspace(stream);
-  GS_REQUIRE(ws, "gs_mse_const: library not initialised (call gs_init)");
+  if (!ws) { if (!gs_zero_page()) gs_set_error("gs_mse_const: library not initialised (call gs_init)"); return 2; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (loss) hipLaunchKernelGGL(mse_const_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, ws, loss);
   if (grad) hipLaunchKernelGGL(mse_const_grad_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, grad, grad_scale);
@@ -116,7 +116,7 @@ extern "C" int gs_l1(const float* a, const float* b, int64_t n, float* loss, flo
                      void* stream) {
   GS_REQUIRE(a && b && n > 0 && (loss || grad_a), "gs_l1: bad argument");
   float* ws = gs_reduce_workspace(stream);
-  GS_REQUIRE(ws, "gs_l1: library not initialised (call gs_init)");
+  if (!ws) { if (!gs_zero_page()) gs_set_error("gs_l1: library not initialised (call gs_init)"); return 2; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (loss) hipLaunchKernelGGL(l1_kernel, dim3(red_blocks(n)), dim3(256), 0, st, a, b, (long long)n, ws, loss);
   if (grad_a) hipLaunchKernelGGL(l1_grad_kernel, dim3(red_blocks(n)), dim3(256), 0, st, a, b, (long long)n, grad_a, grad_scale);
@@ -126,7 +126,7 @@ extern "C" int gs_l1(const float* a, const float* b, int64_t n, float* loss, flo
 extern "C" int gs_mean(const float* x, int64_t n, float* out, void* stream) {
   GS_REQUIRE(x && out && n > 0, "gs_mean: bad argument");
   float* ws = gs_reduce_workspace(stream);
-  GS_REQUIRE(ws, "gs_mean: library not initialised (call gs_init)");
+  if (!ws) { if (!gs_zero_page()) gs_set_error("gs_mean: library not initialised (call gs_init)"); return 2; }
   hipLaunchKernelGGL(mean_kernel, dim3(red_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)n, ws, out);
   GS_CHECK_HIP(hipGetLastError());
   return 0;

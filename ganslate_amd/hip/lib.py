@@ -56,8 +56,8 @@ _PROTOS = {
     "gs_gconv_stat_slots": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
-    "gs_gconv_splitk_ws_floats": (C.c_int64, [C.c_void_p]),
-    "gs_gconv_forward_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "gs_gconv_splitk_ws_floats": (C.c_int64, [C.POINTER(GConvDesc)]),
+    "gs_gconv_forward_ws": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_gconv_forward_fused": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.POINTER(GConvFuse), C.c_void_p]),

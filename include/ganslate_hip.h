@@ -102,15 +102,7 @@ int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack,
 typedef struct gs_gconv_fuse {
   const void* y;
   const float* mean_rstd;
-  const void* g2;              /* Same launch with a caller-owned fp32 workspace for split-K: layers with few output tiles and a long K loop (U-Net
- * bottleneck convs, the PatchGAN 512->1 tail) run their K range split over the chip and a second pass sums the partial
- * results and applies bias / statistics / activation. gs_gconv_splitk_ws_floats(d) is the workspace the launch wants
- * (0: it does not split; gs_gconv_forward_ws then equals gs_gconv_forward). Results match gs_gconv_forward up to the
- * fp32 summation order. */
-int64_t gs_gconv_splitk_ws_floats(const gs_gconv_desc* d);
-int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
-                        void* out, float* stats, float* ws, int64_t ws_floats, void* stream);
-/* optional residual-join gradient on the unpadded domain */
+  const void* g2;              /* optional residual-join gradient on the unpadded domain */
   float* partial;
   int32_t Dy, Hy, Wy;
   int32_t fold, fold_mode, act;
@@ -118,6 +110,14 @@ int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const void* w_pa
 } gs_gconv_fuse;
 int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
                            float* stats, const gs_gconv_fuse* fuse, void* stream);
+/* Same launch as gs_gconv_forward with a caller-owned fp32 workspace for split-K: layers with few output tiles and a
+ * long K loop (U-Net bottleneck convs unet2d.py:129-136, the PatchGAN 512->1 tail patchgan2d.py:62) run their K range
+ * split over the chip and a second pass sums the partial results and applies bias / statistics / activation.
+ * gs_gconv_splitk_ws_floats(d) is the workspace the launch wants (0: it does not split; gs_gconv_forward_ws then
+ * equals gs_gconv_forward). Results match gs_gconv_forward up to the fp32 summation order. */
+int64_t gs_gconv_splitk_ws_floats(const gs_gconv_desc* d);
+int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                        void* out, float* stats, float* ws, int64_t ws_floats, void* stream);
 int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream);
 /* dw += wgrad(a1, g1) + wgrad(a2, g2): two operand pairs of the same layer and shapes — the two backward passes a
  * generator sees per step (cyclegan.py:139-150: G_AB(real_A) and G_AB(fake_A)) — in one launch where possible */

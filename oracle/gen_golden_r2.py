@@ -1,0 +1,115 @@
+"""Round-2 golden vectors from the REAL reference (/root/reference through oracle/ref_stubs), build container only:
+
+    python -m oracle.gen_golden_r2 grads       # tests/golden/cyclegan_grads.json
+    python -m oracle.gen_golden_r2 envelope    # tests/golden/envelope.json
+
+* cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
+  after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
+  ("D_A") :154-189): per tensor the L2 norm and 8 strided samples, plus the first two iterations' losses. Cases:
+  `c64_default` (the 64x64 case of cyclegan_steps.json) and `cfg2_256_b8` (BASELINE configs[1] shape: 256x256, batch 8).
+* envelope.json — the reference against ITSELF: the same 100 iterations (64x64, batch 2, horse2zebra hyper-parameters)
+  run with 1 and with 8 intra-op threads. The arithmetic is identical, only the summation order of MKL-DNN's
+  reductions differs; the gap between the two curves is the floor no other implementation can be asked to beat and
+  the tolerances of the step tests are derived from it (tests/envelope.py).
+"""
+import json
+import random
+import subprocess
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "tests" / "golden"
+
+GRAD_CASES = {
+    "c64_default": dict(size=64, batch=2, steps=2, n_iters=20, n_iters_decay=10, pool_size=50,
+                        lambda_identity=0.0, proportion_ssim=0.0, seed=11),
+    # BASELINE configs[1]: horse2zebra CycleGAN ResNet-9 256x256 batch 8 (yaml hyper-parameters)
+    "cfg2_256_b8": dict(size=256, batch=8, steps=2, n_iters=100, n_iters_decay=100, pool_size=50,
+                        lambda_identity=0.0, proportion_ssim=0.0, seed=14),
+}
+ENVELOPE_CASE = dict(size=64, batch=2, steps=100, n_iters=50, n_iters_decay=50, pool_size=50,
+                     lambda_identity=0.0, proportion_ssim=0.0, seed=11)
+
+
+def _model(c):
+    from oracle import gen_golden as G          # imports the reference
+    from oracle.torch_ref import seeded_state_dict
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    model = G.CycleGAN(G.make_conf(c))
+    for k, (n, net) in enumerate(model.networks.items()):
+        net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+    random.seed(c["seed"])
+    return model, G.inputs
+
+
+def _record(model):
+    lrs, losses, visuals, metrics = model.get_loggable_data()
+    return {"lrs": {k: float(v) for k, v in lrs.items()},
+            "losses": {k: float(v) for k, v in losses.items() if v is not None},
+            "metrics": {k: float(v) for k, v in metrics.items() if v is not None}}
+
+
+def grad_case(name, c):
+    model, inputs = _model(c)
+    rec, grads = [], None
+    for s in range(c["steps"]):
+        A, B = inputs(c, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        rec.append(_record(model))
+        if s == 0:
+            grads = {}
+            for net_name, net in model.networks.items():
+                per = {}
+                for n, p in net.named_parameters():
+                    if n.startswith("encoder."):      # Resnet2D registers the same tensors twice (resnet2d.py:46)
+                        continue
+                    flat = p.grad.detach().flatten()
+                    idx = torch.linspace(0, flat.numel() - 1, min(8, flat.numel())).long()
+                    per[n] = {"norm": float(flat.double().norm()), "idx": [int(i) for i in idx],
+                              "samples": [float(v) for v in flat[idx]]}
+                grads[net_name] = per
+        model.update_learning_rate()
+        print(name, s, rec[-1]["losses"], flush=True)
+    return {"config": c, "steps": rec, "step0_grads": grads}
+
+
+def envelope_run(threads):
+    torch.set_num_threads(threads)
+    model, inputs = _model(ENVELOPE_CASE)
+    rec = []
+    for s in range(ENVELOPE_CASE["steps"]):
+        A, B = inputs(ENVELOPE_CASE, s)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        rec.append(_record(model))
+        model.update_learning_rate()
+    return rec
+
+
+def main():
+    what = sys.argv[1]
+    if what == "grads":
+        torch.set_num_threads(8)
+        out = {n: grad_case(n, c) for n, c in GRAD_CASES.items()}
+        (OUT / "cyclegan_grads.json").write_text(json.dumps(out, indent=1))
+    elif what == "envelope-run":            # one curve, printed as JSON (child process: thread pools are per process)
+        print("CURVE" + json.dumps(envelope_run(int(sys.argv[2]))))
+    elif what == "envelope":
+        curves = {}
+        for t in (1, 8):
+            r = subprocess.run([sys.executable, "-m", "oracle.gen_golden_r2", "envelope-run", str(t)], cwd=ROOT,
+                               capture_output=True, text=True, check=True)
+            curves[f"threads_{t}"] = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("CURVE"))[5:])
+        (OUT / "envelope.json").write_text(json.dumps({"config": ENVELOPE_CASE, "torch": torch.__version__,
+                                                       **curves}, indent=1))
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == "__main__":
+    main()

@@ -48,3 +48,53 @@ def test_no_cpu_fallback_without_gpu():
     from ganslate_amd.hip.ops import HipOps
     with pytest.raises(RuntimeError, match="no CPU path"):
         HipOps()
+
+
+def test_header_is_valid_c11():
+    """the boundary is a C ABI: the header must compile as C, not only as C++ (hipcc accepted a struct with member
+    function declarations in round 1)"""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                        str(ROOT / "include" / "ganslate_hip.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_c_caller_sees_the_ctypes_layout(tmp_path):
+    """a C11 program including the header fills a gs_gconv_desc, dlopens the library and calls its host-side planning
+    entry points; sizeof / offsetof of every descriptor must equal the ctypes mirrors the Python host side uses"""
+    import subprocess
+    from ganslate_amd.hip import lib as L
+    if not L.library_path().is_file():
+        import __graft_entry__
+        __graft_entry__.build()
+    exe = tmp_path / "abi_probe"
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", str(ROOT / "include"),
+                        str(ROOT / "tests" / "abi" / "abi_probe.c"), "-o", str(exe), "-ldl"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), str(L.library_path())], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mirrors = {"gs_gconv_desc": L.GConvDesc, "gs_wgrad_desc": L.WGradDesc, "gs_gconv_fuse": L.GConvFuse,
+               "gs_norm_ex_desc": L.NormExDesc, "gs_pnorm_desc": L.PNormDesc}
+    calls, seen = {}, set()
+    for line in r.stdout.splitlines():
+        w = line.split()
+        if w[0] == "sizeof":
+            assert ctypes.sizeof(mirrors[w[1]]) == int(w[2]), line
+            seen.add(w[1])
+        elif w[0] == "offsetof":
+            assert getattr(mirrors[w[1]], w[2]).offset == int(w[3]), line
+        elif w[0] == "call":
+            calls[w[1]] = int(w[2])
+    assert seen == set(mirrors)
+    # the same descriptors through ctypes give the same answers as the C caller got
+    lib = L.load()
+    d = L.GConvDesc()
+    d.N = 8; d.Hi = d.Wi = d.Ho = d.Wo = d.Hc = d.Wc = 64; d.Ci = d.Co = d.in_cs = d.out_cs = 256
+    d.Di = d.Do = d.Dc = 1; d.so = d.si = 1; d.T = 9; d.Kp = 9 * 256; d.w_rows = 256; d.border = L.BORDER["reflect"]
+    for t in range(9):
+        d.dh[t], d.dw[t] = t // 3 - 1, t % 3 - 1
+    assert calls["stat_slots"] == lib.gs_gconv_stat_slots(ctypes.byref(d)) > 0
+    assert calls["tile_m"] == lib.gs_tile_m(ctypes.byref(d)) > 0
+    assert calls["splitk_ws_floats"] == lib.gs_gconv_splitk_ws_floats(ctypes.byref(d)) == 0
+    assert calls["tail_splitk_ws_floats"] > 0
