@@ -2,9 +2,10 @@
 """Headline benchmark: training images/sec of the CycleGAN ResNet-9 256x256 bf16 step (BASELINE.json configs[1]:
 horse2zebra hyper-parameters, batch 8 per GPU) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N          # no WORLD_SIZE in the environment: starts the N ranks itself (child process)
 
 A "step" = set_input + optimize_parameters of ganslate_amd.nn.gans.unpaired.CycleGAN (what the reference's
 `t_comp` brackets, engines/trainer.py:56-60) on a synthetic batch already resident in HBM. One process per GPU;
@@ -23,7 +24,10 @@ sys.path.insert(0, str(ROOT))
 # algorithmic work (BASELINE.md §3 / SURVEY.md §8d): conv MACs x 2 of one CycleGAN step per image pair
 GFLOP_PER_IMAGE = 1289.9
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-HCONVW_HBM_BYTES = 43.7e6    # measured, see profiles/r01_hconvw_hbm_pmc.txt
+# HBM bytes per launch of the three residual-conv kernels at the headline shape, from rocprofv3 PMC passes (bench.py
+# cannot run the profiler on itself): 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction of
+# MI355X_MICROARCH.md. Filled from profiles/ by name; None = not measured for this build.
+HBM_BYTES = {"rb_fwd": (43.7e6, "profiles/r01_hconvw_hbm_pmc.txt"), "rb_dgrad": (None, None), "rb_wgrad_pair": (None, None)}
 
 
 def make_pix2pix_conf(batch, n_iters):
@@ -154,8 +158,8 @@ def cpu_baseline(size=256, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cut", "cyclegan3d", "brats"],
@@ -166,6 +170,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+
+    # a timed kernel must never be one that was told to skip work: the ablation switches of round 1 are compiled out
+    # of the library; refuse to run if somebody still sets them, or any other kernel "variant" selector
+    bad = [k for k in os.environ if k.startswith("GS_") and (k.endswith("_VARIANT") or k.endswith("_ABL"))]
+    if bad:
+        raise SystemExit(f"bench.py refuses to run with {bad} set: ablation / variant switches are not benchmarks")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start one rank per GPU as a CHILD process (torch.distributed.run) before this
+        # process has touched the GPU, and exit with its code (a process that has initialised the GPU must not exec)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -242,19 +265,27 @@ def main():
     graphed = bool(getattr(model, "_graph", None) is not None and model.step_graph_enabled)
     timing = None
     if not args.no_kernel_timing:
-        # HIP events around every launch of the dominant kernel (residual-block 3x3 conv, forward form) on the stream it
-        # is launched on (torch's current stream). A replayed hipGraph cannot hold event records, so when the timed
-        # region ran as graph replays the events are taken in a few launch-by-launch, single-stream steps of the same
-        # workload right after it (same kernels, same arguments, no other stream sharing the chip — which is also how
-        # rocprofv3's kernel trace runs them; profiles/ holds its average for the same kernel).
-        rb_taps, rb_border = (27, "replicate") if args.workload == "cyclegan3d" else (9, "reflect")
-        timing = ops.enable_kernel_timing(lambda g: g.T == rb_taps and g.Ci == 256 and g.Co == 256 and g.si == 1
-                                          and g.border == rb_border)
+        # HIP events around every launch of the three residual-block 3x3 conv forms (forward, fused data gradient,
+        # merged weight-gradient pair) on the stream they are launched on (torch's current stream). A replayed hipGraph
+        # cannot hold event records, so when the timed region ran as graph replays the events are taken in a few
+        # launch-by-launch, single-stream steps of the same workload right after it (same kernels, same arguments, no
+        # other stream sharing the chip — which is also how rocprofv3's kernel trace runs them; profiles/ holds its
+        # averages for the same kernels). The kernel with the largest per-step total goes into `roofline`.
+        rb_taps = 27 if args.workload == "cyclegan3d" else 9
+
+        def select(kind, spec, flag):
+            if kind == "gconv" and spec.T == rb_taps and spec.Ci == 256 and spec.Co == 256 and spec.si == 1 and spec.so == 1:
+                return "rb_dgrad" if (flag or spec.border == "zero") else "rb_fwd"
+            if kind == "wgrad" and spec.T == rb_taps and spec.P == 256 and spec.Q == 256 and spec.si == 1:
+                return "rb_wgrad_pair" if flag else "rb_wgrad"
+            return None
+        timing = ops.enable_kernel_timing(select)
         if graphed:
             model.step_graph_enabled = False
         side = os.environ.get("GS_SIDE_STREAM")
         os.environ["GS_SIDE_STREAM"] = "0"       # one stream: a launch's duration is its own, not a share of the chip
-        for _ in range(min(args.steps, 5)):
+        timing_steps = min(args.steps, 5)
+        for _ in range(timing_steps):
             step()
         torch.cuda.synchronize()
         ops.disable_kernel_timing()
@@ -304,7 +335,7 @@ def main():
                "step_tflops": round(value * tflop_per_pair, 1),
                "step_mfma_frac": round(value * tflop_per_pair / (PEAK_BF16_TFLOPS * world), 4)}
         if timing is not None:
-            n, ms = ops.kernel_timing_result()
+            n, ms = ops.kernel_timing_result().get("rb_fwd", (0, 0.0))
             vox = (args.size // 4) ** 3
             flop = 2.0 * vox * args.batch * 256 * 6912
             tf = flop / (ms * 1e-3) / 1e12 if n else 0.0
@@ -330,23 +361,38 @@ def main():
             "step_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 1),
             "step_mfma_frac": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }
+        if world > 1:
+            out["ddp_path"] = ("captured: graph(forward+backward) | one RCCL all-reduce per network, per-network overlap "
+                               "with the remaining backward | graph(Adam)") if graphed else \
+                "launch by launch: bucketed all-reduce overlapped with the last backward pass"
         if timing is not None:
-            n, ms = ops.kernel_timing_result()
+            res = ops.kernel_timing_result()
             hw = (args.size // 4) ** 2
-            flop = 2.0 * hw * args.batch * 256 * 2304           # 2*M*N*K of one launch
-            tf = flop / (ms * 1e-3) / 1e12 if n else 0.0
-            out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-                               # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (bench.py
-                               # cannot run the profiler on itself): profiles/r01_hconvw_hbm_pmc.txt
-                               "traffic": HCONVW_HBM_BYTES if (args.batch == 8 and args.size == 256) else None,
-                               "traffic_source": "profiles/r01_hconvw_hbm_pmc.txt (2 x FETCH_SIZE + WRITE_SIZE, separate "
-                                                 "rocprofv3 --pmc passes; algorithmic 34.8e6)",
-                               "kernel": "hconvw_kernel<9> (3x3 256->256 reflect conv, halo-resident, M=%d N=256 K=2304)"
-                                         % (hw * args.batch),
-                               "launches_timed": n, "avg_ms": round(ms, 4),
+            flop1 = 2.0 * hw * args.batch * 256 * 2304           # 2*M*N*K of one 3x3 256->256 conv over the batch
+            names = {"rb_fwd": "hconvw_kernel<9> (forward, halo-resident)",
+                     "rb_dgrad": "residual-conv data gradient (+ fused norm-backward reduction)",
+                     "rb_wgrad_pair": "hwgrad_wide_kernel<9> (weight gradient of two backward passes in one launch)",
+                     "rb_wgrad": "hwgrad_wide_kernel<9> (weight gradient, one pass)"}
+            kernels = {}
+            for label, (n, ms) in res.items():
+                flop = flop1 * (2 if label == "rb_wgrad_pair" else 1)
+                kernels[label] = {"kernel": names[label], "launches_per_step": round(n / timing_steps, 1),
+                                  "avg_ms": round(ms, 4), "ms_per_step": round(n / timing_steps * ms, 3),
+                                  "tflops": round(flop / (ms * 1e-3) / 1e12, 1) if n else 0.0,
+                                  "frac": round(flop / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if n else 0.0}
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            hbm, hbm_src = HBM_BYTES.get(dom, (None, None)) if (args.batch == 8 and args.size == 256) else (None, None)
+            out["roofline"] = {"bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": kernels[dom]["frac"], "traffic": hbm,
+                               "traffic_source": hbm_src,
+                               "kernel": f"{names[dom]}: 3x3 256->256 reflect conv, M={hw * args.batch} N=256 K=2304"
+                                         + (" x 2 passes" if dom == "rb_wgrad_pair" else ""),
+                               "dominant_of": "the three residual-conv launch forms, by per-step total of their own "
+                                              "HIP-event timings",
+                               "launches_timed": res[dom][0], "avg_ms": kernels[dom]["avg_ms"],
                                "timed_in": "%d launch-by-launch single-stream steps right after the timed region%s"
-                                           % (min(args.steps, 5), " (which ran as hipGraph replays)" if graphed else "")}
+                                           % (timing_steps, " (which ran as hipGraph replays)" if graphed else "")}
+            out["residual_conv_kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

@@ -41,6 +41,37 @@ float* gs_reduce_workspace(void* stream) {
   return nullptr;
 }
 
+namespace {
+struct OptDef { const char* name; int value; };
+OptDef g_opts[GS_OPT_COUNT] = {
+    {"splitk", 1},              // split-K for launches with few output tiles and a long K loop (gconv.hip)
+    {"splitk_max_blocks", 128}, // ... only below this many output tiles
+    {"splitk_target", 256},     // ... aiming at this many workgroups
+    {"hconv", 1},               // halo-resident forward kernel for narrow stride-1 layers (hconv.hip)
+    {"hconv_wide", 1},          // halo-resident forward kernel for the wide 3x3 layers (hconvw.hip)
+    {"hconvw_waves", 16},       // 16 or 8 waves per workgroup in hconvw_kernel
+    {"hwgrad", 1},              // halo-resident weight-gradient kernels (hwgrad.hip)
+    {"hwgrad_wide", 1},         // ... the wide 3x3 form
+    {"hwgrad_planes", 1},       // ... 3x3x3 layers as three depth planes of it
+    {"norm_bwd_ppb", 0},        // pixels per workgroup of the norm-backward reduction (0 = heuristic; tuning aid)
+    {"norm_apply_unroll", 4},   // elements per thread of the norm-backward apply pass (tuning aid)
+};
+}  // namespace
+int gs_opt(int id) { return g_opts[id].value; }
+
+extern "C" int gs_set_option(const char* name, int value) {
+  for (int i = 0; i < GS_OPT_COUNT; ++i)
+    if (name && strcmp(name, g_opts[i].name) == 0) { g_opts[i].value = value; return 0; }
+  gs_set_error("gs_set_option: unknown option '%s'", name ? name : "(null)");
+  return 2;
+}
+extern "C" int gs_get_option(const char* name, int* value) {
+  for (int i = 0; i < GS_OPT_COUNT; ++i)
+    if (name && value && strcmp(name, g_opts[i].name) == 0) { *value = g_opts[i].value; return 0; }
+  gs_set_error("gs_get_option: unknown option '%s'", name ? name : "(null)");
+  return 2;
+}
+
 extern "C" const char* gs_last_error(void) { return g_err; }
 
 extern "C" int gs_init(int device) {

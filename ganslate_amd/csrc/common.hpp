@@ -70,6 +70,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// kernel-selection switches (api.hip; set through gs_set_option, never read from the environment by the library)
+enum GsOpt {
+  GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE, GS_OPT_HCONVW_WAVES,
+  GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL,
+  GS_OPT_COUNT
+};
+int gs_opt(int id);
+
 // host-side error plumbing shared by the launchers
 void gs_set_error(const char* fmt, ...);
 const void* gs_zero_page();

@@ -44,7 +44,7 @@ struct GConvK {
   gs_gconv_desc d;
 };
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   constexpr int NW = WM * WN;           // waves per workgroup
   constexpr int WT = BN * 128;          // weight tile bytes per stage
@@ -208,54 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     }
   };
 
-  // fragment load / MFMA halves of a K-step (kk = 0, 1) for the software-pipelined 3-stage loop
-  auto load_frags = [&](int buf, int kk, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
-    const char* wb = smem + buf * STAGE + (wn * (BN / WN) + frow) * 128;
-    const char* xb = smem + buf * STAGE + WT + (wm * (BM / WM) + frow) * 128;
-    const int coff = ((kk * 4 + fk) ^ swz) << 4;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + coff);
-  };
-  auto mfma_frags = [&](const bf16x8 (&wf)[TI], const bf16x8 (&xf)[TJ]) {
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-  };
-
-  if constexpr (NSTAGE == 3 && VARIANT == 19) {   // measured: -2 % at best, and its extra live fragments spill at 16 waves
-    // Software-pipelined ring: the LDS reads of the next half K-step are in flight while the matrix pipe works on the
-    // current one, across the barrier too (the plain loop below had every wave read right after the barrier and only
-    // then start its MFMAs: LDS and matrix phases alternated instead of overlapping). DMA runs up to 3 stages ahead:
-    // stage ks+3 goes into the buffer of stage ks as soon as every wave's reads of it have returned.
-    if (nk > 2) issue(2, 2);
-    const int pend0 = (nk > 2 ? 2 : (nk > 1 ? 1 : 0)) * LOADS;
-    if (pend0 == 2 * LOADS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-    else if (pend0 == LOADS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    bf16x8 wa[TI], xa[TJ], wb2[TI], xb2[TJ];
-    load_frags(0, 0, wa, xa);
-    int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-      load_frags(cur, 1, wb2, xb2);
-      mfma_frags(wa, xa);
-      if (ks + 1 < nk) {
-        if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // stage ks+1 landed everywhere; nobody still reads stage ks
-        if (ks + 3 < nk) issue(ks + 3, cur);
-        const int nxt = cur == 2 ? 0 : cur + 1;
-        load_frags(nxt, 0, wa, xa);
-        cur = nxt;
-      }
-      mfma_frags(wb2, xb2);
-    }
-    __syncthreads();
-  } else if constexpr (NSTAGE == 2) {
+  if constexpr (NSTAGE == 2) {
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const int cur = (ks - ks_begin) & 1;
       if (ks + 1 < ks_end) issue(ks + 1, cur ^ 1);
@@ -267,47 +220,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     // 3-stage ring, DMA two K-steps ahead; one raw barrier per K-step; counted vmcnt keeps the younger stage in
     // flight across the barrier (a __syncthreads() here would drain it: LDS-DMA counts as a pending LDS write)
     int cur = 0, nxt2 = 2;
-    const int nk_run = (VARIANT == 6 || VARIANT == 8 || VARIANT == 17 || VARIANT == 18) ? (nk < 2 ? nk : 2) : nk;   // ablations: no main loop
-    for (int ks = 0; ks < nk_run; ++ks) {
+    for (int ks = 0; ks < nk; ++ks) {
       if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if constexpr (VARIANT == 7) {
-        // wave-group ping-pong: waves w and w+NW/2 share a SIMD; one half issues its LDS-DMA (slow to issue,
-        // ~100+ cycles per instruction) while the other half runs its MFMA cluster, then they swap
-        const bool second = wave >= NW / 2;
-        if (!second) compute(cur);
-        else if (ks + 2 < nk) issue(ks + 2, nxt2);
-        __builtin_amdgcn_s_barrier();
-        if (second) compute(cur);
-        else if (ks + 2 < nk) issue(ks + 2, nxt2);
-      } else if constexpr (VARIANT == 0 || VARIANT == 16) {   // 16: the plain (not software-pipelined) loop, for A/B runs
-        if (ks + 2 < nk) issue(ks + 2, nxt2);
-        compute(cur);
-      } else if constexpr (VARIANT == 1) {       // MFMAs first, DMA issue behind them
-        compute(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < nk) issue(ks + 2, nxt2);
-      } else if constexpr (VARIANT == 3) {       // ablation: DMA only
-        if (ks + 2 < nk) issue(ks + 2, nxt2);
-      } else if constexpr (VARIANT == 4) {       // ablation: LDS reads + MFMA only
-        compute(cur);
-      } else if constexpr (VARIANT == 6 || VARIANT == 8 || VARIANT == 17 || VARIANT == 18) {
-        compute(cur);
-      } else {                                   // VARIANT 2: priority on the MFMA cluster
-        if (ks + 2 < nk) issue(ks + 2, nxt2);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        compute(cur);
-        __builtin_amdgcn_s_setprio(0);
-      }
+      if (ks + 2 < nk) issue(ks + 2, nxt2);
+      compute(cur);
       cur = cur == 2 ? 0 : cur + 1;
       nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
     __syncthreads();
   }
 
-  if constexpr (VARIANT == 8) { if (acc[0][0][0] == 12345.678f) p.out[0] = 1; return; }
   if constexpr (NSTAGE == 2) {
     if (p.splits > 1) {       // raw partial sums, dense [output pixel][Co] per split; the epilogue runs in the finalize pass
       float* part = p.partial + (size_t)sp * p.split_stride;
@@ -338,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // ---- epilogue: bias, InstanceNorm partial statistics, activation, bf16 NHWC store -----------------
-  const bool want_stats = d.stats_slots > 0 && VARIANT != 10;
+  const bool want_stats = d.stats_slots > 0;
   float s1[TI][4], s2[TI][4];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -405,8 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       }
     }
   }
-  if constexpr (VARIANT == 17) { if (s1[0][0] == 12345.678f) p.out[0] = 1; return; }   // ablation: slab only
-  if constexpr (VARIANT != 18) {
+  {
     constexpr int LPR = CW / 8;               // lanes per pixel row (16 B each)
     constexpr int PPI = 64 / LPR;             // pixels per store instruction
     const int sub = lane % LPR, prow = lane / LPR;
@@ -471,7 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
           val.z = pack_bf2(bf_lo(val.z) + bf_lo(old.z), bf_hi(val.z) + bf_hi(old.z));
           val.w = pack_bf2(bf_lo(val.w) + bf_lo(old.w), bf_hi(val.w) + bf_hi(old.w));
         }
-        if (VARIANT != 9 || val.x == 0x12345678u) *dst = val;
+        *dst = val;
       }
     }
     if (fuse) {
@@ -609,14 +532,14 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
 // 2..128 pixels and K = 16*1024, the PatchGAN 512->1 tail) are latency-bound on a handful of workgroups that each
 // stream megabytes of weights through a 2-stage ring; splitting K spreads that stream over all CUs. Returns 1 = no split.
 int splitk_plan(const gs_gconv_desc* d, const TileCfg& tc, bool fused) {
-  static const bool enabled = !(getenv("GS_SPLITK") && atoi(getenv("GS_SPLITK")) == 0);
+  const bool enabled = gs_opt(GS_OPT_SPLITK) != 0;
   if (!enabled || fused || d->accumulate || (tc.bm != 128 && tc.bn != 16)) return 1;
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)d->N * ((pix + tc.bm - 1) / tc.bm) * ((d->Co + tc.bn - 1) / tc.bn);
   const int nk = d->Kp >> 6;
-  static const int max_blocks = getenv("GS_SPLITK_MAXB") ? atoi(getenv("GS_SPLITK_MAXB")) : 128;
+  const int max_blocks = gs_opt(GS_OPT_SPLITK_MAX_BLOCKS);
   if (blocks > max_blocks || nk < 16) return 1;
-  static const int target = getenv("GS_SPLITK_TARGET") ? atoi(getenv("GS_SPLITK_TARGET")) : 256;
+  const int target = gs_opt(GS_OPT_SPLITK_TARGET);
   long long splits = target / blocks;
   if (splits > nk / 4) splits = nk / 4;
   const long long out_floats = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
@@ -624,17 +547,17 @@ int splitk_plan(const gs_gconv_desc* d, const TileCfg& tc, bool fused) {
   return splits < 2 ? 1 : (int)splits;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int VARIANT = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch(const GConvK& k, int blocks, hipStream_t st) {
   const int lds = NSTAGE * (BM + BN) * 128 + GS_MAX_TAPS * 2 + BM * (k.nh + k.nw) * 2;
   GS_REQUIRE(lds <= 160 * 1024, "gs_gconv_forward: gather tables do not fit in LDS (T=%d)", k.d.T);
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, NSTAGE, VARIANT>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<BM, BN, WM, WN, NSTAGE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     configured = true;
   }
-  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, NSTAGE, VARIANT>), dim3(blocks), dim3(WM * WN * 64), lds, st, k);
+  hipLaunchKernelGGL((gconv_kernel<BM, BN, WM, WN, NSTAGE>), dim3(blocks), dim3(WM * WN * 64), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -781,26 +704,6 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
   if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, (int)blocks, st);
   if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
   if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, (int)blocks, st);
-  if (tc.bm == 256) {
-    static const int variant = getenv("GS_GCONV_VARIANT") ? atoi(getenv("GS_GCONV_VARIANT")) : 0;
-    if (variant == 1) return launch<256, 128, 4, 2, 3, 1>(k, (int)blocks, st);
-    if (variant == 2) return launch<256, 128, 4, 2, 3, 2>(k, (int)blocks, st);
-    if (variant == 3) return launch<256, 128, 4, 2, 3, 3>(k, (int)blocks, st);
-    if (variant == 4) return launch<256, 128, 4, 2, 3, 4>(k, (int)blocks, st);
-    if (variant == 6) return launch<256, 128, 4, 2, 3, 6>(k, (int)blocks, st);
-    if (variant == 7) return launch<256, 128, 4, 2, 3, 7>(k, (int)blocks, st);
-    if (variant == 8) return launch<256, 128, 4, 2, 3, 8>(k, (int)blocks, st);
-    if (variant == 9) return launch<256, 128, 4, 2, 3, 9>(k, (int)blocks, st);
-    if (variant == 13) return launch<256, 128, 8, 2, 3, 0>(k, (int)blocks, st);   // 16 waves
-    if (variant == 14) return launch<256, 128, 4, 4, 3, 0>(k, (int)blocks, st);   // 16 waves
-    if (variant == 11) return launch<256, 128, 2, 2, 3, 0>(k, (int)blocks, st);   // 4 waves, 128x64 per wave
-    if (variant == 12) return launch<256, 128, 4, 1, 3, 0>(k, (int)blocks, st);   // 4 waves, 64 px x 128 co per wave
-    if (variant == 10) return launch<256, 128, 4, 2, 3, 10>(k, (int)blocks, st);
-    if (variant == 15) return launch<256, 128, 4, 2, 3>(k, (int)blocks, st);       // 8 waves
-    if (variant == 19) return launch<256, 128, 4, 4, 3, 19>(k, (int)blocks, st);   // 16 waves, software-pipelined loop
-    if (variant == 17) return launch<256, 128, 4, 2, 3, 17>(k, (int)blocks, st);   // ablation: epilogue = slab only
-    if (variant == 18) return launch<256, 128, 4, 2, 3, 18>(k, (int)blocks, st);   // ablation: epilogue = slab + stats
-    return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);                            // 16 waves: best measured
-  }
+  if (tc.bm == 256) return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);   // 16 waves: best measured (8 and 4 lose)
   return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
 }

@@ -248,7 +248,7 @@ struct HPlan {
 
 HPlan plan(const gs_gconv_desc* d) {
   HPlan h{};
-  static const bool enabled = !(getenv("GS_HCONV") && atoi(getenv("GS_HCONV")) == 0);
+  const bool enabled = gs_opt(GS_OPT_HCONV) != 0;
   if (!enabled) return h;
   // T < 9: the W-folded boundary convs (7 taps) measured slower here than on the im2col kernel (stem fwd 93 vs 74 us)
   if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 64 || d->T < 9) return h;

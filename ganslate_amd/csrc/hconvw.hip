@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
 }
 
 static bool hconvw_eligible(const gs_gconv_desc* d, int* lo) {
-  static const bool enabled = !(getenv("GS_HCONV_WIDE") && atoi(getenv("GS_HCONV_WIDE")) == 0);
+  const bool enabled = gs_opt(GS_OPT_HCONV_WIDE) != 0;
   if (!enabled || d->si != 1 || d->so != 1 || d->T != 9 || d->Ci % 64 != 0 || d->Co % 128 != 0 || d->accumulate) return false;
   if (d->Di != 1 || d->Do != 1 || d->Dc != 1 || d->Hc != d->Ho || d->Wc != d->Wo || d->py || d->px || d->pz) return false;
   if (d->Ho % 16 != 0 || d->Wo % 16 != 0) return false;
@@ -310,7 +310,7 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.chunks = d->Ci / 64;
   k.d = *d;
   const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
-  static const int nw = getenv("GS_HCONVW_NW") ? atoi(getenv("GS_HCONVW_NW")) : 16;
+  const int nw = gs_opt(GS_OPT_HCONVW_WAVES);
   static bool configured = false;
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 16>),

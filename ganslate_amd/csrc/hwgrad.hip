@@ -297,8 +297,7 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
   for (; box < p.nboxes; box += gridDim.x) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this box landed (nothing else is outstanding)
     __syncthreads();                                     // ... for every wave; the other buffer is fully consumed
-    if (box + (int)gridDim.x < p.nboxes && p.tgroups != 3) issue_box(box + gridDim.x, cur ^ 1);
-    if (p.tgroups == 2) { cur ^= 1; continue; }          // ablation: staging only
+    if (box + (int)gridDim.x < p.nboxes) issue_box(box + gridDim.x, cur ^ 1);
     // address-space-3 base pointers once per box: per-read addresses are then 32-bit adds (a generic -> LDS cast per
     // read was a third of the loop's VALU work)
     typedef __attribute__((address_space(3))) char lds_char;
@@ -350,7 +349,6 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
 
   const int col = lane & 15;
   const int q = qt * 64 + wq * 16 + col;
-  if (p.tgroups == 1 && acc[0][0][0] != 12345.678f) return;   // ablation: no atomics
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     if (t < d.T) {
@@ -392,9 +390,9 @@ int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* d
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
                    void* stream, int* handled) {
   *handled = 0;
-  static const bool enabled = !(getenv("GS_HWGRAD") && atoi(getenv("GS_HWGRAD")) == 0);
-  static const bool wide_enabled = !(getenv("GS_HWGRAD_WIDE") && atoi(getenv("GS_HWGRAD_WIDE")) == 0);
-  static const bool planes_enabled = !(getenv("GS_HWGRAD_PLANES") && atoi(getenv("GS_HWGRAD_PLANES")) == 0);
+  const bool enabled = gs_opt(GS_OPT_HWGRAD) != 0;
+  const bool wide_enabled = gs_opt(GS_OPT_HWGRAD_WIDE) != 0;
+  const bool planes_enabled = gs_opt(GS_OPT_HWGRAD_PLANES) != 0;
   // 3x3x3 layers of volumes (Resnet3D residual convs): the 27 taps are three depth planes of 9, and a plane is the 2-D
   // problem over (image, slice) pairs with the gathered operand read from slice z + dd (border rule applied in depth):
   // three launches of the wide kernel, each writing its own 9 tap rows of dw
@@ -448,7 +446,7 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
       k.a2 = static_cast<const char*>(a2);
       k.g2 = static_cast<const char*>(g2);
       k.qchunks = k.phalves = 1;
-      k.tgroups = getenv("GS_HWW_ABL") ? atoi(getenv("GS_HWW_ABL")) : 0;   // 0 = normal; 1/2/3 = ablations
+      k.tgroups = 1;
       k.a = static_cast<const char*>(a);
       k.g = static_cast<const char*>(g);
       k.dw = dw;

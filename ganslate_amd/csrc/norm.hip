@@ -379,7 +379,7 @@ int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, fl
 // pixels per block of the reduction pass: 64 for 2-D sized maps, more for volumes so that the second-level sum
 // stays at <= 4096 slots per image
 static int bwd_pix_per_block(long long pixels) {
-  static const int forced = getenv("GS_BWD_PPB") ? atoi(getenv("GS_BWD_PPB")) : 0;   // tuning aid
+  const int forced = gs_opt(GS_OPT_NORM_BWD_PPB);   // tuning aid
   if (forced > 0) return forced;
   long long ppb = (pixels + 4095) / 4096;
   return ppb < 64 ? 64 : (int)((ppb + 63) / 64 * 64);
@@ -437,7 +437,7 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   }
   const long long per_img = (long long)HW * C8;
   GS_REQUIRE(per_img < (1LL << 31), "gs_inorm_act_backward: image too large");
-  static const int apply_u = getenv("GS_APPLY_U") ? atoi(getenv("GS_APPLY_U")) : 4;   // elements per thread
+  const int apply_u = gs_opt(GS_OPT_NORM_APPLY_UNROLL);   // elements per thread
   long long bx = (per_img + 256LL * apply_u - 1) / (256LL * apply_u);
   if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;

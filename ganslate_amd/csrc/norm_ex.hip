@@ -22,7 +22,12 @@ __device__ __forceinline__ unsigned gs_hash32(unsigned x) {   // murmur3 finalis
 // keep-mask * 1/(1-p) for element (n, idx) — idx counts scalars of one image in NHWC order
 __device__ __forceinline__ float drop_scale(const gs_norm_ex_desc& d, int n, unsigned idx) {
   if (d.drop_p <= 0.f) return 1.f;
-  const unsigned h = gs_hash32(idx ^ gs_hash32((unsigned)d.seed_lo + 0x9e3779b9u * (unsigned)(n + 1)) ^ (unsigned)d.seed_hi);
+  // 64-bit seed = host part (+ device part: a captured step replays this launch with the same arguments, so what
+  // changes per iteration has to be read from memory — unet2d.py:146 draws a new mask every forward)
+  unsigned long long seed = ((unsigned long long)d.seed_hi << 32) | d.seed_lo;
+  if (d.seed_dev) seed += ((unsigned long long)d.seed_dev[1] << 32) | d.seed_dev[0];
+  const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
+  const unsigned h = gs_hash32(idx ^ gs_hash32(lo + 0x9e3779b9u * (unsigned)(n + 1)) ^ hi);
   const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
   return u >= d.drop_p ? 1.0f / (1.0f - d.drop_p) : 0.f;
 }

@@ -27,7 +27,7 @@ struct WGradK {
 // over all 16 slots
 __device__ __forceinline__ int wg_swz(int R) { return ((R & 3) << 1) | (((R >> 3) & 1) << 3); }
 
-template <int BP, int BQ, int WP, int WQ, int VARIANT = 0, bool VOL = true>
+template <int BP, int BQ, int WP, int WQ, bool VOL = true>
 __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   constexpr int NW = WP * WQ, BK = 64, NSTAGE = 3;
   constexpr int ARB = BP * 2, GRB = BQ * 2;                  // row bytes of the two LDS tiles
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int wp = wave / WQ, wq = wave % WQ;
-  const int nk = VARIANT == 3 ? 2 : (k1 - k0 + BK - 1) / BK;
+  const int nk = (k1 - k0 + BK - 1) / BK;
   // transpose-read geometry: lane supplies the address of 4 consecutive channels of one pixel row
   const int fk = lane >> 4;            // 8-pixel block inside a 32-deep MFMA step
   const int frr = (lane & 15) >> 2;    // pixel row inside a 4-row block
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int col = tq * BQ + wq * (BQ / WQ) + j * 16 + frow;
-          if (col < TQ && (VARIANT != 2 || acc[i][j][r] == 1234.5f)) unsafeAtomicAdd(row + col, acc[i][j][r]);
+          if (col < TQ) unsafeAtomicAdd(row + col, acc[i][j][r]);
         }
       }
     }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
 }
 
 namespace {
-template <int BP, int BQ, int WP, int WQ, int VARIANT = 0, bool VOL = true>
+template <int BP, int BQ, int WP, int WQ, bool VOL = true>
 int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   k.tiles_p = (d->P + BP - 1) / BP;
   k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
@@ -256,19 +256,19 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 4 + 1024;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ, VARIANT, VOL>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<BP, BQ, WP, WQ, VOL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ, VARIANT, VOL>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
+  hipLaunchKernelGGL((wgrad_kernel<BP, BQ, WP, WQ, VOL>), dim3((unsigned)blocks), dim3(WP * WQ * 64), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
-template <int BP, int BQ, int WP, int WQ, int VARIANT = 0>
+template <int BP, int BQ, int WP, int WQ>
 int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   // depth-1 tensors (the 2-D nets) run the instantiation without the depth bookkeeping in the K loop
-  if (d->Da == 1 && d->Dg == 1) return launch_wgrad_impl<BP, BQ, WP, WQ, VARIANT, false>(k, d, st);
-  return launch_wgrad_impl<BP, BQ, WP, WQ, VARIANT, true>(k, d, st);
+  if (d->Da == 1 && d->Dg == 1) return launch_wgrad_impl<BP, BQ, WP, WQ, false>(k, d, st);
+  return launch_wgrad_impl<BP, BQ, WP, WQ, true>(k, d, st);
 }
 }  // namespace
 
@@ -320,10 +320,6 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (d->P <= 16) return launch_wgrad<16, 256, 1, 8>(k, d, st);      // Cout 1/3 layers: skinny P
   if (d->P <= 64) return launch_wgrad<64, 256, 1, 8>(k, d, st);
-  static const int variant = getenv("GS_WGRAD_VARIANT") ? atoi(getenv("GS_WGRAD_VARIANT")) : 0;
-  if (variant == 1) return launch_wgrad<128, 256, 2, 4>(k, d, st);   // 8 waves
-  if (variant == 2) return launch_wgrad<128, 256, 4, 4, 2>(k, d, st);   // ablation: no atomics
-  if (variant == 3) return launch_wgrad<128, 256, 4, 4, 3>(k, d, st);   // ablation: 2 K-steps only
   return launch_wgrad<128, 256, 4, 4>(k, d, st);                      // 16 waves: best measured
 }
 

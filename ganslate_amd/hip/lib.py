@@ -32,7 +32,7 @@ class NormExDesc(C.Structure):
     """Mirror of gs_norm_ex_desc."""
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "act1", "act2")] + [("slope", C.c_float)] + [
         (n, C.c_int32) for n in ("x1_cs", "x1_co", "x2_cs", "x2_co", "g1_cs", "g1_co", "g2_cs", "g2_co")] + [
-        ("drop_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+        ("drop_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("seed_dev", C.c_void_p)]
 
 
 class GConvFuse(C.Structure):
@@ -52,6 +52,8 @@ _PROTOS = {
     "gs_init": (C.c_int, [C.c_int]),
     "gs_shutdown": (None, []),
     "gs_last_error": (C.c_char_p, []),
+    "gs_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "gs_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "gs_tile_m": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_stat_slots": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

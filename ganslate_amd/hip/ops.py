@@ -37,21 +37,60 @@ class HipOps:
         L.check(self.lib.gs_init(self.device.index or 0), "gs_init")
         self._desc_cache = {}
         self._timing_filter, self._timing_events = None, []
+        self.sync_options()
+
+    # ---- kernel-selection switches ------------------------------------------------------------------------
+    # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
+    # host side are mapped onto its options here, when the backend is created and whenever a model is built.
+    ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
+                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_NW": "hconvw_waves",
+                   "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
+                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll"}
+
+    def set_option(self, name, value):
+        L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")
+        self._desc_cache = {k: v for k, v in self._desc_cache.items() if not (isinstance(k, tuple) and k[0] == "splitk")}
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        L.check(self.lib.gs_get_option(name.encode(), C.byref(v)), "gs_get_option")
+        return v.value
+
+    def sync_options(self):
+        if not hasattr(self, "_option_defaults"):
+            self._option_defaults = {opt: self.get_option(opt) for opt in self.ENV_OPTIONS.values()}
+        for env, opt in self.ENV_OPTIONS.items():
+            want = int(os.environ[env]) if env in os.environ else self._option_defaults[opt]
+            if want != self.get_option(opt):
+                self.set_option(opt, want)
 
     # ---- per-kernel timing with HIP events on the launch stream (used by bench.py) ------------------
-    def enable_kernel_timing(self, gconv_filter):
-        self._timing_filter, self._timing_events = gconv_filter, []
+    def enable_kernel_timing(self, select):
+        """select(kind, spec, flag) -> label or None. kind "gconv": spec = GConv class, flag = fused norm-backward
+        epilogue; kind "wgrad": spec = WGrad, flag = merged pair launch. Launches with a label are bracketed by HIP
+        events on the stream they are launched on."""
+        self._timing_filter, self._timing_events = select, {}
         return self._timing_events
 
     def disable_kernel_timing(self):
         self._timing_filter = None
 
+    def _time_begin(self, kind, spec, flag):
+        if self._timing_filter is None:
+            return None
+        label = self._timing_filter(kind, spec, flag)
+        if label is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._timing_events.setdefault(label, []).append((e0, e1))
+        return e1
+
     def kernel_timing_result(self):
-        """(launches, average milliseconds) of the gconv launches selected by the filter"""
+        """{label: (launches, average milliseconds)}"""
         torch.cuda.synchronize()
-        ev = self._timing_events
-        ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-        return len(ev), ms
+        return {label: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1))
+                for label, ev in self._timing_events.items()}
 
     # ---- descriptors ------------------------------------------------------------------------------------
     def _gdesc(self, g: GConv, N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0, accumulate=False):
@@ -109,6 +148,7 @@ class HipOps:
         out_cs = out_cs if out_cs is not None else out.shape[-1]
         d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0, accumulate)
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
+        t_end = self._time_begin("gconv", g, fuse is not None)
         if fuse is not None:     # data gradient + first pass of the consumer's InstanceNorm backward (fused_norm_plan)
             f = L.GConvFuse()
             f.y, f.mean_rstd, f.partial = fuse["y"].data_ptr(), fuse["mean_rstd"].data_ptr(), fuse["partial"].data_ptr()
@@ -119,11 +159,9 @@ class HipOps:
                 float(fuse.get("slope", 0.2))
             L.check(self.lib.gs_gconv_forward_fused(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats),
                                                     C.byref(f), _stream()), "gs_gconv_forward_fused")
+            if t_end is not None:
+                t_end.record()
             return
-        timed = self._timing_filter is not None and self._timing_filter(g)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         nws = self._splitk_floats(d)
         if nws:      # few output tiles, long K: split-K with a per-launch workspace (stream-safe through the allocator)
             ws = torch.empty(nws, dtype=torch.float32, device=self.device)
@@ -132,9 +170,8 @@ class HipOps:
         else:
             L.check(self.lib.gs_gconv_forward(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _stream()),
                     "gs_gconv_forward")
-        if timed:
-            e1.record()
-            self._timing_events.append((e0, e1))
+        if t_end is not None:
+            t_end.record()
 
     @staticmethod
     def can_merge_wgrad(w: WGrad) -> bool:
@@ -163,11 +200,14 @@ class HipOps:
                 d.dh[i], d.dw_[i], d.dd[i] = p, q, r
             ent = (d, w)
             self._desc_cache[key] = ent
+        t_end = self._time_begin("wgrad", w, pair is not None)
         if pair is not None:      # (a2, g2): the same layer's operands from another backward pass, one launch
             L.check(self.lib.gs_wgrad_pair(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(pair[0]), _ptr(pair[1]), _ptr(dw),
                                            _stream()), "gs_wgrad_pair")
-            return
-        L.check(self.lib.gs_wgrad(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(dw), _stream()), "gs_wgrad")
+        else:
+            L.check(self.lib.gs_wgrad(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(dw), _stream()), "gs_wgrad")
+        if t_end is not None:
+            t_end.record()
 
     def bias_grad(self, dy, C_, db, *, cs=None, co=0):
         pixels = dy.numel() // dy.shape[-1]
@@ -200,8 +240,9 @@ class HipOps:
                 "gs_inorm_act_backward")
 
     # ---- generalised norm / activation for skip-connection graphs (U-Net) ---------------------------------
-    def _norm_ex_desc(self, y, act1, act2, slope, drop_p, seed):
+    def _norm_ex_desc(self, y, act1, act2, slope, drop_p, seed, seed_dev=None):
         d = L.NormExDesc()
+        d.seed_dev = seed_dev.data_ptr() if seed_dev is not None else None      # int32[2] device tensor (lo, hi)
         d.N, d.W, d.C = y.shape[0], y.shape[-2], y.shape[-1]       # geometry-free kernels: a volume is D*H rows
         d.H = y.numel() // (d.N * d.W * d.C)
         d.act1, d.act2, d.slope = L.ACT[act1], L.ACT[act2], slope
@@ -209,8 +250,8 @@ class HipOps:
         return d
 
     def norm_act_forward_ex(self, y, mean_rstd, x1, x2=None, act1="none", act2="none", slope=0.2, x1_co=0, x2_co=0,
-                            drop_p=0.0, seed=0):
-        d = self._norm_ex_desc(y, act1, act2, slope, drop_p, seed)
+                            drop_p=0.0, seed=0, seed_dev=None):
+        d = self._norm_ex_desc(y, act1, act2, slope, drop_p, seed, seed_dev)
         d.x1_cs, d.x1_co = x1.shape[-1], x1_co
         if x2 is not None:
             d.x2_cs, d.x2_co = x2.shape[-1], x2_co
@@ -218,8 +259,8 @@ class HipOps:
                 "gs_norm_act_forward_ex")
 
     def norm_act_backward_ex(self, g1, g2, y, mean_rstd, dy, act1="none", act2="none", slope=0.2, g1_co=0, g2_co=0,
-                             drop_p=0.0, seed=0, bias_grad=None):
-        d = self._norm_ex_desc(y, act1, act2, slope, drop_p, seed)
+                             drop_p=0.0, seed=0, bias_grad=None, seed_dev=None):
+        d = self._norm_ex_desc(y, act1, act2, slope, drop_p, seed, seed_dev)
         d.g1_cs, d.g1_co = g1.shape[-1], g1_co
         if g2 is not None:
             d.g2_cs, d.g2_co = g2.shape[-1], g2_co

@@ -89,6 +89,8 @@ class BaseGAN(ABC):
         if self.conf[self.conf.mode].mixed_precision:
             self.logger.info("mixed_precision: bf16 activations / fp32 master weights are always on in this build; "
                              "apex opt_level is ignored")
+        from ..native.backend import get_ops
+        getattr(get_ops(), "sync_options", lambda: None)()      # GS_* kernel-selection switches -> library options
         self.init_networks()
         if self.is_train:
             self.init_criterions()
@@ -182,6 +184,9 @@ class BaseGAN(ABC):
             optim.external_prepare = on
         for pool in self._step_pools():
             pool.external_draw = on
+        for net in self.networks.values():          # per-iteration host state of the networks (dropout seeds)
+            if hasattr(net, "external_draw"):
+                net.external_draw = on
 
     def _prepare_host_state(self):
         """what the host contributes to one iteration besides the launches: optimiser step counters / learning rates /
@@ -191,6 +196,9 @@ class BaseGAN(ABC):
             pool.draw(batch)
         for optim in self.optimizers.values():
             optim.prepare()
+        for net in self.networks.values():
+            if hasattr(net, "prepare_host_state"):
+                net.prepare_host_state()
 
     def _graph_set_input(self, input):
         self._eager_set_input(input)

@@ -62,6 +62,19 @@ class Unet2D(NativeNet):
             nodes.append(Node(ConvSpec("convT", cin, cout, 4, 2, 1, 0, bias=True if k == 1 else use_bias, dims=dims),
                               norm=(k > 1), act="none", name=up_name(k)))
         super().__init__(nodes, in_channels, out_channels, out_act="tanh")
+        self.external_draw = False       # True while a captured step owns the launches: the recipe draws before replay
+        self._seed_dev = torch.zeros(2, dtype=torch.int32, device=self.device) if self.dropout_levels else None
+
+    def prepare_host_state(self):
+        """host side of one training forward: a fresh 64-bit dropout seed from Python's RNG (seeded by the Trainer like
+        the reference's global seeds), uploaded to the device words the norm_ex kernels read"""
+        if self._seed_dev is None or not self.training:
+            return
+        bits = random.getrandbits(62)
+        words = torch.tensor([bits & 0xFFFFFFFF, bits >> 32], dtype=torch.int64).to(torch.int32)   # wraps to two's complement
+        if self._seed_dev.is_cuda:
+            words = words.pin_memory()
+        self._seed_dev.copy_(words, non_blocking=True)
 
     def _down(self, k):
         return k - 1
@@ -113,7 +126,15 @@ class Unet2D(NativeNet):
         lows, pk = self._lowered(*sizes), self._get_packs(*sizes)
         s = _Saved()
         s.x_img, s.N, s.sizes, s.lows = x, N, sizes, lows
-        s.seed = random.getrandbits(62) if (self.training and self.dropout_levels) else 0
+        # nn.Dropout draws a new mask per forward (unet2d.py:146-147). The 64-bit mask seed lives in device memory
+        # (gs_norm_ex_desc.seed_dev): a captured step replays these launches with identical arguments, so the recipe
+        # uploads a fresh seed before every replay (prepare_host_state); launch by launch the pass draws it itself.
+        s.seed = 1 if (self.training and self.dropout_levels) else 0     # host part: flag + per-level offset
+        s.seed_dev = None
+        if s.seed:
+            if not self.external_draw:
+                self.prepare_host_state()
+            s.seed_dev = self._seed_dev
         a0 = self._new(N, sizes, self.nodes[0].spec.cin_p)
         ops.image_to_act(x, a0)
         s.L = {0: a0}          # L[k]: LeakyReLU(h_k), the input of down_{k+1}
@@ -144,7 +165,7 @@ class Unet2D(NativeNet):
                 s.mru[k] = self._conv(i, lw, pk, xin, y, stats=True)
                 p = 0.5 if (k in self.dropout_levels and self.training) else 0.0
                 ops.norm_act_forward_ex(y, s.mru[k], s.cat[k - 1], None, act1="relu", x1_co=c[k - 1], drop_p=p,
-                                        seed=s.seed + k)
+                                        seed=s.seed + k, seed_dev=s.seed_dev if p else None)
             else:
                 self._conv(i, lw, pk, xin, y)
                 s.y1 = y
@@ -176,7 +197,7 @@ class Unet2D(NativeNet):
         if self.master.grad is None:
             self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         grad = self.master.grad
-        final_pass = want_w and self._dist is not None and self._fw_pending == 0
+        final_pass = want_w and self._dist is not None and self._fw_pending == 0 and not self.external_reduce
         bias_slice = lambda i: grad[self.b_off[i]:self.b_off[i] + self.nodes[i].spec.cout_p] if want_w else None
         dy = torch.empty_like(s.y1)
         ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, dy, act="tanh")
@@ -194,7 +215,8 @@ class Unet2D(NativeNet):
                 dy = torch.empty_like(s.yu[k + 1])
                 p = 0.5 if (k + 1 in self.dropout_levels and s.seed) else 0.0
                 ops.norm_act_backward_ex(gcat[k], None, s.yu[k + 1], s.mru[k + 1], dy, act1="relu", g1_co=c[k],
-                                         drop_p=p, seed=s.seed + k + 1, bias_grad=bias_slice(self._up(k + 1)))
+                                         drop_p=p, seed=s.seed + k + 1, seed_dev=s.seed_dev if p else None,
+                                         bias_grad=bias_slice(self._up(k + 1)))
         # ---- down path, innermost first ----
         gL = None
         for k in range(D, 0, -1):

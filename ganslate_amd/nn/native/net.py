@@ -541,6 +541,7 @@ class NativeNet:
         if self.external_reduce:       # a captured step: the runner all-reduces the flat gradient between its graphs
             import torch.distributed as dist
             self._fw_pending = 0
+            self._reduce_handles, self._reduced_buckets = [], set()
             return 1.0 / dist.get_world_size(self._dist)
         import torch.distributed as dist
         if self.grad_dirty:

@@ -84,6 +84,12 @@ typedef struct gs_wgrad_desc {
 int gs_init(int device);                 /* torch.cuda.set_device + lazy cuDNN handle (base.py:84-91) */
 void gs_shutdown(void);
 const char* gs_last_error(void);
+/* Kernel-selection switches (A/B measurements, parity tests): the library reads NO environment variable; the host
+ * side maps its GS_* variables onto these (ganslate_amd/hip/ops.py). Names: splitk, splitk_max_blocks, splitk_target,
+ * hconv, hconv_wide, hconvw_waves, hwgrad, hwgrad_wide, hwgrad_planes, norm_bwd_ppb, norm_apply_unroll. Every setting
+ * computes the same function (up to the fp32 summation order); none skips work. Unknown name -> non-zero. */
+int gs_set_option(const char* name, int value);
+int gs_get_option(const char* name, int* value);
 int gs_tile_m(const gs_gconv_desc* d);   /* pixel-tile height of the im2col kernel for this class */
 /* number of partial-statistics slots per image gs_gconv_forward writes for this class (pixel tiles of the im2col
  * kernel, or output boxes of the halo-resident kernel narrow stride-1 layers run on): size `stats` with it */
@@ -163,7 +169,9 @@ typedef struct gs_norm_ex_desc {
   int32_t x1_cs, x1_co, x2_cs, x2_co;      /* forward outputs: channel stride / offset (elements) */
   int32_t g1_cs, g1_co, g2_cs, g2_co;      /* backward gradient inputs */
   float   drop_p;              /* 0 = no dropout */
-  uint32_t seed_lo, seed_hi;
+  uint32_t seed_lo, seed_hi;   /* host part of the 64-bit mask seed */
+  const uint32_t* seed_dev;    /* optional DEVICE part (2 words, lo/hi), added to the host part: lets a captured hipGraph
+                                * of the step draw a fresh nn.Dropout mask per replay (unet2d.py:146-147) */
 } gs_norm_ex_desc;
 int gs_norm_act_forward_ex(const gs_norm_ex_desc* d, const void* y, const float* mean_rstd, void* x1, void* x2,
                            void* stream);

@@ -2,6 +2,7 @@
 
     python -m oracle.gen_golden_r2 grads       # tests/golden/cyclegan_grads.json
     python -m oracle.gen_golden_r2 envelope    # tests/golden/envelope.json
+    python -m oracle.gen_golden_r2 fullsize    # tests/golden/fullsize.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -65,7 +66,7 @@ def grad_case(name, c):
             grads = {}
             for net_name, net in model.networks.items():
                 per = {}
-                for n, p in net.named_parameters():
+                for n, p in net.named_parameters(remove_duplicate=False):
                     if n.startswith("encoder."):      # Resnet2D registers the same tensors twice (resnet2d.py:46)
                         continue
                     flat = p.grad.detach().flatten()
@@ -91,9 +92,26 @@ def envelope_run(threads):
     return rec
 
 
+def fullsize():
+    """BASELINE configs[3] / [4] shapes the round-1 goldens only covered at 64x64 / 16x32x32: CUT at 256x256 batch 2 and
+    the brats-yaml 3-D CycleGAN (Vnet3D + PatchGAN3D n_layers 2) at 64^3 -> tests/golden/fullsize.json"""
+    from oracle import gen_golden as G
+    torch.set_num_threads(8)
+    out = {}
+    c = dict(size=256, batch=2, steps=2, n_iters=100, n_iters_decay=100, num_patches=256, seed=42)
+    out["cut_256_b2"] = G.run_cut_case("cut_256_b2", c)
+    c = dict(size=[64, 64, 64], batch=1, steps=2, n_iters=100, n_iters_decay=100, pool_size=50, lambda_identity=0.0,
+             proportion_ssim=0.0, d_layers=2, seed=54,
+             vnet=dict(first_layer_channels=16, down_blocks=[2, 2, 3], up_blocks=[3, 3, 3]))
+    out["vnet_64"] = G.run_case_3d("vnet_64", c)
+    (OUT / "fullsize.json").write_text(json.dumps(out, indent=1))
+
+
 def main():
     what = sys.argv[1]
-    if what == "grads":
+    if what == "fullsize":
+        fullsize()
+    elif what == "grads":
         torch.set_num_threads(8)
         out = {n: grad_case(n, c) for n, c in GRAD_CASES.items()}
         (OUT / "cyclegan_grads.json").write_text(json.dumps(out, indent=1))

@@ -219,6 +219,14 @@ class RefOps:
 
     # ---- generalised norm / activation for skip-connection graphs (U-Net) -------------------------------
     @staticmethod
+    def _full_seed(seed, seed_dev):
+        """64-bit mask seed = host part + optional device part int32[2] (lo, hi), as in gs_norm_ex_desc.seed_dev"""
+        if seed_dev is None:
+            return seed
+        lo, hi = (int(v) & 0xFFFFFFFF for v in seed_dev.tolist())
+        return (seed + (hi << 32 | lo)) & 0xFFFFFFFFFFFFFFFF
+
+    @staticmethod
     def _drop_scale(shape, drop_p, seed):
         """same counter-based hash as ganslate_amd/csrc/norm_ex.hip (murmur3 finaliser), evaluated with int64"""
         N, H, W, Cc = shape
@@ -240,7 +248,8 @@ class RefOps:
         return torch.where(u >= drop_p, torch.full(shape, 1.0 / (1.0 - drop_p)), torch.zeros(shape))
 
     def norm_act_forward_ex(self, y, mean_rstd, x1, x2=None, act1="none", act2="none", slope=0.2, x1_co=0, x2_co=0,
-                            drop_p=0.0, seed=0):
+                            drop_p=0.0, seed=0, seed_dev=None):
+        seed = self._full_seed(seed, seed_dev)
         flat = lambda t: t if t is None or t.dim() == 4 else t.view(t.shape[0], -1, t.shape[-2], t.shape[-1])
         y, x1, x2 = flat(y), flat(x1), flat(x2)        # geometry-free: a volume is D*H rows
         N, H, W, Cc = y.shape
@@ -254,7 +263,8 @@ class RefOps:
             x2[..., x2_co:x2_co + Cc] = _act(v, act2, slope).to(x2.dtype)
 
     def norm_act_backward_ex(self, g1, g2, y, mean_rstd, dy, act1="none", act2="none", slope=0.2, g1_co=0, g2_co=0,
-                             drop_p=0.0, seed=0, bias_grad=None):
+                             drop_p=0.0, seed=0, bias_grad=None, seed_dev=None):
+        seed = self._full_seed(seed, seed_dev)
         flat = lambda t: t if t is None or t.dim() == 4 else t.view(t.shape[0], -1, t.shape[-2], t.shape[-1])
         g1, g2, y, dy = flat(g1), flat(g2), flat(y), flat(dy)
         N, H, W, Cc = y.shape

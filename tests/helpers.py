@@ -198,3 +198,34 @@ def run_product_cut_steps(model, c, n_steps):
         out.append({"lrs": dict(lrs), "losses": {k: float(v.detach()) for k, v in losses.items() if v is not None}})
         model.update_learning_rate()
     return out
+
+
+# ---- step-0 parameter gradients -----------------------------------------------------------------------------------------
+def load_golden_grads():
+    return json.loads((GOLD / "cyclegan_grads.json").read_text())
+
+
+FROZEN = ("train.gan.optimizer.lr_G=0.0", "train.gan.optimizer.lr_D=0.0")
+
+
+def adam_first_moments(model):
+    """{network: {tensor name: exp_avg in torch layout}} of a product model. With the learning rates at 0 the weights
+    never move, and after ONE iteration exp_avg = (1 - beta1) * g: the gradients exactly as the optimiser consumed them
+    (after gradient accumulation over the backward passes, the merged weight-gradient launches, the data-parallel
+    average), which `.grad` no longer shows because the update kernel clears it."""
+    out = {}
+    for optim in model.optimizers.values():
+        if not hasattr(optim, "param_groups"):
+            continue
+        for group in optim.param_groups:
+            for p in group["params"]:
+                net = getattr(p, "_owner_net", None)
+                if net is None or "exp_avg" not in optim.state[p]:
+                    continue
+                name = next(n for n, v in model.networks.items() if v is net)
+                keep, net.master.grad = net.master.grad, optim.state[p]["exp_avg"]
+                try:
+                    out[name] = {k: v.detach().float().cpu() for k, v in net.grads_state_dict().items()}
+                finally:
+                    net.master.grad = keep
+    return out

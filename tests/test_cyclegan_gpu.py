@@ -113,6 +113,21 @@ def test_resnet2d_matches_reference_golden(hip_ops):
     assert abs(y.double().abs().sum().item() - gold["y_abs_sum"]) <= 2e-2 * gold["y_abs_sum"]
 
 
+from .envelope import step_tolerance  # noqa: E402
+
+
+def _check_steps(got, gold_steps, n_steps, metrics=True):
+    for s in range(n_steps):
+        g = gold_steps[s]
+        assert got[s]["lrs"] == pytest.approx(g["lrs"], abs=1e-12)
+        assert set(got[s]["losses"]) == set(g["losses"])
+        for k, v in g["losses"].items():
+            assert got[s]["losses"][k] == pytest.approx(v, rel=step_tolerance(k, s)), (s, k, got[s]["losses"][k], v)
+        if metrics and s == 0:
+            for k, v in g["metrics"].items():
+                assert got[s]["metrics"][k] == pytest.approx(v, rel=2e-2, abs=1e-2), (s, k)
+
+
 @pytest.mark.parametrize("name", ["c64_default", "c64_idt_ssim", "cfg1_256"])
 def test_training_step_matches_reference_golden(hip_ops, name):
     gold = load_golden_steps()[name]
@@ -120,17 +135,46 @@ def test_training_step_matches_reference_golden(hip_ops, name):
     n_steps = min(c["steps"], 6)
     model = build_product_cyclegan(c)
     got = run_product_steps(model, c, n_steps)
-    for s in range(n_steps):
-        g = gold["steps"][s]
-        assert got[s]["lrs"] == pytest.approx(g["lrs"], abs=1e-12)
-        assert set(got[s]["losses"]) == set(g["losses"])
-        tol_adv, tol_cyc = (2e-2, 2e-2) if s == 0 else (0.25, 0.03)
-        for k, v in g["losses"].items():
-            tol = tol_cyc if k.startswith(("cycle", "idt")) else tol_adv
-            assert got[s]["losses"][k] == pytest.approx(v, rel=tol), (s, k, got[s]["losses"][k], v)
-        for k, v in g["metrics"].items():
-            if s == 0:
-                assert got[s]["metrics"][k] == pytest.approx(v, rel=2e-2, abs=1e-2), (s, k)
+    _check_steps(got, gold["steps"], n_steps)
+
+
+def test_training_step_at_headline_shape_matches_reference_golden(hip_ops):
+    """BASELINE configs[1] (256x256, batch 8: the shape bench.py times, with its own tile selection — gconv<320,128>,
+    hconvw, hwgrad_wide pairs) against two iterations of the real reference (tests/golden/cyclegan_grads.json)"""
+    from .helpers import load_golden_grads
+    gold = load_golden_grads()["cfg2_256_b8"]
+    c = gold["config"]
+    model = build_product_cyclegan(c)
+    got = run_product_steps(model, c, 2)
+    _check_steps(got, gold["steps"], 2)
+
+
+def test_loss_curve_100_iterations_inside_the_reference_envelope(hip_ops):
+    """north_star: "loss curves matching reference over 100 steps". The reference does not match ITSELF point-wise over
+    100 iterations when only its thread count changes (tests/golden/envelope.json: 1e-3 at iteration 3, tens of percent
+    from iteration ~10); what is checked is that the HIP path stays inside that scatter: every iteration within the
+    envelope-derived tolerance while that is below 50 %, and decade means afterwards."""
+    from .envelope import family, reference_curve, window_tolerance
+    c, curve = reference_curve()
+    model = build_product_cyclegan(c)
+    got = run_product_steps(model, c, c["steps"])
+    keys = list(curve[0]["losses"])
+    worst = {}
+    for s in range(c["steps"]):
+        for k in keys:
+            tol = step_tolerance(k, s)
+            if tol < 0.5:
+                ref, mine = curve[s]["losses"][k], got[s]["losses"][k]
+                worst[k] = max(worst.get(k, 0.0), abs(mine - ref) / abs(ref) / tol)
+                assert mine == pytest.approx(ref, rel=tol), (s, k, mine, ref, tol)
+    for k in keys:
+        ref = torch.tensor([s["losses"][k] for s in curve])
+        mine = torch.tensor([s["losses"][k] for s in got])
+        for lo in range(0, c["steps"], 10):
+            r, m = ref[lo:lo + 10].mean().item(), mine[lo:lo + 10].mean().item()
+            tol = window_tolerance(family(k), 10)      # 3 x the 1-vs-8-thread gap of the decade means: 2 % / 31 %
+            assert abs(m - r) <= tol * abs(r), (k, lo, m, r, tol)
+    print("\nworst |err| / tolerance per loss:", {k: round(v, 3) for k, v in worst.items()})
 
 
 def test_loss_curve_stays_in_reference_envelope(hip_ops):
@@ -144,5 +188,5 @@ def test_loss_curve_stays_in_reference_envelope(hip_ops):
         mine = torch.tensor([s["losses"][k] for s in got])
         for lo, hi in ((0, 10), (10, 20), (20, 30)):
             r, m = ref[lo:hi].mean().item(), mine[lo:hi].mean().item()
-            tol = 0.03 if k.startswith("cycle") else 0.30
-            assert abs(m - r) <= tol * abs(r), (k, lo, m, r)
+            from .envelope import family, window_tolerance
+            assert abs(m - r) <= window_tolerance(family(k), 10) * abs(r), (k, lo, m, r)

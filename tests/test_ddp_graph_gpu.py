@@ -61,3 +61,64 @@ def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch):
         assert [st["step"] for st in live.optimizers["G"].state.values()] == [6, 6]
     finally:
         dist.destroy_process_group()
+
+
+# ---- two ranks over RCCL (runs the moment the box has >= 2 GPUs; the 1-GPU pool skips it) -----------------------------
+def _rccl_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import random
+    import torch.distributed as dist
+    from ganslate_amd.utils import communication
+    from tests.helpers import FROZEN, adam_first_moments, golden_inputs
+    communication.init_distributed()
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    c["pool_size"], c["batch"] = 0, 1
+    random.seed(c["seed"])
+    model = build_product_cyclegan(c, FROZEN)
+    A, B = golden_inputs(dict(c, batch=world), 0)
+    for _ in range(3):                       # launch by launch (bucketed, overlapped), capture, replay
+        model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    assert model._graph is not None and model._graph_update is not None
+    torch.save({"moments": adam_first_moments(model),
+                "losses": {k: float(v.detach()) for k, v in model.losses.items() if v is not None}},
+               Path(out_dir) / f"rccl_rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_over_rccl_average_to_the_big_batch_gradient(hip_ops, tmp_path):
+    """2 ranks x batch 1 over RCCL (xGMI) against one process on the batch of 2: with frozen weights Adam's first
+    moment after three identical iterations is 0.875 * g, and the averaged rank gradients must equal the big-batch
+    gradient (InstanceNorm is per sample, every loss a batch mean — SURVEY.md §8e)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import random
+    import torch.multiprocessing as mp
+    from tests.helpers import FROZEN, adam_first_moments, golden_inputs
+    world = 2
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rccl_rank{r}.pt") for r in range(world))
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    c["pool_size"], c["batch"] = 0, 2
+    random.seed(c["seed"])
+    single = build_product_cyclegan(c, FROZEN)
+    A, B = golden_inputs(c, 0)
+    for _ in range(3):
+        single.set_input({"A": A, "B": B})
+        single.optimize_parameters()
+    torch.cuda.synchronize()
+    want = adam_first_moments(single)
+    for net, per in want.items():
+        for n, w in per.items():
+            assert torch.equal(r0["moments"][net][n], r1["moments"][net][n]), (net, n, "ranks differ")
+            if w.norm().item() > 1e-9:
+                assert (r0["moments"][net][n] - w).norm().item() <= 2e-2 * w.norm().item(), (net, n)

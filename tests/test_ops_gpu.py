@@ -181,6 +181,51 @@ def test_wgrad_and_bias_grad(hip_ops, case):
     close_f32(res[1][1], res[0][1], "bias grad")
 
 
+WGRAD_PAIR_CASES = [
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),                       # headline RB conv (cfg2)
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 2, 16, 16),
+    (ConvSpec("conv", 128, 128, 3, 1, 1, pad_mode="reflect"), 1, 24, 40),                       # ragged boxes
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),         # cfg5 RB: 3 depth planes
+    (ConvSpec("conv", 64, 64, 3, 1, 1, pad_mode="replicate", dims=3), 2, 6, 10, 12),
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 2, 32, 32),                                            # not mergeable: two launches
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PAIR_CASES, ids=_ids)
+@pytest.mark.parametrize("planes", ["1", "0"])
+def test_wgrad_pair_vs_oracle(hip_ops, case, planes, monkeypatch):
+    """gs_wgrad_pair — the launch that carries the weight gradients of the residual convs in a CycleGAN step (two
+    backward passes of one generator, cyclegan.py:139-150) — against the oracle's two separate accumulations, on the
+    wide halo kernel (2-D: one launch; 3x3x3: three depth planes, GS_HWGRAD_PLANES=1) and on the im2col kernel"""
+    monkeypatch.setenv("GS_HWGRAD_PLANES", planes)
+    hip_ops.sync_options()
+    spec, N, sizes = case[0], case[1], case[2:]
+    if planes == "0" and spec.dims == 2:
+        pytest.skip("GS_HWGRAD_PLANES only changes the 3-D lowering")
+    low = lower(spec, *sizes)
+    g = torch.Generator().manual_seed(27)
+
+    def operands():
+        xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
+        xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
+        gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+        gy[..., :spec.cout] = torch.randn(N, *low.out_dims, spec.cout, generator=g).to(torch.bfloat16)
+        return (gy, xa) if spec.kind == "conv" else (xa, gy)
+    (a1, g1), (a2, g2) = operands(), operands()
+    res = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        dw = torch.full((spec.P * spec.T * spec.Q,), 0.5, dtype=torch.float32, device=dev)   # accumulate semantics
+        ops.wgrad(low.wgrad, a1.to(dev), g1.to(dev), dw, pair=(a2.to(dev), g2.to(dev)))
+        res.append(dw)
+    torch.cuda.synchronize()
+    close_f32(res[1], res[0], "wgrad pair")
+    # ... and the merged launch equals two single launches of the product
+    dw2 = torch.full_like(res[1], 0.5)
+    hip_ops.wgrad(low.wgrad, a1.to(hip_ops.device), g1.to(hip_ops.device), dw2)
+    hip_ops.wgrad(low.wgrad, a2.to(hip_ops.device), g2.to(hip_ops.device), dw2)
+    close_f32(res[1], dw2.cpu(), "pair vs two launches", rel=1e-3)
+
+
 @pytest.mark.parametrize("case", [
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 2, 16, 16),
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),                       # 320-pixel tiles

@@ -29,9 +29,9 @@ def test_pix2pix_step_matches_reference_golden(hip_ops, name):
     for s in range(n_steps):
         g = gold["steps"][s]
         assert got[s]["lrs"] == pytest.approx(g["lrs"], abs=1e-12)
-        tol_adv, tol_l1 = (2e-2, 2e-2) if s == 0 else (0.30, 0.03)
+        from .envelope import step_tolerance      # iteration 0: 2e-2; later: the reference's own scatter (envelope.json)
         for k, v in g["losses"].items():
-            assert got[s]["losses"][k] == pytest.approx(v, rel=tol_l1 if k == "pix2pix" else tol_adv), (s, k)
+            assert got[s]["losses"][k] == pytest.approx(v, rel=step_tolerance(k, s, {"adv": 2e-2, "cycle": 2e-2})), (s, k)
 
 
 def test_pix2pix_cfg3_full_width_runs(hip_ops):
@@ -45,3 +45,64 @@ def test_pix2pix_cfg3_full_width_runs(hip_ops):
     for s in got:
         for k, v in s["losses"].items():
             assert v == v and 0 < v < 1e3, (k, v)
+
+
+def test_dropout_mask_changes_between_graph_replays(hip_ops):
+    """nn.Dropout(0.5) of the pix2pix U-Net (unet2d.py:146-147) draws a new mask every forward. The
+    captured step replays its launches with identical arguments, so the mask seed is read from device memory and
+    refreshed by the recipe before every replay: with the weights frozen and the SAME batch every iteration, the
+    generator output must still change from replay to replay (and must not when dropout is off)."""
+    import random
+    from .helpers import p2p_inputs
+    outs = {}
+    for use_dropout in (True, False):
+        c = dict(size=[64, 128], batch=2, steps=5, n_iters=100, n_iters_decay=100, num_downs=6, ngf=16,
+                 use_dropout=use_dropout, n_layers=3, lambda_pix2pix=30.0, seed=34)
+        model = build_product_pix2pix(c, ("train.gan.optimizer.lr_G=0.0", "train.gan.optimizer.lr_D=0.0"))
+        random.seed(7)
+        A, B = p2p_inputs(c, 0)
+        fakes = []
+        for s in range(5):
+            model.set_input({"A": A, "B": B})
+            model.optimize_parameters()
+            torch.cuda.synchronize()
+            fakes.append(model.visuals["fake_B"].detach().float().cpu().clone())
+        assert model._graph is not None, "iterations 3-5 must have been graph replays"
+        outs[use_dropout] = fakes
+    for i in range(5):
+        for j in range(i + 1, 5):
+            assert not torch.equal(outs[True][i], outs[True][j]), f"iterations {i} and {j} used the same dropout mask"
+            assert torch.equal(outs[False][i], outs[False][j]), "without dropout the frozen generator is deterministic"
+    # the masks drop half of the dropout layers' activations: outputs differ visibly, not by rounding
+    assert (outs[True][3] - outs[True][4]).abs().mean().item() > 1e-3
+
+
+def test_pix2pix_data_parallel_graph_step(hip_ops, monkeypatch):
+    """the U-Net's backward must not issue its own bucketed all-reduce inside a captured
+    data-parallel step (the runner reduces between its two graphs). 1-rank RCCL group, GS_FORCE_DDP."""
+    import datetime
+    import torch.distributed as dist
+    from .test_ddp_graph_gpu import _free_port
+    c = dict(size=[64, 128], batch=2, steps=4, n_iters=100, n_iters_decay=100, num_downs=5, ngf=16,
+             use_dropout=False, n_layers=3, lambda_pix2pix=30.0, seed=35)
+    frozen = ("train.gan.optimizer.lr_G=0.0", "train.gan.optimizer.lr_D=0.0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    single = build_product_pix2pix(c, frozen)
+    want = run_product_pix2pix_steps(single, c, 4)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            timeout=datetime.timedelta(minutes=2))
+    try:
+        monkeypatch.setenv("GS_FORCE_DDP", "1")
+        ddp = build_product_pix2pix(c, frozen)
+        got = run_product_pix2pix_steps(ddp, c, 4)
+        torch.cuda.synchronize()
+        assert ddp._graph is not None and ddp._graph_update is not None
+        for s in range(4):
+            for k, v in want[s]["losses"].items():
+                assert got[s]["losses"][k] == pytest.approx(v, rel=1e-4, abs=1e-6), (s, k)
+        for oa, ob in zip(single.optimizers.values(), ddp.optimizers.values()):
+            for pa, pb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
+                a, b = oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]
+                assert (a - b).norm().item() <= 1e-3 * a.norm().item()
+    finally:
+        dist.destroy_process_group()

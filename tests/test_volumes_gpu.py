@@ -9,7 +9,7 @@ import torch
 
 from oracle import torch_ref
 
-from .helpers import build_product_cyclegan3d, load_golden_volumes, run_product_volume_steps
+from .helpers import build_product_cyclegan3d, load_golden_volumes, run_product_volume_steps, volume_inputs
 from .test_cyclegan_gpu import _net_case, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -67,10 +67,59 @@ def test_volume_training_step_matches_reference_golden(hip_ops, name):
         assert set(got[s]["losses"]) == set(g["losses"])
         # after the first updates the trajectory is only statistically pinned: on these tiny volumes the
         # third iteration's cycle terms sit 2.9-3.5 % from the reference's whichever summation order the kernels use
-        tol_adv, tol_cyc = (2e-2, 2e-2) if s == 0 else (0.25, 0.05)
+        from .envelope import step_tolerance      # iteration 0: 2e-2; later: the reference's own scatter (envelope.json)
         for k, v in g["losses"].items():
-            tol = tol_cyc if k.startswith(("cycle", "idt")) else tol_adv
+            tol = step_tolerance(k, s, {"adv": 2e-2, "cycle": 2e-2})
             assert got[s]["losses"][k] == pytest.approx(v, rel=tol), (s, k, got[s]["losses"][k], v)
         if s == 0:
             for k, v in g["metrics"].items():
                 assert got[s]["metrics"][k] == pytest.approx(v, rel=2e-2, abs=1e-2), (s, k)
+
+
+def test_brats_step_at_64_cubed_matches_reference_golden(hip_ops):
+    """BASELINE configs[4] networks (brats yaml: Vnet3D 16 / [2,2,3] / [3,3,3] + PatchGAN3D n_layers 2) at 64^3 against
+    two iterations of the real reference (tests/golden/fullsize.json)"""
+    import json
+    from .envelope import step_tolerance
+    from .helpers import GOLD
+    gold = json.loads((GOLD / "fullsize.json").read_text())["vnet_64"]
+    c = gold["config"]
+    got = run_product_volume_steps(build_product_cyclegan3d(c), c, c["steps"])
+    for s in range(c["steps"]):
+        for k, v in gold["steps"][s]["losses"].items():
+            tol = step_tolerance(k, s, {"adv": 2e-2, "cycle": 2e-2})
+            assert got[s]["losses"][k] == pytest.approx(v, rel=tol), (s, k, got[s]["losses"][k], v)
+
+
+def test_brats_step_at_128_cubed_properties(hip_ops):
+    """BASELINE configs[4] at its full size (128^3 per rank): no CPU reference finishes in test time, so size-independent
+    properties of the step are checked instead. With frozen weights and an empty image pool an iteration is a pure
+    function of its batch: (i) the same volume twice in a batch of 2 gives the batch-1 losses (every loss is a mean over
+    per-sample terms and InstanceNorm is per sample); (ii) repeating the iteration reproduces it; (iii)
+    the first moments of Adam — the gradients — of the batch-2 run equal those of the batch-1 run."""
+    from .helpers import FROZEN, adam_first_moments
+    c = dict(size=[128, 128, 128], batch=1, steps=1, n_iters=100, n_iters_decay=100, pool_size=0, lambda_identity=0.0,
+             proportion_ssim=0.0, d_layers=2, seed=55,
+             vnet=dict(first_layer_channels=16, down_blocks=[2, 2, 3], up_blocks=[3, 3, 3]))
+    A, B = volume_inputs(c, 0)
+    runs = {}
+    for batch in (1, 2):
+        model = build_product_cyclegan3d(dict(c, batch=batch), FROZEN)
+        rec = []
+        for _ in range(2):
+            model.set_input({"A": A.repeat(batch, 1, 1, 1, 1), "B": B.repeat(batch, 1, 1, 1, 1)})
+            model.optimize_parameters()
+            torch.cuda.synchronize()
+            rec.append({k: float(v.detach()) for k, v in model.losses.items() if v is not None})
+        runs[batch] = (rec, adam_first_moments(model))
+        del model
+        torch.cuda.empty_cache()
+    for k, v in runs[1][0][0].items():
+        assert v == v and 0 < v < 1e3, (k, v)
+        assert runs[1][0][1][k] == pytest.approx(v, rel=1e-4), ("repeat", k)
+        assert runs[2][0][0][k] == pytest.approx(v, rel=2e-3), ("batch 2 of the same volume", k)
+    for net, per in runs[1][1].items():
+        for n, g1 in per.items():
+            g2 = runs[2][1][net][n]
+            if g1.norm().item() > 1e-8:
+                assert (g1 - g2).norm().item() <= 2e-2 * g1.norm().item(), (net, n)
