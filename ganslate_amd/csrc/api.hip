@@ -11,7 +11,7 @@ void* g_zero = nullptr;      // 256-byte zero page: source of masked LDS-DMA lan
 // Loss reductions: 1024 partials + 1 arrival counter per workspace. Launches on one stream are ordered and share a
 // workspace; launches on different streams may overlap (the discriminator pass runs beside the generators' backward),
 // so every stream that ever launched a reduction owns one of GS_WS_SLOTS workspaces.
-constexpr int GS_WS_SLOTS = 16;
+constexpr int GS_WS_SLOTS = 256;     // torch hands out streams from pools of 32 per priority: far below this
 constexpr int GS_WS_FLOATS = 1040;
 float* g_reduce_ws = nullptr;
 void* g_ws_stream[GS_WS_SLOTS] = {};

