@@ -49,12 +49,13 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"splitk_target", 256},     // ... aiming at this many workgroups
     {"hconv", 1},               // halo-resident forward kernel for narrow stride-1 layers (hconv.hip)
     {"hconv_wide", 1},          // halo-resident forward kernel for the wide 3x3 layers (hconvw.hip)
-    {"hconvw_waves", 16},       // 16 or 8 waves per workgroup in hconvw_kernel
+    {"hconvw_waves", 16},       // 16 or 8 (64 x 64 wave tiles) waves per workgroup: equal in an interleaved A/B (39.9 vs 40.5 us)
     {"hwgrad", 1},              // halo-resident weight-gradient kernels (hwgrad.hip)
     {"hwgrad_wide", 1},         // ... the wide 3x3 form
     {"hwgrad_planes", 1},       // ... 3x3x3 layers as three depth planes of it
     {"norm_bwd_ppb", 0},        // pixels per workgroup of the norm-backward reduction (0 = heuristic; tuning aid)
     {"norm_apply_unroll", 4},   // elements per thread of the norm-backward apply pass (tuning aid)
+    {"debug", 0},               // TEMPORARY timing experiments
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/ganslate_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -28,6 +29,53 @@ __device__ __forceinline__ unsigned short f2bf(float a) { return (unsigned short
 // 16-byte LDS-DMA: LDS destination = wave-uniform base + lane*16; global source is per lane.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(GS_GLB(gsrc), GS_LDS(lds_wave_base), 16, 0, 0);
+}
+
+// ---- LDS fragment reads the compiler does not count --------------------------------------------------------------
+// With an LDS-DMA (global_load_lds) anywhere in a loop, hipcc (ROCm 7.2) no longer emits counted lgkmcnt(N) waits for
+// ds_read results: every consumer waits lgkmcnt(0), i.e. also for the reads issued AFTER the ones it needs (the
+// software-pipelined "issue the next fragments, then run the MFMAs on the current ones" degenerates into read - wait -
+// MFMA; verified on a 20-line kernel: lgkmcnt(6)/(5)/(4) ladders without the DMA, lgkmcnt(0) with it). Reads issued
+// through these statements are invisible to that bookkeeping; the kernel waits for them itself with gs_lgkm_wait<N>(...)
+// naming every destination ("+v": no consumer can be scheduled above the wait, cdna_hip_programming.md §5.7 form (ii)).
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gs_lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gs_lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f,
+                                             bf16x8& g, bf16x8& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "i"(N) : "memory");
+}
+
+// 64-bit transpose read (pixel-major operands of the weight-gradient kernels): 4 bf16 of one k-column per lane
+template <int OFF>
+__device__ __forceinline__ void lds_read64_tr(uint2& v, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gs_lgkm_wait64(uint2& a, uint2& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gs_lgkm_wait64(uint2& a, uint2& b, uint2& c, uint2& d, uint2& e, uint2& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N) : "memory");
+}
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
 }
 
 // m / d for 0 <= m < 2^24 with rcp = 1.0f/d (exact after one fix-up step each way)
@@ -64,6 +112,27 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act, float slope
   return 1.f;
 }
 
+// ---- lane reductions on the DPP path -----------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32: an LDS instruction with ~100 cycles of latency per step. The statistics
+// epilogue of the conv kernels ran 64 of them per wave in dependent chains of four (4.5 us of a 44 us launch, measured
+// by leaving the statistics out). The same sums through DPP modifiers are plain VALU adds (v_add_f32_dpp).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in all of them
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror: quads 0<->1, 2<->3 (values are quad-uniform by now)
+  v += dpp_mov<0x140>(v);    // row_mirror: halves of the row
+  return v;
+}
+// v[i] + v[i ^ STEP] for lanes whose values are NOT uniform below STEP (lane i keeps its low bits): STEP = 4, 8 inside a
+// row via rotations (ror:4 then ror:8 sums the 4 lanes with equal i mod 4; ror:8 alone the 2 with equal i mod 8)
+__device__ __forceinline__ float row_sum_stride4(float v) { v += dpp_mov<0x124>(v); v += dpp_mov<0x128>(v); return v; }
+__device__ __forceinline__ float row_sum_stride8(float v) { v += dpp_mov<0x128>(v); return v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -73,7 +142,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // kernel-selection switches (api.hip; set through gs_set_option, never read from the environment by the library)
 enum GsOpt {
   GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE, GS_OPT_HCONVW_WAVES,
-  GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL,
+  GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL, GS_OPT_DEBUG,
   GS_OPT_COUNT
 };
 int gs_opt(int id);

@@ -305,8 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float a = s1[i][r], q = s2[i][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        a = row16_sum(a);
+        q = row16_sum(q);
         if (frow == 0) {
           const int cl = wn * (BN / WN) + i * 16 + fk * 4 + r;
           red[(wm * BN + cl) * 2 + 0] = a;
@@ -403,8 +403,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       float* red3 = reinterpret_cast<float*>(smem);   // [WM][BN][3]
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
+        // inside a 16-lane row through DPP rotations, across the 4 rows through the (LDS) permute
+        if constexpr (LPR == 4) { fa1[k] = row_sum_stride4(fa1[k]); fa2[k] = row_sum_stride4(fa2[k]); fa3[k] = row_sum_stride4(fa3[k]); }
+        else if constexpr (LPR == 8) { fa1[k] = row_sum_stride8(fa1[k]); fa2[k] = row_sum_stride8(fa2[k]); fa3[k] = row_sum_stride8(fa3[k]); }
+        else {
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) {
+          for (int o = LPR; o < 16; o <<= 1) {
+            fa1[k] += __shfl_xor(fa1[k], o, 64); fa2[k] += __shfl_xor(fa2[k], o, 64); fa3[k] += __shfl_xor(fa3[k], o, 64);
+          }
+        }
+#pragma unroll
+        for (int o = (LPR > 16 ? LPR : 16); o < 64; o <<= 1) {
           fa1[k] += __shfl_xor(fa1[k], o, 64);
           fa2[k] += __shfl_xor(fa2[k], o, 64);
           fa3[k] += __shfl_xor(fa3[k], o, 64);

@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float a = s1[i][r], q = s2[i][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        a = row16_sum(a);
+        q = row16_sum(q);
         if (row == 0) {
           const int c = i * 16 + kg * 4 + r;
           red[(wave * 64 + c) * 2 + 0] = a;

@@ -11,6 +11,7 @@
 // contract as gconv_kernel (bias, one statistics slot per box, activation, dense or sliced output).
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 struct HConvWK {
   const char* in;
@@ -124,13 +125,29 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   // reads of the second half are issued before the MFMAs of the first, and the reads of the NEXT step's first half
   // (after the one barrier per K-step) before the MFMAs of the second: LDS latency hides under the matrix pipe.
   const int nk = p.chunks * T;
-  auto load_frags = [&](const char* wb, const char* xb, int kk, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
-    const int coff = ((kk * 4 + fk) ^ swz) << 4;
+  // Fragment reads go through lds_read128 (common.hpp): the compiler would wait lgkmcnt(0) before every MFMA block
+  // because of the LDS-DMA in the loop; here block A waits with lgkmcnt(TI + TJ), i.e. only for ITS fragments while the
+  // TI + TJ reads of block B issued after them are still in flight.
+  const unsigned smem0 = lds_addr(smem);
+  const unsigned woff = (unsigned)((wn * CWV + frow) * 128);
+  const unsigned c0 = (unsigned)(((0 * 4 + fk) ^ swz) << 4), c1 = (unsigned)(((1 * 4 + fk) ^ swz) << 4);
+  auto load_frags = [&](unsigned wb, unsigned xb, auto kk_tag, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
+    constexpr int kk = decltype(kk_tag)::value;
+    const unsigned wa = wb + (kk ? c1 : c0);
+    lds_read128<0>(wf[0], wa);
+    lds_read128<2048>(wf[1], wa);
+    if constexpr (TI == 4) { lds_read128<4096>(wf[2], wa); lds_read128<6144>(wf[3], wa); }
 #pragma unroll
-    for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + coff);
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + rowb[j] + kk * 64);
+    for (int j = 0; j < TJ; ++j) lds_read128<kk * 64>(xf[j], xb + (unsigned)rowb[j]);
   };
+  auto wait_frags = [&](auto n_tag, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
+    constexpr int n = decltype(n_tag)::value;
+    if constexpr (TI == 2) gs_lgkm_wait<n>(wf[0], wf[1], xf[0], xf[1], xf[2], xf[3]);
+    else gs_lgkm_wait<n>(wf[0], wf[1], wf[2], wf[3], xf[0], xf[1], xf[2], xf[3]);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using NF = std::integral_constant<int, TI + TJ>;
   auto mma = [&](const bf16x8 (&wf)[TI], const bf16x8 (&xf)[TJ]) {
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -139,48 +156,68 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   };
   auto ct_of = [&](int ks, int& c, int& t) { c = ks / T; t = ks - c * T; };
+  // ---- main loop: two wave groups, one phase apart ----------------------------------------------------------------
+  // Measured on the barrier-per-K-step loop this replaces (profiles/r01_hconvw_pmc.txt): matrix pipe busy 45 %, LDS
+  // array busy 42 %, and a K-step took the SUM of its fragment-read time and its MFMA time — the barrier phase-locks all
+  // 16 waves, so everybody queues on the LDS (SQ_WAIT_INST_LDS 17 % of the wave cycles) and then everybody queues on the
+  // matrix pipe. Here a K-step is two phases separated by barriers, L = issue the 2*(TI+TJ) fragment reads of the step
+  // and wait for them, M = its 2*TI*TJ MFMAs, and the upper half of the waves executes ONE extra barrier up front: from
+  // then on one group is always in L while the other is in M (each SIMD hosts waves of both groups), the LDS and the
+  // matrix pipe work at the same time, and priority is raised for the M phase (cdna_hip_programming.md T3-T5).
+  // LDS-DMA: weights of step ks+2 go into the slot of step ks-1 at the start of L(ks) (that slot's last reader finished
+  // a phase ago), the halo of chunk c+1 into the buffer of chunk c-1 at the first L of chunk c; a wave waits for its
+  // share of step ks+1's weights at the end of the last phase before the first reader (group 0: end of M(ks), group 1:
+  // end of L(ks)) and the barrier that follows publishes it.
+  const bool grp = wave >= NW / 2;
   issue_halo(0, 0);
   if (p.chunks > 1) issue_halo(1, 1);
 #pragma unroll
   for (int s0 = 0; s0 < 3; ++s0)
-    if (s0 < nk) { int c0, t0; ct_of(s0, c0, t0); issue_w(c0, t0, s0); }
+    if (s0 < nk) { int c0_, t0; ct_of(s0, c0_, t0); issue_w(c0_, t0, s0); }
   // halo 0 (and, in order, halo 1) and weights 0 landed; weights 1, 2 may still fly
   if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPI) : "memory");
   else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();
+  const unsigned wring0 = smem0 + woff, hbuf0 = smem0 + 3 * WT;
   bf16x8 wA[TI], xA[TJ], wB[TI], xB[TJ];
-  load_frags(wring + (wn * CWV + frow) * 128, hbuf + tb[0], 0, wA, xA);
   int stage = 0;
   for (int c = 0; c < p.chunks; ++c) {
-    const char* hb = hbuf + (c & 1) * HBUF;
+    const unsigned hb = hbuf0 + (unsigned)((c & 1) * HBUF);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int ks = c * T + t;
-      const char* wb = wring + stage * WT + (wn * CWV + frow) * 128;
-      load_frags(wb, hb + tb[t], 1, wB, xB);
+      // ---- L(ks) ----
+      const bool halo_now = t == 0 && c >= 1 && c + 1 < p.chunks;
+      if (halo_now) issue_halo(c + 1, (c + 1) & 1);
+      if (ks >= 1 && ks + 2 < nk) { int c2, t2; ct_of(ks + 2, c2, t2); issue_w(c2, t2, stage == 0 ? 2 : stage - 1); }
+      load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K0{}, wA, xA);
+      load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K1{}, wB, xB);
+      wait_frags(std::integral_constant<int, 0>{}, wA, xA);
+      wait_frags(std::integral_constant<int, 0>{}, wB, xB);
+      auto wait_next_weights = [&]() {       // this wave's share of step ks+1's weights (and anything older) has landed
+        if (ks + 1 >= nk) return;
+        if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");     // w1 | w2 outstanding
+        else if (halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
+      };
+      if (grp) wait_next_weights();
+      __builtin_amdgcn_s_barrier();
+      // ---- M(ks) ----
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
       mma(wA, xA);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks + 1 < nk) {
-        // weights ks+1 landed, this wave's reads of slot `stage` (and, at t == T-1, of this chunk's halo) returned
-        if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (t == 0 && c >= 1 && c + 1 < p.chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(HPW + WPI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPI) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t == T - 1 && c + 2 < p.chunks) issue_halo(c + 2, c & 1);
-        if (ks + 3 < nk) { int c3, t3; ct_of(ks + 3, c3, t3); issue_w(c3, t3, stage); }
-        const int nstage = stage == 2 ? 0 : stage + 1;
-        const char* nwb = wring + nstage * WT + (wn * CWV + frow) * 128;
-        const char* nxb = (t == T - 1) ? hbuf + ((c + 1) & 1) * HBUF + tb[0] : hb + tb[t + 1 < T ? t + 1 : 0];
-        load_frags(nwb, nxb, 0, wA, xA);
-        stage = nstage;
-      }
-      __builtin_amdgcn_sched_barrier(0);
       mma(wB, xB);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (!grp) wait_next_weights();
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
     }
   }
+  if (!grp) __builtin_amdgcn_s_barrier();       // group 1 ran one barrier ahead of the loop: every wave has passed the same count
   f32x4 bia[TI];                                // loaded after the loop: inside it they would spill (128-VGPR cap)
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
@@ -240,8 +277,8 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float a = s1[i][r], q = s2[i][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+        a = row16_sum(a);
+        q = row16_sum(q);
         if (frow == 0) {
           const int cl = wn * CW + i * 16 + fk * 4 + r;
           red[(wm * BN + cl) * 2 + 0] = a;

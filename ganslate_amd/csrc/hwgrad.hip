@@ -13,6 +13,7 @@
 // loop issues 2 transpose reads per MFMA; atomics happen once per workgroup at the end.
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 struct HWGradK {
   const char* a;
@@ -28,6 +29,11 @@ struct HWGradK {
   int nbd, nbh, nbw;
   int nboxes;            // N * nbd * nbh * nbw
   int qchunks, phalves, tgroups;
+  // deterministic accumulation (gs_wgrad_ws): workgroups that share output elements (the box groups, blockIdx.x) write
+  // their partial sums to slab blockIdx.x of ws ([slabs][P * dw_ld] floats, dw's own layout) instead of fp32 atomics
+  // on dw; wgrad_reduce_kernel then adds the slabs in a fixed order
+  float* ws;
+  long long ws_stride;
   gs_wgrad_desc d;
 };
 
@@ -159,7 +165,11 @@ __global__ __launch_bounds__(512) void hwgrad_kernel(const HWGradK p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pp = pch0 + i * 16 + fk * 4 + r;
-          if (pp < d.P) unsafeAtomicAdd(p.dw + (size_t)pp * d.dw_ld + tap * d.Q + q, acc[t][i][r]);
+          if (pp < d.P) {
+            const size_t e = (size_t)pp * d.dw_ld + tap * d.Q + q;
+            if (p.ws) p.ws[(size_t)blockIdx.x * p.ws_stride + e] = acc[t][i][r];
+            else unsafeAtomicAdd(p.dw + e, acc[t][i][r]);
+          }
         }
     }
   }
@@ -298,52 +308,45 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this box landed (nothing else is outstanding)
     __syncthreads();                                     // ... for every wave; the other buffer is fully consumed
     if (box + (int)gridDim.x < p.nboxes) issue_box(box + gridDim.x, cur ^ 1);
-    // address-space-3 base pointers once per box: per-read addresses are then 32-bit adds (a generic -> LDS cast per
-    // read was a third of the loop's VALU work)
-    typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* at3 = (lds_char*)GS_LDS(at_of(cur));
-    lds_char* halo3 = (lds_char*)GS_LDS(halo_of(cur));
-    auto tr64 = [](lds_char* a) {
-      return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a));
-    };
-    // fragments of K-step ks: 2 dense + T gathered (T == TMAX, host dispatch)
-    auto load_frags = [&](int ks, bf16x8 (&af)[2], bf16x8 (&gf)[TMAX]) {
+    // ---- 8 K-steps x T taps as a rolling pipeline of "units" (one tap of one K-step = 2 transpose reads of the gathered
+    // fragment, plus the 4 reads of the K-step's two dense fragments in front of tap 0; 2 MFMAs) ---------------------
+    // The reads go through inline asm (common.hpp, lds_read128 family): with the LDS-DMA in this loop hipcc waits
+    // lgkmcnt(0) before every MFMA block, and the 22 reads of a K-step do not even fit the 4-bit counter, so the former
+    // "issue the next K-step's reads, then run this one's MFMAs" ran read - wait - MFMA (matrix pipe 38 % busy, LDS 23 %).
+    // Here the reads of unit u + D are issued before the MFMAs of unit u and the wait in front of those MFMAs counts the
+    // reads issued after unit u's own (<= 14).
+    const unsigned at_a = lds_addr(at_of(cur)), ha = lds_addr(halo_of(cur));
+    constexpr int D = 5, NU = 8 * TMAX;
+    uint2 glo[D + 1], ghi[D + 1], alo[2][2], ahi[2][2];
+    auto issue_unit = [&](auto uu) {
+      constexpr int u = decltype(uu)::value, ks = u / TMAX, t = u % TMAX, slot = u % (D + 1);
+      if constexpr (t == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint2 lo = tr64(at3 + aoff[i][0] + ks * (32 * APITCH));
-        const uint2 hi = tr64(at3 + aoff[i][1] + ks * (32 * APITCH));
-        af[i] = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+        for (int i2 = 0; i2 < 2; ++i2) {
+          lds_read64_tr<ks * 32 * APITCH>(alo[ks & 1][i2], at_a + (unsigned)aoff[i2][0]);
+          lds_read64_tr<ks * 32 * APITCH>(ahi[ks & 1][i2], at_a + (unsigned)aoff[i2][1]);
+        }
       }
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        lds_char* g0 = halo3 + rbk[ks] + tb[t];
-        const uint2 lo = tr64(g0);
-        const uint2 hi = tr64(g0 + 4 * GPITCH);
-        gf[t] = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
-      }
+      const unsigned g0 = ha + (unsigned)(rbk[ks] + tb[t]);
+      lds_read64_tr<0>(glo[slot], g0);
+      lds_read64_tr<4 * GPITCH>(ghi[slot], g0);
     };
-    auto mma = [&](const bf16x8 (&af)[2], const bf16x8 (&gf)[TMAX]) {
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[t], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[t], acc[t][1], 0, 0, 0);
-      }
-    };
-    // software pipeline over the 8 K-steps: the 22 transpose reads of step ks+1 are issued before the 18 MFMAs of
-    // step ks (the compiler otherwise emits read-wait-MFMA per tap and the LDS latency is exposed 72 times per box)
-    bf16x8 afA[2], gfA[TMAX], afB[2], gfB[TMAX];
-    load_frags(0, afA, gfA);
-#pragma unroll
-    for (int ks = 0; ks < 8; ks += 2) {
-      load_frags(ks + 1, afB, gfB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(afA, gfA);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks + 2 < 8) load_frags(ks + 2, afA, gfA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(afB, gfB);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    static_for<0, D>(issue_unit);
+    static_for<0, NU>([&](auto uu) {
+      constexpr int u = decltype(uu)::value, ks = u / TMAX, t = u % TMAX, slot = u % (D + 1);
+      if constexpr (u + D < NU) issue_unit(std::integral_constant<int, u + D>{});
+      constexpr int last = u + D < NU ? u + D : NU - 1;
+      constexpr int newer = 2 * (last - u) + 4 * ((last / TMAX) - ks);      // reads issued after unit u's
+      if constexpr (t == 0)
+        gs_lgkm_wait64<newer>(glo[slot], ghi[slot], alo[ks & 1][0], ahi[ks & 1][0], alo[ks & 1][1], ahi[ks & 1][1]);
+      else
+        gs_lgkm_wait64<newer>(glo[slot], ghi[slot]);
+      const bf16x8 gf = __builtin_bit_cast(bf16x8, uint4{glo[slot].x, glo[slot].y, ghi[slot].x, ghi[slot].y});
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, uint4{alo[ks & 1][0].x, alo[ks & 1][0].y, ahi[ks & 1][0].x, ahi[ks & 1][0].y});
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, uint4{alo[ks & 1][1].x, alo[ks & 1][1].y, ahi[ks & 1][1].x, ahi[ks & 1][1].y});
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, gf, acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, gf, acc[t][1], 0, 0, 0);
+    });
     cur ^= 1;
   }
 
@@ -357,7 +360,9 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pp = pt * 64 + wp * 32 + i * 16 + fk * 4 + r;
-          unsafeAtomicAdd(p.dw + (size_t)pp * d.dw_ld + t * d.Q + q, acc[t][i][r]);
+          const size_t e = (size_t)pp * d.dw_ld + t * d.Q + q;
+          if (p.ws) p.ws[(size_t)blockIdx.x * p.ws_stride + e] = acc[t][i][r];
+          else unsafeAtomicAdd(p.dw + e, acc[t][i][r]);
         }
     }
   }
@@ -379,17 +384,16 @@ int launch_hw(const HWGradK& k, dim3 grid, int lds, hipStream_t st) {
 }  // namespace
 
 // returns 0 and sets *handled when the layer ran here; *handled = 0 -> the caller falls back to wgrad_kernel
+// ws != nullptr: partial sums go to slabs of ws (see HWGradK) and *handled returns the number of slabs written (the caller
+// runs the reduction); plan_only: nothing is launched, *handled is what a launch would return.
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
-                   void* stream, int* handled);
-
-int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream, int* handled) {
-  return gs_hwgrad_try2(d, a, g, nullptr, nullptr, dw, stream, handled);
-}
+                   float* ws, int plan_only, void* stream, int* handled);
 
 // a2/g2 != nullptr: a second operand pair of the same layer (only the wide kernel merges; otherwise *handled stays 0)
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
-                   void* stream, int* handled) {
+                   float* ws, int plan_only, void* stream, int* handled) {
   *handled = 0;
+  const long long ws_stride = (long long)d->P * d->dw_ld;
   const bool enabled = gs_opt(GS_OPT_HWGRAD) != 0;
   const bool wide_enabled = gs_opt(GS_OPT_HWGRAD_WIDE) != 0;
   const bool planes_enabled = gs_opt(GS_OPT_HWGRAD_PLANES) != 0;
@@ -409,13 +413,15 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
         sub.T = 9;
         for (int t = 0; t < 9; ++t) { sub.dd[t] = d->dd[9 * k + t]; sub.dh[t] = d->dh[9 * k + t]; sub.dw_[t] = d->dw_[9 * k + t]; }
         int h = 0;
-        if (int rc = gs_hwgrad_try2(&sub, a, g, a2, g2, dw + (size_t)9 * k * d->Q, stream, &h)) return rc;
+        // (the plane's slab columns start 9 k Q floats into every slab row, like its columns of dw)
+        if (int rc = gs_hwgrad_try2(&sub, a, g, a2, g2, dw + (size_t)9 * k * d->Q, ws ? ws + (size_t)9 * k * d->Q : nullptr,
+                                    plan_only, stream, &h)) return rc;
         if (!h) {
           GS_REQUIRE(k == 0, "gs_wgrad: depth plane %d of a 27-tap layer was refused after plane 0 ran", k);
           return 0;                                  // not eligible after all: the caller falls back for all 27 taps
         }
+        *handled = h;
       }
-      *handled = 1;
       return 0;
     }
   }
@@ -451,7 +457,7 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
       k.g = static_cast<const char*>(g);
       k.dw = dw;
       k.zero = static_cast<const char*>(gs_zero_page());
-      GS_REQUIRE(k.zero, "gs_wgrad: library not initialised (call gs_init)");
+      GS_REQUIRE(k.zero || plan_only, "gs_wgrad: library not initialised (call gs_init)");
       k.d = *d;
       long long groups = 256 / tiles;                    // one workgroup per CU
       if (groups < 1) groups = 1;
@@ -462,7 +468,10 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
       }
-      *handled = 1;
+      k.ws = ws;
+      k.ws_stride = ws_stride;
+      *handled = ws || plan_only ? (int)groups : 1;
+      if (plan_only) return 0;
       hipLaunchKernelGGL((hwgrad_wide_kernel<9>), dim3((unsigned)groups, (unsigned)tiles), dim3(512), lds,
                          static_cast<hipStream_t>(stream), k);
       GS_CHECK_HIP(hipGetLastError());
@@ -500,14 +509,17 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
   k.g = static_cast<const char*>(g);
   k.dw = dw;
   k.zero = static_cast<const char*>(gs_zero_page());
-  GS_REQUIRE(k.zero, "gs_wgrad: library not initialised (call gs_init)");
+  GS_REQUIRE(k.zero || plan_only, "gs_wgrad: library not initialised (call gs_init)");
   k.d = *d;
   // one workgroup per CU (its registers hold 16 taps per wave); ~2 rounds of box groups keep the tail short
   const int per_y = k.qchunks * k.phalves * k.tgroups;
   long long groups = 512 / per_y;
   if (groups < 1) groups = 1;
   if (groups > nboxes) groups = nboxes;
-  *handled = 1;
+  k.ws = ws;
+  k.ws_stride = ws_stride;
+  *handled = ws || plan_only ? (int)groups : 1;
+  if (plan_only) return 0;
   const dim3 grid((unsigned)groups, (unsigned)per_y);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (TI == 1) return TPW == 8 ? launch_hw<1, 8>(k, grid, lds, st) : launch_hw<1, 16>(k, grid, lds, st);

@@ -20,6 +20,8 @@ struct WGradK {
   const char* zero;
   int tiles_p, tiles_q, splits, chunk, q_shift;
   float rcp_wa, rcp_hw, rcp_da;
+  float* ws;                  // != nullptr: split sp writes its partial tile to slab sp of ws ([splits][P * dw_ld] floats)
+  long long ws_stride;        // instead of fp32 atomics on dw (deterministic accumulation, gs_wgrad_ws)
   gs_wgrad_desc d;
 };
 
@@ -211,11 +213,14 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     for (int r = 0; r < 4; ++r) {
       const int pp = tp * BP + wp * (BP / WP) + i * 16 + fk * 4 + r;
       if (pp < d.P) {
-        float* row = p.dw + (size_t)pp * d.dw_ld;
+        float* row = (p.ws ? p.ws + (size_t)sp * p.ws_stride : p.dw) + (size_t)pp * d.dw_ld;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int col = tq * BQ + wq * (BQ / WQ) + j * 16 + frow;
-          if (col < TQ) unsafeAtomicAdd(row + col, acc[i][j][r]);
+          if (col < TQ) {
+            if (p.ws) row[col] = acc[i][j][r];
+            else unsafeAtomicAdd(row + col, acc[i][j][r]);
+          }
         }
       }
     }
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
 
 namespace {
 template <int BP, int BQ, int WP, int WQ, bool VOL = true>
-int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
+int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int plan_only, int* slabs) {
   k.tiles_p = (d->P + BP - 1) / BP;
   k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
   // split-K over the batch-flattened pixel index: one workgroup per CU is resident (144 KiB of LDS), so aim for
@@ -253,6 +258,8 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   k.rcp_hw = 1.0f / (float)(d->Ha * d->Wa);
   const long long blocks = tiles * splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_wgrad: bad grid %lld", blocks);
+  *slabs = (int)splits;
+  if (plan_only) return 0;
   constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 4 + 1024;
   static bool configured = false;
   if (!configured) {
@@ -265,62 +272,138 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
   return 0;
 }
 template <int BP, int BQ, int WP, int WQ>
-int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st) {
+int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int plan_only, int* slabs) {
   // depth-1 tensors (the 2-D nets) run the instantiation without the depth bookkeeping in the K loop
-  if (d->Da == 1 && d->Dg == 1) return launch_wgrad_impl<BP, BQ, WP, WQ, false>(k, d, st);
-  return launch_wgrad_impl<BP, BQ, WP, WQ, true>(k, d, st);
+  if (d->Da == 1 && d->Dg == 1) return launch_wgrad_impl<BP, BQ, WP, WQ, false>(k, d, st, plan_only, slabs);
+  return launch_wgrad_impl<BP, BQ, WP, WQ, true>(k, d, st, plan_only, slabs);
 }
 }  // namespace
 
-// hwgrad.hip: halo-resident kernels for narrow stride-1 layers and the wide 3x3 layers
-int gs_hwgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream, int* handled);
-int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
-                   void* stream, int* handled);
-
-extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream);
-
-// dw += wgrad(a1, g1) + wgrad(a2, g2) for two operand pairs of the SAME layer and shapes (the two backward passes a
-// network sees per step): one launch where the kernel can merge them (fixed costs and atomics paid once), else two
-extern "C" int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2,
-                             float* dw, void* stream) {
-  GS_REQUIRE(d && a1 && g1 && a2 && g2 && dw, "gs_wgrad_pair: null argument");
-  int handled = 0;
-  if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, stream, &handled)) return rc;
-  if (handled) return 0;
-  if (int rc = gs_wgrad(d, a1, g1, dw, stream)) return rc;
-  return gs_wgrad(d, a2, g2, dw, stream);
+// dw[e] += ws[0][e] + ws[1][e] + ... in slab order: the fixed-order second stage of the deterministic accumulation.
+// Elementwise, 16 B per lane, every slab read once.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, float4* dw, long long n4, int slabs,
+                                                           long long stride4) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    float4 s = ws[e];
+    for (int k = 1; k < slabs; ++k) {
+      const float4 t = ws[(long long)k * stride4 + e];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float4 o = dw[e];
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    dw[e] = o;
+  }
 }
 
-extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream) {
-  GS_REQUIRE(d && a && g && dw, "gs_wgrad: null argument");
+// hwgrad.hip: halo-resident kernels for narrow stride-1 layers and the wide 3x3 layers
+int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
+                   float* ws, int plan_only, void* stream, int* handled);
+
+namespace {
+// the im2col kernel for one operand pair; ws != nullptr: partial tiles to slabs, *slabs = how many
+int wgrad_generic(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, float* ws, int plan_only,
+                  void* stream, int* slabs) {
+  WGradK k;
+  k.a = static_cast<const char*>(a);
+  k.g = static_cast<const char*>(g);
+  k.dw = dw;
+  k.ws = ws;
+  k.ws_stride = (long long)d->P * d->dw_ld;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero || plan_only, "gs_wgrad: library not initialised (call gs_init)");
+  int sh = 0;
+  while ((8 << sh) < d->Q) ++sh;
+  k.q_shift = sh;
+  k.rcp_wa = 1.0f / (float)d->Wa;
+  k.rcp_da = 1.0f / (float)d->Da;
+  k.d = *d;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d->P <= 16) return launch_wgrad<16, 256, 1, 8>(k, d, st, plan_only, slabs);      // Cout 1/3 layers: skinny P
+  if (d->P <= 64) return launch_wgrad<64, 256, 1, 8>(k, d, st, plan_only, slabs);
+  return launch_wgrad<128, 256, 4, 4>(k, d, st, plan_only, slabs);                      // 16 waves: best measured
+}
+
+int wgrad_check(const gs_wgrad_desc* d) {
   GS_REQUIRE(d->Q >= 8 && (d->Q & 7) == 0 && ((d->Q >> 3) & ((d->Q >> 3) - 1)) == 0,
              "gs_wgrad: Q=%d must be 8*2^k", d->Q);
   GS_REQUIRE((d->P & 7) == 0, "gs_wgrad: P=%d must be a multiple of 8", d->P);
   GS_REQUIRE(d->T >= 1 && d->T <= GS_MAX_TAPS, "gs_wgrad: T=%d out of range", d->T);
   GS_REQUIRE((d->a_cs & 7) == 0 && (d->a_co & 7) == 0 && (d->g_cs & 7) == 0 && (d->g_co & 7) == 0,
              "gs_wgrad: channel strides/offsets must be multiples of 8");
-  {
-    int handled = 0;
-    if (int rc = gs_hwgrad_try(d, a, g, dw, stream, &handled)) return rc;
-    if (handled) return 0;
-  }
-  WGradK k;
-  k.a = static_cast<const char*>(a);
-  k.g = static_cast<const char*>(g);
-  k.dw = dw;
-  k.zero = static_cast<const char*>(gs_zero_page());
-  GS_REQUIRE(k.zero, "gs_wgrad: library not initialised (call gs_init)");
-  int sh = 0;
-  while ((8 << sh) < d->Q) ++sh;
-  k.q_shift = sh;
-  k.rcp_wa = 1.0f / (float)d->Wa;
-  k.rcp_da = 1.0f / (float)d->Da;
   GS_REQUIRE(d->Da >= 1 && d->Dg >= 1, "gs_wgrad: depths must be >= 1 (1 for 2-D tensors)");
-  k.d = *d;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (d->P <= 16) return launch_wgrad<16, 256, 1, 8>(k, d, st);      // Cout 1/3 layers: skinny P
-  if (d->P <= 64) return launch_wgrad<64, 256, 1, 8>(k, d, st);
-  return launch_wgrad<128, 256, 4, 4>(k, d, st);                      // 16 waves: best measured
+  GS_REQUIRE(d->dw_ld == d->T * d->Q, "gs_wgrad: dw_ld must be T * Q");
+  return 0;
+}
+
+int wgrad_reduce(const gs_wgrad_desc* d, const float* ws, float* dw, int slabs, void* stream) {
+  const long long n = (long long)d->P * d->dw_ld;          // multiple of 64: P and Q are multiples of 8
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw), n / 4, slabs, n / 4);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// one implementation behind gs_wgrad / gs_wgrad_pair / gs_wgrad_ws / gs_wgrad_ws_floats
+int wgrad_impl(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
+               float* ws, int64_t ws_floats, int plan_only, void* stream, int64_t* need_floats) {
+  if (int rc = wgrad_check(d)) return rc;
+  const long long slab = (long long)d->P * d->dw_ld;
+  const bool det = ws != nullptr || plan_only;
+  int handled = 0;
+  if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, det ? ws : nullptr, plan_only, stream, &handled)) return rc;
+  if (handled) {
+    if (need_floats) *need_floats = (int64_t)handled * slab;
+    if (plan_only || !det) return 0;
+    GS_REQUIRE(ws_floats >= (int64_t)handled * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
+               (long long)ws_floats, (long long)handled * slab);
+    return wgrad_reduce(d, ws, dw, handled, stream);
+  }
+  // the im2col kernel: one launch (+ one reduction) per operand pair, the workspace is reused
+  int64_t need = 0;
+  for (int pass = 0; pass < (a2 ? 2 : 1); ++pass) {
+    int slabs = 0;
+    if (int rc = wgrad_generic(d, pass ? a2 : a1, pass ? g2 : g1, dw, det ? ws : nullptr, plan_only, stream, &slabs))
+      return rc;
+    if ((int64_t)slabs * slab > need) need = (int64_t)slabs * slab;
+    if (plan_only || !det) continue;
+    GS_REQUIRE(ws_floats >= (int64_t)slabs * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
+               (long long)ws_floats, (long long)slabs * slab);
+    if (int rc = wgrad_reduce(d, ws, dw, slabs, stream)) return rc;
+  }
+  if (need_floats) *need_floats = need;
+  return 0;
+}
+}  // namespace
+
+extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, void* stream) {
+  GS_REQUIRE(d && a && g && dw, "gs_wgrad: null argument");
+  return wgrad_impl(d, a, g, nullptr, nullptr, dw, nullptr, 0, 0, stream, nullptr);
+}
+
+// dw += wgrad(a1, g1) + wgrad(a2, g2) for two operand pairs of the SAME layer and shapes (the two backward passes a
+// network sees per step): one launch where the kernel can merge them (fixed costs paid once), else two
+extern "C" int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2,
+                             float* dw, void* stream) {
+  GS_REQUIRE(d && a1 && g1 && a2 && g2 && dw, "gs_wgrad_pair: null argument");
+  return wgrad_impl(d, a1, g1, a2, g2, dw, nullptr, 0, 0, stream, nullptr);
+}
+
+// Deterministic form of both: workgroups that share output elements write partial sums to slabs of the caller's
+// workspace and a second launch adds the slabs in a fixed order (no fp32 atomics: two runs give bit-identical dw).
+extern "C" int64_t gs_wgrad_ws_floats(const gs_wgrad_desc* d, int32_t pair) {
+  if (!d) return 0;
+  int64_t need = 0;
+  static const char dummy = 0;
+  if (wgrad_impl(d, &dummy, &dummy, pair ? &dummy : nullptr, pair ? &dummy : nullptr, nullptr, nullptr, 0, 1, nullptr, &need))
+    return -1;
+  return need;
+}
+extern "C" int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2,
+                           float* dw, float* ws, int64_t ws_floats, void* stream) {
+  GS_REQUIRE(d && a1 && g1 && dw && ws && (a2 == nullptr) == (g2 == nullptr), "gs_wgrad_ws: null argument");
+  return wgrad_impl(d, a1, g1, a2, g2, dw, ws, ws_floats, 0, stream, nullptr);
 }
 
 // ---- bias gradient: db[c] += sum_pixels dy[pix][c] ---------------------------------------------------

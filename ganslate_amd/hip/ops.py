@@ -45,11 +45,12 @@ class HipOps:
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
                    "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_NW": "hconvw_waves",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
-                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll"}
+                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_DEBUG": "debug"}
 
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")
-        self._desc_cache = {k: v for k, v in self._desc_cache.items() if not (isinstance(k, tuple) and k[0] == "splitk")}
+        self._desc_cache = {k: v for k, v in self._desc_cache.items()
+                            if not (isinstance(k, tuple) and k[0] in ("splitk", "wgrad_ws"))}
 
     def get_option(self, name):
         v = C.c_int(0)
@@ -201,7 +202,20 @@ class HipOps:
             ent = (d, w)
             self._desc_cache[key] = ent
         t_end = self._time_begin("wgrad", w, pair is not None)
-        if pair is not None:      # (a2, g2): the same layer's operands from another backward pass, one launch
+        if os.environ.get("GS_WGRAD_DET", "1") != "0":
+            # deterministic accumulation (default): partial sums to a per-launch workspace, fixed-order second stage
+            wkey = ("wgrad_ws", id(ent[0]), pair is not None)        # (set_option drops these plans)
+            nws = self._desc_cache.get(wkey)
+            if nws is None:
+                nws = int(self.lib.gs_wgrad_ws_floats(C.byref(ent[0]), int(pair is not None)))
+                if nws < 0:
+                    L.check(2, "gs_wgrad_ws_floats")
+                self._desc_cache[wkey] = nws
+            ws = torch.empty(nws, dtype=torch.float32, device=self.device)      # stream-safe through the allocator
+            a2, g2 = pair if pair is not None else (None, None)
+            L.check(self.lib.gs_wgrad_ws(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(a2), _ptr(g2), _ptr(dw), _ptr(ws), nws,
+                                         _stream()), "gs_wgrad_ws")
+        elif pair is not None:      # (a2, g2): the same layer's operands from another backward pass, one launch
             L.check(self.lib.gs_wgrad_pair(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(pair[0]), _ptr(pair[1]), _ptr(dw),
                                            _stream()), "gs_wgrad_pair")
         else:

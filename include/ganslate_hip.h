@@ -129,6 +129,14 @@ int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, vo
  * generator sees per step (cyclegan.py:139-150: G_AB(real_A) and G_AB(fake_A)) — in one launch where possible */
 int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
                   void* stream);
+/* Deterministic form of gs_wgrad (a2 = g2 = NULL) / gs_wgrad_pair: workgroups that share output elements (split-K over
+ * pixels) write partial sums to slabs of a caller-owned workspace and a second launch adds the slabs to dw in a fixed
+ * order, instead of fp32 atomics on dw — two runs give bit-identical gradients (torch.use_deterministic_algorithms-like
+ * behaviour of the reference's cuDNN weight gradients is NOT guaranteed either; this is what the loss-curve parity tests
+ * run on). gs_wgrad_ws_floats: workspace the call wants (floats; < 0: bad descriptor). */
+int64_t gs_wgrad_ws_floats(const gs_wgrad_desc* d, int32_t pair);
+int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
+                float* ws, int64_t ws_floats, void* stream);
 /* db[c] += sum over pixels of dy[pix, c]  (bias gradient of any conv) */
 int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, void* stream);
 

@@ -15,6 +15,8 @@ from ganslate_amd.nn.native.spec import ConvSpec, lower  # noqa: E402
 CASES = {
     # name: (spec, N, H, W)
     "rb": (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),
+    "rbk64": (ConvSpec("conv", 64, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),      # same tile, 9 / 18 K-steps:
+    "rbk128": (ConvSpec("conv", 128, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),    # loop cost vs fixed cost
     "d2": (ConvSpec("conv", 128, 256, 3, 2, 1), 8, 128, 128),
     "d1": (ConvSpec("conv", 64, 128, 3, 2, 1), 8, 256, 256),
     "u1": (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 8, 64, 64),
