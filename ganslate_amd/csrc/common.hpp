@@ -56,6 +56,12 @@ __device__ __forceinline__ void gs_lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "i"(N) : "memory");
 }
 
+// wait-only statement + per-fragment register fences (any number of fragments): nothing that consumes x can be scheduled
+// above reg_fence(x), and the fences follow the wait in program order (all are asm volatile)
+template <int N>
+__device__ __forceinline__ void gs_lgkm_wait_only() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ __forceinline__ void reg_fence(bf16x8& x) { asm volatile("" : "+v"(x)); }
+
 // 64-bit transpose read (pixel-major operands of the weight-gradient kernels): 4 bf16 of one k-column per lane
 template <int OFF>
 __device__ __forceinline__ void lds_read64_tr(uint2& v, unsigned addr) {

@@ -189,6 +189,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     if (nk > 1) issue(1, 1);
   }
 
+  // (Fragment reads stay compiler-managed here: issuing both 32-deep halves through lds_read128 with counted waits, as
+  // hconvw / hwgrad do, measured no gain on these two-wave-per-SIMD+ tiles and cost the 320-pixel tile 28 spills.)
   auto compute = [&](int cur) {
     const char* wb = smem + cur * STAGE + (wn * (BN / WN) + frow) * 128;
     const char* xb = smem + cur * STAGE + WT + (wm * (BM / WM) + frow) * 128;

@@ -116,6 +116,91 @@ extern "C" int gs_inorm_act_forward(const void* y, const float* mean_rstd, const
   return 0;
 }
 
+
+// ---- forward apply with the statistics finalised in the prologue ---------------------------------------------------
+// The producing conv leaves per-tile partial sums [N][slots][2][C]; the old path ran slot_sum_kernel (a ~5 us launch of
+// 128 tiny workgroups, ~200 of them per training step) and then the apply kernel. Here the apply kernel is laid out by
+// channel group — grid (pixel chunks, N, C/64), 256 threads = 8 x 8-channel columns x 32 pixel lanes — so a workgroup
+// only needs the totals of ITS 64 channels: it adds up their slots itself (double accumulation, fixed order), and the
+// workgroups of the first pixel chunk also publish mean / rstd for the backward pass.
+__global__ __launch_bounds__(256) void inorm_stats_act_fwd_kernel(const uint4* y, const float* partial, int slots,
+                                                                  float eps, float* mean_rstd, const uint4* res,
+                                                                  uint4* x, int hw, int C8, int act, float slope,
+                                                                  int pix_per_block) {
+  __shared__ double tot[2][64];
+  __shared__ float mrs[2][64];
+  // channel group fastest in dispatch order: the C/64 workgroups that together cover whole 2*C-byte pixel rows of one
+  // pixel chunk run side by side (DRAM pages are walked once, not C/64 times at different moments)
+  const int cg = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int C = C8 * 8;
+  if (tid < 128) {
+    const int r = tid >> 6, ch = tid & 63;
+    const float* src = partial + ((size_t)n * slots * 2 + r) * C + cg * 64 + ch;
+    double sacc = 0.0;
+    for (int sl = 0; sl < slots; ++sl) sacc += (double)src[(size_t)sl * 2 * C];
+    tot[r][ch] = sacc;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double inv_hw = 1.0 / (double)hw;
+    const double mean = tot[0][tid] * inv_hw;
+    double var = tot[1][tid] * inv_hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+    mrs[0][tid] = m;
+    mrs[1][tid] = rs;
+    if (chunk == 0) {
+      mean_rstd[(size_t)n * 2 * C + cg * 64 + tid] = m;
+      mean_rstd[(size_t)n * 2 * C + C + cg * 64 + tid] = rs;
+    }
+  }
+  __syncthreads();
+  const int cl = tid & 7, lane = tid >> 3;
+  float mu[8], rs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mu[k] = mrs[0][cl * 8 + k]; rs[k] = mrs[1][cl * 8 + k]; }
+  const size_t img = (size_t)n * hw * C8;
+  const int p0 = chunk * pix_per_block, p1 = min(hw, p0 + pix_per_block);
+  for (int px = p0 + lane; px < p1; px += 32) {
+    const size_t e = img + (size_t)px * C8 + cg * 8 + cl;
+    const uint4 v = y[e];
+    float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = apply_act((f[k] - mu[k]) * rs[k], act, slope);
+    if (res) {
+      const uint4 r = res[e];
+      f[0] += bf_lo(r.x); f[1] += bf_hi(r.x); f[2] += bf_lo(r.y); f[3] += bf_hi(r.y);
+      f[4] += bf_lo(r.z); f[5] += bf_hi(r.z); f[6] += bf_lo(r.w); f[7] += bf_hi(r.w);
+    }
+    uint4 o;
+    o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+    x[e] = o;
+  }
+}
+
+extern "C" int gs_inorm_stats_act_forward(const void* y, const float* partial, int32_t slots, float eps,
+                                          float* mean_rstd, const void* res, void* x, int32_t N, int64_t hw, int32_t C,
+                                          int32_t act, float slope, void* stream) {
+  GS_REQUIRE(y && partial && mean_rstd && x && N > 0 && slots > 0 && hw > 0 && C > 0 && (C & 7) == 0,
+             "gs_inorm_stats_act_forward: bad argument");
+  // every workgroup repeats the slot sum of its 64 channels: only worth it while that prologue is short (the 64 x 64 maps
+  // of the residual blocks have 16 slots; a 256 x 256 map has 256-512 and keeps the two-launch form)
+  if ((C & 63) != 0 || hw >= (1LL << 31) || slots > 64) {
+    if (int rc = gs_inorm_finalize(partial, N, slots, C, hw, eps, mean_rstd, stream)) return rc;
+    return gs_inorm_act_forward(y, mean_rstd, res, x, N, hw, C, act, slope, stream);
+  }
+  // 64 pixels x 64 channels per workgroup: thousands of workgroups for the 64 x 64 maps (a streaming kernel wants the
+  // occupancy), while the slot sums (<= 64 slots x 128 floats) stay a short prologue
+  int ppb = 64;
+  while ((hw + ppb - 1) / ppb > 1024) ppb *= 2;
+  hipLaunchKernelGGL(inorm_stats_act_fwd_kernel, dim3(C / 64, (unsigned)((hw + ppb - 1) / ppb), N), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint4*>(y), partial, slots, eps, mean_rstd,
+                     static_cast<const uint4*>(res), static_cast<uint4*>(x), (int)hw, C / 8, act, slope, ppb);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- backward ------------------------------------------------------------------------------------------
 // folded gradient: g(n, ih, iw, c8) = sum over the padded-domain positions that the padding maps to (ih, iw)
 // reflect: up to 3 source positions per axis; replicate: one contiguous range per axis (the border cell collects its
@@ -363,6 +448,73 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
   }
 }
 
+
+// pass 2 by channel group (C % 64 == 0): grid (pixel chunks, N, C/64), 256 threads = 8 x 8-channel columns x 32 pixel
+// lanes. The totals S1 = sum ghat, S2 = sum ghat*yhat (and S3 = sum yhat for the bias gradient) of the workgroup's 64
+// channels are summed from the partial slots in the prologue (fixed order): no slot_sum launch between the passes.
+template <int FM>
+__global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
+                                                                 const float* mean_rstd, const float* partial,
+                                                                 int slots, uint4* dy, uint4* gsum, float* db, int D,
+                                                                 int H, int W, int C8, int fold, int act, float slope,
+                                                                 int pix_per_block) {
+  __shared__ float tot[3][64];
+  const int cg = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;      // channel group fastest, see the forward kernel
+  const int tid = threadIdx.x;
+  const int C = C8 * 8;
+  const int HW = D * H * W;
+  const float inv_hw = 1.0f / (float)HW;
+  if (tid < 192) {
+    const int r = tid >> 6, ch = tid & 63;
+    const float* src = partial + ((size_t)n * slots * 3 + r) * C + cg * 64 + ch;
+    double sacc = 0.0;
+    for (int sl = 0; sl < slots; ++sl) sacc += (double)src[(size_t)sl * 3 * C];
+    tot[r][ch] = (float)sacc;
+  }
+  __syncthreads();
+  const float* mr = mean_rstd + (size_t)n * 2 * C;
+  if (db && chunk == 0 && tid < 64) {
+    // bias gradient of the conv in front of the norm = sum over pixels of dy = -rstd * S2 * S3 / hw (zero up to rounding)
+    unsafeAtomicAdd(db + cg * 64 + tid, -mr[C + cg * 64 + tid] * tot[1][tid] * tot[2][tid] * inv_hw);
+  }
+  const int cl = tid & 7, lane = tid >> 3;
+  const int c8 = cg * 8 + cl;
+  float mu[8], rs[8], s1[8], s2[8];
+  load8(mu, mr + c8 * 8);
+  load8(rs, mr + C + c8 * 8);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = tot[0][cl * 8 + k] * inv_hw; s2[k] = tot[1][cl * 8 + k] * inv_hw; }
+  const size_t per_img = (size_t)HW * C8;
+  const size_t pad_img = padded_pixels(D, H, W, fold) * C8;
+  const uint4* gpad_n = gpad + (size_t)n * pad_img;
+  const uint4* g2_n = g2 ? g2 + (size_t)n * per_img : nullptr;
+  const uint4* y_n = y + (size_t)n * per_img;
+  uint4* dy_n = dy + (size_t)n * per_img;
+  uint4* gs_n = gsum ? gsum + (size_t)n * per_img : nullptr;
+  const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+#pragma unroll 2
+  for (int px = p0 + lane; px < p1; px += 32) {
+    const size_t e = (size_t)px * C8 + c8;
+    float g[8], yy[8], d[8];
+    load_folded<FM>(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold);
+    if (gs_n) {
+      uint4 o;
+      o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]); o.z = pack_bf2(g[4], g[5]); o.w = pack_bf2(g[6], g[7]);
+      gs_n[e] = o;
+    }
+    unpack8(yy, y_n[e]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float yh = (yy[k] - mu[k]) * rs[k];
+      const float gh = g[k] * act_grad_from_out(yh, act, slope);
+      d[k] = rs[k] * (gh - s1[k] - yh * s2[k]);
+    }
+    uint4 o;
+    o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
+    dy_n[e] = o;
+  }
+}
+
 // shared with norm_ex.hip
 int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, float inv_hw, const float* mean_rstd,
                         float* db, hipStream_t st) {
@@ -432,6 +584,24 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
 #undef GS_LAUNCH_REDUCE
 #undef GS_LAUNCH_REDUCE2
     GS_CHECK_HIP(hipGetLastError());
+    }
+    if ((C & 63) == 0 && chunks <= 64) {
+      // wide layers with few slots: the apply pass sums the slots of its own 64 channels in its prologue (no slot_sum
+      // launch); with hundreds of slots (256 x 256 maps) that prologue would dominate, so those keep the slot_sum launch
+      int ppb = 64;
+      while ((HW + ppb - 1) / ppb > 1024) ppb *= 2;
+#define GS_LAUNCH_APPLY_CG(FM)                                                                                      \
+  hipLaunchKernelGGL((inorm_bwd_apply_cg_kernel<FM>), dim3(C / 64, (unsigned)((HW + ppb - 1) / ppb), N), dim3(256), 0, \
+                     st, static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2),                            \
+                     static_cast<const uint4*>(y), mean_rstd, scratch, chunks, static_cast<uint4*>(dy),              \
+                     static_cast<uint4*>(gsum), bias_grad, D, H, W, C8, fold, act, slope, ppb)
+      if (fm == 0) GS_LAUNCH_APPLY_CG(0);
+      else if (fm == 1) GS_LAUNCH_APPLY_CG(1);
+      else if (fm == 2) GS_LAUNCH_APPLY_CG(2);
+      else GS_LAUNCH_APPLY_CG(3);
+#undef GS_LAUNCH_APPLY_CG
+      GS_CHECK_HIP(hipGetLastError());
+      return 0;
     }
     if (int rc = gs_launch_slot_sum3(scratch, sums, N, chunks, C, 1.0f / (float)HW, mean_rstd, bias_grad, st)) return rc;
   }

@@ -279,19 +279,31 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int plan_onl
 }
 }  // namespace
 
-// dw[e] += ws[0][e] + ws[1][e] + ... in slab order: the fixed-order second stage of the deterministic accumulation.
-// Elementwise, 16 B per lane, every slab read once.
+// dw[e] += ws[0][e] + ws[1][e] + ... : the fixed-order second stage of the deterministic accumulation. 16 B per lane;
+// 256 threads = 64 element lanes x 4 slab lanes (slab lane l adds slabs l, l+4, ... in order, then the four partial sums
+// are added in lane order through LDS): the order never depends on timing, and layers with few output elements but
+// hundreds of slabs (the 64-channel boundary convs) still spread over the chip.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, float4* dw, long long n4, int slabs,
                                                            long long stride4) {
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
-    float4 s = ws[e];
-    for (int k = 1; k < slabs; ++k) {
-      const float4 t = ws[(long long)k * stride4 + e];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  __shared__ float4 part[4][64];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (long long e0 = (long long)blockIdx.x * 64; e0 < n4; e0 += (long long)gridDim.x * 64) {
+    const long long e = e0 + el;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (e < n4)
+      for (int k = sl; k < slabs; k += 4) {
+        const float4 t = ws[(long long)k * stride4 + e];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    part[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && e < n4) {
+      float4 o = dw[e];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) { o.x += part[l][el].x; o.y += part[l][el].y; o.z += part[l][el].z; o.w += part[l][el].w; }
+      dw[e] = o;
     }
-    float4 o = dw[e];
-    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-    dw[e] = o;
+    __syncthreads();
   }
 }
 
@@ -337,8 +349,8 @@ int wgrad_check(const gs_wgrad_desc* d) {
 
 int wgrad_reduce(const gs_wgrad_desc* d, const float* ws, float* dw, int slabs, void* stream) {
   const long long n = (long long)d->P * d->dw_ld;          // multiple of 64: P and Q are multiples of 8
-  long long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  long long blocks = (n / 4 + 63) / 64;
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw), n / 4, slabs, n / 4);
   GS_CHECK_HIP(hipGetLastError());

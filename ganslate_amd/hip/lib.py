@@ -74,6 +74,9 @@ _PROTOS = {
                                     C.c_void_p, C.c_void_p]),
     "gs_inorm_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                        C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "gs_inorm_stats_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float,
+                                             C.c_void_p]),
     "gs_inorm_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),

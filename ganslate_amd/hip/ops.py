@@ -239,6 +239,13 @@ class HipOps:
                                               y.numel() // (N * Cc), Cc,
                                               L.ACT[act], slope, _stream()), "gs_inorm_act_forward")
 
+    def inorm_stats_act_forward(self, y, partial, slots, mean_rstd, res, x, act="none", slope=0.2, eps=1e-5):
+        """inorm_finalize + inorm_act_forward as one launch (the apply kernel sums the slots of its own channels)"""
+        N, Cc = y.shape[0], y.shape[-1]
+        L.check(self.lib.gs_inorm_stats_act_forward(_ptr(y), _ptr(partial), slots, eps, _ptr(mean_rstd), _ptr(res),
+                                                    _ptr(x), N, y.numel() // (N * Cc), Cc, L.ACT[act], slope,
+                                                    _stream()), "gs_inorm_stats_act_forward")
+
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
                            slope=0.2, bias_grad=None, pre=None):
         N, D, H, W, Cc = y.shape if y.dim() == 5 else (y.shape[0], 1) + tuple(y.shape[1:])

@@ -346,10 +346,10 @@ class NativeNet:
                 for g, o in zip(lw.fwd, offs):
                     ops.gconv(g, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
                 mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=dev)
-                ops.inorm_finalize(part, N, slots, sp.cout_p, lw.out_pixels, mr)
                 xo = torch.empty_like(y)
                 res = acts[nd.res + 1] if nd.res is not None else None
-                ops.inorm_act_forward(y, mr, res, xo, act=nd.act, slope=nd.slope)
+                # statistics finalised inside the apply launch (no separate slot-sum kernel)
+                ops.inorm_stats_act_forward(y, part, slots, mr, res, xo, act=nd.act, slope=nd.slope)
                 ys.append(y if save else None); mrs.append(mr if save else None)
                 acts.append(xo)
             else:

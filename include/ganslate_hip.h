@@ -147,6 +147,12 @@ int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C,
 /* x = act((y-mean)*rstd) [+ res]   (resnet2d.py:26-27, 83-84, 87, 93) */
 int gs_inorm_act_forward(const void* y, const float* mean_rstd, const void* res, void* x, int32_t N,
                          int64_t hw, int32_t C, int32_t act, float slope, void* stream);
+/* The two calls above as ONE launch: every workgroup adds up the partial slots of its own 64 channels in its prologue,
+ * the first pixel chunk's workgroups also write mean_rstd [N][2][C] (needed by the backward pass), then x is produced as
+ * in gs_inorm_act_forward. (C % 64 != 0: falls back to the two launches.) */
+int gs_inorm_stats_act_forward(const void* y, const float* partial, int32_t slots, float eps, float* mean_rstd,
+                               const void* res, void* x, int32_t N, int64_t hw, int32_t C, int32_t act, float slope,
+                               void* stream);
 /* Backward of the above. g_pad is the incoming gradient on a domain padded by `fold` on each side of every
  * spatial axis with extent > 1 (the data-gradient of a reflect/replicate-padded conv; fold=0 for a plain gradient)
  * — the border is folded back here (adjoint of nn.ReflectionPad2d resnet2d.py:24 / nn.ReplicationPad3d

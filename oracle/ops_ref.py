@@ -188,6 +188,11 @@ class RefOps:
             v = v + res.float()
         x.copy_(v.to(x.dtype))
 
+    def inorm_stats_act_forward(self, y, partial, slots, mean_rstd, res, x, act="none", slope=0.2, eps=1e-5):
+        N, Cc = y.shape[0], y.shape[-1]
+        self.inorm_finalize(partial, N, slots, Cc, y.numel() // (N * Cc), mean_rstd, eps)
+        self.inorm_act_forward(y, mean_rstd, res, x, act=act, slope=slope)
+
     def inorm_act_backward(self, g_pad, g2, y, mean_rstd, dy, gsum, fold=0, fold_mode="reflect", act="none",
                            slope=0.2, bias_grad=None, pre=None):
         N, Cc = y.shape[0], y.shape[-1]

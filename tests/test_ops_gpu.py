@@ -665,3 +665,28 @@ def test_wgrad_is_bitwise_reproducible(hip_ops, case):
         outs.append(dw.cpu())
     assert torch.equal(outs[0], outs[1]), "two runs of the deterministic weight gradient differ"
     close_f32(outs[2] - 0.5, 2 * (outs[0] - 0.5), "pair of identical operands = twice the single pass", rel=1e-5)
+
+
+@pytest.mark.parametrize("shape,slots", [((8, 64, 64, 256), 16), ((2, 17, 13, 64), 3), ((1, 30, 30, 512), 1),
+                                         ((2, 9, 11, 24), 2)])
+@pytest.mark.parametrize("res", [False, True])
+def test_inorm_stats_act_forward_fused(hip_ops, shape, slots, res):
+    """gs_inorm_stats_act_forward = gs_inorm_finalize + gs_inorm_act_forward in one launch (slot sums in the prologue)"""
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(33)
+    y = (torch.randn(N, H, W, C, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    r = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16) if res else None
+    # partial slots: split the pixels of each image into `slots` ragged groups
+    flat = y.float().view(N, H * W, C)
+    bounds = torch.linspace(0, H * W, slots + 1).long()
+    part = torch.stack([torch.stack([flat[:, a:b].sum(1), (flat[:, a:b] ** 2).sum(1)], 1)
+                        for a, b in zip(bounds[:-1], bounds[1:])], 1).contiguous()      # [N][slots][2][C]
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        mr = torch.full((N * 2 * C,), float("nan"), dtype=torch.float32, device=dev)
+        x = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+        ops.inorm_stats_act_forward(y.to(dev), part.reshape(-1).to(dev), slots, mr, r.to(dev) if res else None, x,
+                                    act="relu")
+        outs.append((x, mr))
+    close_bf16(outs[1][0], outs[0][0], "fused stats + apply")
+    close_f32(outs[1][1], outs[0][1], "mean/rstd", rel=1e-4)
