@@ -49,12 +49,38 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = tot[r][col];
-      if (db) {
-        const float rstd = mean_rstd[(size_t)n * 2 * C + C + c];
-        unsafeAtomicAdd(db + c, -rstd * tot[1][col] * tot[R - 1][col] * inv_hw);
-      }
     }
   }
+}
+
+// Parameter gradients that are sums over the images of per-image totals, added in IMAGE ORDER by one thread per channel
+// (they used to be fp32 atomics from the per-image workgroups: order, and with it the last bit, changed from run to run):
+//   db[c]     += sum_n -rstd[n][c] * S2[n][c] * S3[n][c] / hw    (bias of the conv in front of a norm: = sum of dy, which is
+//                                                                  zero up to rounding — the reference's is rounding noise too)
+//   dslope[c] += sum_n S4[n][c]                                   (nn.PReLU slope, R == 4)
+__global__ __launch_bounds__(256) void norm_param_grads_kernel(const float* sums, int R, const float* mean_rstd, float* db,
+                                                               float* dslope, int N, int C, float inv_hw) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (db && mean_rstd) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n)
+      acc += -mean_rstd[(size_t)n * 2 * C + C + c] * sums[((size_t)n * R + 1) * C + c] * sums[((size_t)n * R + 2) * C + c] * inv_hw;
+    db[c] += acc;
+  }
+  if (dslope) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += sums[((size_t)n * R + 3) * C + c];
+    dslope[c] += acc;
+  }
+}
+int gs_launch_norm_param_grads(const float* sums, int R, const float* mean_rstd, float* db, float* dslope, int N, int C,
+                               float inv_hw, hipStream_t st) {
+  if (!db && !dslope) return 0;
+  hipLaunchKernelGGL(norm_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, R, mean_rstd, db, dslope, N, C,
+                     inv_hw);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int gs_inorm_finalize(const float* partial, int32_t N, int32_t slots, int32_t C, int64_t hw, float eps,
@@ -473,9 +499,18 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
   }
   __syncthreads();
   const float* mr = mean_rstd + (size_t)n * 2 * C;
-  if (db && chunk == 0 && tid < 64) {
-    // bias gradient of the conv in front of the norm = sum over pixels of dy = -rstd * S2 * S3 / hw (zero up to rounding)
-    unsafeAtomicAdd(db + cg * 64 + tid, -mr[C + cg * 64 + tid] * tot[1][tid] * tot[2][tid] * inv_hw);
+  if (db && chunk == 0 && n == 0 && tid < 64) {
+    // bias gradient of the conv in front of the norm = sum over images and pixels of dy = sum_n -rstd * S2 * S3 / hw (zero
+    // up to rounding, like the reference's). One workgroup per channel group walks the images in order: no atomics.
+    const int N = gridDim.z;
+    float acc = 0.f;
+    for (int n2 = 0; n2 < N; ++n2) {
+      double t1 = 0.0, t2 = 0.0;
+      const float* src = partial + (size_t)n2 * slots * 3 * C + cg * 64 + tid;
+      for (int sl = 0; sl < slots; ++sl) { t1 += (double)src[((size_t)sl * 3 + 1) * C]; t2 += (double)src[((size_t)sl * 3 + 2) * C]; }
+      acc += -mean_rstd[(size_t)n2 * 2 * C + C + cg * 64 + tid] * (float)t1 * (float)t2 * inv_hw;
+    }
+    db[cg * 64 + tid] += acc;
   }
   const int cl = tid & 7, lane = tid >> 3;
   const int c8 = cg * 8 + cl;
@@ -525,7 +560,7 @@ int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, fl
     hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
                        mean_rstd, db);
   GS_CHECK_HIP(hipGetLastError());
-  return 0;
+  return gs_launch_norm_param_grads(out, 3, mean_rstd, db, nullptr, N, C, inv_hw, st);
 }
 
 // pixels per block of the reduction pass: 64 for 2-D sized maps, more for volumes so that the second-level sum

@@ -11,6 +11,10 @@
 // final per-image accumulation into the parameter-gradient buffer, as in wgrad).
 #include "common.hpp"
 
+// norm.hip: parameter gradients summed over the images in a fixed order
+int gs_launch_norm_param_grads(const float* sums, int R, const float* mean_rstd, float* db, float* dslope, int N, int C,
+                               float inv_hw, hipStream_t st);
+
 struct PNormK {
   gs_pnorm_desc d;
   int C8;
@@ -204,11 +208,6 @@ __global__ __launch_bounds__(256) void pnorm_bwd_finalize_kernel(const float* pa
   if (lane == 0 && c < C) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) sums[((size_t)n * 4 + r) * C + c] = tot[r][col];
-    if (dslope) unsafeAtomicAdd(dslope + c, tot[3][col]);
-    if (db && mean_rstd) {
-      const float rstd = mean_rstd[(size_t)n * 2 * C + C + c];
-      unsafeAtomicAdd(db + c, -rstd * tot[1][col] * tot[2][col] * inv_hw);
-    }
   }
 }
 
@@ -320,6 +319,9 @@ extern "C" int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const vo
       hipLaunchKernelGGL((pnorm_bwd_finalize_kernel<16>), dim3((d->C + 15) / 16, d->N), dim3(256), 0, st, scratch, sums,
                          chunks, d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
     GS_CHECK_HIP(hipGetLastError());
+    // slope and bias gradients: per-image totals added in image order (norm.hip), not by atomics
+    if (int rc = gs_launch_norm_param_grads(sums, 4, mean_rstd, bias_grad, slope ? dslope : nullptr, d->N, d->C,
+                                            1.0f / (float)d->pixels, st)) return rc;
   }
   long long bx = ((long long)k.HW * k.C8 + 255) / 256;
   if (bx > 1024) bx = 1024;

@@ -422,7 +422,7 @@ extern "C" int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g
 // 256 threads = COLS 8-channel columns x (256/COLS) pixel lanes, 16-B loads; grid (pixel chunks, column groups)
 template <int COLS>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy, long long pixels, int C8, int cs,
-                                                        int co, float* db, int pix_per_block) {
+                                                        int co, float* db, int pix_per_block, float* ws) {
   constexpr int ROWS = 256 / COLS;
   __shared__ float red[ROWS][COLS][9];
   const int tid = threadIdx.x;
@@ -449,24 +449,50 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) s += red[r][cc][k];
-      unsafeAtomicAdd(db + ch8 * 8 + k, s);
+      if (ws) ws[(size_t)blockIdx.x * C8 * 8 + ch8 * 8 + k] = s;      // slab per pixel chunk, summed in order afterwards
+      else unsafeAtomicAdd(db + ch8 * 8 + k, s);
     }
   }
 }
 
-extern "C" int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db,
-                            void* stream) {
-  GS_REQUIRE(dy && db && pixels > 0 && C > 0 && (C & 7) == 0 && (cs & 7) == 0 && (co & 7) == 0,
+static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, float* ws,
+                          int64_t ws_floats, int plan_only, void* stream, int64_t* need) {
+  GS_REQUIRE(pixels > 0 && C > 0 && (C & 7) == 0 && (cs & 7) == 0 && (co & 7) == 0,
              "gs_bias_grad: bad argument (C, cs, co must be multiples of 8)");
   const int C8 = C / 8;
   int ppb = (int)((pixels + 1023) / 1024);
   if (ppb < 64) ppb = 64;
   const unsigned bx = (unsigned)((pixels + ppb - 1) / ppb);
+  if (need) *need = (int64_t)bx * C;
+  if (plan_only) return 0;
+  GS_REQUIRE(dy && db, "gs_bias_grad: null argument");
+  GS_REQUIRE(!ws || ws_floats >= (int64_t)bx * C, "gs_bias_grad_ws: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned short* p = static_cast<const unsigned short*>(dy);
-  if (C8 >= 32) hipLaunchKernelGGL((bias_grad_kernel<32>), dim3(bx, (C8 + 31) / 32), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb);
-  else if (C8 >= 8) hipLaunchKernelGGL((bias_grad_kernel<8>), dim3(bx, (C8 + 7) / 8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb);
-  else hipLaunchKernelGGL((bias_grad_kernel<1>), dim3(bx, C8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb);
+  if (C8 >= 32) hipLaunchKernelGGL((bias_grad_kernel<32>), dim3(bx, (C8 + 31) / 32), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
+  else if (C8 >= 8) hipLaunchKernelGGL((bias_grad_kernel<8>), dim3(bx, (C8 + 7) / 8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
+  else hipLaunchKernelGGL((bias_grad_kernel<1>), dim3(bx, C8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   GS_CHECK_HIP(hipGetLastError());
+  if (ws) {
+    const long long n4 = C / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(db), n4, (int)bx, n4);
+    GS_CHECK_HIP(hipGetLastError());
+  }
   return 0;
+}
+
+extern "C" int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db,
+                            void* stream) {
+  return bias_grad_impl(dy, pixels, C, cs, co, db, nullptr, 0, 0, stream, nullptr);
+}
+// deterministic form: per-chunk partial sums to the caller's workspace, then added to db in chunk order
+extern "C" int64_t gs_bias_grad_ws_floats(int64_t pixels, int32_t C) {
+  int64_t need = 0;
+  return bias_grad_impl(nullptr, pixels, C, 8, 0, nullptr, nullptr, 0, 1, nullptr, &need) ? -1 : need;
+}
+extern "C" int gs_bias_grad_ws(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, float* ws,
+                               int64_t ws_floats, void* stream) {
+  GS_REQUIRE(ws, "gs_bias_grad_ws: null workspace");
+  return bias_grad_impl(dy, pixels, C, cs, co, db, ws, ws_floats, 0, stream, nullptr);
 }

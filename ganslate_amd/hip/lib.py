@@ -70,6 +70,9 @@ _PROTOS = {
     "gs_wgrad_ws": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_bias_grad": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gs_bias_grad_ws_floats": (C.c_int64, [C.c_int64, C.c_int32]),
+    "gs_bias_grad_ws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_void_p]),
     "gs_inorm_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float,
                                     C.c_void_p, C.c_void_p]),
     "gs_inorm_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

@@ -225,6 +225,12 @@ class HipOps:
 
     def bias_grad(self, dy, C_, db, *, cs=None, co=0):
         pixels = dy.numel() // dy.shape[-1]
+        if os.environ.get("GS_WGRAD_DET", "1") != "0":      # deterministic: partial sums + fixed-order second stage
+            nws = int(self.lib.gs_bias_grad_ws_floats(pixels, C_))
+            ws = torch.empty(nws, dtype=torch.float32, device=self.device)
+            L.check(self.lib.gs_bias_grad_ws(_ptr(dy), pixels, C_, cs if cs is not None else dy.shape[-1], co, _ptr(db),
+                                             _ptr(ws), nws, _stream()), "gs_bias_grad_ws")
+            return
         L.check(self.lib.gs_bias_grad(_ptr(dy), pixels, C_, cs if cs is not None else dy.shape[-1], co, _ptr(db),
                                       _stream()), "gs_bias_grad")
 

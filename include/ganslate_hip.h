@@ -139,6 +139,10 @@ int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g1, const vo
                 float* ws, int64_t ws_floats, void* stream);
 /* db[c] += sum over pixels of dy[pix, c]  (bias gradient of any conv) */
 int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, void* stream);
+/* deterministic form (per-chunk partial sums in a caller-owned workspace, added in chunk order) */
+int64_t gs_bias_grad_ws_floats(int64_t pixels, int32_t C);
+int gs_bias_grad_ws(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, float* ws,
+                    int64_t ws_floats, void* stream);
 
 /* ---- InstanceNorm + activation (nn.InstanceNorm2d eps=1e-5 affine=False, nn/utils.py:53-59) ------ */
 /* partial [N][slots][2][C] -> mean_rstd [N][2][C] */

@@ -14,7 +14,9 @@ the merged weight-gradient launch (gs_wgrad_pair), the fused norm-backward reduc
 Stated tolerances and where they come from (measured table: profiles/r02_gradient_parity.txt).
   * NORM — every tensor's gradient norm within 2 % of the fp32 oracle's (5 % below 100 elements). Measured at 256x256
     batch 8: 1.000 +- 0.002 for all 48 generator and 10 discriminator tensors with >= 100 elements. A dropped, doubled or
-    halved backward pass moves a norm by tens of percent: this is the check that sees it (8 % below 100 elements).
+    halved backward pass moves a norm by tens of percent: this is the check that sees it. Small tensors right under the
+    loss (the 9408-element output conv: 0.974 .. 1.019 over runs and shapes; its 3-element bias: 0.88 .. 1.02) carry the
+    sign-flip noise described below un-averaged: 4 % below 100 000 elements, 15 % below 100.
   * COSINE — discriminators >= 0.965 (measured 0.980 .. 1.000, degrading ~0.3 % per layer: bf16 rounding moves the
     ~0.5 % of pre-activations next to a LeakyReLU kink across it). Generators >= 0.92 (measured 0.935 .. 0.999): flat
     over the 21 lower layers and set almost entirely at the TOP of the backward pass by the L1 cycle loss, whose
@@ -73,7 +75,7 @@ def test_step0_gradients_vs_oracle_and_reference(hip_ops, name):
     for net, n, cos, ratio, numel in rows:
         print(f"  {net:5s} {n:32s} cos {cos:.5f}  norm ratio {ratio:.4f}  ({numel} elements)")
     bad = [(net, n, round(cos, 4), round(ratio, 4)) for net, n, cos, ratio, numel in rows
-           if cos < COS[net[0]] or abs(ratio - 1) > (NORM if numel >= 100 else 0.08)]
+           if cos < COS[net[0]] or abs(ratio - 1) > (NORM if numel >= 100_000 else (0.04 if numel >= 100 else 0.15))]
     assert not bad, bad
 
 
