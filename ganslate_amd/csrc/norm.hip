@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const uint4* gpad,
 template <int FM>
 __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gpad, const uint4* g2, const uint4* y,
                                                                  const float* mean_rstd, const float* partial,
-                                                                 int slots, uint4* dy, uint4* gsum, float* db, int D,
+                                                                 int slots, uint4* dy, uint4* gsum, float* sums, int D,
                                                                  int H, int W, int C8, int fold, int act, float slope,
                                                                  int pix_per_block) {
   __shared__ float tot[3][64];
@@ -499,18 +499,11 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
   }
   __syncthreads();
   const float* mr = mean_rstd + (size_t)n * 2 * C;
-  if (db && chunk == 0 && n == 0 && tid < 64) {
-    // bias gradient of the conv in front of the norm = sum over images and pixels of dy = sum_n -rstd * S2 * S3 / hw (zero
-    // up to rounding, like the reference's). One workgroup per channel group walks the images in order: no atomics.
-    const int N = gridDim.z;
-    float acc = 0.f;
-    for (int n2 = 0; n2 < N; ++n2) {
-      double t1 = 0.0, t2 = 0.0;
-      const float* src = partial + (size_t)n2 * slots * 3 * C + cg * 64 + tid;
-      for (int sl = 0; sl < slots; ++sl) { t1 += (double)src[((size_t)sl * 3 + 1) * C]; t2 += (double)src[((size_t)sl * 3 + 2) * C]; }
-      acc += -mean_rstd[(size_t)n2 * 2 * C + C + cg * 64 + tid] * (float)t1 * (float)t2 * inv_hw;
-    }
-    db[cg * 64 + tid] += acc;
+  if (sums && chunk == 0 && tid < 192) {
+    // per-image totals for the bias gradient of the conv in front of the norm (gs_norm_bias_grads adds them up over the
+    // images in order; they used to be fp32 atomics)
+    const int r = tid >> 6, ch = tid & 63;
+    sums[((size_t)n * 3 + r) * C + cg * 64 + ch] = tot[r][ch];
   }
   const int cl = tid & 7, lane = tid >> 3;
   const int c8 = cg * 8 + cl;
@@ -561,6 +554,41 @@ int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, fl
                        mean_rstd, db);
   GS_CHECK_HIP(hipGetLastError());
   return gs_launch_norm_param_grads(out, 3, mean_rstd, db, nullptr, N, C, inv_hw, st);
+}
+
+// Bias gradients of the convs in front of InstanceNorms for MANY layers in one launch: item i adds
+// sum_n -rstd[n][c] * S2[n][c] * S3[n][c] / hw to db_i[c] from the per-image totals gs_inorm_act_backward left at
+// scratch + N * slots * 3 * C (block = (256 channels, item)); one thread per channel walks the images in order.
+struct NormDbBatch {
+  gs_norm_db_item it[GS_NORM_DB_MAX];
+};
+__global__ __launch_bounds__(256) void norm_bias_grads_kernel(const NormDbBatch b) {
+  const gs_norm_db_item& it = b.it[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= it.C) return;
+  float acc = 0.f;
+  for (int n = 0; n < it.N; ++n)
+    acc += -it.mean_rstd[(size_t)n * 2 * it.C + it.C + c] * it.sums[((size_t)n * 3 + 1) * it.C + c] *
+           it.sums[((size_t)n * 3 + 2) * it.C + c] * it.inv_hw;
+  it.db[c] += acc;
+}
+extern "C" int gs_norm_bias_grads(const gs_norm_db_item* items, int32_t count, void* stream) {
+  GS_REQUIRE(items && count > 0, "gs_norm_bias_grads: bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int i0 = 0; i0 < count; i0 += GS_NORM_DB_MAX) {
+    NormDbBatch b;
+    const int n = count - i0 < GS_NORM_DB_MAX ? count - i0 : GS_NORM_DB_MAX;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+      b.it[i] = items[i0 + i];
+      GS_REQUIRE(b.it[i].sums && b.it[i].mean_rstd && b.it[i].db && b.it[i].N > 0 && b.it[i].C > 0,
+                 "gs_norm_bias_grads: bad item %d", i0 + i);
+      if (b.it[i].C > cmax) cmax = b.it[i].C;
+    }
+    hipLaunchKernelGGL(norm_bias_grads_kernel, dim3((cmax + 255) / 256, n), dim3(256), 0, st, b);
+    GS_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 // pixels per block of the reduction pass: 64 for 2-D sized maps, more for volumes so that the second-level sum
@@ -629,14 +657,16 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   hipLaunchKernelGGL((inorm_bwd_apply_cg_kernel<FM>), dim3(C / 64, (unsigned)((HW + ppb - 1) / ppb), N), dim3(256), 0, \
                      st, static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2),                            \
                      static_cast<const uint4*>(y), mean_rstd, scratch, chunks, static_cast<uint4*>(dy),              \
-                     static_cast<uint4*>(gsum), bias_grad, D, H, W, C8, fold, act, slope, ppb)
+                     static_cast<uint4*>(gsum), sums, D, H, W, C8, fold, act, slope, ppb)
       if (fm == 0) GS_LAUNCH_APPLY_CG(0);
       else if (fm == 1) GS_LAUNCH_APPLY_CG(1);
       else if (fm == 2) GS_LAUNCH_APPLY_CG(2);
       else GS_LAUNCH_APPLY_CG(3);
 #undef GS_LAUNCH_APPLY_CG
       GS_CHECK_HIP(hipGetLastError());
-      return 0;
+      // per-image totals are at `sums` now; the bias gradient, if asked for here, is one more tiny launch (executors
+      // pass bias_grad = NULL and batch all their norm layers into one gs_norm_bias_grads call)
+      return gs_launch_norm_param_grads(sums, 3, mean_rstd, bias_grad, nullptr, N, C, 1.0f / (float)HW, st);
     }
     if (int rc = gs_launch_slot_sum3(scratch, sums, N, chunks, C, 1.0f / (float)HW, mean_rstd, bias_grad, st)) return rc;
   }

@@ -41,6 +41,12 @@ class GConvFuse(C.Structure):
         (n, C.c_int32) for n in ("Dy", "Hy", "Wy", "fold", "fold_mode", "act")] + [("slope", C.c_float)]
 
 
+class NormDbItem(C.Structure):
+    """Mirror of gs_norm_db_item."""
+    _fields_ = [("sums", C.c_void_p), ("mean_rstd", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("C", C.c_int32),
+                ("inv_hw", C.c_float), ("pad_", C.c_int32)]
+
+
 class PNormDesc(C.Structure):
     """Mirror of gs_pnorm_desc."""
     _fields_ = [("pixels", C.c_int64)] + [(n, C.c_int32) for n in (
@@ -83,6 +89,7 @@ _PROTOS = {
     "gs_inorm_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "gs_norm_bias_grads": (C.c_int, [C.POINTER(NormDbItem), C.c_int32, C.c_void_p]),
     "gs_inorm_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gs_norm_act_forward_ex": (C.c_int, [C.POINTER(NormExDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),

@@ -265,6 +265,21 @@ class HipOps:
                                                _ptr(gsum), _ptr(scratch), _ptr(bias_grad), N, D, H, W, Cc, fold,
                                                L.BORDER[fold_mode], L.ACT[act], slope, pre_slots, _stream()),
                 "gs_inorm_act_backward")
+        if mean_rstd is None:
+            return None
+        # the per-image totals [N][3][C] sit behind the partial slots: (holder tensor, float offset) for norm_bias_grads
+        return scratch, scratch.numel() - N * 3 * Cc
+
+    def norm_bias_grads(self, items):
+        """bias gradients of the convs in front of InstanceNorms for many layers in one launch;
+        items: (sums holder, float offset, mean_rstd, db, N, C, hw)"""
+        if not items:
+            return
+        arr = (L.NormDbItem * len(items))()
+        for a, (holder, off, mean_rstd, db, N, Cc, hw) in zip(arr, items):
+            a.sums, a.mean_rstd, a.db = holder.data_ptr() + 4 * off, mean_rstd.data_ptr(), db.data_ptr()
+            a.N, a.C, a.inv_hw = N, Cc, 1.0 / hw
+        L.check(self.lib.gs_norm_bias_grads(arr, len(items), _stream()), "gs_norm_bias_grads")
 
     # ---- generalised norm / activation for skip-connection graphs (U-Net) ---------------------------------
     def _norm_ex_desc(self, y, act1, act2, slope, drop_p, seed, seed_dev=None):

@@ -400,6 +400,7 @@ class NativeNet:
                 ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
             pending = (ga, 0, None, "reflect")
         skip: Dict[int, torch.Tensor] = {}
+        db_items = []        # bias gradients of the convs in front of norms: one batched launch at the end of the pass
         final_pass = want_w and self._dist is not None and self._fw_pending == 0 and not self.external_reduce
         # another recorded forward of this net still awaits its backward (G_AB(real_A) and G_AB(fake_A) in one step):
         # hold the weight gradients of mergeable layers back and issue both passes as one launch then
@@ -424,8 +425,12 @@ class NativeNet:
                 if nd.norm:
                     # the bias gradient of a conv in front of an InstanceNorm comes out of the norm's reduction sums
                     db = grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
-                    ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, fold_mode=fmode,
-                                           act=nd.act, slope=nd.slope, bias_grad=db, pre=pre)
+                    # (data parallel, bucketed: the bucket holding db is all-reduced as soon as this layer is done -> inline)
+                    sums = ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, fold_mode=fmode,
+                                                  act=nd.act, slope=nd.slope, bias_grad=db if final_pass else None,
+                                                  pre=pre)
+                    if db is not None and not final_pass:
+                        db_items.append((sums[0], sums[1], s.mrs[i], db, N, sp.cout_p, lw.out_pixels))
                 else:
                     ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, fold_mode=fmode, act=nd.act,
                                            slope=nd.slope)
@@ -486,6 +491,8 @@ class NativeNet:
                     pending = (gx, f, g2n, fmode_n)
             if start is None:
                 s.acts[i + 1] = None  # release as we go
+        if db_items:
+            ops.norm_bias_grads(db_items)
         if not need_input_grad:
             return None
         gx, f, _, fmode = pending[:4]

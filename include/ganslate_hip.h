@@ -172,6 +172,21 @@ int gs_inorm_act_backward(const void* g_pad, const void* g2, const void* y, cons
 /* pre_slots > 0: `scratch` already holds the partial sums [N][pre_slots][3][C] (written by gs_gconv_forward_fused)
  * followed by room for the [N][3][C] totals; the reduction pass is skipped. */
 int64_t gs_inorm_backward_scratch_floats(int32_t N, int32_t D, int32_t H, int32_t W, int32_t C);
+/* gs_inorm_act_backward always leaves the per-image totals [N][3][C] (sum ghat, sum ghat*yhat, sum yhat) behind the
+ * partial slots, at scratch + N * slots * 3 * C (slots = pre_slots, or the chunk count of its own reduction pass =
+ * gs_inorm_backward_scratch_floats / (3 N C) - 1). An executor that passes bias_grad = NULL there can add the bias
+ * gradients of ALL its norm layers with one launch afterwards: item i does db[c] += sum over images (in order) of
+ * -rstd * S2 * S3 / hw. */
+#define GS_NORM_DB_MAX 32
+typedef struct gs_norm_db_item {
+  const float* sums;        /* [N][3][C] totals left by gs_inorm_act_backward */
+  const float* mean_rstd;   /* [N][2][C] */
+  float* db;                /* [C], accumulated into */
+  int32_t N, C;
+  float inv_hw;             /* 1 / (D*H*W) */
+  int32_t pad_;
+} gs_norm_db_item;
+int gs_norm_bias_grads(const gs_norm_db_item* items, int32_t count, void* stream);
 
 /* Generalised form for skip-connection graphs (nn/generators/unet/unet2d.py:110-157): the normalised tensor is read
  * through up to two activations (LeakyReLU by the next down-conv, ReLU by the up-conv on the skip half of

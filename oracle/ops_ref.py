@@ -221,6 +221,17 @@ class RefOps:
         dy.copy_(d.to(dy.dtype))
         if bias_grad is not None:      # sum over pixels of dy: identically zero up to rounding
             bias_grad[:Cc] += d.reshape(-1, Cc).sum(0)
+        # per-image totals [N][3][C] for a deferred norm_bias_grads call (same contract as the HIP backend)
+        hw = y.numel() // (N * Cc)
+        sums = torch.stack([s1.reshape(N, Cc) * hw, s2.reshape(N, Cc) * hw, yh.reshape(N, -1, Cc).sum(1)], 1).contiguous()
+        return sums, 0
+
+    def norm_bias_grads(self, items):
+        """items: (sums holder, offset, mean_rstd, db, N, C, hw): db[c] += sum_n -rstd * S2 * S3 / hw"""
+        for holder, off, mean_rstd, db, N, Cc, hw in items:
+            sums = holder.reshape(-1)[off:off + N * 3 * Cc].view(N, 3, Cc)
+            rstd = mean_rstd.view(N, 2, Cc)[:, 1]
+            db[:Cc] += (-rstd * sums[:, 1] * sums[:, 2] / hw).sum(0)
 
     # ---- generalised norm / activation for skip-connection graphs (U-Net) -------------------------------
     @staticmethod
