@@ -307,7 +307,9 @@ class BaseGAN(ABC):
         for name, net in self.networks.items():
             checkpoint[name] = {k: v.cpu() for k, v in net.state_dict().items()}
         for name, optim in self.optimizers.items():      # reference saves only G and D (base.py:244-245)
-            checkpoint[f"optimizer_{name}"] = optim.state_dict()
+            # per-parameter Adam state in the reference's layout (a reference run can resume from it and vice versa)
+            checkpoint[f"optimizer_{name}"] = optim.reference_state_dict() if hasattr(optim, "reference_state_dict") \
+                else optim.state_dict()
         torch.save(checkpoint, path)
 
     def load_networks(self, iter_idx):
@@ -319,10 +321,14 @@ class BaseGAN(ABC):
         if self.is_train and self.conf[self.conf.mode].checkpointing.load_optimizers:
             for name, optim in self.optimizers.items():
                 key = f"optimizer_{name}"
-                if key in checkpoint and _is_native_optimizer_state(checkpoint[key], optim):
+                if key not in checkpoint:
+                    self.logger.info(f"{key}: not in the checkpoint; starting from scratch")
+                elif _is_native_optimizer_state(checkpoint[key], optim):       # round-1 checkpoints: flat layout
                     optim.load_state_dict(checkpoint[key])
+                elif hasattr(optim, "load_reference_state_dict"):
+                    optim.load_reference_state_dict(checkpoint[key])           # raises on a shape / count mismatch
                 else:
-                    self.logger.info(f"{key}: no compatible state in the checkpoint; starting from scratch")
+                    optim.load_state_dict(checkpoint[key])
 
     def set_requires_grad(self, networks, requires_grad=False):
         if not isinstance(networks, list):

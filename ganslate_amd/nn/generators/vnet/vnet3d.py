@@ -76,12 +76,18 @@ class Vnet3D(NativeNet):
         conv = lambda *a, **k: ConvSpec(*a, dims=dims, **k)
         nodes, extras = [], []
 
+        order = []           # parameter keys in the order the blocks register them
+
         def add_conv(spec, norm, name, aliases=()):
             nodes.append(Node(spec, norm, "none", name=name, aliases=tuple(aliases)))
+            order.append(f"{name}.weight")
+            if spec.bias:
+                order.append(f"{name}.bias")
             return len(nodes) - 1
 
         def add_slope(name, size, aliases=()):
             extras.append(Extra(name, size, 0.25, tuple(aliases)))
+            order.append(name)
             return name
 
         enc = lambda i, rest: (f"encoder.{i}.{rest}",)       # `encoder` = [in_ab] + downs (vnet3d.py:88)
@@ -127,6 +133,12 @@ class Vnet3D(NativeNet):
         self.s_o1 = add_slope("out_ab.relu1.weight", 2 * c)
         self.n_o2 = add_conv(conv("conv", 2 * c, out_channels, 1, 1, 0), False, "out_ab.conv2")
         super().__init__(nodes, in_channels, out_channels, out_act="tanh", extras=extras)
+        # the reference registers in_ab, out_ab, downs, ups in that order (vnet3d.py:60-88); inside a block the order above
+        rank = {"in_ab": 0, "out_ab": 1, "downs": 2, "ups": 3}
+        self._param_order = sorted(order, key=lambda k: rank[k.split(".")[0]])       # stable
+
+    def reference_parameter_order(self):
+        return list(self._param_order)
 
     # ---- lowering: every node at the resolution level it runs at -------------------------------------------------
     def _lowered(self, *sizes):

@@ -189,6 +189,41 @@ class NativeNet:
             sd[ex.name] = g[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
         return sd
 
+    # ---- flat buffers <-> the reference's per-parameter tensors (optimizer state in checkpoints) ------------------
+    def reference_parameter_order(self):
+        """state_dict keys of this network's parameters in the order torch's Module.parameters() yields them in the
+        reference network (index i of an `optimizer.state_dict()['state']` saved by the reference, base.py:244-245)"""
+        keys = []
+        for nd in self.nodes:
+            keys.append(f"{nd.name}.weight")
+            if nd.spec.bias:
+                keys.append(f"{nd.name}.bias")
+        return keys + [ex.name for ex in self.extras]
+
+    def flat_to_tensors(self, flat) -> Dict[str, torch.Tensor]:
+        """a flat fp32 buffer laid out like the master (Adam moments, gradients) as torch-layout tensors by key"""
+        out = {}
+        for i, nd in enumerate(self.nodes):
+            out[f"{nd.name}.weight"] = nd.spec.torch_from_master(flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel])
+            if nd.spec.bias:
+                out[f"{nd.name}.bias"] = flat[self.b_off[i]:self.b_off[i] + nd.spec.cout].clone()
+        for ex in self.extras:
+            out[ex.name] = flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+        return out
+
+    def tensors_to_flat(self, tensors, flat):
+        """inverse of flat_to_tensors: writes torch-layout tensors into a flat buffer (padding stays zero)"""
+        host = torch.zeros(self.numel, dtype=torch.float32)
+        for i, nd in enumerate(self.nodes):
+            w = tensors[f"{nd.name}.weight"].detach().float().cpu()
+            host[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
+            if nd.spec.bias:
+                host[self.b_off[i]:self.b_off[i] + nd.spec.cout] = tensors[f"{nd.name}.bias"].detach().float().cpu()
+        for ex in self.extras:
+            host[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = tensors[ex.name].detach().float().cpu().reshape(-1)
+        with torch.no_grad():
+            flat.copy_(host.to(flat.device))
+
     def mark_packs_dirty(self):
         self._packs_dirty = True
 

@@ -81,6 +81,57 @@ class NativeAdam(torch.optim.Optimizer):
             if "hyper" in st_old:
                 st_new["hyper"] = st_old["hyper"]
 
+    # ---- the reference's checkpoint format (torch.optim.Adam.state_dict over per-layer parameters, base.py:244-245) --
+    def reference_state_dict(self):
+        """This optimiser's state as `torch.optim.Adam(itertools.chain(net.parameters() ...)).state_dict()` of the
+        reference would hold it: one entry per torch parameter (conv weight / bias / PReLU slope, torch layouts), indexed
+        in the networks' parameters() order (cyclegan.py:70-82: G_AB then G_BA; D_B then D_A)."""
+        state, index = {}, 0
+        groups = []
+        for group in self.param_groups:
+            ids = []
+            for p in group["params"]:
+                net, st = p._owner_net, self.state.get(p, {})
+                moments = {k: net.flat_to_tensors(st[k].detach()) for k in ("exp_avg", "exp_avg_sq") if k in st}
+                for key in net.reference_parameter_order():
+                    if moments:
+                        state[index] = {"step": torch.tensor(float(st["step"])),
+                                        "exp_avg": moments["exp_avg"][key].cpu(),
+                                        "exp_avg_sq": moments["exp_avg_sq"][key].cpu()}
+                    ids.append(index)
+                    index += 1
+            g = {k: v for k, v in group.items() if k != "params"}
+            g.update(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                     fused=None, params=ids)
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_reference_state_dict(self, sd):
+        """inverse of reference_state_dict: accepts what the reference wrote (`optimizer_G` / `optimizer_D`)"""
+        index = 0
+        for group, saved in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "betas", "eps", "initial_lr"):
+                if k in saved:
+                    group[k] = tuple(saved[k]) if k == "betas" else saved[k]
+            for p in group["params"]:
+                net = p._owner_net
+                keys = net.reference_parameter_order()
+                entries = [sd["state"].get(index + i) for i in range(len(keys))]
+                index += len(keys)
+                if any(e is None for e in entries):
+                    if all(e is None for e in entries):
+                        continue                      # optimiser never stepped
+                    raise ValueError("reference optimizer state covers only part of a network's parameters")
+                st = self.state[p]
+                st.setdefault("exp_avg", torch.zeros_like(p))
+                st.setdefault("exp_avg_sq", torch.zeros_like(p))
+                st["step"] = int(float(entries[0]["step"]))
+                for mk in ("exp_avg", "exp_avg_sq"):
+                    net.tensors_to_flat({key: e[mk] for key, e in zip(keys, entries)}, st[mk])
+        n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_saved != index:
+            raise ValueError(f"reference optimizer state has {n_saved} parameters, these networks have {index}")
+
     def zero_grad(self, set_to_none=True):
         """The update kernel already cleared the gradient it consumed; only buffers written since are cleared."""
         for group in self.param_groups:
