@@ -22,7 +22,29 @@ def init_config(conf, config_class):
             spec.loader.exec_module(module)
             sys.modules["project"] = module
     conf = instantiate_dataclasses_from_yaml(conf)
-    return OmegaConf.merge(OmegaConf.structured(config_class), conf)
+    merged = OmegaConf.merge(OmegaConf.structured(config_class), conf)
+    _complete_optional_sections(config_class, merged)
+    return merged
+
+
+def _complete_optional_sections(dc_type, node):
+    """`val: Optional[ValidationConfig] = None` and the like: when the YAML provides the section, the dataclass defaults
+    of its declared type apply underneath it (OmegaConf's typed merge does this; the lite merge only sees a dict
+    replacing None)."""
+    import dataclasses
+    import typing
+    hints = typing.get_type_hints(dc_type)
+    for f in dataclasses.fields(dc_type):
+        t = hints.get(f.name)
+        args = [a for a in typing.get_args(t) if a is not type(None)] if typing.get_origin(t) is typing.Union else []
+        inner = args[0] if len(args) == 1 else (t if dataclasses.is_dataclass(t) else None)
+        child = node._d.get(f.name) if isinstance(node, DictConfig) else None
+        if inner is None or not dataclasses.is_dataclass(inner) or not isinstance(child, DictConfig):
+            continue
+        if args:        # Optional[...] section present in the YAML: defaults first, the YAML's values on top
+            node._set(f.name, OmegaConf.merge(OmegaConf.structured(inner), child))
+            child = node._d[f.name]
+        _complete_optional_sections(inner, child)
 
 
 def instantiate_dataclasses_from_yaml(conf):

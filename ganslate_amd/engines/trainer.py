@@ -32,6 +32,19 @@ class Trainer:
         self.iter_idx = 0
         self.history = []           # (iter, losses, metrics) captured at logging time
         self._t_comp, self._n_comp = 0.0, 0
+        self.validator = self._init_validator()
+
+    def _init_validator(self):
+        """validation engine built from the training conf (trainer.py:95-101); None without a `val` section"""
+        if not getattr(self.conf, "val", None):
+            return None
+        from .validator import Validator
+        return Validator(self.conf, self.model)
+
+    def _run_validation(self):
+        if self.validator:
+            if self.iter_idx % self.conf.val.freq == 0 and self.iter_idx >= self.conf.val.start_after:
+                self.validator.run(current_idx=self.iter_idx)
 
     def run(self):
         self.logger.info("Training started.")
@@ -45,6 +58,7 @@ class Trainer:
             self._log_iter(learning_rates, losses, metrics)
             self._save_checkpoint()
             self._perform_scheduler_step()
+            self._run_validation()
 
     def _run_iteration(self, data):
         self.model.set_input(data)
