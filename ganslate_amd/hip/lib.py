@@ -47,6 +47,12 @@ class NormDbItem(C.Structure):
                 ("inv_hw", C.c_float), ("pad_", C.c_int32)]
 
 
+class PatchNCEDesc(C.Structure):
+    """Mirror of gs_patchnce_desc."""
+    _fields_ = [("levels", C.c_int32), ("batch", C.c_int32), ("patches", C.c_int32), ("nc", C.c_int32),
+                ("channels", C.c_int32 * 8), ("nce_T", C.c_float), ("lambda_nce", C.c_float)]
+
+
 class PNormDesc(C.Structure):
     """Mirror of gs_pnorm_desc."""
     _fields_ = [("pixels", C.c_int64)] + [(n, C.c_int32) for n in (
@@ -128,6 +134,12 @@ _PROTOS = {
     "gs_ssim_distance_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_ssim_backward_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gs_patchnce_param_floats": (C.c_int64, [C.POINTER(PatchNCEDesc)]),
+    "gs_patchnce_work_bytes": (C.c_int64, [C.POINTER(PatchNCEDesc)]),
+    "gs_patchnce_forward": (C.c_int, [C.POINTER(PatchNCEDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_patchnce_backward": (C.c_int, [C.POINTER(PatchNCEDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float),
                                C.c_float, C.c_int32, C.c_void_p]),
     "gs_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

@@ -467,3 +467,37 @@ class HipOps:
         scratch = torch.empty(self.lib.gs_ssim_backward_scratch_floats(NC, H, W), dtype=torch.float32, device=x.device)
         L.check(self.lib.gs_ssim_distance_backward(_ptr(x), _ptr(y), NC, H, W, _ptr(grad_scale), _ptr(grad_y),
                                                    _ptr(scratch), _stream()), "gs_ssim_distance_backward")
+
+    # ---- PatchNCE + patch MLP (csrc/patchnce.hip) ---------------------------------------------------------------
+    def _nce_desc(self, channels, batch, patches, nc, nce_T, lambda_nce):
+        d = L.PatchNCEDesc()
+        d.levels, d.batch, d.patches, d.nc, d.nce_T, d.lambda_nce = len(channels), batch, patches, nc, nce_T, lambda_nce
+        for i, c in enumerate(channels):
+            d.channels[i] = c
+        return d
+
+    def patchnce_forward(self, xq, xk, params, *, batch, nc=256, nce_T=0.07, lambda_nce=1.0):
+        """xq / xk: lists of [batch, patches, C_l] fp32 (target / source patches per level), params: flat fp32 MLP
+        parameters -> (loss per level [L] fp32, saved state for patchnce_backward)"""
+        channels = [int(t.shape[-1]) for t in xq]
+        patches = int(xq[0].shape[1])
+        d = self._nce_desc(channels, batch, patches, nc, nce_T, lambda_nce)
+        xq = [t.contiguous().float() for t in xq]
+        xk = [t.contiguous().float() for t in xk]
+        work = torch.empty(int(self.lib.gs_patchnce_work_bytes(C.byref(d))), dtype=torch.uint8, device=self.device)
+        loss = torch.empty(len(xq), dtype=torch.float32, device=self.device)
+        pq = (C.c_void_p * len(xq))(*[t.data_ptr() for t in xq])
+        pk = (C.c_void_p * len(xk))(*[t.data_ptr() for t in xk])
+        L.check(self.lib.gs_patchnce_forward(C.byref(d), pq, pk, _ptr(params), _ptr(work), _ptr(loss), _stream()),
+                "gs_patchnce_forward")
+        return loss, (d, xq, work)
+
+    def patchnce_backward(self, saved, params, grads, grad_scale=None):
+        """-> list of d(sum of level losses)/d xq[l] * grad_scale; parameter gradients are added into `grads`"""
+        d, xq, work = saved
+        dxq = [torch.empty_like(t) for t in xq]
+        pq = (C.c_void_p * len(xq))(*[t.data_ptr() for t in xq])
+        pd = (C.c_void_p * len(xq))(*[t.data_ptr() for t in dxq])
+        L.check(self.lib.gs_patchnce_backward(C.byref(d), pq, pd, _ptr(params), _ptr(grads), _ptr(work),
+                                              _ptr(grad_scale), _stream()), "gs_patchnce_backward")
+        return dxq

@@ -14,11 +14,9 @@ from typing import Tuple
 
 import numpy as np
 import torch
-from torch import nn
 
 from .... import configs
 from ...losses.adversarial_loss import AdversarialLoss
-from ...losses.cut_losses import PatchNCELoss
 from ...optim import NativeAdam
 from ..base import BaseGAN
 
@@ -60,7 +58,7 @@ class CUT(BaseGAN):
         if self.is_train:
             G = self.networks["G"]
             channels = [G.encoder_tap(e)[1] for e in self.nce_layers]
-            mlp = FeaturePatchMLP(channels, self.num_patches, self.conf.train.gan.mlp_nc).to(self.device)
+            mlp = FeaturePatchMLP(channels, self.num_patches, self.conf.train.gan.mlp_nc)
             mlp.init_weights(self.conf.train.gan.weight_init_type, self.conf.train.gan.weight_init_gain)
             self.networks["mlp"] = mlp
 
@@ -69,11 +67,12 @@ class CUT(BaseGAN):
         betas = (opt.beta1, opt.beta2)
         self.optimizers["G"] = NativeAdam(self.networks["G"].parameters(), lr=opt.lr_G, betas=betas)
         self.optimizers["D"] = NativeAdam(self.networks["D"].parameters(), lr=opt.lr_D, betas=betas)
-        self.optimizers["mlp"] = torch.optim.Adam(self.networks["mlp"].parameters(), lr=opt.lr_G, betas=betas)
+        self.optimizers["mlp"] = NativeAdam(self.networks["mlp"].parameters(), lr=opt.lr_G, betas=betas)
 
     def init_criterions(self):
         self.criterion_adv = AdversarialLoss(self.conf.train.gan.optimizer.adversarial_loss_type).to(self.device)
-        self.criterion_nce = [PatchNCELoss(self.conf).to(self.device) for _ in self.nce_layers]
+        # PatchNCELoss (cut_losses.py) is fused with the patch MLP into FeaturePatchMLP.nce_loss (csrc/patchnce.hip)
+        self.nce_T = self.conf.train.gan.optimizer.nce_T
 
     def parallelize_networks(self):
         for name, net in self.networks.items():
@@ -92,7 +91,6 @@ class CUT(BaseGAN):
         self.optimizers["mlp"].zero_grad(set_to_none=True)
         self.backward_G_and_mlp()
         self.optimizers["G"].step()
-        self.networks["mlp"].finish_grad_reduction()
         self.optimizers["mlp"].step()
 
     def set_input(self, input):
@@ -164,53 +162,144 @@ class CUT(BaseGAN):
                 w = (W + 6) if e == 0 else (W if e < 4 else (W // 2 if e < 7 else W // 4))
                 tgt_ids.append((pid // w) * w + (w - 1 - pid % w))
         target_feats = G.extract_patch_features(target, self.nce_layers, tgt_ids)
-        source_pool = mlp(source_feats)
-        target_pool = mlp(target_feats)
-        nce_loss = 0
-        for target_feat, source_feat, criterion in zip(target_pool, source_pool, self.criterion_nce):
-            nce_loss = nce_loss + (criterion(target_feat, source_feat) * self.lambda_nce).mean()
-        return nce_loss / len(self.nce_layers)
+        # both MLP passes, the logits, the cross-entropy and the mean over patches and levels: one autograd node
+        return mlp.nce_loss(target_feats, source_feats, source.shape[0], self.nce_T, self.lambda_nce)
 
 
-class FeaturePatchMLP(nn.Module):
-    """per-level Linear(C, nc) - ReLU - Linear(nc, nc) - L2 normalise on already-sampled patches [N, P, C]
-    (cut.py:229-294; the patch sampling itself happens at the activation gather). Plain library GEMMs."""
+class _PatchNCEFn(torch.autograd.Function):
+    """FeaturePatchMLP + PatchNCELoss over all feature levels as ONE autograd node on the HIP kernels of
+    csrc/patchnce.hip: forward = 3 launches (MLP both sides, logits/loss/dL/dF, loss sum), backward = 2 (MLP data
+    gradient, parameter gradients). Source (key) features are detached like in the reference (cut_losses.py:16)."""
+
+    @staticmethod
+    def forward(ctx, token, mlp, batch, nce_T, lambda_nce, n, *feats):
+        target, source = list(feats[:n]), list(feats[n:])
+        loss, saved = mlp.ops.patchnce_forward(target, source, mlp.master.detach(), batch=batch, nc=mlp.nc, nce_T=nce_T,
+                                               lambda_nce=lambda_nce)
+        ctx.mlp, ctx.saved, ctx.n = mlp, saved, n
+        ctx.needs = [ctx.needs_input_grad[6 + i] for i in range(n)]
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        mlp = ctx.mlp
+        if mlp.master.grad is None:
+            mlp.master.grad = torch.zeros_like(mlp.master)
+        dxq = mlp.ops.patchnce_backward(ctx.saved, mlp.master.detach(), mlp.master.grad if mlp.requires_grad else
+                                        torch.zeros_like(mlp.master), grad_scale=g.contiguous().float())
+        mlp.grad_dirty = True
+        ctx.saved = None
+        return (None,) * 6 + tuple(d if need else None for d, need in zip(dxq, ctx.needs)) + (None,) * ctx.n
+
+
+class FeaturePatchMLP:
+    """per-level Linear(C, nc) - ReLU - Linear(nc, nc) - L2 normalise on the sampled patches (cut.py:229-294; the patch
+    sampling itself happens at the activation gather). Parameters live in ONE flat fp32 buffer — per level W1 [nc][C],
+    b1 [nc], W2 [nc][nc], b2 [nc], the layout of gs_patchnce_* (include/ganslate_hip.h) — updated by NativeAdam like
+    the conv networks' masters; state_dict() speaks the reference's key names (`mlps.{i}.{0,2}.{weight,bias}`)."""
 
     def __init__(self, channels_per_feature, num_patches=256, nc=256):
-        super().__init__()
-        self.num_patches = num_patches
-        self.mlps = nn.ModuleList(
-            nn.Sequential(nn.Linear(c, nc), nn.ReLU(), nn.Linear(nc, nc)) for c in channels_per_feature)
-        self._dist = None
+        from ...native.backend import get_ops
+        self.ops = get_ops()
+        self.device = self.ops.device
+        self.channels, self.num_patches, self.nc = [int(c) for c in channels_per_feature], num_patches, nc
+        self.numel = sum(nc * c + nc + nc * nc + nc for c in self.channels)
+        self.master = torch.nn.Parameter(torch.zeros(self.numel, dtype=torch.float32, device=self.device))
+        self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.master._owner_net = self
+        self._token = torch.zeros(1, requires_grad=True, device=self.device)
+        self.grad_dirty, self._dist, self.external_reduce, self.training = False, None, False, True
 
-    def init_weights(self, init_type="normal", gain=0.02):
-        assert init_type == "normal", "FeaturePatchMLP: only `normal` init is used by the reference configs"
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                nn.init.normal_(m.weight, 0.0, gain)
-                nn.init.constant_(m.bias, 0.0)
+    # ---- nn.Module-like surface -------------------------------------------------------------------------------------
+    def parameters(self):
+        return [self.master]
 
-    def forward(self, feats):
-        out = []
-        for mlp, feat in zip(self.mlps, feats):
-            f = mlp(feat.flatten(0, 1))
-            norm = f.pow(2).sum(1, keepdim=True).pow(0.5)
-            out.append(f.div(norm + 1e-7))
+    @property
+    def requires_grad(self):
+        return self.master.requires_grad
+
+    def to(self, device):
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def mark_packs_dirty(self):
+        pass
+
+    def _views(self, flat):
+        out, off, nc = [], 0, self.nc
+        for c in self.channels:
+            W1 = flat[off:off + nc * c].view(nc, c); off += nc * c
+            b1 = flat[off:off + nc]; off += nc
+            W2 = flat[off:off + nc * nc].view(nc, nc); off += nc * nc
+            b2 = flat[off:off + nc]; off += nc
+            out.append((W1, b1, W2, b2))
         return out
 
+    def init_weights(self, init_type="normal", gain=0.02):
+        """ganslate/nn/utils.py:13-36 applied to nn.Linear: N(0, gain) weights, zero biases, drawn on the CPU generator
+        in module order (mlps.0.0, mlps.0.2, mlps.1.0, ...)"""
+        assert init_type == "normal", "FeaturePatchMLP: only `normal` init is used by the reference configs"
+        flat = torch.zeros(self.numel, dtype=torch.float32)
+        for W1, b1, W2, b2 in self._views(flat):
+            W1.copy_(torch.empty(W1.shape).normal_(0.0, gain))
+            W2.copy_(torch.empty(W2.shape).normal_(0.0, gain))
+        with torch.no_grad():
+            self.master.copy_(flat.to(self.device))
+
+    def reference_parameter_order(self):
+        return [f"mlps.{i}.{m}.{k}" for i in range(len(self.channels)) for m in (0, 2) for k in ("weight", "bias")]
+
+    def flat_to_tensors(self, flat):
+        out = {}
+        for i, (W1, b1, W2, b2) in enumerate(self._views(flat)):
+            out.update({f"mlps.{i}.0.weight": W1.clone(), f"mlps.{i}.0.bias": b1.clone(),
+                        f"mlps.{i}.2.weight": W2.clone(), f"mlps.{i}.2.bias": b2.clone()})
+        return out
+
+    def tensors_to_flat(self, tensors, flat):
+        host = torch.zeros(self.numel, dtype=torch.float32)
+        for i, views in enumerate(self._views(host)):
+            for v, key in zip(views, ("0.weight", "0.bias", "2.weight", "2.bias")):
+                v.copy_(tensors[f"mlps.{i}.{key}"].detach().float().cpu().reshape(v.shape))
+        with torch.no_grad():
+            flat.copy_(host.to(flat.device))
+
+    def state_dict(self):
+        return self.flat_to_tensors(self.master.detach())
+
+    def load_state_dict(self, sd, strict=True):
+        self.tensors_to_flat(sd, self.master)
+
+    # ---- the loss -----------------------------------------------------------------------------------------------------
+    def nce_loss(self, target_feats, source_feats, batch, nce_T, lambda_nce):
+        """sum over the levels of mean_patches(PatchNCE(mlp(target), mlp(source))) * lambda_nce / len(levels)
+        (cut.py:218-226)"""
+        n = len(target_feats)
+        return _PatchNCEFn.apply(self._token, self, batch, float(nce_T), float(lambda_nce), n, *target_feats,
+                                 *[f.detach() for f in source_feats])
+
+    # ---- data parallelism (the reference never gets this far: SURVEY.md §2.4) --------------------------------------------
     def parallelize(self, process_group=None):
         import torch.distributed as dist
         self._dist = process_group if process_group is not None else dist.group.WORLD
-        for p in self.parameters():
-            dist.broadcast(p.data, 0, group=self._dist)
+        with torch.no_grad():
+            dist.broadcast(self.master.data, 0, group=self._dist)
         return self
 
+    def flush_deferred_wgrads(self):
+        pass
+
     def finish_grad_reduction(self):
+        """called by NativeAdam before the update; returns the factor the summed gradient is scaled by"""
         if self._dist is None:
-            return
+            return 1.0
         import torch.distributed as dist
-        world = dist.get_world_size(self._dist)
-        for p in self.parameters():
-            if p.grad is not None:
-                dist.all_reduce(p.grad, group=self._dist)
-                p.grad.div_(world)
+        if not self.external_reduce and self.grad_dirty:
+            dist.all_reduce(self.master.grad, op=dist.ReduceOp.SUM, group=self._dist)
+        return 1.0 / dist.get_world_size(self._dist)

@@ -300,6 +300,29 @@ int gs_ssim_distance_backward(const float* x, const float* y, int32_t NC, int32_
                               const float* grad_scale, float* grad_y, float* scratch, void* stream);
 int64_t gs_ssim_backward_scratch_floats(int32_t NC, int32_t H, int32_t W);
 
+/* ---- PatchNCE + patch MLP of CUT (ganslate/nn/gans/unpaired/cut.py:229-294, ganslate/nn/losses/cut_losses.py:14-43) ----
+ * For every feature level l: sampled patches xq[l], xk[l] are [batch*patches][channels[l]] fp32 (target = query, source =
+ * key, row = image * patches + patch); FeaturePatchMLP level l = Linear(C_l, nc) - ReLU - Linear(nc, nc) - x/(||x||+1e-7);
+ * PatchNCE: logits [q.k+ , q.k_j over the other patches of the same image, diagonal -> -10] / nce_T, cross-entropy vs 0,
+ * keys detached. params / grads: one flat fp32 buffer, per level W1 [nc][C_l], b1 [nc], W2 [nc][nc], b2 [nc]
+ * (gs_patchnce_param_floats). loss[l] = lambda_nce / (levels * batch * patches) * sum over rows of the row loss, so that
+ * sum_l loss[l] is what CUT._calculate_nce_loss returns (cut.py:218-226).
+ * forward leaves what backward needs in `work` (gs_patchnce_work_bytes, caller-owned, same buffer for both calls);
+ * backward: dxq[l] = d(sum_l loss[l]) / d xq[l] * grad_scale[0], grads += parameter gradients * grad_scale[0]
+ * (grad_scale: device scalar, NULL = 1). nc must be 256 and patches <= 256 (the reference's defaults, cut.py:16-20). */
+#define GS_PATCHNCE_MAX_LEVELS 8
+typedef struct gs_patchnce_desc {
+  int32_t levels, batch, patches, nc;
+  int32_t channels[GS_PATCHNCE_MAX_LEVELS];
+  float nce_T, lambda_nce;
+} gs_patchnce_desc;
+int64_t gs_patchnce_param_floats(const gs_patchnce_desc* d);
+int64_t gs_patchnce_work_bytes(const gs_patchnce_desc* d);
+int gs_patchnce_forward(const gs_patchnce_desc* d, const float* const* xq, const float* const* xk, const float* params,
+                        void* work, float* loss, void* stream);
+int gs_patchnce_backward(const gs_patchnce_desc* d, const float* const* xq, float* const* dxq, const float* params,
+                         float* grads, void* work, const float* grad_scale, void* stream);
+
 /* ---- optimiser (torch.optim.Adam betas=(0.5,0.999) eps=1e-8, cyclegan.py:81-82) ------------------ */
 /* hyper (host pointer to 6 floats): lr, beta1, beta2, eps, bias_correction1, sqrt(bias_correction2).
  * grad_scale multiplies the gradient (1/world_size after an all-reduce SUM). zero_grad != 0 clears g. */

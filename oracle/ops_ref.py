@@ -507,6 +507,23 @@ class RefOps:
                 pool[c] = img
                 out[b] = img
 
+    # ---- PatchNCE + patch MLP: torch autograd of the reference composition --------------------------------------
+    def patchnce_forward(self, xq, xk, params, *, batch, nc=256, nce_T=0.07, lambda_nce=1.0):
+        with torch.enable_grad():
+            xq_ = [t.detach().float().clone().requires_grad_() for t in xq]
+            p_ = params.detach().clone().requires_grad_()
+            loss = patchnce_reference(xq_, [t.detach() for t in xk], p_, batch, nc, nce_T, lambda_nce)
+        return loss.detach(), (loss, xq_, p_)
+
+    def patchnce_backward(self, saved, params, grads, grad_scale=None):
+        loss, xq_, p_ = saved
+        with torch.enable_grad():
+            total = loss.sum()
+        g = torch.autograd.grad(total, xq_ + [p_])
+        s = float(grad_scale) if grad_scale is not None else 1.0
+        grads += g[-1] * s
+        return [t * s for t in g[:-1]]
+
     def repack(self, master, index, pack):
         idx = index.long()
         vals = master.reshape(-1)[idx.clamp_min(0)]
@@ -515,6 +532,40 @@ class RefOps:
     def repack_tiled(self, master, index, pack, rows, kp):
         """same refresh for one [rows][kp] segment (the HIP side only changes the access order)"""
         self.repack(master, index, pack)
+
+
+def _nce_levels(params, channels, nc):
+    """views of the flat parameter buffer: per level (W1 [nc][C], b1, W2 [nc][nc], b2)"""
+    out, off = [], 0
+    for c in channels:
+        W1 = params[off:off + nc * c].view(nc, c); off += nc * c
+        b1 = params[off:off + nc]; off += nc
+        W2 = params[off:off + nc * nc].view(nc, nc); off += nc * nc
+        b2 = params[off:off + nc]; off += nc
+        out.append((W1, b1, W2, b2))
+    return out
+
+
+def patchnce_reference(xq, xk, params, batch, nc, nce_T, lambda_nce):
+    """FeaturePatchMLP + PatchNCELoss exactly as the reference composes them (cut.py:218-226,229-294;
+    cut_losses.py:14-43), differentiable: returns the per-level losses whose sum is CUT._calculate_nce_loss"""
+    channels = [int(t.shape[-1]) for t in xq]
+    losses = []
+    for (W1, b1, W2, b2), q, k in zip(_nce_levels(params, channels, nc), xq, xk):
+        feats = []
+        for x in (q, k):
+            f = torch.relu(x.flatten(0, 1).float() @ W1.t() + b1) @ W2.t() + b2
+            feats.append(f / (f.pow(2).sum(1, keepdim=True).pow(0.5) + 1e-7))
+        fq, fk = feats[0], feats[1].detach()
+        l_pos = (fq * fk).sum(1, keepdim=True)
+        qb, kb = fq.view(batch, -1, nc), fk.view(batch, -1, nc)
+        n = qb.size(1)
+        l_neg = torch.bmm(qb, kb.transpose(2, 1))
+        l_neg = l_neg.masked_fill(torch.eye(n, dtype=torch.bool)[None], -10.0).view(-1, n)
+        out = torch.cat((l_pos, l_neg), dim=1) / nce_T
+        ce = torch.nn.functional.cross_entropy(out, torch.zeros(out.size(0), dtype=torch.long), reduction="none")
+        losses.append((ce * lambda_nce).mean() / len(xq))
+    return torch.stack(losses)
 
 
 def ssim_distance(X, Y):
