@@ -362,8 +362,11 @@ def main():
             "step_mfma_frac": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }
         if world > 1:
-            out["ddp_path"] = ("captured: graph(forward+backward) | one RCCL all-reduce per network, per-network overlap "
-                               "with the remaining backward | graph(Adam)") if graphed else \
+            out["ddp_path"] = (("one graph per iteration with the bucketed RCCL all-reduces captured inside it (overlapped "
+                                "with the remaining backward; GS_DDP_GRAPH_COLLECTIVES=1)")
+                               if getattr(model, "_graph_collectives", False) else
+                               ("graph(forward + backward) | one RCCL all-reduce per network on the flat gradient | "
+                                "graph(Adam)")) if graphed else \
                 "launch by launch: bucketed all-reduce overlapped with the last backward pass"
         if timing is not None:
             res = ops.kernel_timing_result()

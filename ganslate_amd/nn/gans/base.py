@@ -248,6 +248,13 @@ class BaseGAN(ABC):
         self._set_external_host_state(True)
         self._prepare_host_state()
         dp_nets = self._data_parallel_nets()
+        # GS_DDP_GRAPH_COLLECTIVES=1 (opt-in, verified with a 1-rank RCCL group only): the bucketed all-reduces the executors
+        # issue during their last backward pass are CAPTURED into the step graph (RCCL's kernels become nodes on their own
+        # branch, joined by the event wait in finish_grad_reduction), so a replayed iteration overlaps the reduction of the
+        # upper buckets and of the discriminators with the remaining backward work, and the step stays one graph.
+        self._graph_collectives = bool(dp_nets) and os.environ.get("GS_DDP_GRAPH_COLLECTIVES", "0") == "1"
+        if self._graph_collectives:
+            dp_nets = []
         pending = [] if dp_nets else None
         for optim in self.optimizers.values():
             optim.deferred_to = pending
@@ -258,7 +265,7 @@ class BaseGAN(ABC):
         try:
             # data parallel: RCCL's watchdog thread may poll events of earlier collectives while this thread captures;
             # only this thread's calls are policed then
-            mode = "thread_local" if dp_nets else "global"
+            mode = "thread_local" if (dp_nets or self._graph_collectives) else "global"
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 self._eager_step()
                 for net in dp_nets:

@@ -122,3 +122,19 @@ def test_two_ranks_over_rccl_average_to_the_big_batch_gradient(hip_ops, tmp_path
             assert torch.equal(r0["moments"][net][n], r1["moments"][net][n]), (net, n, "ranks differ")
             if w.norm().item() > 1e-9:
                 assert (r0["moments"][net][n] - w).norm().item() <= 2e-2 * w.norm().item(), (net, n)
+
+
+@pytest.mark.timeout(600)
+def test_captured_collectives_mode_single_rank(hip_ops):
+    """GS_DDP_GRAPH_COLLECTIVES=1 (opt-in): the bucketed RCCL all-reduces issued during the last backward pass are captured
+    INTO the step graph (one graph per iteration, reduction overlapped with the remaining backward). Run in a child
+    process with a hard timeout (a capture problem in RCCL must not take the test session down); with one rank the
+    replayed iterations must equal the single-process run bit for bit."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "ddp_graph_collectives_probe.py")], capture_output=True,
+                       text=True, timeout=420, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "collectives captured True" in r.stdout and "bitwise equal to single process: True" in r.stdout, r.stdout[-2000:]
