@@ -534,6 +534,10 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
     // one workgroup per CU is resident: if the 256-pixel tiling needs a second, mostly empty round of workgroups
     // but 320-pixel tiles fit in one round, the larger tile wins (e.g. the 66x66 padded-domain data gradients)
     const long long big320 = (long long)d->N * ((pix + 319) / 320) * ((d->Co + 127) / 128);
+    // ... and 288-pixel tiles (12 waves) when those fit too: 16 x 8 x 2 = 256 workgroups for the 66 x 66 domain at batch 8,
+    // every CU busy with 10 % less work each than the 224 workgroups of the 320-pixel tiling
+    const long long big288 = (long long)d->N * ((pix + 287) / 288) * ((d->Co + 127) / 128);
+    if (big > 256 && big <= 512 && big288 <= 256 && gs_opt(GS_OPT_GCONV_TILE288)) return {288, 128};
     if (big > 256 && big <= 512 && big320 <= 256) return {320, 128};
     return {256, 128};
   }
@@ -715,6 +719,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
   if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, (int)blocks, st);
   if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
   if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, (int)blocks, st);
+  if (tc.bm == 288) return launch<288, 128, 6, 2, 2>(k, (int)blocks, st);
   if (tc.bm == 256) return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);   // 16 waves: best measured (8 and 4 lose)
   return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
 }
