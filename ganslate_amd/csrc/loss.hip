@@ -69,6 +69,62 @@ __global__ __launch_bounds__(256) void mse_const_grad_kernel(const float* x, lon
     grad[i] = k * (x[i] - target);
 }
 
+// The other GAN objectives of AdversarialLoss (adversarial_loss.py:26-34,60-73) as one pointwise function per mode:
+//   vanilla       nn.BCEWithLogitsLoss vs the expanded label t: f = max(x,0) - x t + log1p(exp(-|x|)), f' = sigmoid(x) - t
+//   wgangp        -mean(x) for real, +mean(x) for fake
+//   nonsaturating softplus(-x) for real / softplus(x) for fake, averaged PER SAMPLE (a vector of `rows` losses); the
+//                 reference's branch raises NameError (F is never imported, :68-73) — F.softplus' definition (threshold 20)
+enum { ADV_LSGAN = 0, ADV_VANILLA = 1, ADV_WGANGP = 2, ADV_NONSAT = 3 };
+template <int MODE>
+__device__ __forceinline__ float adv_point(float x, float label, float sgn) {
+  if constexpr (MODE == ADV_LSGAN) { const float d = x - label; return d * d; }
+  if constexpr (MODE == ADV_VANILLA) return fmaxf(x, 0.f) - x * label + log1pf(expf(-fabsf(x)));
+  if constexpr (MODE == ADV_WGANGP) return sgn * x;
+  const float z = sgn * x;
+  return z > 20.f ? z : log1pf(expf(z));
+}
+template <int MODE>
+__device__ __forceinline__ float adv_point_grad(float x, float label, float sgn) {
+  if constexpr (MODE == ADV_LSGAN) return 2.f * (x - label);
+  if constexpr (MODE == ADV_VANILLA) return 1.f / (1.f + expf(-x)) - label;
+  if constexpr (MODE == ADV_WGANGP) return sgn;
+  const float z = sgn * x;
+  return z > 20.f ? sgn : sgn / (1.f + expf(-z));
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void adv_loss_kernel(const float* x, long long n, float label, float sgn, float* ws,
+                                                       float* loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    s += adv_point<MODE>(x[i], label, sgn);
+  s = block_sum(s, sh);
+  finish_reduction(s, ws, 1.0f / (float)n, loss);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void adv_loss_grad_kernel(const float* x, long long n, float label, float sgn,
+                                                            float* grad, const float* gscale) {
+  const float k = (gscale ? gscale[0] : 1.f) / (float)n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    grad[i] = k * adv_point_grad<MODE>(x[i], label, sgn);
+}
+// nonsaturating: one workgroup per sample, fixed-shape sum
+__global__ __launch_bounds__(256) void adv_rows_kernel(const float* x, long long per, float sgn, float* loss) {
+  __shared__ float sh[4];
+  const float* xr = x + (long long)blockIdx.x * per;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < per; i += blockDim.x) s += adv_point<ADV_NONSAT>(xr[i], 0.f, sgn);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) loss[blockIdx.x] = s / (float)per;
+}
+__global__ __launch_bounds__(256) void adv_rows_grad_kernel(const float* x, long long per, float sgn, float* grad,
+                                                            const float* gscale) {
+  const long long base = (long long)blockIdx.x * per;
+  const float k = (gscale ? gscale[blockIdx.x] : 1.f) / (float)per;
+  for (long long i = threadIdx.x; i < per; i += blockDim.x)
+    grad[base + i] = k * adv_point_grad<ADV_NONSAT>(x[base + i], 0.f, sgn);
+}
+
 __global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b, long long n, float* ws, float* loss) {
   __shared__ float sh[4];
   float s = 0.f;
@@ -109,6 +165,32 @@ extern "C" int gs_mse_const(const float* x, int64_t n, float target, float* loss
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (loss) hipLaunchKernelGGL(mse_const_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, ws, loss);
   if (grad) hipLaunchKernelGGL(mse_const_grad_kernel, dim3(red_blocks(n)), dim3(256), 0, st, x, (long long)n, target, grad, grad_scale);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+template <int MODE>
+static void adv_launch(const float* x, long long n, float label, float sgn, float* ws, float* loss, float* grad,
+                       const float* gscale, hipStream_t st) {
+  if (loss) hipLaunchKernelGGL(adv_loss_kernel<MODE>, dim3(red_blocks(n)), dim3(256), 0, st, x, n, label, sgn, ws, loss);
+  if (grad) hipLaunchKernelGGL(adv_loss_grad_kernel<MODE>, dim3(red_blocks(n)), dim3(256), 0, st, x, n, label, sgn, grad, gscale);
+}
+extern "C" int gs_adv_loss(const float* x, int64_t n, int32_t rows, int32_t mode, int32_t target_is_real, float label,
+                           float* loss, float* grad, const float* grad_scale, void* stream) {
+  GS_REQUIRE(x && n > 0 && (loss || grad) && mode >= ADV_LSGAN && mode <= ADV_NONSAT, "gs_adv_loss: bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float sgn = target_is_real ? -1.f : 1.f;
+  if (mode == ADV_NONSAT) {
+    GS_REQUIRE(rows > 0 && n % rows == 0, "gs_adv_loss: nonsaturating needs n divisible by rows (the batch)");
+    if (loss) hipLaunchKernelGGL(adv_rows_kernel, dim3(rows), dim3(256), 0, st, x, (long long)(n / rows), sgn, loss);
+    if (grad) hipLaunchKernelGGL(adv_rows_grad_kernel, dim3(rows), dim3(256), 0, st, x, (long long)(n / rows), sgn, grad, grad_scale);
+    GS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  float* ws = gs_reduce_workspace(stream);
+  if (!ws) { if (!gs_zero_page()) gs_set_error("gs_adv_loss: library not initialised (call gs_init)"); return 2; }
+  if (mode == ADV_LSGAN) adv_launch<ADV_LSGAN>(x, n, label, sgn, ws, loss, grad, grad_scale, st);
+  else if (mode == ADV_VANILLA) adv_launch<ADV_VANILLA>(x, n, label, sgn, ws, loss, grad, grad_scale, st);
+  else adv_launch<ADV_WGANGP>(x, n, label, sgn, ws, loss, grad, grad_scale, st);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -126,6 +126,8 @@ _PROTOS = {
     "gs_shiftadd_to_image_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_mse_const": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_adv_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]),
     "gs_l1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gs_ssim_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -415,6 +415,13 @@ class HipOps:
                 "gs_shiftadd_to_image_backward")
 
     # ---- losses ---------------------------------------------------------------------------------------------
+    ADV_MODES = {"lsgan": 0, "vanilla": 1, "wgangp": 2, "nonsaturating": 3}
+
+    def adv_loss(self, x, mode, target_is_real, label, loss=None, grad=None, grad_scale=None):
+        """gs_adv_loss: `x` is one discriminator map (B, ...), fp32; nonsaturating reduces per sample (loss: B floats)"""
+        L.check(self.lib.gs_adv_loss(_ptr(x), x.numel(), x.shape[0], self.ADV_MODES[mode], int(bool(target_is_real)),
+                                     float(label), _ptr(loss), _ptr(grad), _ptr(grad_scale), _stream()), "gs_adv_loss")
+
     def mse_const(self, x, target, loss=None, grad=None, grad_scale=None):
         L.check(self.lib.gs_mse_const(_ptr(x), x.numel(), float(target), _ptr(loss), _ptr(grad), _ptr(grad_scale),
                                       _stream()), "gs_mse_const")

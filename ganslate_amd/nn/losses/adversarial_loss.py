@@ -1,11 +1,11 @@
 """GAN objectives — interface of ganslate/nn/losses/adversarial_loss.py:7-98 (lsgan | vanilla | wgangp |
-nonsaturating; dict-of-predictions averaged). `lsgan` runs the fused MSE-vs-constant kernel."""
+nonsaturating; dict-of-predictions averaged). Every mode is one fused reduction kernel forward and one elementwise kernel
+backward (gs_mse_const / gs_adv_loss)."""
 from typing import Dict, Union
 
 import torch
-import torch.nn.functional as F
 
-from .functional import mse_const_loss
+from .functional import adversarial_loss, mse_const_loss
 
 
 class AdversarialLoss:
@@ -23,15 +23,9 @@ class AdversarialLoss:
         target = self.real_label if target_is_real else self.fake_label
         if self.gan_mode == "lsgan":
             return mse_const_loss(prediction, target)
-        if self.gan_mode == "vanilla":
-            return F.binary_cross_entropy_with_logits(prediction, torch.full_like(prediction, target))
-        if self.gan_mode == "wgangp":
-            return -prediction.mean() if target_is_real else prediction.mean()
         # nonsaturating: the reference raises NameError here (adversarial_loss.py:68-73 uses F without importing
-        # it); the intended softplus form is implemented instead
-        bs = prediction.size(0)
-        sign = -1.0 if target_is_real else 1.0
-        return F.softplus(sign * prediction).view(bs, -1).mean(dim=1)
+        # it); the intended per-sample softplus form is implemented instead
+        return adversarial_loss(prediction, self.gan_mode, target_is_real, target)
 
     def __call__(self, prediction: Union[Dict[str, torch.Tensor], torch.Tensor], target_is_real: bool):
         if isinstance(prediction, dict):

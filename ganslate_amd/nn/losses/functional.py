@@ -1,4 +1,4 @@
-"""Autograd entry points of the fused loss kernels (libganslate_hip: gs_l1, gs_mse_const, gs_mean,
+"""Autograd entry points of the fused loss kernels (libganslate_hip: gs_l1, gs_mse_const, gs_adv_loss, gs_mean,
 gs_ssim_distance). Each forward is one wavefront-reduced kernel writing a 0-d fp32 tensor; each backward is one
 elementwise kernel that folds the upstream scalar gradient in (passed as a device pointer — no host sync)."""
 import torch
@@ -39,6 +39,30 @@ class _MSEConst(torch.autograd.Function):
         gx = torch.empty_like(x)
         get_ops().mse_const(x, ctx.target, grad=gx, grad_scale=g.contiguous())
         return gx, None
+
+
+class _Adversarial(torch.autograd.Function):
+    """gs_adv_loss: vanilla / wgangp give a 0-d loss, nonsaturating one loss per sample"""
+    @staticmethod
+    def forward(ctx, x, mode, target_is_real, label):
+        x = x.contiguous()
+        loss = torch.empty((x.shape[0],) if mode == "nonsaturating" else (), dtype=torch.float32, device=x.device)
+        get_ops().adv_loss(x, mode, target_is_real, label, loss=loss)
+        ctx.save_for_backward(x)
+        ctx.args = (mode, target_is_real, label)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        get_ops().adv_loss(x, *ctx.args, grad=gx, grad_scale=g.contiguous().float())
+        return gx, None, None, None
+
+
+def adversarial_loss(x, mode: str, target_is_real: bool, label: float):
+    """AdversarialLoss.calculate_loss for the modes other than lsgan (adversarial_loss.py:52-73)"""
+    return _Adversarial.apply(x.float(), mode, bool(target_is_real), float(label))
 
 
 def l1_loss(a, b):

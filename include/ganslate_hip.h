@@ -283,6 +283,16 @@ int gs_shiftadd_to_image_backward(const float* g_img, const float* out_img, void
  * (nn.MSELoss vs expanded constant, adversarial_loss.py:28-29,60-62) */
 int gs_mse_const(const float* x, int64_t n, float target, float* loss, float* grad, const float* grad_scale,
                  void* stream);
+/* Every objective of AdversarialLoss.calculate_loss (adversarial_loss.py:52-73) on one discriminator map of n floats.
+ * mode GS_ADV_LSGAN      mean((x-label)^2)                                    (= gs_mse_const)
+ *      GS_ADV_VANILLA    nn.BCEWithLogitsLoss vs the expanded label            (:31-32,60-62)
+ *      GS_ADV_WGANGP     -mean(x) if target_is_real else +mean(x)             (:63-67)
+ *      GS_ADV_NONSAT     per-sample mean of softplus(-x) / softplus(x): loss and grad_scale hold `rows` floats, rows = the
+ *                        batch (:68-73; the reference's branch dies on an unimported F — this is what it spells out)
+ * loss and/or grad (n floats, = grad_scale * d loss / d x) are written; either may be NULL. */
+enum { GS_ADV_LSGAN = 0, GS_ADV_VANILLA = 1, GS_ADV_WGANGP = 2, GS_ADV_NONSAT = 3 };
+int gs_adv_loss(const float* x, int64_t n, int32_t rows, int32_t mode, int32_t target_is_real, float label,
+                float* loss, float* grad, const float* grad_scale, void* stream);
 /* loss[0] = mean(|a-b|); if grad_a != NULL: grad_a = grad_scale * sign(a-b)/n
  * (nn.L1Loss, cyclegan_losses.py:64,75,97-101) */
 int gs_l1(const float* a, const float* b, int64_t n, float* loss, float* grad_a, const float* grad_scale,

@@ -156,8 +156,8 @@ def make_conf(c):
                               "in_out_channels": {"AB": [3, 3], "BA": [3, 3]}},
                 "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN2D", "ndf": 64, "n_layers": 3,
                                   "kernel_size": [4, 4], "in_channels": {"B": 3, "A": 3}},
-                "optimizer": {"adversarial_loss_type": "lsgan", "beta1": 0.5, "beta2": 0.999, "lr_D": 0.0002,
-                              "lr_G": 0.0002, "lambda_AB": 10.0, "lambda_BA": 10.0,
+                "optimizer": {"adversarial_loss_type": c.get("adv", "lsgan"), "beta1": 0.5, "beta2": 0.999,
+                              "lr_D": 0.0002, "lr_G": 0.0002, "lambda_AB": 10.0, "lambda_BA": 10.0,
                               "lambda_identity": c["lambda_identity"], "proportion_ssim": c["proportion_ssim"]},
             },
         },

@@ -3,6 +3,7 @@
     python -m oracle.gen_golden_r2 grads       # tests/golden/cyclegan_grads.json
     python -m oracle.gen_golden_r2 envelope    # tests/golden/envelope.json
     python -m oracle.gen_golden_r2 fullsize    # tests/golden/fullsize.json
+    python -m oracle.gen_golden_r2 advmodes    # tests/golden/adv_modes.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -12,6 +13,9 @@
   run with 1 and with 8 intra-op threads. The arithmetic is identical, only the summation order of MKL-DNN's
   reductions differs; the gap between the two curves is the floor no other implementation can be asked to beat and
   the tolerances of the step tests are derived from it (tests/envelope.py).
+* adv_modes.json — the objectives of AdversarialLoss other than lsgan (adversarial_loss.py:26-34,60-67): its value and
+  input gradient on a seeded discriminator map, and four CycleGAN iterations with `adversarial_loss_type` vanilla /
+  wgangp. (`nonsaturating` cannot be recorded: the reference's branch raises NameError, :68-73.)
 """
 import json
 import random
@@ -107,10 +111,48 @@ def fullsize():
     (OUT / "fullsize.json").write_text(json.dumps(out, indent=1))
 
 
+ADV_CASES = {
+    "c64_vanilla": dict(size=64, batch=2, steps=4, n_iters=20, n_iters_decay=10, pool_size=50, lambda_identity=0.0,
+                        proportion_ssim=0.0, seed=15, adv="vanilla"),
+    "c64_wgangp": dict(size=64, batch=2, steps=4, n_iters=20, n_iters_decay=10, pool_size=50, lambda_identity=0.0,
+                       proportion_ssim=0.0, seed=16, adv="wgangp"),
+}
+
+
+def adv_pred(seed=21):
+    """the seeded discriminator map the op-level vectors are taken on: logits of a few units, both signs"""
+    return torch.randn(8, 1, 30, 30, generator=torch.Generator().manual_seed(seed)) * 3.0
+
+
+def advmodes():
+    from oracle import gen_golden as G          # imports the reference
+    from ganslate.nn.losses.adversarial_loss import AdversarialLoss
+    torch.set_num_threads(8)
+    ops = {}
+    for mode in ("lsgan", "vanilla", "wgangp"):
+        crit = AdversarialLoss(mode)
+        for real in (True, False):
+            x = adv_pred().requires_grad_()
+            val = crit(x, real)
+            (g,) = torch.autograd.grad(val, x)
+            flat = g.flatten()
+            idx = torch.linspace(0, flat.numel() - 1, 8).long()
+            ops[f"{mode}_{'real' if real else 'fake'}"] = {
+                "loss": float(val), "grad_norm": float(flat.double().norm()), "idx": [int(i) for i in idx],
+                "grad_samples": [float(v) for v in flat[idx]]}
+        # dict of predictions: mean over the keys (adversarial_loss.py:91-94)
+        d = {"a": adv_pred(22), "b": adv_pred(23)[:, :, :7, :7]}
+        ops[f"{mode}_dict_real"] = {"loss": float(crit(d, True))}
+    steps = {n: G.run_case(n, c) for n, c in ADV_CASES.items()}
+    (OUT / "adv_modes.json").write_text(json.dumps({"ops": ops, "steps": steps}, indent=1))
+
+
 def main():
     what = sys.argv[1]
     if what == "fullsize":
         fullsize()
+    elif what == "advmodes":
+        advmodes()
     elif what == "grads":
         torch.set_num_threads(8)
         out = {n: grad_case(n, c) for n, c in GRAD_CASES.items()}

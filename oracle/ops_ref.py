@@ -443,6 +443,26 @@ class RefOps:
             gz[..., dw:dw + W, dw * Co:(dw + 1) * Co] = gl.to(gz.dtype)
 
     # ---- losses -----------------------------------------------------------------------------------------
+    def adv_loss(self, x, mode, target_is_real, label, loss=None, grad=None, grad_scale=None):
+        """AdversarialLoss.calculate_loss (ganslate/nn/losses/adversarial_loss.py:52-73) through torch autograd"""
+        import torch.nn.functional as F
+        with torch.enable_grad():
+            xi = x.detach().clone().requires_grad_()
+            if mode == "lsgan":
+                val = F.mse_loss(xi, torch.full_like(xi, label))
+            elif mode == "vanilla":
+                val = F.binary_cross_entropy_with_logits(xi, torch.full_like(xi, label))
+            elif mode == "wgangp":
+                val = -xi.mean() if target_is_real else xi.mean()
+            else:
+                val = F.softplus(-xi if target_is_real else xi).view(xi.size(0), -1).mean(dim=1)
+            if grad is not None:
+                up = grad_scale if grad_scale is not None else torch.ones_like(val)
+                (g,) = torch.autograd.grad(val, xi, up.reshape(val.shape).to(val.dtype))
+                grad.copy_(g)
+        if loss is not None:
+            loss.copy_(val.detach().reshape(loss.shape))
+
     def mse_const(self, x, target, loss=None, grad=None, grad_scale=None):
         if loss is not None:
             loss.copy_(((x - target) ** 2).mean())

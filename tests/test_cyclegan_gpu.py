@@ -138,6 +138,29 @@ def test_training_step_matches_reference_golden(hip_ops, name):
     _check_steps(got, gold["steps"], n_steps)
 
 
+@pytest.mark.parametrize("name", ["c64_vanilla", "c64_wgangp"])
+def test_training_step_with_other_adversarial_objectives(hip_ops, name):
+    """`adversarial_loss_type` vanilla / wgangp (adversarial_loss.py:31-34,60-67) through the whole captured step against
+    four iterations of the real reference (tests/golden/adv_modes.json). The wgangp terms are differences of means of
+    order 0.5 that pass through zero, so the adversarial family gets an absolute floor of 2e-2 (= the relative bf16
+    term of the lsgan case on quantities of order one) next to the envelope-derived relative tolerance."""
+    import json
+    from .helpers import GOLD
+    gold = json.loads((GOLD / "adv_modes.json").read_text())["steps"][name]
+    c = gold["config"]
+    model = build_product_cyclegan(c, (f"train.gan.optimizer.adversarial_loss_type={c['adv']}",))
+    got = run_product_steps(model, c, c["steps"])
+    assert model._graph is not None, "the step was never captured"
+    from .envelope import family
+    for s in range(c["steps"]):
+        g = gold["steps"][s]
+        assert got[s]["lrs"] == pytest.approx(g["lrs"], abs=1e-12)
+        for k, v in g["losses"].items():
+            floor = 2e-2 * (s + 1) if family(k) == "adv" else 0.0
+            assert got[s]["losses"][k] == pytest.approx(v, rel=step_tolerance(k, s), abs=floor), \
+                (s, k, got[s]["losses"][k], v)
+
+
 def test_training_step_at_headline_shape_matches_reference_golden(hip_ops):
     """BASELINE configs[1] (256x256, batch 8: the shape bench.py times, with its own tile selection — gconv<320,128>,
     hconvw, hwgrad_wide pairs) against two iterations of the real reference (tests/golden/cyclegan_grads.json)"""

@@ -523,6 +523,70 @@ def test_losses_and_metrics(hip_ops):
     close_f32(outs[1][2], outs[0][2], "mse grad", rel=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["lsgan", "vanilla", "wgangp", "nonsaturating"])
+@pytest.mark.parametrize("real", [True, False])
+def test_adversarial_objectives(hip_ops, mode, real):
+    """gs_adv_loss — every branch of AdversarialLoss.calculate_loss (adversarial_loss.py:52-73) — against the op-level
+    oracle (autograd of the torch formulas) and, where the reference can produce them, its own vectors
+    (tests/golden/adv_modes.json); logits up to +-12 so both tails of the sigmoid / softplus are exercised"""
+    import json
+    from pathlib import Path
+    x = torch.randn(8, 1, 30, 30, generator=torch.Generator().manual_seed(21)) * 3.0
+    label = 1.0 if real else 0.0
+    rows = 8 if mode == "nonsaturating" else 1
+    scale = torch.linspace(0.5, 2.5, rows).reshape(rows if rows > 1 else ())
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        loss = torch.zeros((rows,) if rows > 1 else (), device=dev)
+        grad = torch.empty_like(x, device=dev)
+        ops.adv_loss(x.to(dev), mode, real, label, loss=loss)
+        ops.adv_loss(x.to(dev), mode, real, label, grad=grad, grad_scale=scale.to(dev))
+        outs.append((loss.cpu(), grad.cpu()))
+    assert torch.allclose(outs[1][0], outs[0][0], rtol=2e-5, atol=1e-6), (outs[1][0], outs[0][0])
+    close_f32(outs[1][1], outs[0][1], f"{mode} grad", rel=2e-6)
+    if mode != "nonsaturating":
+        g = json.loads((Path(__file__).parent / "golden" / "adv_modes.json").read_text())["ops"]
+        g = g[f"{mode}_{'real' if real else 'fake'}"]
+        assert float(outs[1][0]) == pytest.approx(g["loss"], rel=2e-5, abs=1e-6)
+        got = outs[1][1].flatten()[g["idx"]] / float(scale)
+        assert torch.allclose(got, torch.tensor(g["grad_samples"]), rtol=1e-5, atol=1e-9)
+
+
+def test_adversarial_loss_module(hip_ops):
+    """the product's AdversarialLoss (autograd wrappers over gs_mse_const / gs_adv_loss): dict of predictions -> mean
+    over the keys (adversarial_loss.py:91-94), per-sample vector for nonsaturating, gradients through both"""
+    import json
+    from pathlib import Path
+    from ganslate_amd.nn.losses.adversarial_loss import AdversarialLoss
+    gold = json.loads((Path(__file__).parent / "golden" / "adv_modes.json").read_text())["ops"]
+    mk = lambda seed: torch.randn(8, 1, 30, 30, generator=torch.Generator().manual_seed(seed)) * 3.0
+    for mode in ("lsgan", "vanilla", "wgangp"):
+        d = {"a": mk(22).to(hip_ops.device).requires_grad_(),
+             "b": mk(23)[:, :, :7, :7].contiguous().to(hip_ops.device).requires_grad_()}
+        val = AdversarialLoss(mode)(d, True)
+        assert float(val) == pytest.approx(gold[f"{mode}_dict_real"]["loss"], rel=2e-5, abs=1e-6)
+        val.backward()
+        want = {k: v.detach().cpu().clone().requires_grad_() for k, v in d.items()}
+        ref = torch.stack([torch_ref_adv(p, True, mode) for p in want.values()]).mean()
+        ref.backward()
+        for k in d:
+            close_f32(d[k].grad.cpu(), want[k].grad, f"{mode} dict grad {k}", rel=2e-6)
+    x = mk(24).to(hip_ops.device).requires_grad_()
+    per_sample = AdversarialLoss("nonsaturating")(x, False)
+    assert per_sample.shape == (8,)
+    per_sample.mean().backward()
+    xr = mk(24).requires_grad_()
+    want = torch.nn.functional.softplus(xr).view(8, -1).mean(dim=1)
+    want.mean().backward()
+    assert torch.allclose(per_sample.detach().cpu(), want.detach(), rtol=2e-5, atol=1e-6)
+    close_f32(x.grad.cpu(), xr.grad, "nonsaturating grad", rel=2e-6)
+
+
+def torch_ref_adv(pred, real, mode):
+    from oracle.torch_ref import adversarial_loss
+    return adversarial_loss(pred, real, mode)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 1, 37, 53), (1, 2, 6, 40, 44)])
 def test_ssim_distance_backward(hip_ops, shape):
     """hand-written gradient of the SSIM distance (gradient maps + transposed separable Gaussian) against autograd of
