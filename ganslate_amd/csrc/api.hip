@@ -55,8 +55,8 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hwgrad_planes", 1},       // ... 3x3x3 layers as three depth planes of it
     {"norm_bwd_ppb", 0},        // pixels per workgroup of the norm-backward reduction (0 = heuristic; tuning aid)
     {"norm_apply_unroll", 4},   // elements per thread of the norm-backward apply pass (tuning aid)
-    {"debug", 0},               // TEMPORARY timing experiments
     {"gconv_tile288", 1},       // 288-pixel im2col tiles where they make exactly one round of workgroups (else 320)
+    {"gconv_multi", 1},         // the parity classes of a stride-2 transposed conv / data gradient as one launch
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -20,6 +20,17 @@
 #include "common.hpp"
 #include <cstdlib>
 
+// What differs between the output-parity classes of one stride-2 transposed conv / stride-2 data gradient (same tensors,
+// same class extent, same Co): weight block, taps, output phase, statistics slot. Up to 8 classes (3-D) of up to 8 taps
+// ride in one launch (gs_gconv_forward_multi): workgroup -> (class, image, pixel tile, channel tile).
+constexpr int GS_MULTI_MAX_CLS = 8, GS_MULTI_MAX_TAPS = 8;
+struct GConvCls {
+  long long w_off;             // byte offset of this class's [w_rows][Kp] block from GConvK::w
+  int T, Kp, pz, py, px, stats_slot0, nh, nw;
+  signed char ud[GS_MULTI_MAX_TAPS], uh[GS_MULTI_MAX_TAPS], uw[GS_MULTI_MAX_TAPS];
+  unsigned char tap_h[GS_MULTI_MAX_TAPS], tap_w[GS_MULTI_MAX_TAPS];
+};
+
 struct GConvK {
   const char* in;
   const char* w;
@@ -41,6 +52,8 @@ struct GConvK {
   int splits;
   float* partial;
   long long split_stride;      // floats per split = N * Do*Ho*Wo * Co
+  int n_cls;                   // > 0: merged launch over cls[0..n_cls) (their fields replace the per-class ones of p / d)
+  GConvCls cls[GS_MULTI_MAX_CLS];
   gs_gconv_desc d;
 };
 
@@ -77,11 +90,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   b /= p.splits;
   const int nt = b % p.tiles_n;
   b /= p.tiles_n;
+  // merged parity classes: the classes of one pixel tile are neighbours in the grid (they gather the same input rows)
+  const bool multi = p.n_cls > 0;
+  const int ci = multi ? b % p.n_cls : 0;
+  if (multi) b /= p.n_cls;
+  const GConvCls& cl = p.cls[ci];
+  const int cT = multi ? cl.T : d.T, cKp = multi ? cl.Kp : d.Kp;
+  const int cpz = multi ? cl.pz : d.pz, cpy = multi ? cl.py : d.py, cpx = multi ? cl.px : d.px;
+  const int cslot0 = multi ? cl.stats_slot0 : d.stats_slot0;
+  const int cnh = multi ? cl.nh : p.nh, cnw = multi ? cl.nw : p.nw;
+  const char* cw = p.w + (multi ? cl.w_off : 0);
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
 
-  for (int t = tid; t < d.T; t += NW * 64)
-    taps[t] = (short)((int)p.tap_h[t] | ((int)p.tap_w[t] << 8));   // (row-table, column-table) index
+  for (int t = tid; t < cT; t += NW * 64) {
+    const int th = multi ? (int)cl.tap_h[t] : (int)p.tap_h[t], tw = multi ? (int)cl.tap_w[t] : (int)p.tap_w[t];
+    taps[t] = (short)(th | (tw << 8));   // (row-table, column-table) index
+  }
 
   // ---- per-lane DMA bookkeeping -------------------------------------------------------------------
   const int lrow = lane >> 3;
@@ -93,8 +118,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   // VALU-issue bound: 200 VALU per 32 MFMA).
   constexpr unsigned GS_TAB_BAD = 0x8000u;
   unsigned short* tabh = reinterpret_cast<unsigned short*>(smem + NSTAGE * STAGE + GS_MAX_TAPS * 2);
-  unsigned short* tabw = tabh + p.nh * BM;
-  for (int e = tid; e < BM * (p.nh + p.nw); e += NW * 64) {
+  unsigned short* tabw = tabh + cnh * BM;
+  for (int e = tid; e < BM * (cnh + cnw); e += NW * 64) {
     const int k = e / BM, row = e - k * BM;
     const int m = mt * BM + row;
     bool ok = m < HWc;
@@ -103,11 +128,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int zz = div_small(zi, d.Hc, p.rcp_hc);
     const int ii = zi - zz * d.Hc;
     unsigned v;
-    if (k < p.nh) {
-      const int iz = border_index(zz * d.si + (int)p.ud[k], d.Di, d.border, ok);
-      v = (unsigned)(iz * d.Hi + border_index(ii * d.si + (int)p.uh[k], d.Hi, d.border, ok));
+    if (k < cnh) {
+      const int od = multi ? (int)cl.ud[k] : (int)p.ud[k], oh = multi ? (int)cl.uh[k] : (int)p.uh[k];
+      const int iz = border_index(zz * d.si + od, d.Di, d.border, ok);
+      v = (unsigned)(iz * d.Hi + border_index(ii * d.si + oh, d.Hi, d.border, ok));
     } else {
-      v = (unsigned)border_index(jj * d.si + (int)p.uw[k - p.nh], d.Wi, d.border, ok);
+      const int ow = multi ? (int)cl.uw[k - cnh] : (int)p.uw[k - cnh];
+      v = (unsigned)border_index(jj * d.si + ow, d.Wi, d.border, ok);
     }
     tabh[e] = (unsigned short)(ok ? v : GS_TAB_BAD);
   }
@@ -119,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int wi = wave + NW * i;
     const int co = nt * BN + wi * 8 + lrow;
     const bool wv = co < d.w_rows;
-    const char* real = p.w + ((size_t)co * d.Kp + chunk * 8) * 2;
+    const char* real = cw + ((size_t)co * cKp + chunk * 8) * 2;
     wsrc[i] = wv ? real : p.zero;
     winc[i] = wv ? 128 : 0;
   }
@@ -129,15 +156,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   // shifted re-reads of an input chunk are back to back and hit L2; for Ci < 64 a K-step spans several taps
   // and the natural (tap, channel) order of the pack is kept. `issue` is always called with ks increasing by 1.
   const bool chunk_major = d.Ci >= 64;
-  const int nk = d.Kp >> 6;
+  const int nk = cKp >> 6;
   const int ks_begin = (int)((long long)sp * nk / p.splits), ks_end = (int)((long long)(sp + 1) * nk / p.splits);
-  int it_t = ks_begin % d.T, it_c = ks_begin / d.T;     // (tap, chunk) of the first K-step (chunk-major order)
+  int it_t = ks_begin % cT, it_c = ks_begin / cT;     // (tap, chunk) of the first K-step (chunk-major order)
   auto issue = [&](int ks, int buf) {
     char* sb = smem + buf * STAGE;
     int q0;                                   // first 16-B k-group of this K-step inside a pack row
     if (chunk_major) {
       q0 = (it_t << p.ci_shift) + it_c * 8;
-      if (++it_t == d.T) { it_t = 0; ++it_c; }
+      if (++it_t == cT) { it_t = 0; ++it_c; }
     } else {
       q0 = ks * 8;
     }
@@ -149,7 +176,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int q = q0 + chunk;
     const int t = q >> p.ci_shift;
     const int c8 = q & cmask;
-    const bool tv = t < d.T;
+    const bool tv = t < cT;
     const int tt = tv ? t : 0;
     const int tp = taps[tt];
     const unsigned short* hrow = tabh + (tp & 0xff) * BM + wave * 8 + lrow;
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         const int jj = m - zi * d.Wc;
         const int zz = div_small(zi, d.Hc, p.rcp_hc);
         const int ii = zi - zz * d.Hc;
-        const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+        const size_t opix = (((size_t)n * d.Do + (zz * d.so + cpz)) * d.Ho + (ii * d.so + cpy)) * d.Wo + (jj * d.so + cpx);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
           const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+        float* sp = p.stats + (((size_t)n * d.stats_slots + cslot0 + mt) * 2) * d.Co;
         sp[co] = a;
         sp[d.Co + co] = q;
       }
@@ -356,7 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
         const int jj = m - zi * d.Wc;
         const int zz = div_small(zi, d.Hc, p.rcp_hc);
         const int ii = zi - zz * d.Hc;
-        const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+        const size_t opix = (((size_t)n * d.Do + (zz * d.so + cpz)) * d.Ho + (ii * d.so + cpy)) * d.Wo + (jj * d.so + cpx);
         uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
         uint4* dst = reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2);
         if (fuse) {
@@ -576,6 +603,16 @@ int launch(const GConvK& k, int blocks, hipStream_t st) {
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
+// wave counts per tile picked by measurement (tools/bench_kernels.py): more waves hide the LDS-DMA issue latency
+int launch_tile(const TileCfg& tc, const GConvK& k, int blocks, hipStream_t st) {
+  if (tc.bn == 16) return launch<256, 16, 8, 1, 2>(k, blocks, st);
+  if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, blocks, st);
+  if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, blocks, st);
+  if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, blocks, st);
+  if (tc.bm == 288) return launch<288, 128, 6, 2, 2>(k, blocks, st);
+  if (tc.bm == 256) return launch<256, 128, 4, 4, 3>(k, blocks, st);   // 16 waves: best measured (8 and 4 lose)
+  return launch<128, 128, 4, 4, 2>(k, blocks, st);
+}
 }  // namespace
 
 // hconv.hip: halo-resident kernel for narrow stride-1 layers
@@ -691,6 +728,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     k.tap_h[t] = (unsigned char)h;
     k.tap_w[t] = (unsigned char)w;
   }
+  k.n_cls = 0;
   k.splits = 1;
   k.partial = nullptr;
   k.split_stride = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
@@ -714,12 +752,92 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     GS_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  // wave counts per tile picked by measurement (tools/bench_kernels.py): more waves hide the LDS-DMA issue latency
-  if (tc.bn == 16) return launch<256, 16, 8, 1, 2>(k, (int)blocks, st);
-  if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, (int)blocks, st);
-  if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
-  if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, (int)blocks, st);
-  if (tc.bm == 288) return launch<288, 128, 6, 2, 2>(k, (int)blocks, st);
-  if (tc.bm == 256) return launch<256, 128, 4, 4, 3>(k, (int)blocks, st);   // 16 waves: best measured (8 and 4 lose)
-  return launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
+  return launch_tile(tc, k, (int)blocks, st);
+}
+
+// ---- merged launch over the output-parity classes of one layer ---------------------------------------------------------
+// A stride-2 transposed conv (and the data gradient of a stride-2 conv) is one class per output parity: 4 launches in 2-D
+// (k3: 1/2/2/4 taps, k4: 4 each), 8 in 3-D, each of them a quarter of the layer's pixels — at batch 8 the 32x32 / 64x64
+// PatchGAN gradients are 64-256 workgroups of a few K-steps per launch, paid four times with a split-K pass behind each
+// (profiles/r02_conv_table.txt: 100-250 TFLOP/s). Merged, the classes are one grid: fixed costs once, 4x the workgroups.
+extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t count, const void* in,
+                                      const void* const* w_packs, const float* bias, void* out, float* stats,
+                                      void* stream) {
+  GS_REQUIRE(descs && w_packs && count >= 1 && in && out, "gs_gconv_forward_multi: null argument");
+  const gs_gconv_desc* d0 = descs[0];
+  bool merge = count >= 2 && count <= GS_MULTI_MAX_CLS && gs_opt(GS_OPT_GCONV_MULTI) != 0;
+  for (int c = 0; c < count && merge; ++c) {
+    const gs_gconv_desc* d = descs[c];
+    GS_REQUIRE(d && w_packs[c], "gs_gconv_forward_multi: null class %d", c);
+    merge = d->T >= 1 && d->T <= GS_MULTI_MAX_TAPS && !d->accumulate && d->N == d0->N && d->Hi == d0->Hi &&
+            d->Wi == d0->Wi && d->Ci == d0->Ci && d->Di == d0->Di && d->Do == d0->Do && d->Dc == d0->Dc &&
+            d->in_cs == d0->in_cs && d->in_co == d0->in_co && d->Ho == d0->Ho && d->Wo == d0->Wo && d->Co == d0->Co &&
+            d->out_cs == d0->out_cs && d->out_co == d0->out_co && d->Hc == d0->Hc && d->Wc == d0->Wc && d->so == d0->so &&
+            d->si == d0->si && d->w_rows == d0->w_rows && d->border == d0->border && d->act == d0->act &&
+            d->slope == d0->slope && d->stats_slots == d0->stats_slots && !gs_hconv_slots(d) && !gs_hconvw_slots(d);
+  }
+  if (!merge) {      // classes of different shapes (odd extents), long tap lists, a single class: one launch each
+    for (int c = 0; c < count; ++c)
+      if (int rc = gconv_forward_impl(descs[c], in, w_packs[c], bias, out, stats, nullptr, nullptr, 0, stream)) return rc;
+    return 0;
+  }
+  // validate through the single-class checks, then build the shared arguments from class 0
+  const gs_gconv_desc* d = d0;
+  GS_REQUIRE(d->Ci >= 8 && (d->Ci & 7) == 0 && ((d->Ci >> 3) & ((d->Ci >> 3) - 1)) == 0,
+             "gs_gconv_forward_multi: Ci=%d must be 8*2^k", d->Ci);
+  GS_REQUIRE((d->Co & 7) == 0 && d->Co > 0, "gs_gconv_forward_multi: Co=%d must be a multiple of 8", d->Co);
+  GS_REQUIRE((d->in_cs & 7) == 0 && (d->in_co & 7) == 0 && (d->out_cs & 7) == 0 && (d->out_co & 7) == 0,
+             "gs_gconv_forward_multi: channel strides/offsets must be multiples of 8 (16-B accesses)");
+  GS_REQUIRE(d->Di >= 1 && d->Do >= 1 && d->Dc >= 1, "gs_gconv_forward_multi: depths must be >= 1");
+  GS_REQUIRE((long long)d->Dc * d->Hc * d->Wc < (1 << 24) && (long long)d->Di * d->Hi < 32768 && d->Wi < 32768 &&
+                 (long long)d->Di * d->Hi * d->Wi * d->in_cs * 2 < (1LL << 32),
+             "gs_gconv_forward_multi: class extent too large");
+  GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward_multi: stats requested without buffer");
+  // the tile one class alone would get: the statistics slots (gs_gconv_stat_slots) are counted per class from it
+  const TileCfg tc = pick_tile(d);
+  static GConvK k;      // ~3 KB: filled per call, passed by value to the launch
+  k.f = gs_gconv_fuse{};
+  k.fuse_slots = 0;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_packs[0]);
+  k.bias = bias;
+  k.out = static_cast<char*>(out);
+  k.stats = stats;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward_multi: library not initialised (call gs_init)");
+  k.tiles_m = (d->Dc * d->Hc * d->Wc + tc.bm - 1) / tc.bm;
+  k.tiles_n = (d->Co + tc.bn - 1) / tc.bn;
+  int sh = 0;
+  while ((8 << sh) < d->Ci) ++sh;
+  k.ci_shift = sh;
+  k.rcp_wc = 1.0f / (float)d->Wc;
+  k.rcp_hc = 1.0f / (float)d->Hc;
+  k.d = *d;
+  k.nh = k.nw = 0;
+  k.n_cls = count;
+  for (int c = 0; c < count; ++c) {
+    const gs_gconv_desc* dc = descs[c];
+    GConvCls& cl = k.cls[c];
+    GS_REQUIRE(dc->Kp % 64 == 0 && dc->Kp >= dc->T * dc->Ci, "gs_gconv_forward_multi: bad Kp=%d", dc->Kp);
+    cl.w_off = static_cast<const char*>(w_packs[c]) - k.w;
+    cl.T = dc->T; cl.Kp = dc->Kp; cl.pz = dc->pz; cl.py = dc->py; cl.px = dc->px; cl.stats_slot0 = dc->stats_slot0;
+    cl.nh = cl.nw = 0;
+    for (int t = 0; t < dc->T; ++t) {
+      int h = 0, w = 0;
+      while (h < cl.nh && (cl.uh[h] != dc->dh[t] || cl.ud[h] != dc->dd[t])) ++h;
+      if (h == cl.nh) { cl.ud[cl.nh] = dc->dd[t]; cl.uh[cl.nh++] = dc->dh[t]; }
+      while (w < cl.nw && cl.uw[w] != dc->dw[t]) ++w;
+      if (w == cl.nw) cl.uw[cl.nw++] = dc->dw[t];
+      cl.tap_h[t] = (unsigned char)h;
+      cl.tap_w[t] = (unsigned char)w;
+    }
+    if (cl.nh > k.nh) k.nh = cl.nh;         // LDS gather tables are sized for the largest class
+    if (cl.nw > k.nw) k.nw = cl.nw;
+  }
+  k.splits = 1;
+  k.partial = nullptr;
+  k.split_stride = 0;
+  const long long blocks = (long long)count * d->N * k.tiles_m * k.tiles_n;
+  GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward_multi: bad grid %lld", blocks);
+  return launch_tile(tc, k, (int)blocks, static_cast<hipStream_t>(stream));
 }

@@ -143,6 +143,22 @@ extern "C" int gs_inorm_act_forward(const void* y, const float* mean_rstd, const
 }
 
 
+// sum of `slots` partial values in slot order (double accumulation): the loads of eight slots are issued together, the
+// additions keep the order — a plain loop waits out one L2 round trip per slot (16 slots: ~6 us of a 21 us launch)
+__device__ __forceinline__ double slot_sum_ordered(const float* __restrict__ src, size_t stride, int slots) {
+  double s = 0.0;
+  int sl = 0;
+  for (; sl + 8 <= slots; sl += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(sl + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (double)v[k];
+  }
+  for (; sl < slots; ++sl) s += (double)src[(size_t)sl * stride];
+  return s;
+}
+
 // ---- forward apply with the statistics finalised in the prologue ---------------------------------------------------
 // The producing conv leaves per-tile partial sums [N][slots][2][C]; the old path ran slot_sum_kernel (a ~5 us launch of
 // 128 tiny workgroups, ~200 of them per training step) and then the apply kernel. Here the apply kernel is laid out by
@@ -160,12 +176,18 @@ __global__ __launch_bounds__(256) void inorm_stats_act_fwd_kernel(const uint4* y
   const int cg = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;
   const int tid = threadIdx.x;
   const int C = C8 * 8;
+  // the first two pixels of this thread do not depend on the statistics: their loads go out before the slot sums
+  const int cl = tid & 7, lane = tid >> 3;
+  const size_t img = (size_t)n * hw * C8;
+  const int p0 = chunk * pix_per_block, p1 = min(hw, p0 + pix_per_block);
+  const int pxa = p0 + lane, pxb = pxa + 32;
+  const size_t ea = img + (size_t)pxa * C8 + cg * 8 + cl, eb = img + (size_t)pxb * C8 + cg * 8 + cl;
+  uint4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0}, ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+  if (pxa < p1) { va = y[ea]; if (res) ra = res[ea]; }
+  if (pxb < p1) { vb = y[eb]; if (res) rb = res[eb]; }
   if (tid < 128) {
     const int r = tid >> 6, ch = tid & 63;
-    const float* src = partial + ((size_t)n * slots * 2 + r) * C + cg * 64 + ch;
-    double sacc = 0.0;
-    for (int sl = 0; sl < slots; ++sl) sacc += (double)src[(size_t)sl * 2 * C];
-    tot[r][ch] = sacc;
+    tot[r][ch] = slot_sum_ordered(partial + ((size_t)n * slots * 2 + r) * C + cg * 64 + ch, (size_t)2 * C, slots);
   }
   __syncthreads();
   if (tid < 64) {
@@ -182,26 +204,29 @@ __global__ __launch_bounds__(256) void inorm_stats_act_fwd_kernel(const uint4* y
     }
   }
   __syncthreads();
-  const int cl = tid & 7, lane = tid >> 3;
   float mu[8], rs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mu[k] = mrs[0][cl * 8 + k]; rs[k] = mrs[1][cl * 8 + k]; }
-  const size_t img = (size_t)n * hw * C8;
-  const int p0 = chunk * pix_per_block, p1 = min(hw, p0 + pix_per_block);
-  for (int px = p0 + lane; px < p1; px += 32) {
-    const size_t e = img + (size_t)px * C8 + cg * 8 + cl;
-    const uint4 v = y[e];
+  auto finish = [&](const uint4& v, const uint4& r, size_t e) {
     float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = apply_act((f[k] - mu[k]) * rs[k], act, slope);
     if (res) {
-      const uint4 r = res[e];
       f[0] += bf_lo(r.x); f[1] += bf_hi(r.x); f[2] += bf_lo(r.y); f[3] += bf_hi(r.y);
       f[4] += bf_lo(r.z); f[5] += bf_hi(r.z); f[6] += bf_lo(r.w); f[7] += bf_hi(r.w);
     }
     uint4 o;
     o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
     x[e] = o;
+  };
+  if (pxa < p1) finish(va, ra, ea);
+  if (pxb < p1) finish(vb, rb, eb);
+  for (int px = pxb + 32; px < p1; px += 32) {
+    const size_t e = img + (size_t)px * C8 + cg * 8 + cl;
+    const uint4 v = y[e];
+    uint4 r = {0, 0, 0, 0};
+    if (res) r = res[e];
+    finish(v, r, e);
   }
 }
 
@@ -490,28 +515,8 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
   const int C = C8 * 8;
   const int HW = D * H * W;
   const float inv_hw = 1.0f / (float)HW;
-  if (tid < 192) {
-    const int r = tid >> 6, ch = tid & 63;
-    const float* src = partial + ((size_t)n * slots * 3 + r) * C + cg * 64 + ch;
-    double sacc = 0.0;
-    for (int sl = 0; sl < slots; ++sl) sacc += (double)src[(size_t)sl * 3 * C];
-    tot[r][ch] = (float)sacc;
-  }
-  __syncthreads();
-  const float* mr = mean_rstd + (size_t)n * 2 * C;
-  if (sums && chunk == 0 && tid < 192) {
-    // per-image totals for the bias gradient of the conv in front of the norm (gs_norm_bias_grads adds them up over the
-    // images in order; they used to be fp32 atomics)
-    const int r = tid >> 6, ch = tid & 63;
-    sums[((size_t)n * 3 + r) * C + cg * 64 + ch] = tot[r][ch];
-  }
   const int cl = tid & 7, lane = tid >> 3;
   const int c8 = cg * 8 + cl;
-  float mu[8], rs[8], s1[8], s2[8];
-  load8(mu, mr + c8 * 8);
-  load8(rs, mr + C + c8 * 8);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { s1[k] = tot[0][cl * 8 + k] * inv_hw; s2[k] = tot[1][cl * 8 + k] * inv_hw; }
   const size_t per_img = (size_t)HW * C8;
   const size_t pad_img = padded_pixels(D, H, W, fold) * C8;
   const uint4* gpad_n = gpad + (size_t)n * pad_img;
@@ -520,17 +525,38 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
   uint4* dy_n = dy + (size_t)n * per_img;
   uint4* gs_n = gsum ? gsum + (size_t)n * per_img : nullptr;
   const int p0 = chunk * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-#pragma unroll 2
-  for (int px = p0 + lane; px < p1; px += 32) {
+  // the first two pixels of this thread do not depend on the totals: their loads go out before the slot sums
+  const int pxa = p0 + lane, pxb = pxa + 32;
+  float ga[8], gb[8];
+  uint4 ya = {0, 0, 0, 0}, yb = {0, 0, 0, 0};
+  if (pxa < p1) { load_folded<FM>(ga, gpad_n, g2_n, pxa, D, H, W, C8, c8, fold); ya = y_n[(size_t)pxa * C8 + c8]; }
+  if (pxb < p1) { load_folded<FM>(gb, gpad_n, g2_n, pxb, D, H, W, C8, c8, fold); yb = y_n[(size_t)pxb * C8 + c8]; }
+  const float* mr = mean_rstd + (size_t)n * 2 * C;
+  float mu[8], rs[8], s1[8], s2[8];
+  load8(mu, mr + c8 * 8);
+  load8(rs, mr + C + c8 * 8);
+  if (tid < 192) {
+    const int r = tid >> 6, ch = tid & 63;
+    tot[r][ch] = (float)slot_sum_ordered(partial + ((size_t)n * slots * 3 + r) * C + cg * 64 + ch, (size_t)3 * C, slots);
+  }
+  __syncthreads();
+  if (sums && chunk == 0 && tid < 192) {
+    // per-image totals for the bias gradient of the conv in front of the norm (gs_norm_bias_grads adds them up over the
+    // images in order; they used to be fp32 atomics)
+    const int r = tid >> 6, ch = tid & 63;
+    sums[((size_t)n * 3 + r) * C + cg * 64 + ch] = tot[r][ch];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = tot[0][cl * 8 + k] * inv_hw; s2[k] = tot[1][cl * 8 + k] * inv_hw; }
+  auto finish = [&](const float* g, const uint4& yv, int px) {
     const size_t e = (size_t)px * C8 + c8;
-    float g[8], yy[8], d[8];
-    load_folded<FM>(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold);
+    float yy[8], d[8];
     if (gs_n) {
       uint4 o;
       o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]); o.z = pack_bf2(g[4], g[5]); o.w = pack_bf2(g[6], g[7]);
       gs_n[e] = o;
     }
-    unpack8(yy, y_n[e]);
+    unpack8(yy, yv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float yh = (yy[k] - mu[k]) * rs[k];
@@ -540,6 +566,13 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
     uint4 o;
     o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
     dy_n[e] = o;
+  };
+  if (pxa < p1) finish(ga, ya, pxa);
+  if (pxb < p1) finish(gb, yb, pxb);
+  for (int px = pxb + 32; px < p1; px += 32) {
+    float g[8];
+    load_folded<FM>(g, gpad_n, g2_n, px, D, H, W, C8, c8, fold);
+    finish(g, y_n[(size_t)px * C8 + c8], px);
   }
 }
 

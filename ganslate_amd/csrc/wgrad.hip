@@ -280,18 +280,21 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int plan_onl
 }  // namespace
 
 // dw[e] += ws[0][e] + ws[1][e] + ... : the fixed-order second stage of the deterministic accumulation. 16 B per lane;
-// 256 threads = 64 element lanes x 4 slab lanes (slab lane l adds slabs l, l+4, ... in order, then the four partial sums
-// are added in lane order through LDS): the order never depends on timing, and layers with few output elements but
-// hundreds of slabs (the 64-channel boundary convs) still spread over the chip.
+// 256 threads = EL element lanes x 256/EL slab lanes (slab lane l adds slabs l, l+SL, ... in order, then the SL partial
+// sums are added in lane order through LDS): the order never depends on timing, and layers with few output elements but
+// hundreds of slabs (the 64-channel boundary convs) still spread over the chip. EL = 16 / 4 for outputs of <= 16 / 4
+// float4 (a 64-channel bias gradient over 4096 pixel chunks took 44 us with 4 slab lanes walking 1024 slabs each).
+template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, float4* dw, long long n4, int slabs,
                                                            long long stride4) {
-  __shared__ float4 part[4][64];
-  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  for (long long e0 = (long long)blockIdx.x * 64; e0 < n4; e0 += (long long)gridDim.x * 64) {
+  constexpr int SL = 256 / EL;
+  __shared__ float4 part[SL][EL];
+  const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+  for (long long e0 = (long long)blockIdx.x * EL; e0 < n4; e0 += (long long)gridDim.x * EL) {
     const long long e = e0 + el;
     float4 s = {0.f, 0.f, 0.f, 0.f};
     if (e < n4)
-      for (int k = sl; k < slabs; k += 4) {
+      for (int k = sl; k < slabs; k += SL) {
         const float4 t = ws[(long long)k * stride4 + e];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
@@ -299,11 +302,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, flo
     __syncthreads();
     if (sl == 0 && e < n4) {
       float4 o = dw[e];
-#pragma unroll
-      for (int l = 0; l < 4; ++l) { o.x += part[l][el].x; o.y += part[l][el].y; o.z += part[l][el].z; o.w += part[l][el].w; }
+#pragma unroll 4
+      for (int l = 0; l < SL; ++l) { o.x += part[l][el].x; o.y += part[l][el].y; o.z += part[l][el].z; o.w += part[l][el].w; }
       dw[e] = o;
     }
     __syncthreads();
+  }
+}
+static inline void launch_slab_reduce(const float* ws, float* dst, long long n4, int slabs, long long stride4,
+                                      hipStream_t st) {
+  const float4* w4 = reinterpret_cast<const float4*>(ws);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  if (n4 <= 4 && slabs > 16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(1), dim3(256), 0, st, w4, d4, n4, slabs, stride4);
+  else if (n4 <= 16 && slabs > 16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(1), dim3(256), 0, st, w4, d4, n4, slabs, stride4);
+  else {
+    long long blocks = (n4 + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, w4, d4, n4, slabs, stride4);
   }
 }
 
@@ -349,10 +366,7 @@ int wgrad_check(const gs_wgrad_desc* d) {
 
 int wgrad_reduce(const gs_wgrad_desc* d, const float* ws, float* dw, int slabs, void* stream) {
   const long long n = (long long)d->P * d->dw_ld;          // multiple of 64: P and Q are multiples of 8
-  long long blocks = (n / 4 + 63) / 64;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(dw), n / 4, slabs, n / 4);
+  launch_slab_reduce(ws, dw, n / 4, slabs, n / 4, static_cast<hipStream_t>(stream));
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -475,8 +489,7 @@ static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs,
   GS_CHECK_HIP(hipGetLastError());
   if (ws) {
     const long long n4 = C / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(ws), reinterpret_cast<float4*>(db), n4, (int)bx, n4);
+    launch_slab_reduce(ws, db, n4, (int)bx, n4, st);
     GS_CHECK_HIP(hipGetLastError());
   }
   return 0;

@@ -45,7 +45,7 @@ class HipOps:
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
                    "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_NW": "hconvw_waves",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
-                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_DEBUG": "debug", "GS_GCONV_TILE288": "gconv_tile288"}
+                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi"}
 
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")
@@ -171,6 +171,43 @@ class HipOps:
         else:
             L.check(self.lib.gs_gconv_forward(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats), _stream()),
                     "gs_gconv_forward")
+        if t_end is not None:
+            t_end.record()
+
+    def gconv_classes(self, classes, x, wpack, bias, out, *, in_co=0, out_co=0, act="none", slope=0.2, stats=None,
+                      stats_slots=0, stats_slot0s=None, accumulate=False):
+        """every output-parity class of one layer (Lowered.fwd / .dgrad). More than one class: gs_gconv_forward_multi, one
+        launch when the classes are mergeable (the library decides; it runs them one by one otherwise). Layers so small
+        that even the merged grid leaves the chip empty keep the per-class launches, which split K."""
+        N = x.shape[0]
+        slot0 = lambda i: stats_slot0s[i] if stats_slot0s else 0
+        g0 = classes[0]
+        merged = len(classes) > 1 and not accumulate
+        if merged:
+            key = ("multi", tuple(id(g) for g in classes), N, x.shape[-1], in_co, out.shape[-1], out_co, act, float(slope),
+                   stats_slots, tuple(stats_slot0s or ()))
+            ent = self._desc_cache.get(key)
+            if ent is None:
+                descs = [self._gdesc(g, N, x.shape[-1], in_co, out.shape[-1], out_co, act, float(slope), stats_slots,
+                                     slot0(i)) for i, g in enumerate(classes)]
+                tn = 16 if g0.Co <= 16 else (64 if g0.Co <= 64 else 128)
+                tm = self.tile_m(g0, N)
+                blocks = len(classes) * N * ((g0.pixels + tm - 1) // tm) * ((g0.Co + tn - 1) // tn)
+                use = blocks >= 128 or not any(self._splitk_floats(d) for d in descs)
+                arr = (C.POINTER(L.GConvDesc) * len(descs))(*[C.pointer(d) for d in descs])
+                ent = (arr, descs, use)
+                self._desc_cache[key] = ent
+            merged = ent[2]
+        if not merged:
+            for i, g in enumerate(classes):
+                self.gconv(g, x, wpack, bias, out, in_co=in_co, out_co=out_co, act=act, slope=slope, stats=stats,
+                           stats_slots=stats_slots, stats_slot0=slot0(i), accumulate=accumulate)
+            return
+        base = wpack.data_ptr()
+        ws = (C.c_void_p * len(classes))(*[base + 2 * g.pack_offset for g in classes])
+        t_end = self._time_begin("gconv_multi", classes, False)
+        L.check(self.lib.gs_gconv_forward_multi(ent[0], len(classes), _ptr(x), ws, _ptr(bias), _ptr(out), _ptr(stats),
+                                                _stream()), "gs_gconv_forward_multi")
         if t_end is not None:
             t_end.record()
 

@@ -102,16 +102,14 @@ class Unet2D(NativeNet):
         bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
         fpack = pk["fpack"][pk["f_off"][i]:]
         if not stats:
-            for g in lw.fwd:
-                ops.gconv(g, x, fpack, bias, y, act=act, slope=0.2)
+            ops.gconv_classes(lw.fwd, x, fpack, bias, y, act=act, slope=0.2)
             return None
         slots, offs = 0, []
         for g in lw.fwd:
             offs.append(slots)
             slots += ops.stat_slots(g, N)
         part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
-        for g, o in zip(lw.fwd, offs):
-            ops.gconv(g, x, fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
+        ops.gconv_classes(lw.fwd, x, fpack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
         mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
         ops.inorm_finalize(part, N, slots, sp.cout_p, lw.out_pixels, mr)
         return mr
@@ -187,8 +185,7 @@ class Unet2D(NativeNet):
         sp = self.nodes[i].spec
         gx = self._new(N, lw.in_dims, sp.cin_p)
         dpack = pk["dpack"][pk["d_off"][i]:]
-        for g in lw.dgrad:
-            self.ops.gconv(g, dy, dpack, None, gx)
+        self.ops.gconv_classes(lw.dgrad, dy, dpack, None, gx)
         return gx
 
     def _backward(self, s, g_img, need_input_grad, want_w):

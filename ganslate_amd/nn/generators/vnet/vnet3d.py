@@ -175,16 +175,14 @@ class Vnet3D(NativeNet):
         fpack = s.pk["fpack"][s.pk["f_off"][i]:]
         y = out if out is not None else self._new(N, lw.out_dims, sp.cout_p)
         if not stats:
-            for g in lw.fwd:
-                ops.gconv(g, x, fpack, bias, y, in_co=in_co)
+            ops.gconv_classes(lw.fwd, x, fpack, bias, y, in_co=in_co)
             return y, None
         slots, offs = 0, []
         for g in lw.fwd:
             offs.append(slots)
             slots += ops.stat_slots(g, N)
         part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
-        for g, o in zip(lw.fwd, offs):
-            ops.gconv(g, x, fpack, bias, y, in_co=in_co, stats=part, stats_slots=slots, stats_slot0=o)
+        ops.gconv_classes(lw.fwd, x, fpack, bias, y, in_co=in_co, stats=part, stats_slots=slots, stats_slot0s=offs)
         mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
         ops.inorm_finalize(part, N, slots, sp.cout_p, lw.out_pixels, mr)
         return y, mr
@@ -284,8 +282,7 @@ class Vnet3D(NativeNet):
         sp, lw = self.nodes[i].spec, s.lows[i]
         gx = out if out is not None else self._new(s.N, lw.in_dims, sp.cin_p)
         dpack = s.pk["dpack"][s.pk["d_off"][i]:]
-        for g in lw.dgrad:
-            self.ops.gconv(g, dy, dpack, None, gx, out_co=out_co, accumulate=accumulate)
+        self.ops.gconv_classes(lw.dgrad, dy, dpack, None, gx, out_co=out_co, accumulate=accumulate)
         return gx
 
     def _block_backward(self, s, blk, rec, g, g2, g2_co, want_w):

@@ -378,8 +378,7 @@ class NativeNet:
                     offs.append(slots)
                     slots += ops.stat_slots(g, N)
                 part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=dev)
-                for g, o in zip(lw.fwd, offs):
-                    ops.gconv(g, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
+                ops.gconv_classes(lw.fwd, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
                 mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=dev)
                 xo = torch.empty_like(y)
                 res = acts[nd.res + 1] if nd.res is not None else None
@@ -390,9 +389,8 @@ class NativeNet:
             else:
                 assert nd.res is None
                 wf_out = sp.wfold == "out"     # bias and activation move behind the shift-add
-                for g in lw.fwd:
-                    ops.gconv(g, acts[-1], fpack, None if wf_out else bias, y, act="none" if wf_out else nd.act,
-                              slope=nd.slope)
+                ops.gconv_classes(lw.fwd, acts[-1], fpack, None if wf_out else bias, y,
+                                  act="none" if wf_out else nd.act, slope=nd.slope)
                 ys.append(None); mrs.append(None)
                 acts.append(y)
         out = None
@@ -521,8 +519,7 @@ class NativeNet:
                                     "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope})
                     pending = (gx, f, g2n, fmode_n, plan)
                 else:
-                    for g in lw.dgrad:
-                        ops.gconv(g, dy, dpack, None, gx)
+                    ops.gconv_classes(lw.dgrad, dy, dpack, None, gx)
                     pending = (gx, f, g2n, fmode_n)
             if start is None:
                 s.acts[i + 1] = None  # release as we go

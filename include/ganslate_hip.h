@@ -99,6 +99,14 @@ int gs_gconv_stat_slots(const gs_gconv_desc* d);
 /* resnet2d.py:25,35,52-57,65,80-87; patchgan2d.py:29,36-62; backward via loss.backward() base.py:170 */
 int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                      void* out, float* stats, void* stream);
+/* The output-parity classes of ONE layer (stride-2 transposed conv forward, data gradient of a stride-2 conv: 4 classes in
+ * 2-D, 8 in 3-D — SURVEY.md §2.3 K3/K4; resnet2d.py:52-57, patchgan2d.py:36-48 backward) in one launch. descs[c] /
+ * w_packs[c] are what `count` calls of gs_gconv_forward would take; the classes must agree in everything but taps, Kp,
+ * output phase (pz,py,px) and stats_slot0, with at most 8 taps each — otherwise (and for count == 1) the call runs them one
+ * after the other, so it is always valid to use. Same results as the separate launches, bit for bit. */
+int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
+                           const float* bias, void* out, float* stats, void* stream);
+
 /* Data-gradient launch of a stride-1 conv with the first pass of the consumer's InstanceNorm backward fused into its
  * epilogue: while the tile of the (padded-domain) gradient g is stored, the per-tile sums of ghat = (fold(g) + g2) *
  * act'(yhat), ghat * yhat and yhat over the pixels of the tile are written to partial[N][slots][3][C] (slots =

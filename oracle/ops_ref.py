@@ -94,6 +94,14 @@ class RefOps:
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
     # ---- convolution family ---------------------------------------------------------------------------
+    def gconv_classes(self, classes, x, wpack, bias, out, *, in_co=0, out_co=0, act="none", slope=0.2, stats=None,
+                      stats_slots=0, stats_slot0s=None, accumulate=False):
+        """the output-parity classes of one layer, one after the other (what gs_gconv_forward_multi merges)"""
+        for i, g in enumerate(classes):
+            self.gconv(g, x, wpack, bias, out, in_co=in_co, out_co=out_co, act=act, slope=slope, stats=stats,
+                       stats_slots=stats_slots, stats_slot0=(stats_slot0s[i] if stats_slot0s else 0),
+                       accumulate=accumulate)
+
     def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
               stats=None, stats_slots=0, stats_slot0=0, accumulate=False, fuse=None):
         N = x.shape[0]

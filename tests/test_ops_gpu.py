@@ -108,9 +108,8 @@ def run_forward(ops, dev, low, bias, fpack, xa, N, act="none"):
     slots, offs = stats_slots(ops, low, low.fwd, N)
     # NaN-filled: every slot must be written by the kernel (a stale slot count shows up as NaN statistics)
     part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
-    for g, o in zip(low.fwd, offs):
-        ops.gconv(g, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act=act, stats=part, stats_slots=slots,
-                  stats_slot0=o)
+    ops.gconv_classes(low.fwd, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act=act, stats=part, stats_slots=slots,
+                      stats_slot0s=offs)
     mr = torch.empty(N * 2 * spec.cout_p, dtype=torch.float32, device=dev)
     ops.inorm_finalize(part, N, slots, spec.cout_p, low.out_pixels, mr)
     return ya, mr
@@ -154,10 +153,57 @@ def test_dgrad(hip_ops, case):
     outs = []
     for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
         gx = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16, device=dev)
-        for gc in low.dgrad:
-            ops.gconv(gc, gy.to(dev), dpack.to(dev), None, gx)
+        ops.gconv_classes(low.dgrad, gy.to(dev), dpack.to(dev), None, gx)
         outs.append(gx)
     close_bf16(outs[1], outs[0], "dgrad")
+
+
+MULTI_CASES = [
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 8, 64, 64),                    # u128 at cfg2: classes of 1/2/2/4 taps
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 2, 128, 128),                   # u64 (64-channel tile)
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 1, 9, 12),                      # ragged
+    (ConvSpec("convT", 64, 32, 4, 2, 1, 0), 1, 8, 8),                        # U-Net k4
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 8, 64, 64),                        # PatchGAN conv3: its data gradient, 4 x 4 taps
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 4, 128, 128),                       # d128: data gradient
+    (ConvSpec("conv", 3, 64, 4, 2, 1), 2, 32, 32),                           # PatchGAN first (gradient to 8 padded channels)
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1, dims=3), 1, 6, 8, 8),           # 8 classes of 1..8 taps
+    (ConvSpec("conv", 64, 128, 4, 2, 1, dims=3), 1, 12, 12, 12),             # k4 in 3-D: 8 taps per class
+    (ConvSpec("conv", 128, 256, 3, 2, 1), 1, 31, 33),                        # odd sizes: classes of different extents
+]
+
+
+@pytest.mark.parametrize("case", MULTI_CASES, ids=_ids)
+def test_merged_parity_classes_equal_separate_launches(hip_ops, case):
+    """gs_gconv_forward_multi (all output-parity classes of a stride-2 layer in one grid) against one launch per class:
+    the same workgroup programme per tile, so the outputs and the statistics slots must be bit-identical — forward with
+    bias + statistics + activation, and the data gradient."""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 21)
+    g = torch.Generator().manual_seed(22)
+    dev = hip_ops.device
+    xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
+    xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
+    gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., :spec.cout] = torch.randn(N, *low.out_dims, spec.cout, generator=g).to(torch.bfloat16)
+    res = {}
+    try:
+        for merged in (1, 0):
+            hip_ops.set_option("gconv_multi", merged)
+            slots, offs = stats_slots(hip_ops, low, low.fwd, N)
+            ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+            part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
+            hip_ops.gconv_classes(low.fwd, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act="lrelu", stats=part,
+                                  stats_slots=slots, stats_slot0s=offs)
+            gx = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16, device=dev)
+            hip_ops.gconv_classes(low.dgrad, gy.to(dev), dpack.to(dev), None, gx)
+            torch.cuda.synchronize()
+            res[merged] = (ya.cpu(), part.cpu(), gx.cpu())
+    finally:
+        hip_ops.set_option("gconv_multi", 1)
+    assert len(low.fwd) > 1 or len(low.dgrad) > 1
+    assert not torch.isnan(res[1][1]).any()
+    for a, b, what in zip(res[1], res[0], ("forward", "statistics", "data gradient")):
+        assert torch.equal(a, b), what
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=_ids)
