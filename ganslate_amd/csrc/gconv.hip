@@ -514,7 +514,15 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
     const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
     f32x4 v = bia;
     const float* src = p.partial + opix * d.Co + co;
-    for (int sp = 0; sp < p.splits; ++sp) {      // fixed order: reproducible
+    int sp = 0;                                  // fixed order: reproducible; four splits' loads in flight
+    for (; sp + 4 <= p.splits; sp += 4) {
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(sp + u) * p.split_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v[0] += t[u][0]; v[1] += t[u][1]; v[2] += t[u][2]; v[3] += t[u][3]; }
+    }
+    for (; sp < p.splits; ++sp) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)sp * p.split_stride);
       v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }

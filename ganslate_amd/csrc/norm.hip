@@ -26,8 +26,17 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
-    if (c < C)
-      for (int sl = lane; sl < slots; sl += LANES) s += (double)src[((size_t)sl * R + r) * C + c];
+    if (c < C) {      // eight loads in flight, additions in slot order (see slot_sum_ordered)
+      int sl = lane;
+      for (; sl + 7 * LANES < slots; sl += 8 * LANES) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[((size_t)(sl + k * LANES) * R + r) * C + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v[k];
+      }
+      for (; sl < slots; sl += LANES) s += (double)src[((size_t)sl * R + r) * C + c];
+    }
     __syncthreads();
     red[lane][col] = s;
     __syncthreads();

@@ -192,8 +192,17 @@ __global__ __launch_bounds__(256) void pnorm_bwd_finalize_kernel(const float* pa
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     double s = 0.0;
-    if (c < C)
-      for (int sl = lane; sl < chunks; sl += LANES) s += (double)src[((size_t)sl * 4 + r) * C + c];
+    if (c < C) {      // eight loads in flight, additions in chunk order
+      int sl = lane;
+      for (; sl + 7 * LANES < chunks; sl += 8 * LANES) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[((size_t)(sl + k * LANES) * 4 + r) * C + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v[k];
+      }
+      for (; sl < chunks; sl += LANES) s += (double)src[((size_t)sl * 4 + r) * C + c];
+    }
     __syncthreads();
     red[lane][col] = s;
     __syncthreads();

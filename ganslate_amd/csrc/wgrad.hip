@@ -293,11 +293,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, flo
   for (long long e0 = (long long)blockIdx.x * EL; e0 < n4; e0 += (long long)gridDim.x * EL) {
     const long long e = e0 + el;
     float4 s = {0.f, 0.f, 0.f, 0.f};
-    if (e < n4)
-      for (int k = sl; k < slabs; k += SL) {
+    if (e < n4) {      // four slabs in flight per lane, added in slab order (a plain loop waits one round trip per slab)
+      int k = sl;
+      for (; k + 3 * SL < slabs; k += 4 * SL) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = ws[(long long)(k + u * SL) * stride4 + e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+      }
+      for (; k < slabs; k += SL) {
         const float4 t = ws[(long long)k * stride4 + e];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
+    }
     part[sl][el] = s;
     __syncthreads();
     if (sl == 0 && e < n4) {
