@@ -226,8 +226,12 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
   for (int i = 0; i < NA; ++i) {
     const int q = i * 512 + wave * 64 + lane;
     const int px = q >> 3, part = q & 7;
-    a_lz[i] = px / (p.BH * p.BW);
-    const int rem = px - a_lz[i] * (p.BH * p.BW);
+    // LDS row px = 8 m + 4 h + j holds box pixel 8 m + 2 j + h: the MFMA's K order inside an 8-pixel run is "even pixels, then
+    // odd pixels" for BOTH operands, which is what makes the halo's transpose reads conflict-free (see rbk below); the
+    // dense tile keeps its row pattern (and hw_swz) and only the source of each row moves
+    const int spx = (px & ~7) | ((px & 3) << 1) | ((px >> 2) & 1);
+    a_lz[i] = spx / (p.BH * p.BW);
+    const int rem = spx - a_lz[i] * (p.BH * p.BW);
     a_ly[i] = rem / p.BW;
     a_lx[i] = rem - a_ly[i] * p.BW;
     const int spart = part ^ (hw_swz(px) << 1);          // LDS piece `part` of row px holds source piece spart
@@ -298,7 +302,12 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
     const int px0 = (ks * 4 + fk) * 8;
     const int lz = px0 / (p.BH * p.BW), rem = px0 - lz * (p.BH * p.BW);
     const int ly = rem / p.BW, lx0 = rem - ly * p.BW;
-    rbk[ks] = ((lz * p.HH + ly) * p.HW + lx0 + frr) * GPITCH + wq * 32 + fcc * 8;   // byte offset incl. this lane's columns
+    // A 32-lane half of a transpose read covers two 8-pixel runs x 4 rows x 4 column pieces. With the rows at pixels
+    // +0..3 of each run (pitch 144 B = 36 banks, runs 8 pixels = 32 banks apart) the 8-bank patches overlapped pairwise:
+    // SQ_LDS_BANK_CONFLICT = 2 extra cycles on every one of these reads, 45 % of the kernel's LDS cycles
+    // (profiles/r02_trunk_pmc.txt). Rows at the EVEN pixels +0,2,4,6 (the odd ones in the second read) land 8 banks apart:
+    // 2 runs x 4 rows x 8 banks = all 64 banks once.
+    rbk[ks] = ((lz * p.HH + ly) * p.HW + lx0 + 2 * frr) * GPITCH + wq * 32 + fcc * 8;   // byte offset incl. this lane's columns
   }
 
   int cur = 0;
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
       }
       const unsigned g0 = ha + (unsigned)(rbk[ks] + tb[t]);
       lds_read64_tr<0>(glo[slot], g0);
-      lds_read64_tr<4 * GPITCH>(ghi[slot], g0);
+      lds_read64_tr<GPITCH>(ghi[slot], g0);
     };
     static_for<0, D>(issue_unit);
     static_for<0, NU>([&](auto uu) {
