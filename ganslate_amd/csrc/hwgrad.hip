@@ -206,6 +206,28 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
   const int wp = wave >> 2, wq = wave & 3;         // 32-row half of p, 16-column quarter of q
   for (int t = tid; t < d.T; t += 512)
     toff[t] = ((((int)d.dd[t] - p.dmin) * p.HH + ((int)d.dh[t] - p.hmin)) * p.HW + ((int)d.dw_[t] - p.wmin)) * GPITCH;
+  // Border-resolved source rows / columns of every halo row / column of every box row / column, once per workgroup:
+  // ytab[by][hy] = B(by*BH + hy + hmin) in [0, Hg), 0x8000 for a zero-padded position; xtab likewise. Staging a box then
+  // costs two 2-byte LDS reads and a multiply-add per piece; resolving the borders per piece per box (reflect / clamp /
+  // validity on three axes) was 440 VALU instructions per wave per box next to 144 MFMAs, and with both waves of a SIMD
+  // doing it at the same moment (right behind the barrier) it stretched every box by a third (profiles/r02_trunk_pmc.txt).
+  unsigned short* ytab = reinterpret_cast<unsigned short*>(bufs + 2 * (size_t)(ABYTES + hbytes));
+  unsigned short* xtab = ytab + p.nbh * p.HH;
+  for (int e = tid; e < p.nbh * p.HH + p.nbw * p.HW; e += 512) {
+    bool ok = true;
+    int v;
+    if (e < p.nbh * p.HH) {
+      const int by = e / p.HH, hy = e - by * p.HH;
+      v = border_index(by * p.BH + hy + p.hmin, d.Hg, d.border, ok);
+      v = min(max(v, 0), d.Hg - 1);
+    } else {
+      const int e2 = e - p.nbh * p.HH;
+      const int bx = e2 / p.HW, hx = e2 - bx * p.HW;
+      v = border_index(bx * p.BW + hx + p.wmin, d.Wg, d.border, ok);
+      v = min(max(v, 0), d.Wg - 1);
+    }
+    ytab[e] = ok ? (unsigned short)v : (unsigned short)0x8000;
+  }
   __syncthreads();
   int tb[TMAX];                                    // tap byte offsets inside the halo, in registers for the whole kernel
 #pragma unroll
@@ -237,16 +259,17 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
     const int spart = part ^ (hw_swz(px) << 1);          // LDS piece `part` of row px holds source piece spart
     a_rel[i] = ((a_lz[i] * d.Ha + a_ly[i]) * d.Wa + a_lx[i]) * d.a_cs + pt * 64 + spart * 8;
   }
-  int h_z[NHMAX], h_y[NHMAX], h_x[NHMAX], h_c[NHMAX];
+  int h_y[NHMAX], h_x[NHMAX], h_c[NHMAX];            // halo row / column (table indices) and channel of each piece; HD == 1
 #pragma unroll
   for (int i = 0; i < NHMAX; ++i) {
     const int q = i * 512 + wave * 64 + lane;
     const int v = q / 9, part = q - v * 9;               // piece 8 of a voxel is the pad
-    const int hz = v / hhw, r2 = v - hz * hhw;
+    const int r2 = v % hhw;
     const int hy = r2 / p.HW;
-    h_z[i] = hz + p.dmin; h_y[i] = hy + p.hmin; h_x[i] = r2 - hy * p.HW + p.wmin;
+    h_y[i] = min(hy, p.HH - 1); h_x[i] = r2 - hy * p.HW;
     h_c[i] = (q < hpieces && part < 8) ? qt * 64 + part * 8 : -1;
   }
+  const bool ragged = (d.Ha % p.BH) != 0 || (d.Wa % p.BW) != 0;
 
   auto issue_box = [&](int box, int b) {
     int bb = box;
@@ -261,24 +284,33 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
     const bool second = box >= p.nboxes1;                // wave-uniform
     const size_t pix0 = (((size_t)n * d.Da + oz0) * d.Ha + oy0) * d.Wa + ox0;
     const char* a_n = (second ? p.a2 : p.a) + (pix0 * d.a_cs + d.a_co) * 2;
+    if (ragged) {                                        // wave-uniform: boxes that hang over the image edge
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const bool ok = oz0 + a_lz[i] < d.Da && oy0 + a_ly[i] < d.Ha && ox0 + a_lx[i] < d.Wa;
-      const char* src = ok ? a_n + (size_t)a_rel[i] * 2 : p.zero;
-      glds16(src, at + (size_t)(i * 512 + wave * 64) * 16);
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = oz0 + a_lz[i] < d.Da && oy0 + a_ly[i] < d.Ha && ox0 + a_lx[i] < d.Wa;
+        const char* src = ok ? a_n + (size_t)a_rel[i] * 2 : p.zero;
+        glds16(src, at + (size_t)(i * 512 + wave * 64) * 16);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) glds16(a_n + (size_t)a_rel[i] * 2, at + (size_t)(i * 512 + wave * 64) * 16);
     }
-    const char* g_n = (second ? p.g2 : p.g) + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+    // gathered operand: the slice (depth border rule) is the same for the whole box, rows / columns come from the tables
+    bool okz = true;
+    int izs = border_index(oz0 + p.dmin, d.Dg, d.border, okz);
+    izs = min(max(izs, 0), d.Dg - 1);
+    const char* g_n = (second ? p.g2 : p.g) + (((size_t)n * d.Dg + izs) * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+    const unsigned short* yrow = ytab + by * p.HH;
+    const unsigned short* xrow = xtab + bx * p.HW;
+    unsigned iy[NHMAX], ix[NHMAX];
+#pragma unroll
+    for (int i = 0; i < NHMAX; ++i)
+      if (i * 512 + wave * 64 < hpieces) { iy[i] = yrow[h_y[i]]; ix[i] = xrow[h_x[i]]; }
 #pragma unroll
     for (int i = 0; i < NHMAX; ++i) {
       if (i * 512 + wave * 64 < hpieces) {               // wave-uniform: whole 64-piece instructions inside the halo
-        bool ok = h_c[i] >= 0;
-        int iz = border_index(oz0 + h_z[i], d.Dg, d.border, ok);
-        int iy = border_index(oy0 + h_y[i], d.Hg, d.border, ok);
-        int ix = border_index(ox0 + h_x[i], d.Wg, d.border, ok);
-        iz = min(max(iz, 0), d.Dg - 1);
-        iy = min(max(iy, 0), d.Hg - 1);
-        ix = min(max(ix, 0), d.Wg - 1);
-        unsigned off = ((unsigned)((iz * d.Hg + iy) * d.Wg + ix) * (unsigned)d.g_cs + (unsigned)h_c[i]) * 2u;
+        const bool ok = okz && h_c[i] >= 0 && !((iy[i] | ix[i]) & 0x8000u);
+        unsigned off = ((iy[i] * (unsigned)d.Wg + ix[i]) * (unsigned)d.g_cs + (unsigned)h_c[i]) * 2u;
         asm volatile("" : "+v"(off));
         const char* src = ok ? g_n + off : p.zero;
         glds16(src, halo + (size_t)(i * 512 + wave * 64) * 16);
@@ -452,9 +484,10 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     const long long nboxes = a2 ? 2 * nboxes1 : nboxes1;
     const long long hv = (long long)k.HD * k.HH * k.HW;
     const int hbytes = (int)((hv * 144 + 1023) / 1024 * 1024 + 1024);
-    const int lds = 256 + 2 * (256 * 128 + hbytes);
+    const long long tab_bytes = ((long long)k.nbh * k.HH + (long long)k.nbw * k.HW) * 2;      // border tables, see the kernel
+    const int lds = (int)(256 + 2 * (256 * 128 + hbytes) + (tab_bytes + 15) / 16 * 16);
     const int tiles = (d->P / 64) * (d->Q / 64);
-    if (lds <= 160 * 1024 && hv * 9 <= 4096 && nboxes >= 4 && nboxes < (1LL << 31) && tiles <= 65535 &&
+    if (lds <= 160 * 1024 && k.HD == 1 && d->Hg < 32768 && d->Wg < 32768 && tab_bytes < 8192 && hv * 9 <= 4096 && nboxes >= 4 && nboxes < (1LL << 31) && tiles <= 65535 &&
         (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31)) {
       k.nboxes = (int)nboxes;
       k.nboxes1 = (int)nboxes1;
