@@ -159,8 +159,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int nk = cKp >> 6;
   const int ks_begin = (int)((long long)sp * nk / p.splits), ks_end = (int)((long long)(sp + 1) * nk / p.splits);
   int it_t = ks_begin % cT, it_c = ks_begin / cT;     // (tap, chunk) of the first K-step (chunk-major order)
-  auto issue = [&](int ks, int buf) {
-    char* sb = smem + buf * STAGE;
+  // Staging of a K-step in two parts: `prep` is the address generation (tap / table look-ups, border select: ~50 VALU
+  // per wave), `fire` the NWI + NXI LDS-DMA instructions on the prepared addresses. Issued back to back behind the barrier
+  // (`issue`) they put every wave of a SIMD into a VALU phase at the same moment, followed by an MFMA phase with the VALU
+  // idle (SQ_INSTS_VALU: 99 VALU per wave per K-step against 24 MFMAs in the 288-pixel tile, profiles/r02_trunk_pmc.txt);
+  // the 2-stage loop below runs prep(ks + 2) between the two 32-deep halves of compute(ks) instead.
+  const char* nx_src[NXI];
+  int n_q0 = 0;
+  auto prep = [&](int ks) {
     int q0;                                   // first 16-B k-group of this K-step inside a pack row
     if (chunk_major) {
       q0 = (it_t << p.ci_shift) + it_c * 8;
@@ -168,11 +174,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     } else {
       q0 = ks * 8;
     }
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      const int wi = wave + NW * i;
-      if (W_UNIFORM || wi < BN / 8) glds16(wsrc[i] + q0 * (winc[i] >> 3), sb + wi * 1024);
-    }
+    n_q0 = q0;
     const int q = q0 + chunk;
     const int t = q >> p.ci_shift;
     const int c8 = q & cmask;
@@ -189,10 +191,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       const bool ok = tv && !((a | bq) & GS_TAB_BAD);
       unsigned off = (a * wi + bq) * cs2 + (unsigned)(c8 * 16);
       asm volatile("" : "+v"(off));  // keep the address math unconditional: select, don't branch
-      const char* src = ok ? in_n + off : p.zero;
-      glds16(src, sb + WT + (wave + NW * i) * 1024);
+      nx_src[i] = ok ? in_n + off : p.zero;
     }
   };
+  auto fire = [&](int buf) {
+    char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int wi = wave + NW * i;
+      if (W_UNIFORM || wi < BN / 8) glds16(wsrc[i] + n_q0 * (winc[i] >> 3), sb + wi * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) glds16(nx_src[i], sb + WT + (wave + NW * i) * 1024);
+  };
+  auto issue = [&](int ks, int buf) { prep(ks); fire(buf); };
 
   f32x4 acc[TI][TJ];
 #pragma unroll
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   __syncthreads();  // taps visible
   if constexpr (NSTAGE == 2) {
     issue(ks_begin, 0);
+    if (ks_begin + 1 < ks_end) prep(ks_begin + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {
@@ -218,11 +231,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
 
   // (Fragment reads stay compiler-managed here: issuing both 32-deep halves through lds_read128 with counted waits, as
   // hconvw / hwgrad do, measured no gain on these two-wave-per-SIMD+ tiles and cost the 320-pixel tile 28 spills.)
-  auto compute = [&](int cur) {
+  auto compute_half = [&](int cur, int kk) {
     const char* wb = smem + cur * STAGE + (wn * (BN / WN) + frow) * 128;
     const char* xb = smem + cur * STAGE + WT + (wm * (BM / WM) + frow) * 128;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    {
       const int coff = ((kk * 4 + fk) ^ swz) << 4;
       bf16x8 wf[TI], xf[TJ];
 #pragma unroll
@@ -236,12 +248,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   };
+  auto compute = [&](int cur) { compute_half(cur, 0); compute_half(cur, 1); };
 
   if constexpr (NSTAGE == 2) {
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const int cur = (ks - ks_begin) & 1;
-      if (ks + 1 < ks_end) issue(ks + 1, cur ^ 1);
-      compute(cur);
+      if (ks + 1 < ks_end) fire(cur ^ 1);               // addresses of K-step ks + 1 were prepared one iteration ago
+      compute_half(cur, 0);
+      if (ks + 2 < ks_end) prep(ks + 2);                // the DMA of ks + 1 is in flight while ks + 2 is being addressed
+      compute_half(cur, 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's share)
       __syncthreads();
     }

@@ -13,10 +13,14 @@ run() {  # name, counters...
   rm -rf /tmp/pmc_$name
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$out/$name.log" 2>&1
   local db=$(find /tmp/pmc_$name -name "*.db" | head -1)
-  for k in gconv_kernelILi288 hwgrad_wide hconvw_kernel inorm_bwd_apply_cg wgrad_reduce; do
+  for k in "gconv_kernel<288" hwgrad_wide hconvw_kernel inorm_bwd_apply_cg inorm_stats_act; do
     python tools/pmc_summary.py "$db" "$k"
   done > "$out/$name.txt" 2>> "$out/$name.log"
 }
+if [ "${2:-}" = "valu" ]; then
+  run valu SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_VALU
+  exit 0
+fi
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
