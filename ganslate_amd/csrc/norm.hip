@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
                                                        float eps, const float* mean_rstd, float* db) {
   constexpr int LANES = 256 / CH;
   __shared__ double red[LANES][CH + 1];
-  __shared__ float tot[R][CH];
+  __shared__ double tot[R][CH];      // double up to mean / rstd: E[y^2] - mean^2 in fp32 loses the variance when |mean| >> std
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const int col = tid % CH, lane = tid / CH;
@@ -44,20 +44,20 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
       double t = 0.0;
 #pragma unroll
       for (int l = 0; l < LANES; ++l) t += red[l][col];
-      tot[r][col] = (float)t;
+      tot[r][col] = t;
     }
   }
   __syncthreads();
   if (lane == 0 && c < C) {
     if (R == 2) {
-      const double mean = (double)tot[0][col] * (double)inv_hw;
-      double var = (double)tot[1][col] * (double)inv_hw - mean * mean;
+      const double mean = tot[0][col] * (double)inv_hw;
+      double var = tot[1][col] * (double)inv_hw - mean * mean;
       if (var < 0.0) var = 0.0;
       out[(size_t)n * 2 * C + c] = (float)mean;
       out[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
     } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = tot[r][col];
+      for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = (float)tot[r][col];
     }
   }
 }

@@ -159,7 +159,7 @@ class CUT(BaseGAN):
         if self.is_flipped:       # target features are flipped back along W before sampling (cut.py:214-215)
             tgt_ids = []
             for e, pid in zip(self.nce_layers, ids):
-                w = (W + 6) if e == 0 else (W if e < 4 else (W // 2 if e < 7 else W // 4))
+                w = G.tap_dims(e, H, W)[1]          # the generator knows its own feature widths
                 tgt_ids.append((pid // w) * w + (w - 1 - pid % w))
         target_feats = G.extract_patch_features(target, self.nce_layers, tgt_ids)
         # both MLP passes, the logits, the cross-entropy and the mean over patches and levels: one autograd node

@@ -101,12 +101,18 @@ class Resnet2D(NativeNet):
                 out.append(next(native))
         return out
 
+    def tap_dims(self, e, H, W):
+        """(rows, columns) of encoder layer e for an H x W input: the ReflectionPad2d(3) output, the k7 conv block, the two
+        stride-2 blocks (k3 p1: ceil(n / 2)), the residual trunk"""
+        if e == 0:
+            return H + 6, W + 6
+        if e < 4:
+            return H, W
+        if e < 7:
+            return (H + 1) // 2, (W + 1) // 2
+        return ((H + 1) // 2 + 1) // 2, ((W + 1) // 2 + 1) // 2
+
     def tap_extent(self, e, H, W):
         """number of pixels of encoder layer e for an H x W input"""
-        if e == 0:
-            return (H + 6) * (W + 6)
-        if e < 4:
-            return H * W
-        if e < 7:
-            return (H // 2) * (W // 2)
-        return (H // 4) * (W // 4)
+        h, w = self.tap_dims(e, H, W)
+        return h * w
