@@ -21,6 +21,8 @@ class UnpairedImageDatasetConfig(configs.base.BaseDatasetConfig):
     preprocess: Tuple[str] = ("resize", "random_crop", "random_flip")
     load_size: Tuple[int, int] = field(default_factory=lambda: [286, 286])
     final_size: Tuple[int, int] = field(default_factory=lambda: [256, 256])
+    # not in the reference: workers only decode, resize / crop / flip / normalise run on the GPU (data/device_transforms.py)
+    device_transforms: bool = False
 
 
 @dataclass
@@ -29,6 +31,7 @@ class PairedImageDatasetConfig(configs.base.BaseDatasetConfig):
     preprocess: Tuple[str] = ("resize", "random_crop", "random_flip")
     load_size: Tuple[int, int] = field(default_factory=lambda: [286, 286])
     final_size: Tuple[int, int] = field(default_factory=lambda: [256, 256])
+    device_transforms: bool = False
 
 
 def _files(root):
@@ -41,13 +44,25 @@ class _Transform:
     def __init__(self, conf):
         d = conf[conf.mode].dataset
         self.pre, self.load, self.final = list(d.preprocess), tuple(d.load_size), tuple(d.final_size)
+        try:
+            self.raw = bool(d["device_transforms"])
+        except (KeyError, AttributeError):
+            self.raw = False
 
     def params(self):
         return {"crop": (random.random(), random.random()), "flip": random.random() > 0.5}
 
+    def decode_only(self, img, prm):
+        """device_transforms: hand the decoded bytes and the drawn parameters to DeviceImagePipeline"""
+        import numpy as np
+        from .device_transforms import RawImage
+        return RawImage(torch.from_numpy(np.array(img, dtype=np.uint8)), prm["crop"], prm["flip"])
+
     def __call__(self, img, prm):
         import numpy as np
         from PIL import Image
+        if self.raw:
+            return self.decode_only(img, prm)
         if "resize" in self.pre:
             img = img.resize((self.load[1], self.load[0]), Image.BICUBIC)
         if "random_crop" in self.pre:
@@ -62,7 +77,24 @@ class _Transform:
         return (a - 0.5) / 0.5
 
 
-class UnpairedImageDataset(Dataset):
+class _DevicePipelineMixin:
+    """build_loader picks these up: raw batches are lists (images differ in size), the Trainer runs the pipeline"""
+
+    @property
+    def collate_fn(self):
+        if not self.transform.raw:
+            return None
+        from .device_transforms import collate_raw
+        return collate_raw
+
+    def device_pipeline(self, conf, device):
+        if not self.transform.raw:
+            return None
+        from .device_transforms import DeviceImagePipeline
+        return DeviceImagePipeline(conf, device)
+
+
+class UnpairedImageDataset(_DevicePipelineMixin, Dataset):
 
     def __init__(self, conf):
         root = Path(conf[conf.mode].dataset.root)
@@ -80,7 +112,7 @@ class UnpairedImageDataset(Dataset):
         return max(len(self.A_paths), len(self.B_paths))
 
 
-class PairedImageDataset(Dataset):
+class PairedImageDataset(_DevicePipelineMixin, Dataset):
 
     def __init__(self, conf):
         root = Path(conf[conf.mode].dataset.root)

@@ -23,6 +23,10 @@ class Trainer:
             environment.set_seed(self.conf.train.seed)
         self.data_loader = build_loader(self.conf)
         self.model = build_gan(self.conf)
+        # device-side input pipeline (train.dataset.device_transforms, data/device_transforms.py): the loader hands over
+        # decoded bytes, the transform of data/utils/transforms.py runs on the GPU in front of set_input
+        make = getattr(getattr(self.data_loader, "dataset", None), "device_pipeline", None)
+        self.input_pipeline = make(self.conf, self.model.device) if make else None
         start_iter = 1
         if self.conf.train.checkpointing.load_iter:
             start_iter += self.conf.train.checkpointing.load_iter
@@ -61,6 +65,8 @@ class Trainer:
             self._run_validation()
 
     def _run_iteration(self, data):
+        if self.input_pipeline is not None:
+            data = self.input_pipeline(data)
         self.model.set_input(data)
         self.model.optimize_parameters()
 

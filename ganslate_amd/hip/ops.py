@@ -452,6 +452,23 @@ class HipOps:
                 "gs_shiftadd_to_image_backward")
 
     # ---- losses ---------------------------------------------------------------------------------------------
+    # ---- device-side image preprocessing (csrc/imgproc.hip) ---------------------------------------------
+    def u8_resample_h(self, img, out, bounds, kk):
+        """Pillow's horizontal 8-bit pass: img (H, W, C) uint8 -> out (H, W', C) uint8; bounds (W', 2), kk (W', ksize) int32"""
+        H, W, Cc = img.shape
+        L.check(self.lib.gs_u8_resample_h(_ptr(img), _ptr(out), H, W, out.shape[1], Cc, _ptr(bounds), _ptr(kk),
+                                          kk.shape[1], _stream()), "gs_u8_resample_h")
+
+    def u8_resample_v_crop_normalize(self, tmp, out, out_h, bounds, kk, top, left, flip):
+        """Pillow's vertical pass on the crop window + flip + ToTensor + Normalize(0.5, 0.5): tmp (H, W', C) uint8 ->
+        out (C, fh, fw) fp32 (a contiguous slice of the NCHW batch)"""
+        H, W2, Cc = tmp.shape
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == Cc
+        L.check(self.lib.gs_u8_resample_v_crop_normalize(_ptr(tmp), _ptr(out), H, W2, out_h, Cc, _ptr(bounds), _ptr(kk),
+                                                         kk.shape[1], int(top), int(left), out.shape[1], out.shape[2],
+                                                         int(bool(flip)), _stream()),
+                "gs_u8_resample_v_crop_normalize")
+
     ADV_MODES = {"lsgan": 0, "vanilla": 1, "wgangp": 2, "nonsaturating": 3}
 
     def adv_loss(self, x, mode, target_is_real, label, loss=None, grad=None, grad_scale=None):

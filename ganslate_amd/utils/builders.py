@@ -48,8 +48,10 @@ def build_loader(conf):
         if torch.distributed.is_initialized():
             sampler = DistributedSampler(dataset, shuffle=False, num_replicas=communication.get_world_size(),
                                          rank=communication.get_rank())
+    collate = getattr(dataset, "collate_fn", None)      # device_transforms: raw images of different sizes stay a list
     return DataLoader(dataset, sampler=sampler, batch_size=mode_conf.batch_size,
-                      num_workers=mode_conf.dataset.num_workers, pin_memory=mode_conf.dataset.pin_memory)
+                      num_workers=mode_conf.dataset.num_workers,
+                      pin_memory=mode_conf.dataset.pin_memory and collate is None, collate_fn=collate)
 
 
 def build_gan(conf):

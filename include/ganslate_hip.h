@@ -286,6 +286,22 @@ int gs_shiftadd_to_image(const void* z, const float* bias, float* img, int32_t N
 int gs_shiftadd_to_image_backward(const float* g_img, const float* out_img, void* gz, int32_t N, int32_t Co,
                                   int64_t rows, int32_t W, int32_t Pp, int32_t k, int32_t act_kind, void* stream);
 
+/* ---- device-side image preprocessing --------------------------------------------- */
+/* What ganslate/data/utils/transforms.py:9-61 composes on the host from torchvision / PIL for the image-folder datasets
+ * (unpaired_image_dataset.py:31-62, paired_image_dataset.py): Resize(load_size, Image.BICUBIC), RandomCrop(final_size),
+ * RandomHorizontalFlip, ToTensor, Normalize(0.5, 0.5) — here on decoded 8-bit HWC images (C = 1 or 3) in device memory.
+ * The resize is Pillow's two-pass 8-bit resampler bit for bit (src/libImaging/Resample.c): the caller supplies, per axis,
+ * bounds[out][2] = (first input index, count) and kk[out][ksize] = 22-bit fixed-point coefficients
+ * (precompute_coeffs + normalize_coeffs_8bpc; identity tables when an axis keeps its size).
+ * Pass 1, horizontal: out[y][xx][c] = clip8((2^21 + sum_k in[y][xmin+k][c] * kk[xx][k]) >> 22), all in_h rows. */
+int gs_u8_resample_h(const void* in, void* out, int32_t in_h, int32_t in_w, int32_t out_w, int32_t C,
+                     const int32_t* bounds, const int32_t* kk, int32_t ksize, void* stream);
+/* Pass 2, vertical, only for the crop window [top, top+fh) x [left, left+fw) of the out_h x tmp_w resized image, then flip,
+ * x/255 and (x-0.5)/0.5 in torchvision's fp32 order: out[c][i][j] (planes of fh*fw floats — a slice of the NCHW batch). */
+int gs_u8_resample_v_crop_normalize(const void* tmp, float* out, int32_t tmp_h, int32_t tmp_w, int32_t out_h, int32_t C,
+                                    const int32_t* bounds, const int32_t* kk, int32_t ksize, int32_t top, int32_t left,
+                                    int32_t fh, int32_t fw, int32_t flip, void* stream);
+
 /* ---- losses (fp32, on the boundary images / discriminator maps) --------------------------------- */
 /* loss[0] = mean((x-target)^2); if grad != NULL: grad = grad_scale * 2*(x-target)/n
  * (nn.MSELoss vs expanded constant, adversarial_loss.py:28-29,60-62) */

@@ -451,6 +451,34 @@ class RefOps:
             gz[..., dw:dw + W, dw * Co:(dw + 1) * Co] = gl.to(gz.dtype)
 
     # ---- losses -----------------------------------------------------------------------------------------
+    # ---- device-side image preprocessing (oracle/pil_ref.py: Pillow's resampler restated) ---------------------------
+    def u8_resample_h(self, img, out, bounds, kk):
+        """out[y][xx][c] = clip8((2^21 + sum_k img[y][xmin + k][c] * kk[xx][k]) >> 22) from the tables as given"""
+        a = img.to(torch.int64)
+        for xx in range(out.shape[1]):
+            xmin, xn = int(bounds[xx, 0]), int(bounds[xx, 1])
+            acc = torch.full(a[:, 0].shape, 1 << 21, dtype=torch.int64)
+            for x in range(xn):
+                acc += a[:, xmin + x] * int(kk[xx, x])
+            out[:, xx] = (acc >> 22).clamp(0, 255).to(torch.uint8)
+
+    def u8_resample_v_crop_normalize(self, tmp, out, out_h, bounds, kk, top, left, flip):
+        a = tmp.to(torch.int64)
+        fh, fw = out.shape[1], out.shape[2]
+        rows = torch.empty((fh, a.shape[1], a.shape[2]), dtype=torch.uint8)
+        for i in range(fh):
+            yy = top + i
+            ymin, yn = int(bounds[yy, 0]), int(bounds[yy, 1])
+            acc = torch.full(a[0].shape, 1 << 21, dtype=torch.int64)
+            for y in range(yn):
+                acc += a[ymin + y] * int(kk[yy, y])
+            rows[i] = (acc >> 22).clamp(0, 255).to(torch.uint8)
+        win = rows[:, left:left + fw]
+        if flip:
+            win = win.flip(1)
+        x = win.to(torch.float32) / 255.0
+        out.copy_(((x - 0.5) / 0.5).permute(2, 0, 1))
+
     def adv_loss(self, x, mode, target_is_real, label, loss=None, grad=None, grad_scale=None):
         """AdversarialLoss.calculate_loss (ganslate/nn/losses/adversarial_loss.py:52-73) through torch autograd"""
         import torch.nn.functional as F

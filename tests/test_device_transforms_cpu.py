@@ -1,0 +1,88 @@
+"""Device input pipeline, host side: the Pillow restatement (oracle/pil_ref.py) and the coefficient
+tables the product uploads (ganslate_amd/data/device_transforms.resample_tables) against PIL.Image.resize itself — the
+resampler is third-party arithmetic (Pillow, present in the image: the pin is the library), bit-exact — and the whole
+single-image transform against the PIL + torch host transform the datasets use without device_transforms."""
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from ganslate_amd.data.device_transforms import resample_tables
+from oracle import pil_ref
+
+CASES = [(256, 256, 286, 286, 3), (300, 400, 286, 286, 3), (37, 53, 64, 64, 3), (512, 384, 143, 143, 1),
+         (100, 100, 100, 130, 3), (240, 320, 286, 286, 1), (1024, 768, 286, 286, 3), (5, 7, 64, 48, 3), (64, 64, 64, 64, 3)]
+
+
+def _image(h, w, c, seed):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, c), dtype=np.uint8)
+
+
+def _pil(a):
+    return Image.fromarray(a if a.shape[-1] == 3 else a[..., 0], "RGB" if a.shape[-1] == 3 else "L")
+
+
+@pytest.mark.parametrize("h,w,oh,ow,c", CASES)
+def test_restatement_equals_pillow_bit_for_bit(h, w, oh, ow, c):
+    a = _image(h, w, c, 1)
+    ref = np.asarray(_pil(a).resize((ow, oh), Image.BICUBIC))
+    ref = ref[..., None] if c == 1 else ref
+    assert np.array_equal(pil_ref.resize_bicubic(a, oh, ow), ref)
+
+
+@pytest.mark.parametrize("n_in,n_out", [(256, 286), (400, 286), (1024, 286), (53, 64), (7, 48), (64, 64)])
+def test_product_tables_equal_the_restatement(n_in, n_out):
+    bounds, kk = resample_tables(n_in, n_out)
+    if n_in == n_out:
+        assert np.array_equal(bounds[:, 0], np.arange(n_out)) and (bounds[:, 1] == 1).all() and (kk == 1 << 22).all()
+        return
+    rb, rk = pil_ref.precompute_coeffs(n_in, n_out)
+    assert np.array_equal(bounds, np.array(rb, np.int32))
+    assert np.array_equal(kk, np.array(rk, np.int32))
+
+
+@pytest.mark.parametrize("c", [3, 1])
+def test_oracle_transform_equals_the_host_dataset_transform(c, tmp_path):
+    """oracle single_image_transform == the PIL + torch transform of ganslate_amd/data/image_datasets.py (which is what
+    torchvision's Resize / RandomCrop / RandomHorizontalFlip / ToTensor / Normalize compute) for the same draws"""
+    from ganslate_amd.data.image_datasets import _Transform
+
+    class D(dict):
+        __getattr__ = dict.__getitem__
+    conf = D(mode="train", train=D(dataset=D(preprocess=["resize", "random_crop", "random_flip"], load_size=[72, 80],
+                                             final_size=[64, 64])))
+    t = _Transform(conf)
+    random.seed(3)
+    for k in range(4):
+        a = _image(50 + 7 * k, 90 - 5 * k, c, k)
+        prm = t.params()
+        want = t(_pil(a), prm)
+        got = pil_ref.single_image_transform(a, t.pre, t.load, t.final, prm["crop"], prm["flip"])
+        assert torch.equal(torch.from_numpy(got), want)
+
+
+def test_loader_hands_over_raw_images_with_device_transforms(tmp_path):
+    """train.dataset.device_transforms=true: the workers only decode — a batch is a list of RawImage (decoded bytes + the
+    drawn crop / flip parameters) per domain; without it the same files come out as the usual fp32 batch"""
+    from ganslate_amd.data.device_transforms import RawImage
+    from ganslate_amd.utils.builders import build_conf, build_loader
+    for dom in "AB":
+        (tmp_path / dom).mkdir()
+        for k in range(3):
+            Image.fromarray(_image(40 + 3 * k, 52, 3, k), "RGB").save(tmp_path / dom / f"{k}.png")
+    base = ["config=tests/configs/cyclegan_imagefolder.yaml", f"train.dataset.root={tmp_path}"]
+    conf = build_conf(base + ["train.dataset.device_transforms=True"])
+    conf.mode = "train"
+    loader = build_loader(conf)
+    batch = next(iter(loader))
+    assert set(batch) == {"A", "B"} and len(batch["A"]) == 2
+    r = batch["A"][0]
+    assert isinstance(r, RawImage) and r.pixels.dtype == torch.uint8 and r.pixels.shape[1:] == (52, 3)
+    assert 0.0 <= r.crop[0] < 1.0 and isinstance(r.flip, bool)
+    assert loader.dataset.device_pipeline(conf, "cpu") is not None
+    conf = build_conf(base)
+    conf.mode = "train"
+    loader = build_loader(conf)
+    assert next(iter(loader))["A"].shape == (2, 3, 32, 32) and loader.dataset.device_pipeline(conf, "cpu") is None
