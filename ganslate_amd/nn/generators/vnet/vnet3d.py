@@ -372,3 +372,23 @@ class Vnet3D(NativeNet):
         ops.image_to_act_backward(gx, g_in, fold=0)
         ops.repeat_backward(gres, g_in, c)               # adjoint of x.repeat (vnet3d.py:165-166)
         return g_in
+
+
+@dataclass
+class Vnet2DConfig(configs.base.BaseGeneratorConfig):
+    """Partially-invertible V-Net generator, 2-D (ganslate/nn/generators/vnet/vnet2d.py:14-19: the block counts are not
+    configurable there; the defaults build the RevGAN inverse path, which raises here — set both to False)"""
+    use_memory_saving: bool = True
+    use_inverse: bool = True
+    first_layer_channels: int = 16
+
+
+class Vnet2D(Vnet3D):
+    """ganslate/nn/generators/vnet/vnet2d.py:22-248: Vnet3D's constructor, channel plan and state_dict names on 2-D
+    layers — the executor above treats an image as the depth-1 volume, so only the lowering dimension changes"""
+    dims = 2
+
+    def __init__(self, in_channels, out_channels, norm_type, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
+                 up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True):
+        super().__init__(in_channels, out_channels, norm_type, first_layer_channels, down_blocks, up_blocks,
+                         use_memory_saving, use_inverse, False)

@@ -4,6 +4,7 @@
     python -m oracle.gen_golden_r2 envelope    # tests/golden/envelope.json
     python -m oracle.gen_golden_r2 fullsize    # tests/golden/fullsize.json
     python -m oracle.gen_golden_r2 advmodes    # tests/golden/adv_modes.json
+    python -m oracle.gen_golden_r2 vnet2d      # tests/golden/vnet2d.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -147,10 +148,27 @@ def advmodes():
     (OUT / "adv_modes.json").write_text(json.dumps({"ops": ops, "steps": steps}, indent=1))
 
 
+def vnet2d():
+    """the reference's Vnet2D (nn/generators/vnet/vnet2d.py) with use_memory_saving=False, use_inverse=False over the memcnn
+    stand-in: forward output, input gradient and every parameter-gradient norm (gen_golden.net_case)"""
+    from oracle import gen_golden as G          # imports the reference
+    from ganslate.nn.generators.vnet.vnet2d import Vnet2D
+    torch.set_num_threads(8)
+    out = {
+        "vnet2d_default_blocks": G.net_case("v2d", Vnet2D(2, 3, "instance", 16, (1, 2, 3, 2), (2, 2, 1, 1), False, False),
+                                            (2, 2, 32, 48), 67),
+        "vnet2d_1ch_small": G.net_case("v2s", Vnet2D(1, 1, "instance", 8, (1, 2), (2, 1), False, False),
+                                       (1, 1, 16, 24), 68),
+    }
+    (OUT / "vnet2d.json").write_text(json.dumps(out, indent=1))
+
+
 def main():
     what = sys.argv[1]
     if what == "fullsize":
         fullsize()
+    elif what == "vnet2d":
+        vnet2d()
     elif what == "advmodes":
         advmodes()
     elif what == "grads":

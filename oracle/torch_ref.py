@@ -237,10 +237,15 @@ class _Wrapper(nn.Module):
         return self._fn(x)
 
 
+def _vconv(dims):
+    return (nn.Conv2d, nn.ConvTranspose2d, nn.InstanceNorm2d) if dims == 2 else (nn.Conv3d, nn.ConvTranspose3d, nn.InstanceNorm3d)
+
+
 class _InvertibleBlock(nn.Module):
-    def __init__(self, h):
+    def __init__(self, h, dims=3):
         super().__init__()
-        mk = lambda: nn.Sequential(nn.Conv3d(h, h, 5, padding=2), nn.InstanceNorm3d(h), nn.PReLU(h))
+        Conv, _, Norm = _vconv(dims)
+        mk = lambda: nn.Sequential(Conv(h, h, 5, padding=2), Norm(h), nn.PReLU(h))
         self.invertible_block = _Wrapper(_AdditiveCoupling(mk(), mk()))
 
     def forward(self, x):
@@ -248,32 +253,34 @@ class _InvertibleBlock(nn.Module):
 
 
 class _InvertibleSequence(nn.Module):
-    def __init__(self, h, n):
+    def __init__(self, h, n, dims=3):
         super().__init__()
-        self.sequence = nn.Sequential(*[_InvertibleBlock(h) for _ in range(n)])
+        self.sequence = nn.Sequential(*[_InvertibleBlock(h, dims) for _ in range(n)])
 
     def forward(self, x):
         return self.sequence(x)
 
 
 class _VInput(nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, dims=3):
         super().__init__()
+        Conv, _, Norm = _vconv(dims)
         self.n_repeats = cout // cin
-        self.conv1 = nn.Conv3d(cin, cout, 5, padding=2)
-        self.bn1 = nn.InstanceNorm3d(cout)
+        self.conv1 = Conv(cin, cout, 5, padding=2)
+        self.bn1 = Norm(cout)
         self.relu = nn.PReLU(cout)
 
     def forward(self, x):
-        return self.relu(self.bn1(self.conv1(x)) + x.repeat(1, self.n_repeats, 1, 1, 1))
+        return self.relu(self.bn1(self.conv1(x)) + x.repeat(1, self.n_repeats, *([1] * (x.dim() - 2))))
 
 
 class _VDown(nn.Module):
-    def __init__(self, cin, n):
+    def __init__(self, cin, n, dims=3):
         super().__init__()
+        Conv, _, Norm = _vconv(dims)
         cout = 2 * cin
-        self.down_conv_ab = nn.Sequential(nn.Conv3d(cin, cout, 2, stride=2), nn.InstanceNorm3d(cout), nn.PReLU(cout))
-        self.core = _InvertibleSequence(cout // 2, n)
+        self.down_conv_ab = nn.Sequential(Conv(cin, cout, 2, stride=2), Norm(cout), nn.PReLU(cout))
+        self.core = _InvertibleSequence(cout // 2, n, dims)
         self.relu = nn.PReLU(cout)
 
     def forward(self, x):
@@ -282,11 +289,11 @@ class _VDown(nn.Module):
 
 
 class _VUp(nn.Module):
-    def __init__(self, cin, cout, n):
+    def __init__(self, cin, cout, n, dims=3):
         super().__init__()
-        self.up_conv_ab = nn.Sequential(nn.ConvTranspose3d(cin, cout // 2, 2, stride=2), nn.InstanceNorm3d(cout // 2),
-                                        nn.PReLU(cout // 2))
-        self.core = _InvertibleSequence(cout // 2, n)
+        _, ConvT, Norm = _vconv(dims)
+        self.up_conv_ab = nn.Sequential(ConvT(cin, cout // 2, 2, stride=2), Norm(cout // 2), nn.PReLU(cout // 2))
+        self.core = _InvertibleSequence(cout // 2, n, dims)
         self.relu = nn.PReLU(cout)
 
     def forward(self, x, skip):
@@ -295,12 +302,13 @@ class _VUp(nn.Module):
 
 
 class _VOut(nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, dims=3):
         super().__init__()
-        self.conv1 = nn.Conv3d(cin, cin, 5, padding=2)
-        self.bn1 = nn.InstanceNorm3d(cin)
+        Conv, _, Norm = _vconv(dims)
+        self.conv1 = Conv(cin, cin, 5, padding=2)
+        self.bn1 = Norm(cin)
         self.relu1 = nn.PReLU(cin)
-        self.conv2 = nn.Conv3d(cin, cout, 1)
+        self.conv2 = Conv(cin, cout, 1)
 
     def forward(self, x):
         return torch.tanh(self.conv2(self.relu1(self.bn1(self.conv1(x)))))
@@ -308,19 +316,20 @@ class _VOut(nn.Module):
 
 class Vnet3D(nn.Module):
     """use_inverse=False, use_memory_saving=False, is_separable=False (the brats yaml's settings)"""
+    dims = 3
 
     def __init__(self, in_channels, out_channels, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
                  up_blocks=(2, 2, 1, 1)):
         super().__init__()
-        c = first_layer_channels
-        self.in_ab = _VInput(in_channels, c)
-        self.out_ab = _VOut(2 * c, out_channels)
-        self.downs = nn.ModuleList([_VDown(c * 2 ** i, n) for i, n in enumerate(down_blocks)])
+        c, dims = first_layer_channels, type(self).dims
+        self.in_ab = _VInput(in_channels, c, dims)
+        self.out_ab = _VOut(2 * c, out_channels, dims)
+        self.downs = nn.ModuleList([_VDown(c * 2 ** i, n, dims) for i, n in enumerate(down_blocks)])
         self.encoder = nn.ModuleList([self.in_ab]).extend(self.downs)
         ucf = [2 * 2 ** i for i in reversed(range(len(down_blocks)))]
-        ups = [_VUp(c * ucf[0], c * ucf[0], up_blocks[0])]
+        ups = [_VUp(c * ucf[0], c * ucf[0], up_blocks[0], dims)]
         for i, n in enumerate(up_blocks[1:]):
-            ups.append(_VUp(c * ucf[i], c * ucf[i + 1], n))
+            ups.append(_VUp(c * ucf[i], c * ucf[i + 1], n, dims))
         self.ups = nn.ModuleList(ups)
 
     def forward(self, x):
@@ -333,6 +342,12 @@ class Vnet3D(nn.Module):
         for i, up in enumerate(self.ups):
             out = up(out, out1 if i == len(self.ups) - 1 else rev[i + 1])
         return self.out_ab(out)
+
+
+class Vnet2D(Vnet3D):
+    """ganslate/nn/generators/vnet/vnet2d.py:22-248 with use_inverse=False, use_memory_saving=False: the same network on
+    Conv2d / ConvTranspose2d / InstanceNorm2d"""
+    dims = 2
 
 
 def seeded_state_dict(module: nn.Module, seed: int, gain=0.02, bias_gain=0.01):
