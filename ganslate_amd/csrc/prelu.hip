@@ -95,6 +95,11 @@ __global__ __launch_bounds__(256) void pnorm_fwd_kernel(const PNormK p, const un
       pn_res8(r, d, res, pix, c8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) u[k] += r[k];
+    } else if (d.res_mode == 3) {        // inverse of an additive coupling: x = y - F(.)  (memcnn AdditiveCoupling.inverse)
+      float r[8];
+      pn_res8(r, d, res, pix, c8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = r[k] - u[k];
     }
     *reinterpret_cast<uint4*>(out + pix * d.out_cs + d.out_co + c8 * 8) = pn_pack8(u);
   }
@@ -111,6 +116,10 @@ __device__ __forceinline__ void pn_gu(float* gu, float* gs, const PNormK& p, con
     pn_view8(b, g2, pix, d.g2_cs, d.g2_co, c8);
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] += b[k];
+  }
+  if (d.res_mode == 3) {                 // out = res - v: the branch sees the negated gradient
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = -a[k];
   }
   if (slope) {
     pn_load8(sl, slope + c8 * 8);
@@ -263,7 +272,7 @@ static int pn_pix_per_block(long long pixels) {
 static int pn_check(const gs_pnorm_desc* d, const char* who) {
   GS_REQUIRE(d && d->N > 0 && d->pixels > 0 && d->C > 0 && (d->C & 7) == 0, "%s: bad shape", who);
   GS_REQUIRE(d->pixels * (d->C / 8) < (1LL << 31), "%s: image too large", who);
-  GS_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2, "%s: res_mode must be 0, 1 or 2", who);
+  GS_REQUIRE(d->res_mode >= 0 && d->res_mode <= 3, "%s: res_mode must be 0 .. 3", who);
   GS_REQUIRE((d->y_cs & 7) == 0 && (d->y_co & 7) == 0, "%s: y view must be 8-channel aligned", who);
   GS_REQUIRE(d->res_mode == 0 || d->res_mod > 0 || ((d->res_cs & 7) == 0 && (d->res_co & 7) == 0),
              "%s: residual view must be 8-channel aligned", who);

@@ -13,7 +13,15 @@ Execution: a coupling never splits or concatenates — convs read / write channe
 buffers (in_co / out_co of gs_gconv_desc), the norm + PReLU + residual chain is one kernel per half
 (gs_pnorm_forward), and in the backward pass the gradient buffer of [y1|y2] is turned into the gradient of [x1|x2] in
 place by data-gradient launches that accumulate into a slice (gs_gconv_desc.accumulate). PReLU slopes live in the flat
-master buffer behind the conv weights (`Extra`), their gradients come out of the norm-backward reductions."""
+master buffer behind the conv weights (`Extra`), their gradients come out of the norm-backward reductions.
+
+`use_inverse=True` (RevGAN, ganslate/nn/gans/unpaired/revgan.py:120-146) adds the B->A copies of the non-invertible layers
+(in_ba, out_ba, down_conv_ba, up_conv_ba: vnet3d.py:60-69,179-181,213-214) and `forward(x, inverse=True)`: the same walk
+with those layers and every core run backwards, x2 = y2 - G(y1), x1 = y1 - F(x2) per coupling in reversed block order
+(memcnn AdditiveCoupling.inverse through invertible.py:21-24,36-48) — gs_pnorm_forward's res_mode 3; the tail PReLUs and
+the couplings' weights are shared by both directions. `use_memory_saving` only changes what memcnn keeps alive between
+forward and backward (it recomputes inputs from outputs); the values are the same, and with 288 GB of HBM the activations
+are simply kept."""
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -58,9 +66,7 @@ class Vnet3D(NativeNet):
     def __init__(self, in_channels, out_channels, norm_type, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
                  up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True, is_separable=False):
         require_instance_norm(norm_type)
-        if use_inverse:
-            raise NotImplementedError("Vnet3D(use_inverse=True) builds the RevGAN inverse path, which is outside the "
-                                      "training-step scope; the shipped configs use use_inverse: False")
+        self.use_inverse = bool(use_inverse)
         if is_separable:
             raise NotImplementedError("separable convolutions are not implemented")
         if first_layer_channels % in_channels:
@@ -94,6 +100,11 @@ class Vnet3D(NativeNet):
         self.n_in = add_conv(conv("conv", in_channels, c, 5, 1, 2, bias=use_bias), True, "in_ab.conv1",
                              enc(0, "conv1"))
         self.s_in = add_slope("in_ab.relu.weight", c, enc(0, "relu.weight"))
+        inv = self.use_inverse
+        if inv:      # B -> A copies of the non-invertible layers, built with the same widths as the A -> B ones
+            # (vnet3d.py:60-62,67-69)
+            self.n_in_ba = add_conv(conv("conv", in_channels, c, 5, 1, 2, bias=use_bias), True, "in_ba.conv1")
+            self.s_in_ba = add_slope("in_ba.relu.weight", c)
 
         def couplings(blk, prefix, h, n, alias_prefix=None):
             for j in range(n):
@@ -114,6 +125,11 @@ class Vnet3D(NativeNet):
             blk.conv = add_conv(conv("conv", cin, 2 * cin, 2, 2, 0, bias=use_bias), True,
                                 f"downs.{i}.down_conv_ab.0", enc(i + 1, "down_conv_ab.0"))
             blk.conv_slope = add_slope(f"downs.{i}.down_conv_ab.2.weight", 2 * cin, enc(i + 1, "down_conv_ab.2.weight"))
+            if inv:
+                blk.conv_ba = add_conv(conv("conv", cin, 2 * cin, 2, 2, 0, bias=use_bias), True,
+                                       f"downs.{i}.down_conv_ba.0", enc(i + 1, "down_conv_ba.0"))
+                blk.conv_slope_ba = add_slope(f"downs.{i}.down_conv_ba.2.weight", 2 * cin,
+                                              enc(i + 1, "down_conv_ba.2.weight"))
             couplings(blk, f"downs.{i}", cin, n, f"encoder.{i + 1}")
             blk.tail_slope = add_slope(f"downs.{i}.relu.weight", 2 * cin, enc(i + 1, "relu.weight"))
             self.downs.append(blk)
@@ -126,15 +142,26 @@ class Vnet3D(NativeNet):
             blk.conv = add_conv(conv("convT", cin, cout // 2, 2, 2, 0, 0, bias=use_bias), True,
                                 f"ups.{i}.up_conv_ab.0")
             blk.conv_slope = add_slope(f"ups.{i}.up_conv_ab.2.weight", cout // 2)
+            if inv:
+                blk.conv_ba = add_conv(conv("convT", cin, cout // 2, 2, 2, 0, 0, bias=use_bias), True,
+                                       f"ups.{i}.up_conv_ba.0")
+                blk.conv_slope_ba = add_slope(f"ups.{i}.up_conv_ba.2.weight", cout // 2)
             couplings(blk, f"ups.{i}", cout // 2, n)
             blk.tail_slope = add_slope(f"ups.{i}.relu.weight", cout)
             self.ups.append(blk)
         self.n_o1 = add_conv(conv("conv", 2 * c, 2 * c, 5, 1, 2, bias=use_bias), True, "out_ab.conv1")
         self.s_o1 = add_slope("out_ab.relu1.weight", 2 * c)
         self.n_o2 = add_conv(conv("conv", 2 * c, out_channels, 1, 1, 0), False, "out_ab.conv2")
+        if inv:
+            self.n_o1_ba = add_conv(conv("conv", 2 * c, 2 * c, 5, 1, 2, bias=use_bias), True, "out_ba.conv1")
+            self.s_o1_ba = add_slope("out_ba.relu1.weight", 2 * c)
+            self.n_o2_ba = add_conv(conv("conv", 2 * c, out_channels, 1, 1, 0), False, "out_ba.conv2")
+            if in_channels != out_channels:
+                raise ValueError("use_inverse needs in_channels == out_channels (both directions share in / out widths)")
         super().__init__(nodes, in_channels, out_channels, out_act="tanh", extras=extras)
-        # the reference registers in_ab, out_ab, downs, ups in that order (vnet3d.py:60-88); inside a block the order above
-        rank = {"in_ab": 0, "out_ab": 1, "downs": 2, "ups": 3}
+        # the reference registers in_ab, in_ba, out_ab, out_ba, downs, ups in that order (vnet3d.py:60-104); inside a block
+        # the order above
+        rank = {"in_ab": 0, "in_ba": 1, "out_ab": 2, "out_ba": 3, "downs": 4, "ups": 5}
         self._param_order = sorted(order, key=lambda k: rank[k.split(".")[0]])       # stable
 
     def reference_parameter_order(self):
@@ -148,6 +175,14 @@ class Vnet3D(NativeNet):
             lv = lambda k: tuple(x >> k for x in key)
             lows = [None] * len(self.nodes)
             lows[self.n_in] = lower(self.nodes[self.n_in].spec, *key)
+            if self.use_inverse:
+                lows[self.n_in_ba] = lower(self.nodes[self.n_in_ba].spec, *key)
+                lows[self.n_o1_ba] = lower(self.nodes[self.n_o1_ba].spec, *key)
+                lows[self.n_o2_ba] = lower(self.nodes[self.n_o2_ba].spec, *key)
+                for blk in self.downs:
+                    lows[blk.conv_ba] = lower(self.nodes[blk.conv_ba].spec, *lv(blk.level - 1))
+                for blk in self.ups:
+                    lows[blk.conv_ba] = lower(self.nodes[blk.conv_ba].spec, *lv(blk.level + 1))
             for blk in self.downs:
                 lows[blk.conv] = lower(self.nodes[blk.conv].spec, *lv(blk.level - 1))
                 for nf, _, ng, _ in blk.couplings:
@@ -205,11 +240,43 @@ class Vnet3D(NativeNet):
             X = Y
         return X, saved
 
+    def _couplings_inverse(self, s, blk, Y):
+        """Y [.., 2h] -> core.inverse(Y): couplings in reversed order, x2 = y2 - G(y1), x1 = y1 - F(x2)"""
+        ops, h = self.ops, blk.C // 2
+        saved = []
+        for nf, sf, ng, sg in reversed(blk.couplings):
+            X = self._new(s.N, Y.shape[1:-1], blk.C)
+            yb, mrb = self._conv(s, ng, Y, in_co=0)                         # G reads y1
+            ops.pnorm_forward(yb, mrb, X, C=h, slope=self._slope(sg), res=Y, res_mode=3, res_co=h, out_co=h)
+            ya, mra = self._conv(s, nf, X, in_co=h)                         # F reads x2
+            ops.pnorm_forward(ya, mra, X, C=h, slope=self._slope(sf), res=Y, res_mode=3, res_co=0, out_co=0)
+            saved.append((X, Y, ya, mra, yb, mrb))
+            Y = X
+        return Y, saved
+
+    def forward(self, x, inverse=False):
+        """forward(x) = A -> B; forward(x, inverse=True) = B -> A through the *_ba layers and the inverted cores
+        (vnet3d.py:107-150); needs use_inverse=True"""
+        if inverse and not self.use_inverse:
+            raise ValueError("Trying to perform inverse forward while `use_inverse` flag is turned off.")
+        self._next_inverse = bool(inverse)
+        try:
+            return super().forward(x)
+        finally:
+            self._next_inverse = False
+
+    __call__ = forward
+
     def _forward(self, x, save, stop=None):
         assert stop is None, "feature taps are not implemented for Vnet3D"
         ops, c, L = self.ops, self.c, self.L
         N, sizes = x.shape[0], tuple(x.shape[2:])
         s = _Saved()
+        inv = s.inverse = bool(getattr(self, "_next_inverse", False))
+        n_in, s_in = (self.n_in_ba, self.s_in_ba) if inv else (self.n_in, self.s_in)
+        n_o1, s_o1, n_o2 = (self.n_o1_ba, self.s_o1_ba, self.n_o2_ba) if inv else (self.n_o1, self.s_o1, self.n_o2)
+        bconv = (lambda b: (b.conv_ba, b.conv_slope_ba)) if inv else (lambda b: (b.conv, b.conv_slope))
+        core = self._couplings_inverse if inv else self._couplings_forward
         s.x_img, s.N, s.sizes = x, N, sizes
         s.lows, s.pk = self._lowered(*sizes), self._get_packs(*sizes)
         lv = lambda k: tuple(v >> k for v in sizes)
@@ -217,9 +284,9 @@ class Vnet3D(NativeNet):
         ops.image_to_act(x, a0)
         s.a0 = a0
         # InputBlock
-        s.y_in, s.mr_in = self._conv(s, self.n_in, a0)
+        s.y_in, s.mr_in = self._conv(s, n_in, a0)
         out1 = self._new(N, sizes, c)
-        ops.pnorm_forward(s.y_in, s.mr_in, out1, C=c, slope=self._slope(self.s_in), res=a0, res_mode=1,
+        ops.pnorm_forward(s.y_in, s.mr_in, out1, C=c, slope=self._slope(s_in), res=a0, res_mode=1,
                           res_mod=self.in_channels)
         s.out1 = out1
         # DownBlocks
@@ -228,10 +295,11 @@ class Vnet3D(NativeNet):
         for blk in self.downs:
             rec = _Saved()
             rec.x_in = cur
-            rec.y, rec.mr = self._conv(s, blk.conv, cur)
+            nconv, sconv = bconv(blk)
+            rec.y, rec.mr = self._conv(s, nconv, cur)
             rec.D0 = self._new(N, lv(blk.level), blk.C)
-            ops.pnorm_forward(rec.y, rec.mr, rec.D0, C=blk.C, slope=self._slope(blk.conv_slope))
-            rec.Xn, rec.coup = self._couplings_forward(s, blk, rec.D0)
+            ops.pnorm_forward(rec.y, rec.mr, rec.D0, C=blk.C, slope=self._slope(sconv))
+            rec.Xn, rec.coup = core(s, blk, rec.D0)
             rec.out = self._new(N, lv(blk.level), blk.C)
             ops.pnorm_forward(rec.Xn, None, rec.out, C=blk.C, slope=self._slope(blk.tail_slope), res=rec.D0, res_mode=1)
             s.down.append(rec)
@@ -243,21 +311,22 @@ class Vnet3D(NativeNet):
             rec = _Saved()
             rec.x_in = cur
             h = blk.C // 2
-            rec.y, rec.mr = self._conv(s, blk.conv, cur)
+            nconv, sconv = bconv(blk)
+            rec.y, rec.mr = self._conv(s, nconv, cur)
             rec.D0 = self._new(N, lv(blk.level), blk.C)                      # xcat = [up | skip]
-            ops.pnorm_forward(rec.y, rec.mr, rec.D0, C=h, slope=self._slope(blk.conv_slope), out_co=0)
+            ops.pnorm_forward(rec.y, rec.mr, rec.D0, C=h, slope=self._slope(sconv), out_co=0)
             ops.add_views(rec.D0, skips[i], h, dst_co=h, src_co=0, accumulate=False)
-            rec.Xn, rec.coup = self._couplings_forward(s, blk, rec.D0)
+            rec.Xn, rec.coup = core(s, blk, rec.D0)
             rec.out = self._new(N, lv(blk.level), blk.C)
             ops.pnorm_forward(rec.Xn, None, rec.out, C=blk.C, slope=self._slope(blk.tail_slope), res=rec.D0, res_mode=1)
             s.up.append(rec)
             cur = rec.out
         # OutBlock
         s.o_in = cur
-        s.y_o1, s.mr_o1 = self._conv(s, self.n_o1, cur)
+        s.y_o1, s.mr_o1 = self._conv(s, n_o1, cur)
         s.t = self._new(N, sizes, 2 * c)
-        ops.pnorm_forward(s.y_o1, s.mr_o1, s.t, C=2 * c, slope=self._slope(self.s_o1))
-        s.z, _ = self._conv(s, self.n_o2, s.t, stats=False)
+        ops.pnorm_forward(s.y_o1, s.mr_o1, s.t, C=2 * c, slope=self._slope(s_o1))
+        s.z, _ = self._conv(s, n_o2, s.t, stats=False)
         out = torch.empty(N, self.out_channels, *sizes, dtype=torch.float32, device=self.device)
         ops.act_to_image(s.z, out, act="tanh")
         s.out_img = out
@@ -293,6 +362,24 @@ class Vnet3D(NativeNet):
         ops.pnorm_backward(g, rec.Xn, None, gu, C=blk.C, slope=self._slope(blk.tail_slope), dslope=dsl(blk.tail_slope),
                            g2=g2, g2_co=g2_co, res=rec.D0, res_mode=1)
         G = gu.clone()                                   # becomes the gradient w.r.t. core's input, in place
+        if s.inverse:
+            # rec.coup was recorded over reversed(blk.couplings): walk it back. Per coupling x1 = y1 - F(x2), x2 = y2 - G(y1):
+            # G holds the gradient w.r.t. [x1 | x2] and ends as the gradient w.r.t. [y1 | y2]
+            for (nf, sf, ng, sg), (X, Y, ya, mra, yb, mrb) in zip(blk.couplings, reversed(rec.coup)):
+                dya = torch.empty_like(ya)
+                ops.pnorm_backward(G, ya, mra, dya, C=h, slope=self._slope(sf), dslope=dsl(sf), g_co=0, res_mode=3,
+                                   bias_grad=self._bias_slice(nf, want_w))
+                if want_w:
+                    self._wgrad(s, nf, X, dya, x_co=h)
+                self._dgrad(s, nf, dya, out=G, out_co=h, accumulate=True)      # x2 also fed F
+                dyb = torch.empty_like(yb)
+                ops.pnorm_backward(G, yb, mrb, dyb, C=h, slope=self._slope(sg), dslope=dsl(sg), g_co=h, res_mode=3,
+                                   bias_grad=self._bias_slice(ng, want_w))
+                if want_w:
+                    self._wgrad(s, ng, Y, dyb, x_co=0)
+                self._dgrad(s, ng, dyb, out=G, out_co=0, accumulate=True)      # y1 also fed G
+            ops.add_views(G, gu, blk.C, accumulate=True)     # out = core.inverse(D0) + D0
+            return G
         for (nf, sf, ng, sg), (X, Y, ya, mra, yb, mrb) in zip(reversed(blk.couplings), reversed(rec.coup)):
             # y2 = x2 + G(y1): gradient of G's conv output from the y2 half, its data gradient joins the y1 half
             dyb = torch.empty_like(yb)
@@ -318,20 +405,24 @@ class Vnet3D(NativeNet):
             self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
         grad = self.master.grad
         dsl = (lambda name: self._slope(name, grad=True)) if want_w else (lambda name: None)
+        inv = s.inverse
+        n_in, s_in = (self.n_in_ba, self.s_in_ba) if inv else (self.n_in, self.s_in)
+        n_o1, s_o1, n_o2 = (self.n_o1_ba, self.s_o1_ba, self.n_o2_ba) if inv else (self.n_o1, self.s_o1, self.n_o2)
+        bconv = (lambda b: (b.conv_ba, b.conv_slope_ba)) if inv else (lambda b: (b.conv, b.conv_slope))
         # OutBlock
         gz = torch.empty_like(s.z)
         ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, gz, act="tanh")
         if want_w:
-            self._wgrad(s, self.n_o2, s.t, gz)
-            sp = self.nodes[self.n_o2].spec
-            ops.bias_grad(gz, sp.cout_p, grad[self.b_off[self.n_o2]:self.b_off[self.n_o2] + sp.cout_p])
-        gt = self._dgrad(s, self.n_o2, gz)
+            self._wgrad(s, n_o2, s.t, gz)
+            sp = self.nodes[n_o2].spec
+            ops.bias_grad(gz, sp.cout_p, grad[self.b_off[n_o2]:self.b_off[n_o2] + sp.cout_p])
+        gt = self._dgrad(s, n_o2, gz)
         dy = torch.empty_like(s.y_o1)
-        ops.pnorm_backward(gt, s.y_o1, s.mr_o1, dy, C=2 * c, slope=self._slope(self.s_o1), dslope=dsl(self.s_o1),
-                           bias_grad=self._bias_slice(self.n_o1, want_w))
+        ops.pnorm_backward(gt, s.y_o1, s.mr_o1, dy, C=2 * c, slope=self._slope(s_o1), dslope=dsl(s_o1),
+                           bias_grad=self._bias_slice(n_o1, want_w))
         if want_w:
-            self._wgrad(s, self.n_o1, s.o_in, dy)
-        g_cur = self._dgrad(s, self.n_o1, dy)            # gradient w.r.t. the last UpBlock's output
+            self._wgrad(s, n_o1, s.o_in, dy)
+        g_cur = self._dgrad(s, n_o1, dy)            # gradient w.r.t. the last UpBlock's output
         # UpBlocks, last first; skip gradients are slices of the blocks' xcat gradients
         skip_grad = {}                                   # forward skip index -> (tensor, channel offset)
         for i in range(L - 1, -1, -1):
@@ -339,35 +430,37 @@ class Vnet3D(NativeNet):
             h = blk.C // 2
             G = self._block_backward(s, blk, rec, g_cur, None, 0, want_w)
             skip_grad[i] = (G, h)
+            nconv, sconv = bconv(blk)
             dy = torch.empty_like(rec.y)
-            ops.pnorm_backward(G, rec.y, rec.mr, dy, C=h, slope=self._slope(blk.conv_slope),
-                               dslope=dsl(blk.conv_slope), g_co=0, bias_grad=self._bias_slice(blk.conv, want_w))
+            ops.pnorm_backward(G, rec.y, rec.mr, dy, C=h, slope=self._slope(sconv),
+                               dslope=dsl(sconv), g_co=0, bias_grad=self._bias_slice(nconv, want_w))
             if want_w:
-                self._wgrad(s, blk.conv, rec.x_in, dy)
-            g_cur = self._dgrad(s, blk.conv, dy)         # w.r.t. the previous UpBlock's output / the last DownBlock's
+                self._wgrad(s, nconv, rec.x_in, dy)
+            g_cur = self._dgrad(s, nconv, dy)         # w.r.t. the previous UpBlock's output / the last DownBlock's
         # DownBlocks, deepest first: output k also fed UpBlock L-1-k as its skip (k < L-1)
         for k in range(L - 1, -1, -1):
             blk, rec = self.downs[k], s.down[k]
             g2, g2_co = skip_grad[L - 2 - k] if k < L - 1 else (None, 0)
             G = self._block_backward(s, blk, rec, g_cur, g2, g2_co, want_w)
+            nconv, sconv = bconv(blk)
             dy = torch.empty_like(rec.y)
-            ops.pnorm_backward(G, rec.y, rec.mr, dy, C=blk.C, slope=self._slope(blk.conv_slope),
-                               dslope=dsl(blk.conv_slope), bias_grad=self._bias_slice(blk.conv, want_w))
+            ops.pnorm_backward(G, rec.y, rec.mr, dy, C=blk.C, slope=self._slope(sconv),
+                               dslope=dsl(sconv), bias_grad=self._bias_slice(nconv, want_w))
             if want_w:
-                self._wgrad(s, blk.conv, rec.x_in, dy)
-            g_cur = self._dgrad(s, blk.conv, dy)
+                self._wgrad(s, nconv, rec.x_in, dy)
+            g_cur = self._dgrad(s, nconv, dy)
         # InputBlock: out1 also was the skip of the last UpBlock
         g2, g2_co = skip_grad[L - 1]
         dy = torch.empty_like(s.y_in)
         gres = torch.empty_like(s.y_in) if need_input_grad else None
-        ops.pnorm_backward(g_cur, s.y_in, s.mr_in, dy, C=c, slope=self._slope(self.s_in), dslope=dsl(self.s_in),
+        ops.pnorm_backward(g_cur, s.y_in, s.mr_in, dy, C=c, slope=self._slope(s_in), dslope=dsl(s_in),
                            g2=g2, g2_co=g2_co, res=s.a0, res_mode=1, res_mod=self.in_channels, gres=gres,
-                           bias_grad=self._bias_slice(self.n_in, want_w))
+                           bias_grad=self._bias_slice(n_in, want_w))
         if want_w:
-            self._wgrad(s, self.n_in, s.a0, dy)
+            self._wgrad(s, n_in, s.a0, dy)
         if not need_input_grad:
             return None
-        gx = self._dgrad(s, self.n_in, dy)
+        gx = self._dgrad(s, n_in, dy)
         g_in = torch.empty_like(s.x_img)
         ops.image_to_act_backward(gx, g_in, fold=0)
         ops.repeat_backward(gres, g_in, c)               # adjoint of x.repeat (vnet3d.py:165-166)

@@ -224,8 +224,9 @@ int64_t gs_norm_backward_ex_scratch_floats(const gs_norm_ex_desc* d);
  * InstanceNorm3d(affine=False) -> [+ residual] -> nn.PReLU(C) -> [+ residual] on channel slices, and its backward incl.
  * the gradient of the learnable slope:
  *   forward : u = norm(y) (mean_rstd == NULL: u = y);  res_mode 1: u += res;  v = u > 0 ? u : slope[c]*u (slope == NULL:
- *             v = u);  res_mode 2: v += res;  out = v
- *   backward: gt = g (+ g2);  gu = gt*(u > 0 ? 1 : slope[c]);  dslope[c] += sum gt*min(u, 0);  gres = gu (optional);
+ *             v = u);  res_mode 2: v += res;  res_mode 3: v = res - v (the inverse of an additive coupling, x = y - F(.),
+ *             memcnn AdditiveCoupling.inverse through nn/invertible.py:21-24);  out = v
+ *   backward: gt = g (+ g2), negated for res_mode 3;  gu = gt*(u > 0 ? 1 : slope[c]);  dslope[c] += sum gt*min(u, 0);  gres = gu (optional);
  *             dy = rstd*(gu - mean gu - yhat*mean(gu*yhat)) (no norm: dy = gu);  bias_grad[c] += sum over pixels of dy
  * res_mod > 0: channel c reads residual channel c % res_mod (InputBlock's x.repeat, vnet3d.py:162-167). */
 typedef struct gs_pnorm_desc {

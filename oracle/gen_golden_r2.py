@@ -5,6 +5,7 @@
     python -m oracle.gen_golden_r2 fullsize    # tests/golden/fullsize.json
     python -m oracle.gen_golden_r2 advmodes    # tests/golden/adv_modes.json
     python -m oracle.gen_golden_r2 vnet2d      # tests/golden/vnet2d.json
+    python -m oracle.gen_golden_r2 revgan      # tests/golden/revgan.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -163,10 +164,104 @@ def vnet2d():
     (OUT / "vnet2d.json").write_text(json.dumps(out, indent=1))
 
 
+REVGAN_CASES = {
+    # RevGAN (nn/gans/unpaired/revgan.py) with ONE partially-invertible V-Net used in both directions and the CycleGAN losses
+    "rev3d_16x32x32": dict(size=[16, 32, 32], batch=1, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
+                           lambda_identity=0.0, proportion_ssim=0.0, d_layers=2, seed=55, dims=3,
+                           vnet=dict(first_layer_channels=8, down_blocks=[1, 2], up_blocks=[2, 1])),
+    "rev2d_64x64_idt": dict(size=[64, 64], batch=2, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
+                            lambda_identity=0.5, proportion_ssim=0.0, d_layers=2, seed=56, dims=2,
+                            vnet=dict(first_layer_channels=8)),
+}
+
+
+def _both_directions_case(net, x_shape, seed):
+    """y = net(x); r = net(y, inverse=True); gradients of sum(y*gy) + sum(r*gr)"""
+    from oracle.torch_ref import seeded_state_dict
+    net.load_state_dict(seeded_state_dict(net, seed))
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(x_shape, generator=g) * 2 - 1).requires_grad_()
+    y = net(x)
+    r = net(y, inverse=True)
+    gy, gr = torch.randn(y.shape, generator=g), torch.randn(r.shape, generator=g)
+    ((y * gy).sum() + (r * gr).sum()).backward()
+    idx = torch.linspace(0, y.numel() - 1, 32).long()
+    return {"seed": seed, "x_shape": list(x_shape), "state_dict_keys": list(net.state_dict().keys()),
+            "n_params": sum(p.numel() for p in net.parameters()), "sample_idx": [int(i) for i in idx],
+            "y_samples": [float(v) for v in y.detach().flatten()[idx]],
+            "r_samples": [float(v) for v in r.detach().flatten()[idx]],
+            "y_abs_sum": float(y.detach().double().abs().sum()), "r_abs_sum": float(r.detach().double().abs().sum()),
+            "x_grad_abs_sum": float(x.grad.double().abs().sum()),
+            "param_grad_norms": {n: float(p.grad.norm()) for n, p in net.named_parameters()}}
+
+
+def revgan():
+    """the reference's RevGAN and its generators' inverse direction over the memcnn stand-in (oracle/ref_stubs/memcnn:
+    additive coupling forward / inverse with plain autograd — what memcnn's memory saving recomputes, it does not change)"""
+    from oracle import gen_golden as G          # imports the reference
+    from omegaconf import DictConfig
+    from ganslate.nn.gans.unpaired.revgan import RevGAN
+    from ganslate.nn.generators.vnet.vnet2d import Vnet2D
+    from ganslate.nn.generators.vnet.vnet3d import Vnet3D
+    from oracle.torch_ref import seeded_state_dict
+    torch.set_num_threads(8)
+    nets = {
+        "vnet3d_inverse": _both_directions_case(Vnet3D(1, 1, "instance", 8, (1, 2), (2, 1), True, True, False),
+                                                (1, 1, 8, 12, 16), 69),
+        "vnet2d_inverse_default_blocks": _both_directions_case(Vnet2D(2, 2, "instance", 8), (1, 2, 64, 96), 70),
+    }
+    steps = {}
+    for name, c in REVGAN_CASES.items():
+        conf = G.make_conf(c)
+        conf.train.metrics["ssim"] = False
+        gan = conf.train.gan
+        gan["_target_"] = "ganslate.nn.gans.unpaired.RevGAN"
+        if c["dims"] == 3:
+            gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet3D", "use_memory_saving": True,
+                                           "use_inverse": True, "is_separable": False,
+                                           "first_layer_channels": c["vnet"]["first_layer_channels"],
+                                           "down_blocks": c["vnet"]["down_blocks"], "up_blocks": c["vnet"]["up_blocks"],
+                                           "in_out_channels": {"AB": [1, 1]}})
+            gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
+                                               "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                               "in_channels": {"B": 1, "A": 1}})
+            shape = (c["batch"], 1, *c["size"])
+        else:
+            gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet2D", "use_memory_saving": True,
+                                           "use_inverse": True, "first_layer_channels": c["vnet"]["first_layer_channels"],
+                                           "in_out_channels": {"AB": [2, 2]}})
+            gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN2D", "ndf": 64,
+                                               "n_layers": c["d_layers"], "kernel_size": [4, 4],
+                                               "in_channels": {"B": 2, "A": 2}})
+            shape = (c["batch"], 2, *c["size"])
+        torch.manual_seed(c["seed"])
+        random.seed(c["seed"])
+        model = RevGAN(conf)
+        for k, (n, net) in enumerate(model.networks.items()):
+            net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+        random.seed(c["seed"])
+        rec = []
+        for s_ in range(c["steps"]):
+            g = torch.Generator().manual_seed(c["seed"] * 100 + s_)
+            A, B = torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+            model.set_input({"A": A, "B": B})
+            model.optimize_parameters()
+            rec.append(_record(model))
+            model.update_learning_rate()
+            print(name, s_, rec[-1]["losses"], flush=True)
+        norms = {n: float(torch.sqrt(sum((p.detach() ** 2).sum() for p in net.parameters())))
+                 for n, net in model.networks.items()}
+        steps[name] = {"config": c, "steps": rec, "final_param_norms": norms,
+                       "network_names": list(model.networks.keys())}
+    (OUT / "revgan.json").write_text(json.dumps({"nets": nets, "steps": steps}, indent=1))
+
+
 def main():
     what = sys.argv[1]
     if what == "fullsize":
         fullsize()
+    elif what == "revgan":
+        revgan()
     elif what == "vnet2d":
         vnet2d()
     elif what == "advmodes":

@@ -335,6 +335,8 @@ class RefOps:
         v = torch.where(u > 0, u, u * slope[:C]) if slope is not None else u
         if res_mode == 2:
             v = v + r
+        elif res_mode == 3:
+            v = r - v
         out[..., out_co:out_co + C] = v.to(out.dtype)
 
     def pnorm_backward(self, g, y, mean_rstd, dy, *, C, slope=None, dslope=None, g2=None, res=None, res_mode=0,
@@ -343,6 +345,8 @@ class RefOps:
         gt = g[..., g_co:g_co + C].float()
         if g2 is not None:
             gt = gt + g2[..., g2_co:g2_co + C].float()
+        if res_mode == 3:
+            gt = -gt
         if slope is not None:
             gu = torch.where(u > 0, gt, gt * slope[:C])
             if dslope is not None:

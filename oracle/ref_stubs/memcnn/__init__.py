@@ -19,11 +19,24 @@ class AdditiveCoupling(nn.Module):
         y2 = x2 + self.Gm(y1)
         return torch.cat([y1, y2], dim=self.split_dim)
 
+    def inverse(self, y):
+        y1, y2 = torch.chunk(y, 2, dim=self.split_dim)
+        x2 = y2 - self.Gm(y1)
+        x1 = y1 - self.Fm(x2)
+        return torch.cat([x1, x2], dim=self.split_dim)
+
 
 class InvertibleModuleWrapper(nn.Module):
+    """keep_input / keep_input_inverse / disable only steer what memcnn frees and recomputes between forward and backward;
+    the values and gradients are those of the plain calls below"""
+
     def __init__(self, fn, keep_input=False, keep_input_inverse=False, disable=False, **kw):
         super().__init__()
         self._fn = fn
+        self.keep_input, self.keep_input_inverse, self.disable = keep_input, keep_input_inverse, disable
 
     def forward(self, x):
         return self._fn(x)
+
+    def inverse(self, y):
+        return self._fn.inverse(y)

@@ -227,6 +227,12 @@ class _AdditiveCoupling(nn.Module):
         y2 = x2 + self.Gm(y1)
         return torch.cat([y1, y2], dim=1)
 
+    def inverse(self, y):
+        y1, y2 = torch.chunk(y, 2, dim=1)
+        x2 = y2 - self.Gm(y1)
+        x1 = y1 - self.Fm(x2)
+        return torch.cat([x1, x2], dim=1)
+
 
 class _Wrapper(nn.Module):
     def __init__(self, fn):
@@ -235,6 +241,9 @@ class _Wrapper(nn.Module):
 
     def forward(self, x):
         return self._fn(x)
+
+    def inverse(self, y):
+        return self._fn.inverse(y)
 
 
 def _vconv(dims):
@@ -248,8 +257,8 @@ class _InvertibleBlock(nn.Module):
         mk = lambda: nn.Sequential(Conv(h, h, 5, padding=2), Norm(h), nn.PReLU(h))
         self.invertible_block = _Wrapper(_AdditiveCoupling(mk(), mk()))
 
-    def forward(self, x):
-        return self.invertible_block(x)
+    def forward(self, x, inverse=False):
+        return self.invertible_block.inverse(x) if inverse else self.invertible_block(x)
 
 
 class _InvertibleSequence(nn.Module):
@@ -257,8 +266,10 @@ class _InvertibleSequence(nn.Module):
         super().__init__()
         self.sequence = nn.Sequential(*[_InvertibleBlock(h, dims) for _ in range(n)])
 
-    def forward(self, x):
-        return self.sequence(x)
+    def forward(self, x, inverse=False):          # invertible.py:36-48
+        for block in (reversed(self.sequence) if inverse else self.sequence):
+            x = block(x, inverse)
+        return x
 
 
 class _VInput(nn.Module):
@@ -275,30 +286,34 @@ class _VInput(nn.Module):
 
 
 class _VDown(nn.Module):
-    def __init__(self, cin, n, dims=3):
+    def __init__(self, cin, n, dims=3, use_inverse=False):
         super().__init__()
         Conv, _, Norm = _vconv(dims)
         cout = 2 * cin
         self.down_conv_ab = nn.Sequential(Conv(cin, cout, 2, stride=2), Norm(cout), nn.PReLU(cout))
+        if use_inverse:
+            self.down_conv_ba = nn.Sequential(Conv(cin, cout, 2, stride=2), Norm(cout), nn.PReLU(cout))
         self.core = _InvertibleSequence(cout // 2, n, dims)
         self.relu = nn.PReLU(cout)
 
-    def forward(self, x):
-        down = self.down_conv_ab(x)
-        return self.relu(self.core(down) + down)
+    def forward(self, x, inverse=False):
+        down = (self.down_conv_ba if inverse else self.down_conv_ab)(x)
+        return self.relu(self.core(down, inverse) + down)
 
 
 class _VUp(nn.Module):
-    def __init__(self, cin, cout, n, dims=3):
+    def __init__(self, cin, cout, n, dims=3, use_inverse=False):
         super().__init__()
         _, ConvT, Norm = _vconv(dims)
         self.up_conv_ab = nn.Sequential(ConvT(cin, cout // 2, 2, stride=2), Norm(cout // 2), nn.PReLU(cout // 2))
+        if use_inverse:
+            self.up_conv_ba = nn.Sequential(ConvT(cin, cout // 2, 2, stride=2), Norm(cout // 2), nn.PReLU(cout // 2))
         self.core = _InvertibleSequence(cout // 2, n, dims)
         self.relu = nn.PReLU(cout)
 
-    def forward(self, x, skip):
-        xcat = torch.cat((self.up_conv_ab(x), skip), 1)
-        return self.relu(self.core(xcat) + xcat)
+    def forward(self, x, skip, inverse=False):
+        xcat = torch.cat(((self.up_conv_ba if inverse else self.up_conv_ab)(x), skip), 1)
+        return self.relu(self.core(xcat, inverse) + xcat)
 
 
 class _VOut(nn.Module):
@@ -315,33 +330,39 @@ class _VOut(nn.Module):
 
 
 class Vnet3D(nn.Module):
-    """use_inverse=False, use_memory_saving=False, is_separable=False (the brats yaml's settings)"""
+    """is_separable=False; use_inverse=False is the brats yaml's network, use_inverse=True adds the B -> A copies of the
+    non-invertible layers and forward(x, inverse=True) (vnet3d.py:55-150) — memory saving does not change values"""
     dims = 3
 
     def __init__(self, in_channels, out_channels, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
-                 up_blocks=(2, 2, 1, 1)):
+                 up_blocks=(2, 2, 1, 1), use_inverse=False):
         super().__init__()
-        c, dims = first_layer_channels, type(self).dims
+        c, dims, inv = first_layer_channels, type(self).dims, use_inverse
+        self.use_inverse = inv
         self.in_ab = _VInput(in_channels, c, dims)
+        if inv:
+            self.in_ba = _VInput(in_channels, c, dims)
         self.out_ab = _VOut(2 * c, out_channels, dims)
-        self.downs = nn.ModuleList([_VDown(c * 2 ** i, n, dims) for i, n in enumerate(down_blocks)])
+        if inv:
+            self.out_ba = _VOut(2 * c, out_channels, dims)
+        self.downs = nn.ModuleList([_VDown(c * 2 ** i, n, dims, inv) for i, n in enumerate(down_blocks)])
         self.encoder = nn.ModuleList([self.in_ab]).extend(self.downs)
         ucf = [2 * 2 ** i for i in reversed(range(len(down_blocks)))]
-        ups = [_VUp(c * ucf[0], c * ucf[0], up_blocks[0], dims)]
+        ups = [_VUp(c * ucf[0], c * ucf[0], up_blocks[0], dims, inv)]
         for i, n in enumerate(up_blocks[1:]):
-            ups.append(_VUp(c * ucf[i], c * ucf[i + 1], n, dims))
+            ups.append(_VUp(c * ucf[i], c * ucf[i + 1], n, dims, inv))
         self.ups = nn.ModuleList(ups)
 
-    def forward(self, x):
-        out1 = self.in_ab(x)
+    def forward(self, x, inverse=False):
+        out1 = (self.in_ba if inverse else self.in_ab)(x)
         downs = []
         for i, d in enumerate(self.downs):
-            downs.append(d(out1 if i == 0 else downs[-1]))
+            downs.append(d(out1 if i == 0 else downs[-1], inverse))
         rev = list(reversed(downs))
         out = rev[0]
         for i, up in enumerate(self.ups):
-            out = up(out, out1 if i == len(self.ups) - 1 else rev[i + 1])
-        return self.out_ab(out)
+            out = up(out, out1 if i == len(self.ups) - 1 else rev[i + 1], inverse)
+        return (self.out_ba if inverse else self.out_ab)(out)
 
 
 class Vnet2D(Vnet3D):
@@ -488,6 +509,75 @@ class CycleGANStep:
 
     def lrs(self):
         return {"lr_G": self.opt_G.param_groups[0]["lr"], "lr_D": self.opt_D.param_groups[0]["lr"]}
+
+
+class RevGANStep(CycleGANStep):
+    """fp32 restatement of RevGAN.optimize_parameters (ganslate/nn/gans/unpaired/revgan.py:89-206): CycleGAN's losses and
+    update order with ONE generator used in both directions — G(x) and G(x, inverse=True) — networks G, D_B, D_A (:50-51),
+    one Adam over G (:71-76). The generator-side adversarial terms are taken as written in the reference: D_B judges fake_A
+    and D_A judges fake_B (:187-193), unlike CycleGAN."""
+
+    def __init__(self, ch=1, ndf=64, n_layers=2, lr_G=2e-4, lr_D=2e-4, beta1=0.5, beta2=0.999, lambda_AB=10.0,
+                 lambda_BA=10.0, lambda_identity=0.0, proportion_ssim=0.0, pool_size=50, adv="lsgan", n_iters=100,
+                 n_iters_decay=100, metrics_ssim=False, metrics_D=True, seed=0, dims=3, vnet=None):
+        V, D = (Vnet2D, PatchGAN2D) if dims == 2 else (Vnet3D, PatchGAN3D)
+        kw = dict(first_layer_channels=vnet["first_layer_channels"])
+        if "down_blocks" in vnet:
+            kw.update(down_blocks=tuple(vnet["down_blocks"]), up_blocks=tuple(vnet["up_blocks"]))
+        self.nets = OrderedDict(G=V(ch, ch, use_inverse=True, **kw), D_B=D(ch, ndf, n_layers), D_A=D(ch, ndf, n_layers))
+        for k, (name, net) in enumerate(self.nets.items()):
+            net.load_state_dict(seeded_state_dict(net, seed + k))
+        self.hp = dict(lambda_AB=lambda_AB, lambda_BA=lambda_BA, lambda_identity=lambda_identity,
+                       proportion_ssim=proportion_ssim, adv=adv, metrics_ssim=metrics_ssim, metrics_D=metrics_D)
+        pD = list(self.nets["D_B"].parameters()) + list(self.nets["D_A"].parameters())
+        self.opt_G = torch.optim.Adam(self.nets["G"].parameters(), lr=lr_G, betas=(beta1, beta2))
+        self.opt_D = torch.optim.Adam(pD, lr=lr_D, betas=(beta1, beta2))
+        rule = lambda it: 1.0 - max(0, it + 1 - n_iters) / float(n_iters_decay + 1)
+        self.sched = [torch.optim.lr_scheduler.LambdaLR(o, rule) for o in (self.opt_G, self.opt_D)]
+        self.pool_A, self.pool_B = ImagePool(pool_size), ImagePool(pool_size)
+        self.visuals = {}
+
+    def step(self, real_A, real_B):
+        hp, nets = self.hp, self.nets
+        G = nets["G"]
+        losses, metrics = {}, {}
+        fake_B = G(real_A); rec_A = G(fake_B, inverse=True)
+        fake_A = G(real_B, inverse=True); rec_B = G(fake_A)
+        idt_A = idt_B = None
+        if hp["lambda_identity"] > 0:
+            idt_B = G(real_B); idt_A = G(real_A, inverse=True)
+        self.visuals = dict(real_A=real_A, real_B=real_B, fake_A=fake_A, fake_B=fake_B, rec_A=rec_A, rec_B=rec_B,
+                            idt_A=idt_A, idt_B=idt_B)
+        if hp["metrics_ssim"]:
+            with torch.no_grad():
+                metrics["ssim_A"] = 1 - ssim_distance(real_A, rec_A)
+                metrics["ssim_B"] = 1 - ssim_distance(real_B, rec_B)
+        self._set_D_grad(False)
+        self.opt_G.zero_grad(set_to_none=True)
+        losses["G_AB"] = adversarial_loss(nets["D_B"](fake_A), True, hp["adv"])      # revgan.py:187,191 (as written)
+        losses["G_BA"] = adversarial_loss(nets["D_A"](fake_B), True, hp["adv"])      # revgan.py:188,193
+        losses["cycle_A"] = hp["lambda_AB"] * cycle_loss(real_A, rec_A, hp["proportion_ssim"])
+        losses["cycle_B"] = hp["lambda_BA"] * cycle_loss(real_B, rec_B, hp["proportion_ssim"])
+        total = losses["cycle_A"] + losses["cycle_B"]
+        if hp["lambda_identity"] > 0:
+            losses["idt_B"] = hp["lambda_AB"] * (idt_B - real_B).abs().mean() * hp["lambda_identity"]
+            losses["idt_A"] = hp["lambda_BA"] * (idt_A - real_A).abs().mean() * hp["lambda_identity"]
+            total = total + losses["idt_B"] + losses["idt_A"]
+        (total + losses["G_AB"] + losses["G_BA"]).backward()
+        self.opt_G.step()
+        self._set_D_grad(True)
+        self.opt_D.zero_grad(set_to_none=True)
+        for name, real, fake, pool in (("D_B", real_B, fake_B, self.pool_B), ("D_A", real_A, fake_A, self.pool_A)):
+            fake = pool.query(fake)
+            pred_real = nets[name](real)
+            pred_fake = nets[name](fake.detach())
+            losses[name] = adversarial_loss(pred_real, True, hp["adv"]) + adversarial_loss(pred_fake, False, hp["adv"])
+            losses[name].backward()
+            if hp["metrics_D"]:
+                metrics[f"{name}_real"] = pred_real.detach().mean()
+                metrics[f"{name}_fake"] = pred_fake.detach().mean()
+        self.opt_D.step()
+        return {k: float(v.detach()) for k, v in losses.items()}, {k: float(v) for k, v in metrics.items()}
 
 
 class Pix2PixStep:

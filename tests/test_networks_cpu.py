@@ -134,10 +134,69 @@ def test_vnet2d_against_reference_golden_and_oracle(fp32_oracle_backend, case):
     _compare(native, torch_ref.Vnet2D(cin, cout, first, down, up), tuple(gold["x_shape"]), 46)
 
 
-def test_vnet2d_defaults_build_the_inverse_path_and_raise(fp32_oracle_backend):
+def _compare_both_directions(native, shadow, x_shape, seed, tol=2e-3):
+    """RevGAN's use of one network (revgan.py:120-130): y = G(x), r = G(y, inverse=True) and the gradients of a loss on
+    both — A -> B and B -> A layers, shared couplings and tail PReLUs each seeing two passes"""
+    sd = torch_ref.seeded_state_dict(shadow, seed)
+    shadow.load_state_dict(sd)
+    native.load_state_dict(sd)
+    assert set(native.state_dict().keys()) == set(shadow.state_dict().keys())
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(x_shape, generator=g) * 2 - 1
+    outs = []
+    for net in (shadow, native):
+        xi = x.clone().requires_grad_()
+        y = net(xi)
+        r = net(y, inverse=True)
+        outs.append((xi, y, r))
+    gy, gr = torch.randn(outs[0][1].shape, generator=g), torch.randn(outs[0][2].shape, generator=g)
+    for xi, y, r in outs:
+        ((y * gy).sum() + (r * gr).sum()).backward()
+    (xa, ya, ra), (xb, yb, rb) = outs
+    assert torch.allclose(ya, yb, atol=2e-5, rtol=1e-4) and torch.allclose(ra, rb, atol=5e-5, rtol=1e-4)
+    gscale = xa.grad.abs().max().item()
+    assert (xa.grad - xb.grad).abs().max().item() <= tol * gscale
+    grads = native.grads_state_dict()
+    normed = {nd.name for nd in native.nodes if nd.norm}
+    named = dict(shadow.named_parameters())
+    for n, p in named.items():
+        if n.startswith("encoder."):
+            continue
+        ref, got = p.grad, grads[n]
+        if n.endswith(".bias") and n[:-5] in normed:
+            continue
+        scale = ref.abs().max().item()
+        assert (ref - got).abs().max().item() <= tol * scale + 1e-7, (n, (ref - got).abs().max().item(), scale)
+
+
+def test_vnet3d_inverse_direction(fp32_oracle_backend):
+    """Vnet3D(use_inverse=True): forward(x, inverse=True) through in_ba / down_conv_ba / up_conv_ba / out_ba and the cores
+    run backwards (x2 = y2 - G(y1), x1 = y1 - F(x2)); vnet3d.py:107-150, invertible.py:21-48"""
+    from ganslate_amd.nn.generators import Vnet3D
+    native = Vnet3D(1, 1, "instance", 8, (1, 2), (2, 1), use_memory_saving=True, use_inverse=True)
+    _compare_both_directions(native, torch_ref.Vnet3D(1, 1, 8, (1, 2), (2, 1), use_inverse=True), (1, 1, 8, 12, 16), 47)
+
+
+def test_vnet2d_defaults_build_the_inverse_path(fp32_oracle_backend):
     from ganslate_amd.nn.generators import Vnet2D
-    with pytest.raises(NotImplementedError):
-        Vnet2D(1, 1, "instance")
+    native = Vnet2D(2, 2, "instance", 8)
+    assert native.use_inverse and "in_ba.conv1.weight" in native.state_dict()
+    # default block counts (14 couplings per direction): keys and both directions' outputs; the gradient comparison runs
+    # on a shallower pair — through 112 chained conv + InstanceNorm + PReLU stages, the deepest over 8 x 12 pixels, fp32
+    # reassociation alone (torch's own InstanceNorm backward included) reaches 1e-2 of the largest gradient
+    shadow = torch_ref.Vnet2D(2, 2, 8, use_inverse=True)
+    sd = torch_ref.seeded_state_dict(shadow, 48)
+    shadow.load_state_dict(sd)
+    native.load_state_dict(sd)
+    x = torch.rand(1, 2, 64, 96, generator=torch.Generator().manual_seed(48)) * 2 - 1
+    with torch.no_grad():
+        ya, yb = shadow(x), native(x)
+        assert torch.allclose(ya, yb, atol=2e-5, rtol=1e-4)
+        assert torch.allclose(shadow(ya, inverse=True), native(yb, inverse=True), atol=1e-4, rtol=1e-4)
+    _compare_both_directions(Vnet2D(2, 2, "instance", 8, (1, 2), (2, 1)),
+                             torch_ref.Vnet2D(2, 2, 8, (1, 2), (2, 1), use_inverse=True), (1, 2, 32, 48), 49)
+    with pytest.raises(ValueError):
+        Vnet2D(2, 2, "instance", 8, use_memory_saving=False, use_inverse=False)(torch.zeros(1, 2, 32, 32), inverse=True)
 
 
 def test_frozen_network_gets_no_weight_gradients(fp32_oracle_backend):

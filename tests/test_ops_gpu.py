@@ -416,7 +416,7 @@ def test_image_boundary_3d(hip_ops):
 
 
 @pytest.mark.parametrize("norm", [True, False])
-@pytest.mark.parametrize("res_mode,res_mod", [(0, 0), (1, 0), (2, 0), (1, 2)])
+@pytest.mark.parametrize("res_mode,res_mod", [(0, 0), (1, 0), (2, 0), (3, 0), (1, 2)])
 def test_pnorm_forward_backward(hip_ops, norm, res_mode, res_mod):
     """IN3d -> [+res] -> PReLU(C) -> [+res] on channel slices, slope gradient, gres (vnet3d.py:155-267)"""
     N, sp, C, Cb = 2, (6, 7, 9), 16, 48           # operands are 16-channel slices of 48-channel buffers
