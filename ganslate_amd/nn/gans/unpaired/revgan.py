@@ -5,9 +5,9 @@ Ouderaa & Worrall, CVPR 2019): CycleGAN's losses with ONE partially-invertible g
 one Adam over G.
 
 Kept as the reference has it: the generator-side adversarial terms pair D_B with fake_A and D_A with fake_B
-(revgan.py:187-193; CycleGAN pairs them the other way round). `use_memory_saving` is accepted and has no effect on the
-values: memcnn's wrapper frees a coupling's input after the forward pass and recomputes it from the output in backward;
-here the activations stay in HBM. Launch by launch on one stream (four to six passes through the same network: nothing to
+(revgan.py:187-193; CycleGAN pairs them the other way round). The generator's `use_memory_saving` is memcnn's
+activation recompute, implemented by the V-Net executor (nn/generators/vnet/vnet3d.py): coupling inputs are rebuilt from
+outputs during backward instead of being kept. Launch by launch on one stream (four to six passes through the same network: nothing to
 overlap, and the generator's gradient buffer is shared by all of them)."""
 from dataclasses import dataclass, field
 

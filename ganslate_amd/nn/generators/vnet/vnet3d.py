@@ -19,9 +19,14 @@ master buffer behind the conv weights (`Extra`), their gradients come out of the
 (in_ba, out_ba, down_conv_ba, up_conv_ba: vnet3d.py:60-69,179-181,213-214) and `forward(x, inverse=True)`: the same walk
 with those layers and every core run backwards, x2 = y2 - G(y1), x1 = y1 - F(x2) per coupling in reversed block order
 (memcnn AdditiveCoupling.inverse through invertible.py:21-24,36-48) — gs_pnorm_forward's res_mode 3; the tail PReLUs and
-the couplings' weights are shared by both directions. `use_memory_saving` only changes what memcnn keeps alive between
-forward and backward (it recomputes inputs from outputs); the values are the same, and with 288 GB of HBM the activations
-are simply kept."""
+the couplings' weights are shared by both directions.
+
+`use_memory_saving=True` is memcnn's activation recompute (InvertibleModuleWrapper(keep_input=False), the point of the
+RevGAN paper): the forward pass keeps only each core's OUTPUT; the backward pass walks a core from its last coupling to its
+first and rebuilds every coupling's input from its output with the inverse equations — which produces exactly the conv
+outputs F(x2), G(y1) the gradient needs — before differentiating it. Per core the live activations drop from
+O(couplings) to O(1) at the price of one extra evaluation of F and G per coupling (+1/3 of the core's work). The rebuilt
+input equals the original up to storage rounding (bf16 here, fp32 in memcnn)."""
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -67,6 +72,7 @@ class Vnet3D(NativeNet):
                  up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True, is_separable=False):
         require_instance_norm(norm_type)
         self.use_inverse = bool(use_inverse)
+        self.use_memory_saving = bool(use_memory_saving)
         if is_separable:
             raise NotImplementedError("separable convolutions are not implemented")
         if first_layer_channels % in_channels:
@@ -227,30 +233,42 @@ class Vnet3D(NativeNet):
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def _couplings_forward(self, s, blk, X):
-        """X [.., 2h] -> core(X); saves what the backward pass needs"""
-        ops, h = self.ops, blk.C // 2
+        """X [.., 2h] -> core(X); saves what the backward pass needs (nothing per coupling with memory saving)"""
         saved = []
-        for nf, sf, ng, sg in blk.couplings:
-            Y = self._new(s.N, X.shape[1:-1], blk.C)
-            ya, mra = self._conv(s, nf, X, in_co=h)                         # F reads x2
-            ops.pnorm_forward(ya, mra, Y, C=h, slope=self._slope(sf), res=X, res_mode=2, res_co=0, out_co=0)
-            yb, mrb = self._conv(s, ng, Y, in_co=0)                         # G reads y1
-            ops.pnorm_forward(yb, mrb, Y, C=h, slope=self._slope(sg), res=X, res_mode=2, res_co=h, out_co=h)
-            saved.append((X, Y, ya, mra, yb, mrb))
+        for cp in blk.couplings:
+            Y, ya, mra, yb, mrb = self._coupling_fwd_one(s, blk, cp, X)
+            saved.append(None if s.recompute else (X, Y, ya, mra, yb, mrb))
             X = Y
         return X, saved
 
+    def _coupling_fwd_one(self, s, blk, cp, X):
+        """y1 = x1 + F(x2), y2 = x2 + G(y1); returns Y and the raw conv outputs (+ statistics) of F and G"""
+        ops, h = self.ops, blk.C // 2
+        nf, sf, ng, sg = cp
+        Y = self._new(s.N, X.shape[1:-1], blk.C)
+        ya, mra = self._conv(s, nf, X, in_co=h)                             # F reads x2
+        ops.pnorm_forward(ya, mra, Y, C=h, slope=self._slope(sf), res=X, res_mode=2, res_co=0, out_co=0)
+        yb, mrb = self._conv(s, ng, Y, in_co=0)                             # G reads y1
+        ops.pnorm_forward(yb, mrb, Y, C=h, slope=self._slope(sg), res=X, res_mode=2, res_co=h, out_co=h)
+        return Y, ya, mra, yb, mrb
+
+    def _coupling_inv_one(self, s, blk, cp, Y):
+        """x2 = y2 - G(y1), x1 = y1 - F(x2); returns X and the raw conv outputs (+ statistics) of F and G"""
+        ops, h = self.ops, blk.C // 2
+        nf, sf, ng, sg = cp
+        X = self._new(s.N, Y.shape[1:-1], blk.C)
+        yb, mrb = self._conv(s, ng, Y, in_co=0)                             # G reads y1
+        ops.pnorm_forward(yb, mrb, X, C=h, slope=self._slope(sg), res=Y, res_mode=3, res_co=h, out_co=h)
+        ya, mra = self._conv(s, nf, X, in_co=h)                             # F reads x2
+        ops.pnorm_forward(ya, mra, X, C=h, slope=self._slope(sf), res=Y, res_mode=3, res_co=0, out_co=0)
+        return X, ya, mra, yb, mrb
+
     def _couplings_inverse(self, s, blk, Y):
         """Y [.., 2h] -> core.inverse(Y): couplings in reversed order, x2 = y2 - G(y1), x1 = y1 - F(x2)"""
-        ops, h = self.ops, blk.C // 2
         saved = []
-        for nf, sf, ng, sg in reversed(blk.couplings):
-            X = self._new(s.N, Y.shape[1:-1], blk.C)
-            yb, mrb = self._conv(s, ng, Y, in_co=0)                         # G reads y1
-            ops.pnorm_forward(yb, mrb, X, C=h, slope=self._slope(sg), res=Y, res_mode=3, res_co=h, out_co=h)
-            ya, mra = self._conv(s, nf, X, in_co=h)                         # F reads x2
-            ops.pnorm_forward(ya, mra, X, C=h, slope=self._slope(sf), res=Y, res_mode=3, res_co=0, out_co=0)
-            saved.append((X, Y, ya, mra, yb, mrb))
+        for cp in reversed(blk.couplings):
+            X, ya, mra, yb, mrb = self._coupling_inv_one(s, blk, cp, Y)
+            saved.append(None if s.recompute else (X, Y, ya, mra, yb, mrb))
             Y = X
         return Y, saved
 
@@ -273,6 +291,7 @@ class Vnet3D(NativeNet):
         N, sizes = x.shape[0], tuple(x.shape[2:])
         s = _Saved()
         inv = s.inverse = bool(getattr(self, "_next_inverse", False))
+        s.recompute = bool(save and self.use_memory_saving)
         n_in, s_in = (self.n_in_ba, self.s_in_ba) if inv else (self.n_in, self.s_in)
         n_o1, s_o1, n_o2 = (self.n_o1_ba, self.s_o1_ba, self.n_o2_ba) if inv else (self.n_o1, self.s_o1, self.n_o2)
         bconv = (lambda b: (b.conv_ba, b.conv_slope_ba)) if inv else (lambda b: (b.conv, b.conv_slope))
@@ -362,10 +381,18 @@ class Vnet3D(NativeNet):
         ops.pnorm_backward(g, rec.Xn, None, gu, C=blk.C, slope=self._slope(blk.tail_slope), dslope=dsl(blk.tail_slope),
                            g2=g2, g2_co=g2_co, res=rec.D0, res_mode=1)
         G = gu.clone()                                   # becomes the gradient w.r.t. core's input, in place
+        cur = rec.Xn                                     # memory saving: the core's output, walked back coupling by coupling
         if s.inverse:
             # rec.coup was recorded over reversed(blk.couplings): walk it back. Per coupling x1 = y1 - F(x2), x2 = y2 - G(y1):
             # G holds the gradient w.r.t. [x1 | x2] and ends as the gradient w.r.t. [y1 | y2]
-            for (nf, sf, ng, sg), (X, Y, ya, mra, yb, mrb) in zip(blk.couplings, reversed(rec.coup)):
+            for cp, kept in zip(blk.couplings, reversed(rec.coup)):
+                nf, sf, ng, sg = cp
+                if kept is None:                         # rebuild [y1 | y2] from [x1 | x2] with the forward equations
+                    X = cur
+                    Y, ya, mra, yb, mrb = self._coupling_fwd_one(s, blk, cp, X)
+                    cur = Y
+                else:
+                    X, Y, ya, mra, yb, mrb = kept
                 dya = torch.empty_like(ya)
                 ops.pnorm_backward(G, ya, mra, dya, C=h, slope=self._slope(sf), dslope=dsl(sf), g_co=0, res_mode=3,
                                    bias_grad=self._bias_slice(nf, want_w))
@@ -380,7 +407,14 @@ class Vnet3D(NativeNet):
                 self._dgrad(s, ng, dyb, out=G, out_co=0, accumulate=True)      # y1 also fed G
             ops.add_views(G, gu, blk.C, accumulate=True)     # out = core.inverse(D0) + D0
             return G
-        for (nf, sf, ng, sg), (X, Y, ya, mra, yb, mrb) in zip(reversed(blk.couplings), reversed(rec.coup)):
+        for cp, kept in zip(reversed(blk.couplings), reversed(rec.coup)):
+            nf, sf, ng, sg = cp
+            if kept is None:                             # rebuild [x1 | x2] from [y1 | y2] with the inverse equations
+                Y = cur
+                X, ya, mra, yb, mrb = self._coupling_inv_one(s, blk, cp, Y)
+                cur = X
+            else:
+                X, Y, ya, mra, yb, mrb = kept
             # y2 = x2 + G(y1): gradient of G's conv output from the y2 half, its data gradient joins the y1 half
             dyb = torch.empty_like(yb)
             ops.pnorm_backward(G, yb, mrb, dyb, C=h, slope=self._slope(sg), dslope=dsl(sg), g_co=h,

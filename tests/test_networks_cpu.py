@@ -235,3 +235,31 @@ def test_unet2d_dropout_statistics(fp32_oracle_backend):
     with torch.no_grad():
         t1, t2 = net(x), net(x)
     assert not torch.equal(t1, t2) and (t1 - e1).abs().max() > 1e-4
+
+
+def test_vnet_memory_saving_recomputes_the_same_gradients(fp32_oracle_backend):
+    """use_memory_saving=True (memcnn's keep_input=False): coupling inputs are rebuilt from outputs in the backward pass;
+    in fp32 that changes the gradients by rounding only (both directions, shared couplings)"""
+    from ganslate_amd.nn.generators import Vnet3D
+    shadow = torch_ref.Vnet3D(1, 1, 8, (2, 3), (3, 2), use_inverse=True)
+    sd = torch_ref.seeded_state_dict(shadow, 50)
+    g = torch.Generator().manual_seed(50)
+    x = torch.rand(1, 1, 8, 12, 16, generator=g) * 2 - 1
+    gy, gr = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+    res = []
+    for saving in (False, True):
+        net = Vnet3D(1, 1, "instance", 8, (2, 3), (3, 2), use_memory_saving=saving, use_inverse=True)
+        net.load_state_dict(sd)
+        xi = x.clone().requires_grad_()
+        y = net(xi)
+        r = net(y, inverse=True)
+        ((y * gy).sum() + (r * gr).sum()).backward()
+        res.append((y.detach(), r.detach(), xi.grad, net.grads_state_dict()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])      # the forward pass is the same
+    assert (res[0][2] - res[1][2]).abs().max().item() <= 1e-4 * res[0][2].abs().max().item()
+    normed = {nd.name for nd in net.nodes if nd.norm}
+    for k, a in res[0][3].items():
+        if k.endswith(".bias") and k[:-5] in normed:
+            continue                                   # exactly-zero true gradient: rounding noise on both sides
+        b = res[1][3][k]
+        assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item() + 1e-8, k

@@ -104,3 +104,41 @@ def test_revgan_training_step_matches_reference_golden(hip_ops, name, conf_name)
         model.update_learning_rate()
     out = model.infer(A.to(hip_ops.device), "BA")
     assert out.shape == A.shape and bool(torch.isfinite(out).all())
+
+
+def test_memory_saving_frees_the_couplings_activations(hip_ops):
+    """use_memory_saving on the GPU: the live activation memory between forward and backward no longer grows with the number
+    of couplings (measured through the caching allocator's peak), and the gradients stay those of the kept-activation run
+    up to the bf16 rounding of the rebuilt inputs"""
+    from ganslate_amd.nn.generators import Vnet3D
+    shadow = torch_ref.Vnet3D(1, 1, 16, (4, 4), (4, 4), use_inverse=True)
+    sd = torch_ref.seeded_state_dict(shadow, 83)
+    g = torch.Generator().manual_seed(83)
+    x = torch.rand(1, 1, 32, 64, 64, generator=g) * 2 - 1
+    gy = torch.randn(x.shape, generator=g)
+    res = {}
+    for saving in (False, True):
+        net = Vnet3D(1, 1, "instance", 16, (4, 4), (4, 4), use_memory_saving=saving, use_inverse=True)
+        net.load_state_dict(sd)
+        xi = x.clone().to(hip_ops.device).requires_grad_()
+        net(xi).sum().backward()                       # warm-up: packs, gradient buffer, workspaces
+        xi.grad = None
+        net.master.grad.zero_()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y = net(xi)
+        held = torch.cuda.memory_allocated() - base    # what the recorded pass keeps alive for backward
+        y.backward(gy.to(hip_ops.device))
+        torch.cuda.synchronize()
+        res[saving] = (held, y.detach().float().cpu(), xi.grad.cpu(),
+                       {k: v.float().cpu() for k, v in net.grads_state_dict().items()})
+        del net, xi, y
+    print(f"\nactivations held between forward and backward: {res[False][0] / 2**20:.0f} MiB kept, "
+          f"{res[True][0] / 2**20:.0f} MiB with memory saving")
+    assert res[True][0] < 0.6 * res[False][0]
+    assert torch.equal(res[True][1], res[False][1])
+    assert rel_l2(res[True][2], res[False][2]) <= 0.15 and cosine(res[True][2], res[False][2]) >= 0.98
+    for k, a in res[False][3].items():
+        if a.dim() > 1 and float(a.abs().max()) > 0:         # (the *_ba layers saw no pass here)
+            assert cosine(res[True][3][k], a) >= 0.97, (k, cosine(res[True][3][k], a))
