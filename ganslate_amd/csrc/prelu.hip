@@ -406,3 +406,68 @@ extern "C" int gs_repeat_backward(const void* g, int32_t g_cs, int32_t g_co, flo
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- statistics of a channel slice of an activation tensor -----------------------------------------------------------
+// Piresnet3D's coupling function starts with an InstanceNorm of its INPUT half (piresnet3d.py:104-108), a tensor that no
+// conv epilogue has seen: per (n, pixel chunk) partial sums [N][slots][2][C] in the layout gs_inorm_finalize reads.
+// 256 threads = COLS 8-channel columns x 256/COLS pixel rows, 16-B loads.
+template <int COLS>
+__global__ __launch_bounds__(256) void slice_stats_kernel(const unsigned short* x, unsigned pixels, int cs, int co, int C8,
+                                                          int C, float* partial, int pix_per_block, int slots) {
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[ROWS][COLS][17];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int col = tid % COLS, row = tid / COLS;
+  const int c8 = blockIdx.z * COLS + col;
+  const unsigned p0 = blockIdx.x * pix_per_block;
+  const unsigned p1 = min(pixels, p0 + (unsigned)pix_per_block);
+  float a[8], q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = q[k] = 0.f;
+  if (c8 < C8) {
+    for (unsigned px = p0 + row; px < p1; px += ROWS) {
+      float v[8];
+      pn_view8(v, x, (size_t)n * pixels + px, cs, co, c8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] += v[k]; q[k] += v[k] * v[k]; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[row][col][k] = a[k]; red[row][col][8 + k] = q[k]; }
+  __syncthreads();
+  for (int o = tid; o < COLS * 16; o += 256) {
+    const int cc = o / 16, k = o - cc * 16;
+    const int ch8 = blockIdx.z * COLS + cc;
+    if (ch8 < C8) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) sum += red[r][cc][k];
+      partial[(((size_t)n * slots + blockIdx.x) * 2 + (k >> 3)) * C + ch8 * 8 + (k & 7)] = sum;
+    }
+  }
+}
+
+extern "C" int32_t gs_slice_stats_slots(int64_t pixels) {
+  long long ppb = (pixels + 255) / 256;
+  if (ppb < 256) ppb = 256;
+  return (int32_t)((pixels + ppb - 1) / ppb);
+}
+extern "C" int gs_slice_stats(const void* x, int32_t N, int64_t pixels, int32_t cs, int32_t co, int32_t C, float* partial,
+                              void* stream) {
+  GS_REQUIRE(x && partial && N > 0 && pixels > 0 && pixels < (1LL << 31) && C > 0 && (C & 7) == 0 && (cs & 7) == 0 &&
+                 (co & 7) == 0,
+             "gs_slice_stats: bad argument (C, cs, co multiples of 8)");
+  const int slots = gs_slice_stats_slots(pixels);
+  const int ppb = (int)((pixels + slots - 1) / slots);
+  const int C8 = C / 8;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned short* xs = static_cast<const unsigned short*>(x);
+  if (C8 >= 8)
+    hipLaunchKernelGGL((slice_stats_kernel<8>), dim3(slots, N, (C8 + 7) / 8), dim3(256), 0, st, xs, (unsigned)pixels, cs, co,
+                       C8, C, partial, ppb, slots);
+  else
+    hipLaunchKernelGGL((slice_stats_kernel<1>), dim3(slots, N, C8), dim3(256), 0, st, xs, (unsigned)pixels, cs, co, C8, C,
+                       partial, ppb, slots);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -127,6 +127,8 @@ _PROTOS = {
                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_shiftadd_to_image_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_slice_stats_slots": (C.c_int32, [C.c_int64]),
+    "gs_slice_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_u8_resample_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_void_p]),
     "gs_u8_resample_v_crop_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -387,6 +387,16 @@ class HipOps:
                                            _ptr(slope), _ptr(dy), _ptr(gres), _ptr(dslope), _ptr(bias_grad),
                                            _ptr(scratch), _stream()), "gs_pnorm_backward")
 
+    def slice_stats(self, x, co, C, mean_rstd, eps=1e-5):
+        """mean / rstd [N][2][C] of channels [co, co + C) of x (any NHWC / NDHWC activation tensor): gs_slice_stats +
+        gs_inorm_finalize"""
+        N = x.shape[0]
+        pixels = x.numel() // (N * x.shape[-1])
+        slots = int(self.lib.gs_slice_stats_slots(pixels))
+        part = torch.empty(N * slots * 2 * C, dtype=torch.float32, device=x.device)
+        L.check(self.lib.gs_slice_stats(_ptr(x), N, pixels, x.shape[-1], co, C, _ptr(part), _stream()), "gs_slice_stats")
+        self.inorm_finalize(part, N, slots, C, pixels, mean_rstd, eps)
+
     def add_views(self, dst, src, C, dst_co=0, src_co=0, accumulate=True):
         pixels = dst.numel() // dst.shape[-1]
         L.check(self.lib.gs_add_views(_ptr(dst), dst.shape[-1], dst_co, _ptr(src), src.shape[-1], src_co, pixels, C,

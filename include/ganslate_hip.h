@@ -287,6 +287,13 @@ int gs_shiftadd_to_image(const void* z, const float* bias, float* img, int32_t N
 int gs_shiftadd_to_image_backward(const float* g_img, const float* out_img, void* gz, int32_t N, int32_t Co,
                                   int64_t rows, int32_t W, int32_t Pp, int32_t k, int32_t act_kind, void* stream);
 
+/* Partial InstanceNorm statistics of a channel slice [co, co + C) of an activation tensor with channel stride cs — for a
+ * norm whose input is not a conv output (the pre-norm of Piresnet3D's coupling function, piresnet3d.py:104-108):
+ * partial [N][slots][2][C] with slots = gs_slice_stats_slots(pixels), finalised by gs_inorm_finalize. */
+int32_t gs_slice_stats_slots(int64_t pixels);
+int gs_slice_stats(const void* x, int32_t N, int64_t pixels, int32_t cs, int32_t co, int32_t C, float* partial,
+                   void* stream);
+
 /* ---- device-side image preprocessing --------------------------------------------- */
 /* What ganslate/data/utils/transforms.py:9-61 composes on the host from torchvision / PIL for the image-folder datasets
  * (unpaired_image_dataset.py:31-62, paired_image_dataset.py): Resize(load_size, Image.BICUBIC), RandomCrop(final_size),

@@ -169,6 +169,9 @@ REVGAN_CASES = {
     "rev3d_16x32x32": dict(size=[16, 32, 32], batch=1, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
                            lambda_identity=0.0, proportion_ssim=0.0, d_layers=2, seed=55, dims=3,
                            vnet=dict(first_layer_channels=8, down_blocks=[1, 2], up_blocks=[2, 1])),
+    "rev3d_piresnet": dict(size=[16, 32, 32], batch=1, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
+                           lambda_identity=0.0, proportion_ssim=0.0, d_layers=2, seed=57, dims=3,
+                           piresnet=dict(first_layer_channels=16, depth=2)),
     "rev2d_64x64_idt": dict(size=[64, 64], batch=2, steps=3, n_iters=100, n_iters_decay=100, pool_size=50,
                             lambda_identity=0.5, proportion_ssim=0.0, d_layers=2, seed=56, dims=2,
                             vnet=dict(first_layer_channels=8)),
@@ -205,7 +208,9 @@ def revgan():
     from ganslate.nn.generators.vnet.vnet3d import Vnet3D
     from oracle.torch_ref import seeded_state_dict
     torch.set_num_threads(8)
+    from ganslate.nn.generators.resnet.piresnet3d import Piresnet3D
     nets = {
+        "piresnet3d": _both_directions_case(Piresnet3D(1, 1, "instance", 3, 16, True, True), (1, 1, 8, 12, 16), 71),
         "vnet3d_inverse": _both_directions_case(Vnet3D(1, 1, "instance", 8, (1, 2), (2, 1), True, True, False),
                                                 (1, 1, 8, 12, 16), 69),
         "vnet2d_inverse_default_blocks": _both_directions_case(Vnet2D(2, 2, "instance", 8), (1, 2, 64, 96), 70),
@@ -216,7 +221,16 @@ def revgan():
         conf.train.metrics["ssim"] = False
         gan = conf.train.gan
         gan["_target_"] = "ganslate.nn.gans.unpaired.RevGAN"
-        if c["dims"] == 3:
+        if "piresnet" in c:
+            gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Piresnet3D", "use_memory_saving": True,
+                                           "use_inverse": True, "depth": c["piresnet"]["depth"],
+                                           "first_layer_channels": c["piresnet"]["first_layer_channels"],
+                                           "in_out_channels": {"AB": [1, 1]}})
+            gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
+                                               "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                               "in_channels": {"B": 1, "A": 1}})
+            shape = (c["batch"], 1, *c["size"])
+        elif c["dims"] == 3:
             gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet3D", "use_memory_saving": True,
                                            "use_inverse": True, "is_separable": False,
                                            "first_layer_channels": c["vnet"]["first_layer_channels"],

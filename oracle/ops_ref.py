@@ -366,6 +366,15 @@ class RefOps:
         if bias_grad is not None:
             bias_grad[:C] += d.reshape(-1, C).sum(0)
 
+    def slice_stats(self, x, co, C, mean_rstd, eps=1e-5):
+        N = x.shape[0]
+        v = x[..., co:co + C].double().reshape(N, -1, C)
+        mean = v.mean(1)
+        var = ((v * v).mean(1) - mean * mean).clamp_min(0)
+        mr = mean_rstd.view(N, 2, C)
+        mr[:, 0] = mean.float()
+        mr[:, 1] = (1.0 / torch.sqrt(var + eps)).float()
+
     def add_views(self, dst, src, C, dst_co=0, src_co=0, accumulate=True):
         v = src[..., src_co:src_co + C].float()
         if accumulate:

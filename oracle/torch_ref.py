@@ -371,6 +371,50 @@ class Vnet2D(Vnet3D):
     dims = 2
 
 
+class _PiInvBlock(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        mk = lambda: nn.Sequential(nn.InstanceNorm3d(h), nn.ReplicationPad3d(1), nn.Conv3d(h, h, 3), nn.InstanceNorm3d(h),
+                                   nn.ReLU())
+        self.invertible_block = _Wrapper(_AdditiveCoupling(mk(), mk()))
+
+    def forward(self, x, inverse=False):
+        return self.invertible_block.inverse(x) if inverse else self.invertible_block(x)
+
+
+class _PiSequence(nn.Module):
+    def __init__(self, h, n):
+        super().__init__()
+        self.sequence = nn.Sequential(*[_PiInvBlock(h) for _ in range(n)])
+
+    def forward(self, x, inverse=False):
+        for block in (reversed(self.sequence) if inverse else self.sequence):
+            x = block(x, inverse)
+        return x
+
+
+class Piresnet3D(nn.Module):
+    """ganslate/nn/generators/resnet/piresnet3d.py:29-108 (memory saving does not change values)"""
+
+    def __init__(self, in_channels, out_channels, depth, first_layer_channels=64, use_inverse=True):
+        super().__init__()
+        c = first_layer_channels
+        down = lambda: nn.Sequential(nn.ReplicationPad3d(2), nn.Conv3d(in_channels, c, 5), nn.InstanceNorm3d(c), nn.ReLU(),
+                                     nn.Conv3d(c, 2 * c, 3, stride=2, padding=1), nn.InstanceNorm3d(2 * c), nn.ReLU())
+        up = lambda: nn.Sequential(nn.ConvTranspose3d(2 * c, c, 3, stride=2, padding=1, output_padding=1),
+                                   nn.InstanceNorm3d(c), nn.ReLU(), nn.ReplicationPad3d(2), nn.Conv3d(c, out_channels, 5),
+                                   nn.Tanh())
+        self.use_inverse = use_inverse
+        self.downconv_ab, self.upconv_ab = down(), up()
+        if use_inverse:
+            self.downconv_ba, self.upconv_ba = down(), up()
+        self.core = _PiSequence(c, depth)
+
+    def forward(self, x, inverse=False):
+        d, u = (self.downconv_ba, self.upconv_ba) if inverse else (self.downconv_ab, self.upconv_ab)
+        return u(self.core(d(x), inverse))
+
+
 def seeded_state_dict(module: nn.Module, seed: int, gain=0.02, bias_gain=0.01):
     """Deterministic weights independent of module construction order / torch's default init RNG use:
     every tensor of the state_dict (in key order, aliases share one draw) ~ N(0, gain) (biases N(0, bias_gain))
@@ -519,12 +563,16 @@ class RevGANStep(CycleGANStep):
 
     def __init__(self, ch=1, ndf=64, n_layers=2, lr_G=2e-4, lr_D=2e-4, beta1=0.5, beta2=0.999, lambda_AB=10.0,
                  lambda_BA=10.0, lambda_identity=0.0, proportion_ssim=0.0, pool_size=50, adv="lsgan", n_iters=100,
-                 n_iters_decay=100, metrics_ssim=False, metrics_D=True, seed=0, dims=3, vnet=None):
+                 n_iters_decay=100, metrics_ssim=False, metrics_D=True, seed=0, dims=3, vnet=None, piresnet=None):
         V, D = (Vnet2D, PatchGAN2D) if dims == 2 else (Vnet3D, PatchGAN3D)
-        kw = dict(first_layer_channels=vnet["first_layer_channels"])
-        if "down_blocks" in vnet:
-            kw.update(down_blocks=tuple(vnet["down_blocks"]), up_blocks=tuple(vnet["up_blocks"]))
-        self.nets = OrderedDict(G=V(ch, ch, use_inverse=True, **kw), D_B=D(ch, ndf, n_layers), D_A=D(ch, ndf, n_layers))
+        if piresnet is not None:
+            G = Piresnet3D(ch, ch, piresnet["depth"], piresnet["first_layer_channels"], use_inverse=True)
+        else:
+            kw = dict(first_layer_channels=vnet["first_layer_channels"])
+            if "down_blocks" in vnet:
+                kw.update(down_blocks=tuple(vnet["down_blocks"]), up_blocks=tuple(vnet["up_blocks"]))
+            G = V(ch, ch, use_inverse=True, **kw)
+        self.nets = OrderedDict(G=G, D_B=D(ch, ndf, n_layers), D_A=D(ch, ndf, n_layers))
         for k, (name, net) in enumerate(self.nets.items()):
             net.load_state_dict(seeded_state_dict(net, seed + k))
         self.hp = dict(lambda_AB=lambda_AB, lambda_BA=lambda_BA, lambda_identity=lambda_identity,

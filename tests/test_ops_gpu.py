@@ -454,6 +454,19 @@ def test_pnorm_forward_backward(hip_ops, norm, res_mode, res_mod):
         assert outs[1][4].abs().max().item() <= 1e-2 * outs[0][1].float().abs().sum().item() / C
 
 
+@pytest.mark.parametrize("shape,co,C", [((2, 6, 7, 9, 48), 16, 16), ((1, 16, 24, 24, 16), 0, 16), ((2, 40, 56, 128), 64, 64)])
+def test_slice_stats(hip_ops, shape, co, C):
+    """mean / rstd of a channel slice of an activation tensor (the pre-norm of Piresnet3D's coupling function,
+    piresnet3d.py:104-108): gs_slice_stats + gs_inorm_finalize against the double-precision oracle"""
+    x = (torch.randn(shape, generator=torch.Generator().manual_seed(23)) * 1.7 + 0.4).to(torch.bfloat16)
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        mr = torch.empty(shape[0] * 2 * C, dtype=torch.float32, device=dev)
+        ops.slice_stats(x.to(dev), co, C, mr)
+        outs.append(mr.cpu())
+    close_f32(outs[1], outs[0], "slice mean / rstd", rel=1e-4)
+
+
 def test_gconv_accumulate_into_slice(hip_ops):
     """data gradient accumulated into one half of a coupling block's gradient buffer (invertible.py:8-48)"""
     spec, N, sizes = ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, (8, 8, 12)

@@ -27,8 +27,9 @@ def _eight_threads():
 @pytest.mark.parametrize("name", list(GOLD["nets"]))
 def test_inverse_direction_of_the_oracle_networks(name):
     gold = GOLD["nets"][name]
-    net = torch_ref.Vnet3D(1, 1, 8, (1, 2), (2, 1), use_inverse=True) if name == "vnet3d_inverse" else \
-        torch_ref.Vnet2D(2, 2, 8, use_inverse=True)
+    net = {"vnet3d_inverse": lambda: torch_ref.Vnet3D(1, 1, 8, (1, 2), (2, 1), use_inverse=True),
+           "vnet2d_inverse_default_blocks": lambda: torch_ref.Vnet2D(2, 2, 8, use_inverse=True),
+           "piresnet3d": lambda: torch_ref.Piresnet3D(1, 1, 3, 16, use_inverse=True)}[name]()
     assert list(net.state_dict().keys()) == gold["state_dict_keys"]
     assert sum(p.numel() for p in net.parameters()) == gold["n_params"]
     net.load_state_dict(torch_ref.seeded_state_dict(net, gold["seed"]))
@@ -54,7 +55,7 @@ def test_revgan_step_restatement_matches_reference(name):
     model = torch_ref.RevGANStep(ch=1 if c["dims"] == 3 else 2, n_layers=c["d_layers"], n_iters=c["n_iters"],
                                  n_iters_decay=c["n_iters_decay"], pool_size=c["pool_size"],
                                  lambda_identity=c["lambda_identity"], proportion_ssim=c["proportion_ssim"],
-                                 seed=c["seed"], dims=c["dims"], vnet=c["vnet"])
+                                 seed=c["seed"], dims=c["dims"], vnet=c.get("vnet"), piresnet=c.get("piresnet"))
     assert list(model.nets) == gold["network_names"]
     random.seed(c["seed"])
     ch = 1 if c["dims"] == 3 else 2
@@ -81,10 +82,14 @@ def _product_revgan(c, conf_name, extra=()):
     model = build_gan(conf)
     ch = 1 if c["dims"] == 3 else 2
     V, D = (torch_ref.Vnet3D, torch_ref.PatchGAN3D) if c["dims"] == 3 else (torch_ref.Vnet2D, torch_ref.PatchGAN2D)
-    kw = dict(first_layer_channels=c["vnet"]["first_layer_channels"])
-    if "down_blocks" in c["vnet"]:
-        kw.update(down_blocks=tuple(c["vnet"]["down_blocks"]), up_blocks=tuple(c["vnet"]["up_blocks"]))
-    shadow = {"G": V(ch, ch, use_inverse=True, **kw), "D_B": D(ch, 64, c["d_layers"]), "D_A": D(ch, 64, c["d_layers"])}
+    if "piresnet" in c:
+        G = torch_ref.Piresnet3D(ch, ch, c["piresnet"]["depth"], c["piresnet"]["first_layer_channels"], use_inverse=True)
+    else:
+        kw = dict(first_layer_channels=c["vnet"]["first_layer_channels"])
+        if "down_blocks" in c["vnet"]:
+            kw.update(down_blocks=tuple(c["vnet"]["down_blocks"]), up_blocks=tuple(c["vnet"]["up_blocks"]))
+        G = V(ch, ch, use_inverse=True, **kw)
+    shadow = {"G": G, "D_B": D(ch, 64, c["d_layers"]), "D_A": D(ch, 64, c["d_layers"])}
     assert list(model.networks) == ["G", "D_B", "D_A"]
     for k, name in enumerate(["G", "D_B", "D_A"]):
         model.networks[name].load_state_dict(torch_ref.seeded_state_dict(shadow[name], c["seed"] + k))
@@ -93,6 +98,7 @@ def _product_revgan(c, conf_name, extra=()):
 
 
 @pytest.mark.parametrize("name,conf_name", [("rev3d_16x32x32", "revgan3d_synthetic.yaml"),
+                                            ("rev3d_piresnet", "revgan3d_piresnet_synthetic.yaml"),
                                             ("rev2d_64x64_idt", "revgan2d_synthetic.yaml")])
 def test_product_recipe_on_the_oracle_backend_matches_reference(name, conf_name):
     from ganslate_amd.nn.native import backend
@@ -133,5 +139,24 @@ def test_parameter_order_with_the_inverse_layers_is_the_reference_registration_o
         shadow = torch_ref.Vnet3D(1, 1, 8, (1, 2), (2, 1), use_inverse=True)
         want = [n for n, _ in shadow.named_parameters()]          # named_parameters() drops the `encoder.*` aliases
         assert native.reference_parameter_order() == want
+    finally:
+        backend.set_ops(None)
+
+
+@pytest.mark.parametrize("saving", [False, True])
+def test_piresnet3d_product_vs_oracle_both_directions(saving):
+    """Piresnet3D (piresnet3d.py:29-108): the product's executor on the fp32 oracle backend against the oracle twin (pinned to
+    the real reference above) — A -> B, then B -> A on its output, gradients of a loss on both; with and without the
+    activation recompute"""
+    from ganslate_amd.nn.generators import Piresnet3D
+    from ganslate_amd.nn.native import backend
+    from oracle.ops_ref import RefOps
+    from .test_networks_cpu import _compare_both_directions
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    try:
+        native = Piresnet3D(1, 1, "instance", 3, 16, use_memory_saving=saving, use_inverse=True)
+        shadow = torch_ref.Piresnet3D(1, 1, 3, 16, use_inverse=True)
+        assert native.reference_parameter_order() == [n for n, _ in shadow.named_parameters()]
+        _compare_both_directions(native, shadow, (1, 1, 8, 12, 16), 72)
     finally:
         backend.set_ops(None)

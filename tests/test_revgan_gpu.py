@@ -83,6 +83,7 @@ def test_both_directions_hip_vs_oracle(hip_ops, dims, ch, c, blocks, shape):
 
 
 @pytest.mark.parametrize("name,conf_name", [("rev3d_16x32x32", "revgan3d_synthetic.yaml"),
+                                            ("rev3d_piresnet", "revgan3d_piresnet_synthetic.yaml"),
                                             ("rev2d_64x64_idt", "revgan2d_synthetic.yaml")])
 def test_revgan_training_step_matches_reference_golden(hip_ops, name, conf_name):
     gold = GOLD["steps"][name]
@@ -142,3 +143,50 @@ def test_memory_saving_frees_the_couplings_activations(hip_ops):
     for k, a in res[False][3].items():
         if a.dim() > 1 and float(a.abs().max()) > 0:         # (the *_ba layers saw no pass here)
             assert cosine(res[True][3][k], a) >= 0.97, (k, cosine(res[True][3][k], a))
+
+
+def test_piresnet3d_both_directions_hip_vs_oracle(hip_ops):
+    """Piresnet3D on the HIP kernels (replicate-padded k5 / k3 convs with their padding fold in the norm backward,
+    gs_slice_stats pre-norms, res_mode 3 inverse) against the fp32 oracle twin and the bf16 CPU emulation"""
+    from ganslate_amd.nn.generators import Piresnet3D
+    from ganslate_amd.nn.native import backend
+    from oracle.ops_ref import RefOps
+    shadow = torch_ref.Piresnet3D(1, 1, 3, 16, use_inverse=True)
+    sd = torch_ref.seeded_state_dict(shadow, 84)
+    shadow.load_state_dict(sd)
+    g = torch.Generator().manual_seed(85)
+    shape = (1, 1, 16, 24, 32)
+    x = torch.rand(shape, generator=g) * 2 - 1
+    gy, gr = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    xa = x.clone().requires_grad_()
+    ya = shadow(xa)
+    ra = shadow(ya, inverse=True)
+    ((ya * gy).sum() + (ra * gr).sum()).backward()
+    res = {}
+    for name, ops in (("hip", hip_ops), ("emu", RefOps(act_dtype=torch.bfloat16))):
+        backend.set_ops(ops)
+        try:
+            net = Piresnet3D(1, 1, "instance", 3, 16)
+            net.load_state_dict(sd)
+            xb = x.clone().to(ops.device).requires_grad_()
+            yb = net(xb)
+            rb = net(yb, inverse=True)
+            ((yb * gy.to(ops.device)).sum() + (rb * gr.to(ops.device)).sum()).backward()
+            if ops.device.type == "cuda":
+                torch.cuda.synchronize()
+            res[name] = (yb.detach().cpu(), rb.detach().cpu(), xb.grad.cpu(),
+                         {k: v.float().cpu() for k, v in net.grads_state_dict().items()})
+        finally:
+            backend.set_ops(hip_ops)
+    yh, rh, gxh, gh = res["hip"]
+    assert rel_l2(yh, ya.detach()) <= 3e-2 and rel_l2(rh, ra.detach()) <= 4e-2, (rel_l2(yh, ya.detach()), rel_l2(rh, ra.detach()))
+    assert rel_l2(gxh, xa.grad) <= 0.35 and cosine(gxh, xa.grad) >= 0.94, (rel_l2(gxh, xa.grad), cosine(gxh, xa.grad))
+    bad = []
+    for n, p in shadow.named_parameters():
+        if p.dim() == 1:
+            continue
+        a, e = gh[n], res["emu"][3][n]
+        if rel_l2(a, e) > 0.33 or cosine(a, e) < 0.94 or rel_l2(a, p.grad) > 0.42 or cosine(a, p.grad) < 0.91:
+            bad.append((n, round(rel_l2(a, e), 3), round(cosine(a, e), 3), round(rel_l2(a, p.grad), 3),
+                        round(cosine(a, p.grad), 3)))
+    assert not bad, bad
