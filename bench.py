@@ -309,7 +309,9 @@ def main():
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                           "data": "synthetic", "config": {"workload": "cityscapes pix2pix (BASELINE configs[2])",
                                                           "global_batch": args.batch * world},
-                          "step_tflops": round(value * 371.5 / 1e3, 1)}), flush=True)
+                          "step_tflops": round(value * 371.5 / 1e3, 1),
+                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
+              flush=True)
     elif rank == 0 and args.workload == "cut":
         value = args.batch * world * args.steps / dt
         print(json.dumps({"metric": "training images/sec, CUT ResNet-9 + PatchGAN-3 + PatchNCE 256x256 bf16",
@@ -319,7 +321,9 @@ def main():
                           "data": "synthetic",
                           "config": {"workload": f"horse2zebra CUT (BASELINE configs[3]), {args.size}x{args.size}, "
                                                  f"batch {args.batch} per GPU, nce_layers 0/4/8/12/16, 256 patches",
-                                     "global_batch": args.batch * world, "parallelism": f"dp{world}"}}), flush=True)
+                                     "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
+              flush=True)
     elif rank == 0 and args.workload in ("cyclegan3d", "brats"):
         value = args.batch * world * args.steps / dt
         vnet = args.workload == "brats"
@@ -335,7 +339,8 @@ def main():
                                       f"shape), {nets}, lsgan, lambda 10/10",
                           "global_batch": args.batch * world, "parallelism": f"dp{world}"},
                "step_tflops": round(value * tflop_per_pair, 1),
-               "step_mfma_frac": round(value * tflop_per_pair / (PEAK_BF16_TFLOPS * world), 4)}
+               "step_mfma_frac": round(value * tflop_per_pair / (PEAK_BF16_TFLOPS * world), 4),
+               "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}
         if timing is not None:
             n, ms = ops.kernel_timing_result().get("rb_fwd", (0, 0.0))
             vox = (args.size // 4) ** 3

@@ -39,9 +39,16 @@ class CUTConfig(configs.base.BaseGANConfig):
 
 
 class CUT(BaseGAN):
+    # The launch sequence of an iteration is fixed once the patch ids are data: they are drawn on the host in the reference's
+    # order before a replay and copied into static index tensors (see _prepare_host_state). With the round-2 kernels a CUT
+    # iteration is ~17 ms of GPU work but ~22 ms of launch-by-launch enqueueing, so the captured step is what the GPU's
+    # pace is. `use_equivariance_flip` draws a host coin that changes the graph (a flip kernel or none): not captured.
+    graph_capturable = True
 
     def __init__(self, conf):
         super().__init__(conf)
+        self.graph_capturable = not conf.train.gan.use_equivariance_flip
+        self.external_draw_ids, self._pid_static, self._nce_call = False, None, 0
         opt = conf.train.gan.optimizer
         self.lambda_adv, self.lambda_nce, self.lambda_nce_idt = opt.lambda_adv, opt.lambda_nce, opt.lambda_nce_idt
         self.nce_layers = list(conf.train.gan.nce_layers)
@@ -150,9 +157,32 @@ class CUT(BaseGAN):
             ids.append(pid[:int(min(self.num_patches, n))] if self.num_patches > 0 else torch.arange(n, device=self.device))
         return ids
 
+    # ---- captured step: the patch ids are host state ---------------------------------------------------------------
+    def _nce_calls_per_step(self):
+        return (1 if self.lambda_nce > 0 else 0) + (1 if self.lambda_nce > 0 and self.lambda_nce_idt > 0 else 0)
+
+    def _set_external_host_state(self, on):
+        super()._set_external_host_state(on)
+        self.external_draw_ids = on
+
+    def _prepare_host_state(self):
+        super()._prepare_host_state()
+        H, W = self.visuals["real_A"].shape[-2:]
+        drawn = [self.sample_patch_ids(H, W) for _ in range(self._nce_calls_per_step())]      # the step's own draw order
+        if self._pid_static is None or [[t.shape for t in c] for c in self._pid_static] != [[t.shape for t in c] for c in drawn]:
+            self._pid_static = [[t.clone() for t in c] for c in drawn]
+        else:
+            for dst, src in zip(self._pid_static, drawn):
+                for d, t in zip(dst, src):
+                    d.copy_(t)
+        self._nce_call = 0
+
     def _calculate_nce_loss(self, source, target, patch_ids=None):
         G, mlp = self.networks["G"], self.networks["mlp"]
         H, W = source.shape[-2:]
+        if patch_ids is None and self.external_draw_ids:          # captured / replayed iteration: ids are static tensors
+            patch_ids = self._pid_static[self._nce_call]
+            self._nce_call += 1
         ids = patch_ids if patch_ids is not None else self.sample_patch_ids(H, W)
         source_feats = G.extract_patch_features(source, self.nce_layers, ids)
         tgt_ids = ids
