@@ -109,7 +109,7 @@ def test_product_recipe_on_the_oracle_backend_matches_reference(name, conf_name)
     try:
         model = _product_revgan(c, conf_name)
         ch = 1 if c["dims"] == 3 else 2
-        for s in range(2):
+        for s in range(2 if c["dims"] == 2 else 1):          # (3-D: one iteration keeps the CPU suite short)
             g = torch.Generator().manual_seed(c["seed"] * 100 + s)
             shape = (c["batch"], ch, *c["size"])
             A, B = torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1

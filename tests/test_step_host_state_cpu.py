@@ -50,10 +50,10 @@ def test_externally_prepared_and_deferred_steps_match_the_plain_step(fp32_oracle
     c["pool_size"] = 3                      # swaps start in the second iteration
     plain = build_product_cyclegan(c)
     assert not plain.step_graph_enabled     # no GPU, no graph: the recipe runs as written
-    want = _steps(plain, c, 4)
+    want = _steps(plain, c, 3)
     other = build_product_cyclegan(c)
-    got = _steps(other, c, 4, externally_prepared=True, deferred="deferred" in mode)
-    for s in range(4):
+    got = _steps(other, c, 3, externally_prepared=True, deferred="deferred" in mode)
+    for s in range(3):
         for k, v in want[s].items():
             assert got[s][k] == pytest.approx(v, rel=1e-6, abs=1e-7), (s, k)
     for name in plain.networks:
