@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cut", "cyclegan3d", "brats"],
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "cut", "cyclegan3d", "brats", "revgan"],
                     help="cyclegan = the headline (BASELINE configs[1]); pix2pix = configs[2] (batch 1, 256x512); "
                          "cut = configs[3] (PatchNCE, batch 8, 256x256); "
                          "cyclegan3d = 3-D CycleGAN on 128^3 volumes with Resnet3D (configs[4] shape, batch 1); "
@@ -232,6 +232,30 @@ def main():
         model = build_gan(make_volume_conf(args.batch, args.size, 10 ** 6,
                                            "vnet" if args.workload == "brats" else "resnet"))
         shape = (args.batch, 1, args.size, args.size, args.size)
+    elif args.workload == "revgan":
+        # projects/brats_mri_sequence_translation/experiments/revgan.yaml: RevGAN with Piresnet3D(depth 5, 32 channels,
+        # memory saving + inverse) and PatchGAN3D(2 layers), lambda 5 / 5, lr_G 4e-4; 32 x 176 x 176 patches in the yaml
+        args.no_cpu_baseline = args.no_kernel_timing = True
+        if args.batch == 8:
+            args.batch = 1
+        from ganslate_amd.configs.omegalite import OmegaConf
+        from ganslate_amd.configs.config import Config
+        from ganslate_amd.configs.utils import init_config
+        y = OmegaConf.create({"train": {
+            "output_dir": "/tmp/ganslate_amd_bench", "cuda": True, "batch_size": args.batch, "n_iters": 10 ** 6,
+            "n_iters_decay": 10 ** 6,
+            "dataset": {"_target_": "ganslate.data.SyntheticImageDataset", "image_channels": 1,
+                        "final_size": [32, 176, 176]},
+            "gan": {"_target_": "ganslate.nn.gans.unpaired.RevGAN", "pool_size": 50,
+                    "generator": {"_target_": "ganslate.nn.generators.Piresnet3D", "use_memory_saving": True,
+                                  "use_inverse": True, "depth": 5, "in_out_channels": {"AB": [1, 1]}},
+                    "discriminator": {"_target_": "ganslate.nn.discriminators.PatchGAN3D", "n_layers": 2,
+                                      "in_channels": {"B": 1, "A": 1}},
+                    "optimizer": {"lambda_AB": 5.0, "lambda_BA": 5.0, "lambda_identity": 0, "proportion_ssim": 0,
+                                  "lr_D": 0.0002, "lr_G": 0.0004}},
+            "metrics": {"discriminator_evolution": True, "ssim": False}}})
+        model = build_gan(init_config(y, Config))
+        shape = (args.batch, 1, 32, 176, 176)
     else:
         model = build_gan(make_conf(args.batch, args.size, 10 ** 6))
         shape = (args.batch, 3, args.size, args.size)
@@ -322,6 +346,18 @@ def main():
                           "config": {"workload": f"horse2zebra CUT (BASELINE configs[3]), {args.size}x{args.size}, "
                                                  f"batch {args.batch} per GPU, nce_layers 0/4/8/12/16, 256 patches",
                                      "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
+              flush=True)
+    elif rank == 0 and args.workload == "revgan":
+        value = args.batch * world * args.steps / dt
+        print(json.dumps({"metric": "training volumes/sec, RevGAN Piresnet3D(5, 32) + PatchGAN3D-2 32x176x176 bf16",
+                          "value": round(value, 3), "unit": "vol/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "synthetic",
+                          "config": {"workload": "brats revgan.yaml networks and patch size (not a BASELINE configuration), "
+                                                 "activation recompute on", "global_batch": args.batch * world,
+                                     "parallelism": f"dp{world}"},
                           "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
               flush=True)
     elif rank == 0 and args.workload in ("cyclegan3d", "brats"):
