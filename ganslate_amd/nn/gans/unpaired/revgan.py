@@ -1,14 +1,14 @@
 """RevGAN recipe — class surface, step order and loss assembly of
 ganslate/nn/gans/unpaired/revgan.py:19-220 ("Reversible GANs for Memory-efficient Image-to-Image Translation", van der
 Ouderaa & Worrall, CVPR 2019): CycleGAN's losses with ONE partially-invertible generator used in both directions,
-`G(x)` for A -> B and `G(x, inverse=True)` for B -> A (Vnet2D / Vnet3D with `use_inverse: true`), networks G, D_B, D_A and
+`G(x)` for A -> B and `G(x, inverse=True)` for B -> A (Piresnet3D / Vnet2D / Vnet3D with `use_inverse: true`), networks G, D_B, D_A and
 one Adam over G.
 
 Kept as the reference has it: the generator-side adversarial terms pair D_B with fake_A and D_A with fake_B
 (revgan.py:187-193; CycleGAN pairs them the other way round). The generator's `use_memory_saving` is memcnn's
-activation recompute, implemented by the V-Net executor (nn/generators/vnet/vnet3d.py): coupling inputs are rebuilt from
-outputs during backward instead of being kept. Launch by launch on one stream (four to six passes through the same network: nothing to
-overlap, and the generator's gradient buffer is shared by all of them)."""
+activation recompute, implemented by the generators' executors (vnet3d.py, piresnet3d.py): coupling inputs are rebuilt from
+outputs during backward instead of being kept. Iterations replay as one hipGraph on one stream (four to six passes
+through the same network share its gradient buffer)."""
 from dataclasses import dataclass, field
 
 import torch
@@ -34,7 +34,7 @@ class RevGANConfig(configs.base.BaseGANConfig):
 
 
 class RevGAN(BaseGAN):
-    graph_capturable = False
+    graph_capturable = True      # same fixed launch sequence as CycleGAN: pools' coin flips and Adam's scalars are device data
 
     def __init__(self, conf):
         super().__init__(conf)
@@ -51,6 +51,9 @@ class RevGAN(BaseGAN):
         self.setup()
         if not getattr(self.networks["G"], "use_inverse", False):
             raise ValueError("RevGAN needs a generator with an inverse direction (Vnet2D / Vnet3D with use_inverse: true)")
+
+    def _step_pools(self):
+        return [self.fake_B_pool, self.fake_A_pool]      # backward_D("D_B") runs first
 
     def init_criterions(self):
         self.criterion_adv = AdversarialLoss(self.conf.train.gan.optimizer.adversarial_loss_type).to(self.device)
