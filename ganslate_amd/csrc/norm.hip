@@ -16,48 +16,55 @@ template <int R, int CH = 16>
 __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* out, int slots, int C, float inv_hw,
                                                        float eps, const float* mean_rstd, float* db) {
   constexpr int LANES = 256 / CH;
-  __shared__ double red[LANES][CH + 1];
-  __shared__ double tot[R][CH];      // double up to mean / rstd: E[y^2] - mean^2 in fp32 loses the variance when |mean| >> std
+  __shared__ double red[R][LANES][CH + 1];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const int col = tid % CH, lane = tid / CH;
   const int c = blockIdx.x * CH + col;
   const float* src = in + (size_t)n * slots * R * C;
+  // all R sums of a channel in one sweep (R x 4 loads in flight per thread, additions in slot order per lane), then a
+  // fixed-shape tree over the lanes: the narrow layers of the V-Nets / Piresnet (8 workgroups of this kernel per launch)
+  // spent 8-16 us here walking R serial phases with a 64-term sum on one thread each
+  double s[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    double s = 0.0;
-    if (c < C) {      // eight loads in flight, additions in slot order (see slot_sum_ordered)
-      int sl = lane;
-      for (; sl + 7 * LANES < slots; sl += 8 * LANES) {
-        float v[8];
+  for (int r = 0; r < R; ++r) s[r] = 0.0;
+  if (c < C) {
+    int sl = lane;
+    for (; sl + 3 * LANES < slots; sl += 4 * LANES) {
+      float v[4][R];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = src[((size_t)(sl + k * LANES) * R + r) * C + c];
+      for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += (double)v[k];
-      }
-      for (; sl < slots; sl += LANES) s += (double)src[((size_t)sl * R + r) * C + c];
+        for (int r = 0; r < R; ++r) v[k][r] = src[((size_t)(sl + k * LANES) * R + r) * C + c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += (double)v[k][r];
     }
-    __syncthreads();
-    red[lane][col] = s;
-    __syncthreads();
-    if (lane == 0) {
-      double t = 0.0;
+    for (; sl < slots; sl += LANES)
 #pragma unroll
-      for (int l = 0; l < LANES; ++l) t += red[l][col];
-      tot[r][col] = t;
-    }
+      for (int r = 0; r < R; ++r) s[r] += (double)src[((size_t)sl * R + r) * C + c];
   }
+#pragma unroll
+  for (int r = 0; r < R; ++r) red[r][lane][col] = s[r];
   __syncthreads();
+  for (int w = LANES / 2; w > 0; w >>= 1) {
+    if (lane < w) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) red[r][lane][col] += red[r][lane + w][col];
+    }
+    __syncthreads();
+  }
   if (lane == 0 && c < C) {
     if (R == 2) {
-      const double mean = tot[0][col] * (double)inv_hw;
-      double var = tot[1][col] * (double)inv_hw - mean * mean;
+      const double mean = red[0][0][col] * (double)inv_hw;
+      double var = red[1][0][col] * (double)inv_hw - mean * mean;
       if (var < 0.0) var = 0.0;
       out[(size_t)n * 2 * C + c] = (float)mean;
       out[(size_t)n * 2 * C + C + c] = (float)(1.0 / sqrt(var + (double)eps));
     } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = (float)tot[r][col];
+      for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = (float)red[r][0][col];
     }
   }
 }
