@@ -248,7 +248,8 @@ class HipOps:
                 if nws < 0:
                     L.check(2, "gs_wgrad_ws_floats")
                 self._desc_cache[wkey] = nws
-            ws = torch.empty(nws, dtype=torch.float32, device=self.device)      # stream-safe through the allocator
+            # (0 floats: single-contributor layers accumulate straight into dw, no workspace)
+            ws = torch.empty(nws, dtype=torch.float32, device=self.device) if nws else None   # stream-safe via the allocator
             a2, g2 = pair if pair is not None else (None, None)
             L.check(self.lib.gs_wgrad_ws(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(a2), _ptr(g2), _ptr(dw), _ptr(ws), nws,
                                          _stream()), "gs_wgrad_ws")

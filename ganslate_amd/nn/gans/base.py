@@ -262,6 +262,14 @@ class BaseGAN(ABC):
             net.external_reduce = True
         torch.cuda.synchronize()
         graph, update = torch.cuda.CUDAGraph(), None
+        # No garbage collection while the capture is open: a cyclic-garbage sweep that happens to run between two launches
+        # may finalise streams / events / graphs of objects that died earlier (another model, a finished validation run), and
+        # destroying those is not permitted during a global-mode capture — the process aborts inside a destructor
+        # (seen in the test-suite: "Fatal Python error: Aborted ... Garbage-collecting" under _capture_step).
+        import gc
+        gc_was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             # data parallel: RCCL's watchdog thread may poll events of earlier collectives while this thread captures;
             # only this thread's calls are policed then
@@ -283,6 +291,8 @@ class BaseGAN(ABC):
             raise RuntimeError(f"{type(self).__name__}: the training step could not be captured into a hipGraph "
                                f"({e}); set GS_STEP_GRAPH=0 to run it launch by launch") from e
         finally:
+            if gc_was_enabled:
+                gc.enable()
             for optim in self.optimizers.values():
                 optim.deferred_to = None
             for net in dp_nets:

@@ -141,7 +141,8 @@ int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const 
  * pixels) write partial sums to slabs of a caller-owned workspace and a second launch adds the slabs to dw in a fixed
  * order, instead of fp32 atomics on dw — two runs give bit-identical gradients (torch.use_deterministic_algorithms-like
  * behaviour of the reference's cuDNN weight gradients is NOT guaranteed either; this is what the loss-curve parity tests
- * run on). gs_wgrad_ws_floats: workspace the call wants (floats; < 0: bad descriptor). */
+ * run on). gs_wgrad_ws_floats: workspace the call wants (floats; < 0: bad descriptor; 0: every output element has a single
+ * contributing workgroup, which then accumulates straight into dw — ws may be NULL). */
 int64_t gs_wgrad_ws_floats(const gs_wgrad_desc* d, int32_t pair);
 int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
                 float* ws, int64_t ws_floats, void* stream);
