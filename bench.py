@@ -192,6 +192,16 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
+    # The ONE JSON line must be the only thing this process puts on stdout: RCCL prints a version block to stdout when its
+    # communicator is torn down (after everything else), which would follow the JSON line of a data-parallel run. File
+    # descriptor 1 is pointed at stderr for the whole run and the JSON line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     from ganslate_amd.utils import communication
@@ -327,18 +337,17 @@ def main():
 
     if rank == 0 and args.workload == "pix2pix":
         value = args.batch * world * args.steps / dt
-        print(json.dumps({"metric": "training images/sec, Pix2Pix U-Net(7,128)+PatchGAN-4 256x512 bf16",
+        emit({"metric": "training images/sec, Pix2Pix U-Net(7,128)+PatchGAN-4 256x512 bf16",
                           "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                           "data": "synthetic", "config": {"workload": "cityscapes pix2pix (BASELINE configs[2])",
                                                           "global_batch": args.batch * world},
                           "step_tflops": round(value * 371.5 / 1e3, 1),
-                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
-              flush=True)
+                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed})
     elif rank == 0 and args.workload == "cut":
         value = args.batch * world * args.steps / dt
-        print(json.dumps({"metric": "training images/sec, CUT ResNet-9 + PatchGAN-3 + PatchNCE 256x256 bf16",
+        emit({"metric": "training images/sec, CUT ResNet-9 + PatchGAN-3 + PatchNCE 256x256 bf16",
                           "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -346,11 +355,10 @@ def main():
                           "config": {"workload": f"horse2zebra CUT (BASELINE configs[3]), {args.size}x{args.size}, "
                                                  f"batch {args.batch} per GPU, nce_layers 0/4/8/12/16, 256 patches",
                                      "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
-              flush=True)
+                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed})
     elif rank == 0 and args.workload == "revgan":
         value = args.batch * world * args.steps / dt
-        print(json.dumps({"metric": "training volumes/sec, RevGAN Piresnet3D(5, 32) + PatchGAN3D-2 32x176x176 bf16",
+        emit({"metric": "training volumes/sec, RevGAN Piresnet3D(5, 32) + PatchGAN3D-2 32x176x176 bf16",
                           "value": round(value, 3), "unit": "vol/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -358,8 +366,7 @@ def main():
                           "config": {"workload": "brats revgan.yaml networks and patch size (not a BASELINE configuration), "
                                                  "activation recompute on", "global_batch": args.batch * world,
                                      "parallelism": f"dp{world}"},
-                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed}),
-              flush=True)
+                          "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3), "step_graph": graphed})
     elif rank == 0 and args.workload in ("cyclegan3d", "brats"):
         value = args.batch * world * args.steps / dt
         vnet = args.workload == "brats"
@@ -387,7 +394,7 @@ def main():
                                "kernel": "gconv_kernel (3x3x3 256->256 replicate conv, M=%d N=256 K=6912)"
                                          % (vox * args.batch),
                                "launches_timed": n, "avg_ms": round(ms, 4)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     elif rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
@@ -441,7 +448,7 @@ def main():
             out["residual_conv_kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
