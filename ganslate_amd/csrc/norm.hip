@@ -692,6 +692,8 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
   } while (0)
     if (C8 >= 32) GS_LAUNCH_REDUCE(32);
     else if (C8 >= 8) GS_LAUNCH_REDUCE(8);
+    else if (C8 >= 4) GS_LAUNCH_REDUCE(4);      // 32- / 16-channel layers: the columns of a pixel in one workgroup
+    else if (C8 >= 2) GS_LAUNCH_REDUCE(2);
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
 #undef GS_LAUNCH_REDUCE2

@@ -325,8 +325,12 @@ extern "C" int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const vo
 #define GS_LAUNCH_REDUCE(COLS)                                                                                      \
   hipLaunchKernelGGL((pnorm_bwd_reduce_kernel<COLS>), dim3(chunks, d->N, (k.C8 + COLS - 1) / COLS), dim3(256), 0, \
                      st, k, gp, g2p, yp, mean_rstd, rp, slope, scratch, ppb, chunks)
+    // (COLS columns of one pixel are neighbouring 16-B loads: with one column per workgroup a 16- or 32-channel slice was
+    // read as every second / fourth 16 bytes of a line by two / four different workgroups)
     if (k.C8 >= 32) GS_LAUNCH_REDUCE(32);
     else if (k.C8 >= 8) GS_LAUNCH_REDUCE(8);
+    else if (k.C8 >= 4) GS_LAUNCH_REDUCE(4);
+    else if (k.C8 >= 2) GS_LAUNCH_REDUCE(2);
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
     GS_CHECK_HIP(hipGetLastError());
@@ -464,6 +468,12 @@ extern "C" int gs_slice_stats(const void* x, int32_t N, int64_t pixels, int32_t 
   const unsigned short* xs = static_cast<const unsigned short*>(x);
   if (C8 >= 8)
     hipLaunchKernelGGL((slice_stats_kernel<8>), dim3(slots, N, (C8 + 7) / 8), dim3(256), 0, st, xs, (unsigned)pixels, cs, co,
+                       C8, C, partial, ppb, slots);
+  else if (C8 >= 4)
+    hipLaunchKernelGGL((slice_stats_kernel<4>), dim3(slots, N, (C8 + 3) / 4), dim3(256), 0, st, xs, (unsigned)pixels, cs, co,
+                       C8, C, partial, ppb, slots);
+  else if (C8 >= 2)
+    hipLaunchKernelGGL((slice_stats_kernel<2>), dim3(slots, N, (C8 + 1) / 2), dim3(256), 0, st, xs, (unsigned)pixels, cs, co,
                        C8, C, partial, ppb, slots);
   else
     hipLaunchKernelGGL((slice_stats_kernel<1>), dim3(slots, N, C8), dim3(256), 0, st, xs, (unsigned)pixels, cs, co, C8, C,

@@ -500,6 +500,7 @@ static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs,
   const unsigned short* p = static_cast<const unsigned short*>(dy);
   if (C8 >= 32) hipLaunchKernelGGL((bias_grad_kernel<32>), dim3(bx, (C8 + 31) / 32), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   else if (C8 >= 8) hipLaunchKernelGGL((bias_grad_kernel<8>), dim3(bx, (C8 + 7) / 8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
+  else if (C8 >= 2) hipLaunchKernelGGL((bias_grad_kernel<2>), dim3(bx, (C8 + 1) / 2), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   else hipLaunchKernelGGL((bias_grad_kernel<1>), dim3(bx, C8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   GS_CHECK_HIP(hipGetLastError());
   if (ws) {
