@@ -646,6 +646,8 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
 int gs_hconvw_slots(const gs_gconv_desc* d);
 int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
                   void* stream, int* handled);
+int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, void* out, const gs_gconv_fuse* fuse,
+                   void* stream);
 
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
 
@@ -689,6 +691,11 @@ extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, co
                  d->out_cs == d->Co && d->out_co == 0,
              "gs_gconv_forward_fused: only plain stride-1 data-gradient launches with a dense output can be fused");
   const int fd = fuse->Dy > 1 ? fuse->fold : 0;
+  if (fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy) {
+    // unpadded output domain: the launch applies the pad adjoint itself (hconvw.hip RING; gs_gconv_ring_slots says when)
+    GS_REQUIRE(in && w_pack && out && !bias, "gs_gconv_forward_fused: null argument / bias on a data-gradient launch");
+    return gs_hconvw_ring(d, in, w_pack, out, fuse, stream);
+  }
   GS_REQUIRE(d->Do == fuse->Dy + 2 * fd && d->Ho == fuse->Hy + 2 * fuse->fold && d->Wo == fuse->Wy + 2 * fuse->fold,
              "gs_gconv_forward_fused: output domain must be the norm's domain padded by `fold`");
   return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, nullptr, 0, stream);

@@ -24,11 +24,24 @@ struct HConvWK {
   int hh, hw, hmin, wmin;      // halo extent and smallest tap offsets
   int chunks;                  // Ci / 64
   gs_gconv_desc d;
+  gs_gconv_fuse f;             // RING: the consumer's InstanceNorm backward sums ride in the epilogue (gs_gconv_forward_fused)
 };
 
 // NW = 16: waves as 4 x 4, 64 pixels x 32 channels each; NW = 8: 4 x 2, 64 x 64 each (a third fewer fragment reads per
 // MFMA — the loop is bound by LDS reads — for half the latency hiding)
-template <int T, int NW = 16>
+//
+// RING: data gradient of a reflect-padded (pad 1) 3x3 conv on the UNPADDED domain (resnet2d.py:80-87 backward). With
+// C(u) = sum_t dY[u + off_t] W_t the zero-border conv on the extended domain u in [-1, H] x [-1, W], the gradient is
+// dX[v] = sum over {u : reflect(u) = v} C(u): the box itself plus, for boxes on the image border, the ring pixels one
+// step outside it (row -1 folds onto row 1, row H onto row H-2, same for columns, the four corners onto (1,1) ...).
+// A ring pixel sees the image through 3 of the 9 taps only (1 for a corner), and the destination pixel lives in the same
+// box, so each pixel-row group of waves takes one ring fragment as a side job — wm 0: top row (or a bottom corner),
+// wm 3: bottom row (or a top corner), wm 1: left column, wm 2: right column — two extra MFMAs per half K-step on three
+// taps, accumulated apart and added to the destination pixels in fp32 before rounding (through LDS, fixed order).
+// gconv_kernel runs this layer on the 66 x 66 padded domain instead (+6 % pixels, 288-pixel im2col tiles: 59 us
+// vs 41 here) and leaves the fold to the consumer. The epilogue is gs_gconv_forward_fused's: per-box sums of the
+// consumer's InstanceNorm backward.
+template <int T, int NW = 16, bool RING = false>
 __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   constexpr int BM = 256, BN = 128, WM = 4, WN = NW / 4;
   constexpr int WT = BN * 128;                   // weight stage: 128 rows x 64 k
@@ -119,6 +132,32 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- RING: this wave's ring fragment (lane frow = one ring pixel), its taps and its slot in the ring buffer ----
+  // taps come in the data-gradient order t = 3*ry + rx with (dh, dw) = (1 - ry, 1 - rx) (checked by the launcher)
+  [[maybe_unused]] const bool e_top = oy0 == 0, e_bot = oy0 + 16 == d.Ho, e_lef = ox0 == 0, e_rig = ox0 + 16 == d.Wo;
+  [[maybe_unused]] unsigned e_mask = 0;          // wave-uniform: taps that reach the image from this wave's ring pixels
+  [[maybe_unused]] int e_rb = 0, e_slot = 0;
+  [[maybe_unused]] bool e_lane = true;           // false: this lane carries no ring pixel (reads the zero sink)
+  [[maybe_unused]] f32x4 accE[TI];
+  if constexpr (RING) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) accE[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int py = 0, px = 0, sy = 0, sx = 0;          // ring pixel of lane frow: (py + sy*frow, px + sx*frow), box coordinates
+    const bool side = e_lef || e_rig;
+    if (wm == 0) {
+      if (e_top) { e_mask = 0x007u; py = -1; sx = 1; e_slot = 0; }
+      else if (e_bot && side) { e_mask = e_lef ? 0x040u : 0x100u; py = 16; px = e_lef ? -1 : 16; e_lane = frow == 0; e_slot = 4; }
+    } else if (wm == 3) {
+      if (e_bot) { e_mask = 0x1C0u; py = 16; sx = 1; e_slot = 1; }
+      else if (e_top && side) { e_mask = e_lef ? 0x001u : 0x004u; py = -1; px = e_lef ? -1 : 16; e_lane = frow == 0; e_slot = 4; }
+    } else if (wm == 1) {
+      if (e_lef) { e_mask = 0x049u; px = -1; sy = 1; e_slot = 2; }
+    } else {
+      if (e_rig) { e_mask = 0x124u; px = 16; sy = 1; e_slot = 3; }
+    }
+    e_mask = __builtin_amdgcn_readfirstlane(e_mask);
+    e_rb = ((py + sy * frow) * p.hw + (px + sx * frow)) * HP + fk * 16;
+  }
 
   // ---- main loop: chunks x taps, software-pipelined over half K-steps --------------------------------------------
   // Weights run 3 K-steps ahead in a 3-slot ring, halo boxes 2 chunks ahead in 2 buffers. Inside a K-step the fragment
@@ -182,6 +221,8 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   if (grp) __builtin_amdgcn_s_barrier();
   const unsigned wring0 = smem0 + woff, hbuf0 = smem0 + 3 * WT;
   bf16x8 wA[TI], xA[TJ], wB[TI], xB[TJ];
+  [[maybe_unused]] bf16x8 xE0, xE1;
+  [[maybe_unused]] const unsigned sink0 = smem0 + 3 * WT + 2 * HBUF;
   int stage = 0;
   for (int c = 0; c < p.chunks; ++c) {
     const unsigned hb = hbuf0 + (unsigned)((c & 1) * HBUF);
@@ -194,8 +235,19 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       if (ks >= 1 && ks + 2 < nk) { int c2, t2; ct_of(ks + 2, c2, t2); issue_w(c2, t2, stage == 0 ? 2 : stage - 1); }
       load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K0{}, wA, xA);
       load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K1{}, wB, xB);
+      [[maybe_unused]] const bool e_now = RING && ((e_mask >> t) & 1u);
+      if constexpr (RING) {
+        if (e_now) {
+          const unsigned ea = e_lane ? hb + (unsigned)tb[t] + (unsigned)e_rb : sink0;
+          lds_read128<0>(xE0, ea);
+          lds_read128<64>(xE1, ea);
+        }
+      }
       wait_frags(std::integral_constant<int, 0>{}, wA, xA);
       wait_frags(std::integral_constant<int, 0>{}, wB, xB);
+      if constexpr (RING) {
+        if (e_now) { reg_fence(xE0); reg_fence(xE1); }
+      }
       auto wait_next_weights = [&]() {       // this wave's share of step ks+1's weights (and anything older) has landed
         if (ks + 1 >= nk) return;
         if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,6 +262,14 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       __builtin_amdgcn_s_setprio(1);
       mma(wA, xA);
       mma(wB, xB);
+      if constexpr (RING) {
+        if (e_now) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) accE[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[i], xE0, accE[i], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TI; ++i) accE[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wB[i], xE1, accE[i], 0, 0, 0);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (!grp) wait_next_weights();
@@ -218,6 +278,113 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
     }
   }
   if (!grp) __builtin_amdgcn_s_barrier();       // group 1 ran one barrier ahead of the loop: every wave has passed the same count
+  if constexpr (RING) {
+    // ---- RING epilogue: ring sums -> LDS -> added (fp32) to the pixels they fold onto, bf16 tile through the per-wave
+    // slabs, coalesced stores with the consumer's InstanceNorm-backward sums (same contract as gconv_kernel's fused
+    // epilogue: sums over the box of ghat = (g + g2) * act'(yhat), ghat * yhat, yhat; one slot per box) -------------
+    constexpr int CW = CWV, PW = 64, SROW = CW * 2 + 16;
+    constexpr int RED_BYTES = WM * BN * 3 * 4;
+    constexpr int SLAB0 = ((RED_BYTES + 255) / 256) * 256;
+    constexpr int RING0 = SLAB0 + NW * PW * SROW;            // [5 slots: top, bottom, left, right, corner][16 pixels][BN] fp32
+    float* ringbuf = reinterpret_cast<float*>(smem + RING0);
+    __syncthreads();                                         // the last K-step's operands have been read by every wave
+    if (e_mask) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        *reinterpret_cast<f32x4*>(ringbuf + (e_slot * 16 + frow) * BN + wn * CWV + i * 16 + fk * 4) = accE[i];
+    }
+    __syncthreads();
+    const int cy = e_top ? 1 : 14, cx = e_lef ? 1 : 14;      // where this box's image corner (if it has one) folds onto
+    const bool corner = (e_top || e_bot) && (e_lef || e_rig);
+    char* slab = smem + SLAB0 + wave * (PW * SROW);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int y = wm * 4 + j;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int cl = wn * CWV + i * 16 + fk * 4;
+        f32x4 v = acc[i][j];
+        if (e_top && y == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (0 * 16 + frow) * BN + cl);
+        if (e_bot && y == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (1 * 16 + frow) * BN + cl);
+        if (e_lef && frow == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (2 * 16 + y) * BN + cl);
+        if (e_rig && frow == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (3 * 16 + y) * BN + cl);
+        if (corner && y == cy && frow == cx) v += *reinterpret_cast<const f32x4*>(ringbuf + (4 * 16 + 0) * BN + cl);
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(slab + (j * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
+      }
+    }
+    __syncthreads();
+    constexpr int LPR = CW / 8, PPI = 64 / LPR;
+    static_assert(LPR == 4, "ring epilogue: 32 channels per wave");
+    const int sub = lane % LPR, prow = lane / LPR;
+    const int co = nt * BN + wn * CW + sub * 8;
+    float fa1[8], fa2[8], fa3[8], fmu[8], frs[8];
+    {
+      const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { fa1[k] = fa2[k] = fa3[k] = 0.f; fmu[k] = mr[co + k]; frs[k] = mr[d.Co + co + k]; }
+    }
+#pragma unroll
+    for (int it = 0; it < PW / PPI; ++it) {
+      const int pl = it * PPI + prow;
+      const int ly = wm * 4 + (pl >> 4), lx = pl & 15;
+      const size_t opix = ((size_t)n * d.Ho + (oy0 + ly)) * d.Wo + (ox0 + lx);
+      const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
+      const uint4 yv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.y) + (opix * d.Co + co) * 2);
+      *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
+      float g[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y),
+                    bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
+      const float yr[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
+                           bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
+      if (p.f.g2) {
+        const uint4 gv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.g2) + (opix * d.Co + co) * 2);
+        g[0] += bf_lo(gv.x); g[1] += bf_hi(gv.x); g[2] += bf_lo(gv.y); g[3] += bf_hi(gv.y);
+        g[4] += bf_lo(gv.z); g[5] += bf_hi(gv.z); g[6] += bf_lo(gv.w); g[7] += bf_hi(gv.w);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float yh = (yr[k] - fmu[k]) * frs[k];
+        const float gh = g[k] * act_grad_from_out(yh, p.f.act, p.f.slope);
+        fa1[k] += gh;
+        fa2[k] += gh * yh;
+        fa3[k] += yh;
+      }
+    }
+    float* red3 = reinterpret_cast<float*>(smem);            // [WM][BN][3]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      fa1[k] = row_sum_stride4(fa1[k]); fa2[k] = row_sum_stride4(fa2[k]); fa3[k] = row_sum_stride4(fa3[k]);
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        fa1[k] += __shfl_xor(fa1[k], o, 64);
+        fa2[k] += __shfl_xor(fa2[k], o, 64);
+        fa3[k] += __shfl_xor(fa3[k], o, 64);
+      }
+    }
+    if (prow == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int cl = wn * CW + sub * 8 + k;
+        red3[(wm * BN + cl) * 3 + 0] = fa1[k];
+        red3[(wm * BN + cl) * 3 + 1] = fa2[k];
+        red3[(wm * BN + cl) * 3 + 2] = fa3[k];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int c = nt * BN + tid;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t0 += red3[(w * BN + tid) * 3]; t1 += red3[(w * BN + tid) * 3 + 1]; t2 += red3[(w * BN + tid) * 3 + 2];
+      }
+      float* sp = p.f.partial + ((size_t)n * p.tiles_m + mt) * 3 * d.Co;
+      sp[c] = t0; sp[d.Co + c] = t1; sp[2 * d.Co + c] = t2;
+    }
+    return;
+  }
   f32x4 bia[TI];                                // loaded after the loop: inside it they would spill (128-VGPR cap)
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
@@ -346,6 +513,7 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.hh = 18; k.hw = 18; k.hmin = lo[0]; k.wmin = lo[1];
   k.chunks = d->Ci / 64;
   k.d = *d;
+  k.f = gs_gconv_fuse{};
   const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
   const int nw = gs_opt(GS_OPT_HCONVW_WAVES);
   static bool configured = false;
@@ -361,6 +529,58 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
     hipLaunchKernelGGL((hconvw_kernel<9, 8>), dim3((unsigned)blocks), dim3(512), lds, static_cast<hipStream_t>(stream), k);
   else
     hipLaunchKernelGGL((hconvw_kernel<9, 16>), dim3((unsigned)blocks), dim3(1024), lds, static_cast<hipStream_t>(stream), k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- RING form: fused data gradient of a reflect-padded 3x3 conv on the unpadded domain ---------------------------------
+static bool hconvw_ring_eligible(const gs_gconv_desc* d) {
+  int lo[2];
+  if (gs_opt(GS_OPT_HCONVW_RING) == 0 || !hconvw_eligible(d, lo)) return false;
+  if (d->border != GS_BORDER_ZERO || d->Hi != d->Ho || d->Wi != d->Wo || d->Ho < 32 || d->Wo < 32) return false;
+  if (d->stats_slots != 0 || d->act != GS_ACT_NONE || d->out_cs != d->Co || d->out_co != 0) return false;
+  for (int t = 0; t < 9; ++t)
+    if (d->dh[t] != 1 - t / 3 || d->dw[t] != 1 - t % 3) return false;   // the data-gradient tap order the kernel assumes
+  return true;
+}
+
+// slots of partial sums per image of the ring form (one per 16x16 box), 0 when the layer does not run in it: then the
+// caller lowers the data gradient onto the padded domain (gs_gconv_forward_fused with the padded output extent)
+extern "C" int gs_gconv_ring_slots(const gs_gconv_desc* d) {
+  return (d && hconvw_ring_eligible(d)) ? (d->Ho / 16) * (d->Wo / 16) : 0;
+}
+
+int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, void* out, const gs_gconv_fuse* fuse,
+                   void* stream) {
+  GS_REQUIRE(hconvw_ring_eligible(d), "gs_gconv_forward_fused: layer is not eligible for the unpadded (ring) form, see "
+                                      "gs_gconv_ring_slots");
+  GS_REQUIRE(fuse->fold == 1 && fuse->fold_mode == GS_BORDER_REFLECT && fuse->Dy == 1,
+             "gs_gconv_forward_fused: the unpadded form folds a reflect padding of 1");
+  HConvWK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_pack);
+  k.bias = nullptr;
+  k.out = static_cast<char*>(out);
+  k.stats = nullptr;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
+  k.tiles_m = (d->Ho / 16) * (d->Wo / 16);
+  k.tiles_n = d->Co / 128;
+  k.nbw = d->Wo / 16;
+  k.hh = 18; k.hw = 18; k.hmin = -1; k.wmin = -1;
+  k.chunks = d->Ci / 64;
+  k.d = *d;
+  k.f = *fuse;
+  const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
+  const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 16, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((hconvw_kernel<9, 16, true>), dim3((unsigned)blocks), dim3(1024), lds,
+                     static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -68,6 +68,7 @@ _PROTOS = {
     "gs_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "gs_tile_m": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_stat_slots": (C.c_int, [C.POINTER(GConvDesc)]),
+    "gs_gconv_ring_slots": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "gs_gconv_splitk_ws_floats": (C.c_int64, [C.POINTER(GConvDesc)]),

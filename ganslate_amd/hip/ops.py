@@ -45,7 +45,8 @@ class HipOps:
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
                    "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_NW": "hconvw_waves",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
-                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi"}
+                   "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
+                   "GS_HCONVW_RING": "hconvw_ring"}
 
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")
@@ -135,6 +136,16 @@ class HipOps:
             return None
         tm = self.tile_m(g, N)
         slots = (g.pixels + tm - 1) // tm
+        return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
+
+    def fused_ring_plan(self, g: GConv, N: int, C_: int):
+        """(slots, scratch) when the fused data gradient of a reflect-padded 3x3 layer can run on the unpadded domain
+        (class g = Lowered.dgrad_ring; the launch folds the ring itself, hconvw.hip RING), else None"""
+        if g is None or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
+            return None
+        slots = self.lib.gs_gconv_ring_slots(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+        if slots <= 0:
+            return None
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
     def stat_slots(self, g: GConv, N: int) -> int:

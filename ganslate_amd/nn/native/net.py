@@ -504,7 +504,6 @@ class NativeNet:
             # ---- data gradient ------------------------------------------------------------------------------------------
             if i > 0 or need_input_grad:
                 f = lw.dgrad_fold
-                gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
                 dpack = pk["dpack"][pk["d_off"][i]:]
                 g2n = skip.pop(i - 1, None)
                 fmode_n = sp.pad_mode if f else "reflect"
@@ -513,7 +512,18 @@ class NativeNet:
                 plan = None
                 if i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 1 and (i - 1) not in inj_x:
                     plan = ops.fused_norm_plan(lw.dgrad[0], N, sp.cin_p)
-                if plan is not None:
+                ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p) if plan is not None else None
+                if ring is None:
+                    gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
+                if ring is not None:
+                    # reflect-padded wide 3x3 layer: the launch folds the ring of padded-domain pixels itself, the gradient
+                    # arrives on the unpadded domain
+                    gx = torch.empty(N, *lw.in_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
+                    ops.gconv(lw.dgrad_ring, dy, dpack, None, gx,
+                              fuse={"y": s.ys[i - 1], "mean_rstd": s.mrs[i - 1], "g2": g2n, "partial": ring[1], "fold": f,
+                                    "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope})
+                    pending = (gx, 0, g2n, fmode_n, ring)
+                elif plan is not None:
                     ops.gconv(lw.dgrad[0], dy, dpack, None, gx,
                               fuse={"y": s.ys[i - 1], "mean_rstd": s.mrs[i - 1], "g2": g2n, "partial": plan[1], "fold": f,
                                     "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope})

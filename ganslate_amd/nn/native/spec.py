@@ -165,6 +165,8 @@ class Lowered:
     dgrad: List[GConv] = field(default_factory=list)
     dgrad_index: Optional[np.ndarray] = None
     dgrad_fold: int = 0                           # dgrad output is padded by this much (reflect/replicate)
+    dgrad_ring: Optional[GConv] = None            # same gradient on the UNPADDED domain: zero-border class whose fused launch
+                                                  # applies the reflect fold itself (gs_gconv_ring_slots; same pack)
     wgrad: Optional[WGrad] = None
     Di: int = 1
     Do: int = 1
@@ -270,6 +272,9 @@ def lower(spec: ConvSpec, *sizes) -> Lowered:
                 low.dgrad = [gconv(outs, spec.cout_p, pad3, spec.cin_p, pad3, 1, (0, 0, 0), 1,
                                    off(lambda r, a: -r), "zero", 0, spec.cin_p)]
                 low.dgrad_fold = p
+                if spec.pad_mode == "reflect" and spec.dims == 2 and k == 3 and p == 1 and not wf:
+                    low.dgrad_ring = gconv(outs, spec.cout_p, ins, spec.cin_p, ins, 1, (0, 0, 0), 1,
+                                           off(lambda r, a: pa[a] - r), "zero", 0, spec.cin_p)
             low.dgrad_index = _pack_index(spec.cin_p, list(range(T)), spec.cout_p, m_tr).reshape(-1)
         else:
             assert spec.pad_mode == "zero", "strided convs use zero padding in the reference nets"

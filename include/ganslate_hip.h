@@ -124,6 +124,15 @@ typedef struct gs_gconv_fuse {
 } gs_gconv_fuse;
 int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
                            float* stats, const gs_gconv_fuse* fuse, void* stream);
+/* Unpadded form of the same launch for the reflect-padded (pad 1) wide 3x3 residual convs (resnet2d.py:80-87): when
+ * gs_gconv_ring_slots(d) > 0 for the ZERO-border data-gradient descriptor on the unpadded domain (Hi x Wi = Ho x Wo = the
+ * conv's input extent, taps t = 3*ry + rx at (dh, dw) = (1 - ry, 1 - rx)), gs_gconv_forward_fused may be called with that
+ * descriptor and fold = 1, fold_mode = reflect, Hy x Wy = Ho x Wo: the launch computes the gradient pixels one step
+ * outside the image as well and adds them to the pixels the reflection folds them onto (in fp32, before rounding), so
+ * `out` is the finished input gradient and the consumer runs with fold = 0. partial is [N][slots][3][C] with
+ * slots = gs_gconv_ring_slots(d). Returns 0 slots when the layer / grid does not suit the halo kernel; the padded form
+ * above is always available. */
+int gs_gconv_ring_slots(const gs_gconv_desc* d);
 /* Same launch as gs_gconv_forward with a caller-owned fp32 workspace for split-K: layers with few output tiles and a
  * long K loop (U-Net bottleneck convs unet2d.py:129-136, the PatchGAN 512->1 tail patchgan2d.py:62) run their K range
  * split over the chip and a second pass sums the partial results and applies bias / statistics / activation.

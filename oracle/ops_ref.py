@@ -81,6 +81,7 @@ class RefOps:
     def __init__(self, act_dtype=torch.bfloat16):
         # bf16 emulates the HIP storage precision; fp32 isolates the executor/lowering logic from rounding
         self.act_dtype = act_dtype
+        self.ring_min_blocks = 192     # the library's grid-size rule; tests lower it to walk the ring form at small batch
 
     def tile_m(self, g, N=1):
         return 1 << 30  # one statistics slot per class
@@ -90,6 +91,14 @@ class RefOps:
 
     def fused_norm_plan(self, g, N, C_, force=False):
         if g.so != 1 or g.si != 1 or g.Co <= 64 or g.Co != C_:
+            return None
+        return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
+
+    def fused_ring_plan(self, g, N, C_):
+        """the layers the library's gs_gconv_ring_slots accepts (hconvw.hip hconvw_ring_eligible), restated"""
+        if g is None or g.Co != C_ or g.T != 9 or g.Ci % 64 or g.Co % 128 or g.Ho % 16 or g.Wo % 16:
+            return None
+        if g.Ho < 32 or g.Wo < 32 or N * (g.Ho // 16) * (g.Wo // 16) * (g.Co // 128) < self.ring_min_blocks:
             return None
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
@@ -108,10 +117,14 @@ class RefOps:
         xin = _v5(x)[..., in_co:in_co + g.Ci].float()
         Wt = wpack[g.pack_offset:g.pack_offset + g.w_rows * g.Kp].view(g.w_rows, g.Kp).float()
         Wt = Wt[:g.Co, :g.T * g.Ci].reshape(g.Co, g.T, g.Ci)
+        # unpadded form of the fused data gradient (gs_gconv_ring_slots): the zero-border conv on the domain extended by
+        # the fold, folded in fp32 before the storage rounding
+        ring = fuse["fold"] if (fuse is not None and fuse["fold"] > 0 and
+                                tuple(fuse["y"].shape[-3:-1]) == (g.Ho, g.Wo)) else 0
         z = torch.arange(g.Dc) * g.si
-        i = torch.arange(g.Hc) * g.si
-        j = torch.arange(g.Wc) * g.si
-        acc = torch.zeros(N, g.Dc, g.Hc, g.Wc, g.Co)
+        i = torch.arange(-ring, g.Hc + ring) * g.si
+        j = torch.arange(-ring, g.Wc + ring) * g.si
+        acc = torch.zeros(N, g.Dc, g.Hc + 2 * ring, g.Wc + 2 * ring, g.Co)
         for t in range(g.T):
             iz, okz = _border(z + g.dd[t], g.Di, g.border)
             ih, okh = _border(i + g.dh[t], g.Hi, g.border)
@@ -125,6 +138,8 @@ class RefOps:
             sv = stats.view(N, stats_slots, 2, g.Co)
             sv[:, stats_slot0, 0] = acc.sum((1, 2, 3))
             sv[:, stats_slot0, 1] = (acc * acc).sum((1, 2, 3))
+        if ring:
+            acc = _fold(acc.squeeze(1), (g.Hc, g.Wc), ring, fuse["fold_mode"]).view(N, g.Dc, g.Hc, g.Wc, g.Co)
         acc = _act(acc, act, slope)
         oz = torch.arange(g.Dc) * g.so + g.pz
         oh = torch.arange(g.Hc) * g.so + g.py
@@ -135,7 +150,7 @@ class RefOps:
         _v5(out)[idx] = acc.to(out.dtype)
         if fuse is not None:   # gs_gconv_forward_fused: reduction pass of the consumer's InstanceNorm backward
             y, Cc = fuse["y"], g.Co
-            gf = _fold(out.float(), y.shape[1:-1], fuse["fold"], fuse["fold_mode"])
+            gf = out.float() if ring else _fold(out.float(), y.shape[1:-1], fuse["fold"], fuse["fold_mode"])
             if fuse.get("g2") is not None:
                 gf = gf + fuse["g2"].float()
             bc = (N,) + (1,) * (y.dim() - 2) + (Cc,)

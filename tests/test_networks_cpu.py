@@ -60,6 +60,24 @@ def test_resnet2d_forward_backward(fp32_oracle_backend):
     _compare(Resnet2D(3, 3, "instance", 3), torch_ref.Resnet2D(3, 3, 3), (2, 3, 32, 40), 131)
 
 
+def test_resnet2d_ring_form_of_the_residual_data_gradients():
+    """Lowered.dgrad_ring: the residual convs' fused data gradients on the unpadded domain (the launch folds the reflect
+    ring itself, gs_gconv_ring_slots) — walked here on the fp32 oracle backend against autograd at a size where the
+    residual stage (32 x 32 x 256) qualifies; the grid-size rule of the library is lowered so batch 1 takes the path."""
+    from ganslate_amd.nn.generators import Resnet2D
+    ops = RefOps(act_dtype=torch.float32)
+    ops.ring_min_blocks = 0
+    taken = []
+    plan = ops.fused_ring_plan
+    ops.fused_ring_plan = lambda g, N, C_: (taken.append(g is not None), plan(g, N, C_))[1]
+    backend.set_ops(ops)
+    try:
+        _compare(Resnet2D(3, 3, "instance", 2), torch_ref.Resnet2D(3, 3, 2), (1, 3, 128, 128), 134)
+    finally:
+        backend.set_ops(None)
+    assert sum(taken) == 4, taken      # both convs of both residual blocks
+
+
 def test_resnet2d_two_uses_accumulate(fp32_oracle_backend):
     from ganslate_amd.nn.generators import Resnet2D
     _compare(Resnet2D(3, 3, "instance", 2), torch_ref.Resnet2D(3, 3, 2), (1, 3, 32, 32), 32, use_twice=True)

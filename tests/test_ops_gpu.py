@@ -319,6 +319,55 @@ def test_dgrad_with_fused_norm_reduction(hip_ops, case, with_g2, act):
     close_bf16(res["hip"][2], res["ref"][3], "dy vs oracle")
 
 
+@pytest.mark.parametrize("case", [(256, 8, 64, 64), (256, 16, 32, 48), (128, 48, 32, 32), (256, 2, 96, 128)],
+                         ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none")])
+def test_dgrad_ring_form(hip_ops, case, with_g2, act):
+    """Unpadded (ring) form of the fused data gradient of a reflect-padded 3x3 conv (gs_gconv_ring_slots, hconvw.hip
+    RING): the finished input gradient equals the padded-domain launch folded by the consumer (same kernel family,
+    fold in fp32 before the rounding here, after it there), the oracle's restatement, and the epilogue sums drive
+    gs_inorm_act_backward to the same dy. resnet2d.py:80-87 backward."""
+    C, N, H, W = case
+    spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
+    low, master, bias, fpack, dpack = make_layer(spec, (H, W), 31)
+    assert low.dgrad_ring is not None
+    g = torch.Generator().manual_seed(32)
+    gy = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    y = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16)
+    g2 = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16) if with_g2 else None
+    res = {}
+    ref = RefOps()
+    ref.ring_min_blocks = 0
+    for name, ops, dev in (("ref", ref, "cpu"), ("hip", hip_ops, hip_ops.device)):
+        yd, g2d = y.to(dev), None if g2 is None else g2.to(dev)
+        part = torch.stack([yd.float().sum((1, 2)), (yd.float() ** 2).sum((1, 2))], 1).reshape(-1).contiguous()
+        mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+        ops.inorm_finalize(part, N, 1, C, H * W, mr)
+        ring = ops.fused_ring_plan(low.dgrad_ring, N, C)
+        assert ring is not None, "case must be eligible for the ring form"
+        fz = lambda partial, fold: {"y": yd, "mean_rstd": mr, "g2": g2d, "partial": partial, "fold": fold,
+                                    "fold_mode": "reflect", "act": act, "slope": 0.2}
+        gx = torch.zeros(N, H, W, C, dtype=torch.bfloat16, device=dev)
+        ops.gconv(low.dgrad_ring, gy.to(dev), dpack.to(dev), None, gx, fuse=fz(ring[1], 1))
+        plan = ops.fused_norm_plan(low.dgrad[0], N, C, force=True)
+        gp = torch.zeros(N, H + 2, W + 2, C, dtype=torch.bfloat16, device=dev)
+        ops.gconv(low.dgrad[0], gy.to(dev), dpack.to(dev), None, gp, fuse=fz(plan[1], 1))
+        dy_ring, dy_pad, tot_ring, tot_pad = (torch.empty_like(yd) for _ in range(4))
+        ops.inorm_act_backward(gx, g2d, yd, mr, dy_ring, tot_ring if with_g2 else None, fold=0, act=act, pre=ring)
+        ops.inorm_act_backward(gp, g2d, yd, mr, dy_pad, tot_pad, fold=1, fold_mode="reflect", act=act, pre=plan)
+        sums = ring[1][:N * ring[0] * 3 * C].view(N, ring[0], 3, C).sum(1)
+        sums_pad = plan[1][:N * plan[0] * 3 * C].view(N, plan[0], 3, C).sum(1)
+        res[name] = (gx, dy_ring, dy_pad, sums, sums_pad, tot_pad)
+    torch.cuda.synchronize()
+    close_bf16(res["hip"][0], res["ref"][0], "ring dgrad vs oracle")
+    # the padded launch rounds every padded-domain pixel to bf16 before the consumer folds it: up to 4 roundings at a corner
+    close_bf16(res["hip"][0], res["hip"][5].cpu() if not with_g2 else res["ref"][0], "ring dgrad vs padded launch folded")
+    close_f32(res["hip"][3], res["ref"][3], "ring partial sums", rel=3e-3)
+    close_f32(res["hip"][3], res["hip"][4].cpu(), "ring sums vs padded-launch sums", rel=2e-2)
+    close_bf16(res["hip"][1], res["ref"][1], "dy vs oracle")
+    close_bf16(res["hip"][1], res["hip"][2].cpu(), "dy: ring form vs padded form")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 256), (2, 17, 13, 64), (1, 32, 32, 8), (1, 5, 7, 512)])
 @pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
 @pytest.mark.parametrize("res", [False, True])
