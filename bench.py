@@ -27,9 +27,9 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROAR
 # HBM bytes per launch of the three residual-conv kernels at the headline shape, from rocprofv3 PMC passes (bench.py
 # cannot run the profiler on itself): 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction of
 # MI355X_MICROARCH.md. Filled from profiles/ by name; None = not measured for this build.
-# HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), profiles/r02_trunk_pmc.txt
-HBM_BYTES = {"rb_fwd": (42.6e6, "profiles/r02_trunk_pmc.txt"), "rb_dgrad": (68.7e6, "profiles/r02_trunk_pmc.txt"),
-             "rb_wgrad_pair": (109.2e6, "profiles/r02_trunk_pmc.txt")}
+# HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), profiles/r02_trunk_pmc_v2.txt
+HBM_BYTES = {"rb_fwd": (42.6e6, "profiles/r02_trunk_pmc_v2.txt"), "rb_dgrad": (67.3e6, "profiles/r02_trunk_pmc_v2.txt"),
+             "rb_wgrad_pair": (109.2e6, "profiles/r02_trunk_pmc_v2.txt")}
 
 
 def make_pix2pix_conf(batch, n_iters):
@@ -422,8 +422,11 @@ def main():
             res = ops.kernel_timing_result()
             hw = (args.size // 4) ** 2
             flop1 = 2.0 * hw * args.batch * 256 * 2304           # 2*M*N*K of one 3x3 256->256 conv over the batch
-            names = {"rb_fwd": "hconvw_kernel<9> (forward, halo-resident)",
-                     "rb_dgrad": "residual-conv data gradient (+ fused norm-backward reduction)",
+            names = {"rb_fwd": "hconvw_kernel<9, 16> (forward, halo-resident)",
+                     "rb_dgrad": ("hconvw_kernel<9, 16, RING> (data gradient on the unpadded domain, reflect ring "
+                                  "folded in-launch, fused norm-backward reduction)" if (ops.get_option("hconvw_ring") and rb_taps == 9)
+                                  else "gconv_kernel<288, 128> (data gradient on the padded domain + fused norm-backward "
+                                       "reduction)"),
                      "rb_wgrad_pair": "hwgrad_wide_kernel<9> (weight gradient of two backward passes in one launch)",
                      "rb_wgrad": "hwgrad_wide_kernel<9> (weight gradient, one pass)"}
             kernels = {}

@@ -98,3 +98,40 @@ def test_c_caller_sees_the_ctypes_layout(tmp_path):
     assert calls["tile_m"] == lib.gs_tile_m(ctypes.byref(d)) > 0
     assert calls["splitk_ws_floats"] == lib.gs_gconv_splitk_ws_floats(ctypes.byref(d)) == 0
     assert calls["tail_splitk_ws_floats"] > 0
+
+
+def test_ring_form_eligibility_rule_matches_the_oracle_restatement():
+    """gs_gconv_ring_slots (pure host code, callable without a GPU) and RefOps.fused_ring_plan, which walks the same
+    executor branch on CPU, must accept the same data-gradient classes: the zero-border, unpadded descriptor of a
+    reflect-padded 3x3 stride-1 conv with Ci % 64 == Co % 128 == 0, sides multiples of 16 and >= 32, >= 192 boxes x
+    channel tiles (hconvw.hip hconvw_ring_eligible)."""
+    import types
+    from ganslate_amd.hip import lib as L
+    from ganslate_amd.hip.ops import HipOps
+    from ganslate_amd.nn.native.spec import ConvSpec, lower
+    from oracle.ops_ref import RefOps
+    lib = L.load()
+    ref = RefOps()
+    shim = types.SimpleNamespace(_desc_cache={})
+    seen = set()
+    for cin, cout, N, H, W, mode in [(256, 256, 8, 64, 64, "reflect"), (256, 256, 1, 64, 64, "reflect"),
+                                     (256, 256, 6, 64, 64, "reflect"), (128, 128, 48, 32, 32, "reflect"),
+                                     (128, 64, 48, 32, 32, "reflect"), (256, 256, 64, 16, 16, "reflect"),
+                                     (256, 256, 8, 64, 72, "reflect"), (256, 256, 2, 96, 128, "reflect"),
+                                     (64, 128, 48, 32, 32, "reflect"), (256, 256, 8, 64, 64, "replicate"),
+                                     (256, 256, 8, 64, 64, "zero")]:
+        low = lower(ConvSpec("conv", cin, cout, 3, 1, 1, pad_mode=mode), H, W)
+        g = low.dgrad_ring
+        assert (g is not None) == (mode == "reflect")
+        if g is None:
+            continue
+        assert (g.Hi, g.Wi, g.Ho, g.Wo, g.border) == (H, W, H, W, "zero")
+        assert [(a, b) for a, b in zip(g.dh, g.dw)] == [(1 - t // 3, 1 - t % 3) for t in range(9)]
+        d = HipOps._gdesc(shim, g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
+        slots = lib.gs_gconv_ring_slots(ctypes.byref(d))
+        plan = ref.fused_ring_plan(g, N, low.spec.cin_p)
+        assert (slots > 0) == (plan is not None), (cin, cout, N, H, W, slots)
+        if slots:
+            assert slots == (H // 16) * (W // 16)
+        seen.add(slots > 0)
+    assert seen == {True, False}

@@ -162,6 +162,21 @@ def test_kernel_selection_switches_do_not_change_gradients_2d(hip_ops, var, monk
     _assert_same(res["1"], res["0"], var, SWITCH_TOL[var])
 
 
+def test_ring_form_of_the_data_gradient_does_not_change_gradients(hip_ops, monkeypatch):
+    """headline shape (batch 8, 256 x 256: the residual stage qualifies for gs_gconv_ring_slots): step-0 gradients with
+    the residual data gradients on the unpadded domain (GS_HCONVW_RING=1, reflect ring folded inside the launch in fp32)
+    and on the padded domain (=0, every padded-domain pixel rounded to bf16, then folded by the consumer). Same
+    products, another rounding placement: the tolerance of GS_FUSE_NORM."""
+    c = load_golden_grads()["cfg2_256_b8"]["config"]
+    res = {}
+    for val in ("1", "0"):
+        monkeypatch.setenv("GS_HCONVW_RING", val)
+        random.seed(c["seed"])
+        res[val] = product_step0_grads(c)[1]
+    assert hip_ops.get_option("hconvw_ring") == 0      # the switch reached the library
+    _assert_same(res["1"], res["0"], "GS_HCONVW_RING", SWITCH_TOL["GS_FUSE_NORM"])
+
+
 @pytest.mark.parametrize("var", ["GS_WGRAD_PAIR", "GS_HWGRAD_PLANES", "GS_FUSE_NORM"])
 def test_kernel_selection_switches_do_not_change_gradients_3d(hip_ops, var, monkeypatch):
     c = dict(load_golden_volumes()["steps"]["v32_default"]["config"])

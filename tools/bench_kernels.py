@@ -44,7 +44,7 @@ def main():
     dev = ops.device
     for name, case in CASES.items():
         spec, N, sizes = case[0], case[1], case[2:]
-        if args.only and not any(args.only in f"{name}_{k}" for k in ("fwd", "dgrad", "wgrad")):
+        if args.only and not any(args.only in f"{name}_{k}" for k in ("fwd", "dgrad", "wgrad", "dgradf")):
             continue
         low = lower(spec, *sizes)
         in_px = 1
@@ -79,7 +79,26 @@ def main():
         def wgrad():
             ops.wgrad(low.wgrad, a, gt, dw)
 
-        for kind, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+        kinds = [("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)]
+        # fused data gradient (consumer's norm-backward sums in the epilogue): ring form where the library offers it
+        plan = ops.fused_norm_plan(low.dgrad[0], N, spec.cin_p) if (spec.kind == "conv" and len(low.dgrad) == 1) else None
+        if plan is not None:
+            ring = ops.fused_ring_plan(low.dgrad_ring, N, spec.cin_p)
+            yprev = torch.randn(N, *sizes, spec.cin_p, device=dev).to(torch.bfloat16)
+            g2 = torch.randn(N, *sizes, spec.cin_p, device=dev).to(torch.bfloat16)
+            mr = torch.ones(N * 2 * spec.cin_p, device=dev)
+            gxr = torch.empty(N, *sizes, spec.cin_p, device=dev, dtype=torch.bfloat16)
+            fz = {"y": yprev, "mean_rstd": mr, "g2": g2, "partial": (ring or plan)[1], "fold": low.dgrad_fold,
+                  "fold_mode": spec.pad_mode if low.dgrad_fold else "reflect", "act": "relu", "slope": 0.2}
+
+            def dgradf():
+                if ring is not None:
+                    ops.gconv(low.dgrad_ring, gy, dpack, None, gxr, fuse=fz)
+                else:
+                    ops.gconv(low.dgrad[0], gy, dpack, None, gx, fuse=fz)
+            kinds.append(("dgradf", dgradf))
+
+        for kind, fn in kinds:
             tag = f"{name}_{kind}"
             if args.only and args.only not in tag:
                 continue
