@@ -135,6 +135,10 @@ _PROTOS = {
     "gs_u8_resample_v_crop_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_patch_zscore_ws_floats": (C.c_int64, []),
+    "gs_patch_zscore": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "gs_mse_const": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_adv_loss": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p]),

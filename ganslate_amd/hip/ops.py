@@ -491,6 +491,22 @@ class HipOps:
                                                          int(bool(flip)), _stream()),
                 "gs_u8_resample_v_crop_normalize")
 
+    VOL_DTYPES = {torch.float32: 0, torch.int16: 1}
+
+    def patch_zscore(self, volume, start, size, out, scale_to_range=(-1.0, 1.0)):
+        """gs_patch_zscore: out (d, h, w) fp32 = z_score_normalize(volume[z:z+d, y:y+h, x:x+w], scale_to_range) for a dense
+        (D, H, W) fp32 / int16 volume resident on the device (normalization.py:18-30); scale_to_range None: plain z-score"""
+        assert volume.dim() == 3 and volume.is_contiguous() and volume.dtype in self.VOL_DTYPES, (volume.shape, volume.dtype)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == size[0] * size[1] * size[2]
+        nws = getattr(self, "_patch_ws", None) or int(self.lib.gs_patch_zscore_ws_floats())
+        self._patch_ws = nws
+        ws = torch.empty(nws, dtype=torch.float32, device=self.device)        # per launch: stream-safe through the allocator
+        st, sz = (C.c_int32 * 3)(*[int(v) for v in start]), (C.c_int32 * 3)(*[int(v) for v in size])
+        lo, hi = scale_to_range if scale_to_range else (0.0, 0.0)
+        L.check(self.lib.gs_patch_zscore(_ptr(volume), self.VOL_DTYPES[volume.dtype], *volume.shape, st, sz,
+                                         int(bool(scale_to_range)), float(lo), float(hi), _ptr(out), _ptr(ws), _stream()),
+                "gs_patch_zscore")
+
     ADV_MODES = {"lsgan": 0, "vanilla": 1, "wgangp": 2, "nonsaturating": 3}
 
     def adv_loss(self, x, mode, target_is_real, label, loss=None, grad=None, grad_scale=None):

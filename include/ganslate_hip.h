@@ -320,6 +320,19 @@ int gs_u8_resample_v_crop_normalize(const void* tmp, float* out, int32_t tmp_h, 
                                     const int32_t* bounds, const int32_t* kk, int32_t ksize, int32_t top, int32_t left,
                                     int32_t fh, int32_t fw, int32_t flip, void* stream);
 
+/* ---- device-side 3-D training patches ------------------------------------------- */
+/* What the 3-D datasets' workers do per sample on the host (projects/brats_mri_sequence_translation/datasets/
+ * train_dataset.py:83-86 -> ganslate/data/utils/normalization.py:18-30): out = z_score_normalize(volume[z:z+d, y:y+h,
+ * x:x+w], scale_to_range=(lo, hi)) — t = (v - mean) / std with the patch's own mean and unbiased std, then
+ * (hi - lo) * (t - min t) / (max t - min t) + lo when rescale != 0 — on a dense D x H x W volume resident in device
+ * memory (dtype GS_VOL_F32 or GS_VOL_I16). start / size: host arrays {z, y, x} / {d, h, w}; out: d*h*w floats;
+ * scratch: gs_patch_zscore_ws_floats() floats, 8-byte aligned, private to the launch. A constant patch gives NaN, as in
+ * the reference. The start coordinates come from data/utils/stochastic_focal_patching.py (host RNG). */
+enum { GS_VOL_F32 = 0, GS_VOL_I16 = 1 };
+int64_t gs_patch_zscore_ws_floats(void);
+int gs_patch_zscore(const void* vol, int32_t dtype, int32_t D, int32_t H, int32_t W, const int32_t* start,
+                    const int32_t* size, int32_t rescale, float lo, float hi, float* out, float* scratch, void* stream);
+
 /* ---- losses (fp32, on the boundary images / discriminator maps) --------------------------------- */
 /* loss[0] = mean((x-target)^2); if grad != NULL: grad = grad_scale * 2*(x-target)/n
  * (nn.MSELoss vs expanded constant, adversarial_loss.py:28-29,60-62) */

@@ -6,6 +6,7 @@
     python -m oracle.gen_golden_r2 advmodes    # tests/golden/adv_modes.json
     python -m oracle.gen_golden_r2 vnet2d      # tests/golden/vnet2d.json
     python -m oracle.gen_golden_r2 revgan      # tests/golden/revgan.json
+    python -m oracle.gen_golden_r2 volpatch    # tests/golden/volume_patches.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -18,6 +19,11 @@
 * adv_modes.json — the objectives of AdversarialLoss other than lsgan (adversarial_loss.py:26-34,60-67): its value and
   input gradient on a seeded discriminator map, and four CycleGAN iterations with `adversarial_loss_type` vanilla /
   wgangp. (`nonsaturating` cannot be recorded: the reference's branch raises NameError, :68-73.)
+* volume_patches.json — the 3-D training-patch path of the volume datasets (projects/brats_mri_sequence_translation/
+  datasets/train_dataset.py:76-85): `StochasticFocalPatchSampler.get_patch_pair` (data/utils/stochastic_focal_patching.py)
+  under `random.seed(s)` — the patch start coordinates it draws for volumes of given shapes, several draws per case — and
+  `z_score_normalize(patch, scale_to_range=(-1, 1))` (data/utils/normalization.py:18-30) of the first pair's patches on
+  seeded volumes (samples + moments), plus `min_max_normalize` and `z_score_normalize_with_precomputed_stats`.
 """
 import json
 import random
@@ -270,9 +276,77 @@ def revgan():
     (OUT / "revgan.json").write_text(json.dumps({"nets": nets, "steps": steps}, indent=1))
 
 
+VOLPATCH_CASES = {
+    # name: (shape_A, shape_B, patch_size, focal_region_proportion, seed, draws)
+    "brats_like": ((20, 36, 30), (24, 33, 31), (8, 16, 16), 0.0, 5, 4),
+    "focal_0.2": ((20, 36, 30), (24, 33, 31), (8, 16, 16), 0.2, 6, 4),
+    "focal_0.5_tight": ((9, 18, 17), (8, 16, 20), (8, 16, 16), 0.5, 7, 4),
+    "patch_2d": ((5, 40, 44), (6, 41, 39), (32, 32), 0.3, 8, 3),
+    "exact_fit": ((8, 16, 16), (8, 16, 16), (8, 16, 16), 0.4, 9, 2),
+}
+
+
+def _seeded_volume(shape, seed):
+    """MRI-like intensities: non-negative, skewed, with a zero background slab (numpy Generator: stable across versions)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    v = rng.gamma(2.0, 180.0, size=shape).astype(np.float32)
+    v[: max(1, shape[0] // 5)] = 0.0
+    return torch.from_numpy(np.round(v))
+
+
+def volpatch():
+    from oracle import gen_golden as G          # noqa: F401  (puts the reference on sys.path)
+    import numpy as np
+    from ganslate.data.utils.normalization import (min_max_normalize, z_score_normalize,
+                                                   z_score_normalize_with_precomputed_stats)
+    from ganslate.data.utils.stochastic_focal_patching import StochasticFocalPatchSampler
+    out = {}
+    for name, (sa, sb, ps, frp, seed, draws) in VOLPATCH_CASES.items():
+        A, B = _seeded_volume(sa, seed), _seeded_volume(sb, seed + 100)
+        sampler = StochasticFocalPatchSampler(np.array(ps), frp)
+        random.seed(seed)
+        recs = []
+        for d in range(draws):
+            st = random.getstate()
+            pa, pb = sampler.get_patch_pair(A, B)
+            # recover the starts the sampler drew: replay its two public steps under the same RNG state
+            random.setstate(st)
+            za, xa, ya = sampler.pick_random_start(A)
+            rel = sampler.calculate_relative_focal_point(za, xa, ya, A)
+            zb, xb, yb = sampler.pick_stochastic_focal_start(B, rel)
+            full = [1, *ps] if len(ps) == 2 else list(ps)
+            assert torch.equal(pa.reshape(full), A[za:za + full[0], xa:xa + full[1], ya:ya + full[2]])
+            assert torch.equal(pb.reshape(full), B[zb:zb + full[0], xb:xb + full[1], yb:yb + full[2]])
+            rec = {"start_A": [int(za), int(xa), int(ya)], "start_B": [int(zb), int(xb), int(yb)],
+                   "shape": list(pa.shape)}
+            if d == 0:
+                for key, patch in (("A", pa), ("B", pb)):
+                    z = z_score_normalize(patch.clone(), scale_to_range=(-1, 1))
+                    flat = z.flatten()
+                    idx = torch.linspace(0, flat.numel() - 1, 16).long()
+                    rec["z_" + key] = {"samples_at": idx.tolist(), "samples": flat[idx].tolist(),
+                                       "mean": float(flat.double().mean()), "sq": float((flat.double() ** 2).mean()),
+                                       "min": float(flat.min()), "max": float(flat.max()),
+                                       "patch_mean": float(patch.mean()), "patch_std": float(patch.std())}
+                    plain = z_score_normalize(patch.clone())
+                    rec["z_plain_" + key] = plain.flatten()[idx].tolist()
+                mm = min_max_normalize(pa.clone(), 0.0, 1500.0).flatten()
+                rec["minmax_A"] = mm[idx].tolist()
+                pre = z_score_normalize_with_precomputed_stats(pa.clone(), (210.0, 95.0), original_scale=(0.0, 1800.0),
+                                                               scale_to_range=(-1, 1)).flatten()
+                rec["precomputed_A"] = pre[idx].tolist()
+            recs.append(rec)
+        out[name] = {"shape_A": list(sa), "shape_B": list(sb), "patch_size": list(ps), "focal_region_proportion": frp,
+                     "seed": seed, "draws": recs}
+    (OUT / "volume_patches.json").write_text(json.dumps({"torch": torch.__version__, "cases": out}, indent=1))
+
+
 def main():
     what = sys.argv[1]
-    if what == "fullsize":
+    if what == "volpatch":
+        volpatch()
+    elif what == "fullsize":
         fullsize()
     elif what == "revgan":
         revgan()

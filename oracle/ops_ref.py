@@ -479,6 +479,18 @@ class RefOps:
             gz[..., dw:dw + W, dw * Co:(dw + 1) * Co] = gl.to(gz.dtype)
 
     # ---- losses -----------------------------------------------------------------------------------------
+    # ---- device-side 3-D training patches: the reference's own expression (normalization.py:18-30) ---------------------
+    def patch_zscore(self, volume, start, size, out, scale_to_range=(-1.0, 1.0)):
+        z, y, x = start
+        d, h, w = size
+        t = volume[z:z + d, y:y + h, x:x + w].float()
+        t = (t - t.mean()) / t.std()
+        if scale_to_range:
+            delta1 = t.max() - t.min()
+            delta2 = scale_to_range[1] - scale_to_range[0]
+            t = (delta2 * (t - t.min()) / delta1) + scale_to_range[0]
+        out.copy_(t.reshape(out.shape))
+
     # ---- device-side image preprocessing (oracle/pil_ref.py: Pillow's resampler restated) ---------------------------
     def u8_resample_h(self, img, out, bounds, kk):
         """out[y][xx][c] = clip8((2^21 + sum_k img[y][xmin + k][c] * kk[xx][k]) >> 22) from the tables as given"""
