@@ -6,7 +6,8 @@
 #include <mutex>
 
 namespace {
-char g_err[512] = "";
+thread_local char g_err[512] = "";   // per host thread: autograd runs backward launches on its own threads, and a caller
+                                      // reads the message right after the failing call on the thread that made it
 void* g_zero = nullptr;      // 256-byte zero page: source of masked LDS-DMA lanes
 // Loss reductions: 1024 partials + 1 arrival counter per workspace. Launches on one stream are ordered and share a
 // workspace; launches on different streams may overlap (the discriminator pass runs beside the generators' backward),

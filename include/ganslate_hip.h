@@ -10,7 +10,10 @@
  *   - every call enqueues on the caller's `stream` (a hipStream_t passed as void*) and never
  *     synchronises; the caller owns all tensors, the library owns nothing but a 256-byte zero page;
  *   - return value 0 = ok, non-zero = error, message via gs_last_error();
- *   - not thread-safe per process (one process per GPU, like the reference's DDP launch).
+ *   - one process per GPU, like the reference's DDP launch: the library's state (zero page, loss-reduction workspaces per
+ *     launching stream, kernel-selection options) is per process. Launch calls may come from several host threads (the
+ *     autograd engine runs backward on its own): workspace assignment is locked and gs_last_error() is per thread — read
+ *     it on the thread whose call failed. gs_set_option is not synchronised against concurrent launches.
  *
  * Data layout: activations are NHWC bf16 with the channel count padded to a multiple
  * of 8 ("act" below); images at the network boundary are NCHW fp32 exactly as the reference's
