@@ -1,2 +1,3 @@
 from .patchgan.patchgan2d import PatchGAN2D, PatchGAN2DConfig  # noqa: F401
 from .patchgan.patchgan3d import PatchGAN3D, PatchGAN3DConfig  # noqa: F401
+from .patchgan.multiscale_patchgan3d import MultiScalePatchGAN3D, MultiScalePatchGAN3DConfig  # noqa: F401

@@ -163,7 +163,9 @@ class BaseGAN(ABC):
         from ..native.backend import get_ops
         self._graph, self._graph_shapes, self._graph_calls, self._graph_broken = None, None, 0, False
         self._graph_update = None
-        self.step_graph_enabled = (self.graph_capturable and os.environ.get("GS_STEP_GRAPH", "1") != "0"
+        nets_capturable = all(getattr(net, "graph_capturable", True) for net in self.networks.values())
+        self.step_graph_enabled = (self.graph_capturable and nets_capturable
+                                   and os.environ.get("GS_STEP_GRAPH", "1") != "0"
                                    and getattr(get_ops(), "name", "") == "hip" and self.device.type == "cuda")
         if self.device.type == "cuda":
             self._side = {n: {"stream": torch.cuda.Stream(device=self.device), "fork": None, "busy": False}
@@ -172,8 +174,15 @@ class BaseGAN(ABC):
             self._eager_set_input, self._eager_step = self.set_input, self.optimize_parameters
             self.set_input, self.optimize_parameters = self._graph_set_input, self._graph_step
 
+    def _native_nets(self):
+        """the executors behind `networks`: a composite (MultiScalePatchGAN3D: one PatchGAN3D per scale) counts as its parts"""
+        out = []
+        for net in self.networks.values():
+            out.extend(net.native_children() if hasattr(net, "native_children") else [net])
+        return out
+
     def _data_parallel_nets(self):
-        return [net for net in self.networks.values() if getattr(net, "_dist", None) is not None]
+        return [net for net in self._native_nets() if getattr(net, "_dist", None) is not None]
 
     def _step_pools(self):
         """ImagePools in the order optimize_parameters queries them (their coin flips are drawn before a replay)"""
@@ -184,7 +193,7 @@ class BaseGAN(ABC):
             optim.external_prepare = on
         for pool in self._step_pools():
             pool.external_draw = on
-        for net in self.networks.values():          # per-iteration host state of the networks (dropout seeds)
+        for net in self._native_nets():             # per-iteration host state of the networks (dropout seeds)
             if hasattr(net, "external_draw"):
                 net.external_draw = on
 
@@ -196,7 +205,7 @@ class BaseGAN(ABC):
             pool.draw(batch)
         for optim in self.optimizers.values():
             optim.prepare()
-        for net in self.networks.values():
+        for net in self._native_nets():
             if hasattr(net, "prepare_host_state"):
                 net.prepare_host_state()
 

@@ -15,7 +15,9 @@ class TrainingMetrics:
         if not self.output_distributions:
             return None
         if isinstance(out, dict):
-            return torch.stack([mean_nograd(e) for e in out.values()])
+            # multi-scale discriminators: the reference builds the per-scale means and then falls off the end of its `if`
+            # (train_metrics.py:22-25: no return on this branch), so the metric is None and the tracker drops it. Kept.
+            return None
         return mean_nograd(out) if out.dim() > 1 else out.detach()
 
     def get_SSIM_metric(self, input, target):

@@ -7,6 +7,7 @@
     python -m oracle.gen_golden_r2 vnet2d      # tests/golden/vnet2d.json
     python -m oracle.gen_golden_r2 revgan      # tests/golden/revgan.json
     python -m oracle.gen_golden_r2 volpatch    # tests/golden/volume_patches.json
+    python -m oracle.gen_golden_r2 multiscale  # tests/golden/multiscale_patchgan3d.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -342,9 +343,48 @@ def volpatch():
     (OUT / "volume_patches.json").write_text(json.dumps({"torch": torch.__version__, "cases": out}, indent=1))
 
 
+MULTISCALE_CASES = {
+    # name: (in_channels, ndf, n_layers, scales, batch, (D, H, W), seed)
+    "s2_default_layers": (1, 4, 3, 2, 1, (64, 64, 72), 3),
+    "s2_two_layers": (1, 8, 2, 2, 2, (32, 40, 48), 5),
+    "s3_one_layer": (2, 8, 1, 3, 1, (24, 36, 30), 4),
+}
+
+
+def multiscale():
+    """the REAL MultiScalePatchGAN3D (multiscale_patchgan3d.py:44-60, over the monai stand-in) with seeded weights: the
+    per-scale maps, input gradient and parameter-gradient norms of sum_s mean(map_s^2) under random.seed(seed)"""
+    from oracle import gen_golden as G          # noqa: F401  (puts the reference on sys.path)
+    from ganslate.nn.discriminators.patchgan.multiscale_patchgan3d import MultiScalePatchGAN3D
+    from oracle.torch_ref import seeded_state_dict
+    out = {}
+    for name, (cin, ndf, nl, scales, B, dims, seed) in MULTISCALE_CASES.items():
+        net = MultiScalePatchGAN3D(cin, ndf, nl, (4, 4, 4), scales, "instance")
+        net.load_state_dict(seeded_state_dict(net, seed))
+        g = torch.Generator().manual_seed(seed)
+        x = (torch.rand((B, cin, *dims), generator=g) * 2 - 1).requires_grad_()
+        random.seed(seed)
+        maps = net(x)
+        loss = sum((m ** 2).mean() for m in maps.values())
+        loss.backward()
+        rec = {"config": dict(in_channels=cin, ndf=ndf, n_layers=nl, scales=scales, batch=B, dims=list(dims), seed=seed),
+               "keys": list(net.state_dict().keys()), "maps": {}, "loss": float(loss),
+               "input_grad": {"norm": float(x.grad.norm()), "nonzero": int((x.grad != 0).sum())},
+               "param_grad_norms": {k: float(p.grad.norm()) for k, p in net.named_parameters()}}
+        for s, m in maps.items():
+            flat = m.detach().flatten()
+            idx = torch.linspace(0, flat.numel() - 1, 12).long()
+            rec["maps"][s] = {"shape": list(m.shape), "samples_at": idx.tolist(), "samples": flat[idx].tolist(),
+                              "norm": float(flat.norm())}
+        out[name] = rec
+    (OUT / "multiscale_patchgan3d.json").write_text(json.dumps(out, indent=1))
+
+
 def main():
     what = sys.argv[1]
-    if what == "volpatch":
+    if what == "multiscale":
+        multiscale()
+    elif what == "volpatch":
         volpatch()
     elif what == "fullsize":
         fullsize()

@@ -1,1 +1,2 @@
-"""Empty stand-in for `monai` (oracle-only)."""
+"""Stand-in for `monai` (oracle-only): the one transform the reference's networks call lives in .transforms."""
+from . import transforms  # noqa: F401

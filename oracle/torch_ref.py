@@ -130,6 +130,30 @@ class PatchGAN3D(nn.Module):
         return self.model(x)
 
 
+class MultiScalePatchGAN3D(nn.Module):
+    """ganslate/nn/discriminators/patchgan/multiscale_patchgan3d.py:44-60 restated: one PatchGAN3D per scale in an
+    nn.ModuleDict keyed "1".."scales"; scale s sees a random window of the input with spatial extents // s (one window per
+    call, shared by the batch). The window start is drawn with Python's `random` (one randint per shrinking axis, D-H-W
+    order) — see oracle/ref_stubs/monai/transforms for why the reference's own draws cannot be pinned."""
+
+    def __init__(self, in_channels, ndf=64, n_layers=3, kernel_size=4, scales=2):
+        super().__init__()
+        self.model = nn.ModuleDict({str(s): PatchGAN3D(in_channels, ndf, n_layers, kernel_size)
+                                    for s in range(1, scales + 1)})
+
+    @staticmethod
+    def crop(x, scale):
+        import random
+        if scale == 1:
+            return x
+        sizes = [x.shape[a] // scale for a in (2, 3, 4)]
+        st = [random.randint(0, x.shape[a] - n) if x.shape[a] > n else 0 for a, n in zip((2, 3, 4), sizes)]
+        return x[:, :, st[0]:st[0] + sizes[0], st[1]:st[1] + sizes[1], st[2]:st[2] + sizes[2]]
+
+    def forward(self, x):
+        return {s: m(self.crop(x, int(s))) for s, m in self.model.items()}
+
+
 class _UnetBlock(nn.Module):
     """ganslate/nn/generators/unet/unet2d.py:80-157 restated"""
 
