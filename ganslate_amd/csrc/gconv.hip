@@ -648,6 +648,10 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
                   void* stream, int* handled);
 int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, void* out, const gs_gconv_fuse* fuse,
                    void* stream);
+// hconvt.hip: the four parity classes of a stride-2 layer out of one halo-resident pass
+int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count);
+int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
+                     const float* bias, void* out, float* stats, void* stream);
 
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
 
@@ -823,6 +827,13 @@ extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t
                  (long long)d->Di * d->Hi * d->Wi * d->in_cs * 2 < (1LL << 32),
              "gs_gconv_forward_multi: class extent too large");
   GS_REQUIRE(d->stats_slots == 0 || stats, "gs_gconv_forward_multi: stats requested without buffer");
+  for (int c = 0; c < count; ++c)
+    GS_REQUIRE(descs[c]->Kp % 64 == 0 && descs[c]->Kp >= descs[c]->T * descs[c]->Ci, "gs_gconv_forward_multi: bad Kp=%d",
+               descs[c]->Kp);
+  {
+    const int pat = gs_hconvt_pattern(descs, count);      // 2-D k3 / k4 stride-2 layers with 64-multiple channels: one pass
+    if (pat >= 0) return gs_hconvt_launch(descs, pat, in, w_packs, bias, out, stats, stream);
+  }
   // the tile one class alone would get: the statistics slots (gs_gconv_stat_slots) are counted per class from it
   const TileCfg tc = pick_tile(d);
   static GConvK k;      // ~3 KB: filled per call, passed by value to the launch

@@ -1,0 +1,387 @@
+// Halo-resident kernel for the output-parity classes of a stride-2 layer in ONE pass over the input: the forward of
+// ConvTranspose2d(k3, s2, p1, op1) (resnet2d.py:52-57: u128, u64 — classes of 1 / 2 / 2 / 4 taps) and the data gradient of a
+// stride-2 conv (resnet2d.py:35 backward: same classes; patchgan2d.py:36-48 backward, k4: 4 / 4 / 4 / 4 taps).
+//
+// gs_gconv_forward_multi runs these as im2col tiles: every class gathers every input pixel once per tap from L2 — 442 MB
+// of L2 -> LDS traffic for the 100 MB u64 layer at ~4.7 TB/s, whatever the tile size. All classes read
+// the SAME input through offsets inside a 3 x 3 window, so here a workgroup owns a 16 x 16 box of class-grid pixels,
+// stages its 18 x 18 halo box ONCE per 64-channel chunk (double-buffered LDS-DMA, like hconvw.hip) and runs every
+// (class, tap) K-step out of it: 51 KB of halo + 8 KB of weights per K-step instead of 16 + 8 KB per K-step per 128
+// pixels. A wave holds 64 pixels x 16 output channels of ALL four classes (64 accumulator registers); weights stream
+// through a 3-slot ring of PAIRS of K-steps (one 1-KiB DMA instruction per wave per pair). Fragment reads roll two
+// half-K-step sets ahead of the MFMAs with counted waits (common.hpp). Epilogue: bias, statistics (one slot per box over
+// all classes, the rest of the layer's slots zeroed), activation, class by class through an LDS slab into 128-B stores at
+// out[2i + py][2j + px].
+#include "common.hpp"
+#include <cstdlib>
+
+namespace {
+constexpr int NC = 4;
+struct HConvTK {
+  const char* in;
+  const char* w;               // class 0's pack; w_off[c] = byte offset of class c's [w_rows][Kp] block
+  const float* bias;
+  char* out;
+  float* stats;
+  const char* zero;
+  long long w_off[NC];
+  int kp[NC], py[NC], px[NC];
+  int tb[16];                  // halo byte offset of K-step s of a chunk (tap offset relative to the window's corner)
+  int wtap[16];                // tap index inside its class of K-step s (k offset = wtap * Ci + chunk * 64)
+  int tiles_m, tiles_n, nbw, hmin, wmin, chunks;
+  gs_gconv_desc d;             // class 0's descriptor (shared fields)
+};
+
+// PAT 0: taps per class 1 / 2 / 2 / 4 (k3 transposed conv / stride-2 k3 gradient), PAT 1: 4 / 4 / 4 / 4 (k4)
+template <int PAT> struct Pat;
+template <> struct Pat<0> { static constexpr int NS = 9; static constexpr int CPS = 2; };
+template <> struct Pat<1> { static constexpr int NS = 16; static constexpr int CPS = 1; };
+template <int PAT>
+__device__ __host__ constexpr int cls_of(int s) {
+  if (PAT == 0) return s < 1 ? 0 : (s < 3 ? 1 : (s < 5 ? 2 : 3));
+  return s >> 2;
+}
+
+template <int PAT>
+__global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
+  // 8 waves as 4 (pixel rows) x 2 (channels): 64 pixels x 32 channels x 4 classes = 128 accumulator registers per lane —
+  // the 16-wave split (64 x 16 per wave) fits the 128-VGPR cap only with spills, whose reloads wait vmcnt(0) right behind
+  // the weight DMA (measured 80 us for the u64 layer against 93 on the im2col path)
+  constexpr int NW = 8, BN = 64, TI = 2, WPI = 2;
+  constexpr int NS = Pat<PAT>::NS, CPS = Pat<PAT>::CPS;      // K-steps per chunk, chunks per unrolled super-chunk
+  constexpr int NPAIR = NS * CPS / 2;                        // pairs of K-steps per super-chunk
+  constexpr int WT = 2 * BN * 128;                           // weight stage: a PAIR of K-steps, 64 rows x 64 k each
+  constexpr int HP = 160, HPIECES = 18 * 18 * 10, HINSTR = (HPIECES + 63) / 64, HBUF = HINSTR * 1024;
+  constexpr int HPW = (HINSTR + NW - 1) / NW;
+  constexpr int TJ = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wring = smem;                                        // 3 x 16 KiB
+  char* hbuf = smem + 3 * WT;                                // 2 x 51 KiB
+  char* sink = hbuf + 2 * HBUF;                              // 1 KiB
+  const gs_gconv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int b;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int nt = b % p.tiles_n;
+  b /= p.tiles_n;
+  const int mt = b % p.tiles_m;
+  const int n = b / p.tiles_m;
+  const int oy0 = (mt / p.nbw) * 16, ox0 = (mt % p.nbw) * 16;      // class-grid coordinates of the box
+
+  // ---- halo pieces of this thread: source byte offset of channel chunk 0, or -1 (zero border) ----
+  const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+  // (recomputed at every issue — a few dozen VALU instructions two times per super-chunk — instead of held in registers:
+  //  the 64 accumulator + 40 fragment registers leave no room for them under the 128-VGPR cap of a 16-wave workgroup)
+  auto issue_halo = [&](int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      int q = (i * NW + wave) * 64 + lane;
+      asm volatile("" : "+v"(q));
+      const int v = q / 10, part = q - v * 10;
+      const int hy = v / 18, hx = v - hy * 18;
+      const int iy = oy0 + hy + p.hmin, ix = ox0 + hx + p.wmin;
+      const bool ok = q < HPIECES && part < 8 && (unsigned)iy < (unsigned)d.Hi && (unsigned)ix < (unsigned)d.Wi;
+      const unsigned off = (unsigned)(((iy * d.Wi + ix) * d.in_cs + part * 8) * 2) + (unsigned)chunk * 128u;
+      const char* src = ok ? in_n + off : p.zero;
+      const int inst = i * NW + wave;
+      glds16(src, inst < HINSTR ? hbuf + buf * HBUF + inst * 1024 : sink);
+    }
+  };
+  // ---- weight stage of a pair (s0, s0 + 1) of K-steps: waves 0-7 bring step s0's 64 rows, waves 8-15 step s0 + 1's ----
+  const int lrow = lane >> 3;
+  const int wpiece = (lane & 7) ^ lrow;
+  const int wrow0 = nt * BN + (wave & 3) * 16 + lrow;        // output channel this lane fetches (+ 8 for its second instruction)
+  auto issue_w = [&](int chunk, int s, int stage) {          // s: this wave's K-step inside its chunk (compile-time after unrolling)
+    const int c = cls_of<PAT>(s);
+    int wr = wrow0;
+    asm volatile("" : "+v"(wr));                             // keep the 18 per-step addresses out of loop-invariant registers
+    const char* base = p.w + (p.w_off[c] + ((long long)p.wtap[s] * d.Ci + chunk * 64) * 2);
+#pragma unroll
+    for (int i = 0; i < WPI; ++i)
+      glds16(base + (unsigned)(((wr + i * 8) * p.kp[c] + wpiece * 8) * 2), wring + stage * WT + (wave * WPI + i) * 1024);
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fk = lane >> 4, swz = lane & 7;
+  const unsigned rowb0 = (unsigned)(((wm * 4) * 18 + frow) * HP + fk * 16);   // box row wm*4 + j: + j * 18 * HP as the read's offset
+
+  f32x4 acc[NC][TI][TJ];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned smem0 = lds_addr(smem);
+  const unsigned wfrag0 = smem0 + (unsigned)((wn * 32 + frow) * 128);
+  const unsigned kc0 = (unsigned)(((0 * 4 + fk) ^ swz) << 4);        // k-piece of half 1: (4 + fk) ^ swz = (fk ^ swz) ^ 4 -> kc0 ^ 64
+  const unsigned hbuf0 = smem0 + 3 * WT;
+  struct Frags { bf16x8 w[TI], x[TJ]; };
+  auto load = [&](Frags& f, unsigned wbase, unsigned xbase, auto kk_tag) {
+    constexpr int kk = decltype(kk_tag)::value;
+    const unsigned wa = wbase + (kk ? (kc0 ^ 64u) : kc0);
+    lds_read128<0>(f.w[0], wa);
+    lds_read128<2048>(f.w[1], wa);
+    const unsigned xa = xbase + rowb0;
+    lds_read128<kk * 64 + 0 * 18 * HP>(f.x[0], xa);
+    lds_read128<kk * 64 + 1 * 18 * HP>(f.x[1], xa);
+    lds_read128<kk * 64 + 2 * 18 * HP>(f.x[2], xa);
+    lds_read128<kk * 64 + 3 * 18 * HP>(f.x[3], xa);
+  };
+  auto mma = [&](const Frags& f, f32x4 (&a)[TI][TJ]) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.x[j], a[i][j], 0, 0, 0);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: halo of chunks 0 (and 1), weight pairs 0, 1, 2 --------------------------------------------------------
+  const int nk = p.chunks * NS, npairs = nk >> 1;            // launcher guarantees nk even and a whole number of super-chunks
+  auto issue_pair = [&](int pr) {                            // runtime pair index: only used in the prologue
+    const int ks = pr * 2 + (wave >> 2);
+    const int c = ks / NS, s = ks - c * NS;
+    // (runtime s: the class tables are indexed dynamically here, three times per launch)
+    const int cl = PAT == 0 ? (s < 1 ? 0 : (s < 3 ? 1 : (s < 5 ? 2 : 3))) : (s >> 2);
+    const char* base = p.w + (p.w_off[cl] + ((long long)p.wtap[s] * d.Ci + c * 64) * 2);
+#pragma unroll
+    for (int i = 0; i < WPI; ++i)
+      glds16(base + (unsigned)(((wrow0 + i * 8) * p.kp[cl] + wpiece * 8) * 2), wring + (pr % 3) * WT + (wave * WPI + i) * 1024);
+  };
+  issue_halo(0, 0);
+  if (p.chunks > 1) issue_halo(1, 1);
+#pragma unroll
+  for (int pr = 0; pr < 3; ++pr)
+    if (pr < npairs) issue_pair(pr);
+  if (npairs >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPI) : "memory");
+  else if (npairs == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  Frags S0, S1;
+  int stage = 0;
+  for (int sc = 0; sc < p.chunks / CPS; ++sc) {
+    const int cbase = sc * CPS;
+    static_for<0, NPAIR>([&](auto pr_tag) {
+      constexpr int pr = decltype(pr_tag)::value;
+      constexpr int sA = (2 * pr) % NS, sB = (2 * pr + 1) % NS;          // K-steps inside their chunks
+      constexpr int cA = (2 * pr) / NS, cB = (2 * pr + 1) / NS;          // chunk inside the super-chunk
+      const int gp = sc * NPAIR + pr;                                    // global pair index
+      // weights of pair gp + 2 into the slot pair gp - 1 used; the halo of the chunk after next into the buffer of the
+      // chunk that just finished (issued AFTER the weights: it may stay in flight for one more pair)
+      bool halo_now = false;
+      if (gp >= 1 && gp + 2 < npairs) {
+        constexpr int p2 = pr + 2;
+        constexpr int sW0 = (2 * (p2 % NPAIR)) % NS, sW1 = (2 * (p2 % NPAIR) + 1) % NS;
+        constexpr int cW0 = (2 * (p2 % NPAIR)) / NS, cW1 = (2 * (p2 % NPAIR) + 1) / NS;
+        const int cw = cbase + (p2 / NPAIR) * CPS;
+        const int st2 = stage == 0 ? 2 : stage - 1;
+        if (wave < 4) issue_w(cw + cW0, sW0, st2); else issue_w(cw + cW1, sW1, st2);
+      }
+      if constexpr (PAT == 0) {
+        // chunk cbase + 1 -> its box was staged when? chunk 1 in the prologue, later ones here: the box of chunk
+        // cbase + 1 goes into the buffer chunk cbase - 1 left (free since the previous super-chunk) at pair 0, the box of
+        // chunk cbase + 2 into the buffer chunk cbase leaves at pair 4 (its last K-step) from pair 5 on
+        if (pr == 0 && sc >= 1 && cbase + 1 < p.chunks) { issue_halo(cbase + 1, (cbase + 1) & 1); halo_now = true; }
+        if (pr == 5 && cbase + 2 < p.chunks) { issue_halo(cbase + 2, (cbase + 2) & 1); halo_now = true; }
+      } else {
+        if (pr == 0 && sc >= 1 && cbase + 1 < p.chunks) { issue_halo(cbase + 1, (cbase + 1) & 1); halo_now = true; }
+      }
+      const unsigned wst = wfrag0 + (unsigned)(stage * WT);
+      unsigned hA = hbuf0 + (unsigned)(((cbase + cA) & 1) * HBUF) + (unsigned)p.tb[sA];
+      unsigned hB = hbuf0 + (unsigned)(((cbase + cB) & 1) * HBUF) + (unsigned)p.tb[sB];
+      // (with two chunks per super-chunk the buffer parity is loop-invariant and the compiler would keep all 18 x 4 fragment
+      //  addresses of the unrolled body in registers: 160 spilled VGPRs)
+      asm volatile("" : "+s"(hA), "+s"(hB));
+      load(S0, wst, hA, K0{});
+      load(S1, wst, hA, K1{});
+      gs_lgkm_wait<6>(S0.w[0], S0.w[1], S0.x[0], S0.x[1], S0.x[2], S0.x[3]);
+      mma(S0, acc[cls_of<PAT>(sA)]);
+      load(S0, wst + BN * 128, hB, K0{});
+      gs_lgkm_wait<6>(S1.w[0], S1.w[1], S1.x[0], S1.x[1], S1.x[2], S1.x[3]);
+      mma(S1, acc[cls_of<PAT>(sA)]);
+      load(S1, wst + BN * 128, hB, K1{});
+      gs_lgkm_wait<6>(S0.w[0], S0.w[1], S0.x[0], S0.x[1], S0.x[2], S0.x[3]);
+      mma(S0, acc[cls_of<PAT>(sB)]);
+      gs_lgkm_wait<0>(S1.w[0], S1.w[1], S1.x[0], S1.x[1], S1.x[2], S1.x[3]);
+      mma(S1, acc[cls_of<PAT>(sB)]);
+      // the weights of pair gp + 1 (issued a pair ago) and everything older have landed; what may still fly: the weights
+      // of gp + 2 and a halo box issued in this pair
+      if (gp + 1 < npairs) {
+        if (gp + 2 >= npairs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (gp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");           // w1 | w2 (prologue)
+        else if (halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
+    });
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------
+  f32x4 bia[TI];                                             // this lane's 2 x 4 output channels
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
+    bia[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_stats = d.stats_slots > 0;
+  float s1[TI][4], s2[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+  constexpr int SROW = BN * 2 + 16;                          // slab row: 64 channels + a pad piece
+  char* slab = smem;                                         // [256 pixels][SROW]
+  float* red = reinterpret_cast<float*>(smem + 256 * SROW);  // [4 wm][64][2]
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[c][i][j][r] + bia[i][r];
+          s1[i][r] += v[r];
+          s2[i][r] += v[r] * v[r];
+          v[r] = apply_act(v[r], d.act, d.slope);
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(slab + ((wm * 4 + j) * 16 + frow) * SROW + (wn * 32 + i * 16 + fk * 4) * 2) = o;
+      }
+    __syncthreads();
+    {
+      const int piece = tid & 7;                             // 8 lanes x 16 B = the 64 channels of a pixel: 128-B stores
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int pl = it * 64 + (tid >> 3);
+        const int ly = pl >> 4, lx = pl & 15;
+        const size_t opix = ((size_t)n * d.Ho + ((oy0 + ly) * 2 + p.py[c])) * d.Wo + ((ox0 + lx) * 2 + p.px[c]);
+        const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + piece * 16);
+        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + nt * BN + piece * 8) * 2) = val;
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[i][r]), q = row16_sum(s2[i][r]);
+        if (frow == 0) {
+          red[(wm * BN + wn * 32 + i * 16 + fk * 4 + r) * 2 + 0] = a;
+          red[(wm * BN + wn * 32 + i * 16 + fk * 4 + r) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < BN) {
+      const int cc = nt * BN + tid;
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+      // slot `mt` holds this box (all classes); the layer's other slots — counted per class by the caller — are zeroed, each
+      // by the box whose index it is congruent to
+      for (int slot = mt; slot < d.stats_slots; slot += p.tiles_m) {
+        float* sp = p.stats + (((size_t)n * d.stats_slots + slot) * 2) * d.Co;
+        sp[cc] = slot == mt ? a : 0.f;
+        sp[d.Co + cc] = slot == mt ? q : 0.f;
+      }
+    }
+  }
+}
+
+bool window(const gs_gconv_desc* const* descs, int* lo) {
+  int hi[2] = {-128, -128};
+  lo[0] = lo[1] = 127;
+  for (int c = 0; c < NC; ++c)
+    for (int t = 0; t < descs[c]->T; ++t) {
+      if (descs[c]->dd[t] != 0) return false;
+      const int o[2] = {descs[c]->dh[t], descs[c]->dw[t]};
+      for (int a = 0; a < 2; ++a) { if (o[a] < lo[a]) lo[a] = o[a]; if (o[a] > hi[a]) hi[a] = o[a]; }
+    }
+  return hi[0] - lo[0] <= 2 && hi[1] - lo[1] <= 2;
+}
+}  // namespace
+
+// pattern of the classes (0: 1/2/2/4 taps, 1: 4/4/4/4) when the layer runs here, -1 when it does not
+int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count) {
+  if (gs_opt(GS_OPT_HCONVT) == 0 || count != NC) return -1;
+  const gs_gconv_desc* d = descs[0];
+  if (d->so != 2 || d->si != 1 || d->Ci % 64 != 0 || d->Co % 64 != 0 || d->border != GS_BORDER_ZERO) return -1;
+  if (d->Di != 1 || d->Do != 1 || d->Dc != 1 || d->Hc % 16 != 0 || d->Wc % 16 != 0) return -1;
+  if (d->Ho != 2 * d->Hc || d->Wo != 2 * d->Wc || d->accumulate) return -1;
+  int pat = -1;
+  if (descs[0]->T == 1 && descs[1]->T == 2 && descs[2]->T == 2 && descs[3]->T == 4) pat = 0;
+  if (descs[0]->T == 4 && descs[1]->T == 4 && descs[2]->T == 4 && descs[3]->T == 4) pat = 1;
+  if (pat < 0) return -1;
+  for (int c = 0; c < NC; ++c)
+    if (descs[c]->pz != 0 || descs[c]->py < 0 || descs[c]->py > 1 || descs[c]->px < 0 || descs[c]->px > 1) return -1;
+  int lo[2];
+  if (!window(descs, lo)) return -1;
+  const int chunks = d->Ci / 64;
+  if (pat == 0 && chunks % 2 != 0) return -1;                 // K-steps are consumed in pairs over super-chunks of 2 chunks
+  const long long blocks = (long long)d->N * (d->Hc / 16) * (d->Wc / 16) * (d->Co / 64);
+  if (blocks < 192 || blocks >= (1LL << 31)) return -1;
+  if ((long long)d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 31)) return -1;
+  if (d->stats_slots > 0 && d->stats_slots < (d->Hc / 16) * (d->Wc / 16)) return -1;
+  return pat;
+}
+
+int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
+                     const float* bias, void* out, float* stats, void* stream) {
+  const gs_gconv_desc* d = descs[0];
+  static HConvTK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_packs[0]);
+  k.bias = bias;
+  k.out = static_cast<char*>(out);
+  k.stats = stats;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward_multi: library not initialised (call gs_init)");
+  int lo[2];
+  window(descs, lo);
+  int s = 0;
+  for (int c = 0; c < NC; ++c) {
+    const gs_gconv_desc* dc = descs[c];
+    k.w_off[c] = static_cast<const char*>(w_packs[c]) - k.w;
+    k.kp[c] = dc->Kp; k.py[c] = dc->py; k.px[c] = dc->px;
+    for (int t = 0; t < dc->T; ++t, ++s) {
+      k.tb[s] = ((dc->dh[t] - lo[0]) * 18 + (dc->dw[t] - lo[1])) * 160;
+      k.wtap[s] = t;
+    }
+  }
+  k.tiles_m = (d->Hc / 16) * (d->Wc / 16);
+  k.tiles_n = d->Co / 64;
+  k.nbw = d->Wc / 16;
+  k.hmin = lo[0]; k.wmin = lo[1];
+  k.chunks = d->Ci / 64;
+  k.d = *d;
+  const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
+  const int lds = 3 * 2 * 64 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvt_kernel<0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvt_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+  else hipLaunchKernelGGL((hconvt_kernel<1>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -206,6 +206,63 @@ def test_merged_parity_classes_equal_separate_launches(hip_ops, case):
         assert torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 8, 128, 128),          # u64 forward: classes of 1 / 2 / 2 / 4 taps, 2 chunks
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 8, 64, 64),           # u128 forward: 4 chunks, two channel tiles
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 8, 256, 256),              # d128 data gradient (same classes, Co = 64)
+    (ConvSpec("conv", 128, 256, 3, 2, 1), 3, 128, 160),             # d256 data gradient, ragged box grid 4 x 5
+    (ConvSpec("conv", 64, 128, 4, 2, 1), 12, 128, 128),             # PatchGAN k4 gradient: 4 / 4 / 4 / 4 taps
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 16, 64, 96),              # PatchGAN k4 gradient, Co = 128
+], ids=_ids)
+def test_halo_resident_parity_classes(hip_ops, case):
+    """hconvt.hip (all four output-parity classes of a stride-2 layer out of one halo-resident pass) against the per-class
+    im2col launches of the same library and against the oracle: outputs to bf16 rounding (another K order), statistics
+    totals to fp32 summation order; every statistics slot of the layer is written (box sums or zeros)."""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 41)
+    g = torch.Generator().manual_seed(42)
+    dev = hip_ops.device
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16)
+    fwd_multi, dg_multi = len(low.fwd) == 4, len(low.dgrad) == 4
+    assert fwd_multi or dg_multi
+    res = {}
+    try:
+        for on in (1, 0):
+            hip_ops.set_option("hconvt", on)
+            out = {}
+            if fwd_multi:
+                slots, offs = stats_slots(hip_ops, low, low.fwd, N)
+                ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+                part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
+                hip_ops.gconv_classes(low.fwd, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act="none", stats=part,
+                                      stats_slots=slots, stats_slot0s=offs)
+                out["y"], out["stats"] = ya.cpu(), part.view(N, slots, 2, spec.cout_p).sum(1).cpu()
+                assert not torch.isnan(part).any()
+            if dg_multi:
+                gx = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16, device=dev)
+                hip_ops.gconv_classes(low.dgrad, gy.to(dev), dpack.to(dev), None, gx)
+                out["gx"] = gx.cpu()
+            torch.cuda.synchronize()
+            res[on] = out
+    finally:
+        hip_ops.set_option("hconvt", 1)
+    ref = RefOps()
+    if fwd_multi:
+        yr = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+        pr = torch.zeros(N * 4 * 2 * spec.cout_p, dtype=torch.float32)
+        ref.gconv_classes(low.fwd, xa, fpack, bias, yr, act="none", stats=pr, stats_slots=4, stats_slot0s=[0, 1, 2, 3])
+        close_bf16(res[1]["y"], res[0]["y"], "forward vs per-class launches")
+        close_bf16(res[1]["y"], yr, "forward vs oracle")
+        close_f32(res[1]["stats"], res[0]["stats"], "statistics totals vs per-class launches", rel=2e-3)
+        close_f32(res[1]["stats"], pr.view(N, 4, 2, spec.cout_p).sum(1), "statistics totals vs oracle", rel=2e-3)
+    if dg_multi:
+        gr = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16)
+        ref.gconv_classes(low.dgrad, gy, dpack, None, gr)
+        close_bf16(res[1]["gx"], res[0]["gx"], "data gradient vs per-class launches")
+        close_bf16(res[1]["gx"], gr, "data gradient vs oracle")
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=_ids)
 def test_wgrad_and_bias_grad(hip_ops, case):
     spec, N, sizes = case[0], case[1], case[2:]

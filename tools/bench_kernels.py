@@ -68,13 +68,11 @@ def main():
         part = torch.empty(N * slots * 2 * spec.cout_p, device=dev)
         a, gt = (gy, x) if spec.kind == "conv" else (x, gy)
 
-        def fwd():
-            for g, o in zip(low.fwd, offs):
-                ops.gconv(g, x, fpack, bias, y, stats=part, stats_slots=slots, stats_slot0=o)
+        def fwd():       # the product's call: all parity classes of a stride-2 layer through gs_gconv_forward_multi
+            ops.gconv_classes(low.fwd, x, fpack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
 
         def dgrad():
-            for g in low.dgrad:
-                ops.gconv(g, gy, dpack, None, gx)
+            ops.gconv_classes(low.dgrad, gy, dpack, None, gx)
 
         def wgrad():
             ops.wgrad(low.wgrad, a, gt, dw)
