@@ -59,7 +59,8 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"gconv_tile288", 1},       // 288-pixel im2col tiles where they make exactly one round of workgroups (else 320)
     {"gconv_multi", 1},         // the parity classes of a stride-2 transposed conv / data gradient as one launch
     {"hconvw_ring", 1},         // fused data gradient of the reflect-padded wide 3x3 layers on the unpadded domain (hconvw.hip RING)
-    {"hconvt", 1},              // halo-resident kernel for the four parity classes of a stride-2 layer in one pass (hconvt.hip)
+    {"hconvt", 192},            // halo-resident kernel for the four parity classes of a stride-2 layer in one pass (hconvt.hip):
+                                // smallest grid (boxes x channel tiles x batch) it takes, 0 = off
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -334,7 +334,7 @@ int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count) {
   const int chunks = d->Ci / 64;
   if (pat == 0 && chunks % 2 != 0) return -1;                 // K-steps are consumed in pairs over super-chunks of 2 chunks
   const long long blocks = (long long)d->N * (d->Hc / 16) * (d->Wc / 16) * (d->Co / 64);
-  if (blocks < 192 || blocks >= (1LL << 31)) return -1;
+  if (blocks < gs_opt(GS_OPT_HCONVT) || blocks >= (1LL << 31)) return -1;      // option value = smallest grid taken
   if ((long long)d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 31)) return -1;
   if (d->stats_slots > 0 && d->stats_slots < (d->Hc / 16) * (d->Wc / 16)) return -1;
   return pat;

@@ -186,7 +186,9 @@ def test_merged_parity_classes_equal_separate_launches(hip_ops, case):
     gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
     gy[..., :spec.cout] = torch.randn(N, *low.out_dims, spec.cout, generator=g).to(torch.bfloat16)
     res = {}
+    hconvt_default = hip_ops.get_option("hconvt")
     try:
+        hip_ops.set_option("hconvt", 0)          # the im2col class launches are what is compared here (hconvt.hip has its own test)
         for merged in (1, 0):
             hip_ops.set_option("gconv_multi", merged)
             slots, offs = stats_slots(hip_ops, low, low.fwd, N)
@@ -200,6 +202,7 @@ def test_merged_parity_classes_equal_separate_launches(hip_ops, case):
             res[merged] = (ya.cpu(), part.cpu(), gx.cpu())
     finally:
         hip_ops.set_option("gconv_multi", 1)
+        hip_ops.set_option("hconvt", hconvt_default)
     assert len(low.fwd) > 1 or len(low.dgrad) > 1
     assert not torch.isnan(res[1][1]).any()
     for a, b, what in zip(res[1], res[0], ("forward", "statistics", "data gradient")):
@@ -227,6 +230,7 @@ def test_halo_resident_parity_classes(hip_ops, case):
     fwd_multi, dg_multi = len(low.fwd) == 4, len(low.dgrad) == 4
     assert fwd_multi or dg_multi
     res = {}
+    hconvt_default = hip_ops.get_option("hconvt")     # = the smallest grid the kernel takes; 1: every eligible layer, 0: off
     try:
         for on in (1, 0):
             hip_ops.set_option("hconvt", on)
@@ -246,7 +250,7 @@ def test_halo_resident_parity_classes(hip_ops, case):
             torch.cuda.synchronize()
             res[on] = out
     finally:
-        hip_ops.set_option("hconvt", 1)
+        hip_ops.set_option("hconvt", hconvt_default)
     ref = RefOps()
     if fwd_multi:
         yr = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
