@@ -61,6 +61,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconvw_ring", 1},         // fused data gradient of the reflect-padded wide 3x3 layers on the unpadded domain (hconvw.hip RING)
     {"hconvt", 192},            // halo-resident kernel for the four parity classes of a stride-2 layer in one pass (hconvt.hip):
                                 // smallest grid (boxes x channel tiles x batch) it takes, 0 = off
+    {"hstrip", 1024},           // halo-resident kernel for the W-folded k7 boundary convs (hstrip.hip): smallest grid, 0 = off
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

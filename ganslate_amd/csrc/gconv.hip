@@ -648,6 +648,10 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
                   void* stream, int* handled);
 int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, void* out, const gs_gconv_fuse* fuse,
                    void* stream);
+// hstrip.hip: W-folded k7 boundary convs (vertical taps, <= 64 channels) out of a resident input strip
+int gs_hstrip_slots(const gs_gconv_desc* d);
+int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
+                  void* stream, int* handled);
 // hconvt.hip: the four parity classes of a stride-2 layer out of one halo-resident pass
 int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count);
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
@@ -661,6 +665,8 @@ extern "C" int gs_gconv_stat_slots(const gs_gconv_desc* d) {
   if (hs) return hs;
   const int ws = gs_hconvw_slots(d);
   if (ws) return ws;
+  const int ss = gs_hstrip_slots(d);
+  if (ss) return ss;
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const int bm = pick_tile(d).bm;
   return (int)((pix + bm - 1) / bm);
@@ -677,7 +683,7 @@ extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const vo
 // floats of workspace gs_gconv_forward_ws wants for this launch (0: the launch does not split K)
 extern "C" int64_t gs_gconv_splitk_ws_floats(const gs_gconv_desc* d) {
   if (!d || d->Dc < 1 || d->Hc < 1 || d->Wc < 1 || d->Co < 1) return 0;
-  if (gs_hconv_slots(d) || gs_hconvw_slots(d)) return 0;
+  if (gs_hconv_slots(d) || gs_hconvw_slots(d) || gs_hstrip_slots(d)) return 0;
   const TileCfg tc = pick_tile(d);
   const int splits = splitk_plan(d, tc, false);
   return splits > 1 ? (int64_t)splits * d->N * d->Do * d->Ho * d->Wo * d->Co : 0;
@@ -727,6 +733,8 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
     if (handled) return 0;
     if (int rc = gs_hconvw_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
+    if (handled) return 0;
+    if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
     if (handled) return 0;
   }
   const TileCfg tc = pick_tile(d);

@@ -1,0 +1,247 @@
+// Halo-resident kernel for the W-folded k7 boundary convolutions of the ResNets (stem c7s1-64, output c7s1-3 and their data
+// gradients: resnet2d.py:25,65 — after csrc/wfold.hip moved the W taps into channels they are 7 VERTICAL taps over 32 / 64
+// channels, 21-64 output channels, at full image resolution).
+//
+// 1.4 GFLOP over 100 MB of activations: pure streaming. On the im2col kernel every tap gathers the input again from L2
+// (7 x 67 MB for the output conv) and the launches sit at 68-86 us against an HBM floor of ~21. With taps in one column
+// the input window of a tile of R rows x 8 columns is the (R + 6) x 8 strip above and below it — contiguous pixels, tap t
+// = a shift by dh_t x 8 pixels — so a workgroup stages that strip once (LDS-DMA, row border resolved per lane), keeps ALL
+// the layer's weights in LDS (<= 29 KB) and runs the taps out of it: input read once, no K loop over global memory.
+// 4 waves x (64 pixels x Co), 256-pixel tiles (32 x 8), <= 78 KB of LDS: two workgroups per CU overlap each other's
+// load / compute / store phases. Epilogue contract of gconv_kernel: bias, one statistics slot per tile, activation,
+// dense or sliced output.
+#include "common.hpp"
+#include <cstdlib>
+
+namespace {
+constexpr int TR = 32, TC = 8;          // tile rows x columns (256 pixels)
+struct HStripK {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  float* stats;
+  const char* zero;
+  int tiles_y, tiles_x, hmin, span, dwc;   // span = rows of the input window beyond the tile (max dh - min dh)
+  int toff[8];                             // tap -> row offset inside the window (dh - hmin)
+  gs_gconv_desc d;
+};
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void hstrip_kernel(const HStripK p) {
+  constexpr int PP = CI / 8 + 2;                 // 16-B pieces per pixel incl. 2 pad pieces (160 B / 96 B... see below)
+  constexpr int PITCH = CI == 64 ? 160 : 80;     // bytes per staged pixel: 16 consecutive pixels cover all banks once
+  constexpr int PIECES = PITCH / 16;             // 10 / 5
+  constexpr int TI = CO / 16, TJ = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const gs_gconv_desc& d = p.d;
+  const int T = d.T;
+  const int WROW = T * CI * 2 + 16;              // weight row pitch (one pad piece spreads 16 rows over the banks)
+  const int wbytes = ((CO * WROW + 1023) / 1024) * 1024;
+  char* wl = smem;                               // [CO][WROW]
+  char* halo = smem + wbytes;                    // [(TR + span) * TC pixels][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x; b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int n = b / p.tiles_y;
+  const int oy0 = ty * TR, ox0 = tx * TC;
+
+  // ---- input strip: (TR + span) rows x TC columns, all CI channels, by LDS-DMA (border resolved in the source address) ----
+  const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+  const int hpx = (TR + p.span) * TC;
+  const int hinstr = (hpx * PIECES + 63) / 64;
+  for (int inst = wave; inst < hinstr; inst += 4) {
+    const int q = inst * 64 + lane;
+    const int v = q / PIECES, part = q - v * PIECES;
+    const int hy = v / TC, hx = v - hy * TC;
+    bool ok = v < hpx && part < CI / 8;
+    int iy = border_index(oy0 + hy + p.hmin, d.Hi, d.border, ok);
+    int ix = border_index(ox0 + hx + p.dwc, d.Wi, d.border, ok);
+    iy = min(max(iy, 0), d.Hi - 1);
+    ix = min(max(ix, 0), d.Wi - 1);
+    const char* src = ok ? in_n + ((size_t)(iy * d.Wi + ix) * d.in_cs + part * 8) * 2 : p.zero;
+    glds16(src, halo + inst * 1024);
+  }
+  // ---- weights: CO rows x (T * CI) k, row pitch WROW, through registers (once per workgroup, L2-resident) ----
+  {
+    const int rp = T * CI / 8;                   // 16-B pieces per row
+    for (int q = tid; q < CO * rp; q += 256) {
+      const int r = q / rp, piece = q - r * rp;
+      const uint4 v = r < d.w_rows ? *reinterpret_cast<const uint4*>(p.w + ((size_t)r * d.Kp + piece * 8) * 2)
+                                   : uint4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<uint4*>(wl + r * WROW + piece * 16) = v;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- taps out of LDS ------------------------------------------------------------------------------------------------------
+  const int frow = lane & 15, fk = lane >> 4;
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned smem0 = lds_addr(smem);
+  const unsigned wa0 = smem0 + (unsigned)(frow * WROW + fk * 16);
+  const unsigned xa0 = smem0 + (unsigned)wbytes + (unsigned)((wave * 64 + frow) * PITCH + fk * 16);
+  for (int t = 0; t < T; ++t) {
+    const unsigned xt = xa0 + (unsigned)(p.toff[t] * TC * PITCH);
+    const unsigned wt = wa0 + (unsigned)(t * CI * 2);
+#pragma unroll
+    for (int kk = 0; kk < CI / 32; ++kk) {
+      bf16x8 wf[TI], xf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(smem + (wt - smem0) + i * 16 * WROW + kk * 64);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(smem + (xt - smem0) + j * 16 * PITCH + kk * 64);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                               // the strip is free: its LDS becomes the output slab
+
+  // ---- epilogue: bias, statistics (slot = tile), activation, coalesced stores through an LDS slab -------------------------
+  constexpr int SROW = CO * 2 + 16;
+  char* slab = halo;                             // [256 pixels][SROW]  (CO * 2 + 16 <= PITCH * ... checked by the launcher)
+  float* red = reinterpret_cast<float*>(smem);   // [4 waves][CO][2] over the weight area
+  const bool want_stats = d.stats_slots > 0;
+  float s1[TI][4], s2[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int co = i * 16 + fk * 4;
+    const f32x4 bia = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int pl = wave * 64 + j * 16 + frow;
+      const bool inside = oy0 + pl / TC < d.Hc && ox0 + pl % TC < d.Wc;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + bia[r];
+        if (inside) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
+        v[r] = apply_act(v[r], d.act, d.slope);
+      }
+      uint2 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(slab + pl * SROW + co * 2) = o;
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int LPP = CO / 8;                  // lanes (16 B each) per pixel
+    for (int q = tid; q < 256 * LPP; q += 256) {
+      const int pl = q / LPP, piece = q - pl * LPP;
+      const int oy = oy0 + pl / TC, ox = ox0 + pl % TC;
+      if (oy < d.Hc && ox < d.Wc && piece * 8 < d.Co) {
+        const size_t opix = ((size_t)n * d.Ho + oy) * d.Wo + ox;
+        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + piece * 8) * 2) =
+            *reinterpret_cast<const uint4*>(slab + pl * SROW + piece * 16);
+      }
+    }
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[i][r]), q = row16_sum(s2[i][r]);
+        if (frow == 0) {
+          red[(wave * CO + i * 16 + fk * 4 + r) * 2 + 0] = a;
+          red[(wave * CO + i * 16 + fk * 4 + r) * 2 + 1] = q;
+        }
+      }
+    __syncthreads();
+    if (tid < CO && tid < d.Co) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * CO + tid) * 2]; q += red[(w * CO + tid) * 2 + 1]; }
+      float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + ty * p.tiles_x + tx) * 2) * d.Co;
+      sp[tid] = a;
+      sp[d.Co + tid] = q;
+    }
+  }
+}
+
+struct Plan { bool ok; int hmin, span, dwc, ci, co, lds; };
+Plan plan(const gs_gconv_desc* d) {
+  Plan h{};
+  const int minb = gs_opt(GS_OPT_HSTRIP);
+  if (minb == 0 || d->si != 1 || d->so != 1 || d->T < 2 || d->T > 8 || d->accumulate) return h;
+  if (d->Di != 1 || d->Do != 1 || d->Dc != 1 || d->pz || d->py || d->px || d->Hc != d->Ho || d->Wc != d->Wo) return h;
+  if ((d->Ci != 32 && d->Ci != 64) || d->Co > 64 || d->Co % 8 != 0) return h;
+  int lo = 127, hi = -128;
+  for (int t = 0; t < d->T; ++t) {
+    if (d->dd[t] != 0 || d->dw[t] != d->dw[0]) return h;          // vertical taps in one column
+    if (d->dh[t] < lo) lo = d->dh[t];
+    if (d->dh[t] > hi) hi = d->dh[t];
+  }
+  if (hi - lo > 7) return h;
+  h.hmin = lo; h.span = hi - lo; h.dwc = d->dw[0];
+  h.ci = d->Ci; h.co = d->Co <= 32 ? 32 : 64;
+  const long long blocks = (long long)d->N * ((d->Ho + TR - 1) / TR) * ((d->Wo + TC - 1) / TC);
+  if (blocks < minb || blocks >= (1LL << 31)) return h;
+  if ((long long)d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 31)) return h;
+  const int pitch = d->Ci == 64 ? 160 : 80;
+  const int wbytes = ((h.co * (d->T * d->Ci * 2 + 16) + 1023) / 1024) * 1024;
+  const int hbytes = (((TR + h.span) * TC * (pitch / 16) + 63) / 64) * 1024;
+  const int slab = 256 * (h.co * 2 + 16);
+  h.lds = wbytes + (hbytes > slab ? hbytes : slab);
+  if (h.lds > 80 * 1024 || wbytes < 4 * h.co * 2 * 4) return h;    // two workgroups per CU; red[] fits the weight area
+  h.ok = true;
+  return h;
+}
+
+template <int CI, int CO>
+int launch_s(const HStripK& k, long long blocks, int lds, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hstrip_kernel<CI, CO>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    configured = true;
+  }
+  hipLaunchKernelGGL((hstrip_kernel<CI, CO>), dim3((unsigned)blocks), dim3(256), lds, st, k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+// statistics slots per image when the class runs here (one per 32 x 8 tile), 0 when it does not
+int gs_hstrip_slots(const gs_gconv_desc* d) {
+  const Plan h = plan(d);
+  return h.ok ? ((d->Ho + TR - 1) / TR) * ((d->Wo + TC - 1) / TC) : 0;
+}
+
+int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
+                  void* stream, int* handled) {
+  *handled = 0;
+  const Plan h = plan(d);
+  if (!h.ok) return 0;
+  HStripK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_pack);
+  k.bias = bias;
+  k.out = static_cast<char*>(out);
+  k.stats = stats;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
+  k.tiles_y = (d->Ho + TR - 1) / TR;
+  k.tiles_x = (d->Wo + TC - 1) / TC;
+  k.hmin = h.hmin; k.span = h.span; k.dwc = h.dwc;
+  for (int t = 0; t < d->T; ++t) k.toff[t] = d->dh[t] - h.hmin;
+  k.d = *d;
+  const long long blocks = (long long)d->N * k.tiles_y * k.tiles_x;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  *handled = 1;
+  if (h.ci == 64 && h.co == 64) return launch_s<64, 64>(k, blocks, h.lds, st);
+  if (h.ci == 64 && h.co == 32) return launch_s<64, 32>(k, blocks, h.lds, st);
+  if (h.ci == 32 && h.co == 64) return launch_s<32, 64>(k, blocks, h.lds, st);
+  return launch_s<32, 32>(k, blocks, h.lds, st);
+}

@@ -132,6 +132,48 @@ def test_gconv_forward_stats(hip_ops, case):
     close_f32(mr_hip.view(N, 2, C)[:, 1], mr_ref.view(N, 2, C)[:, 1], "rstd", rel=1e-3)
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 40, 56),     # stem, ragged tile grid (40 = 32 + 8)
+    (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 32, 32),    # output conv: 38 columns out
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 256, 256),   # headline size
+    (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 256, 256),
+    (ConvSpec("conv", 1, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 1, 70, 33),     # 1 channel: 7 -> 8 folded channels
+], ids=_ids)
+def test_halo_resident_boundary_convs(hip_ops, case):
+    """hstrip.hip (the W-folded k7 boundary convs out of a resident input strip: vertical taps, weights resident in LDS)
+    against the im2col launches of the same library and the oracle: forward with bias + statistics, and the data gradient
+    (zero border on the padded domain)."""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 51)
+    g = torch.Generator().manual_seed(52)
+    xa = torch.zeros(N, *low.in_dims, low.fwd[0].Ci, dtype=torch.bfloat16)
+    xa.copy_(torch.randn(xa.shape, generator=g).to(torch.bfloat16))
+    gy = torch.randn(N, *low.out_dims, low.fwd[0].Co, generator=g).to(torch.bfloat16)
+    default = hip_ops.get_option("hstrip")
+    res = {}
+    try:
+        for on in (1, 0):
+            hip_ops.set_option("hstrip", on)          # 1: every eligible layer whatever its grid, 0: off
+            if on and low.fwd[0].Ci in (32, 64):      # (the 1-channel stem folds to 8 channels: stays on the im2col kernel)
+                assert hip_ops.stat_slots(low.fwd[0], N) == ((low.fwd[0].Ho + 31) // 32) * ((low.fwd[0].Wo + 7) // 8)
+            y, mr = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N)
+            gx = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16, device=hip_ops.device)
+            hip_ops.gconv_classes(low.dgrad, gy.to(hip_ops.device), dpack.to(hip_ops.device), None, gx)
+            torch.cuda.synchronize()
+            res[on] = (y.cpu(), mr.cpu(), gx.cpu())
+    finally:
+        hip_ops.set_option("hstrip", default)
+    y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N)
+    gx_ref = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16)
+    RefOps().gconv_classes(low.dgrad, gy, dpack, None, gx_ref)
+    C = low.fwd[0].Co
+    for other, what in ((res[0], "im2col launches"), ((y_ref, mr_ref, gx_ref), "oracle")):
+        close_bf16(res[1][0], other[0], f"forward vs {what}")
+        close_f32(res[1][1].view(N, 2, C)[:, 0], other[1].view(N, 2, C)[:, 0], f"mean vs {what}", rel=1e-3)
+        close_f32(res[1][1].view(N, 2, C)[:, 1], other[1].view(N, 2, C)[:, 1], f"rstd vs {what}", rel=1e-3)
+        close_bf16(res[1][2], other[2], f"data gradient vs {what}")
+
+
 @pytest.mark.parametrize("act", ["lrelu", "relu", "tanh"])
 def test_gconv_epilogue_activation(hip_ops, act):
     spec, N, H, W = ConvSpec("conv", 3, 64, 4, 2, 1), 2, 32, 32
