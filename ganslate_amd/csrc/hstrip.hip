@@ -64,14 +64,18 @@ __global__ __launch_bounds__(256) void hstrip_kernel(const HStripK p) {
     const char* src = ok ? in_n + ((size_t)(iy * d.Wi + ix) * d.in_cs + part * 8) * 2 : p.zero;
     glds16(src, halo + inst * 1024);
   }
-  // ---- weights: CO rows x (T * CI) k, row pitch WROW, through registers (once per workgroup, L2-resident) ----
+  // ---- weights: CO rows x (T * CI) k plus one pad piece per row (row pitch WROW), by LDS-DMA as well: lane q -> (row,
+  // piece); L2-resident after the first workgroups. (A register copy loop here — 14 dependent load / store rounds per
+  // thread — was the longest phase of the workgroup.) ----
   {
-    const int rp = T * CI / 8;                   // 16-B pieces per row
-    for (int q = tid; q < CO * rp; q += 256) {
-      const int r = q / rp, piece = q - r * rp;
-      const uint4 v = r < d.w_rows ? *reinterpret_cast<const uint4*>(p.w + ((size_t)r * d.Kp + piece * 8) * 2)
-                                   : uint4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<uint4*>(wl + r * WROW + piece * 16) = v;
+    const int rp1 = T * CI / 8 + 1;              // 16-B pieces per LDS row incl. the pad piece
+    const int winstr = (CO * rp1 + 63) / 64;
+    for (int inst = wave; inst < winstr; inst += 4) {
+      const int q = inst * 64 + lane;
+      const int r = q / rp1, piece = q - r * rp1;
+      const bool ok = r < CO && r < d.w_rows && piece < rp1 - 1;
+      const char* src = ok ? p.w + ((size_t)r * d.Kp + piece * 8) * 2 : p.zero;
+      glds16(src, wl + inst * 1024);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
