@@ -447,7 +447,10 @@ def main():
                                               "HIP-event timings",
                                "launches_timed": res[dom][0], "avg_ms": kernels[dom]["avg_ms"],
                                "timed_in": "%d launch-by-launch single-stream steps right after the timed region%s"
-                                           % (timing_steps, " (which ran as hipGraph replays)" if graphed else "")}
+                                           % (timing_steps, " (which ran as hipGraph replays)" if graphed else ""),
+                               # an event pair brackets the launch AND its dispatch gap: 2-3 us above the kernel-only
+                               # duration rocprofv3 reports for the same kernel (profiles/r02_step_kernel_stats_graph_v4.txt)
+                               "event_bracket_overhead_us": "2-3"}
             out["residual_conv_kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
