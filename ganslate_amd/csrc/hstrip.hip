@@ -6,7 +6,7 @@
 // (7 x 67 MB for the output conv) and the launches sit at 68-86 us against an HBM floor of ~21. With taps in one column
 // the input window of a tile of R rows x 8 columns is the (R + 6) x 8 strip above and below it — contiguous pixels, tap t
 // = a shift by dh_t x 8 pixels — so a workgroup stages that strip once (LDS-DMA, row border resolved per lane), keeps ALL
-// the layer's weights in LDS (<= 29 KB) and runs the taps out of it: input read once, no K loop over global memory.
+// the layer's weights in LDS (<= 30 KB) and runs the taps out of it: input read once, no K loop over global memory.
 // 4 waves x (64 pixels x Co), 256-pixel tiles (32 x 8), <= 78 KB of LDS: two workgroups per CU overlap each other's
 // load / compute / store phases. Epilogue contract of gconv_kernel: bias, one statistics slot per tile, activation,
 // dense or sliced output.
@@ -29,14 +29,16 @@ struct HStripK {
 
 template <int CI, int CO>
 __global__ __launch_bounds__(256) void hstrip_kernel(const HStripK p) {
-  constexpr int PP = CI / 8 + 2;                 // 16-B pieces per pixel incl. 2 pad pieces (160 B / 96 B... see below)
-  constexpr int PITCH = CI == 64 ? 160 : 80;     // bytes per staged pixel: 16 consecutive pixels cover all banks once
-  constexpr int PIECES = PITCH / 16;             // 10 / 5
+  // bytes per staged pixel: data + 2 pad pieces. A ds_read_b128 is served in groups of 8 consecutive pixels x 2 k-pieces
+  // (hconvw.hip): the pitch in banks must be 8 mod 16 for the 16 lanes to land on 16 distinct 4-bank slots — 160 B (40
+  // banks) for 64 channels, 96 B (24) for 32. (80 B / one pad piece measured 48 % of the LDS-active cycles in conflicts.)
+  constexpr int PITCH = CI == 64 ? 160 : 96;
+  constexpr int PIECES = PITCH / 16;             // 10 / 6
   constexpr int TI = CO / 16, TJ = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const gs_gconv_desc& d = p.d;
   const int T = d.T;
-  const int WROW = T * CI * 2 + 16;              // weight row pitch (one pad piece spreads 16 rows over the banks)
+  const int WROW = T * CI * 2 + 32;              // weight row pitch: T * CI / 2 banks = 0 mod 16, + 8 banks of pad (same rule)
   const int wbytes = ((CO * WROW + 1023) / 1024) * 1024;
   char* wl = smem;                               // [CO][WROW]
   char* halo = smem + wbytes;                    // [(TR + span) * TC pixels][PITCH]
@@ -68,12 +70,12 @@ __global__ __launch_bounds__(256) void hstrip_kernel(const HStripK p) {
   // piece); L2-resident after the first workgroups. (A register copy loop here — 14 dependent load / store rounds per
   // thread — was the longest phase of the workgroup.) ----
   {
-    const int rp1 = T * CI / 8 + 1;              // 16-B pieces per LDS row incl. the pad piece
+    const int rp1 = T * CI / 8 + 2;              // 16-B pieces per LDS row incl. the two pad pieces
     const int winstr = (CO * rp1 + 63) / 64;
     for (int inst = wave; inst < winstr; inst += 4) {
       const int q = inst * 64 + lane;
       const int r = q / rp1, piece = q - r * rp1;
-      const bool ok = r < CO && r < d.w_rows && piece < rp1 - 1;
+      const bool ok = r < CO && r < d.w_rows && piece < rp1 - 2;
       const char* src = ok ? p.w + ((size_t)r * d.Kp + piece * 8) * 2 : p.zero;
       glds16(src, wl + inst * 1024);
     }
@@ -193,8 +195,8 @@ Plan plan(const gs_gconv_desc* d) {
   const long long blocks = (long long)d->N * ((d->Ho + TR - 1) / TR) * ((d->Wo + TC - 1) / TC);
   if (blocks < minb || blocks >= (1LL << 31)) return h;
   if ((long long)d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 31)) return h;
-  const int pitch = d->Ci == 64 ? 160 : 80;
-  const int wbytes = ((h.co * (d->T * d->Ci * 2 + 16) + 1023) / 1024) * 1024;
+  const int pitch = d->Ci == 64 ? 160 : 96;
+  const int wbytes = ((h.co * (d->T * d->Ci * 2 + 32) + 1023) / 1024) * 1024;
   const int hbytes = (((TR + h.span) * TC * (pitch / 16) + 63) / 64) * 1024;
   const int slab = 256 * (h.co * 2 + 16);
   h.lds = wbytes + (hbytes > slab ? hbytes : slab);
