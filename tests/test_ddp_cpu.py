@@ -179,3 +179,49 @@ def test_vnet3d_cyclegan_two_ranks_stay_in_sync(tmp_path):
     r0, r1 = (torch.load(tmp_path / f"vnet_rank{r}.pt") for r in range(world))
     for name in r0:
         assert torch.equal(r0[name], r1[name]), f"{name}: ranks diverged"
+
+
+def _multiscale_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), GANSLATE_DIST_BACKEND="gloo")
+    torch.set_num_threads(2)
+    import random
+    from ganslate_amd.nn.native import backend
+    from ganslate_amd.utils import communication
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    from oracle.ops_ref import RefOps
+    communication.init_distributed()
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    conf = build_conf([f"config={ROOT / 'tests/configs/cyclegan3d_synthetic.yaml'}", "train.batch_size=1",
+                       "train.gan.generator.n_residual_blocks=1", "train.gan.pool_size=0",
+                       "train.gan.discriminator._target_=ganslate.nn.discriminators.MultiScalePatchGAN3D",
+                       "train.gan.discriminator.n_layers=1", "train.gan.discriminator.ndf=8",
+                       "train.gan.discriminator.scales=2", "train.dataset.final_size=[16,16,24]"])
+    torch.manual_seed(21 + rank)
+    model = build_gan(conf)
+    random.seed(100 + rank)                   # every rank draws its own crop windows, like it sees its own data
+    g = torch.Generator().manual_seed(79)
+    A, B = torch.rand(world, 1, 16, 16, 24, generator=g) * 2 - 1, torch.rand(world, 1, 16, 16, 24, generator=g) * 2 - 1
+    for step in range(2):
+        model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
+        model.optimize_parameters()
+    weights = {f"{n}.{i}": sub.master.detach().clone() for n, net in model.networks.items()
+               for i, sub in enumerate(net.native_children() if hasattr(net, "native_children") else [net])}
+    torch.save(weights, Path(out_dir) / f"ms_rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_multiscale_discriminators_two_ranks_stay_in_sync(tmp_path):
+    """composite networks under data parallelism: each PatchGAN3D of a MultiScalePatchGAN3D is broadcast from rank 0 and has
+    its flat gradient averaged (BaseGAN._native_nets); ranks with different inputs and crop windows end with identical
+    parameters in every sub-network"""
+    world = 2
+    port = _free_port()
+    mp.spawn(_multiscale_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"ms_rank{r}.pt") for r in range(world))
+    assert sum(k.startswith("D_A.") for k in r0) == 2 and sum(k.startswith("D_B.") for k in r0) == 2
+    for name in r0:
+        assert torch.equal(r0[name], r1[name]), f"{name}: ranks diverged"
