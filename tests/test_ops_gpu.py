@@ -258,6 +258,8 @@ def test_merged_parity_classes_equal_separate_launches(hip_ops, case):
     (ConvSpec("conv", 128, 256, 3, 2, 1), 3, 128, 160),             # d256 data gradient, ragged box grid 4 x 5
     (ConvSpec("conv", 64, 128, 4, 2, 1), 12, 128, 128),             # PatchGAN k4 gradient: 4 / 4 / 4 / 4 taps
     (ConvSpec("conv", 128, 256, 4, 2, 1), 16, 64, 96),              # PatchGAN k4 gradient, Co = 128
+    (ConvSpec("convT", 128, 64, 4, 2, 1, 0), 3, 48, 64),            # U-Net k4 transposed conv forward (bias + statistics)
+    (ConvSpec("convT", 256, 128, 4, 2, 1, 0), 2, 32, 32),           # ... two channel tiles, 4 chunks
 ], ids=_ids)
 def test_halo_resident_parity_classes(hip_ops, case):
     """hconvt.hip (all four output-parity classes of a stride-2 layer out of one halo-resident pass) against the per-class
