@@ -197,12 +197,12 @@ def _multiscale_worker(rank, world, port, out_dir):
                        "train.gan.generator.n_residual_blocks=1", "train.gan.pool_size=0",
                        "train.gan.discriminator._target_=ganslate.nn.discriminators.MultiScalePatchGAN3D",
                        "train.gan.discriminator.n_layers=1", "train.gan.discriminator.ndf=8",
-                       "train.gan.discriminator.scales=2", "train.dataset.final_size=[16,16,24]"])
+                       "train.gan.discriminator.scales=2", "train.dataset.final_size=[16,16,16]"])
     torch.manual_seed(21 + rank)
     model = build_gan(conf)
     random.seed(100 + rank)                   # every rank draws its own crop windows, like it sees its own data
     g = torch.Generator().manual_seed(79)
-    A, B = torch.rand(world, 1, 16, 16, 24, generator=g) * 2 - 1, torch.rand(world, 1, 16, 16, 24, generator=g) * 2 - 1
+    A, B = torch.rand(world, 1, 16, 16, 16, generator=g) * 2 - 1, torch.rand(world, 1, 16, 16, 16, generator=g) * 2 - 1
     for step in range(2):
         model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
         model.optimize_parameters()

@@ -10,7 +10,22 @@ import torch
 from ganslate_amd.nn.native import backend
 from oracle.ops_ref import RefOps
 
-from .helpers import build_product_cyclegan, golden_inputs, load_golden_steps
+from .helpers import CONF, golden_inputs, load_golden_steps
+
+
+def build_product_cyclegan(c):
+    """the recipe of golden case `c` with 2-block generators and seeded random weights: these tests compare two executions of
+    the SAME model with each other (plain vs externally prepared / deferred), not against the reference"""
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    conf = build_conf([f"config={CONF}", f"train.batch_size={c['batch']}", f"train.n_iters={c['n_iters']}",
+                       f"train.n_iters_decay={c['n_iters_decay']}", f"train.gan.pool_size={c['pool_size']}",
+                       f"train.gan.optimizer.lambda_identity={c['lambda_identity']}",
+                       f"train.gan.optimizer.proportion_ssim={c['proportion_ssim']}",
+                       "train.gan.generator.n_residual_blocks=2"])
+    torch.manual_seed(c["seed"])
+    model = build_gan(conf)
+    random.seed(c["seed"])
+    return model
 
 
 @pytest.fixture()
