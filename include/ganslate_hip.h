@@ -89,8 +89,10 @@ void gs_shutdown(void);
 const char* gs_last_error(void);
 /* Kernel-selection switches (A/B measurements, parity tests): the library reads NO environment variable; the host
  * side maps its GS_* variables onto these (ganslate_amd/hip/ops.py). Names: splitk, splitk_max_blocks, splitk_target,
- * hconv, hconv_wide, hconvw_waves, hwgrad, hwgrad_wide, hwgrad_planes, norm_bwd_ppb, norm_apply_unroll. Every setting
- * computes the same function (up to the fp32 summation order); none skips work. Unknown name -> non-zero. */
+ * hconv, hconv_wide, hconvw_waves, hwgrad, hwgrad_wide, hwgrad_planes, norm_bwd_ppb, norm_apply_unroll, gconv_tile288,
+ * gconv_multi, hconvw_ring, hconvt (smallest grid the parity-class halo kernel takes, 0 = off), hstrip (same for the k7
+ * boundary-conv kernel). Every setting computes the same function (up to the fp32 summation order and, for hconvw_ring,
+ * where the bf16 rounding of the folded gradient happens); none skips work. Unknown name -> non-zero. */
 int gs_set_option(const char* name, int value);
 int gs_get_option(const char* name, int* value);
 int gs_tile_m(const gs_gconv_desc* d);   /* pixel-tile height of the im2col kernel for this class */
@@ -106,7 +108,11 @@ int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack,
  * 2-D, 8 in 3-D — SURVEY.md §2.3 K3/K4; resnet2d.py:52-57, patchgan2d.py:36-48 backward) in one launch. descs[c] /
  * w_packs[c] are what `count` calls of gs_gconv_forward would take; the classes must agree in everything but taps, Kp,
  * output phase (pz,py,px) and stats_slot0, with at most 8 taps each — otherwise (and for count == 1) the call runs them one
- * after the other, so it is always valid to use. Same results as the separate launches, bit for bit. */
+ * after the other, so it is always valid to use. On the im2col kernel the results equal the separate launches bit for bit.
+ * 2-D k3 / k4 layers with channel counts that are multiples of 64, a class grid that is a multiple of 16 and a large enough
+ * grid run all four classes out of one halo-resident pass instead (hconvt.hip, option `hconvt`): same function, another
+ * fp32 summation order, and of the layer's `stats_slots` slots the first (class grid / 256) hold the per-box sums over all
+ * classes while the others are written as zeros — consumers sum the slots, as gs_inorm_finalize does. */
 int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
                            const float* bias, void* out, float* stats, void* stream);
 
