@@ -327,8 +327,17 @@ int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count) {
   if (descs[0]->T == 1 && descs[1]->T == 2 && descs[2]->T == 2 && descs[3]->T == 4) pat = 0;
   if (descs[0]->T == 4 && descs[1]->T == 4 && descs[2]->T == 4 && descs[3]->T == 4) pat = 1;
   if (pat < 0) return -1;
-  for (int c = 0; c < NC; ++c)
-    if (descs[c]->pz != 0 || descs[c]->py < 0 || descs[c]->py > 1 || descs[c]->px < 0 || descs[c]->px > 1) return -1;
+  for (int c = 0; c < NC; ++c) {
+    const gs_gconv_desc* e = descs[c];
+    if (e->pz != 0 || e->py < 0 || e->py > 1 || e->px < 0 || e->px > 1) return -1;
+    // the kernel takes geometry, border, strides and the epilogue contract from descs[0]: every class must agree with it
+    if (e->N != d->N || e->Hi != d->Hi || e->Wi != d->Wi || e->Di != d->Di || e->Ci != d->Ci || e->Co != d->Co ||
+        e->Ho != d->Ho || e->Wo != d->Wo || e->Do != d->Do || e->Hc != d->Hc || e->Wc != d->Wc || e->Dc != d->Dc ||
+        e->in_cs != d->in_cs || e->in_co != d->in_co || e->out_cs != d->out_cs || e->out_co != d->out_co ||
+        e->so != d->so || e->si != d->si || e->border != d->border || e->act != d->act || e->slope != d->slope ||
+        e->stats_slots != d->stats_slots || e->accumulate != d->accumulate)
+      return -1;
+  }
   int lo[2];
   if (!window(descs, lo)) return -1;
   const int chunks = d->Ci / 64;
@@ -343,7 +352,7 @@ int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count) {
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
                      const float* bias, void* out, float* stats, void* stream) {
   const gs_gconv_desc* d = descs[0];
-  static HConvTK k;
+  HConvTK k;   // a plain local: autograd issues launches from its own host threads
   k.in = static_cast<const char*>(in);
   k.w = static_cast<const char*>(w_packs[0]);
   k.bias = bias;

@@ -576,27 +576,55 @@ class HipOps:
         return d
 
     def patchnce_forward(self, xq, xk, params, *, batch, nc=256, nce_T=0.07, lambda_nce=1.0):
-        """xq / xk: lists of [batch, patches, C_l] fp32 (target / source patches per level), params: flat fp32 MLP
-        parameters -> (loss per level [L] fp32, saved state for patchnce_backward)"""
+        """xq / xk: lists of [batch, patches_l, C_l] fp32 (target / source patches per level), params: flat fp32 MLP
+        parameters -> (loss per level [L] fp32, saved state for patchnce_backward).
+        Levels normally share one patch count and run as ONE launch group. FeaturePatchMLP draws min(num_patches,
+        pixels of the level) ids per level (cut.py:262-268), so on small inputs deep levels carry fewer patches: then every
+        level runs as its own launch group with its own row count, weighted lambda / (levels * batch * patches_l) like
+        the reference's per-level .mean() (cut.py:218-226)."""
+        n_lv = len(xq)
         channels = [int(t.shape[-1]) for t in xq]
-        patches = int(xq[0].shape[1])
-        d = self._nce_desc(channels, batch, patches, nc, nce_T, lambda_nce)
+        for l, (q, k) in enumerate(zip(xq, xk)):
+            if q.dim() != 3 or tuple(q.shape) != tuple(k.shape) or int(q.shape[0]) != batch:
+                raise ValueError(f"patchnce_forward: level {l}: target {tuple(q.shape)} / source {tuple(k.shape)} patches "
+                                 f"must both be [batch={batch}, patches, channels]")
+        per_level = [int(t.shape[1]) for t in xq]
+        if nc != 256 or max(per_level) > 256 or min(per_level) < 1 or max(channels) > 256:
+            raise NotImplementedError(
+                f"gs_patchnce_*: the fused PatchNCE kernels take mlp_nc == 256, 1..256 patches per image and level "
+                f"and <= 256 channels per level (got mlp_nc={nc}, patches={per_level}, channels={channels}); "
+                "num_patches: 0 (every pixel) and wider features have no HIP path")
         xq = [t.contiguous().float() for t in xq]
         xk = [t.contiguous().float() for t in xk]
-        work = torch.empty(int(self.lib.gs_patchnce_work_bytes(C.byref(d))), dtype=torch.uint8, device=self.device)
-        loss = torch.empty(len(xq), dtype=torch.float32, device=self.device)
-        pq = (C.c_void_p * len(xq))(*[t.data_ptr() for t in xq])
-        pk = (C.c_void_p * len(xk))(*[t.data_ptr() for t in xk])
-        L.check(self.lib.gs_patchnce_forward(C.byref(d), pq, pk, _ptr(params), _ptr(work), _ptr(loss), _stream()),
-                "gs_patchnce_forward")
-        return loss, (d, xq, work)
+        loss = torch.empty(n_lv, dtype=torch.float32, device=self.device)
+        if len(set(per_level)) == 1:
+            groups = [(list(range(n_lv)), 0, lambda_nce)]
+        else:      # one group per level; its lambda carries the 1 / levels of the whole loss
+            offs, off = [], 0
+            for c in channels:
+                offs.append(off)
+                off += nc * c + nc + nc * nc + nc
+            groups = [([l], offs[l], lambda_nce / n_lv) for l in range(n_lv)]
+        saved = []
+        for lv, poff, lam in groups:
+            d = self._nce_desc([channels[l] for l in lv], batch, per_level[lv[0]], nc, nce_T, lam)
+            work = torch.empty(int(self.lib.gs_patchnce_work_bytes(C.byref(d))), dtype=torch.uint8, device=self.device)
+            gq, gk = [xq[l] for l in lv], [xk[l] for l in lv]
+            pq = (C.c_void_p * len(lv))(*[t.data_ptr() for t in gq])
+            pk = (C.c_void_p * len(lv))(*[t.data_ptr() for t in gk])
+            L.check(self.lib.gs_patchnce_forward(C.byref(d), pq, pk, _ptr(params[poff:]), _ptr(work),
+                                                 _ptr(loss[lv[0]:]), _stream()), "gs_patchnce_forward")
+            saved.append((d, gq, work, poff))
+        return loss, saved
 
     def patchnce_backward(self, saved, params, grads, grad_scale=None):
         """-> list of d(sum of level losses)/d xq[l] * grad_scale; parameter gradients are added into `grads`"""
-        d, xq, work = saved
-        dxq = [torch.empty_like(t) for t in xq]
-        pq = (C.c_void_p * len(xq))(*[t.data_ptr() for t in xq])
-        pd = (C.c_void_p * len(xq))(*[t.data_ptr() for t in dxq])
-        L.check(self.lib.gs_patchnce_backward(C.byref(d), pq, pd, _ptr(params), _ptr(grads), _ptr(work),
-                                              _ptr(grad_scale), _stream()), "gs_patchnce_backward")
-        return dxq
+        out = []
+        for d, xq, work, poff in saved:
+            dxq = [torch.empty_like(t) for t in xq]
+            pq = (C.c_void_p * len(xq))(*[t.data_ptr() for t in xq])
+            pd = (C.c_void_p * len(xq))(*[t.data_ptr() for t in dxq])
+            L.check(self.lib.gs_patchnce_backward(C.byref(d), pq, pd, _ptr(params[poff:]), _ptr(grads[poff:]),
+                                                  _ptr(work), _ptr(grad_scale), _stream()), "gs_patchnce_backward")
+            out += dxq
+        return out

@@ -50,7 +50,8 @@ class RevGAN(BaseGAN):
             self.fake_B_pool = ImagePool(conf.train.gan.pool_size)
         self.setup()
         if not getattr(self.networks["G"], "use_inverse", False):
-            raise ValueError("RevGAN needs a generator with an inverse direction (Vnet2D / Vnet3D with use_inverse: true)")
+            raise ValueError("RevGAN needs a generator with an inverse direction (Piresnet3D, or Vnet2D / Vnet3D with "
+                             "use_inverse: true)")
 
     def _step_pools(self):
         return [self.fake_B_pool, self.fake_A_pool]      # backward_D("D_B") runs first

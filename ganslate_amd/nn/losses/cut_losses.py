@@ -1,28 +1,17 @@
-"""PatchNCE (InfoNCE over feature patches) — arithmetic of ganslate/nn/losses/cut_losses.py:5-43:
-logits = [q.k+ , q.k_j (j != i, diagonal -> -10)] / T, cross-entropy against class 0, `feat_k` detached, negatives
-are the other patches of the SAME image (bmm batched by train.batch_size).
-The tensors are tiny ((B*256) x 256 per layer); they run as plain library GEMMs + softmax on the device."""
-import torch
+"""PatchNCE (InfoNCE over feature patches) — ganslate/nn/losses/cut_losses.py:5-43.
+
+In this package the loss is not a stand-alone criterion: the patch MLP, the L2 normalisation, the logits
+[q.k+ , q.k_j (j != i, diagonal -> -10)] / T and the cross-entropy against class 0 run as ONE hand-written kernel family
+(`csrc/patchnce.hip`, `gs_patchnce_forward/backward`) behind `FeaturePatchMLP.nce_loss`
+(`ganslate_amd/nn/gans/unpaired/cut.py`), which is what `CUT` calls. A torch-ops restatement used to live here; it was
+never on the product path and silently left the HIP kernels when instantiated from a user recipe, so the name now fails
+loudly and points at the fused entry."""
 
 
 class PatchNCELoss:
 
     def __init__(self, conf):
-        self.batch_size = conf.train.batch_size
-        self.nce_T = conf.train.gan.optimizer.nce_T
-
-    def to(self, device):
-        return self
-
-    def __call__(self, feat_q, feat_k):
-        bs, dim = feat_q.shape[:2]
-        feat_k = feat_k.detach()
-        l_pos = (feat_q * feat_k).sum(1, keepdim=True)
-        q = feat_q.view(self.batch_size, -1, dim)
-        k = feat_k.view(self.batch_size, -1, dim)
-        n = q.size(1)
-        l_neg = torch.bmm(q, k.transpose(2, 1))
-        l_neg = l_neg.masked_fill(torch.eye(n, device=q.device, dtype=torch.bool)[None], -10.0).view(-1, n)
-        out = torch.cat((l_pos, l_neg), dim=1) / self.nce_T
-        return torch.nn.functional.cross_entropy(out, torch.zeros(out.size(0), dtype=torch.long, device=q.device),
-                                                 reduction="none")
+        raise NotImplementedError(
+            "ganslate_amd has no stand-alone PatchNCELoss: the loss is fused with FeaturePatchMLP "
+            "(FeaturePatchMLP.nce_loss -> gs_patchnce_forward / gs_patchnce_backward, csrc/patchnce.hip). "
+            "Call mlp.nce_loss(target_feats, source_feats, batch, nce_T, lambda_nce) as CUT._calculate_nce_loss does.")

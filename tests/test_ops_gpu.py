@@ -970,7 +970,8 @@ def test_inorm_stats_act_forward_fused(hip_ops, shape, slots, res):
 
 
 @pytest.mark.parametrize("batch,patches,channels", [(8, 256, (3, 128, 256, 256, 256)), (2, 256, (3, 128, 256)),
-                                                    (1, 100, (8, 64)), (3, 64, (256,))])
+                                                    (1, 100, (8, 64)), (3, 64, (256,)),
+                                                    (2, (256, 256, 64, 16), (3, 128, 256, 256))])
 def test_patchnce_forward_backward(hip_ops, batch, patches, channels):
     """gs_patchnce_forward / gs_patchnce_backward (FeaturePatchMLP + PatchNCELoss of CUT, all levels in one launch per
     stage) against torch autograd of the reference composition (oracle/ops_ref.patchnce_reference). bf16 operands with
@@ -978,8 +979,11 @@ def test_patchnce_forward_backward(hip_ops, batch, patches, channels):
     relative; gradients — three chained bf16 GEMMs behind a soft-max — within 4e-2 relative L2 (measured 1.5e-2 .. 3.1e-2)."""
     g = torch.Generator().manual_seed(41)
     nc = 256
-    xq = [torch.randn(batch, patches, c, generator=g) for c in channels]
-    xk = [q + 0.5 * torch.randn(batch, patches, c, generator=g) for q, c in zip(xq, channels)]      # correlated keys
+    # a tuple: patches per level — FeaturePatchMLP draws min(num_patches, pixels of the level) ids (cut.py:262-268), so the
+    # deep levels of a small input carry fewer rows, each level averaged over its own row count (cut.py:218-226)
+    per_level = patches if isinstance(patches, tuple) else (patches,) * len(channels)
+    xq = [torch.randn(batch, p_, c, generator=g) for p_, c in zip(per_level, channels)]
+    xk = [q + 0.5 * torch.randn(q.shape, generator=g) for q in xq]      # correlated keys
     numel = sum(nc * c + nc + nc * nc + nc for c in channels)
     params = torch.randn(numel, generator=g) * 0.05
     gscale = torch.tensor(0.37)
@@ -1004,3 +1008,18 @@ def test_patchnce_forward_backward(hip_ops, batch, patches, channels):
             a, b = res["hip"][2][off:off + n], res["ref"][2][off:off + n]
             assert rel(a, b) <= 5e-2, (c, n, rel(a, b))
             off += n
+
+
+def test_patchnce_rejects_shapes_without_a_hip_path(hip_ops):
+    """mlp_nc != 256, more than 256 patches per image (num_patches: 0 = every pixel) and unequal target / source shapes
+    raise instead of reading past the smaller tensor or leaving the HIP path"""
+    dev = hip_ops.device
+    q = [torch.randn(1, 300, 8, device=dev)]
+    p = torch.zeros(256 * 8 + 256 + 256 * 256 + 256, device=dev)
+    with pytest.raises(NotImplementedError):
+        hip_ops.patchnce_forward(q, q, p, batch=1, nc=256)
+    q = [torch.randn(1, 64, 8, device=dev)]
+    with pytest.raises(NotImplementedError):
+        hip_ops.patchnce_forward(q, q, p, batch=1, nc=128)
+    with pytest.raises(ValueError):
+        hip_ops.patchnce_forward(q, [torch.randn(1, 32, 8, device=dev)], p, batch=1, nc=256)

@@ -7,7 +7,7 @@ out=${1:-gpurun_out/pmc}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-export GS_SIDE_STREAM=0 GS_STEP_GRAPH=0 GS_BENCH_ALLOW_ABLATION=1
+export GS_SIDE_STREAM=0 GS_STEP_GRAPH=0
 run() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
