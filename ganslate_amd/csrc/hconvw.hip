@@ -13,19 +13,24 @@
 #include <cstdlib>
 #include <type_traits>
 
-struct HConvWK {
-  const char* in;
-  const char* w;
-  const float* bias;
-  char* out;
-  float* stats;
-  const char* zero;
-  int tiles_m, tiles_n, nbw;   // boxes per image, channel tiles, boxes per row
-  int hh, hw, hmin, wmin;      // halo extent and smallest tap offsets
-  int chunks;                  // Ci / 64
-  gs_gconv_desc d;
-  gs_gconv_fuse f;             // RING: the consumer's InstanceNorm backward sums ride in the epilogue (gs_gconv_forward_fused)
-};
+#include "hconvw.hpp"
+
+#ifdef GS_TIMELINE
+// Debug build only (tools/probe/timeline.py, never the product library): s_memtime stamps of one workgroup's phases, kept in
+// the 9 KiB of LDS the kernel leaves free and dumped to a global buffer at the end. TLW waves x TLS slots of 32 bits.
+__device__ unsigned* g_tl_buf = nullptr;
+extern "C" int gs_debug_timeline(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+constexpr int TLW = 8, TLS = 160;
+#define TL_STAMP(slot)                                                                            \
+  do {                                                                                            \
+    if (tl_on) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                      \
+      if (lane == 0) tl[tl_w * TLS + (slot)] = t_; }                                              \
+  } while (0)
+#else
+#define TL_STAMP(slot) do {} while (0)
+#endif
 
 // NW = 16: waves as 4 x 4, 64 pixels x 32 channels each; NW = 8: 4 x 2, 64 x 64 each (a third fewer fragment reads per
 // MFMA — the loop is bound by LDS reads — for half the latency hiding)
@@ -64,6 +69,12 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+#ifdef GS_TIMELINE
+  unsigned* tl = reinterpret_cast<unsigned*>(smem + 3 * WT + 2 * HBUF + 1024);
+  const int tl_w = NW == 8 ? wave : ((wave & 3) | ((wave >> 3) << 2));          // NW 16: waves 0-3 and 8-11
+  const bool tl_on = g_tl_buf != nullptr && (NW == 8 || (wave & 4) == 0);
+  TL_STAMP(0);
+#endif
   int b;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
@@ -217,8 +228,10 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPI) : "memory");
   else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TL_STAMP(1);
   __builtin_amdgcn_s_barrier();
   if (grp) __builtin_amdgcn_s_barrier();
+  TL_STAMP(2);
   const unsigned wring0 = smem0 + woff, hbuf0 = smem0 + 3 * WT;
   bf16x8 wA[TI], xA[TJ], wB[TI], xB[TJ];
   [[maybe_unused]] bf16x8 xE0, xE1;
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       if constexpr (RING) {
         if (e_now) { reg_fence(xE0); reg_fence(xE1); }
       }
+      TL_STAMP(8 + ks * 4 + 0);
       auto wait_next_weights = [&]() {       // this wave's share of step ks+1's weights (and anything older) has landed
         if (ks + 1 >= nk) return;
         if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       };
       if (grp) wait_next_weights();
       __builtin_amdgcn_s_barrier();
+      TL_STAMP(8 + ks * 4 + 1);
       // ---- M(ks) ----
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -272,8 +287,10 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      TL_STAMP(8 + ks * 4 + 2);
       if (!grp) wait_next_weights();
       __builtin_amdgcn_s_barrier();
+      TL_STAMP(8 + ks * 4 + 3);
       stage = stage == 2 ? 0 : stage + 1;
     }
   }
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
     bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
+  TL_STAMP(3);
 
   // ---- epilogue: bias, partial statistics (slot = box), activation, LDS-staged coalesced NHWC stores ------------
   const bool want_stats = d.stats_slots > 0;
@@ -437,6 +455,7 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       }
     }
   }
+  TL_STAMP(4);
   if (want_stats) {
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -465,7 +484,16 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       }
     }
   }
+#ifdef GS_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores have been accepted
+  TL_STAMP(5);
+  __syncthreads();
+  if (g_tl_buf != nullptr && (blockIdx.x == 0 || blockIdx.x == 101))
+    for (int i = tid; i < TLW * TLS; i += NW * 64) g_tl_buf[(blockIdx.x == 0 ? 0 : 1) * TLW * TLS + i] = tl[i];
+#endif
 }
+
+int gs_hconvx_launch(const HConvWK& k, long long blocks, void* stream);   // hconvx.hip
 
 static bool hconvw_eligible(const gs_gconv_desc* d, int* lo) {
   const bool enabled = gs_opt(GS_OPT_HCONV_WIDE) != 0;
@@ -514,7 +542,11 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.chunks = d->Ci / 64;
   k.d = *d;
   k.f = gs_gconv_fuse{};
+#ifdef GS_TIMELINE
+  const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024 + TLW * TLS * 4;
+#else
   const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
+#endif
   const int nw = gs_opt(GS_OPT_HCONVW_WAVES);
   static bool configured = false;
   if (!configured) {
@@ -525,6 +557,7 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
     configured = true;
   }
   *handled = 1;
+  if (gs_opt(GS_OPT_HCONVX)) return gs_hconvx_launch(k, blocks, stream);
   if (nw == 8)
     hipLaunchKernelGGL((hconvw_kernel<9, 8>), dim3((unsigned)blocks), dim3(512), lds, static_cast<hipStream_t>(stream), k);
   else

@@ -46,7 +46,8 @@ class HipOps:
                    "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_NW": "hconvw_waves",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
-                   "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip"}
+                   "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
+                   "GS_HCONVX": "hconvx"}
 
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")

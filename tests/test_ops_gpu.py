@@ -132,6 +132,33 @@ def test_gconv_forward_stats(hip_ops, case):
     close_f32(mr_hip.view(N, 2, C)[:, 1], mr_ref.view(N, 2, C)[:, 1], "rstd", rel=1e-3)
 
 
+@pytest.mark.parametrize("form", [1, 100], ids=["8-waves", "8+4-loader-waves"])
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),     # headline trunk conv (4 chunks x 9 taps)
+    (ConvSpec("conv", 64, 128, 3, 1, 1, pad_mode="reflect"), 4, 128, 96),     # one chunk, one channel tile, border boxes
+    (ConvSpec("conv", 128, 256, 3, 1, 1), 4, 64, 96),                         # zero border, two chunks
+], ids=_ids)
+def test_self_pipelined_wide_kernel(hip_ops, monkeypatch, case, form):
+    """hconvx.hip (gs_set_option("hconvx", 1 | 100): the self-pipelined 8-wave form of the wide 3x3 kernel on 32x32x16 MFMAs,
+    alone or with four loader waves; measured equal to hconvw.hip's phase-locked loop — the chip sustains a lower clock under
+    the denser loop, profiles/r03_power_probe.txt — and therefore off by default) against the oracle: same contract as the
+    default form (bias, one statistics slot per 16 x 16 box, bf16 NHWC output)."""
+    monkeypatch.setenv("GS_HCONVX", str(form))
+    hip_ops.sync_options()
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 11)
+    assert hip_ops.stat_slots(low.fwd[0], N) == (sizes[0] // 16) * (sizes[1] // 16), "the wide halo kernel must take this layer"
+    g = torch.Generator().manual_seed(12)
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16)
+    y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N)
+    y_hip, mr_hip = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N)
+    torch.cuda.synchronize()
+    close_bf16(y_hip, y_ref, "conv output")
+    C = spec.cout_p
+    close_f32(mr_hip.view(N, 2, C)[:, 0], mr_ref.view(N, 2, C)[:, 0], "mean", rel=1e-3)
+    close_f32(mr_hip.view(N, 2, C)[:, 1], mr_ref.view(N, 2, C)[:, 1], "rstd", rel=1e-3)
+
+
 @pytest.mark.parametrize("case", [
     (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 40, 56),     # stem, ragged tile grid (40 = 32 + 8)
     (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 32, 32),    # output conv: 38 columns out
