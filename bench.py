@@ -32,6 +32,16 @@ HBM_BYTES = {"rb_fwd": (42.6e6, "profiles/r02_trunk_pmc_v2.txt"), "rb_dgrad": (6
              "rb_wgrad_pair": (109.2e6, "profiles/r02_trunk_pmc_v2.txt")}
 
 
+def algorithmic_bytes(label, batch, hw, C=256, taps=9):
+    """HBM bytes one launch of a residual-conv form has to move at least (bf16 activations [batch, hw, C], fp32 dW):
+    forward: x + y + W; fused data gradient: dY + y + g2 read, dX written, + W; weight-gradient pair: two (a, g) operand
+    pairs read, dW [C][taps][C] fp32 written once"""
+    act = batch * hw * C * 2
+    w = C * taps * C * 2
+    return {"rb_fwd": 2 * act + w, "rb_dgrad": 4 * act + w, "rb_wgrad_pair": 4 * act + 2 * w,
+            "rb_wgrad": 2 * act + 2 * w}.get(label)
+
+
 def make_pix2pix_conf(batch, n_iters):
     """BASELINE configs[2]: cityscapes_label2photo pix2pix.yaml:25-48 — Unet2D(num_downs 7, ngf 128, dropout) +
     PatchGAN2D(n_layers 4, 6 ch), 256x512 (a parity-test workload, measured with --workload pix2pix)"""
@@ -157,6 +167,61 @@ def cpu_baseline(size=256, steps=3):
                       f"{steps} timed steps, {threads} threads of {cores} host cpus"}
 
 
+# BASELINE configs[2..4] (per-GPU shapes, SURVEY.md §8 GFLOP per unit): timed for a few steps behind the headline so that the
+# driver's line shows them too
+SECONDARY = {
+    "pix2pix": {"config": "cityscapes pix2pix (BASELINE configs[2]): U-Net(7,128) + PatchGAN-4, 256x512, batch 1",
+                "unit": "img/s", "gflop_per_unit": 371.5},
+    "cut": {"config": "horse2zebra CUT (BASELINE configs[3]): ResNet-9 + PatchGAN-3 + PatchNCE, 256x256, batch 8",
+            "unit": "img/s", "gflop_per_unit": 1389.0},
+    "brats": {"config": "brats 3-D CycleGAN (BASELINE configs[4]): Vnet3D + PatchGAN3D-2, 128^3 patches, batch 1",
+              "unit": "vol/s", "gflop_per_unit": 27692.0},
+}
+
+
+def run_secondary(dev, steps=10, warmup=4):
+    """value / ms_per_step / fraction of the dense bf16 MFMA peak of the other BASELINE workloads on this GPU, `steps` timed
+    iterations each after `warmup` (the second iteration captures the step graph). Same step definition as the headline."""
+    import gc
+    import torch
+    from ganslate_amd.utils.builders import build_gan
+    out = {}
+    for name, meta in SECONDARY.items():
+        g = torch.Generator().manual_seed(4321)
+        if name == "pix2pix":
+            batch, shape, conf = 1, (1, 3, 256, 512), make_pix2pix_conf(1, 10 ** 6)
+        elif name == "cut":
+            batch, shape, conf = 8, (8, 3, 256, 256), make_cut_conf(8, 256, 10 ** 6)
+        else:
+            batch, shape, conf = 1, (1, 1, 128, 128, 128), make_volume_conf(1, 128, 10 ** 6, "vnet")
+        model = build_gan(conf)
+        data = {"A": (torch.rand(shape, generator=g) * 2 - 1).to(dev), "B": (torch.rand(shape, generator=g) * 2 - 1).to(dev)}
+
+        def step():
+            model.set_input(data)
+            model.optimize_parameters()
+            model.update_learning_rate()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        losses = {k: float(v.detach()) for k, v in model.losses.items() if v is not None}
+        assert all(v == v and abs(v) < 1e6 for v in losses.values()), f"{name}: non-finite losses {losses}"
+        value = batch * steps / dt
+        out[name] = {"config": meta["config"], "value": round(value, 3), "unit": meta["unit"], "steps": steps,
+                     "ms_per_step": round(1e3 * dt / steps, 3),
+                     "step_tflops": round(value * meta["gflop_per_unit"] / 1e3, 1),
+                     "step_mfma_frac": round(value * meta["gflop_per_unit"] / 1e3 / PEAK_BF16_TFLOPS, 4)}
+        del model, data, step
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +236,8 @@ def main():
                          "brats = configs[4] with the brats yaml's own networks (Vnet3D + PatchGAN3D-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short timed runs of the other BASELINE configs attached to the headline line as `secondary`")
     args = ap.parse_args()
 
     # a timed kernel must never be one that was told to skip work: the ablation switches of round 1 are compiled out
@@ -441,6 +508,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": kernels[dom]["frac"], "traffic": hbm,
                                "traffic_source": hbm_src,
+                               "algorithmic_bytes": algorithmic_bytes(dom, args.batch, hw),
                                "kernel": f"{names[dom]}: 3x3 256->256 reflect conv, M={hw * args.batch} N=256 K=2304"
                                          + (" x 2 passes" if dom == "rb_wgrad_pair" else ""),
                                "dominant_of": "the three residual-conv launch forms, by per-step total of their own "
@@ -452,6 +520,9 @@ def main():
                                # duration rocprofv3 reports for the same kernel (profiles/r02_step_kernel_stats_graph_v4.txt)
                                "event_bracket_overhead_us": "2-3"}
             out["residual_conv_kernels"] = kernels
+        if world == 1 and not args.no_secondary and args.batch == 8 and args.size == 256:
+            del model
+            out["secondary"] = run_secondary(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         emit(out)
