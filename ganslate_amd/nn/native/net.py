@@ -474,6 +474,10 @@ class NativeNet:
                 skip[nd.res] = total
             if i in inj_y:
                 dy = dy + inj_y[i]
+                if want_w and sp.bias and nd.norm:
+                    # a feature tapped from the RAW conv output (CUT's nce layer 4, cut.py:297-312) sees the bias: the norm's
+                    # reduction sums above give the (zero) bias gradient of the path through the norm only
+                    ops.bias_grad(inj_y[i], sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
             # ---- parameter gradients ---------------------------------------------------------------------------------
             if want_w:
                 dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]

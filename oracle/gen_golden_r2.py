@@ -8,11 +8,17 @@
     python -m oracle.gen_golden_r2 revgan      # tests/golden/revgan.json
     python -m oracle.gen_golden_r2 volpatch    # tests/golden/volume_patches.json
     python -m oracle.gen_golden_r2 multiscale  # tests/golden/multiscale_patchgan3d.json
+    python -m oracle.gen_golden_r2 recipegrads # tests/golden/recipe_grads.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
   ("D_A") :154-189): per tensor the L2 norm and 8 strided samples, plus the first two iterations' losses. Cases:
   `c64_default` (the 64x64 case of cyclegan_steps.json) and `cfg2_256_b8` (BASELINE configs[1] shape: 256x256, batch 8).
+* recipe_grads.json — the same record (per-tensor `.grad` norm + 8 strided samples after the FIRST iteration, and that
+  iteration's losses) for the other recipes: Pix2Pix (`p2p_64x128` and BASELINE configs[2] at full width, dropout off),
+  CUT (`cut_64`: G, D and the patch MLP), 3-D CycleGAN (`v32_default`, `vnet_16x32x32`), RevGAN (`rev3d_16x32x32`,
+  `rev3d_piresnet`) — the oracle's step classes are pinned to it, and the GPU tests compare the HIP gradients with the
+  oracle's full tensors (tests/test_recipe_gradients_*.py).
 * envelope.json — the reference against ITSELF: the same 100 iterations (64x64, batch 2, horse2zebra hyper-parameters)
   run with 1 and with 8 intra-op threads. The arithmetic is identical, only the summation order of MKL-DNN's
   reductions differs; the gap between the two curves is the floor no other implementation can be asked to beat and
@@ -205,6 +211,52 @@ def _both_directions_case(net, x_shape, seed):
             "param_grad_norms": {n: float(p.grad.norm()) for n, p in net.named_parameters()}}
 
 
+def _revgan_model(c):
+    """the reference's RevGAN for a REVGAN_CASES entry with the seeded weights loaded -> (model, input shape)"""
+    from oracle import gen_golden as G          # imports the reference
+    from omegaconf import DictConfig
+    from ganslate.nn.gans.unpaired.revgan import RevGAN
+    from oracle.torch_ref import seeded_state_dict
+    conf = G.make_conf(c)
+    conf.train.metrics["ssim"] = False
+    gan = conf.train.gan
+    gan["_target_"] = "ganslate.nn.gans.unpaired.RevGAN"
+    if "piresnet" in c:
+        gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Piresnet3D", "use_memory_saving": True,
+                                       "use_inverse": True, "depth": c["piresnet"]["depth"],
+                                       "first_layer_channels": c["piresnet"]["first_layer_channels"],
+                                       "in_out_channels": {"AB": [1, 1]}})
+        gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
+                                           "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                           "in_channels": {"B": 1, "A": 1}})
+        shape = (c["batch"], 1, *c["size"])
+    elif c["dims"] == 3:
+        gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet3D", "use_memory_saving": True,
+                                       "use_inverse": True, "is_separable": False,
+                                       "first_layer_channels": c["vnet"]["first_layer_channels"],
+                                       "down_blocks": c["vnet"]["down_blocks"], "up_blocks": c["vnet"]["up_blocks"],
+                                       "in_out_channels": {"AB": [1, 1]}})
+        gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
+                                           "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                           "in_channels": {"B": 1, "A": 1}})
+        shape = (c["batch"], 1, *c["size"])
+    else:
+        gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet2D", "use_memory_saving": True,
+                                       "use_inverse": True, "first_layer_channels": c["vnet"]["first_layer_channels"],
+                                       "in_out_channels": {"AB": [2, 2]}})
+        gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN2D", "ndf": 64,
+                                           "n_layers": c["d_layers"], "kernel_size": [4, 4],
+                                           "in_channels": {"B": 2, "A": 2}})
+        shape = (c["batch"], 2, *c["size"])
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    model = RevGAN(conf)
+    for k, (n, net) in enumerate(model.networks.items()):
+        net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+    random.seed(c["seed"])
+    return model, shape
+
+
 def revgan():
     """the reference's RevGAN and its generators' inverse direction over the memcnn stand-in (oracle/ref_stubs/memcnn:
     additive coupling forward / inverse with plain autograd — what memcnn's memory saving recomputes, it does not change)"""
@@ -224,43 +276,7 @@ def revgan():
     }
     steps = {}
     for name, c in REVGAN_CASES.items():
-        conf = G.make_conf(c)
-        conf.train.metrics["ssim"] = False
-        gan = conf.train.gan
-        gan["_target_"] = "ganslate.nn.gans.unpaired.RevGAN"
-        if "piresnet" in c:
-            gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Piresnet3D", "use_memory_saving": True,
-                                           "use_inverse": True, "depth": c["piresnet"]["depth"],
-                                           "first_layer_channels": c["piresnet"]["first_layer_channels"],
-                                           "in_out_channels": {"AB": [1, 1]}})
-            gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
-                                               "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
-                                               "in_channels": {"B": 1, "A": 1}})
-            shape = (c["batch"], 1, *c["size"])
-        elif c["dims"] == 3:
-            gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet3D", "use_memory_saving": True,
-                                           "use_inverse": True, "is_separable": False,
-                                           "first_layer_channels": c["vnet"]["first_layer_channels"],
-                                           "down_blocks": c["vnet"]["down_blocks"], "up_blocks": c["vnet"]["up_blocks"],
-                                           "in_out_channels": {"AB": [1, 1]}})
-            gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
-                                               "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
-                                               "in_channels": {"B": 1, "A": 1}})
-            shape = (c["batch"], 1, *c["size"])
-        else:
-            gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Vnet2D", "use_memory_saving": True,
-                                           "use_inverse": True, "first_layer_channels": c["vnet"]["first_layer_channels"],
-                                           "in_out_channels": {"AB": [2, 2]}})
-            gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN2D", "ndf": 64,
-                                               "n_layers": c["d_layers"], "kernel_size": [4, 4],
-                                               "in_channels": {"B": 2, "A": 2}})
-            shape = (c["batch"], 2, *c["size"])
-        torch.manual_seed(c["seed"])
-        random.seed(c["seed"])
-        model = RevGAN(conf)
-        for k, (n, net) in enumerate(model.networks.items()):
-            net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
-        random.seed(c["seed"])
+        model, shape = _revgan_model(c)
         rec = []
         for s_ in range(c["steps"]):
             g = torch.Generator().manual_seed(c["seed"] * 100 + s_)
@@ -380,10 +396,77 @@ def multiscale():
     (OUT / "multiscale_patchgan3d.json").write_text(json.dumps(out, indent=1))
 
 
+def _grad_record(model):
+    grads = {}
+    for net_name, net in model.networks.items():
+        per = {}
+        for n, p in net.named_parameters(remove_duplicate=False):
+            if n.startswith("encoder.") or p.grad is None:      # Resnet2D registers the same tensors twice (resnet2d.py:46)
+                continue
+            flat = p.grad.detach().flatten()
+            k = min(8, flat.numel())          # (integer arithmetic: float32 linspace overshoots on the 33 M-element layers)
+            idx = torch.tensor([(flat.numel() - 1) * i // max(k - 1, 1) for i in range(k)])
+            per[n] = {"norm": float(flat.double().norm()), "numel": flat.numel(), "idx": [int(i) for i in idx],
+                      "samples": [float(v) for v in flat[idx]]}
+        grads[net_name] = per
+    return grads
+
+
+P2P_FULL = dict(size=[256, 512], batch=1, steps=1, n_iters=100, n_iters_decay=100, num_downs=7, ngf=128,
+                use_dropout=False, n_layers=4, lambda_pix2pix=30.0, seed=35)
+
+
+def recipegrads():
+    """one iteration of the reference's recipes; what it leaves in every parameter's .grad"""
+    from oracle import gen_golden as G
+    from oracle.torch_ref import seeded_state_dict
+    torch.set_num_threads(8)
+    out = {}
+
+    def one_step(name, kind, c, model, A, B):
+        if kind == "cut":
+            torch.manual_seed(1000)          # pins the torch.randperm patch ids of the step (as in cut_steps.json)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        out[name] = {"kind": kind, "config": c, "losses": _record(model)["losses"], "step0_grads": _grad_record(model)}
+        print(name, out[name]["losses"], flush=True)
+
+    for name, c in list(G.PIX2PIX_CASES.items())[:1] + [("p2p_cfg3_full", P2P_FULL)]:
+        torch.manual_seed(c["seed"])
+        model = G.Pix2PixConditionalGAN(G.make_pix2pix_conf(c))
+        for k, (n, net) in enumerate(model.networks.items()):
+            net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+        one_step(name, "pix2pix", c, model, *G.p2p_inputs(c, 0))
+    for name, c in G.CUT_CASES.items():
+        torch.manual_seed(c["seed"])
+        model = G.CUT(G.make_cut_conf(c))
+        for k, (n, net) in enumerate(model.networks.items()):
+            net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+        one_step(name, "cut", c, model, *G.inputs(c, 0))
+    for name in ("v32_default", "vnet_16x32x32"):
+        c = G.CASES_3D[name]
+        torch.manual_seed(c["seed"])
+        random.seed(c["seed"])
+        model = G.CycleGAN(G.make_conf_3d(c))
+        for k, (n, net) in enumerate(model.networks.items()):
+            net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+        random.seed(c["seed"])
+        one_step(name, "cyclegan3d", c, model, *G.inputs_3d(c, 0))
+    for name in ("rev3d_16x32x32", "rev3d_piresnet"):
+        c = REVGAN_CASES[name]
+        model, shape = _revgan_model(c)
+        g = torch.Generator().manual_seed(c["seed"] * 100)
+        A, B = torch.rand(shape, generator=g) * 2 - 1, torch.rand(shape, generator=g) * 2 - 1
+        one_step(name, "revgan", c, model, A, B)
+    (OUT / "recipe_grads.json").write_text(json.dumps(out, indent=1))
+
+
 def main():
     what = sys.argv[1]
     if what == "multiscale":
         multiscale()
+    elif what == "recipegrads":
+        recipegrads()
     elif what == "volpatch":
         volpatch()
     elif what == "fullsize":

@@ -223,6 +223,9 @@ def adam_first_moments(model):
                 if net is None or "exp_avg" not in optim.state[p]:
                     continue
                 name = next(n for n, v in model.networks.items() if v is net)
+                if not hasattr(net, "grads_state_dict"):      # CUT's patch MLP: one flat buffer, reference key names
+                    out[name] = {k: v.detach().float().cpu() for k, v in net.flat_to_tensors(optim.state[p]["exp_avg"]).items()}
+                    continue
                 keep, net.master.grad = net.master.grad, optim.state[p]["exp_avg"]
                 try:
                     out[name] = {k: v.detach().float().cpu() for k, v in net.grads_state_dict().items()}
