@@ -349,6 +349,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+        model.reduce_timing = []      # two-graph data-parallel path: events around the all-reduce between the graphs
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -479,6 +480,11 @@ def main():
             "step_mfma_frac": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }
         if world > 1:
+            rt = getattr(model, "reduce_timing", None) or []
+            # the reduction is NOT overlapped on this path: everything between the end of the backward graph and the start of
+            # the optimiser graph that the stream spends inside RCCL (rank 0's view)
+            out["exposed_allreduce_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in rt) / max(len(rt), 1), 3) \
+                if rt else None
             out["ddp_path"] = (("one graph per iteration with the bucketed RCCL all-reduces captured inside it (overlapped "
                                 "with the remaining backward; GS_DDP_GRAPH_COLLECTIVES=1)")
                                if getattr(model, "_graph_collectives", False) else

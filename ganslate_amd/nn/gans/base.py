@@ -238,8 +238,15 @@ class BaseGAN(ABC):
         self._graph.replay()
         if self._graph_update is not None:       # data parallel: sum the flat gradients, then the optimiser launches
             import torch.distributed as dist
+            timing = getattr(self, "reduce_timing", None)      # bench.py: [(event, event)] around the exposed reduction
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for net in self._reduced_nets:
                 dist.all_reduce(net.master.grad, op=dist.ReduceOp.SUM, group=net._dist)
+            if timing is not None:
+                e1.record()
+                timing.append((e0, e1))
             self._graph_update.replay()
 
     def _capture_step(self):

@@ -64,51 +64,73 @@ def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch):
 
 
 # ---- two ranks over RCCL (runs the moment the box has >= 2 GPUs; the 1-GPU pool skips it) -----------------------------
-def _rccl_worker(rank, world, port, out_dir):
+DDP_PATHS = {
+    "launch_by_launch": {"GS_STEP_GRAPH": "0"},                     # bucketed all-reduce overlapped with the last backward pass
+    "two_graphs": {},                                              # graph | one all-reduce per network | graph (default)
+    "captured_collectives": {"GS_DDP_GRAPH_COLLECTIVES": "1"},     # the bucketed all-reduces captured inside the step graph
+}
+
+
+def _rccl_worker(rank, world, port, out_dir, path):
     import os
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     sys.path.insert(0, str(root))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
-                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", **DDP_PATHS[path])
     import random
     import torch.distributed as dist
     from ganslate_amd.utils import communication
     from tests.helpers import FROZEN, adam_first_moments, golden_inputs
-    communication.init_distributed()
+    if world > 1:
+        communication.init_distributed()
+    else:          # the data-parallel code path with a 1-rank RCCL group (what a single-GPU box can run)
+        import datetime
+        os.environ["GS_FORCE_DDP"] = "1"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                timeout=datetime.timedelta(minutes=2))
     c = dict(load_golden_steps()["c64_default"]["config"])
     c["pool_size"], c["batch"] = 0, 1
+    # (a) frozen weights: three identical iterations (launch by launch, capture, replay) -> the averaged gradient
     random.seed(c["seed"])
     model = build_product_cyclegan(c, FROZEN)
     A, B = golden_inputs(dict(c, batch=world), 0)
-    for _ in range(3):                       # launch by launch (bucketed, overlapped), capture, replay
+    for _ in range(3):
         model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
         model.optimize_parameters()
     torch.cuda.synchronize()
-    assert model._graph is not None and model._graph_update is not None
+    if path == "launch_by_launch":
+        assert model._graph is None
+    elif path == "two_graphs":
+        assert model._graph is not None and model._graph_update is not None
+    else:
+        assert model._graph is not None and model._graph_update is None and model._graph_collectives
+    # (b) weights moving: four iterations on this rank's shard -> the replicas must stay identical bit for bit
+    random.seed(c["seed"])
+    live = build_product_cyclegan(c)
+    for s in range(4):
+        A2, B2 = golden_inputs(dict(c, batch=world), s)
+        live.set_input({"A": A2[rank:rank + 1], "B": B2[rank:rank + 1]})
+        live.optimize_parameters()
+        live.update_learning_rate()
+    torch.cuda.synchronize()
     torch.save({"moments": adam_first_moments(model),
-                "losses": {k: float(v.detach()) for k, v in model.losses.items() if v is not None}},
-               Path(out_dir) / f"rccl_rank{rank}.pt")
+                "losses": {k: float(v.detach()) for k, v in model.losses.items() if v is not None},
+                "weights": {n: {k: v.float().cpu() for k, v in net.state_dict().items()} for n, net in live.networks.items()}},
+               Path(out_dir) / f"rccl_{path}_rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
-def test_two_ranks_over_rccl_average_to_the_big_batch_gradient(hip_ops, tmp_path):
-    """2 ranks x batch 1 over RCCL (xGMI) against one process on the batch of 2: with frozen weights Adam's first
-    moment after three identical iterations is 0.875 * g, and the averaged rank gradients must equal the big-batch
-    gradient (InstanceNorm is per sample, every loss a batch mean — SURVEY.md §8e)."""
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
+def _check_against_single_process(tmp_path, path, world):
     import random
-    import torch.multiprocessing as mp
     from tests.helpers import FROZEN, adam_first_moments, golden_inputs
-    world = 2
-    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = (torch.load(tmp_path / f"rccl_rank{r}.pt") for r in range(world))
+    ranks = [torch.load(tmp_path / f"rccl_{path}_rank{r}.pt") for r in range(world)]
+    r0 = ranks[0]
     c = dict(load_golden_steps()["c64_default"]["config"])
-    c["pool_size"], c["batch"] = 0, 2
+    c["pool_size"], c["batch"] = 0, world
     random.seed(c["seed"])
     single = build_product_cyclegan(c, FROZEN)
     A, B = golden_inputs(c, 0)
@@ -119,9 +141,52 @@ def test_two_ranks_over_rccl_average_to_the_big_batch_gradient(hip_ops, tmp_path
     want = adam_first_moments(single)
     for net, per in want.items():
         for n, w in per.items():
-            assert torch.equal(r0["moments"][net][n], r1["moments"][net][n]), (net, n, "ranks differ")
+            for r in ranks[1:]:
+                assert torch.equal(r0["moments"][net][n], r["moments"][net][n]), (path, net, n, "ranks differ")
             if w.norm().item() > 1e-9:
-                assert (r0["moments"][net][n] - w).norm().item() <= 2e-2 * w.norm().item(), (net, n)
+                assert (r0["moments"][net][n] - w).norm().item() <= 2e-2 * w.norm().item(), (path, net, n)
+    random.seed(c["seed"])
+    live = build_product_cyclegan(c)
+    for s in range(4):
+        A, B = golden_inputs(c, s)
+        live.set_input({"A": A, "B": B})
+        live.optimize_parameters()
+        live.update_learning_rate()
+    torch.cuda.synchronize()
+    for net, sd in r0["weights"].items():
+        mine = {k: v.float().cpu() for k, v in live.networks[net].state_dict().items()}
+        for k, v in sd.items():
+            for r in ranks[1:]:
+                assert torch.equal(v, r["weights"][net][k]), (path, net, k, "replicas diverged")
+            # four Adam steps of +-lr per weight: the replicas' path (per-sample gradients averaged over RCCL) and the
+            # big-batch path differ by summation order only -> the same update up to the sign of noise-level gradients
+            assert (v - mine[k]).abs().max().item() <= 4 * 2.5e-4, (path, net, k)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("path", list(DDP_PATHS))
+def test_data_parallel_paths_with_one_rank_over_rccl(hip_ops, tmp_path, path):
+    """the worker of the 2-rank test below with a 1-rank RCCL group in a child process (what this single-GPU pool can run):
+    every one of the three data-parallel paths goes through its collectives and must reproduce the single-process run"""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), path), nprocs=1, join=True)
+    _check_against_single_process(tmp_path, path, 1)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("path", list(DDP_PATHS))
+def test_two_ranks_over_rccl_average_to_the_big_batch_gradient(hip_ops, tmp_path, path):
+    """2 ranks x batch 1 over RCCL (xGMI) against one process on the batch of 2, for each of the three data-parallel paths
+    (ganslate/nn/gans/base.py:172-189 wraps every network in DistributedDataParallel): with frozen weights
+    Adam's first moment after three identical iterations is 0.875 * g, and the averaged rank gradients must equal the
+    big-batch gradient (InstanceNorm is per sample, every loss a batch mean); with moving weights the two replicas must hold
+    bit-identical parameters after four iterations and equal the single-process batch-2 run's to bf16-step accuracy."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path), path), nprocs=world, join=True)
+    _check_against_single_process(tmp_path, path, world)
 
 
 @pytest.mark.timeout(600)
