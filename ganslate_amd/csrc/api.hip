@@ -63,6 +63,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
                                 // smallest grid (boxes x channel tiles x batch) it takes, 0 = off
     {"hstrip", 1024},           // halo-resident kernel for the W-folded k7 boundary convs (hstrip.hip): smallest grid, 0 = off
     {"hconvx", 0},              // self-pipelined 8-wave form of the wide 3x3 kernels (hconvx.hip) instead of hconvw.hip's phase-locked loop
+    {"wfold_rows", 1},          // row-staged forms of the four W-fold boundary transforms (wfold.hip) instead of one thread per pixel
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }
