@@ -53,6 +53,16 @@ class PatchNCEDesc(C.Structure):
                 ("channels", C.c_int32 * 8), ("nce_T", C.c_float), ("lambda_nce", C.c_float)]
 
 
+class AttnDesc(C.Structure):
+    """Mirror of gs_attn_desc."""
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("C", C.c_int32)]
+
+
+class AttnParams(C.Structure):
+    """Mirror of gs_attn_params (device pointers to fp32 tensors in torch layout)."""
+    _fields_ = [(n, C.c_void_p) for n in ("gamma", "wq", "bq", "wk", "bk", "wv", "bv")]
+
+
 class PNormDesc(C.Structure):
     """Mirror of gs_pnorm_desc."""
     _fields_ = [("pixels", C.c_int64)] + [(n, C.c_int32) for n in (
@@ -163,6 +173,11 @@ _PROTOS = {
     "gs_pool_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "gs_repack_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_repack_bf16_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_attn_work_bytes": (C.c_int64, [C.POINTER(AttnDesc)]),
+    "gs_attn_forward": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.POINTER(AttnParams), C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "gs_attn_backward": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p, C.POINTER(AttnParams),
+                                   C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTS = tuple(_PROTOS)

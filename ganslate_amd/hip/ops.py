@@ -568,6 +568,41 @@ class HipOps:
         L.check(self.lib.gs_ssim_distance_backward(_ptr(x), _ptr(y), NC, H, W, _ptr(grad_scale), _ptr(grad_y),
                                                    _ptr(scratch), _stream()), "gs_ssim_distance_backward")
 
+    # ---- SelfAttentionBlock (csrc/attn.hip) ----------------------------------------------------------------------
+    ATTN_KEYS = ("gamma", "wq", "bq", "wk", "bk", "wv", "bv")
+
+    def _attn_args(self, x, tensors):
+        Cc = int(x.shape[-1])
+        d = L.AttnDesc(int(x.shape[0]), int(x.numel() // (x.shape[0] * Cc)), Cc)
+        p = L.AttnParams()
+        for k in self.ATTN_KEYS:
+            t = None if tensors is None else tensors.get(k)
+            if t is not None:
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.device == x.device, k
+            setattr(p, k, t.data_ptr() if t is not None else None)
+        return d, p
+
+    def attn_forward(self, x, params):
+        """x: NDHWC activation [B, ..., C]; params: {gamma [1], wq [C/8, C], bq, wk, bk, wv [C, C], bv} fp32 (torch layout)
+        -> (out like x, saved state for attn_backward)"""
+        assert x.is_contiguous() and x.dtype == self.act_dtype
+        d, p = self._attn_args(x, params)
+        work = torch.empty(int(self.lib.gs_attn_work_bytes(C.byref(d))), dtype=torch.uint8, device=self.device)
+        out = torch.empty_like(x)
+        L.check(self.lib.gs_attn_forward(C.byref(d), _ptr(x), C.byref(p), _ptr(out), _ptr(work), _stream()), "gs_attn_forward")
+        return out, (x, work)
+
+    def attn_backward(self, saved, dout, params, grads):
+        """-> dx; parameter gradients are ADDED into the tensors of `grads` (same keys as params; None: skipped)"""
+        x, work = saved
+        d, p = self._attn_args(x, params)
+        _, g = self._attn_args(x, grads)
+        dx = torch.empty_like(x)
+        L.check(self.lib.gs_attn_backward(C.byref(d), _ptr(x), _ptr(dout.contiguous()), C.byref(p),
+                                          C.byref(g) if grads is not None else None, _ptr(work), _ptr(dx), _stream()),
+                "gs_attn_backward")
+        return dx
+
     # ---- PatchNCE + patch MLP (csrc/patchnce.hip) ---------------------------------------------------------------
     def _nce_desc(self, channels, batch, patches, nc, nce_T, lambda_nce):
         d = L.PatchNCEDesc()

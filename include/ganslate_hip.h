@@ -397,6 +397,19 @@ int gs_patchnce_forward(const gs_patchnce_desc* d, const float* const* xq, const
 int gs_patchnce_backward(const gs_patchnce_desc* d, const float* const* xq, float* const* dxq, const float* params,
                          float* grads, void* work, const float* grad_scale, void* stream);
 
+/* ---- SelfAttentionBlock (ganslate/nn/attention.py:12-47; selfattention_patchgan3d.py:58,73, selfattention_vnet3d.py:97-104) ----
+ * x, out, dout, dx: NDHWC bf16 [B][N][C] (N = D*H*W voxels of the map, C a multiple of 8). q / k = 1x1x1 convs to C/8 channels,
+ * v to C channels; A = softmax over keys of q_i . k_j; out = gamma * (A v) + x. Parameters in torch layout, fp32:
+ * wq, wk [C/8][C], bq, bk [C/8], wv [C][C], bv [C], gamma [1] (device pointers). forward leaves q / k / v, the bf16 attention
+ * matrix [B][N][N] and A v in `work` (gs_attn_work_bytes, caller-owned, the same buffer for both calls); backward writes
+ * dx = d loss / d x and ADDS the parameter gradients into the tensors of `grads` (NULL members / NULL grads: skipped). */
+typedef struct gs_attn_desc { int32_t B, N, C; } gs_attn_desc;
+typedef struct gs_attn_params { float *gamma, *wq, *bq, *wk, *bk, *wv, *bv; } gs_attn_params;
+int64_t gs_attn_work_bytes(const gs_attn_desc* d);
+int gs_attn_forward(const gs_attn_desc* d, const void* x, const gs_attn_params* params, void* out, void* work, void* stream);
+int gs_attn_backward(const gs_attn_desc* d, const void* x, const void* dout, const gs_attn_params* params,
+                     const gs_attn_params* grads, void* work, void* dx, void* stream);
+
 /* ---- optimiser (torch.optim.Adam betas=(0.5,0.999) eps=1e-8, cyclegan.py:81-82) ------------------ */
 /* hyper (host pointer to 6 floats): lr, beta1, beta2, eps, bias_correction1, sqrt(bias_correction2).
  * grad_scale multiplies the gradient (1/world_size after an all-reduce SUM). zero_grad != 0 clears g. */

@@ -604,6 +604,22 @@ class RefOps:
                 out[b] = img
 
     # ---- PatchNCE + patch MLP: torch autograd of the reference composition --------------------------------------
+    # ---- SelfAttentionBlock (ganslate/nn/attention.py:26-47 on NDHWC activations) ------------------------------------
+    def attn_forward(self, x, params):
+        with torch.enable_grad():
+            x_ = x.detach().float().clone().requires_grad_()
+            p_ = {k: v.detach().clone().requires_grad_() for k, v in params.items()}
+            out = attention_reference(x_, p_)
+        return out.detach().to(x.dtype), (x_, p_, out)
+
+    def attn_backward(self, saved, dout, params, grads):
+        x_, p_, out = saved
+        keys = [k for k in p_ if grads is not None and grads.get(k) is not None]
+        g = torch.autograd.grad(out, [x_] + [p_[k] for k in keys], dout.float())
+        for k, gk in zip(keys, g[1:]):
+            grads[k] += gk
+        return g[0].to(dout.dtype)
+
     def patchnce_forward(self, xq, xk, params, *, batch, nc=256, nce_T=0.07, lambda_nce=1.0):
         with torch.enable_grad():
             xq_ = [t.detach().float().clone().requires_grad_() for t in xq]
@@ -628,6 +644,18 @@ class RefOps:
     def repack_tiled(self, master, index, pack, rows, kp):
         """same refresh for one [rows][kp] segment (the HIP side only changes the access order)"""
         self.repack(master, index, pack)
+
+
+def attention_reference(x, p):
+    """SelfAttentionBlock.forward (attention.py:26-47) restated on a channels-last tensor x [B, ..., C]: the 1x1x1 convs are
+    linear maps over C, energy = q k^T over all voxels, softmax over the keys, out = gamma * (attention @ v) + x"""
+    B, Cc = x.shape[0], x.shape[-1]
+    t = x.reshape(B, -1, Cc)
+    q = t @ p["wq"].t() + p["bq"]
+    k = t @ p["wk"].t() + p["bk"]
+    v = t @ p["wv"].t() + p["bv"]
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+    return (p["gamma"] * torch.bmm(att, v) + t).reshape(x.shape)
 
 
 def _nce_levels(params, channels, nc):

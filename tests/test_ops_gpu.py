@@ -1050,3 +1050,50 @@ def test_patchnce_rejects_shapes_without_a_hip_path(hip_ops):
         hip_ops.patchnce_forward(q, q, p, batch=1, nc=128)
     with pytest.raises(ValueError):
         hip_ops.patchnce_forward(q, [torch.randn(1, 32, 8, device=dev)], p, batch=1, nc=256)
+
+
+@pytest.mark.parametrize("B,dims,C", [(2, (4, 6, 5), 64), (1, (10, 10, 10), 256), (1, (9, 9, 9), 512), (2, (8, 8, 8), 128),
+                                      (1, (3, 5), 16)])
+def test_self_attention_block_forward_backward(hip_ops, B, dims, C):
+    """gs_attn_forward / gs_attn_backward (csrc/attn.hip: SelfAttentionBlock as batched MFMA GEMMs + a row softmax) against
+    torch autograd of the reference composition (oracle/ops_ref.attention_reference = ganslate/nn/attention.py:26-47) on the
+    same bf16 input: output within one bf16 ulp of the largest value; dx, and the parameter gradients (accumulated into
+    pre-filled tensors), within 3e-2 relative L2 (bf16 q / k / v / attention / gradient tensors between fp32-accumulating
+    GEMMs). Shapes: the discriminator's two blocks at 128^3 inputs (10^3 x 256, 9^3 x 512), a V-Net level, ragged tiles."""
+    from oracle.ops_ref import attention_reference
+    g = torch.Generator().manual_seed(91)
+    N = 1
+    for v in dims:
+        N *= v
+    dq = C // 8
+    x = torch.randn(B, *dims, C, generator=g).to(torch.bfloat16)
+    params = {"gamma": torch.tensor([0.7]), "wq": torch.randn(dq, C, generator=g) * 0.08, "bq": torch.randn(dq, generator=g) * 0.1,
+              "wk": torch.randn(dq, C, generator=g) * 0.08, "bk": torch.randn(dq, generator=g) * 0.1,
+              "wv": torch.randn(C, C, generator=g) * 0.05, "bv": torch.randn(C, generator=g) * 0.1}
+    dout = torch.randn(B, *dims, C, generator=g).to(torch.bfloat16)
+    # reference
+    xr = x.float().requires_grad_()
+    pr = {k: v.clone().requires_grad_() for k, v in params.items()}
+    out_ref = attention_reference(xr, pr)
+    out_ref.backward(dout.float())
+    # HIP
+    dev = hip_ops.device
+    pd = {k: v.to(dev) for k, v in params.items()}
+    gd = {k: torch.full_like(v, 0.25).to(dev) for k, v in params.items()}
+    out, saved = hip_ops.attn_forward(x.to(dev), pd)
+    dx = hip_ops.attn_backward(saved, dout.to(dev), pd, gd)
+    torch.cuda.synchronize()
+    close_bf16(out, out_ref.detach(), "attention output")
+    rel = lambda a, b: ((a.float().cpu() - b).norm() / (b.norm() + 1e-30)).item()
+    assert rel(dx, xr.grad) <= 3e-2, rel(dx, xr.grad)
+    for k in params:
+        got = gd[k].cpu() - 0.25
+        if k == "gamma":   # one scalar = a sum of n random-sign products dout * O with O stored in bf16: rounding noise of
+            O = (out_ref.detach() - x.float()) / 0.7      # sqrt(n) * rms(dout) * rms(O) * 2^-9 that nothing averages out
+            noise = 2.0 ** -9 * dout.float().norm().item() * O.norm().item() / O.numel() ** 0.5
+            assert abs(got.item() - pr[k].grad.item()) <= 3 * noise + 3e-2 * abs(pr[k].grad.item()), (got, pr[k].grad, noise)
+            continue
+        if k == "bk":      # the key bias shifts every logit of a row by the same q_i . bk: its true gradient is exactly zero
+            assert got.norm().item() <= 5e-2 * pr["bq"].grad.norm().item(), (got.norm().item(), pr["bq"].grad.norm().item())
+            continue
+        assert rel(got, pr[k].grad) <= 3e-2, (k, rel(got, pr[k].grad))
