@@ -33,7 +33,7 @@ from typing import Tuple
 import torch
 
 from .... import configs
-from ...native.net import Extra, NativeNet, Node
+from ...native.net import Extra, NativeNet, Node, attention_extras
 from ...native.spec import ConvSpec, lower
 from ...utils import is_bias_before_norm, require_instance_norm
 
@@ -69,8 +69,11 @@ class Vnet3D(NativeNet):
     dims = 3
 
     def __init__(self, in_channels, out_channels, norm_type, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
-                 up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True, is_separable=False):
+                 up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True, is_separable=False, attention=()):
+        """attention: per down block, whether a SelfAttentionBlock follows it (SelfAttentionVnet3D,
+        selfattention_vnet3d.py:90-104); empty = the plain V-Net"""
         require_instance_norm(norm_type)
+        self.attention = tuple(bool(a) for a in attention) + (False,) * (len(down_blocks) - len(attention))
         self.use_inverse = bool(use_inverse)
         self.use_memory_saving = bool(use_memory_saving)
         if is_separable:
@@ -139,6 +142,11 @@ class Vnet3D(NativeNet):
             couplings(blk, f"downs.{i}", cin, n, f"encoder.{i + 1}")
             blk.tail_slope = add_slope(f"downs.{i}.relu.weight", 2 * cin, enc(i + 1, "relu.weight"))
             self.downs.append(blk)
+        for i, on in enumerate(self.attention):          # registered after all down blocks (selfattention_vnet3d.py:107-108)
+            if on:
+                ex = attention_extras(f"attn_blocks.{i}", 2 * c * 2 ** i, dims=dims)
+                extras.extend(ex)
+                order.extend(e.name for e in ex)
         ucf = [2 * 2 ** i for i in reversed(range(L))]
         self.ups = []
         for i, n in enumerate(up_blocks):
@@ -167,7 +175,7 @@ class Vnet3D(NativeNet):
         super().__init__(nodes, in_channels, out_channels, out_act="tanh", extras=extras)
         # the reference registers in_ab, in_ba, out_ab, out_ba, downs, ups in that order (vnet3d.py:60-104); inside a block
         # the order above
-        rank = {"in_ab": 0, "in_ba": 1, "out_ab": 2, "out_ba": 3, "downs": 4, "ups": 5}
+        rank = {"in_ab": 0, "in_ba": 1, "out_ab": 2, "out_ba": 3, "downs": 4, "attn_blocks": 5, "ups": 6}
         self._param_order = sorted(order, key=lambda k: rank[k.split(".")[0]])       # stable
 
     def reference_parameter_order(self):
@@ -321,6 +329,9 @@ class Vnet3D(NativeNet):
             rec.Xn, rec.coup = core(s, blk, rec.D0)
             rec.out = self._new(N, lv(blk.level), blk.C)
             ops.pnorm_forward(rec.Xn, None, rec.out, C=blk.C, slope=self._slope(blk.tail_slope), res=rec.D0, res_mode=1)
+            rec.attn = None
+            if self.attention[len(s.down)]:      # the attended map feeds the next down block AND the skip connection
+                rec.out, rec.attn = ops.attn_forward(rec.out, self.attn_tensors(f"attn_blocks.{len(s.down)}"))
             s.down.append(rec)
             cur = rec.out
         # UpBlocks
@@ -475,6 +486,19 @@ class Vnet3D(NativeNet):
         for k in range(L - 1, -1, -1):
             blk, rec = self.downs[k], s.down[k]
             g2, g2_co = skip_grad[L - 2 - k] if k < L - 1 else (None, 0)
+            if rec.attn is not None:
+                # gradient w.r.t. the attended map = next stage's data gradient + the skip's slice; the block's backward
+                # returns the gradient w.r.t. the down block's own output and adds the block's parameter gradients
+                tot = g_cur
+                if g2 is not None:
+                    tot = g_cur.clone()
+                    ops.add_views(tot, g2, blk.C, dst_co=0, src_co=g2_co, accumulate=True)
+                prefix = f"attn_blocks.{k}"
+                g_cur = ops.attn_backward(rec.attn, tot, self.attn_tensors(prefix),
+                                          self.attn_tensors(prefix, grad=True) if want_w else None)
+                g2, g2_co = None, 0
+                if want_w:
+                    self.grad_dirty = True
             G = self._block_backward(s, blk, rec, g_cur, g2, g2_co, want_w)
             nconv, sconv = bconv(blk)
             dy = torch.empty_like(rec.y)

@@ -36,6 +36,8 @@ class Node:
     res: Optional[int] = None    # index of the node whose output is added after the norm (residual block tail)
     name: str = ""               # torch module path of the conv in the reference net, e.g. "model.1"
     aliases: Tuple[str, ...] = ()  # additional state_dict prefixes holding the same tensors
+    attn: str = ""               # module path of a SelfAttentionBlock applied to this node's output (nn/attention.py);
+                                 # its parameters are the Extras `attention_extras(attn, channels)`
 
 
 @dataclass
@@ -43,12 +45,32 @@ class Extra:
     """A non-conv parameter vector kept in the flat master buffer after the conv layers (nn.PReLU slopes)."""
     name: str                    # state_dict key, e.g. "in_ab.relu.weight"
     size: int
-    init: float = 0.25           # nn.PReLU default; ganslate's init_weights leaves it alone (nn/utils.py:13-36)
+    init: float = 0.25           # nn.PReLU default; ganslate's init_weights leaves it alone (nn/utils.py:13-36);
+                                 # None: a conv weight drawn by init_weights (N(0, gain), nn/utils.py:19-20)
     aliases: Tuple[str, ...] = ()
+    shape: Optional[Tuple[int, ...]] = None      # torch shape of the tensor in state dicts (default: the flat vector)
+
+
+ATTN_KEYS = {"gamma": "gamma", "wq": "query_conv.weight", "bq": "query_conv.bias", "wk": "key_conv.weight",
+             "bk": "key_conv.bias", "wv": "value_conv.weight", "bv": "value_conv.bias"}
+
+
+def attention_extras(prefix: str, C: int, dims: int = 3) -> List["Extra"]:
+    """parameters of a SelfAttentionBlock(C) (ganslate/nn/attention.py:16-22) as Extras, in the order torch yields them
+    (gamma — a direct parameter of the block — before the three 1x1 convs' weights and biases)"""
+    one = (1,) * dims
+    d = C // 8
+    return [Extra(f"{prefix}.gamma", 1, 0.0, shape=(1,)),
+            Extra(f"{prefix}.query_conv.weight", d * C, None, shape=(d, C) + one),
+            Extra(f"{prefix}.query_conv.bias", d, 0.0, shape=(d,)),
+            Extra(f"{prefix}.key_conv.weight", d * C, None, shape=(d, C) + one),
+            Extra(f"{prefix}.key_conv.bias", d, 0.0, shape=(d,)),
+            Extra(f"{prefix}.value_conv.weight", C * C, None, shape=(C, C) + one),
+            Extra(f"{prefix}.value_conv.bias", C, 0.0, shape=(C,))]
 
 
 class _Saved:
-    __slots__ = ("x_img", "acts", "ys", "mrs", "out_img", "lows", "N")
+    __slots__ = ("x_img", "acts", "ys", "mrs", "out_img", "lows", "N", "attn")
 
 
 class NativeNet:
@@ -72,6 +94,7 @@ class NativeNet:
             self.w_off.append(off); off += nd.spec.master_numel
             self.b_off.append(off); off += nd.spec.cout_p
         self.extras = list(extras or [])
+        self._extra_by_name = {ex.name: ex for ex in self.extras}
         self.x_off = {}
         for ex in self.extras:
             self.x_off[ex.name] = off
@@ -136,10 +159,25 @@ class NativeNet:
                 raise NotImplementedError(f"initialization method `{init_type}` is not implemented")
             flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
         for ex in self.extras:
-            flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = ex.init
+            if ex.init is None:          # a conv weight kept as an Extra (SelfAttentionBlock's 1x1 convs); normal init only
+                assert init_type == "normal", "attention convs: only `normal` init is implemented"
+                flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = torch.empty(ex.size).normal_(0.0, gain)
+            else:
+                flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = ex.init
         with torch.no_grad():
             self.master.copy_(flat.to(self.device))
         self._packs_dirty = True
+
+    def attn_tensors(self, prefix, grad=False):
+        """the SelfAttentionBlock `prefix`'s parameters (or their gradients) as views of the flat buffer, keyed like
+        ops.attn_forward wants them"""
+        buf = self.master.grad if grad else self.master.detach()
+        out = {}
+        for k, suffix in ATTN_KEYS.items():
+            ex = self._extra_by_name[f"{prefix}.{suffix}"]
+            v = buf[self.x_off[ex.name]:self.x_off[ex.name] + ex.size]
+            out[k] = v.view(ex.shape[0], -1) if suffix.endswith("conv.weight") else v
+        return out
 
     def extra(self, name, grad=False):
         """view of an extra parameter vector (padded to 8) in the master / gradient buffer"""
@@ -160,6 +198,8 @@ class NativeNet:
                     sd[f"{prefix}.bias"] = b
         for ex in self.extras:
             v = m[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+            if ex.shape is not None:
+                v = v.view(ex.shape)
             for key in (ex.name,) + tuple(ex.aliases):
                 sd[key] = v
         return sd
@@ -186,7 +226,8 @@ class NativeNet:
             sd[f"{nd.name}.weight"] = nd.spec.torch_from_master(g[self.w_off[i]:self.w_off[i] + nd.spec.master_numel])
             sd[f"{nd.name}.bias"] = g[self.b_off[i]:self.b_off[i] + nd.spec.cout].clone()
         for ex in self.extras:
-            sd[ex.name] = g[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+            v = g[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+            sd[ex.name] = v.view(ex.shape) if ex.shape is not None else v
         return sd
 
     # ---- flat buffers <-> the reference's per-parameter tensors (optimizer state in checkpoints) ------------------
@@ -208,7 +249,8 @@ class NativeNet:
             if nd.spec.bias:
                 out[f"{nd.name}.bias"] = flat[self.b_off[i]:self.b_off[i] + nd.spec.cout].clone()
         for ex in self.extras:
-            out[ex.name] = flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+            v = flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size].clone()
+            out[ex.name] = v.view(ex.shape) if ex.shape is not None else v
         return out
 
     def tensors_to_flat(self, tensors, flat):
@@ -364,10 +406,14 @@ class NativeNet:
             ops.image_unfold(x, a, sp0.k, sp0.pad, sp0.pad_mode)
         else:
             ops.image_to_act(x, a)
-        acts, ys, mrs = [a], [], []
+        acts, ys, mrs, attn_saved = [a], [], [], {}
         for i, (nd, lw) in enumerate(zip(self.nodes, lows)):
             if stop is not None and i > stop:
                 break
+            if i > 0 and self.nodes[i - 1].attn:       # SelfAttentionBlock on the previous node's output
+                xo, sv = ops.attn_forward(acts[-1], self.attn_tensors(self.nodes[i - 1].attn))
+                attn_saved[i - 1] = sv if save else None
+                acts[-1] = xo
             sp = nd.spec
             bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
             fpack = pk["fpack"][pk["f_off"][i]:]
@@ -407,6 +453,7 @@ class NativeNet:
             return out, None
         s = _Saved()
         s.x_img, s.acts, s.ys, s.mrs, s.out_img, s.lows, s.N = x, acts, ys, mrs, out, lows, N
+        s.attn = attn_saved
         return out, s
 
     # ---- backward ---------------------------------------------------------------------------------------------------------
@@ -447,6 +494,16 @@ class NativeNet:
                     f0 = pending[1]
                     inner = (slice(None),) + tuple(slice(f0, f0 + n) for n in lw.out_dims)
                     pending[0][inner] += inj_x[i]   # the pad adjoint is linear
+            if nd.attn:
+                # the gradient arrives w.r.t. the block's output; the block's backward turns it into the gradient w.r.t. this
+                # node's own output (and adds the block's parameter gradients)
+                g_att, f_att = pending[0], pending[1]
+                assert f_att == 0 and pending[2] is None and len(pending) == 4, "attention output: plain gradient expected"
+                gx_att = ops.attn_backward(s.attn[i], g_att, self.attn_tensors(nd.attn),
+                                           self.attn_tensors(nd.attn, grad=True) if want_w else None)
+                pending = (gx_att, 0, None, "reflect")
+                if want_w:
+                    self.grad_dirty = True
             g_pad, fold, g2, fmode = pending[:4]
             pre = pending[4] if len(pending) > 4 else None
             x_out = s.acts[i + 1]
@@ -514,7 +571,7 @@ class NativeNet:
                 # the reduction pass of the previous layer's InstanceNorm backward rides in this launch's epilogue
                 # (wide stride-1 layers; not when a tapped feature gradient is still to be added to gx)
                 plan = None
-                if i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 1 and (i - 1) not in inj_x:
+                if i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 1 and (i - 1) not in inj_x and not nodes[i - 1].attn:
                     plan = ops.fused_norm_plan(lw.dgrad[0], N, sp.cin_p)
                 ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p) if plan is not None else None
                 if ring is None:

@@ -233,27 +233,32 @@ def lower(spec: ConvSpec, *sizes) -> Lowered:
                      pack_off, rows, Di=i3[0], Do=o3[0], Dc=c3[0], pz=ph[0], dd=dd)
 
     def parity_classes(out3, rows, chan, midx, in3):
-        """stride-2 'transposed' gather: out[2i+py] = sum_{r:(py+p-r) even} in[i + (py+p-r)/2] * W[r]"""
+        """stride-s 'transposed' gather: out[s i + py] = sum_{r : (py + p - r) divisible by s} in[i + (py + p - r) / s] * W[r]
+        (s = 2 everywhere in the reference nets but the stride-3 first conv of SelfAttentionPatchGAN3D,
+        selfattention_patchgan3d.py:33-36)"""
         classes, tables, poff = [], [], 0
-        axis_taps = lambda a, ph: [(r, (ph + pa[a] - r) // 2) for r in range(ka[a]) if (ph + pa[a] - r) % 2 == 0]
-        for pz in (range(2) if real[0] else range(1)):
-            for py in range(2):
-                for px in range(2):
+        axis_taps = lambda a, ph: [(r, (ph + pa[a] - r) // s) for r in range(ka[a]) if (ph + pa[a] - r) % s == 0]
+        for pz in (range(s) if real[0] else range(1)):
+            for py in range(s):
+                for px in range(s):
                     ph = (pz, py, px)
                     at = [axis_taps(a, ph[a]) for a in range(3)]
-                    c3 = tuple((out3[a] - ph[a] + 1) // 2 if real[a] else 1 for a in range(3))
-                    if any(not t for t in at) or any(c <= 0 for c in c3):
+                    c3 = tuple((out3[a] - ph[a] + s - 1) // s if real[a] else 1 for a in range(3))
+                    if any(c <= 0 for c in c3):
                         continue
+                    if any(not t for t in at):
+                        # no tap reaches this class (k < s on some axis): its outputs are zero; never the case for k >= s
+                        raise NotImplementedError("strided layer with a kernel smaller than its stride")
                     combos = [(a, b, c) for a in at[0] for b in at[1] for c in at[2]]
                     tm = [(a[0] * ka[1] + b[0]) * ka[2] + c[0] for a, b, c in combos]
                     offs = ([a[1] for a, _, _ in combos], [b[1] for _, b, _ in combos], [c[1] for _, _, c in combos])
-                    g = gconv(in3, chan, out3, rows, c3, 2, ph, 1, offs, "zero", poff, rows)
+                    g = gconv(in3, chan, out3, rows, c3, s, ph, 1, offs, "zero", poff, rows)
                     tab = _pack_index(rows, tm, chan, midx)
                     classes.append(g); tables.append(tab.reshape(-1)); poff += tab.size
         return classes, np.concatenate(tables)
 
     if spec.kind == "conv":
-        assert s in (1, 2), "stride 1 or 2"
+        assert s in (1, 2, 3), "stride 1, 2 or 3"
         # forward: out[i] = sum_r in[B(i*s + r - p)] W[r]
         fwd_offs = off(lambda r, a: r - pa[a] + (woff if a == 2 else 0))
         low.fwd = [gconv(ins, spec.cin_p, outs, spec.cout_p, outs, 1, (0, 0, 0), s, fwd_offs, spec.pad_mode, 0,

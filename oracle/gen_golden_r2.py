@@ -9,6 +9,7 @@
     python -m oracle.gen_golden_r2 volpatch    # tests/golden/volume_patches.json
     python -m oracle.gen_golden_r2 multiscale  # tests/golden/multiscale_patchgan3d.json
     python -m oracle.gen_golden_r2 recipegrads # tests/golden/recipe_grads.json
+    python -m oracle.gen_golden_r2 selfattention # tests/golden/selfattention.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
   after its first iteration (G gradients from backward_G :191-214, D gradients summed over backward_D("D_B") and
@@ -461,12 +462,35 @@ def recipegrads():
     (OUT / "recipe_grads.json").write_text(json.dumps(out, indent=1))
 
 
+def selfattention():
+    """the reference's self-attention networks (nn/attention.py through selfattention_patchgan3d.py:18-79 and
+    selfattention_vnet3d.py:44-181, the latter over the memcnn stand-in) on seeded weights and inputs: output samples, input
+    gradient and every parameter's gradient norm (the record of oracle/gen_golden.net_case)"""
+    from oracle import gen_golden as G          # imports the reference
+    from ganslate.nn.discriminators.patchgan.selfattention_patchgan3d import SelfAttentionPatchGAN3D
+    from ganslate.nn.generators.vnet.selfattention_vnet3d import SelfAttentionVnet3D
+    torch.set_num_threads(8)
+    nets = {
+        "sa_patchgan3d_64": G.net_case("sapg", SelfAttentionPatchGAN3D(1, 32, 3, 4, "instance"), (1, 1, 64, 64, 64), 75),
+        "sa_patchgan3d_2ch_2layers": G.net_case("sapg2", SelfAttentionPatchGAN3D(2, 16, 2, 4, "instance"),
+                                                (2, 2, 34, 40, 46), 76),
+        "sa_vnet3d_small": G.net_case("savn", SelfAttentionVnet3D(1, 1, "instance", 8, (1, 2), (2, 1), False, False,
+                                                                  (True, True), False), (1, 1, 8, 16, 16), 77),
+        "sa_vnet3d_default_flags": G.net_case("savn2", SelfAttentionVnet3D(1, 1, "instance", 8, (1, 1, 2, 1), (1, 2, 1, 1),
+                                                                           False, False, (False, False, True, True), False),
+                                              (1, 1, 16, 32, 32), 78),
+    }
+    (OUT / "selfattention.json").write_text(json.dumps(nets, indent=1))
+
+
 def main():
     what = sys.argv[1]
     if what == "multiscale":
         multiscale()
     elif what == "recipegrads":
         recipegrads()
+    elif what == "selfattention":
+        selfattention()
     elif what == "volpatch":
         volpatch()
     elif what == "fullsize":

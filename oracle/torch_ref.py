@@ -130,6 +130,48 @@ class PatchGAN3D(nn.Module):
         return self.model(x)
 
 
+class SelfAttentionBlock(nn.Module):
+    """ganslate/nn/attention.py:12-47 restated (Self-Attention GAN layer on all D*W*H voxels)"""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.query_conv = nn.Conv3d(in_dim, in_dim // 8, 1)
+        self.key_conv = nn.Conv3d(in_dim, in_dim // 8, 1)
+        self.value_conv = nn.Conv3d(in_dim, in_dim, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        B, Cc = x.shape[:2]
+        q = self.query_conv(x).view(B, -1, x[0, 0].numel()).permute(0, 2, 1)
+        k = self.key_conv(x).view(B, -1, x[0, 0].numel())
+        attention = torch.softmax(torch.bmm(q, k), dim=-1)
+        v = self.value_conv(x).view(B, -1, x[0, 0].numel())
+        out = torch.bmm(v, attention.permute(0, 2, 1)).view(x.shape)
+        return self.gamma * out + x
+
+
+class SelfAttentionPatchGAN3D(nn.Module):
+    """ganslate/nn/discriminators/patchgan/selfattention_patchgan3d.py:18-79 restated"""
+
+    def __init__(self, in_channels, ndf=64, n_layers=3, kernel_size=4):
+        super().__init__()
+        kw = kernel_size
+        seq = [nn.Conv3d(in_channels, ndf, kw, 3, 1), nn.LeakyReLU(0.2, True)]
+        mult = 1
+        for n in range(1, n_layers):
+            prev, mult = mult, min(2 ** n, 8)
+            seq += [nn.Conv3d(ndf * prev, ndf * mult, kw, 2, 1), nn.InstanceNorm3d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        seq += [SelfAttentionBlock(ndf * mult)]
+        prev, mult = mult, min(2 ** n_layers, 8)
+        seq += [nn.Conv3d(ndf * prev, ndf * mult, kw, 1, 1), nn.InstanceNorm3d(ndf * mult), nn.LeakyReLU(0.2, True)]
+        seq += [SelfAttentionBlock(ndf * mult)]
+        seq += [nn.Conv3d(ndf * mult, 1, kw, 1, 1)]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x):
+        return self.model(x)
+
+
 class MultiScalePatchGAN3D(nn.Module):
     """ganslate/nn/discriminators/patchgan/multiscale_patchgan3d.py:44-60 restated: one PatchGAN3D per scale in an
     nn.ModuleDict keyed "1".."scales"; scale s sees a random window of the input with spatial extents // s (one window per
@@ -389,6 +431,32 @@ class Vnet3D(nn.Module):
         return (self.out_ba if inverse else self.out_ab)(out)
 
 
+class SelfAttentionVnet3D(Vnet3D):
+    """ganslate/nn/generators/vnet/selfattention_vnet3d.py:44-181 restated: Vnet3D with a SelfAttentionBlock (or Identity) on
+    the output of every down block, feeding both the next down block and the skip connection"""
+
+    def __init__(self, in_channels, out_channels, first_layer_channels=16, down_blocks=(1, 2, 3, 2), up_blocks=(2, 2, 1, 1),
+                 use_inverse=False, enable_attention_block=(True, True, True, True)):
+        super().__init__(in_channels, out_channels, first_layer_channels, down_blocks, up_blocks, use_inverse)
+        ups, enc = self.ups, self.encoder   # registration order of the reference: downs, attn_blocks, encoder, ups
+        del self.ups, self.encoder
+        self.attn_blocks = nn.ModuleList([SelfAttentionBlock(first_layer_channels * 2 ** i * 2) if on else nn.Identity()
+                                          for i, on in enumerate(enable_attention_block)])
+        self.encoder = enc
+        self.ups = ups
+
+    def forward(self, x, inverse=False):
+        out1 = (self.in_ba if inverse else self.in_ab)(x)
+        downs = []
+        for i, (d, attn) in enumerate(zip(self.downs, self.attn_blocks)):
+            downs.append(attn(d(out1 if i == 0 else downs[-1], inverse)))
+        rev = list(reversed(downs))
+        out = rev[0]
+        for i, up in enumerate(self.ups):
+            out = up(out, out1 if i == len(self.ups) - 1 else rev[i + 1], inverse)
+        return (self.out_ba if inverse else self.out_ab)(out)
+
+
 class Vnet2D(Vnet3D):
     """ganslate/nn/generators/vnet/vnet2d.py:22-248 with use_inverse=False, use_memory_saving=False: the same network on
     Conv2d / ConvTranspose2d / InstanceNorm2d"""
@@ -503,11 +571,15 @@ class CycleGANStep:
     def __init__(self, in_ch=3, out_ch=3, n_blocks=9, ndf=64, n_layers=3, lr_G=2e-4, lr_D=2e-4, beta1=0.5,
                  beta2=0.999, lambda_AB=10.0, lambda_BA=10.0, lambda_identity=0.0, proportion_ssim=0.0,
                  pool_size=50, adv="lsgan", n_iters=100, n_iters_decay=100, metrics_ssim=True, metrics_D=True,
-                 seed=0, dims=2, vnet=None):
+                 seed=0, dims=2, vnet=None, make_G=None, make_D=None):
         G, D = (Resnet2D, PatchGAN2D) if dims == 2 else (Resnet3D, PatchGAN3D)
         if vnet is not None:          # brats yaml generator: Vnet3D(first_layer_channels, down_blocks, up_blocks)
             G = lambda i, o, _n: Vnet3D(i, o, vnet["first_layer_channels"], tuple(vnet["down_blocks"]),
                                         tuple(vnet["up_blocks"]))
+        if make_G is not None:        # any other generator / discriminator pair (the self-attention networks)
+            G = lambda i, o, _n: make_G(i, o)
+        if make_D is not None:
+            D = lambda i, _ndf, _nl: make_D(i)
         self.nets = OrderedDict(G_AB=G(in_ch, out_ch, n_blocks), G_BA=G(out_ch, in_ch, n_blocks),
                                 D_B=D(out_ch, ndf, n_layers), D_A=D(in_ch, ndf, n_layers))
         for k, (name, net) in enumerate(self.nets.items()):

@@ -73,6 +73,24 @@ def _net_case(hip_ops, build_native, shadow, x_shape, seed, grad_tol=0.15, grad_
     for n, p in shadow.named_parameters():
         if n.startswith("encoder.") or (n.endswith(".bias") and n[:-5] in normed):
             continue  # aliases / biases in front of an InstanceNorm (exactly-zero true gradient)
+        if n.endswith("key_conv.bias"):
+            # SelfAttentionBlock: a key bias shifts every logit of a row by the same amount -> exactly-zero true gradient
+            assert gh[n].norm().item() <= 5e-2 * gh[n.replace("key_conv", "query_conv")].norm().item() + 1e-6, n
+            continue
+        if ".query_conv." in n or ".key_conv." in n:
+            # SelfAttentionBlock with near-uniform attention (small seeded weights: logits ~ 0): the gradient reaches q and
+            # k only in second order — when it is below 1 % of the value conv's it is rounding noise on both sides
+            vref = dict(shadow.named_parameters())[n.split(".query_conv.")[0].split(".key_conv.")[0] + ".value_conv.weight"]
+            if p.grad.norm().item() <= 1e-2 * vref.grad.norm().item():
+                assert gh[n].norm().item() <= 2e-2 * vref.grad.norm().item(), n
+                continue
+        if n.endswith(".gamma"):
+            # SelfAttentionBlock: ONE scalar = sum over voxels x channels of dout * (A v), random-sign terms that cancel;
+            # bf16 storage of either factor leaves sqrt(n) * 2^-9 un-averaged (tests/test_ops_gpu.py::
+            # test_self_attention_block_forward_backward bounds it). Sign and order of magnitude only; the weight tensors
+            # behind the block (its q / k / v convs) are compared like every other layer
+            assert gh[n].item() * p.grad.item() > 0 and 0.2 <= gh[n].item() / p.grad.item() <= 5.0, (n, gh[n], p.grad)
+            continue
         assert rel_l2(gh[n], gc[n]) <= grad_tol, (n, rel_l2(gh[n], gc[n]))
         assert rel_l2(gh[n], p.grad) <= grad_tol and cosine(gh[n], p.grad) >= grad_cos, (n, rel_l2(gh[n], p.grad))
 

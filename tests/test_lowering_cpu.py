@@ -16,6 +16,7 @@ SPECS = [
     ConvSpec("conv", 16, 1, 4, 1, 1),
     ConvSpec("convT", 16, 8, 3, 2, 1, 1),                     # resnet2d.py:52-57
     ConvSpec("convT", 8, 3, 4, 2, 1, 0),                      # unet2d.py:122
+    ConvSpec("conv", 3, 8, 4, 3, 1),                          # stride 3 (selfattention_patchgan3d.py:33-36, 2-D twin)
 ]
 
 
@@ -26,6 +27,7 @@ SPECS_3D = [
     ConvSpec("conv", 2, 8, 4, 2, 1, dims=3),                         # patchgan3d.py:28
     ConvSpec("conv", 8, 1, 4, 1, 1, dims=3),                         # patchgan3d.py:57-60
     ConvSpec("convT", 9, 4, 3, 2, 1, 1, dims=3),                     # resnet3d.py:50-55
+    ConvSpec("conv", 2, 8, 4, 3, 1, dims=3),                         # selfattention_patchgan3d.py:33-36: k4 stride 3
 ]
 
 

@@ -281,3 +281,53 @@ def test_vnet_memory_saving_recomputes_the_same_gradients(fp32_oracle_backend):
             continue                                   # exactly-zero true gradient: rounding noise on both sides
         b = res[1][3][k]
         assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item() + 1e-8, k
+
+
+def test_selfattention_patchgan3d_forward_backward(fp32_oracle_backend):
+    """SelfAttentionPatchGAN3D (selfattention_patchgan3d.py:18-79): stride-3 first conv (27 output-parity classes in its data
+    gradient), two SelfAttentionBlocks whose parameters live in the flat master buffer under the reference's names; the
+    executor's forward / backward incl. the block's parameter gradients against torch autograd of the restatement"""
+    from ganslate_amd.nn.discriminators import SelfAttentionPatchGAN3D
+    native = SelfAttentionPatchGAN3D(2, 16, 3, (4, 4, 4), "instance")
+    shadow = torch_ref.SelfAttentionPatchGAN3D(2, 16, 3)
+    assert native.reference_parameter_order() == [n for n, _ in shadow.named_parameters()]
+    assert {k: tuple(v.shape) for k, v in native.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in shadow.state_dict().items()}
+    _compare(native, shadow, (2, 2, 46, 52, 46), 141)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_selfattention_vnet3d_forward_backward(fp32_oracle_backend, inverse):
+    """SelfAttentionVnet3D (selfattention_vnet3d.py:44-181): attention on the down blocks' outputs, feeding the next block and
+    the skip; both directions of the partially-invertible net, with and without activation recompute"""
+    from ganslate_amd.nn.generators import SelfAttentionVnet3D
+    kw = dict(first_layer_channels=8, down_blocks=(1, 2), up_blocks=(2, 1))
+    shadow = torch_ref.SelfAttentionVnet3D(1, 1, use_inverse=inverse, enable_attention_block=(True, True), **kw)
+    sd = torch_ref.seeded_state_dict(shadow, 143)
+    shadow.load_state_dict(sd)
+    for memory_saving in ([False, True] if inverse else [False]):
+        native = SelfAttentionVnet3D(1, 1, "instance", use_memory_saving=memory_saving, use_inverse=inverse,
+                                     enable_attention_block=(True, True), **kw)
+        assert native.reference_parameter_order() == [n for n, _ in shadow.named_parameters() if not n.startswith("encoder.")]
+        native.load_state_dict(sd)
+        g = torch.Generator().manual_seed(144)
+        x = torch.rand(1, 1, 8, 16, 16, generator=g) * 2 - 1
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        for p in shadow.parameters():
+            p.grad = None
+        ya = shadow(xa, inverse=inverse)
+        yb = native(xb, inverse=inverse) if inverse else native(xb)
+        assert torch.allclose(ya, yb, atol=5e-5, rtol=1e-4), (ya - yb).abs().max()
+        gy = torch.randn(ya.shape, generator=g)
+        ya.backward(gy); yb.backward(gy)
+        assert (xa.grad - xb.grad).abs().max().item() <= 2e-3 * xa.grad.abs().max().item()
+        grads = native.grads_state_dict()
+        for n, p in shadow.named_parameters():
+            if n.startswith("encoder.") or p.grad is None or "attn_blocks" not in n:
+                continue
+            scale = p.grad.abs().max().item()
+            tol = 2e-2 if memory_saving else 2e-3       # recompute: the rebuilt inputs carry fp32 rounding
+            if n.endswith("key_conv.bias"):             # exactly-zero true gradient (a constant shift of every logit row)
+                assert grads[n].abs().max().item() <= 1e-4 * shadow.get_parameter(n.replace("key", "query")).grad.abs().max().item()
+                continue
+            assert (p.grad - grads[n]).abs().max().item() <= tol * scale + 1e-7, (n, memory_saving)

@@ -15,6 +15,7 @@ NETS = json.loads((GOLD / "nets.json").read_text())
 STEPS = json.loads((GOLD / "cyclegan_steps.json").read_text())
 VOLUMES = json.loads((GOLD / "volumes.json").read_text())
 NETS = dict(NETS, **VOLUMES["nets"])
+NETS = dict(NETS, **json.loads((GOLD / "selfattention.json").read_text()))      # oracle/gen_golden_r2.py selfattention
 
 NET_BUILDERS = {
     "resnet2d_64": lambda: torch_ref.Resnet2D(3, 3, 9),
@@ -29,6 +30,11 @@ NET_BUILDERS = {
     "unet3d_5downs": lambda: torch_ref.Unet3D(1, 1, 5, 8),
     "vnet3d_brats_blocks": lambda: torch_ref.Vnet3D(1, 1, 16, (2, 2, 3), (3, 3, 3)),
     "vnet3d_2ch_small": lambda: torch_ref.Vnet3D(2, 1, 8, (1, 2), (2, 1)),
+    "sa_patchgan3d_64": lambda: torch_ref.SelfAttentionPatchGAN3D(1, 32, 3, 4),
+    "sa_patchgan3d_2ch_2layers": lambda: torch_ref.SelfAttentionPatchGAN3D(2, 16, 2, 4),
+    "sa_vnet3d_small": lambda: torch_ref.SelfAttentionVnet3D(1, 1, 8, (1, 2), (2, 1), False, (True, True)),
+    "sa_vnet3d_default_flags": lambda: torch_ref.SelfAttentionVnet3D(1, 1, 8, (1, 1, 2, 1), (1, 2, 1, 1), False,
+                                                                     (False, False, True, True)),
 }
 
 
