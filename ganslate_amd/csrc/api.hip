@@ -64,6 +64,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hstrip", 1024},           // halo-resident kernel for the W-folded k7 boundary convs (hstrip.hip): smallest grid, 0 = off
     {"hconvx", 0},              // self-pipelined 8-wave form of the wide 3x3 kernels (hconvx.hip) instead of hconvw.hip's phase-locked loop
     {"wfold_rows", 1},          // row-staged forms of the four W-fold boundary transforms (wfold.hip) instead of one thread per pixel
+    {"hwgrad_ft", 1},           // halo-resident weight gradient of narrow layers with few taps (hwgrad.hip: the 2-D k7 boundary convs)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -175,6 +175,120 @@ __global__ __launch_bounds__(512) void hwgrad_kernel(const HWGradK p) {
   }
 }
 
+// ---- narrow layers with FEW taps (the W-folded k7 boundary convs of 2-D nets: 7 vertical taps, 32 <-> 64 channels) ----------
+// hwgrad_kernel above spreads TAPS over its 8 waves; with 7 taps one wave would work. Here the workgroup stages the dense tile
+// [256 pixels][P] and the gathered box + halo with ALL Q channels once per box, and the waves split the (p, q) plane: wave w
+// owns the 16 x 16 block (w / nq, w % nq) for every tap (nq = Q / 16; np * nq <= 8), T accumulators in registers across the
+// workgroup's boxes. wgrad_kernel gathered the shifted operand once per tap from L2 — 470 MB of L2 -> LDS traffic for a
+// 100 MB layer, 115 / 69 us per launch at 130 / 218 TFLOP/s (profiles/r02_conv_table_v5.txt) — this form reads both operands
+// once per box.
+template <int TMAX>
+__global__ __launch_bounds__(512) void hwgrad_ft_kernel(const HWGradK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* toff = reinterpret_cast<int*>(smem);        // [TMAX] halo-linear tap offsets
+  const gs_wgrad_desc& d = p.d;
+  const int np = p.phalves, nq = p.qchunks;        // 16-channel blocks of the dense / gathered side
+  const int APITCH = np * 32, GPITCH = nq * 32;    // bytes per pixel / voxel
+  char* at = smem + 256;
+  char* halo = at + 256 * APITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < TMAX)
+    toff[tid] = tid < d.T ? (((int)d.dd[tid] - p.dmin) * p.HH + ((int)d.dh[tid] - p.hmin)) * p.HW + ((int)d.dw_[tid] - p.wmin) : 0;
+  const bool active = wave < np * nq;
+  const int pi = active ? wave / nq : 0, qi = active ? wave % nq : 0;
+  f32x4 acc[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fk = lane >> 4, frr = (lane & 15) >> 2, fcc = lane & 3;
+  const int HV = p.HD * p.HH * p.HW, hhw = p.HH * p.HW;
+  const int apieces = 256 * np * 2, hpieces = HV * nq * 2;
+  for (int box = blockIdx.x; box < p.nboxes; box += gridDim.x) {
+    int b = box;
+    const int bx = b % p.nbw; b /= p.nbw;
+    const int by = b % p.nbh; b /= p.nbh;
+    const int bz = b % p.nbd;
+    const int n = b / p.nbd;
+    const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
+    __syncthreads();   // tap table visible / previous box consumed
+    for (int q0 = wave * 64; q0 < apieces; q0 += 8 * 64) {
+      const int q = q0 + lane;
+      const int px = q / (np * 2), part = q - px * (np * 2);
+      const int lz = px / (p.BH * p.BW), rem = px - lz * (p.BH * p.BW);
+      const int ly = rem / p.BW, lx = rem - ly * p.BW;
+      const int oz = oz0 + lz, oy = oy0 + ly, ox = ox0 + lx;
+      const bool ok = oz < d.Da && oy < d.Ha && ox < d.Wa && part * 8 < d.P;
+      const size_t pix = (((size_t)n * d.Da + oz) * d.Ha + oy) * d.Wa + ox;
+      const char* src = ok ? p.a + (pix * d.a_cs + d.a_co + part * 8) * 2 : p.zero;
+      glds16(src, at + (size_t)q0 * 16);
+    }
+    const char* g_n = p.g + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+    for (int q0 = wave * 64; q0 < hpieces; q0 += 8 * 64) {
+      const int q = q0 + lane;
+      const int v = q / (nq * 2), part = q - v * (nq * 2);
+      const int hz = v / hhw, r2 = v - hz * hhw;
+      const int hy = r2 / p.HW, hx = r2 - hy * p.HW;
+      bool ok = q < hpieces && part * 8 < d.Q;
+      int iz = border_index(oz0 + hz + p.dmin, d.Dg, d.border, ok);
+      int iy = border_index(oy0 + hy + p.hmin, d.Hg, d.border, ok);
+      int ix = border_index(ox0 + hx + p.wmin, d.Wg, d.border, ok);
+      iz = min(max(iz, 0), d.Dg - 1);
+      iy = min(max(iy, 0), d.Hg - 1);
+      ix = min(max(ix, 0), d.Wg - 1);
+      unsigned off = ((unsigned)((iz * d.Hg + iy) * d.Wg + ix) * (unsigned)d.g_cs + (unsigned)(part * 8)) * 2u;
+      asm volatile("" : "+v"(off));
+      const char* src = ok ? g_n + off : p.zero;
+      glds16(src, halo + (size_t)q0 * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) {
+      int tbv[TMAX];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) tbv[t] = toff[t];
+#pragma unroll 1
+      for (int ks = 0; ks < 8; ++ks) {             // 8 K-steps of 32 pixels
+        const char* ap = at + (size_t)(ks * 32 + fk * 8 + frr) * APITCH + (pi * 16 + fcc * 4) * 2;
+        const uint2 alo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)GS_LDS(ap)));
+        const uint2 ahi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)GS_LDS(ap + 4 * APITCH)));
+        const bf16x8 af = __builtin_bit_cast(bf16x8, uint4{alo.x, alo.y, ahi.x, ahi.y});
+        const int px0 = (ks * 4 + fk) * 8;         // first pixel of this lane's 8-pixel run (BW is a multiple of 8)
+        const int lz = px0 / (p.BH * p.BW), rem = px0 - lz * (p.BH * p.BW);
+        const int ly = rem / p.BW, lx0 = rem - ly * p.BW;
+        const int rb = (lz * p.HH + ly) * p.HW + lx0 + frr;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+          const char* gp = halo + (size_t)(rb + tbv[t]) * GPITCH + (qi * 16 + fcc * 4) * 2;
+          const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(gp)));
+          const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(gp + 4 * GPITCH)));
+          const bf16x8 gf = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, gf, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const int q = qi * 16 + (lane & 15);
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t < d.T && q < d.Q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pp = pi * 16 + fk * 4 + r;
+        if (pp < d.P) {
+          const size_t e = (size_t)pp * d.dw_ld + t * d.Q + q;
+          if (p.ws) p.ws[(size_t)blockIdx.x * p.ws_stride + e] = acc[t][r];
+          else unsafeAtomicAdd(p.dw + e, acc[t][r]);
+        }
+      }
+    }
+  }
+}
+
 // ---- wide layers with few taps (the 3x3 residual convs: P, Q multiples of 64, T <= 9) -------------------------------------
 // Same staging, different work split: a workgroup owns a 64 x 64 block of (p, q) for ALL taps; its 8 waves each own a
 // 32 x 16 sub-block (two dense fragments, one gathered fragment per tap -> 2 + 2T transpose reads per 2T MFMAs, against
@@ -521,6 +635,54 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     }
   }
   if (a2) return 0;                                // only the wide kernel merges two passes
+  // few taps, narrow on both sides (2-D W-folded k7 boundary convs): the (p, q)-split form
+  if (enabled && gs_opt(GS_OPT_HWGRAD_FT) && d->si == 1 && d->T >= 2 && d->T <= 8 && d->Da == 1 && d->P <= 64 && d->Q <= 64 &&
+      ((d->P + 15) / 16) * ((d->Q + 15) / 16) <= 8 && (long long)d->N * ((d->Ha + 15) / 16) * ((d->Wa + 15) / 16) >= 512) {
+    int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
+    for (int t = 0; t < d->T; ++t) {
+      const int o[3] = {d->dd[t], d->dh[t], d->dw_[t]};
+      for (int ax = 0; ax < 3; ++ax) { if (o[ax] < lo[ax]) lo[ax] = o[ax]; if (o[ax] > hi[ax]) hi[ax] = o[ax]; }
+    }
+    HWGradK k;
+    k.BD = 1; k.BH = 16; k.BW = 16;
+    k.HD = 1 + hi[0] - lo[0]; k.HH = k.BH + hi[1] - lo[1]; k.HW = k.BW + hi[2] - lo[2];
+    k.dmin = lo[0]; k.hmin = lo[1]; k.wmin = lo[2];
+    k.nbd = 1; k.nbh = (d->Ha + 15) / 16; k.nbw = (d->Wa + 15) / 16;
+    const long long nboxes = (long long)d->N * k.nbh * k.nbw;
+    k.phalves = (d->P + 15) / 16;                  // np
+    k.qchunks = (d->Q + 15) / 16;                  // nq
+    k.tgroups = 1;
+    const long long hv = (long long)k.HD * k.HH * k.HW;
+    const int lds = 256 + 256 * k.phalves * 32 + (int)((hv * k.qchunks * 32 + 1023) / 1024 * 1024 + 1024);
+    if (k.HD == 1 && lds <= 96 * 1024 && nboxes < (1LL << 31) &&
+        (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31)) {
+      k.nboxes = (int)nboxes; k.nboxes1 = (int)nboxes;
+      k.a2 = k.g2 = nullptr;
+      k.a = static_cast<const char*>(a);
+      k.g = static_cast<const char*>(g);
+      k.dw = dw;
+      k.zero = static_cast<const char*>(gs_zero_page());
+      GS_REQUIRE(k.zero || plan_only, "gs_wgrad: library not initialised (call gs_init)");
+      k.d = *d;
+      // 512 = two co-resident workgroups per CU (<= 78 KB of LDS each): 61 + 12.6 us (kernel + slab reduction) against 69 + 7.4
+      // with 256 and 81.6 + 6.1 for the im2col form (rocprofv3 averages over both k7 layers, profiles/r03_hwgrad_ft.txt)
+      const long long gmax = gs_opt(GS_OPT_HWGRAD_FT) > 1 ? gs_opt(GS_OPT_HWGRAD_FT) : 512;
+      const long long groups = nboxes < gmax ? nboxes : gmax;    // workgroups walking nboxes / groups boxes each
+      k.ws = ws;
+      k.ws_stride = ws_stride;
+      *handled = ws || plan_only ? (int)groups : 1;
+      if (plan_only) return 0;
+      static bool configured = false;
+      if (!configured) {
+        GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_ft_kernel<8>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        configured = true;
+      }
+      hipLaunchKernelGGL((hwgrad_ft_kernel<8>), dim3((unsigned)groups), dim3(512), lds, static_cast<hipStream_t>(stream), k);
+      GS_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   if (!enabled || d->si != 1 || d->P > 64 || d->Q > 64 || d->T < 9) return 0;
   if (d->Q > 32 && d->P > 16) return 0;            // wide on both sides: the im2col kernel is the better fit (measured)
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};

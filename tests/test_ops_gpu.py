@@ -359,6 +359,38 @@ def test_wgrad_and_bias_grad(hip_ops, case):
     close_f32(res[1][1], res[0][1], "bias grad")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 256, 256),    # stem: P = 64, Q = 21 -> 24 channels
+    (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 256, 256),   # output conv: P = 21 -> 24, Q = 64
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 3, 200, 232),    # ragged boxes (200 = 12 x 16 + 8)
+    (ConvSpec("conv", 1, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 3, 208, 224),    # 1 channel: 7 -> 8 folded channels
+], ids=_ids)
+def test_few_tap_halo_resident_weight_gradient(hip_ops, case, monkeypatch):
+    """hwgrad_ft_kernel (hwgrad.hip): the weight gradient of the W-folded k7 boundary convs of 2-D networks (7 vertical taps,
+    narrow on both sides) out of a resident box + halo with the waves splitting the (p, q) plane — against the im2col
+    weight-gradient kernel of the same library (GS_HWGRAD_FT=0) and the oracle, accumulate semantics, deterministic"""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low = lower(spec, *sizes)
+    g = torch.Generator().manual_seed(17)
+    dev = hip_ops.device
+    # operands of the TRANSFORMED layer (csrc/wfold.hip): the unfolded input / the shift-add's input, all padded channels live
+    x = torch.randn(N, low.Hi, low.Wi, spec.cin_p, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16)
+    out = {}
+    for flag in ("1", "0", "1"):
+        monkeypatch.setenv("GS_HWGRAD_FT", flag)
+        hip_ops.sync_options()
+        dw = torch.full((spec.P * spec.T * spec.Q,), 0.5, dtype=torch.float32, device=dev)
+        hip_ops.wgrad(low.wgrad, gy.to(dev), x.to(dev), dw)
+        torch.cuda.synchronize()
+        out.setdefault(flag, []).append(dw.cpu())
+    ref = torch.full((spec.P * spec.T * spec.Q,), 0.5, dtype=torch.float32)
+    RefOps().wgrad(low.wgrad, gy, x, ref)
+    assert torch.equal(out["1"][0], out["1"][1]), "two runs of the halo-resident form must be bit-identical"
+    close_f32(out["1"][0], ref, "few-tap halo-resident weight gradient vs oracle")
+    close_f32(out["1"][0], out["0"][0], "vs the im2col kernel", rel=1e-3)
+
+
 WGRAD_PAIR_CASES = [
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),                       # headline RB conv (cfg2)
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 2, 16, 16),
