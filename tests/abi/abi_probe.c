@@ -23,6 +23,9 @@ int main(int argc, char** argv) {
   SZ(gs_gconv_fuse); OFF(gs_gconv_fuse, partial); OFF(gs_gconv_fuse, Dy); OFF(gs_gconv_fuse, slope);
   SZ(gs_norm_ex_desc); OFF(gs_norm_ex_desc, slope); OFF(gs_norm_ex_desc, drop_p); OFF(gs_norm_ex_desc, seed_hi);
   SZ(gs_pnorm_desc); OFF(gs_pnorm_desc, N); OFF(gs_pnorm_desc, gres_co);
+  SZ(gs_patchnce_desc); OFF(gs_patchnce_desc, channels); OFF(gs_patchnce_desc, lambda_nce);
+  SZ(gs_attn_desc); OFF(gs_attn_desc, C);
+  SZ(gs_attn_params); OFF(gs_attn_params, wq); OFF(gs_attn_params, bv);
   if (argc < 2) return 0;
   void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!h) { printf("dlopen failed: %s\n", dlerror()); return 3; }
@@ -46,6 +49,12 @@ int main(int argc, char** argv) {
   d.Di = d.Do = d.Dc = 1; d.so = d.si = 1; d.T = 16; d.Kp = 16 * 512; d.w_rows = 8; d.border = GS_BORDER_ZERO;
   for (int t = 0; t < 16; ++t) { d.dh[t] = (int8_t)(t / 4 - 1); d.dw[t] = (int8_t)(t % 4 - 1); }
   printf("call tail_splitk_ws_floats %lld\n", (long long)wsf(&d));
+  /* SelfAttentionBlock(256) on the 10^3 map of the self-attention discriminator at 128^3 inputs (selfattention_patchgan3d.py:58) */
+  typedef int64_t (*attn_bytes_fn)(const gs_attn_desc*);
+  attn_bytes_fn ab = (attn_bytes_fn)dlsym(h, "gs_attn_work_bytes");
+  if (!ab) { printf("dlsym failed\n"); return 4; }
+  gs_attn_desc ad = {1, 1000, 256};
+  printf("call attn_work_bytes %lld\n", (long long)ab(&ad));
   dlclose(h);
   return 0;
 }

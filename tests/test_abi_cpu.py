@@ -75,7 +75,8 @@ def test_c_caller_sees_the_ctypes_layout(tmp_path):
     r = subprocess.run([str(exe), str(L.library_path())], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     mirrors = {"gs_gconv_desc": L.GConvDesc, "gs_wgrad_desc": L.WGradDesc, "gs_gconv_fuse": L.GConvFuse,
-               "gs_norm_ex_desc": L.NormExDesc, "gs_pnorm_desc": L.PNormDesc}
+               "gs_norm_ex_desc": L.NormExDesc, "gs_pnorm_desc": L.PNormDesc, "gs_patchnce_desc": L.PatchNCEDesc,
+               "gs_attn_desc": L.AttnDesc, "gs_attn_params": L.AttnParams}
     calls, seen = {}, set()
     for line in r.stdout.splitlines():
         w = line.split()
@@ -98,6 +99,9 @@ def test_c_caller_sees_the_ctypes_layout(tmp_path):
     assert calls["tile_m"] == lib.gs_tile_m(ctypes.byref(d)) > 0
     assert calls["splitk_ws_floats"] == lib.gs_gconv_splitk_ws_floats(ctypes.byref(d)) == 0
     assert calls["tail_splitk_ws_floats"] > 0
+    ad = L.AttnDesc(1, 1000, 256)
+    # q | k in fp32, [q | k | v] and A v in bf16, the N x N logits (fp32) and probabilities (bf16), the backward's buffers
+    assert calls["attn_work_bytes"] == lib.gs_attn_work_bytes(ctypes.byref(ad)) >= 1000 * 1000 * (4 + 2 + 2)
 
 
 def test_ring_form_eligibility_rule_matches_the_oracle_restatement():
