@@ -56,13 +56,33 @@ class Validator(BaseEngineWithInference):
         try:
             for name, loader in self.data_loaders.items():
                 rows = []
+                dataset = loader.dataset
+                if getattr(getattr(dataset, "conf", None), "device_transforms", False) or \
+                        getattr(dataset, "device_transforms", False):
+                    raise NotImplementedError("validation datasets run the host transform path: set "
+                                              "`val.dataset.device_transforms: false` (the device-side pipeline batches "
+                                              "training samples only)")
+                # Denormalize the data if the dataset defines `denormalize` (validator_tester.py:72-77)
+                denormalize = getattr(dataset, "denormalize", None)
+                over_input = bool(getattr(self.conf.val.metrics, "compute_over_input", False))
                 for data in loader:
                     real_A = data["A"].to(self.model.device)
                     with torch.no_grad():
                         fake_B = self.infer(real_A)
-                    pred, target = fake_B.detach().float().cpu().numpy(), data["B"].float().numpy()
-                    rows.append({k: METRICS[k](target, pred) for k in self.metric_names})
-                mean = {k: float(np.mean([r[k] for r in rows])) for k in self.metric_names} if rows else {}
+                    pred, target, original = fake_B.detach().float().cpu(), data["B"].float(), data["A"].float()
+                    if denormalize:
+                        pred, target = denormalize(pred.clone()), denormalize(target.clone())
+                        if over_input:
+                            original = denormalize(original.clone())
+                    pred, target, original = pred.numpy(), target.numpy(), original.numpy()
+                    # one score per SAMPLE of the batch (ValTestMetrics.get_metrics iterates zip(inputs, targets),
+                    # val_test_metrics.py:152-153): psnr's data range and nmse's norm are per sample
+                    for i in range(pred.shape[0]):
+                        row = {k: METRICS[k](target[i], pred[i]) for k in self.metric_names}
+                        if over_input:
+                            row.update({f"Original_{k}": METRICS[k](target[i], original[i]) for k in self.metric_names})
+                        rows.append(row)
+                mean = {k: float(np.mean([r[k] for r in rows])) for k in rows[0]} if rows else {}
                 self.history.append((current_idx, name, mean))
                 self.logger.info(f"val @ {current_idx} [{name}] {mean}")
         finally:

@@ -85,3 +85,34 @@ def test_trainer_runs_validation_with_sliding_window(fp32_oracle_backend, tmp_pa
         assert set(m) == {"mae", "mse", "nmse", "psnr"} and all(v == v for v in m.values())
     # training state is restored after validation
     assert all(getattr(net, "training", True) for net in tr.model.networks.values())
+
+
+def test_validation_metrics_are_scored_per_sample_and_denormalised(fp32_oracle_backend, tmp_path):
+    """ValTestMetrics.get_metrics scores every sample of a batch on its own (val_test_metrics.py:152-153: psnr's data range
+    and nmse's norm are per sample) after the dataset's `denormalize` hook, and `compute_over_input` adds the Original_*
+    scores of the untranslated input (validator_tester.py:66-86)"""
+    import numpy as np
+    from ganslate_amd.engines import init_engine
+    from ganslate_amd.engines.validator import METRICS
+    conf3d = Path(__file__).parent / "configs" / "cyclegan3d_val_synthetic.yaml"
+    args = [f"config={conf3d}", "train.cuda=false", f"train.output_dir={tmp_path}", f"val.output_dir={tmp_path}",
+            "train.seed=7", "val.batch_size=2", "val.metrics.compute_over_input=true"]
+    tr = init_engine("train", args)
+    v = tr.validator
+    loader = next(iter(v.data_loaders.values()))
+    loader.dataset.denormalize = lambda t: (t + 1) * 500.0          # the hook the reference's medical datasets define
+    seen = []
+    infer = v.infer
+    v.infer = lambda x: (lambda y: (seen.append(y.detach().float().cpu()), y)[1])(infer(x))
+    v.run(current_idx=0)
+    _, _, mean = v.history[-1]
+    assert set(mean) == {k for m in ("mae", "mse", "nmse", "psnr") for k in (m, f"Original_{m}")}
+    # recompute from the recorded predictions, sample by sample
+    rows = []
+    for pred, data in zip(seen, loader):
+        for i in range(pred.shape[0]):
+            p, t = ((pred[i] + 1) * 500.0).numpy(), ((data["B"][i].float() + 1) * 500.0).numpy()
+            rows.append({k: METRICS[k](t, p) for k in ("mae", "mse", "nmse", "psnr")})
+    assert len(rows) >= 2 and len(seen[0]) == 2
+    for k in ("mae", "mse", "nmse", "psnr"):
+        assert mean[k] == pytest.approx(float(np.mean([r[k] for r in rows])), rel=1e-6), k
