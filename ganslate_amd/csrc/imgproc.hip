@@ -42,6 +42,29 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* in
   for (int c = 0; c < C; ++c) o[c] = (unsigned char)clip8(acc[c]);
 }
 
+// plain vertical pass, 8-bit out (the intermediate image between two resizes: scale_width / resize followed by random_zoom)
+template <int C>
+__global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* tmp, unsigned char* out, int w,
+                                                         const int* bounds, const int* kk, int ksize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int yy = blockIdx.y;
+  if (x >= w) return;
+  const int ymin = bounds[yy * 2], yn = bounds[yy * 2 + 1];
+  const int* k = kk + (size_t)yy * ksize;
+  int acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 1 << (PRECISION_BITS - 1);
+  for (int y = 0; y < yn; ++y) {
+    const unsigned char* p = tmp + ((size_t)(ymin + y) * w + x) * C;
+    const int wgt = k[y];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += (int)p[c] * wgt;
+  }
+  unsigned char* o = out + ((size_t)yy * w + x) * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = (unsigned char)clip8(acc[c]);
+}
+
 // vertical pass restricted to the crop window [top, top+fh) x [left, left+fw) of the resized image, then
 // RandomHorizontalFlip, ToTensor (x / 255) and Normalize ((x - 0.5) / 0.5) in torchvision's fp32 operation order:
 // out[c][i][j] fp32, planes fh*fw apart
@@ -83,6 +106,20 @@ extern "C" int gs_u8_resample_h(const void* in, void* out, int32_t in_h, int32_t
   unsigned char* o8 = static_cast<unsigned char*>(out);
   if (C == 3) hipLaunchKernelGGL(resample_h_kernel<3>, grid, dim3(256), 0, st, i8, o8, in_h, in_w, out_w, bounds, kk, ksize);
   else hipLaunchKernelGGL(resample_h_kernel<1>, grid, dim3(256), 0, st, i8, o8, in_h, in_w, out_w, bounds, kk, ksize);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_u8_resample_v(const void* tmp, void* out, int32_t tmp_h, int32_t w, int32_t out_h, int32_t C,
+                                const int32_t* bounds, const int32_t* kk, int32_t ksize, void* stream) {
+  GS_REQUIRE(tmp && out && bounds && kk && tmp_h > 0 && w > 0 && out_h > 0 && ksize > 0 && (C == 1 || C == 3),
+             "gs_u8_resample_v: bad argument (C must be 1 or 3)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((w + 255) / 256, out_h);
+  const unsigned char* t8 = static_cast<const unsigned char*>(tmp);
+  unsigned char* o8 = static_cast<unsigned char*>(out);
+  if (C == 3) hipLaunchKernelGGL(resample_v_kernel<3>, grid, dim3(256), 0, st, t8, o8, w, bounds, kk, ksize);
+  else hipLaunchKernelGGL(resample_v_kernel<1>, grid, dim3(256), 0, st, t8, o8, w, bounds, kk, ksize);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

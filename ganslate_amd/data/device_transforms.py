@@ -69,10 +69,11 @@ def resample_tables(in_size: int, out_size: int):
 
 class RawImage:
     """what a dataset worker hands over with device_transforms on: decoded pixels and the drawn random parameters"""
-    __slots__ = ("pixels", "crop", "flip")
+    __slots__ = ("pixels", "crop", "flip", "zoom")
 
-    def __init__(self, pixels, crop, flip):
-        self.pixels, self.crop, self.flip = pixels, crop, flip      # uint8 (H, W, C) tensor, (u, v) in [0, 1), bool
+    def __init__(self, pixels, crop, flip, zoom=(1.0, 1.0)):
+        # uint8 (H, W, C) tensor, (u, v) in [0, 1), bool, random_zoom's (width, height) levels
+        self.pixels, self.crop, self.flip, self.zoom = pixels, crop, flip, zoom
 
 
 def draw_params():
@@ -90,7 +91,7 @@ class DeviceImagePipeline:
     def __init__(self, conf, device, ops=None):
         d = conf[conf.mode].dataset
         self.pre, self.load, self.final = list(d.preprocess), tuple(d.load_size), tuple(d.final_size)
-        unknown = set(self.pre) - {"resize", "random_crop", "random_flip"}
+        unknown = set(self.pre) - {"resize", "scale_width", "random_zoom", "random_crop", "random_flip"}
         if unknown:
             raise NotImplementedError(f"device_transforms: preprocess steps {sorted(unknown)} have no device path")
         self.device = torch.device(device)
@@ -113,10 +114,17 @@ class DeviceImagePipeline:
             self._tables[key] = t
         return t
 
-    def geometry(self, H, W, crop):
+    def sizes(self, H, W, zoom):
+        """the resizes before the crop — image_datasets._Transform.sizes, the same integer arithmetic"""
+        from .image_datasets import _Transform
+        t = _Transform.__new__(_Transform)
+        t.pre, t.load, t.final = self.pre, self.load, self.final
+        return t.sizes(H, W, {"zoom": zoom})
+
+    def geometry(self, H, W, crop, zoom=(1.0, 1.0)):
         """(resized H, resized W, top, left, fh, fw) of one image — the same integer arithmetic as the host transform of
         ganslate_amd/data/image_datasets.py"""
-        rh, rw = (self.load if "resize" in self.pre else (H, W))
+        rh, rw = (self.sizes(H, W, zoom) or [(H, W)])[-1]
         if "random_crop" in self.pre:
             fh, fw = self.final
             top, left = int(crop[0] * max(rh - fh, 0)), int(crop[1] * max(rw - fw, 0))
@@ -132,7 +140,16 @@ class DeviceImagePipeline:
         if not px.is_cuda:
             px = px.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else px
         H, W, C = px.shape
-        rh, rw, top, left, fh, fw = self.geometry(H, W, raw.crop)
+        rh, rw, top, left, fh, fw = self.geometry(H, W, raw.crop, raw.zoom)
+        steps = self.sizes(H, W, raw.zoom) or [(H, W)]
+        for h1, w1 in steps[:-1]:          # a complete resize with an 8-bit result in front of the last one (Pillow rounds
+            bh, kh = self._dev_tables(W, w1)          # to bytes between two Image.resize calls)
+            bv, kv = self._dev_tables(H, h1)
+            tmp = torch.empty((H, w1, C), dtype=torch.uint8, device=px.device)
+            self.ops.u8_resample_h(px, tmp, bh, kh)
+            px = torch.empty((h1, w1, C), dtype=torch.uint8, device=px.device)
+            self.ops.u8_resample_v(tmp, px, bv, kv)
+            H, W = h1, w1
         bh, kh = self._dev_tables(W, rw)
         bv, kv = self._dev_tables(H, rh)
         tmp = torch.empty((H, rw, C), dtype=torch.uint8, device=px.device)
@@ -148,7 +165,7 @@ class DeviceImagePipeline:
                 continue
             r0 = items[0]
             C = 1 if r0.pixels.ndim == 2 else r0.pixels.shape[-1]
-            shapes = {self.geometry(r.pixels.shape[0], r.pixels.shape[1], r.crop)[4:] for r in items}
+            shapes = {self.geometry(r.pixels.shape[0], r.pixels.shape[1], r.crop, r.zoom)[4:] for r in items}
             assert len(shapes) == 1, f"images of one batch end at different sizes {shapes}: add random_crop or resize"
             fh, fw = next(iter(shapes))
             dst = torch.empty((len(items), C, fh, fw), dtype=torch.float32, device=self.device)

@@ -1,7 +1,7 @@
 """Config dataclasses (and thin PIL loaders) for the reference's image-folder datasets so that
 projects/*/experiments/*.yaml load unchanged (ganslate/data/unpaired_image_dataset.py:19-62,
 paired_image_dataset.py:20-60). Host-side image decoding is outside the hot path: the
-loaders implement resize / random_crop / random_flip with PIL + torch only and [-1,1] normalisation."""
+loaders implement resize / scale_width / random_zoom / random_crop / random_flip with PIL + torch only and [-1,1] normalisation."""
 import random
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -50,21 +50,44 @@ class _Transform:
             self.raw = False
 
     def params(self):
-        return {"crop": (random.random(), random.random()), "flip": random.random() > 0.5}
+        """the random draws of one sample (shared by both images of a pair, transforms.py:101-121): crop position as
+        fractions, flip, and random_zoom's two levels in [0.8, 1) (transforms.py:101,129)"""
+        return {"crop": (random.random(), random.random()), "flip": random.random() > 0.5,
+                "zoom": (random.uniform(0.8, 1.0), random.uniform(0.8, 1.0))}
+
+    def sizes(self, H, W, prm):
+        """[(h, w), ...] of the resizes a decoded H x W image goes through before the crop: `resize` -> load_size, or
+        `scale_width` (transforms.py:163-169: width -> load_w, height in proportion but at least final_w; untouched when the
+        width already is load_w), then `random_zoom` (transforms.py:127-137: each side zoomed by its level, at least final)"""
+        out = []
+        if "resize" in self.pre:
+            H, W = self.load
+            out.append((H, W))
+        elif "scale_width" in self.pre:
+            load_w, final_w = self.load[1], self.final[1]
+            if not (W == load_w and W >= final_w):
+                H, W = int(max(load_w * H / W, final_w)), load_w
+                out.append((H, W))
+        if "random_zoom" in self.pre:
+            zw = max(self.final[1], W * prm["zoom"][0])
+            zh = max(self.final[0], H * prm["zoom"][1])
+            H, W = int(round(zh)), int(round(zw))
+            out.append((H, W))
+        return out
 
     def decode_only(self, img, prm):
         """device_transforms: hand the decoded bytes and the drawn parameters to DeviceImagePipeline"""
         import numpy as np
         from .device_transforms import RawImage
-        return RawImage(torch.from_numpy(np.array(img, dtype=np.uint8)), prm["crop"], prm["flip"])
+        return RawImage(torch.from_numpy(np.array(img, dtype=np.uint8)), prm["crop"], prm["flip"], prm["zoom"])
 
     def __call__(self, img, prm):
         import numpy as np
         from PIL import Image
         if self.raw:
             return self.decode_only(img, prm)
-        if "resize" in self.pre:
-            img = img.resize((self.load[1], self.load[0]), Image.BICUBIC)
+        for h, w in self.sizes(img.size[1], img.size[0], prm):
+            img = img.resize((w, h), Image.BICUBIC)
         if "random_crop" in self.pre:
             W, H = img.size
             top = int(prm["crop"][0] * max(H - self.final[0], 0))

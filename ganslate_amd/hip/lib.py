@@ -142,6 +142,8 @@ _PROTOS = {
     "gs_slice_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_u8_resample_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_void_p]),
+    "gs_u8_resample_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_int32, C.c_void_p]),
     "gs_u8_resample_v_crop_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_void_p]),

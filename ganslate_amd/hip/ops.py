@@ -482,6 +482,12 @@ class HipOps:
         L.check(self.lib.gs_u8_resample_h(_ptr(img), _ptr(out), H, W, out.shape[1], Cc, _ptr(bounds), _ptr(kk),
                                           kk.shape[1], _stream()), "gs_u8_resample_h")
 
+    def u8_resample_v(self, tmp, out, bounds, kk):
+        """Pillow's vertical 8-bit pass: tmp (H, W', C) uint8 -> out (H', W', C) uint8 (the image between two resizes)"""
+        H, W2, Cc = tmp.shape
+        L.check(self.lib.gs_u8_resample_v(_ptr(tmp), _ptr(out), H, W2, out.shape[0], Cc, _ptr(bounds), _ptr(kk),
+                                          kk.shape[1], _stream()), "gs_u8_resample_v")
+
     def u8_resample_v_crop_normalize(self, tmp, out, out_h, bounds, kk, top, left, flip):
         """Pillow's vertical pass on the crop window + flip + ToTensor + Normalize(0.5, 0.5): tmp (H, W', C) uint8 ->
         out (C, fh, fw) fp32 (a contiguous slice of the NCHW batch)"""

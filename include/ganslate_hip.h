@@ -315,7 +315,7 @@ int gs_slice_stats(const void* x, int32_t N, int64_t pixels, int32_t cs, int32_t
 
 /* ---- device-side image preprocessing --------------------------------------------- */
 /* What ganslate/data/utils/transforms.py:9-61 composes on the host from torchvision / PIL for the image-folder datasets
- * (unpaired_image_dataset.py:31-62, paired_image_dataset.py): Resize(load_size, Image.BICUBIC), RandomCrop(final_size),
+ * (unpaired_image_dataset.py:31-62, paired_image_dataset.py): Resize(load_size, Image.BICUBIC) / scale_width / random_zoom, RandomCrop(final_size),
  * RandomHorizontalFlip, ToTensor, Normalize(0.5, 0.5) — here on decoded 8-bit HWC images (C = 1 or 3) in device memory.
  * The resize is Pillow's two-pass 8-bit resampler bit for bit (src/libImaging/Resample.c): the caller supplies, per axis,
  * bounds[out][2] = (first input index, count) and kk[out][ksize] = 22-bit fixed-point coefficients
@@ -323,6 +323,10 @@ int gs_slice_stats(const void* x, int32_t N, int64_t pixels, int32_t cs, int32_t
  * Pass 1, horizontal: out[y][xx][c] = clip8((2^21 + sum_k in[y][xmin+k][c] * kk[xx][k]) >> 22), all in_h rows. */
 int gs_u8_resample_h(const void* in, void* out, int32_t in_h, int32_t in_w, int32_t out_w, int32_t C,
                      const int32_t* bounds, const int32_t* kk, int32_t ksize, void* stream);
+/* Pass 2 as a plain 8-bit image (out_h x w): the intermediate of two consecutive resizes — `scale_width` / `resize` followed by
+ * `random_zoom` (transforms.py:22-37,127-137,163-169). */
+int gs_u8_resample_v(const void* tmp, void* out, int32_t tmp_h, int32_t w, int32_t out_h, int32_t C, const int32_t* bounds,
+                     const int32_t* kk, int32_t ksize, void* stream);
 /* Pass 2, vertical, only for the crop window [top, top+fh) x [left, left+fw) of the out_h x tmp_w resized image, then flip,
  * x/255 and (x-0.5)/0.5 in torchvision's fp32 order: out[c][i][j] (planes of fh*fw floats — a slice of the NCHW batch). */
 int gs_u8_resample_v_crop_normalize(const void* tmp, float* out, int32_t tmp_h, int32_t tmp_w, int32_t out_h, int32_t C,

@@ -502,6 +502,15 @@ class RefOps:
                 acc += a[:, xmin + x] * int(kk[xx, x])
             out[:, xx] = (acc >> 22).clamp(0, 255).to(torch.uint8)
 
+    def u8_resample_v(self, tmp, out, bounds, kk):
+        a = tmp.to(torch.int64)
+        for yy in range(out.shape[0]):
+            ymin, yn = int(bounds[yy, 0]), int(bounds[yy, 1])
+            acc = torch.full(a[0].shape, 1 << 21, dtype=torch.int64)
+            for y in range(yn):
+                acc += a[ymin + y] * int(kk[yy, y])
+            out[yy] = (acc >> 22).clamp(0, 255).to(torch.uint8)
+
     def u8_resample_v_crop_normalize(self, tmp, out, out_h, bounds, kk, top, left, flip):
         a = tmp.to(torch.int64)
         fh, fw = out.shape[1], out.shape[2]

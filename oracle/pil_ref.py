@@ -66,12 +66,32 @@ def resize_bicubic(img, out_h, out_w):
     return img
 
 
-def single_image_transform(img, preprocess, load_size, final_size, crop, flip):
+def scale_width(img, load_w, final_w):
+    """__scale_width (transforms.py:163-169)"""
+    img_h, img_w = img.shape[:2]
+    if img_w == load_w and img_w >= final_w:
+        return img
+    return resize_bicubic(img, int(max(load_w * img_h / img_w, final_w)), load_w)
+
+
+def random_zoom(img, final_size, zoom_level):
+    """__random_zoom (transforms.py:127-137) with the two levels (width, height) passed in"""
+    img_h, img_w = img.shape[:2]
+    zoom_w = max(final_size[1], img_w * zoom_level[0])
+    zoom_h = max(final_size[0], img_h * zoom_level[1])
+    return resize_bicubic(img, int(round(zoom_h)), int(round(zoom_w)))
+
+
+def single_image_transform(img, preprocess, load_size, final_size, crop, flip, zoom=(1.0, 1.0)):
     """get_single_image_transform (transforms.py:9-61) with the random draws passed in: crop = (u, v) in [0, 1) mapped to
-    top = int(u * (H - fh)), left = int(v * (W - fw)) like ganslate_amd/data/image_datasets.py, flip = bool.
-    Returns fp32 (C, fh, fw) in [-1, 1]."""
+    top = int(u * (H - fh)), left = int(v * (W - fw)) like ganslate_amd/data/image_datasets.py, flip = bool, zoom =
+    random_zoom's levels. Returns fp32 (C, fh, fw) in [-1, 1]."""
     if "resize" in preprocess:
         img = resize_bicubic(img, load_size[0], load_size[1])
+    elif "scale_width" in preprocess:
+        img = scale_width(img, load_size[1], final_size[1])
+    if "random_zoom" in preprocess:
+        img = random_zoom(img, final_size, zoom)
     if "random_crop" in preprocess:
         H, W = img.shape[:2]
         top, left = int(crop[0] * max(H - final_size[0], 0)), int(crop[1] * max(W - final_size[1], 0))

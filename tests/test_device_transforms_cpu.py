@@ -43,24 +43,45 @@ def test_product_tables_equal_the_restatement(n_in, n_out):
     assert np.array_equal(kk, np.array(rk, np.int32))
 
 
+PIPELINES = [("resize", "random_crop", "random_flip"), ("scale_width", "random_crop"),
+             ("resize", "random_zoom", "random_crop", "random_flip"), ("scale_width", "random_zoom", "random_crop", "random_flip")]
+
+
+def test_scale_width_and_random_zoom_equal_the_reference_formulas_on_pillow():
+    """the two Lambda transforms (transforms.py:127-137,163-169) applied with PIL itself, against the oracle's restatement:
+    sizes and bytes"""
+    a = _image(120, 200, 3, 5)
+    for load_w, final_w in ((160, 128), (200, 128), (100, 180)):
+        img = _pil(a)
+        w, h = img.size
+        ref = img if (w == load_w and w >= final_w) else img.resize((load_w, int(max(load_w * h / w, final_w))), Image.BICUBIC)
+        assert np.array_equal(pil_ref.scale_width(a, load_w, final_w), np.asarray(ref))
+    for zoom in ((0.8, 0.95), (0.9999, 0.8), (0.3, 0.3)):
+        zw, zh = max(128, 200 * zoom[0]), max(96, 120 * zoom[1])
+        ref = _pil(a).resize((int(round(zw)), int(round(zh))), Image.BICUBIC)
+        assert np.array_equal(pil_ref.random_zoom(a, (96, 128), zoom), np.asarray(ref))
+
+
+@pytest.mark.parametrize("pre", PIPELINES)
 @pytest.mark.parametrize("c", [3, 1])
-def test_oracle_transform_equals_the_host_dataset_transform(c, tmp_path):
+def test_oracle_transform_equals_the_host_dataset_transform(c, pre, tmp_path):
     """oracle single_image_transform == the PIL + torch transform of ganslate_amd/data/image_datasets.py (which is what
     torchvision's Resize / RandomCrop / RandomHorizontalFlip / ToTensor / Normalize compute) for the same draws"""
     from ganslate_amd.data.image_datasets import _Transform
 
     class D(dict):
         __getattr__ = dict.__getitem__
-    conf = D(mode="train", train=D(dataset=D(preprocess=["resize", "random_crop", "random_flip"], load_size=[72, 80],
-                                             final_size=[64, 64])))
+    conf = D(mode="train", train=D(dataset=D(preprocess=list(pre), load_size=[72, 80], final_size=[64, 64])))
     t = _Transform(conf)
     random.seed(3)
     for k in range(4):
         a = _image(50 + 7 * k, 90 - 5 * k, c, k)
         prm = t.params()
         want = t(_pil(a), prm)
-        got = pil_ref.single_image_transform(a, t.pre, t.load, t.final, prm["crop"], prm["flip"])
+        assert 0.8 <= min(prm["zoom"]) and max(prm["zoom"]) <= 1.0
+        got = pil_ref.single_image_transform(a, t.pre, t.load, t.final, prm["crop"], prm["flip"], prm["zoom"])
         assert torch.equal(torch.from_numpy(got), want)
+        assert want.shape[1:] == (64, 64)
 
 
 def test_loader_hands_over_raw_images_with_device_transforms(tmp_path):

@@ -10,6 +10,7 @@ import torch
 from PIL import Image
 
 from ganslate_amd.data.device_transforms import DeviceImagePipeline, RawImage, resample_tables
+from oracle import pil_ref
 from oracle.ops_ref import RefOps
 
 pytestmark = pytest.mark.gpu
@@ -45,12 +46,20 @@ def test_kernels_equal_the_oracle_pass_by_pass(hip_ops, h, w, oh, ow, c):
             ops.u8_resample_v_crop_normalize(tmp, out, oh, bv.to(dev), kv.contiguous().to(dev), top, left, flip)
             res.append(out.cpu())
         outs.append((tmp.cpu(), res))
+        mid = torch.empty((oh, ow, c), dtype=torch.uint8, device=dev)
+        ops.u8_resample_v(tmp, mid, bv.to(dev), kv.contiguous().to(dev))
+        outs[-1] += (mid.cpu(),)
     assert torch.equal(outs[0][0], outs[1][0]), "horizontal pass"
+    assert torch.equal(outs[0][2], outs[1][2]), "vertical pass, 8-bit"
+    ref = pil_ref.resize_bicubic(img.numpy(), oh, ow)
+    assert np.array_equal(outs[1][2].numpy(), ref), "two passes == Pillow's resize"
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b), "vertical pass + crop + flip + normalise"
 
 
-@pytest.mark.parametrize("pre", [("resize", "random_crop", "random_flip"), ("resize",), ("random_crop", "random_flip")])
+@pytest.mark.parametrize("pre", [("resize", "random_crop", "random_flip"), ("resize",), ("random_crop", "random_flip"),
+                                 ("scale_width", "random_crop"), ("resize", "random_zoom", "random_crop", "random_flip"),
+                                 ("scale_width", "random_zoom", "random_crop", "random_flip")])
 @pytest.mark.parametrize("c", [3, 1])
 def test_pipeline_equals_the_host_transform_bit_for_bit(hip_ops, pre, c):
     from ganslate_amd.data.image_datasets import _Transform
@@ -65,7 +74,7 @@ def test_pipeline_equals_the_host_transform_bit_for_bit(hip_ops, pre, c):
         prm = host.params()
         pil = Image.fromarray(a if c == 3 else a[..., 0], "RGB" if c == 3 else "L")
         want.append(host(pil, prm))
-        raws.append(RawImage(torch.from_numpy(a if c == 3 else a[..., 0].copy()), prm["crop"], prm["flip"]))
+        raws.append(RawImage(torch.from_numpy(a if c == 3 else a[..., 0].copy()), prm["crop"], prm["flip"], prm["zoom"]))
     if len({tuple(t.shape) for t in want}) > 1:
         pytest.skip("without resize or crop the images of a batch keep their own sizes")
     got = pipe({"A": raws})["A"]
