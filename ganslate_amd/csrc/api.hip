@@ -65,6 +65,8 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconvx", 0},              // self-pipelined 8-wave form of the wide 3x3 kernels (hconvx.hip) instead of hconvw.hip's phase-locked loop
     {"wfold_rows", 1},          // row-staged forms of the four W-fold boundary transforms (wfold.hip) instead of one thread per pixel
     {"hwgrad_ft", 1},           // halo-resident weight gradient of narrow layers with few taps (hwgrad.hip: the 2-D k7 boundary convs)
+    {"gconv_big", 192},         // smallest number of 256 x 128 im2col tiles that selects them (one workgroup per CU) over 128 x 128 (two)
+    {"hconv_box8", 1},          // hconv.hip: 8 x 8 x 8 boxes on 8 waves for volumes (4 x 8 x 8 on 4 waves otherwise)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

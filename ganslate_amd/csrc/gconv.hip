@@ -580,7 +580,7 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
   // big tile (8 waves, 3 stages, 1 workgroup per CU) once it still fills the chip; else the 4-wave 128x128 tile
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const long long big = (long long)d->N * ((pix + 255) / 256) * ((d->Co + 127) / 128);
-  if (big >= 192) {
+  if (big >= gs_opt(GS_OPT_GCONV_BIG)) {
     // one workgroup per CU is resident: if the 256-pixel tiling needs a second, mostly empty round of workgroups
     // but 320-pixel tiles fit in one round, the larger tile wins (e.g. the 66x66 padded-domain data gradients)
     const long long big320 = (long long)d->N * ((pix + 319) / 320) * ((d->Co + 127) / 128);

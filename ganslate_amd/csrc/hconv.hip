@@ -33,19 +33,19 @@ struct HConvK {
 // LDS map: [tap offsets GS_MAX_TAPS*4][stats scratch 2 KiB][2 weight stages][halo]
 //   weight stage: TI*16 rows (output channels) x 8 K-steps x 32 k, row pitch 33 pieces of 16 B (528 B: the pad piece
 //   spreads the 16 rows of a fragment read over all banks); filled by LDS-DMA, lane q -> (row q/33, piece q%33)
-template <int TI, int CC>
-__global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
+template <int TI, int CC, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void hconv_kernel(const HConvK p) {
   constexpr int PP = CC / 8;                      // 16-B pieces per voxel
   constexpr int SK = 8;                           // K-steps per weight stage
   constexpr int WROWS = TI * 16;
   constexpr int WPIECES = WROWS * 33;
   constexpr int WINSTR = (WPIECES + 63) / 64;     // LDS-DMA instructions per stage
   constexpr int WSTAGE = WINSTR * 1024;           // bytes per stage
-  constexpr int WPW = (WINSTR + 3) / 4;           // instructions per wave per stage
+  constexpr int WPW = (WINSTR + NW - 1) / NW;     // instructions per wave per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* toff = reinterpret_cast<int*>(smem);                        // [GS_MAX_TAPS] halo-linear tap offsets
-  float* red = reinterpret_cast<float*>(smem + GS_MAX_TAPS * 4);   // [4 waves][64 channels][2]
-  char* wst = smem + GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4;
+  float* red = reinterpret_cast<float*>(smem + GS_MAX_TAPS * 4);   // [NW waves][64 channels][2]
+  char* wst = smem + GS_MAX_TAPS * 4 + NW * 64 * 2 * 4;
   char* halo = wst + 2 * WSTAGE;
   const gs_gconv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
   const int box = (bz * p.nbh + by) * p.nbw + bx;
   const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
 
-  for (int t = tid; t < d.T; t += 256)
+  for (int t = tid; t < d.T; t += NW * 64)
     toff[t] = (((int)d.dd[t] - p.dmin) * p.HH + ((int)d.dh[t] - p.hmin)) * p.HW + ((int)d.dw[t] - p.wmin);
 
   const int row = lane & 15, kg = lane >> 4;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
   for (int chunk = 0; chunk < p.chunks; ++chunk) {
     __syncthreads();   // tap table visible / the previous chunk's reads are done
     // ---- stage the input box + halo of this channel chunk: one 16-B piece per lane per LDS-DMA instruction ----
-    for (int q0 = wave * 64; q0 < pieces; q0 += 256) {
+    for (int q0 = wave * 64; q0 < pieces; q0 += NW * 64) {
       const int q = q0 + lane;
       const int v = q / PP, part = q - v * PP;
       const int hz = v / hhw, r2 = v - hz * hhw;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
     if (tid < WROWS && co0 + tid < d.Co) {
       float a = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { a += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
       float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + box) * 2) * d.Co;
       sp[co0 + tid] = a;
       sp[d.Co + co0 + tid] = q;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const HConvK p) {
 namespace {
 struct HPlan {
   bool ok;
-  int BD, BH, BW, HD, HH, HW, dmin, hmin, wmin, nbd, nbh, nbw, CC, TI, cog, lds;
+  int BD, BH, BW, HD, HH, HW, dmin, hmin, wmin, nbd, nbh, nbw, CC, TI, cog, lds, NW;
 };
 
 HPlan plan(const gs_gconv_desc* d) {
@@ -259,7 +259,12 @@ HPlan plan(const gs_gconv_desc* d) {
     const int o[3] = {d->dd[t], d->dh[t], d->dw[t]};
     for (int a = 0; a < 3; ++a) { if (o[a] < lo[a]) lo[a] = o[a]; if (o[a] > hi[a]) hi[a] = o[a]; }
   }
-  if (d->Do > 1) { h.BD = 4; h.BH = 8; h.BW = 8; } else { h.BD = 1; h.BH = 16; h.BW = 16; }
+  // volumes with room for them: 8 x 8 x 8 boxes on 8 waves — the weight stream (64 KB per box for 16 -> 16 channels, k5) is
+  // shared by twice the voxels and the halo box is 3.4x its output instead of 4.5x (826 -> 492 MB of L2 -> LDS traffic per
+  // launch at 128^3, which is what bounds these layers)
+  // (16 output channels only: with 32 the larger box leaves room for ONE workgroup per CU and measured slower, 728 vs 617 us)
+  h.NW = (d->Do >= 8 && d->Co <= 16 && gs_opt(GS_OPT_HCONV_BOX8)) ? 8 : 4;
+  if (d->Do > 1) { h.BD = h.NW == 8 ? 8 : 4; h.BH = 8; h.BW = 8; } else { h.BD = 1; h.BH = 16; h.BW = 16; }
   h.HD = h.BD + hi[0] - lo[0]; h.HH = h.BH + hi[1] - lo[1]; h.HW = h.BW + hi[2] - lo[2];
   h.dmin = lo[0]; h.hmin = lo[1]; h.wmin = lo[2];
   h.nbd = (d->Do + h.BD - 1) / h.BD; h.nbh = (d->Ho + h.BH - 1) / h.BH; h.nbw = (d->Wo + h.BW - 1) / h.BW;
@@ -269,22 +274,22 @@ HPlan plan(const gs_gconv_desc* d) {
   const long long hv = (long long)h.HD * h.HH * h.HW;
   const long long halo_bytes = (hv * h.CC * 2 + 1023) / 1024 * 1024 + 1024;
   const int wstage = (h.TI * 16 * 33 + 63) / 64 * 1024;
-  h.lds = GS_MAX_TAPS * 4 + 4 * 64 * 2 * 4 + 2 * wstage + (int)halo_bytes;
+  h.lds = GS_MAX_TAPS * 4 + h.NW * 64 * 2 * 4 + 2 * wstage + (int)halo_bytes;
   // two workgroups per CU must fit, so a workgroup's staging overlaps the other's tap loop
   if (h.lds > 110 * 1024) return h;
   h.ok = true;
   return h;
 }
 
-template <int TI, int CC>
+template <int TI, int CC, int NW>
 int launch_h(const HConvK& k, int blocks, int cog, int lds, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<TI, CC>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<TI, CC, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
     configured = true;
   }
-  hipLaunchKernelGGL((hconv_kernel<TI, CC>), dim3(blocks, cog), dim3(256), lds, st, k);
+  hipLaunchKernelGGL((hconv_kernel<TI, CC, NW>), dim3(blocks, cog), dim3(NW * 64), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -319,7 +324,9 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   *handled = 1;
-#define GS_H(TI_, CC_) if (h.TI == TI_ && h.CC == CC_) return launch_h<TI_, CC_>(k, (int)blocks, h.cog, h.lds, st)
+#define GS_H(TI_, CC_)                                                                                   \
+  if (h.TI == TI_ && h.CC == CC_)                                                                        \
+    return h.NW == 8 ? launch_h<TI_, CC_, 8>(k, (int)blocks, h.cog, h.lds, st) : launch_h<TI_, CC_, 4>(k, (int)blocks, h.cog, h.lds, st)
   GS_H(1, 8); GS_H(1, 16);
   GS_H(2, 8); GS_H(2, 16);
 #undef GS_H

@@ -30,6 +30,8 @@ def sample(stop, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--ablations", action="store_true",
+                    help="energy per launch of hconvx's ablated forms (needs GANSLATE_HIP_LIB=build/libganslate_hip_tl.so, `make timeline`)")
     args = ap.parse_args()
     ops = HipOps()
     dev = ops.device
@@ -44,10 +46,18 @@ def main():
     part = torch.empty(N * slots * 2 * spec.cout_p, device=dev)
     r = subprocess.run(["rocm-smi", "--showmaxpower", "--showpower"], capture_output=True, text=True)
     print("\n".join(l for l in r.stdout.splitlines() if "ower" in l))
-    for label, opt in (("hconvw (16 waves, phase-locked)", 0), ("hconvx (8 waves, self-pipelined)", 1),
-                       ("hconvx + 4 loader waves", 100), ("idle", None)):
+    cases = (("hconvw (16 waves, phase-locked)", 0), ("hconvx (8 waves, self-pipelined)", 1),
+             ("hconvx + 4 loader waves", 100), ("idle", None))
+    if args.ablations:
+        cases = (("hconvw", 0), ("hconvw, all-zero input and weights", -1), ("hconvx", 1), ("hconvx, no LDS-DMA in the loop", 2),
+                 ("hconvx, no fragment reads", 3), ("hconvx, neither (MFMA + prologue + epilogue)", 4),
+                 ("hconvx, neither, no barrier", 8), ("idle", None))
+    x0, f0 = x.clone(), fpack.clone()
+    for label, opt in cases:
         if opt is not None:
-            ops.set_option("hconvx", opt)
+            ops.set_option("hconvx", max(opt, 0))
+            x.copy_(x0 if opt >= 0 else torch.zeros_like(x0))
+            fpack.copy_(f0 if opt >= 0 else torch.zeros_like(f0))
         stop, out = threading.Event(), []
         th = threading.Thread(target=sample, args=(stop, out))
         th.start()
@@ -69,6 +79,14 @@ def main():
         th.join()
         ms = e0.elapsed_time(e1)
         print(f"== {label}: {n} launches, {1e3 * ms / max(n, 1):.1f} us per launch (incl. sync gaps)")
+        import re
+        mid = out[2:-1] or out
+        watts = [float(m.group(1)) for _, keep in mid for l in keep for m in [re.search(r"Power \(W\): ([0-9.]+)", l)] if m]
+        clk = [int(m.group(1)) for _, keep in mid for l in keep for m in [re.search(r"sclk clock level: \d+: \((\d+)Mhz", l)] if m]
+        if watts and n:
+            w = sum(watts) / len(watts)
+            print(f"   mean {w:.0f} W, sclk {sum(clk) / max(len(clk), 1):.0f} MHz, {w * ms / n:.1f} mJ per launch "
+                  f"({(w - 288) * ms / n:.1f} mJ above idle)")
         for t, keep in out[-3:]:
             print("   ", " | ".join(keep))
 
