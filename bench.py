@@ -27,9 +27,9 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROAR
 # HBM bytes per launch of the three residual-conv kernels at the headline shape, from rocprofv3 PMC passes (bench.py
 # cannot run the profiler on itself): 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction of
 # MI355X_MICROARCH.md. Filled from profiles/ by name; None = not measured for this build.
-# HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), profiles/r02_trunk_pmc_v2.txt
-HBM_BYTES = {"rb_fwd": (42.6e6, "profiles/r02_trunk_pmc_v2.txt"), "rb_dgrad": (67.3e6, "profiles/r02_trunk_pmc_v2.txt"),
-             "rb_wgrad_pair": (109.2e6, "profiles/r02_trunk_pmc_v2.txt")}
+# HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), profiles/r03_trunk_pmc.txt
+HBM_BYTES = {"rb_fwd": (42.6e6, "profiles/r03_trunk_pmc.txt"), "rb_dgrad": (67.3e6, "profiles/r03_trunk_pmc.txt"),
+             "rb_wgrad_pair": (109.2e6, "profiles/r03_trunk_pmc.txt")}
 
 
 def algorithmic_bytes(label, batch, hw, C=256, taps=9):

@@ -11,9 +11,9 @@ export GS_SIDE_STREAM=0 GS_STEP_GRAPH=0
 run() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$out/$name.log" 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary > "$out/$name.log" 2>&1
   local db=$(find /tmp/pmc_$name -name "*.db" | head -1)
-  for k in "gconv_kernel<288" hwgrad_wide hconvw_kernel hconvt_kernel hstrip_kernel inorm_bwd_apply_cg inorm_stats_act; do
+  for k in "gconv_kernel<288" hwgrad_wide hconvw_kernel hconvt_kernel hstrip_kernel hwgrad_ft inorm_bwd_apply_cg inorm_stats_act; do
     python tools/pmc_summary.py "$db" "$k"
   done > "$out/$name.txt" 2>> "$out/$name.log"
 }
