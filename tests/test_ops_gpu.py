@@ -135,28 +135,34 @@ def test_gconv_forward_stats(hip_ops, case):
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0].k == 5 and c[0].dims == 3] +
                          [(ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 20, 8, 40)], ids=_ids)
 def test_halo_resident_narrow_kernel_box_forms(hip_ops, case):
-    """hconv.hip takes volumes at least 8 deep as 8 x 8 x 8 boxes on 8 waves (option hconv_box8, default) and everything else
-    as 4 x 8 x 8 boxes on 4 waves: both forms against the oracle, with ragged boxes on every axis"""
+    """hconv.hip's three forms of a narrow volume layer against the oracle, ragged boxes on every axis: 4 x 8 x 8 boxes on 4
+    waves, 8 x 8 x 8 boxes on 8 waves (option hconv_box8; 16 output channels, depth >= 8), and the persistent form with the
+    weight block resident in LDS (option hconv_persist = smallest number of boxes it takes; 16 output channels, one channel
+    chunk) — forced here onto grids far below its default threshold, i.e. also with fewer boxes than CUs"""
     spec, N, sizes = case[0], case[1], case[2:]
     low, master, bias, fpack, dpack = make_layer(spec, sizes, 1)
     g = torch.Generator().manual_seed(2)
     xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
     xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
     y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N, act="relu")
-    default = hip_ops.get_option("hconv_box8")
+    defaults = {o: hip_ops.get_option(o) for o in ("hconv_box8", "hconv_persist")}
     try:
-        slots = []
-        for on in (0, 1):
-            hip_ops.set_option("hconv_box8", on)
-            slots.append(hip_ops.stat_slots(low.fwd[0], N))
+        slots = {}
+        for form, (box8, persist) in {"4x8x8": (0, 0), "8x8x8": (1, 0), "persistent": (0, 1)}.items():
+            hip_ops.set_option("hconv_box8", box8)
+            hip_ops.set_option("hconv_persist", persist)
+            slots[form] = hip_ops.stat_slots(low.fwd[0], N)
             y_hip, mr_hip = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N, act="relu")
             torch.cuda.synchronize()
-            close_bf16(y_hip, y_ref, f"conv output (box8={on})")
-            close_f32(mr_hip, mr_ref, f"mean / rstd (box8={on})", rel=1e-3)
+            close_bf16(y_hip, y_ref, f"conv output ({form})")
+            close_f32(mr_hip, mr_ref, f"mean / rstd ({form})", rel=1e-3)
         if sizes[0] >= 8 and spec.cout <= 16:
-            assert slots[1] < slots[0], slots          # the 8-deep boxes were really taken
+            assert slots["8x8x8"] < slots["4x8x8"], slots          # the 8-deep boxes were really taken
+        if spec.cout <= 16 and spec.cin <= 16:
+            assert slots["persistent"] == 8 * slots["4x8x8"], slots   # one slot per (box, wave): the persistent form ran
     finally:
-        hip_ops.set_option("hconv_box8", default)
+        for o, v in defaults.items():
+            hip_ops.set_option(o, v)
 
 
 @pytest.mark.parametrize("form", [1, 100], ids=["8-waves", "8+4-loader-waves"])
