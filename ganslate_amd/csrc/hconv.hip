@@ -598,14 +598,11 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
       GS_CHECK_HIP(hipGetDevice(&dev));
       GS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
       cus = prop.multiProcessorCount;
-      GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvp_kernel<8, 16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvp_kernel<16, 32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int grid = (int)(blocks < cus ? blocks : cus);
-    if (h.CC == 8) hipLaunchKernelGGL((hconvp_kernel<8, 16>), dim3(grid), dim3(512), h.lds, st, k, h.wpitch, (int)blocks);
-    else hipLaunchKernelGGL((hconvp_kernel<16, 32>), dim3(grid), dim3(512), h.lds, st, k, h.wpitch, (int)blocks);
+    hipLaunchKernelGGL((hconvp_kernel<16, 32>), dim3(grid), dim3(512), h.lds, st, k, h.wpitch, (int)blocks);
     GS_CHECK_HIP(hipGetLastError());
     return 0;
   }

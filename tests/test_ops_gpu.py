@@ -137,8 +137,7 @@ def test_gconv_forward_stats(hip_ops, case):
 def test_halo_resident_narrow_kernel_box_forms(hip_ops, case):
     """hconv.hip's three forms of a narrow volume layer against the oracle, ragged boxes on every axis: 4 x 8 x 8 boxes on 4
     waves, 8 x 8 x 8 boxes on 8 waves (option hconv_box8; 16 output channels, depth >= 8), and the persistent form with the
-    weight block resident in LDS (option hconv_persist = smallest number of boxes it takes; 16 output channels, one channel
-    chunk) — forced here onto grids far below its default threshold, i.e. also with fewer boxes than CUs"""
+    weight block resident in LDS (option hconv_persist = smallest number of boxes it takes, default off; 16 -> 16 channels, k5) — forced here onto grids far below its default threshold, i.e. also with fewer boxes than CUs"""
     spec, N, sizes = case[0], case[1], case[2:]
     low, master, bias, fpack, dpack = make_layer(spec, sizes, 1)
     g = torch.Generator().manual_seed(2)
@@ -158,7 +157,7 @@ def test_halo_resident_narrow_kernel_box_forms(hip_ops, case):
             close_f32(mr_hip, mr_ref, f"mean / rstd ({form})", rel=1e-3)
         if sizes[0] >= 8 and spec.cout <= 16:
             assert slots["8x8x8"] < slots["4x8x8"], slots          # the 8-deep boxes were really taken
-        if spec.cout <= 16 and spec.cin <= 16:
+        if spec.cout <= 16 and spec.cin == 16:              # (1 -> 16 measured slower on it: hconv_kernel keeps that layer)
             assert slots["persistent"] == 8 * slots["4x8x8"], slots   # one slot per (box, wave): the persistent form ran
     finally:
         for o, v in defaults.items():
