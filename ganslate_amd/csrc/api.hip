@@ -69,6 +69,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconv_box8", 1},          // hconv.hip: 8 x 8 x 8 boxes on 8 waves for volumes (4 x 8 x 8 on 4 waves otherwise)
     {"hconv_persist", 0},       // hconv.hip: smallest number of boxes the persistent resident-weight form takes (16 -> 16 channel k5 volume
                                 // layers), 0 = off (default: 191 vs 204 us alone at 128^3, but 73.4 vs 72.6 ms in the brats step)
+    {"hconvw_ring_waves", 16},  // 16 or 8 waves for the fused data gradient of the wide 3x3 layers (hconvw.hip RING)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -333,8 +333,8 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
       }
     }
     __syncthreads();
-    constexpr int LPR = CW / 8, PPI = 64 / LPR;
-    static_assert(LPR == 4, "ring epilogue: 32 channels per wave");
+    constexpr int LPR = CW / 8, PPI = 64 / LPR;            // 4 (16 waves: 32 channels per wave) or 8 (8 waves: 64) lanes per pixel
+    static_assert(LPR == 4 || LPR == 8, "ring epilogue: 32 or 64 channels per wave");
     const int sub = lane % LPR, prow = lane / LPR;
     const int co = nt * BN + wn * CW + sub * 8;
     float fa1[8], fa2[8], fa3[8], fmu[8], frs[8];
@@ -372,7 +372,11 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
     float* red3 = reinterpret_cast<float*>(smem);            // [WM][BN][3]
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      fa1[k] = row_sum_stride4(fa1[k]); fa2[k] = row_sum_stride4(fa2[k]); fa3[k] = row_sum_stride4(fa3[k]);
+      if constexpr (LPR == 4) {
+        fa1[k] = row_sum_stride4(fa1[k]); fa2[k] = row_sum_stride4(fa2[k]); fa3[k] = row_sum_stride4(fa3[k]);
+      } else {
+        fa1[k] = row_sum_stride8(fa1[k]); fa2[k] = row_sum_stride8(fa2[k]); fa3[k] = row_sum_stride8(fa3[k]);
+      }
 #pragma unroll
       for (int o = 16; o < 64; o <<= 1) {
         fa1[k] += __shfl_xor(fa1[k], o, 64);
@@ -610,10 +614,17 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   if (!configured) {
     GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 16, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 8, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
-  hipLaunchKernelGGL((hconvw_kernel<9, 16, true>), dim3((unsigned)blocks), dim3(1024), lds,
-                     static_cast<hipStream_t>(stream), k);
+  // 8 waves of 64 x 64 (209 registers x 2 waves per SIMD) against 16 waves of 64 x 32 (127 x 4, the whole register file)
+  if (gs_opt(GS_OPT_HCONVW_RING_WAVES) == 8)
+    hipLaunchKernelGGL((hconvw_kernel<9, 8, true>), dim3((unsigned)blocks), dim3(512), lds,
+                       static_cast<hipStream_t>(stream), k);
+  else
+    hipLaunchKernelGGL((hconvw_kernel<9, 16, true>), dim3((unsigned)blocks), dim3(1024), lds,
+                       static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -518,12 +518,16 @@ def test_dgrad_with_fused_norm_reduction(hip_ops, case, with_g2, act):
 @pytest.mark.parametrize("case", [(256, 8, 64, 64), (256, 16, 32, 48), (128, 48, 32, 32), (256, 2, 96, 128)],
                          ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none")])
-def test_dgrad_ring_form(hip_ops, case, with_g2, act):
-    """Unpadded (ring) form of the fused data gradient of a reflect-padded 3x3 conv (gs_gconv_ring_slots, hconvw.hip
+@pytest.mark.parametrize("waves", [16, 8])
+def test_dgrad_ring_form(hip_ops, case, with_g2, act, waves):
+    """Both wave counts of the kernel (option hconvw_ring_waves: 16 waves of 64 x 32, or 8 of 64 x 64 that leave registers
+    for another stream's workgroups on the CU). Unpadded (ring) form of the fused data gradient of a reflect-padded 3x3 conv (gs_gconv_ring_slots, hconvw.hip
     RING): the finished input gradient equals the padded-domain launch folded by the consumer (same kernel family,
     fold in fp32 before the rounding here, after it there), the oracle's restatement, and the epilogue sums drive
     gs_inorm_act_backward to the same dy. resnet2d.py:80-87 backward."""
     C, N, H, W = case
+    default_waves = hip_ops.get_option("hconvw_ring_waves")
+    hip_ops.set_option("hconvw_ring_waves", waves)
     spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
     low, master, bias, fpack, dpack = make_layer(spec, (H, W), 31)
     assert low.dgrad_ring is not None
@@ -555,6 +559,7 @@ def test_dgrad_ring_form(hip_ops, case, with_g2, act):
         sums_pad = plan[1][:N * plan[0] * 3 * C].view(N, plan[0], 3, C).sum(1)
         res[name] = (gx, dy_ring, dy_pad, sums, sums_pad, tot_pad)
     torch.cuda.synchronize()
+    hip_ops.set_option("hconvw_ring_waves", default_waves)
     close_bf16(res["hip"][0], res["ref"][0], "ring dgrad vs oracle")
     # the padded launch rounds every padded-domain pixel to bf16 before the consumer folds it: up to 4 roundings at a corner
     close_bf16(res["hip"][0], res["hip"][5].cpu() if not with_g2 else res["ref"][0], "ring dgrad vs padded launch folded")
