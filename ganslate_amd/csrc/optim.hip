@@ -4,47 +4,85 @@
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 #include "common.hpp"
 
+// One element of the update; the same expression for the scalar tail and the four lanes of a 16-byte access.
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float b1, float b2, float eps,
+                                         float bc2_sqrt, float step_size, float gscale, int zero_grad) {
+  const float gi = g * gscale;
+  const float mi = m + (gi - m) * (1.f - b1);                  // torch: exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v * b2 + (1.f - b2) * gi * gi;              // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p = p - step_size * (mi / denom);
+  m = mi;
+  v = vi;
+  if (zero_grad) g = 0.f;
+}
+
+// 28-32 bytes of HBM traffic per parameter and nothing else: 16-byte accesses, two of them per array in flight per
+// thread (dword accesses with one element per iteration ran at 1.5 TB/s: 469 us for the 57 M parameters of pix2pix's
+// U-Net, a sixth of that step). Buffers are 16-byte aligned (torch allocations); a tail of n % 4 elements and
+// unaligned views take the scalar loop.
+__device__ __forceinline__ void adam_body(float* p, float* g, float* m, float* v, long long n, float lr, float b1,
+                                          float b2, float eps, float bc1, float bc2_sqrt, float gscale, int zero_grad) {
+  const float step_size = lr / bc1;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  const bool aligned = ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) |
+                         reinterpret_cast<size_t>(v)) & 15) == 0;
+  const long long n4 = aligned ? n >> 2 : 0;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  auto upd = [&](float4& P, float4& G, float4& M, float4& V) {
+    adam_one(P.x, G.x, M.x, V.x, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+    adam_one(P.y, G.y, M.y, V.y, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+    adam_one(P.z, G.z, M.z, V.z, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+    adam_one(P.w, G.w, M.w, V.w, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+  };
+  long long i = tid;
+  for (; i + nth < n4; i += 2 * nth) {
+    const long long j = i + nth;
+    float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i];
+    float4 P1 = p4[j], G1 = g4[j], M1 = m4[j], V1 = v4[j];
+    upd(P0, G0, M0, V0);
+    upd(P1, G1, M1, V1);
+    p4[i] = P0; m4[i] = M0; v4[i] = V0;
+    p4[j] = P1; m4[j] = M1; v4[j] = V1;
+    if (zero_grad) { g4[i] = G0; g4[j] = G1; }
+  }
+  for (; i < n4; i += nth) {
+    float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i];
+    upd(P0, G0, M0, V0);
+    p4[i] = P0; m4[i] = M0; v4[i] = V0;
+    if (zero_grad) g4[i] = G0;
+  }
+  for (long long e = n4 * 4 + tid; e < n; e += nth) adam_one(p[e], g[e], m[e], v[e], b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, long long n, float lr,
                                                    float b1, float b2, float eps, float bc1, float bc2_sqrt,
                                                    float gscale, int zero_grad) {
-  const float step_size = lr / bc1;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * gscale;
-    const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;         // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
-    if (zero_grad) g[i] = 0.f;
-  }
+  adam_body(p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, zero_grad);
 }
 
 // Same update with the step-dependent scalars read from device memory: a captured hipGraph of the training step
 // replays this launch unchanged while the host refreshes hyper_dev (lr schedule, bias corrections) between replays.
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, float* g, float* m, float* v, long long n,
                                                        const float* __restrict__ hyper, float gscale, int zero_grad) {
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5];
-  const float step_size = lr / bc1;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * gscale;
-    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
-    if (zero_grad) g[i] = 0.f;
-  }
+  adam_body(p, g, m, v, n, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], gscale, zero_grad);
+}
+
+static long long adam_blocks(int64_t n) {
+  long long blocks = (n / 4 + 511) / 512;         // two 16-byte vectors per thread per pass
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  return blocks;
 }
 
 extern "C" int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev,
                                 float grad_scale, int32_t zero_grad, void* stream) {
   GS_REQUIRE(p && g && m && v && hyper_dev && n > 0, "gs_adam_step_dev: bad argument");
-  long long blocks = (n + 1023) / 1024;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m,
-                     v, (long long)n, hyper_dev, grad_scale, zero_grad);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)adam_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
+                     m, v, (long long)n, hyper_dev, grad_scale, zero_grad);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -87,9 +125,7 @@ extern "C" int gs_pool_query(void* pool, const void* images, void* out, const in
 extern "C" int gs_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_host,
                             float grad_scale, int32_t zero_grad, void* stream) {
   GS_REQUIRE(p && g && m && v && hyper_host && n > 0, "gs_adam_step: bad argument");
-  long long blocks = (n + 1023) / 1024;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)adam_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
                      (long long)n, hyper_host[0], hyper_host[1], hyper_host[2], hyper_host[3], hyper_host[4],
                      hyper_host[5], grad_scale, zero_grad);
   GS_CHECK_HIP(hipGetLastError());
@@ -170,6 +206,119 @@ extern "C" int gs_repack_bf16_tiled(const float* master, const int32_t* index, v
   GS_REQUIRE((reinterpret_cast<uintptr_t>(pack) & 7) == 0, "gs_repack_bf16_tiled: pack must be 8-byte aligned");
   hipLaunchKernelGGL(repack_tiled_kernel, dim3((unsigned)(kp / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), master, index, static_cast<unsigned short*>(pack), rows, kp);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- group-indexed refresh: one index per 8 pack elements ------------------------------------------------------------------
+// The element-wise kernels above read a 4-byte index per 2-byte pack element: 40 % of their HBM traffic (and 4 bytes of HBM per
+// weight, twice, for every network). In every pack the conv kernels use, 8 consecutive pack elements come from 8 consecutive
+// master elements — along k for the row-major packs (8 channels of one tap), along the ROWS for the transposed ones — or are
+// padding, so the executor (nn/native/net.py) stores one base index per group and falls back to the element-wise kernels
+// where that does not hold: a group of the row-major launch marked -2 reads its eight own indices from the element-wise
+// table (`index`, may be null when no group is marked), a group marked -3 belongs to a transposed segment and is skipped.
+__global__ __launch_bounds__(256) void repack_groups_kernel(const float* __restrict__ master, const int* __restrict__ gindex,
+                                                            const int* __restrict__ index, uint4* __restrict__ pack,
+                                                            long long n8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const int b = gindex[i];
+    if (b == -3) continue;         // belongs to a transposed segment: written by the tiled launch
+    uint4 o = {0u, 0u, 0u, 0u};
+    if (b == -2) {                 // an irregular group (small transposed segments merged into a run): its 8 own indices
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int id = index[i * 8 + k]; f[k] = id >= 0 ? master[id] : 0.f; }
+      o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+    } else if (b >= 0) {
+      float f[8];
+      if ((b & 3) == 0) {
+        const float4 lo = *reinterpret_cast<const float4*>(master + b), hi = *reinterpret_cast<const float4*>(master + b + 4);
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = master[b + k];
+      }
+      o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+    }
+    pack[i] = o;
+  }
+}
+
+extern "C" int gs_repack_bf16_groups(const float* master, const int32_t* gindex, const int32_t* index, void* pack,
+                                     int64_t n8, void* stream) {
+  GS_REQUIRE(master && gindex && pack && n8 > 0, "gs_repack_bf16_groups: bad argument");
+  GS_REQUIRE(((reinterpret_cast<uintptr_t>(pack) | reinterpret_cast<uintptr_t>(master)) & 15) == 0,
+             "gs_repack_bf16_groups: master and pack must be 16-byte aligned");
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(repack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+                     gindex, index, static_cast<uint4*>(pack), (long long)n8);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// transposed segments [rows][kp], each with a group index [rows / 8][kp]: pack[8 G + j][k] = master[gindex[G][k] + j]. ALL such
+// segments of a pack in one launch (a network has dozens of them, most far too small for a launch of their own): seg[i] =
+// {pack offset (elements), gindex offset, rows, kp, first tile}; a workgroup finds its segment by its tile number and owns
+// 64 rows x 64 k of it: 8 x 64 group indices, 4096 master elements read as 8-element runs (two 16-byte loads), transposed
+// through LDS.
+__global__ __launch_bounds__(256) void repack_tiled_groups_kernel(const float* __restrict__ master,
+                                                                  const int* __restrict__ gindex,
+                                                                  unsigned short* __restrict__ pack_base,
+                                                                  const long long* __restrict__ seg, int nseg) {
+  __shared__ unsigned short sval[64][68];
+  int lo = 0, hi = nseg - 1;                             // last segment whose first tile is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid * 5 + 4] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* sg = seg + lo * 5;
+  const int rows = (int)sg[2], kp = (int)sg[3];
+  const int tile = (int)((long long)blockIdx.x - sg[4]), tx = kp >> 6;
+  const int r0 = (tile / tx) * 64, k0 = (tile % tx) * 64;
+  const int* gi = gindex + sg[1];
+  unsigned short* pack = pack_base + sg[0];
+  for (int e = threadIdx.x; e < 512; e += 256) {       // (row group, k): 8 x 64
+    const int G = e >> 6, k = e & 63;
+    const int rg = (r0 >> 3) + G;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    if (rg * 8 < rows) {
+      const int b = gi[(size_t)rg * kp + k0 + k];
+      if (b >= 0) {
+        if ((b & 3) == 0) {
+          const float4 lo4 = *reinterpret_cast<const float4*>(master + b), hi4 = *reinterpret_cast<const float4*>(master + b + 4);
+          f[0] = lo4.x; f[1] = lo4.y; f[2] = lo4.z; f[3] = lo4.w; f[4] = hi4.x; f[5] = hi4.y; f[6] = hi4.z; f[7] = hi4.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = master[b + j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sval[G * 8 + j][k] = f2bf(f[j]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += 256) {      // 4 elements (8 bytes) per thread
+    const int r = e >> 4, k4 = (e & 15) * 4;
+    if (r0 + r < rows) {
+      uint2 o;
+      o.x = (unsigned)sval[r][k4] | ((unsigned)sval[r][k4 + 1] << 16);
+      o.y = (unsigned)sval[r][k4 + 2] | ((unsigned)sval[r][k4 + 3] << 16);
+      *reinterpret_cast<uint2*>(pack + (size_t)(r0 + r) * kp + k0 + k4) = o;
+    }
+  }
+}
+
+extern "C" int gs_repack_bf16_tiled_groups(const float* master, const int32_t* gindex, void* pack, const int64_t* seg_dev,
+                                           int32_t nseg, int64_t tiles, void* stream) {
+  GS_REQUIRE(master && gindex && pack && seg_dev && nseg > 0 && tiles > 0 && tiles < (1LL << 31),
+             "gs_repack_bf16_tiled_groups: bad argument");
+  GS_REQUIRE(((reinterpret_cast<uintptr_t>(pack) & 7) | (reinterpret_cast<uintptr_t>(master) & 15)) == 0,
+             "gs_repack_bf16_tiled_groups: pack must be 8-byte, master 16-byte aligned");
+  hipLaunchKernelGGL(repack_tiled_groups_kernel, dim3((unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), master,
+                     gindex, static_cast<unsigned short*>(pack), reinterpret_cast<const long long*>(seg_dev), nseg);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

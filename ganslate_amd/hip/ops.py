@@ -562,6 +562,17 @@ class HipOps:
         L.check(self.lib.gs_repack_bf16(_ptr(master), _ptr(index), _ptr(pack), pack.numel(), _stream()),
                 "gs_repack_bf16")
 
+    def repack_groups(self, master, gindex, pack, index=None):
+        """pack[8 g + j] = bf16(master[gindex[g] + j]); gindex[g] = -1: zeros, -2: the group's own entries of `index`"""
+        L.check(self.lib.gs_repack_bf16_groups(_ptr(master), _ptr(gindex), _ptr(index) if index is not None else None,
+                                               _ptr(pack), gindex.numel(), _stream()), "gs_repack_bf16_groups")
+
+    def repack_tiled_groups(self, master, gindex, pack, seg, tiles):
+        """all transposed segments of a pack: seg int64 [nseg, 5] = (pack offset, gindex offset, rows, kp, first tile) on the
+        device; pack[off + (8 G + j) * kp + k] = bf16(master[gindex[goff + G * kp + k] + j])"""
+        L.check(self.lib.gs_repack_bf16_tiled_groups(_ptr(master), _ptr(gindex), _ptr(pack), _ptr(seg), seg.shape[0],
+                                                     int(tiles), _stream()), "gs_repack_bf16_tiled_groups")
+
     def repack_tiled(self, master, index, pack, rows, kp):
         """one [rows][kp] pack segment whose master indices run along the rows (see NativeNet._get_packs)"""
         L.check(self.lib.gs_repack_bf16_tiled(_ptr(master), _ptr(index), _ptr(pack), rows, kp, _stream()),

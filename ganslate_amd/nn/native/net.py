@@ -308,31 +308,41 @@ class NativeNet:
         return self._low_cache[key]
 
     @staticmethod
-    def _repack_plan(lows, idx, offs, which, min_tiled=1 << 20):
-        """[(start, numel, rows, kp)] covering a network's pack: rows > 0 marks a [rows][kp] class segment whose master
-        indices are consecutive along the ROWS (the transposed packs: data-gradient pack of a conv, forward pack of a
-        transposed conv) and that is large enough for the tiled refresh to pay; everything else is merged into runs for
-        the element-wise kernel (rows = 0)."""
-        plan, run_start, pos = [], 0, 0
+    def _repack_plan(lows, idx, offs, which):
+        """How a network's pack is refreshed from the master: two launches, both with ONE index per 8 pack elements (the
+        element-wise refresh reads a 4-byte index per 2-byte element: 40 % of its bytes).
+          groups  int32 [pack elements / 8], along k over the whole pack: base index of 8 consecutive master elements;
+                  -1 = padding (zeros), -2 = an irregular group (reads its own entries of the element-wise table; does not
+                  occur in the reference's layer types), -3 = part of a transposed segment;
+          seg     int64 [nseg, 5] = (pack offset, offset into tgroups, rows, Kp, first tile) of every class segment whose
+                  master indices are consecutive along the ROWS (the transposed packs: data-gradient pack of a conv, forward
+                  pack of a transposed conv), all refreshed by one tiled launch; tgroups int32 = their [rows / 8][Kp] bases.
+        Returns dict(groups, seg, tgroups, tiles, need_index)."""
+        total = sum(x.size for x in idx)
+        assert total % 8 == 0
+        allidx = np.concatenate([x.reshape(-1) for x in idx]) if idx else np.zeros(0, np.int64)
+        t = allidx.reshape(-1, 8)
+        groups = t[:, 0].copy()
+        want = np.where(groups[:, None] >= 0, groups[:, None] + np.arange(8)[None, :], -1)
+        groups[(t != want).any(1)] = -2
+        seg, tg, tiles, goff = [], [], 0, 0
         for i, lw in enumerate(lows):
-            flat = idx[i].reshape(-1)
             for g in getattr(lw, which):
-                start, n = g.pack_offset, g.w_rows * g.Kp
-                tiled = False
-                if n >= min_tiled and g.w_rows >= 64:
-                    t = flat[start:start + n].reshape(g.w_rows, g.Kp)[:64, :256]
-                    ok = (t[1:] >= 0) & (t[:-1] >= 0)
-                    tiled = bool(ok.any()) and float(((t[1:] == t[:-1] + 1) & ok).sum()) > 0.9 * float(ok.sum())
-                if tiled:
-                    a = offs[i] + start
-                    if a > run_start:
-                        plan.append((run_start, a - run_start, 0, 0))
-                    plan.append((a, n, g.w_rows, g.Kp))
-                    run_start = a + n
-            pos = offs[i] + flat.size
-        if pos > run_start:
-            plan.append((run_start, pos - run_start, 0, 0))
-        return plan
+                start, n = offs[i] + g.pack_offset, g.w_rows * g.Kp
+                if g.w_rows % 8 or start % 8 or not (groups[start // 8:(start + n) // 8] == -2).any():
+                    continue
+                tt = allidx[start:start + n].reshape(g.w_rows // 8, 8, g.Kp)
+                base = tt[:, 0, :]
+                if not np.array_equal(tt, np.where(base[:, None, :] >= 0, base[:, None, :] + np.arange(8)[None, :, None], -1)):
+                    continue
+                seg.append((start, goff, g.w_rows, g.Kp, tiles))
+                tg.append(base.reshape(-1))
+                goff += base.size
+                tiles += (g.w_rows + 63) // 64 * (g.Kp // 64)
+                groups[start // 8:(start + n) // 8] = -3
+        return {"groups": groups.astype(np.int32), "seg": np.asarray(seg, np.int64).reshape(-1, 5),
+                "tgroups": np.concatenate(tg).astype(np.int32) if tg else np.zeros(0, np.int32), "tiles": tiles,
+                "need_index": bool((groups == -2).any())}
 
     def _get_packs(self, *sizes):
         """bf16 packs are size-independent except for the parity-class split, which only depends on the spec;
@@ -348,11 +358,16 @@ class NativeNet:
                 di = lw.dgrad_index.astype(np.int64); di[di >= 0] += self.w_off[i]
                 f_idx.append(fi); d_idx.append(di); f_off.append(fo); d_off.append(do)
                 fo += fi.size; do += di.size
+            def to_dev(plan, idx):
+                d = {k: torch.from_numpy(plan[k]).to(self.device) for k in ("groups", "seg", "tgroups")}
+                d["tiles"] = plan["tiles"]
+                # the element-wise table is only uploaded when some group needs it (4 bytes per weight otherwise, twice)
+                d["index"] = (torch.from_numpy(np.concatenate(idx).astype(np.int32)).to(self.device)
+                              if plan["need_index"] else None)
+                return d
             pk = {
-                "f_plan": self._repack_plan(lows, f_idx, f_off, "fwd"),
-                "d_plan": self._repack_plan(lows, d_idx, d_off, "dgrad"),
-                "f_index": torch.from_numpy(np.concatenate(f_idx).astype(np.int32)).to(self.device),
-                "d_index": torch.from_numpy(np.concatenate(d_idx).astype(np.int32)).to(self.device),
+                "f_plan": to_dev(self._repack_plan(lows, f_idx, f_off, "fwd"), f_idx),
+                "d_plan": to_dev(self._repack_plan(lows, d_idx, d_off, "dgrad"), d_idx),
                 "f_off": f_off, "d_off": d_off,
                 # + 64 elements of slack so the last row's padded K-steps stay inside the allocation
                 "fpack": torch.zeros(fo + 64, dtype=self.ops.act_dtype, device=self.device),
@@ -367,12 +382,11 @@ class NativeNet:
         if not pk["fresh"]:
             m = self.master.detach()
             for which in ("f", "d"):
-                index, pack = pk[which + "_index"], pk[which + "pack"]
-                for start, n, rows, kp in pk[which + "_plan"]:
-                    if rows:         # a large transposed segment: tiled through LDS
-                        self.ops.repack_tiled(m, index[start:start + n], pack[start:start + n], rows, kp)
-                    else:
-                        self.ops.repack(m, index[start:start + n], pack[start:start + n])
+                plan, pack = pk[which + "_plan"], pk[which + "pack"]
+                n8 = plan["groups"].numel()
+                self.ops.repack_groups(m, plan["groups"], pack[:n8 * 8], plan["index"])
+                if plan["tiles"]:
+                    self.ops.repack_tiled_groups(m, plan["tgroups"], pack, plan["seg"], plan["tiles"])
             pk["fresh"] = True
         return pk
 

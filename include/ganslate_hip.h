@@ -435,6 +435,20 @@ int gs_repack_bf16(const float* master, const int32_t* index, void* pack, int64_
 /* Same refresh for one [rows][kp] pack segment whose master indices run along the rows (transposed packs): 64 x 64
  * tiles through LDS so that both the master reads and the pack writes are contiguous. Results are identical. */
 int gs_repack_bf16_tiled(const float* master, const int32_t* index, void* pack, int32_t rows, int32_t kp, void* stream);
+/* Group-indexed forms of the two refreshes (round 3): one base index per 8 pack elements whose sources are 8 consecutive
+ * master elements. Same call sites as gs_repack_bf16 (optimizer.step() -> weights the next forward reads,
+ * cyclegan.py:107,123); an eighth of the index traffic; two launches per pack of a network.
+ * gs_repack_bf16_groups, along k over the WHOLE pack: pack[8 g + j] = master[gindex[g] + j]; gindex[g] = -1 -> zeros,
+ *   -2 -> the group's eight own entries of the element-wise table `index` (null if no group is marked), -3 -> not written
+ *   (the group belongs to a transposed segment); n8 groups.
+ * gs_repack_bf16_tiled_groups, along the rows of ALL transposed segments of the pack: seg_dev[5 i ..] = {pack offset in
+ *   elements, gindex offset, rows (multiple of 8), kp (multiple of 64), first tile}, tiles = sum of ceil(rows / 64) * kp / 64;
+ *   pack[off + (8 G + j) * kp + k] = master[gindex[goff + G * kp + k] + j], negative -> zeros.
+ * master 16-byte aligned, pack 16-byte (8-byte for the segments) aligned. */
+int gs_repack_bf16_groups(const float* master, const int32_t* gindex, const int32_t* index, void* pack, int64_t n8,
+                          void* stream);
+int gs_repack_bf16_tiled_groups(const float* master, const int32_t* gindex, void* pack, const int64_t* seg_dev,
+                                int32_t nseg, int64_t tiles, void* stream);
 
 #ifdef __cplusplus
 }

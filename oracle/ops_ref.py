@@ -654,6 +654,25 @@ class RefOps:
         """same refresh for one [rows][kp] segment (the HIP side only changes the access order)"""
         self.repack(master, index, pack)
 
+    def repack_groups(self, master, gindex, pack, index=None):
+        """one base index per 8 pack elements: pack[8 g + j] = master[gindex[g] + j]; -1: zeros, -2: the group's own
+        entries of the element-wise table, -3: left alone (written by repack_tiled_groups)"""
+        b = gindex.long()[:, None]
+        idx = torch.where(b >= 0, b + torch.arange(8)[None, :], torch.full((len(gindex), 8), -1))
+        if index is not None:
+            idx = torch.where(b == -2, index.long().reshape(-1, 8), idx)
+        vals = master.reshape(-1)[idx.clamp_min(0)]
+        vals = torch.where(idx >= 0, vals, torch.zeros_like(vals)).to(pack.dtype)
+        keep = (gindex != -3)
+        pack.view(-1, 8)[keep] = vals[keep]
+
+    def repack_tiled_groups(self, master, gindex, pack, seg, tiles):
+        """all transposed segments of a pack (see HipOps.repack_tiled_groups)"""
+        for off, goff, rows, kp, _ in seg.tolist():
+            g = gindex[goff:goff + rows // 8 * kp].long().reshape(rows // 8, 1, kp)
+            idx = torch.where(g >= 0, g + torch.arange(8).reshape(1, 8, 1), torch.full((rows // 8, 8, kp), -1))
+            self.repack(master, idx.reshape(-1), pack[off:off + rows * kp])
+
 
 def attention_reference(x, p):
     """SelfAttentionBlock.forward (attention.py:26-47) restated on a channels-last tensor x [B, ..., C]: the 1x1x1 convs are

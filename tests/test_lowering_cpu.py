@@ -169,3 +169,40 @@ def test_master_roundtrip():
     for spec in SPECS + SPECS_3D:
         w = torch.randn(spec.torch_weight_shape())
         assert torch.equal(spec.torch_from_master(spec.master_from_torch(w)), w)
+
+
+def test_every_pack_of_the_headline_networks_has_a_group_index():
+    """NativeNet._repack_plan for the layer types of Resnet2D-9 / PatchGAN2D / Unet2D: every group of 8 pack elements is either
+    8 consecutive master elements along k, padding, or part of a transposed segment that is regular along its rows — no group
+    needs the element-wise table — and expanding both group indices gives back the element-wise tables"""
+    import numpy as np
+    from ganslate_amd.nn.native.net import NativeNet
+    from ganslate_amd.nn.native.spec import ConvSpec, lower
+    specs = [ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), ConvSpec("conv", 64, 128, 3, 2, 1),
+             ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), ConvSpec("convT", 256, 128, 3, 2, 1, 1),
+             ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), ConvSpec("conv", 6, 64, 4, 2, 1),
+             ConvSpec("conv", 256, 512, 4, 1, 1), ConvSpec("convT", 1024, 512, 4, 2, 1),
+             ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), ConvSpec("conv", 1, 16, 5, 1, 2, dims=3)]
+    lows = [lower(s, *((64, 64) if s.dims == 2 else (8, 8, 8))) for s in specs]
+    w_off = np.cumsum([0] + [s.master_numel + 24 for s in specs])        # odd gaps: biases / slopes between the weights
+    for which in ("fwd", "dgrad"):
+        idx, offs, o = [], [], 0
+        for i, lw in enumerate(lows):
+            t = getattr(lw, which + "_index").astype(np.int64)
+            t[t >= 0] += w_off[i]
+            idx.append(t); offs.append(o); o += t.size
+        plan = NativeNet._repack_plan(lows, idx, offs, which)
+        flat = np.concatenate(idx)
+        assert not plan["need_index"] and len(plan["seg"]) >= 4, (which, plan["need_index"], len(plan["seg"]))
+        g = plan["groups"].astype(np.int64)[:, None]
+        full = np.where(g >= 0, g + np.arange(8)[None, :], -1)
+        full[plan["groups"] == -3] = -7
+        full = full.reshape(-1)
+        tiles = 0
+        for off, goff, rows, kp, first in plan["seg"].tolist():
+            assert first == tiles and (full[off:off + rows * kp] == -7).all()
+            tg = plan["tgroups"][goff:goff + rows // 8 * kp].astype(np.int64).reshape(rows // 8, 1, kp)
+            full[off:off + rows * kp] = np.where(tg >= 0, tg + np.arange(8).reshape(1, 8, 1), -1).reshape(-1)
+            tiles += (rows + 63) // 64 * (kp // 64)
+        assert tiles == plan["tiles"]
+        assert np.array_equal(full, flat)

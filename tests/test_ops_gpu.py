@@ -952,6 +952,76 @@ def test_adam_and_repack(hip_ops):
     assert torch.equal(outs[1][4].cpu(), outs[0][4]), "repack must be bit-exact"
 
 
+def test_group_indexed_repack_equals_the_elementwise_refresh(hip_ops):
+    """gs_repack_bf16_groups / gs_repack_bf16_tiled_groups (one base index per 8 pack elements; two launches per pack) against
+    gs_repack_bf16 on the expanded index, bit for bit: aligned and unaligned bases, padding groups, irregular groups (-2),
+    skipped groups (-3) filled by three transposed segments of one tiled launch (one of them with a ragged last row tile)"""
+    g = torch.Generator().manual_seed(5)
+    dev = hip_ops.device
+    master = torch.randn(300_000, generator=g)
+    ar8 = torch.arange(8, dtype=torch.int32)
+    segs = [(8 * 1000, 200, 192), (8 * 9000, 64, 64), (8 * 12000, 8, 128)]        # (pack offset, rows, kp)
+    n8 = 20_001
+    base = torch.randint(0, master.numel() - 8, (n8,), generator=g, dtype=torch.int32)
+    base[::3] = (base[::3] // 4) * 4                       # 16-byte aligned bases take the vector loads
+    base[5::7] = -1
+    base[11::13] = -2
+    full = torch.where(base[:, None] >= 0, base[:, None] + ar8[None, :], torch.full((n8, 8), -1, dtype=torch.int32))
+    rnd = torch.randint(-1, master.numel(), (n8, 8), generator=g, dtype=torch.int32)
+    full = torch.where(base[:, None] == -2, rnd, full)
+    seg_rows, tgroups, goff, tiles = [], [], 0, 0
+    for off, rows, kp in segs:
+        tb = torch.randint(0, master.numel() - 8, (rows // 8, kp), generator=g, dtype=torch.int32)
+        tb[1::2] = (tb[1::2] // 4) * 4
+        tb[:, kp - 12:] = -1                               # K padding
+        ft = torch.where(tb[:, None, :] >= 0, tb[:, None, :] + ar8[None, :, None],
+                         torch.full((rows // 8, 8, kp), -1, dtype=torch.int32)).reshape(-1)
+        full.view(-1)[off:off + rows * kp] = ft
+        base[off // 8:(off + rows * kp) // 8] = -3
+        seg_rows.append((off, goff, rows, kp, tiles))
+        tgroups.append(tb.reshape(-1))
+        goff += tb.numel()
+        tiles += (rows + 63) // 64 * (kp // 64)
+    full = full.reshape(-1)
+    seg = torch.tensor(seg_rows, dtype=torch.int64)
+    tgroups = torch.cat(tgroups)
+    want = torch.empty(n8 * 8, dtype=torch.bfloat16, device=dev)
+    hip_ops.repack(master.to(dev), full.to(dev), want)
+    for ops, d in ((hip_ops, dev), (RefOps(), "cpu")):
+        got = torch.full((n8 * 8,), float("nan"), dtype=torch.bfloat16, device=d)
+        ops.repack_groups(master.to(d), base.to(d), got, full.to(d))
+        assert got.view(-1, 8)[(base == -3).to(d)].isnan().all(), "groups of the transposed segments are not touched"
+        ops.repack_tiled_groups(master.to(d), tgroups.to(d), got, seg.to(d), tiles)
+        assert torch.equal(got.cpu().view(torch.int16), want.cpu().view(torch.int16)), type(ops).__name__
+
+
+@pytest.mark.parametrize("n,offset", [(1 << 20, 0), (300_001, 0), (70_003, 1), (5, 0), (3, 3)])
+def test_adam_vector_paths_equal_the_oracle(hip_ops, n, offset):
+    """gs_adam_step / gs_adam_step_dev use 16-byte accesses on 16-byte aligned buffers (two vectors per thread per pass, a
+    one-vector pass, a scalar tail) and the scalar loop on unaligned views: every path against the oracle's expression,
+    element for element, and the two entry points against each other bit for bit"""
+    g = torch.Generator().manual_seed(n)
+    tot = n + offset
+    p0, g0 = torch.randn(tot, generator=g), torch.randn(tot, generator=g) * 1e-2
+    m0, v0 = torch.randn(tot, generator=g) * 1e-3, torch.rand(tot, generator=g) * 1e-4
+    ref = RefOps()
+    want = [t.clone()[offset:] for t in (p0, g0, m0, v0)]
+    ref.adam_step(*want, 2e-4, 0.5, 0.999, 1e-8, 7, grad_scale=0.25, zero_grad=False)
+    dev = hip_ops.device
+    got = [t.clone().to(dev) for t in (p0, g0, m0, v0)]
+    hip_ops.adam_step(*[t[offset:] for t in got], 2e-4, 0.5, 0.999, 1e-8, 7, grad_scale=0.25, zero_grad=False)
+    got2 = [t.clone().to(dev) for t in (p0, g0, m0, v0)]
+    hyper = torch.tensor([2e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** 7, (1 - 0.999 ** 7) ** 0.5], device=dev)
+    hip_ops.adam_step_dev(*[t[offset:] for t in got2], hyper, grad_scale=0.25, zero_grad=True)
+    torch.cuda.synchronize()
+    for k, name in enumerate(("p", "g", "m", "v")):
+        assert torch.equal(got[k][:offset].cpu(), (p0, g0, m0, v0)[k][:offset]), "elements in front of the view"
+        close_f32(got[k][offset:], want[k], name, rel=1e-6)
+        if name != "g":
+            assert torch.equal(got2[k], got[k]), f"{name}: device-hyper entry point"
+    assert got2[1][offset:].abs().max().item() == 0.0 and torch.equal(got[1].cpu(), g0)
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 12, 64), (1, 16, 16, 256), (2, 5, 7, 8)])
 @pytest.mark.parametrize("norm", [True, False])
 @pytest.mark.parametrize("drop_p", [0.0, 0.5])
@@ -991,9 +1061,12 @@ def test_norm_ex_dual_activation_slices_dropout(hip_ops, shape, norm, drop_p):
         assert 0.4 < kept < 0.6, kept
 
 
-def test_tiled_repack_matches_elementwise(hip_ops):
-    """NativeNet refreshes large transposed pack segments (data-gradient pack of a conv, forward pack of a transposed
-    conv) with gs_repack_bf16_tiled: the packs must be bit-identical to the element-wise refresh of the whole pack"""
+def test_network_pack_refresh_matches_elementwise(hip_ops):
+    """NativeNet refreshes a pack with two group-indexed launches (gs_repack_bf16_groups over the whole pack,
+    gs_repack_bf16_tiled_groups over its transposed segments: data-gradient packs of convs, forward packs of transposed
+    convs): the packs must be bit-identical to the element-wise refresh of the whole pack from the lowering's own tables,
+    and no element-wise table is uploaded"""
+    import numpy as np
     from ganslate_amd.nn.native.net import NativeNet, Node
     nodes = [Node(ConvSpec("conv", 8, 512, 4, 2, 1), norm=True, act="lrelu", name="a"),
              Node(ConvSpec("conv", 512, 512, 4, 2, 1), norm=True, act="relu", name="b"),
@@ -1005,15 +1078,19 @@ def test_tiled_repack_matches_elementwise(hip_ops):
     x = torch.zeros(1, 8, 16, 16, device=hip_ops.device)
     net.refresh_packs(x)
     pk = net._packs[(16, 16)]
-    assert any(rows for _, _, rows, _ in pk["f_plan"]) and any(rows for _, _, rows, _ in pk["d_plan"])
-    for which in ("f", "d"):
+    lows = net._lowered(16, 16)
+    for which, name in (("f", "fwd_index"), ("d", "dgrad_index")):
         plan = pk[which + "_plan"]
-        n = pk[which + "_index"].numel()
-        assert plan[0][0] == 0 and plan[-1][0] + plan[-1][1] == n
-        assert all(a[0] + a[1] == b[0] for a, b in zip(plan, plan[1:]))          # contiguous cover
-        ref = torch.empty(n, dtype=torch.bfloat16, device=hip_ops.device)
-        hip_ops.repack(net.master.detach(), pk[which + "_index"], ref)
-        assert torch.equal(ref, pk[which + "pack"][:n]), which
+        assert plan["tiles"] > 0 and plan["seg"].shape[0] >= 2 and plan["index"] is None, which
+        idx = []
+        for i, lw in enumerate(lows):
+            t = getattr(lw, name).astype(np.int64)
+            t[t >= 0] += net.w_off[i]
+            idx.append(t.reshape(-1))
+        full = torch.from_numpy(np.concatenate(idx).astype(np.int32)).to(hip_ops.device)
+        ref = torch.empty(full.numel(), dtype=torch.bfloat16, device=hip_ops.device)
+        hip_ops.repack(net.master.detach(), full, ref)
+        assert torch.equal(ref, pk[which + "pack"][:full.numel()]), which
 
 
 @pytest.mark.parametrize("case", [c for c in WGRAD_PAIR_CASES] + [
