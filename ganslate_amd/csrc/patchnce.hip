@@ -21,6 +21,7 @@
 
 namespace {
 constexpr int NCE_MAX_LEVELS = 8;
+constexpr int NCE_RSPLIT = 8;             // most row ranges of the parameter-gradient launch
 constexpr int TM = 64;                    // rows per tile
 constexpr int TN = 256;                   // columns per tile (= nc, = patches per image)
 constexpr int AP = (TN + 8) * 2;          // pitch (bytes) of a [64][256] bf16 operand in LDS
@@ -45,6 +46,8 @@ struct NceK {
   unsigned short* dh;   // [L*R][nc] bf16
   float* loss_part;     // [L][B][P/64] partial sums of the per-row losses
   const float* gscale;  // device scalar: upstream gradient of the summed loss
+  float* wpart;         // parameter-gradient partial sums [L][2][RS][nc * TN + nc] (row splits > 1)
+  int rsplit;           // row splits of the parameter-gradient launch
   int L, R, B, P, nc;
   float inv_T, coef;    // 1 / nce_T ; lambda_nce / (L * R): weight of one row's loss in the returned scalar
   long long side_stride;  // L*R*nc
@@ -59,15 +62,32 @@ struct Acc { f32x4 a[4][2]; };
 template <int ROWS, int P, bool TRANS, typename T>
 __device__ __forceinline__ void stage(char* dst, const T* src, long long ld, int r0, int rows_valid, int k0, int k_valid,
                                       float scale = 1.f) {
-  for (int e = threadIdx.x; e < ROWS * 64; e += 512) {
-    int row, k;
-    if (TRANS) { row = e % ROWS; k = e / ROWS; } else { row = e >> 6; k = e & 63; }
-    float v = 0.f;
-    if (r0 + row < rows_valid && k0 + k < k_valid) {
-      const T s = TRANS ? src[(long long)(k0 + k) * ld + r0 + row] : src[(long long)(r0 + row) * ld + k0 + k];
-      if constexpr (sizeof(T) == 2) v = bf2f(s); else v = s;
+  // up to sixteen loads in flight per thread, then their LDS stores: written as one load - convert - store per element the
+  // compiler waited for every load before issuing the next (40 serialised L2 round trips per 64-row chunk; the parameter-
+  // gradient kernel, which walks 32 such chunks on 40 workgroups, took 489 us for 2.7 GFLOP)
+  constexpr int PER = ROWS * 64 / 512, UN = PER < 16 ? PER : 16;
+  static_assert(PER % UN == 0, "stage: rows per tile");
+#pragma unroll 1
+  for (int b = 0; b < PER; b += UN) {
+    float v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int e = threadIdx.x + (b + u) * 512;
+      int row, k;
+      if (TRANS) { row = e % ROWS; k = e / ROWS; } else { row = e >> 6; k = e & 63; }
+      v[u] = 0.f;
+      if (r0 + row < rows_valid && k0 + k < k_valid) {
+        const T s = TRANS ? src[(long long)(k0 + k) * ld + r0 + row] : src[(long long)(r0 + row) * ld + k0 + k];
+        if constexpr (sizeof(T) == 2) v[u] = bf2f(s); else v[u] = s;
+      }
     }
-    *reinterpret_cast<unsigned short*>(dst + row * P + k * 2) = f2bf(v * scale);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int e = threadIdx.x + (b + u) * 512;
+      int row, k;
+      if (TRANS) { row = e % ROWS; k = e / ROWS; } else { row = e >> 6; k = e & 63; }
+      *reinterpret_cast<unsigned short*>(dst + row * P + k * 2) = f2bf(v[u] * scale);
+    }
   }
 }
 
@@ -440,15 +460,17 @@ __global__ __launch_bounds__(512) void nce_mlp_bwd_kernel(const NceK p) {
 }
 
 // ---- parameter gradients: out[m][n] += sum_r P1[r][m] P2[r][n],  bias[m] += sum_r P1[r][m] ----------------------------------
-// which = 0: (dF x gscale, H) -> dW2, db2 ; which = 1: (dH, X) -> dW1, db1. One workgroup per 64 output rows walks ALL
-// rows r in order: no split over r, so the sums are order-fixed without a second stage.
+// which = 0: (dF x gscale, H) -> dW2, db2 ; which = 1: (dH, X) -> dW1, db1. A workgroup owns 64 output rows and one of
+// `rsplit` contiguous ranges of the rows r (walked in order). With one range it adds into the gradient itself; with more
+// (one range = 32 chunks of 64 rows on 40 workgroups took 489 us for 2.7 GFLOP) it leaves its partial sums in wpart and
+// nce_param_reduce_kernel adds the ranges in order: the sums stay order-fixed.
 __global__ __launch_bounds__(512) void nce_param_grad_kernel(const NceK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                          // P1^T chunk: [64 m][64 r] (pitch BP)
   char* Bc = smem + TM * BP;                // P2^T chunk: [256 n][64 r]
-  float* bsum = reinterpret_cast<float*>(Bc + TN * BP);      // [64]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m0 = blockIdx.x * TM, which = blockIdx.y, level = blockIdx.z;
+  const int mtiles = p.nc / TM;
+  const int m0 = (blockIdx.x % mtiles) * TM, split = blockIdx.x / mtiles, which = blockIdx.y, level = blockIdx.z;
   const NceLevel& lv = p.lv[level];
   const float gs = p.gscale ? p.gscale[0] : 1.0f;
   const unsigned short* P1 = (which == 0 ? p.df : p.dh) + lv.row_off * p.nc;
@@ -459,14 +481,22 @@ __global__ __launch_bounds__(512) void nce_param_grad_kernel(const NceK p) {
   float* gb2 = gW2 + (long long)p.nc * p.nc;
   float* out = which == 0 ? gW2 : gW1;
   float* bias = which == 0 ? gb2 : gb1;
+  int ldo = N;
+  if (p.rsplit > 1) {
+    out = p.wpart + ((long long)(level * 2 + which) * p.rsplit + split) * ((long long)p.nc * TN + p.nc);
+    bias = out + (long long)p.nc * TN;
+    ldo = TN;
+  }
+  const int chunks = (p.R + 63) / 64, per = (chunks + p.rsplit - 1) / p.rsplit;
+  const int rbeg = split * per * 64, rend = min(p.R, (split + 1) * per * 64);
   Acc acc;
   zero(acc);
   float bacc = 0.f;
-  for (int r0 = 0; r0 < p.R; r0 += 64) {
+  for (int r0 = rbeg; r0 < rend; r0 += 64) {
     __syncthreads();
-    stage<TM, BP, true>(As, P1, p.nc, m0, p.nc, r0, p.R, which == 0 ? gs : 1.0f);
-    if (which == 0) stage<TN, BP, true>(Bc, p.h + lv.row_off * p.nc, p.nc, 0, p.nc, r0, p.R);
-    else stage<TN, BP, true>(Bc, lv.xq, lv.C, 0, lv.C, r0, p.R);
+    stage<TM, BP, true>(As, P1, p.nc, m0, p.nc, r0, rend, which == 0 ? gs : 1.0f);
+    if (which == 0) stage<TN, BP, true>(Bc, p.h + lv.row_off * p.nc, p.nc, 0, p.nc, r0, rend);
+    else stage<TN, BP, true>(Bc, lv.xq, lv.C, 0, lv.C, r0, rend);
     __syncthreads();
     mma_chunk<BP>(acc, As, 0, Bc, wave, lane);
     if (threadIdx.x < 64) {
@@ -475,8 +505,8 @@ __global__ __launch_bounds__(512) void nce_param_grad_kernel(const NceK p) {
       bacc += s;
     }
   }
-  if (threadIdx.x < 64 && m0 + threadIdx.x < p.nc) bias[m0 + threadIdx.x] += bacc;
-  (void)bsum;
+  const bool add = p.rsplit <= 1;
+  if (threadIdx.x < 64 && m0 + threadIdx.x < p.nc) bias[m0 + threadIdx.x] = (add ? bias[m0 + threadIdx.x] : 0.f) + bacc;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -484,8 +514,37 @@ __global__ __launch_bounds__(512) void nce_param_grad_kernel(const NceK p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + NCE_ROW(i, r), n = NCE_COL(j);
-        if (m < p.nc && n < N) out[(long long)m * N + n] += acc.a[i][j][r];
+        if (m < p.nc && n < N) {
+          float* o = out + (long long)m * ldo + n;
+          *o = (add ? *o : 0.f) + acc.a[i][j][r];
+        }
       }
+}
+
+// grads += the row-split partial sums, ranges in order (grid: (elements / 256, 2, L))
+__global__ __launch_bounds__(256) void nce_param_reduce_kernel(const NceK p) {
+  const int which = blockIdx.y, level = blockIdx.z;
+  const NceLevel& lv = p.lv[level];
+  const int N = which == 0 ? p.nc : lv.C;
+  const long long stride = (long long)p.nc * TN + p.nc;
+  const float* part = p.wpart + (long long)(level * 2 + which) * p.rsplit * stride;
+  float* gW1 = p.grads + lv.w_off;
+  float* gb1 = gW1 + (long long)p.nc * lv.C;
+  float* gW2 = gb1 + p.nc;
+  float* gb2 = gW2 + (long long)p.nc * p.nc;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= stride) return;
+  float* dst;
+  if (e < (long long)p.nc * TN) {
+    const int m = (int)(e / TN), n = (int)(e % TN);
+    if (n >= N) return;
+    dst = (which == 0 ? gW2 : gW1) + (long long)m * N + n;
+  } else {
+    dst = (which == 0 ? gb2 : gb1) + (e - (long long)p.nc * TN);
+  }
+  float s = *dst;
+  for (int k = 0; k < p.rsplit; ++k) s += part[k * stride + e];
+  *dst = s;
 }
 
 // loss[l] = coef * sum of the per-workgroup partials of level l, in order
@@ -521,6 +580,14 @@ int fill(NceK& k, const gs_patchnce_desc* d, const float* const* xq, const float
   k.df = reinterpret_cast<unsigned short*>(w); w += LR * k.nc * 2;
   k.dh = reinterpret_cast<unsigned short*>(w); w += LR * k.nc * 2;
   k.loss_part = loss_part;
+  {   // behind the loss partials (gs_patchnce_work_bytes)
+    const long long tiles = (k.P + TM - 1) / TM;
+    w += ((long long)k.L * k.B * tiles * 4 + 255) / 256 * 256;
+    k.wpart = reinterpret_cast<float*>(w);
+    const int chunks = (k.R + 63) / 64;
+    k.rsplit = chunks >= 16 ? NCE_RSPLIT : (chunks >= 4 ? chunks / 2 : 1);
+    if (k.rsplit > NCE_RSPLIT) k.rsplit = NCE_RSPLIT;
+  }
   long long off = 0;
   for (int l = 0; l < k.L; ++l) {
     GS_REQUIRE(d->channels[l] >= 1 && d->channels[l] <= TN, "gs_patchnce: level %d has %d channels (1..%d)", l,
@@ -552,7 +619,9 @@ extern "C" int64_t gs_patchnce_work_bytes(const gs_patchnce_desc* d) {
   if (!d || d->levels < 1) return -1;
   const int64_t LR = (int64_t)d->levels * d->batch * d->patches;
   const int64_t tiles = (d->patches + TM - 1) / TM;
-  return 2 * LR * d->nc * 4 + LR * 4 + 3 * LR * d->nc * 2 + (int64_t)d->levels * d->batch * tiles * 4 + 256;
+  const int64_t part = ((int64_t)d->levels * d->batch * tiles * 4 + 255) / 256 * 256;
+  const int64_t wpart = (int64_t)d->levels * 2 * NCE_RSPLIT * ((int64_t)d->nc * TN + d->nc) * 4;
+  return 2 * LR * d->nc * 4 + LR * 4 + 3 * LR * d->nc * 2 + part + wpart + 256;
 }
 
 extern "C" int gs_patchnce_forward(const gs_patchnce_desc* d, const float* const* xq, const float* const* xk,
@@ -589,7 +658,10 @@ extern "C" int gs_patchnce_backward(const gs_patchnce_desc* d, const float* cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int row_tiles = (k.R + TM - 1) / TM;
   hipLaunchKernelGGL(nce_mlp_bwd_kernel, dim3(row_tiles, k.L), dim3(512), LDS_FWD, st, k);
-  hipLaunchKernelGGL(nce_param_grad_kernel, dim3(k.nc / TM, 2, k.L), dim3(512), LDS_FWD, st, k);
+  hipLaunchKernelGGL(nce_param_grad_kernel, dim3(k.nc / TM * k.rsplit, 2, k.L), dim3(512), LDS_FWD, st, k);
+  if (k.rsplit > 1)
+    hipLaunchKernelGGL(nce_param_reduce_kernel, dim3((unsigned)(((long long)k.nc * TN + k.nc + 255) / 256), 2, k.L), dim3(256),
+                       0, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
