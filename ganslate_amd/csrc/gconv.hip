@@ -551,7 +551,13 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
     uint2 pk;
     pk.x = pack_bf2(o[0], o[1]);
     pk.y = pack_bf2(o[2], o[3]);
-    *reinterpret_cast<uint2*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = pk;
+    uint2* dst = reinterpret_cast<uint2*>(p.out + (opix * d.out_cs + d.out_co + co) * 2);
+    if (d.accumulate) {     // bf16 read-modify-write, the rounding points of gconv_kernel's own accumulate epilogue
+      const uint2 old = *dst;
+      pk.x = pack_bf2(bf_lo(pk.x) + bf_lo(old.x), bf_hi(pk.x) + bf_hi(old.x));
+      pk.y = pack_bf2(bf_lo(pk.y) + bf_lo(old.y), bf_hi(pk.y) + bf_hi(old.y));
+    }
+    *dst = pk;
   }
   if (d.stats_slots > 0) {
     __shared__ float red[64][16][2];
@@ -598,7 +604,7 @@ TileCfg pick_tile(const gs_gconv_desc* d) {
 // stream megabytes of weights through a 2-stage ring; splitting K spreads that stream over all CUs. Returns 1 = no split.
 int splitk_plan(const gs_gconv_desc* d, const TileCfg& tc, bool fused) {
   const bool enabled = gs_opt(GS_OPT_SPLITK) != 0;
-  if (!enabled || fused || d->accumulate || (tc.bm != 128 && tc.bn != 16)) return 1;
+  if (!enabled || fused || (tc.bm != 128 && tc.bn != 16)) return 1;
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)d->N * ((pix + tc.bm - 1) / tc.bm) * ((d->Co + tc.bn - 1) / tc.bn);
   const int nk = d->Kp >> 6;

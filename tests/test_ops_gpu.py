@@ -734,6 +734,26 @@ def test_gconv_accumulate_into_slice(hip_ops):
     close_bf16(outs[1], outs[0], "accumulated dgrad")
 
 
+def test_gconv_accumulate_with_split_k(hip_ops):
+    """the accumulate-into form on a layer that runs split-K (64 -> 64 channel k5 coupling conv of the V-Net at 16^3: 32 output
+    tiles, K = 8000): the finalize pass does the bf16 read-modify-write of gconv_kernel's own accumulate epilogue"""
+    spec, N, sizes = ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, (16, 16, 16)
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 23)
+    g = torch.Generator().manual_seed(24)
+    gy = torch.randn(N, *sizes, 64, generator=g).to(torch.bfloat16)
+    base = torch.randn(N, *sizes, 128, generator=g).to(torch.bfloat16)
+    d = hip_ops._gdesc(low.dgrad[0], N, 64, 0, 128, 64, "none", 0.2, 0, 0, True)
+    assert hip_ops._splitk_floats(d) > 0, "the case must run split-K"
+    outs = []
+    for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+        G = base.clone().to(dev)
+        for gc in low.dgrad:
+            ops.gconv(gc, gy.to(dev), dpack.to(dev), None, G, out_co=64, accumulate=True)
+        outs.append(G)
+    assert torch.equal(outs[1][..., :64].cpu(), base[..., :64]), "the other half must be untouched"
+    close_bf16(outs[1], outs[0], "accumulated dgrad through split-K")
+
+
 def test_add_views_and_repeat_backward(hip_ops):
     g = torch.Generator().manual_seed(23)
     N, sp = 2, (4, 6, 5)
