@@ -70,6 +70,8 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconv_persist", 0},       // hconv.hip: smallest number of boxes the persistent resident-weight form takes (16 -> 16 channel k5 volume
                                 // layers), 0 = off (default: 191 vs 204 us alone at 128^3, but 73.4 vs 72.6 ms in the brats step)
     {"hconvw_ring_waves", 16},  // 16 or 8 waves for the fused data gradient of the wide 3x3 layers (hconvw.hip RING)
+    {"hstrip_persist", 0},      // hstrip.hip: smallest number of tiles the persistent double-buffered form takes, 0 = off (default:
+                                // measured 62-74 us against 42-55 for one workgroup per tile, two per CU)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -208,13 +208,17 @@ def test_halo_resident_boundary_convs(hip_ops, case):
     xa = torch.zeros(N, *low.in_dims, low.fwd[0].Ci, dtype=torch.bfloat16)
     xa.copy_(torch.randn(xa.shape, generator=g).to(torch.bfloat16))
     gy = torch.randn(N, *low.out_dims, low.fwd[0].Co, generator=g).to(torch.bfloat16)
-    default = hip_ops.get_option("hstrip")
+    default, default_p = hip_ops.get_option("hstrip"), hip_ops.get_option("hstrip_persist")
     res = {}
     try:
-        for on in (1, 0):
-            hip_ops.set_option("hstrip", on)          # 1: every eligible layer whatever its grid, 0: off
+        # 1: every eligible layer whatever its grid (one workgroup per tile), 2: the same through the persistent form (one
+        # workgroup per CU walking over double-buffered tiles — here also with fewer tiles than CUs), 0: off
+        for on in (1, 2, 0):
+            hip_ops.set_option("hstrip", min(on, 1))
+            hip_ops.set_option("hstrip_persist", 1 if on == 2 else 0)
             if on and low.fwd[0].Ci in (32, 64):      # (the 1-channel stem folds to 8 channels: stays on the im2col kernel)
-                assert hip_ops.stat_slots(low.fwd[0], N) == ((low.fwd[0].Ho + 31) // 32) * ((low.fwd[0].Wo + 7) // 8)
+                tiles = ((low.fwd[0].Ho + 31) // 32) * ((low.fwd[0].Wo + 7) // 8)
+                assert hip_ops.stat_slots(low.fwd[0], N) == tiles * (4 if on == 2 else 1)
             y, mr = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N)
             gx = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16, device=hip_ops.device)
             hip_ops.gconv_classes(low.dgrad, gy.to(hip_ops.device), dpack.to(hip_ops.device), None, gx)
@@ -222,6 +226,9 @@ def test_halo_resident_boundary_convs(hip_ops, case):
             res[on] = (y.cpu(), mr.cpu(), gx.cpu())
     finally:
         hip_ops.set_option("hstrip", default)
+        hip_ops.set_option("hstrip_persist", default_p)
+    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][2], res[1][2]), "persistent form: same arithmetic, same bits"
+    close_f32(res[2][1], res[1][1], "persistent form: mean / rstd", rel=1e-4)
     y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N)
     gx_ref = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16)
     RefOps().gconv_classes(low.dgrad, gy, dpack, None, gx_ref)
