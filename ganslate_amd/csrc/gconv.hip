@@ -703,9 +703,10 @@ extern "C" int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const
 extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                                       void* out, float* stats, const gs_gconv_fuse* fuse, void* stream) {
   GS_REQUIRE(d && fuse && fuse->y && fuse->mean_rstd && fuse->partial, "gs_gconv_forward_fused: null argument");
-  GS_REQUIRE(d->so == 1 && d->si == 1 && !d->accumulate && d->stats_slots == 0 && d->act == GS_ACT_NONE &&
+  // (si = 2: the data gradient of a transposed conv — a strided gather on the input side; the epilogue only sees output pixels)
+  GS_REQUIRE(d->so == 1 && (d->si == 1 || d->si == 2) && !d->accumulate && d->stats_slots == 0 && d->act == GS_ACT_NONE &&
                  d->out_cs == d->Co && d->out_co == 0,
-             "gs_gconv_forward_fused: only plain stride-1 data-gradient launches with a dense output can be fused");
+             "gs_gconv_forward_fused: only single-class data-gradient launches with a dense output can be fused");
   const int fd = fuse->Dy > 1 ? fuse->fold : 0;
   if (fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy) {
     // unpadded output domain: the launch applies the pad adjoint itself (hconvw.hip RING; gs_gconv_ring_slots says when)

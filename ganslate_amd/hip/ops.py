@@ -130,7 +130,9 @@ class HipOps:
     def fused_norm_plan(self, g: GConv, N: int, C_: int, force: bool = False):
         """(slots, scratch) for fusing the reduction pass of the consumer's InstanceNorm backward into the data-gradient
         launch of class g, or None when this backend / layer shape does not fuse (narrow layers run on the halo kernel)"""
-        if g.so != 1 or g.si != 1 or g.Co <= 64 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
+        if g.so != 1 or g.si not in (1, 2) or g.Co <= 64 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
+            return None
+        if g.si == 2 and os.environ.get("GS_FUSE_SI2", "1") == "0":     # (A/B switch: data gradients of transposed convs)
             return None
         d = self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
         if self._splitk_floats(d) and not force:   # few output tiles, long K: split-K wins over the fused epilogue

@@ -90,7 +90,7 @@ class RefOps:
         return 1
 
     def fused_norm_plan(self, g, N, C_, force=False):
-        if g.so != 1 or g.si != 1 or g.Co <= 64 or g.Co != C_:
+        if g.so != 1 or g.si not in (1, 2) or g.Co <= 64 or g.Co != C_:
             return None
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
