@@ -661,7 +661,7 @@ int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
 // hconvt.hip: the four parity classes of a stride-2 layer out of one halo-resident pass
 int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count);
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
-                     const float* bias, void* out, float* stats, void* stream);
+                     const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream);
 
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
 
@@ -804,6 +804,27 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
   return launch_tile(tc, k, (int)blocks, st);
 }
 
+// ---- the fused form for the parity classes of a stride-2 data gradient (hconvt.hip) -------------------------------------------
+// slots per image the fused launch writes (one per 16 x 16 box of the class grid), 0 when the layer does not run there
+extern "C" int gs_gconv_multi_fused_slots(const gs_gconv_desc* const* descs, int32_t count) {
+  if (!descs || count < 1 || !descs[0]) return 0;
+  const gs_gconv_desc* d = descs[0];
+  if (d->stats_slots != 0 || d->act != GS_ACT_NONE || d->out_cs != d->Co || d->out_co != 0) return 0;
+  return gs_hconvt_pattern(descs, count) >= 0 ? (d->Hc / 16) * (d->Wc / 16) : 0;
+}
+
+extern "C" int gs_gconv_forward_multi_fused(const gs_gconv_desc* const* descs, int32_t count, const void* in,
+                                            const void* const* w_packs, void* out, const gs_gconv_fuse* fuse, void* stream) {
+  GS_REQUIRE(descs && w_packs && in && out && fuse && fuse->y && fuse->mean_rstd && fuse->partial,
+             "gs_gconv_forward_multi_fused: null argument");
+  GS_REQUIRE(gs_gconv_multi_fused_slots(descs, count) > 0,
+             "gs_gconv_forward_multi_fused: the layer does not run on the halo-resident class kernel (gs_gconv_multi_fused_slots)");
+  const gs_gconv_desc* d = descs[0];
+  GS_REQUIRE(fuse->fold == 0 && fuse->Dy <= 1 && fuse->Hy == d->Ho && fuse->Wy == d->Wo,
+             "gs_gconv_forward_multi_fused: the consumer's tensor must be the unpadded output domain");
+  return gs_hconvt_launch(descs, gs_hconvt_pattern(descs, count), in, w_packs, nullptr, out, nullptr, fuse, stream);
+}
+
 // ---- merged launch over the output-parity classes of one layer ---------------------------------------------------------
 // A stride-2 transposed conv (and the data gradient of a stride-2 conv) is one class per output parity: 4 launches in 2-D
 // (k3: 1/2/2/4 taps, k4: 4 each), 8 in 3-D, each of them a quarter of the layer's pixels — at batch 8 the 32x32 / 64x64
@@ -847,7 +868,7 @@ extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t
                descs[c]->Kp);
   {
     const int pat = gs_hconvt_pattern(descs, count);      // 2-D k3 / k4 stride-2 layers with 64-multiple channels: one pass
-    if (pat >= 0) return gs_hconvt_launch(descs, pat, in, w_packs, bias, out, stats, stream);
+    if (pat >= 0) return gs_hconvt_launch(descs, pat, in, w_packs, bias, out, stats, nullptr, stream);
   }
   // the tile one class alone would get: the statistics slots (gs_gconv_stat_slots) are counted per class from it
   const TileCfg tc = pick_tile(d);

@@ -30,6 +30,8 @@ struct HConvTK {
   int wtap[16];                // tap index inside its class of K-step s (k offset = wtap * Ci + chunk * 64)
   int tiles_m, tiles_n, nbw, hmin, wmin, chunks;
   gs_gconv_desc d;             // class 0's descriptor (shared fields)
+  gs_gconv_fuse f;             // fused != 0: the reduction pass of the consumer's InstanceNorm backward rides in the epilogue
+  int fused;                   // (gs_gconv_forward_multi_fused; contract of gs_gconv_forward_fused, one slot per box)
 };
 
 // PAT 0: taps per class 1 / 2 / 2 / 4 (k3 transposed conv / stride-2 k3 gradient), PAT 1: 4 / 4 / 4 / 4 (k4)
@@ -240,7 +242,17 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
     for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
   constexpr int SROW = BN * 2 + 16;                          // slab row: 64 channels + a pad piece
   char* slab = smem;                                         // [256 pixels][SROW]
-  float* red = reinterpret_cast<float*>(smem + 256 * SROW);  // [4 wm][64][2]
+  float* red = reinterpret_cast<float*>(smem + 256 * SROW);  // [4 wm][64][2]  (fused: [8 waves][64][3])
+  // fused norm-backward sums of this thread's 8 channels (the store loop's `piece`) over the pixels it stores:
+  // ghat = (g + g2) * act'(yhat), ghat * yhat, yhat with yhat = (y - mean) * rstd of the CONSUMER's forward output y
+  float fa1[8], fa2[8], fa3[8], fmu[8], frs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) fa1[k] = fa2[k] = fa3[k] = fmu[k] = frs[k] = 0.f;
+  if (p.fused) {
+    const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co + nt * BN + (tid & 7) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { fmu[k] = mr[k]; frs[k] = mr[d.Co + k]; }
+  }
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -271,9 +283,62 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
         const size_t opix = ((size_t)n * d.Ho + ((oy0 + ly) * 2 + p.py[c])) * d.Wo + ((ox0 + lx) * 2 + p.px[c]);
         const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + piece * 16);
         *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + nt * BN + piece * 8) * 2) = val;
+        if (p.fused) {
+          const size_t e = (opix * d.Co + nt * BN + piece * 8) * 2;
+          const uint4 yv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.y) + e);
+          float g[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y),
+                        bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
+          const float yr[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
+                               bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
+          if (p.f.g2) {
+            const uint4 gv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.g2) + e);
+            g[0] += bf_lo(gv.x); g[1] += bf_hi(gv.x); g[2] += bf_lo(gv.y); g[3] += bf_hi(gv.y);
+            g[4] += bf_lo(gv.z); g[5] += bf_hi(gv.z); g[6] += bf_lo(gv.w); g[7] += bf_hi(gv.w);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float yh = (yr[k] - fmu[k]) * frs[k];
+            const float gh = g[k] * act_grad_from_out(yh, p.f.act, p.f.slope);
+            fa1[k] += gh;
+            fa2[k] += gh * yh;
+            fa3[k] += yh;
+          }
+        }
       }
     }
     __syncthreads();
+  }
+  if (p.fused) {
+    // lanes with equal (lane & 7) hold different pixels of the same 8 channels: sum inside the wave, then over the 8 waves
+    float* red3 = red;                                       // [8 waves][64 channels][3]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      fa1[k] = row_sum_stride8(fa1[k]); fa2[k] = row_sum_stride8(fa2[k]); fa3[k] = row_sum_stride8(fa3[k]);
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        fa1[k] += __shfl_xor(fa1[k], o, 64);
+        fa2[k] += __shfl_xor(fa2[k], o, 64);
+        fa3[k] += __shfl_xor(fa3[k], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red3[((wave * BN) + lane * 8 + k) * 3 + 0] = fa1[k];
+        red3[((wave * BN) + lane * 8 + k) * 3 + 1] = fa2[k];
+        red3[((wave * BN) + lane * 8 + k) * 3 + 2] = fa3[k];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { t0 += red3[(w * BN + tid) * 3]; t1 += red3[(w * BN + tid) * 3 + 1]; t2 += red3[(w * BN + tid) * 3 + 2]; }
+      float* sp = p.f.partial + ((size_t)n * p.tiles_m + mt) * 3 * d.Co;
+      const int cc = nt * BN + tid;
+      sp[cc] = t0; sp[d.Co + cc] = t1; sp[2 * d.Co + cc] = t2;
+    }
+    return;
   }
   if (want_stats) {
 #pragma unroll
@@ -350,7 +415,7 @@ int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count) {
 }
 
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
-                     const float* bias, void* out, float* stats, void* stream) {
+                     const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream) {
   const gs_gconv_desc* d = descs[0];
   HConvTK k;   // a plain local: autograd issues launches from its own host threads
   k.in = static_cast<const char*>(in);
@@ -378,6 +443,8 @@ int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in,
   k.hmin = lo[0]; k.wmin = lo[1];
   k.chunks = d->Ci / 64;
   k.d = *d;
+  k.fused = fuse != nullptr;
+  k.f = fuse ? *fuse : gs_gconv_fuse{};
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   const int lds = 3 * 2 * 64 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
   static bool configured = false;

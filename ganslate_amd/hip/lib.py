@@ -86,6 +86,9 @@ _PROTOS = {
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_gconv_forward_multi": (C.c_int, [C.POINTER(C.POINTER(GConvDesc)), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_gconv_multi_fused_slots": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gs_gconv_forward_multi_fused": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(GConvFuse), C.c_void_p]),
     "gs_gconv_forward_fused": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.POINTER(GConvFuse), C.c_void_p]),
     "gs_wgrad_pair": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

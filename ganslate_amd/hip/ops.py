@@ -141,6 +141,40 @@ class HipOps:
         slots = (g.pixels + tm - 1) // tm
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
+    @staticmethod
+    def _fuse_struct(fuse):
+        f = L.GConvFuse()
+        f.y, f.mean_rstd, f.partial = fuse["y"].data_ptr(), fuse["mean_rstd"].data_ptr(), fuse["partial"].data_ptr()
+        f.g2 = fuse["g2"].data_ptr() if fuse.get("g2") is not None else None
+        yd = fuse["y"].shape[1:-1]
+        f.Dy, f.Hy, f.Wy = (1,) + tuple(yd) if len(yd) == 2 else tuple(yd)
+        f.fold, f.fold_mode, f.act, f.slope = fuse["fold"], L.BORDER[fuse["fold_mode"]], L.ACT[fuse["act"]], \
+            float(fuse.get("slope", 0.2))
+        return f
+
+    def _multi_descs(self, classes, N, in_cs, out_cs):
+        key = ("multi_fused", tuple(id(g) for g in classes), N, in_cs, out_cs)
+        ent = self._desc_cache.get(key)
+        if ent is None:
+            descs = [self._gdesc(g, N, in_cs, 0, out_cs, 0, "none", 0.0, 0, 0) for g in classes]
+            arr = (C.POINTER(L.GConvDesc) * len(descs))(*[C.pointer(d) for d in descs])
+            ent = (arr, descs)
+            self._desc_cache[key] = ent
+        return ent
+
+    def fused_multi_plan(self, classes, N: int, C_: int):
+        """(slots, scratch) when the output-parity classes of a stride-2 conv's data gradient run as ONE halo-resident launch
+        that can carry the reduction pass of the consumer's InstanceNorm backward in its epilogue (hconvt.hip), else None"""
+        g = classes[0]
+        if len(classes) != 4 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0" or \
+                os.environ.get("GS_FUSE_MULTI", "1") == "0":
+            return None
+        arr, _ = self._multi_descs(classes, N, g.Ci, g.Co)
+        slots = self.lib.gs_gconv_multi_fused_slots(arr, len(classes))
+        if slots <= 0:
+            return None
+        return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
+
     def fused_ring_plan(self, g: GConv, N: int, C_: int):
         """(slots, scratch) when the fused data gradient of a reflect-padded 3x3 layer can run on the unpadded domain
         (class g = Lowered.dgrad_ring; the launch folds the ring itself, hconvw.hip RING), else None"""
@@ -165,13 +199,7 @@ class HipOps:
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
         t_end = self._time_begin("gconv", g, fuse is not None)
         if fuse is not None:     # data gradient + first pass of the consumer's InstanceNorm backward (fused_norm_plan)
-            f = L.GConvFuse()
-            f.y, f.mean_rstd, f.partial = fuse["y"].data_ptr(), fuse["mean_rstd"].data_ptr(), fuse["partial"].data_ptr()
-            f.g2 = fuse["g2"].data_ptr() if fuse.get("g2") is not None else None
-            yd = fuse["y"].shape[1:-1]
-            f.Dy, f.Hy, f.Wy = (1,) + tuple(yd) if len(yd) == 2 else tuple(yd)
-            f.fold, f.fold_mode, f.act, f.slope = fuse["fold"], L.BORDER[fuse["fold_mode"]], L.ACT[fuse["act"]], \
-                float(fuse.get("slope", 0.2))
+            f = self._fuse_struct(fuse)
             L.check(self.lib.gs_gconv_forward_fused(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats),
                                                     C.byref(f), _stream()), "gs_gconv_forward_fused")
             if t_end is not None:
@@ -189,11 +217,22 @@ class HipOps:
             t_end.record()
 
     def gconv_classes(self, classes, x, wpack, bias, out, *, in_co=0, out_co=0, act="none", slope=0.2, stats=None,
-                      stats_slots=0, stats_slot0s=None, accumulate=False):
+                      stats_slots=0, stats_slot0s=None, accumulate=False, fuse=None):
         """every output-parity class of one layer (Lowered.fwd / .dgrad). More than one class: gs_gconv_forward_multi, one
         launch when the classes are mergeable (the library decides; it runs them one by one otherwise). Layers so small
         that even the merged grid leaves the chip empty keep the per-class launches, which split K."""
         N = x.shape[0]
+        if fuse is not None:     # fused_multi_plan said yes: all classes + the consumer's norm-backward sums in one launch
+            arr, _ = self._multi_descs(classes, N, x.shape[-1], out.shape[-1])
+            base = wpack.data_ptr()
+            ws = (C.c_void_p * len(classes))(*[base + 2 * g.pack_offset for g in classes])
+            t_end = self._time_begin("gconv_multi", classes, True)
+            L.check(self.lib.gs_gconv_forward_multi_fused(arr, len(classes), _ptr(x), ws, _ptr(out),
+                                                          C.byref(self._fuse_struct(fuse)), _stream()),
+                    "gs_gconv_forward_multi_fused")
+            if t_end is not None:
+                t_end.record()
+            return
         slot0 = lambda i: stats_slot0s[i] if stats_slot0s else 0
         g0 = classes[0]
         merged = len(classes) > 1 and not accumulate

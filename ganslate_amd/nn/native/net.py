@@ -587,6 +587,10 @@ class NativeNet:
                 plan = None
                 if i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 1 and (i - 1) not in inj_x and not nodes[i - 1].attn:
                     plan = ops.fused_norm_plan(lw.dgrad[0], N, sp.cin_p)
+                elif i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 4 and f == 0 and (i - 1) not in inj_x \
+                        and not nodes[i - 1].attn:
+                    # the four parity classes of a stride-2 conv's data gradient as one halo-resident launch (hconvt.hip)
+                    plan = ops.fused_multi_plan(lw.dgrad, N, sp.cin_p)
                 ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p) if plan is not None else None
                 if ring is None:
                     gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
@@ -599,9 +603,12 @@ class NativeNet:
                                     "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope})
                     pending = (gx, 0, g2n, fmode_n, ring)
                 elif plan is not None:
-                    ops.gconv(lw.dgrad[0], dy, dpack, None, gx,
-                              fuse={"y": s.ys[i - 1], "mean_rstd": s.mrs[i - 1], "g2": g2n, "partial": plan[1], "fold": f,
-                                    "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope})
+                    fz = {"y": s.ys[i - 1], "mean_rstd": s.mrs[i - 1], "g2": g2n, "partial": plan[1], "fold": f,
+                          "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope}
+                    if len(lw.dgrad) == 1:
+                        ops.gconv(lw.dgrad[0], dy, dpack, None, gx, fuse=fz)
+                    else:
+                        ops.gconv_classes(lw.dgrad, dy, dpack, None, gx, fuse=fz)
                     pending = (gx, f, g2n, fmode_n, plan)
                 else:
                     ops.gconv_classes(lw.dgrad, dy, dpack, None, gx)

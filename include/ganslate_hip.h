@@ -133,6 +133,14 @@ typedef struct gs_gconv_fuse {
 } gs_gconv_fuse;
 int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
                            float* stats, const gs_gconv_fuse* fuse, void* stream);
+
+/* The fused data gradient (contract of gs_gconv_forward_fused: sums over the consumer's InstanceNorm-backward terms in the
+ * epilogue, one slot of [3][Co] floats per workgroup tile) for the output-parity classes of a stride-2 conv's data gradient
+ * (resnet2d.py:35 backward) when the layer runs on the halo-resident class kernel: gs_gconv_multi_fused_slots says whether
+ * (0 = no) and how many slots per image the launch writes; fuse->fold must be 0 (zero-padded layers). */
+int gs_gconv_multi_fused_slots(const gs_gconv_desc* const* descs, int32_t count);
+int gs_gconv_forward_multi_fused(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
+                                 void* out, const gs_gconv_fuse* fuse, void* stream);
 /* Unpadded form of the same launch for the reflect-padded (pad 1) wide 3x3 residual convs (resnet2d.py:80-87): when
  * gs_gconv_ring_slots(d) > 0 for the ZERO-border data-gradient descriptor on the unpadded domain (Hi x Wi = Ho x Wo = the
  * conv's input extent, taps t = 3*ry + rx at (dh, dw) = (1 - ry, 1 - rx)), gs_gconv_forward_fused may be called with that

@@ -103,13 +103,39 @@ class RefOps:
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
     # ---- convolution family ---------------------------------------------------------------------------
+    def fused_multi_plan(self, classes, N, C_):
+        """the layers gs_gconv_multi_fused_slots accepts (hconvt.hip gs_hconvt_pattern), restated: the four parity classes of
+        a 2-D stride-2 layer, 64-multiple channels, class grid a multiple of 16"""
+        g = classes[0]
+        if len(classes) != 4 or g.Co != C_ or g.so != 2 or g.si != 1 or g.Ci % 64 or g.Co % 64 or g.Dc != 1:
+            return None
+        if g.Hc % 16 or g.Wc % 16 or g.Ho != 2 * g.Hc or g.Wo != 2 * g.Wc or g.border != "zero":
+            return None
+        if sorted(c.T for c in classes) not in ([1, 2, 2, 4], [4, 4, 4, 4]):
+            return None
+        return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
+
     def gconv_classes(self, classes, x, wpack, bias, out, *, in_co=0, out_co=0, act="none", slope=0.2, stats=None,
-                      stats_slots=0, stats_slot0s=None, accumulate=False):
-        """the output-parity classes of one layer, one after the other (what gs_gconv_forward_multi merges)"""
+                      stats_slots=0, stats_slot0s=None, accumulate=False, fuse=None):
+        """the output-parity classes of one layer, one after the other (what gs_gconv_forward_multi merges); with `fuse`
+        (gs_gconv_forward_multi_fused) followed by the consumer's norm-backward sums over the finished gradient"""
         for i, g in enumerate(classes):
             self.gconv(g, x, wpack, bias, out, in_co=in_co, out_co=out_co, act=act, slope=slope, stats=stats,
                        stats_slots=stats_slots, stats_slot0=(stats_slot0s[i] if stats_slot0s else 0),
                        accumulate=accumulate)
+        if fuse is not None:
+            N, y, Cc = x.shape[0], fuse["y"], classes[0].Co
+            gf = out.float()
+            if fuse.get("g2") is not None:
+                gf = gf + fuse["g2"].float()
+            bc = (N,) + (1,) * (y.dim() - 2) + (Cc,)
+            mr = fuse["mean_rstd"].view(N, 2, Cc)
+            yh = (y.float() - mr[:, 0].reshape(bc)) * mr[:, 1].reshape(bc)
+            gh = gf * _act_grad_from_out(yh, fuse["act"], fuse.get("slope", 0.2))
+            part = fuse["partial"][:N * 3 * Cc].view(N, 1, 3, Cc)
+            part[:, 0, 0] = gh.reshape(N, -1, Cc).sum(1)
+            part[:, 0, 1] = (gh * yh).reshape(N, -1, Cc).sum(1)
+            part[:, 0, 2] = yh.reshape(N, -1, Cc).sum(1)
 
     def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
               stats=None, stats_slots=0, stats_slot0=0, accumulate=False, fuse=None):

@@ -576,6 +576,57 @@ def test_dgrad_ring_form(hip_ops, case, with_g2, act, waves):
     close_bf16(res["hip"][1], res["hip"][2].cpu(), "dy: ring form vs padded form")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 8, 256, 256),              # d128: the gradient that reaches the stem's norm
+    (ConvSpec("conv", 128, 256, 3, 2, 1), 3, 128, 160),             # d256, ragged box grid 4 x 5, two channel tiles
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 16, 64, 96),              # PatchGAN k4 gradient
+], ids=_ids)
+@pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "lrelu")])
+def test_parity_class_dgrad_with_fused_norm_sums(hip_ops, case, with_g2, act):
+    """gs_gconv_forward_multi_fused (hconvt.hip): the four parity classes of a stride-2 conv's data gradient in one launch
+    WITH the reduction pass of the consumer's InstanceNorm backward in its epilogue — gradient bit-identical to the plain
+    merged launch, sums against the oracle, and gs_inorm_act_backward driven by them gives the dy of its own reduction"""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 61)
+    C = spec.cin_p
+    g = torch.Generator().manual_seed(62)
+    dev = hip_ops.device
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16)
+    y = (torch.randn(N, *sizes, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16)
+    g2 = torch.randn(N, *sizes, C, generator=g).to(torch.bfloat16) if with_g2 else None
+    hconvt_default = hip_ops.get_option("hconvt")
+    res = {}
+    try:
+        hip_ops.set_option("hconvt", 1)
+        ref = RefOps()
+        for name, ops, d in (("ref", ref, "cpu"), ("hip", hip_ops, dev)):
+            yd, g2d = y.to(d), None if g2 is None else g2.to(d)
+            part = torch.stack([yd.float().sum((1, 2)), (yd.float() ** 2).sum((1, 2))], 1).reshape(-1).contiguous()
+            mr = torch.empty(N * 2 * C, dtype=torch.float32, device=d)
+            ops.inorm_finalize(part, N, 1, C, sizes[0] * sizes[1], mr)
+            plan = ops.fused_multi_plan(low.dgrad, N, C)
+            assert plan is not None, "case must be eligible for the fused class launch"
+            gx = torch.zeros(N, *sizes, C, dtype=torch.bfloat16, device=d)
+            ops.gconv_classes(low.dgrad, gy.to(d), dpack.to(d), None, gx,
+                              fuse={"y": yd, "mean_rstd": mr, "g2": g2d, "partial": plan[1], "fold": 0,
+                                    "fold_mode": "reflect", "act": act, "slope": 0.2})
+            gx_plain = torch.zeros_like(gx)
+            ops.gconv_classes(low.dgrad, gy.to(d), dpack.to(d), None, gx_plain)
+            dy_pre, dy_own = torch.empty_like(yd), torch.empty_like(yd)
+            ops.inorm_act_backward(gx, g2d, yd, mr, dy_pre, None, fold=0, act=act, pre=plan)
+            ops.inorm_act_backward(gx, g2d, yd, mr, dy_own, None, fold=0, act=act)
+            sums = plan[1][:N * plan[0] * 3 * C].view(N, plan[0], 3, C).sum(1)
+            res[name] = (gx, gx_plain, dy_pre, dy_own, sums)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.set_option("hconvt", hconvt_default)
+    assert torch.equal(res["hip"][0], res["hip"][1]), "fusion must not change the data gradient"
+    close_bf16(res["hip"][0], res["ref"][0], "dgrad vs oracle")
+    close_f32(res["hip"][4], res["ref"][4], "fused partial sums", rel=3e-3)
+    close_bf16(res["hip"][2], res["hip"][3].cpu(), "dy from fused sums vs own reduction")
+    close_bf16(res["hip"][2], res["ref"][3], "dy vs oracle")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 256), (2, 17, 13, 64), (1, 32, 32, 8), (1, 5, 7, 512)])
 @pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
 @pytest.mark.parametrize("res", [False, True])
