@@ -44,7 +44,7 @@ __device__ __host__ constexpr int cls_of(int s) {
   return s >> 2;
 }
 
-template <int PAT>
+template <int PAT, bool FUSED = false>
 __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
   // 8 waves as 4 (pixel rows) x 2 (channels): 64 pixels x 32 channels x 4 classes = 128 accumulator registers per lane —
   // the 16-wave split (64 x 16 per wave) fits the 128-VGPR cap only with spills, whose reloads wait vmcnt(0) right behind
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
     const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
     bia[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool want_stats = d.stats_slots > 0;
+  const bool want_stats = !FUSED && d.stats_slots > 0;
   float s1[TI][4], s2[TI][4];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
   float fa1[8], fa2[8], fa3[8], fmu[8], frs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) fa1[k] = fa2[k] = fa3[k] = fmu[k] = frs[k] = 0.f;
-  if (p.fused) {
+  if constexpr (FUSED) {
     const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co + nt * BN + (tid & 7) * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { fmu[k] = mr[k]; frs[k] = mr[d.Co + k]; }
@@ -276,39 +276,51 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
     __syncthreads();
     {
       const int piece = tid & 7;                             // 8 lanes x 16 B = the 64 channels of a pixel: 128-B stores
+      // (FUSED: the consumer's y / g2 of two pixels are requested before the first is used — as load, use, load, use the fused
+      // epilogue tripled the launch; all four at once spill the accumulators of the classes still to come)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int pl = it * 64 + (tid >> 3);
-        const int ly = pl >> 4, lx = pl & 15;
-        const size_t opix = ((size_t)n * d.Ho + ((oy0 + ly) * 2 + p.py[c])) * d.Wo + ((ox0 + lx) * 2 + p.px[c]);
-        const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + piece * 16);
-        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + nt * BN + piece * 8) * 2) = val;
-        if (p.fused) {
-          const size_t e = (opix * d.Co + nt * BN + piece * 8) * 2;
-          const uint4 yv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.y) + e);
-          float g[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y),
-                        bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
-          const float yr[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
-                               bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
-          if (p.f.g2) {
-            const uint4 gv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.g2) + e);
-            g[0] += bf_lo(gv.x); g[1] += bf_hi(gv.x); g[2] += bf_lo(gv.y); g[3] += bf_hi(gv.y);
-            g[4] += bf_lo(gv.z); g[5] += bf_hi(gv.z); g[6] += bf_lo(gv.w); g[7] += bf_hi(gv.w);
+      for (int it0 = 0; it0 < 4; it0 += 2) {
+        uint4 val[2], yv[2], gv[2];
+        size_t opx[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pl = (it0 + u) * 64 + (tid >> 3);
+          const int ly = pl >> 4, lx = pl & 15;
+          opx[u] = ((size_t)n * d.Ho + ((oy0 + ly) * 2 + p.py[c])) * d.Wo + ((ox0 + lx) * 2 + p.px[c]);
+          val[u] = *reinterpret_cast<const uint4*>(slab + pl * SROW + piece * 16);
+          if constexpr (FUSED) {
+            const size_t e = (opx[u] * d.Co + nt * BN + piece * 8) * 2;
+            yv[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.y) + e);
+            if (p.f.g2) gv[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.g2) + e);
           }
+        }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float yh = (yr[k] - fmu[k]) * frs[k];
-            const float gh = g[k] * act_grad_from_out(yh, p.f.act, p.f.slope);
-            fa1[k] += gh;
-            fa2[k] += gh * yh;
-            fa3[k] += yh;
+        for (int u = 0; u < 2; ++u) {
+          *reinterpret_cast<uint4*>(p.out + (opx[u] * d.out_cs + d.out_co + nt * BN + piece * 8) * 2) = val[u];
+          if constexpr (FUSED) {
+            float g[8] = {bf_lo(val[u].x), bf_hi(val[u].x), bf_lo(val[u].y), bf_hi(val[u].y),
+                          bf_lo(val[u].z), bf_hi(val[u].z), bf_lo(val[u].w), bf_hi(val[u].w)};
+            const float yr[8] = {bf_lo(yv[u].x), bf_hi(yv[u].x), bf_lo(yv[u].y), bf_hi(yv[u].y),
+                                 bf_lo(yv[u].z), bf_hi(yv[u].z), bf_lo(yv[u].w), bf_hi(yv[u].w)};
+            if (p.f.g2) {
+              g[0] += bf_lo(gv[u].x); g[1] += bf_hi(gv[u].x); g[2] += bf_lo(gv[u].y); g[3] += bf_hi(gv[u].y);
+              g[4] += bf_lo(gv[u].z); g[5] += bf_hi(gv[u].z); g[6] += bf_lo(gv[u].w); g[7] += bf_hi(gv[u].w);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float yh = (yr[k] - fmu[k]) * frs[k];
+              const float gh = g[k] * act_grad_from_out(yh, p.f.act, p.f.slope);
+              fa1[k] += gh;
+              fa2[k] += gh * yh;
+              fa3[k] += yh;
+            }
           }
         }
       }
     }
     __syncthreads();
   }
-  if (p.fused) {
+  if constexpr (FUSED) {
     // lanes with equal (lane & 7) hold different pixels of the same 8 channels: sum inside the wave, then over the 8 waves
     float* red3 = red;                                       // [8 waves][64 channels][3]
 #pragma unroll
@@ -456,7 +468,18 @@ int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in,
     configured = true;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+  if (fuse) {
+    static bool configured_f = false;
+    if (!configured_f) {
+      GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvt_kernel<0, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvt_kernel<1, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      configured_f = true;
+    }
+    if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0, true>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+    else hipLaunchKernelGGL((hconvt_kernel<1, true>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+  } else if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0>), dim3((unsigned)blocks), dim3(512), lds, st, k);
   else hipLaunchKernelGGL((hconvt_kernel<1>), dim3((unsigned)blocks), dim3(512), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
