@@ -44,7 +44,8 @@ __device__ __host__ constexpr int cls_of(int s) {
   return s >> 2;
 }
 
-template <int PAT, bool FUSED = false>
+// PLAIN: a data-gradient launch — no bias, no statistics, no activation (their 24 registers are what the kernel spills)
+template <int PAT, bool FUSED = false, bool PLAIN = false>
 __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
   // 8 waves as 4 (pixel rows) x 2 (channels): 64 pixels x 32 channels x 4 classes = 128 accumulator registers per lane —
   // the 16-wave split (64 x 16 per wave) fits the 128-VGPR cap only with spills, whose reloads wait vmcnt(0) right behind
@@ -232,9 +233,9 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
-    bia[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bia[i] = (!PLAIN && !FUSED && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool want_stats = !FUSED && d.stats_slots > 0;
+  const bool want_stats = !FUSED && !PLAIN && d.stats_slots > 0;
   float s1[TI][4], s2[TI][4];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -263,10 +264,14 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = acc[c][i][j][r] + bia[i][r];
-          s1[i][r] += v[r];
-          s2[i][r] += v[r] * v[r];
-          v[r] = apply_act(v[r], d.act, d.slope);
+          if constexpr (PLAIN || FUSED) {
+            v[r] = acc[c][i][j][r];
+          } else {
+            v[r] = acc[c][i][j][r] + bia[i][r];
+            s1[i][r] += v[r];
+            s2[i][r] += v[r] * v[r];
+            v[r] = apply_act(v[r], d.act, d.slope);
+          }
         }
         uint2 o;
         o.x = pack_bf2(v[0], v[1]);
@@ -479,6 +484,17 @@ int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in,
     }
     if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0, true>), dim3((unsigned)blocks), dim3(512), lds, st, k);
     else hipLaunchKernelGGL((hconvt_kernel<1, true>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+  } else if (!bias && d->stats_slots == 0 && d->act == GS_ACT_NONE) {
+    static bool configured_p = false;
+    if (!configured_p) {
+      GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvt_kernel<0, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvt_kernel<1, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      configured_p = true;
+    }
+    if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0, false, true>), dim3((unsigned)blocks), dim3(512), lds, st, k);
+    else hipLaunchKernelGGL((hconvt_kernel<1, false, true>), dim3((unsigned)blocks), dim3(512), lds, st, k);
   } else if (pat == 0) hipLaunchKernelGGL((hconvt_kernel<0>), dim3((unsigned)blocks), dim3(512), lds, st, k);
   else hipLaunchKernelGGL((hconvt_kernel<1>), dim3((unsigned)blocks), dim3(512), lds, st, k);
   GS_CHECK_HIP(hipGetLastError());
