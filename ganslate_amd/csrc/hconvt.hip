@@ -283,8 +283,8 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
       const int piece = tid & 7;                             // 8 lanes x 16 B = the 64 channels of a pixel: 128-B stores
       // (FUSED: the consumer's y / g2 of two pixels are requested before the first is used — as load, use, load, use the fused
       // epilogue tripled the launch; all four at once spill the accumulators of the classes still to come)
-#pragma unroll
-      for (int it0 = 0; it0 < 4; it0 += 2) {
+#pragma unroll 1
+      for (int it0 = 0; it0 < 4; it0 += 2) {      // (not unrolled: with all four pixels' loads hoisted the FUSED form spilled 170 registers)
         uint4 val[2], yv[2], gv[2];
         size_t opx[2];
 #pragma unroll

@@ -165,12 +165,10 @@ class HipOps:
     def fused_multi_plan(self, classes, N: int, C_: int):
         """(slots, scratch) when the output-parity classes of a stride-2 conv's data gradient run as ONE halo-resident launch
         that can carry the reduction pass of the consumer's InstanceNorm backward in its epilogue (hconvt.hip), else None"""
-        # OFF unless GS_FUSE_MULTI=1: the class kernel already spills 15 registers at its 256-register cap, its fused
-        # instantiation 177, and the step is 2 % slower with it (17.80 vs 18.20 ms, same box) than with the separate
-        # reduction passes it removes (DESIGN.md §4.11)
+        # (GS_FUSE_MULTI=0: A/B switch. Worth 0.3 % once the fused instantiation stopped spilling, DESIGN.md §4.11)
         g = classes[0]
         if len(classes) != 4 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0" or \
-                os.environ.get("GS_FUSE_MULTI", "0") != "1":
+                os.environ.get("GS_FUSE_MULTI", "1") == "0":
             return None
         arr, _ = self._multi_descs(classes, N, g.Ci, g.Co)
         slots = self.lib.gs_gconv_multi_fused_slots(arr, len(classes))

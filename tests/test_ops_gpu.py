@@ -583,10 +583,9 @@ def test_dgrad_ring_form(hip_ops, case, with_g2, act, waves):
 ], ids=_ids)
 @pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "lrelu")])
 def test_parity_class_dgrad_with_fused_norm_sums(hip_ops, monkeypatch, case, with_g2, act):
-    """gs_gconv_forward_multi_fused (hconvt.hip; the executor uses it only with GS_FUSE_MULTI=1 — it measured slower than the
-    separate reduction pass): the four parity classes of a stride-2 conv's data gradient in one launch WITH the reduction pass
-    of the consumer's InstanceNorm backward in its epilogue — gradient bit-identical to the plain merged launch, sums against
-    the oracle, and gs_inorm_act_backward driven by them gives the dy of its own reduction"""
+    """gs_gconv_forward_multi_fused (hconvt.hip): the four parity classes of a stride-2 conv's data gradient in one launch WITH
+    the reduction pass of the consumer's InstanceNorm backward in its epilogue — gradient bit-identical to the plain merged
+    launch, sums against the oracle, and gs_inorm_act_backward driven by them gives the dy of its own reduction"""
     monkeypatch.setenv("GS_FUSE_MULTI", "1")
     spec, N, sizes = case[0], case[1], case[2:]
     low, master, bias, fpack, dpack = make_layer(spec, sizes, 61)
