@@ -704,6 +704,22 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
       // launch); with hundreds of slots (256 x 256 maps) that prologue would dominate, so those keep the slot_sum launch
       int ppb = 64;
       while ((HW + ppb - 1) / ppb > 1024) ppb *= 2;
+      {
+        // one round of workgroups: the kernel keeps 6 workgroups per CU resident (74 registers), so the 2048 workgroups of a
+        // residual-block layer at batch 8 ran as 1536 + a third-full second round; 96 pixels per workgroup make it 1376
+        // (17.82 -> 17.77 ms on the step)
+        static int slots = 0;
+        if (!slots) {
+          int dev = 0;
+          hipDeviceProp_t prop;
+          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            slots = prop.multiProcessorCount * 6;
+          else
+            slots = 1536;
+        }
+        const long long per = (long long)(C / 64) * N;
+        while (ppb < 256 && per * ((HW + ppb - 1) / ppb) > slots && per * ((HW + ppb + 31) / (ppb + 32)) >= slots / 2) ppb += 32;
+      }
 #define GS_LAUNCH_APPLY_CG(FM)                                                                                      \
   hipLaunchKernelGGL((inorm_bwd_apply_cg_kernel<FM>), dim3(C / 64, (unsigned)((HW + ppb - 1) / ppb), N), dim3(256), 0, \
                      st, static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2),                            \
