@@ -5,8 +5,11 @@ import os
 
 import torch
 
+import functools
+
 from . import lib as L
 from ..nn.native.spec import GConv, WGrad
+from ..nn.native.twin import Twin, TwinSplit, is_twin
 
 
 def _ptr(t):
@@ -24,7 +27,7 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class HipOps:
+class HipOps(TwinSplit):
     """The product backend: hand-written gfx950 kernels behind libganslate_hip.so."""
     name = "hip"
     act_dtype = torch.bfloat16   # storage type of activations and weight packs
@@ -193,6 +196,11 @@ class HipOps:
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
               slope=0.2, stats=None, stats_slots=0, stats_slot0=0, accumulate=False, fuse=None):
+        if is_twin(wpack, bias):      # two networks' weights over one batch (nn/native/twin.py)
+            return self.twin_gconv(functools.partial(self.gconv, g), x, wpack, bias, out, in_cs=in_cs, in_co=in_co,
+                                   out_cs=out_cs, out_co=out_co, act=act, slope=slope, stats=stats,
+                                   stats_slots=stats_slots, stats_slot0=stats_slot0, accumulate=accumulate, fuse=fuse,
+                                   C_=g.Co)
         N = x.shape[0]
         in_cs = in_cs if in_cs is not None else x.shape[-1]
         out_cs = out_cs if out_cs is not None else out.shape[-1]
@@ -222,6 +230,10 @@ class HipOps:
         """every output-parity class of one layer (Lowered.fwd / .dgrad). More than one class: gs_gconv_forward_multi, one
         launch when the classes are mergeable (the library decides; it runs them one by one otherwise). Layers so small
         that even the merged grid leaves the chip empty keep the per-class launches, which split K."""
+        if is_twin(wpack, bias):
+            return self.twin_gconv(functools.partial(self.gconv_classes, classes), x, wpack, bias, out, in_co=in_co,
+                                   out_co=out_co, act=act, slope=slope, stats=stats, stats_slots=stats_slots,
+                                   stats_slot0s=stats_slot0s, accumulate=accumulate, fuse=fuse, C_=classes[0].Co)
         N = x.shape[0]
         if fuse is not None:     # fused_multi_plan said yes: all classes + the consumer's norm-backward sums in one launch
             arr, _ = self._multi_descs(classes, N, x.shape[-1], out.shape[-1])
@@ -278,6 +290,8 @@ class HipOps:
                         for k in range(3) for t in range(9)))
 
     def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
+        if is_twin(dw):
+            return self.twin_wgrad(w, a, g, dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co, pair=pair)
         key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)
         ent = self._desc_cache.get(key)
         if ent is None:
@@ -316,6 +330,8 @@ class HipOps:
             t_end.record()
 
     def bias_grad(self, dy, C_, db, *, cs=None, co=0):
+        if is_twin(db):
+            return self.twin_bias_grad(dy, C_, db, cs=cs, co=co)
         pixels = dy.numel() // dy.shape[-1]
         if os.environ.get("GS_WGRAD_DET", "1") != "0":      # deterministic: partial sums + fixed-order second stage
             nws = int(self.lib.gs_bias_grad_ws_floats(pixels, C_))
@@ -506,6 +522,8 @@ class HipOps:
                 "gs_image_unfold_backward")
 
     def shiftadd_to_image(self, z, bias, img, k, act="none"):
+        if is_twin(bias):
+            return self.twin_shiftadd_to_image(z, bias, img, k, act=act)
         N, Cc, rows, W = self._img_dims(img)
         L.check(self.lib.gs_shiftadd_to_image(_ptr(z), _ptr(bias), _ptr(img), N, Cc, rows, W, z.shape[-1], k,
                                               L.ACT[act], _stream()), "gs_shiftadd_to_image")

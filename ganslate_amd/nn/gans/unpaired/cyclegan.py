@@ -3,6 +3,7 @@ ganslate/nn/gans/unpaired/cyclegan.py:12-224, running on the HIP executors:
 forward (4 or 6 generator passes) -> SSIM metrics -> G step (Ds frozen: no D weight-gradient kernels are
 launched) -> D_B step, D_A step (image pools, `.detach()`), Adam on flat buffers."""
 import itertools
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -11,6 +12,7 @@ from .... import configs
 from ....data.utils.image_pool import ImagePool
 from ...losses.adversarial_loss import AdversarialLoss
 from ...losses.cyclegan_losses import CycleGANLosses
+from ...native.twin import TwinNet
 from ...optim import NativeAdam
 from ..base import BaseGAN
 
@@ -46,6 +48,22 @@ class CycleGAN(BaseGAN):
             self.fake_A_pool = ImagePool(conf.train.gan.pool_size)
             self.fake_B_pool = ImagePool(conf.train.gan.pool_size)
         self.setup()
+        self._init_twins()
+
+    def _init_twins(self):
+        """The two generators (and the two discriminators) have the same layer list and see independent data: each pair
+        runs lock-step as ONE batch of 2N images with per-image-range weights (nn/native/twin.py) — half the launches, and
+        512 instead of 256 tiles per residual-conv launch. GS_TWIN=0 keeps the two passes apart (second cycle on its own
+        stream); volumes stay apart unless GS_TWIN=all (their launches already fill the chip)."""
+        self.twin_G = self.twin_D = None
+        mode = os.environ.get("GS_TWIN", "1")
+        if not self.is_train or mode == "0":
+            return
+        ok = lambda a, b: TwinNet.compatible(a, b) and (a.dims == 2 or mode == "all")
+        if ok(self.networks["G_AB"], self.networks["G_BA"]):
+            self.twin_G = TwinNet(self.networks["G_AB"], self.networks["G_BA"])
+        if ok(self.networks["D_B"], self.networks["D_A"]):
+            self.twin_D = TwinNet(self.networks["D_B"], self.networks["D_A"])
 
     def _step_pools(self):
         return [self.fake_B_pool, self.fake_A_pool]      # backward_D("D_B") runs first
@@ -78,10 +96,13 @@ class CycleGAN(BaseGAN):
         self.set_requires_grad(discriminators, True)
         self.optimizers["D"].zero_grad(set_to_none=True)
         with self.side_work():       # launched beside the generators' backward pass (BaseGAN.fork_side_work)
-            self.backward_D("D_B")
-            self.metrics.update(self.training_metrics.compute_metrics_D("D_B", self.pred_real, self.pred_fake))
-            self.backward_D("D_A")
-            self.metrics.update(self.training_metrics.compute_metrics_D("D_A", self.pred_real, self.pred_fake))
+            if self.twin_D is not None:
+                self.backward_D_twin()
+            else:
+                self.backward_D("D_B")
+                self.metrics.update(self.training_metrics.compute_metrics_D("D_B", self.pred_real, self.pred_fake))
+                self.backward_D("D_A")
+                self.metrics.update(self.training_metrics.compute_metrics_D("D_A", self.pred_real, self.pred_fake))
         self.join_side_work()
         self.optimizers["D"].step()
 
@@ -90,6 +111,14 @@ class CycleGAN(BaseGAN):
         launched on its own stream (BaseGAN.side_work; autograd then runs its backward there too). Host order, and
         with it the autograd graph, is the reference's (cyclegan.py:109-124)."""
         real_A, real_B = self.visuals["real_A"], self.visuals["real_B"]
+        if self.twin_G is not None:
+            # both generators as one batch per phase: (G_AB(real_A), G_BA(real_B)), then (G_AB(fake_A), G_BA(fake_B))
+            fake_B, fake_A = self.twin_G(real_A, real_B)
+            rec_B, rec_A = self.twin_G(fake_A, fake_B)
+            idt_B, idt_A = self.twin_G(real_B, real_A) if self.criterion_G.is_using_identity() else (None, None)
+            self.visuals.update({"fake_B": fake_B, "rec_A": rec_A, "idt_A": idt_A,
+                                 "fake_A": fake_A, "rec_B": rec_B, "idt_B": idt_B})
+            return
         for net in (self.networks["G_AB"], self.networks["G_BA"]):
             net.refresh_packs(real_A)          # weight packs are shared by both streams: refresh them before the fork
             net.multi_stream_passes = True     # ... and their backward passes are ordered per network (NativeNet)
@@ -123,10 +152,30 @@ class CycleGAN(BaseGAN):
         self.losses[discriminator] = loss_real + loss_fake
         self.backward(loss=self.losses[discriminator], optimizer=self.optimizers["D"], loss_id=2)
 
+    def backward_D_twin(self):
+        """backward_D("D_B") and backward_D("D_A") (cyclegan.py:154-189) as one pass: D_B sees [real_B | pooled fake_B] and
+        D_A sees [real_A | pooled fake_A] as a batch of 2N images each (InstanceNorm is per sample: every image's map is what
+        the separate passes give), the two discriminators ride in one twin batch of 4N, and the two losses — which share
+        no parameter — are differentiated together."""
+        fake_B = self.fake_B_pool.query(self.visuals["fake_B"]).detach()      # pool order: D_B first (_step_pools)
+        fake_A = self.fake_A_pool.query(self.visuals["fake_A"]).detach()
+        pred_B, pred_A = self.twin_D((self.visuals["real_B"], fake_B), (self.visuals["real_A"], fake_A))
+        total = None
+        for name, pred in (("D_B", pred_B), ("D_A", pred_A)):
+            self.pred_real, self.pred_fake = pred
+            self.losses[name] = self.criterion_adv(self.pred_real, target_is_real=True) + \
+                self.criterion_adv(self.pred_fake, target_is_real=False)
+            self.metrics.update(self.training_metrics.compute_metrics_D(name, self.pred_real, self.pred_fake))
+            total = self.losses[name] if total is None else total + self.losses[name]
+        self.backward(loss=total, optimizer=self.optimizers["D"], loss_id=2)
+
     def backward_G(self):
         fake_B, fake_A = self.visuals["fake_B"], self.visuals["fake_A"]
-        pred_B = self.networks["D_B"](fake_B)
-        pred_A = self.networks["D_A"](fake_A)
+        if self.twin_D is not None:
+            pred_B, pred_A = self.twin_D(fake_B, fake_A)
+        else:
+            pred_B = self.networks["D_B"](fake_B)
+            pred_A = self.networks["D_A"](fake_A)
         # from here on the discriminators' own update may run: the images exist, the weight packs are refreshed
         self.fork_side_work()
         self.losses["G_AB"] = self.criterion_adv(pred_B, target_is_real=True)

@@ -21,6 +21,7 @@ import torch
 
 from .backend import get_ops
 from .spec import ConvSpec, Lowered, lower
+from .twin import Twin
 
 
 import os
@@ -407,19 +408,35 @@ class NativeNet:
         x = x.contiguous().float()
         return _TapFn.apply(x, self._token, self, tuple(taps), tuple(ids))
 
-    def _forward(self, x, save, stop=None):
-        """stop = index of the last node to run (encoder-only passes of CUT, cut.py:297-312); None = whole net"""
+    def _forward(self, x, save, stop=None, tw=None):
+        """stop = index of the last node to run (encoder-only passes of CUT, cut.py:297-312); None = whole net.
+        tw = a second network of identical architecture (nn/native/twin.py): x is then the pair (xa, xb) and the pass runs
+        as ONE batch of 2N images, images [0, N) through this network's weights and [N, 2N) through tw's."""
         ops, dev = self.ops, self.device
-        N, sizes = x.shape[0], tuple(x.shape[2:])
+        # twin: x = (images of this network, images of tw), each a tuple of tensors that follow each other in the batch
+        xs = tuple(x[0]) + tuple(x[1]) if tw is not None else (x,)
+        sizes = tuple(xs[0].shape[2:])
+        N = sum(t.shape[0] for t in xs)
+        if tw is not None:
+            assert 2 * sum(t.shape[0] for t in x[0]) == N, "twin pass: both networks take the same number of images"
         lows = self._lowered(*sizes)
         pk = self._get_packs(*sizes)
         m = self.master.detach()
+        fpack_all = pk["fpack"]
+        if tw is not None:
+            assert stop is None, "twin passes run whole networks"
+            m = Twin(m, tw.master.detach())
+            fpack_all = Twin(fpack_all, tw._get_packs(*sizes)["fpack"])
         sp0 = self.nodes[0].spec
         a = torch.empty(N, *sizes, sp0.cin_p, dtype=self.ops.act_dtype, device=dev)
-        if sp0.wfold == "in":      # the W taps of the stem become channels while the image is converted
-            ops.image_unfold(x, a, sp0.k, sp0.pad, sp0.pad_mode)
-        else:
-            ops.image_to_act(x, a)
+        n0 = 0
+        for xh in xs:
+            ah = a[n0:n0 + xh.shape[0]]
+            n0 += xh.shape[0]
+            if sp0.wfold == "in":      # the W taps of the stem become channels while the image is converted
+                ops.image_unfold(xh, ah, sp0.k, sp0.pad, sp0.pad_mode)
+            else:
+                ops.image_to_act(xh, ah)
         acts, ys, mrs, attn_saved = [a], [], [], {}
         for i, (nd, lw) in enumerate(zip(self.nodes, lows)):
             if stop is not None and i > stop:
@@ -430,7 +447,7 @@ class NativeNet:
                 acts[-1] = xo
             sp = nd.spec
             bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
-            fpack = pk["fpack"][pk["f_off"][i]:]
+            fpack = fpack_all[pk["f_off"][i]:]
             y = torch.empty(N, *lw.out_dims, sp.cout_p, dtype=self.ops.act_dtype, device=dev)
             if nd.norm:
                 slots, offs = 0, []
@@ -466,32 +483,47 @@ class NativeNet:
         if not save:
             return out, None
         s = _Saved()
-        s.x_img, s.acts, s.ys, s.mrs, s.out_img, s.lows, s.N = x, acts, ys, mrs, out, lows, N
+        s.x_img, s.acts, s.ys, s.mrs, s.out_img, s.lows, s.N = (xs if tw is not None else x), acts, ys, mrs, out, lows, N
         s.attn = attn_saved
         return out, s
 
     # ---- backward ---------------------------------------------------------------------------------------------------------
-    def _backward(self, s: _Saved, g_img, need_input_grad: bool, want_w: bool, start=None, inj_x=None, inj_y=None):
+    def _backward(self, s: _Saved, g_img, need_input_grad: bool, want_w: bool, start=None, inj_x=None, inj_y=None,
+                  tw=None):
         """g_img = gradient of the output image, or None for a partial pass that starts at node `start` and is driven
         only by injected gradients: inj_x[i] / inj_y[i] = dense gradients w.r.t. the output / raw conv output of
-        node i (feature taps of CUT's PatchNCE loss)."""
+        node i (feature taps of CUT's PatchNCE loss).
+        tw: the pass recorded by _forward(..., tw) — g_img holds one gradient per input part (None = that part's output took
+        no part in the loss), the gradients of images [N/2, N) go to tw's flat gradient buffer, and the input gradients come
+        back as a tuple, one per part."""
         inj_x, inj_y = inj_x or {}, inj_y or {}
         ops, dev = self.ops, self.device
         nodes, lows, N = self.nodes, s.lows, s.N
-        if self.master.grad is None:
-            self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        pk = self._get_packs(*s.x_img.shape[2:])
-        grad = self.master.grad
+        x_imgs = s.x_img if tw is not None else (s.x_img,)
+        Nh = N // 2 if tw is not None else N        # images per network
+        for net in (self, tw):
+            if net is not None and net.master.grad is None:
+                net.master.grad = torch.zeros(net.numel, dtype=torch.float32, device=dev)
+        pk = self._get_packs(*x_imgs[0].shape[2:])
+        grad, dpack_all = self.master.grad, pk["dpack"]
+        if tw is not None:
+            grad = Twin(grad, tw.master.grad)
+            dpack_all = Twin(dpack_all, tw._get_packs(*x_imgs[0].shape[2:])["dpack"])
         last = len(nodes) - 1 if start is None else start
         # gradient w.r.t. the output of node i: (tensor on padded domain, fold, extra, pad mode of the fold)
         pending = None
         if g_img is not None:
             ga = torch.empty_like(s.acts[-1])
-            if nodes[-1].spec.wfold == "out":
-                ops.shiftadd_to_image_backward(g_img.contiguous().float(), s.out_img, ga, nodes[-1].spec.k,
-                                               act=self.out_act)
-            else:
-                ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, ga, act=self.out_act)
+            n0 = 0
+            for gh, xh in zip(g_img if tw is not None else (g_img,), x_imgs):     # one gradient per input part
+                gah, outh = ga[n0:n0 + xh.shape[0]], s.out_img[n0:n0 + xh.shape[0]]
+                n0 += xh.shape[0]
+                if gh is None:           # this part's output took no part in the loss
+                    gah.zero_()
+                elif nodes[-1].spec.wfold == "out":
+                    ops.shiftadd_to_image_backward(gh.contiguous().float(), outh, gah, nodes[-1].spec.k, act=self.out_act)
+                else:
+                    ops.act_to_image_backward(gh.contiguous().float(), outh, gah, act=self.out_act)
             pending = (ga, 0, None, "reflect")
         skip: Dict[int, torch.Tensor] = {}
         db_items = []        # bias gradients of the convs in front of norms: one batched launch at the end of the pass
@@ -530,11 +562,21 @@ class NativeNet:
                     # the bias gradient of a conv in front of an InstanceNorm comes out of the norm's reduction sums
                     db = grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
                     # (data parallel, bucketed: the bucket holding db is all-reduced as soon as this layer is done -> inline)
+                    inline_db = final_pass and tw is None
                     sums = ops.inorm_act_backward(g_pad, g2, s.ys[i], s.mrs[i], dy, gsum, fold=fold, fold_mode=fmode,
-                                                  act=nd.act, slope=nd.slope, bias_grad=db if final_pass else None,
+                                                  act=nd.act, slope=nd.slope, bias_grad=db if inline_db else None,
                                                   pre=pre)
-                    if db is not None and not final_pass:
-                        db_items.append((sums[0], sums[1], s.mrs[i], db, N, sp.cout_p, lw.out_pixels))
+                    if db is not None and not inline_db:
+                        if tw is None:
+                            items = [(sums[0], sums[1], s.mrs[i], db, N, sp.cout_p, lw.out_pixels)]
+                        else:        # the per-image totals / statistics of the two halves lie behind each other
+                            hm = s.mrs[i].numel() // 2
+                            items = [(sums[0], sums[1] + h * Nh * 3 * sp.cout_p, s.mrs[i][h * hm:(h + 1) * hm],
+                                      db.half(h), Nh, sp.cout_p, lw.out_pixels) for h in (0, 1)]
+                        if final_pass:       # (bucketed reduction: this layer's bucket may be reduced right behind it)
+                            ops.norm_bias_grads(items)
+                        else:
+                            db_items += items
                 else:
                     ops.inorm_act_backward(g_pad, g2, x_out, None, dy, gsum, fold=fold, fold_mode=fmode, act=nd.act,
                                            slope=nd.slope)
@@ -554,8 +596,8 @@ class NativeNet:
                 dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
                 a_t, g_t = (dy, s.acts[i]) if sp.kind == "conv" else (s.acts[i], dy)
                 held = self._deferred.pop(i, None)
-                if held is not None and (held[0] is not lw.wgrad or held[1].shape != a_t.shape):
-                    ops.wgrad(held[0], held[1], held[2], dw)      # other input size: cannot share a launch
+                if held is not None and (held[0] is not lw.wgrad or held[1].shape != a_t.shape or held[3] is not tw):
+                    self._flush_held(i, held)     # other input size / other twin partner: cannot share a launch
                     held = None
                 if held is not None:
                     if dev.type == "cuda":      # the other pass may have run (and allocated) on another stream
@@ -563,23 +605,30 @@ class NativeNet:
                         held[2].record_stream(torch.cuda.current_stream())
                     ops.wgrad(lw.wgrad, a_t, g_t, dw, pair=(held[1], held[2]))
                 elif more_passes and ops.can_merge_wgrad(lw.wgrad):
-                    self._deferred[i] = (lw.wgrad, a_t, g_t)
+                    self._deferred[i] = (lw.wgrad, a_t, g_t, tw)
                 else:
                     ops.wgrad(lw.wgrad, a_t, g_t, dw)
                 if sp.bias and not nd.norm:
-                    if sp.wfold == "out":   # channels [0, cout) of dy are the dw = 0 slice = the plain output gradient
-                        tmp = torch.zeros(sp.cout_p, dtype=torch.float32, device=dev)
-                        ops.bias_grad(dy, sp.cout_p, tmp)
-                        grad[self.b_off[i]:self.b_off[i] + sp.cout] += tmp[:sp.cout]
-                    else:
-                        ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
+                    for h in range(N // Nh):
+                        gh_ = grad.half(h) if tw is not None else grad
+                        dyh = dy[h * Nh:(h + 1) * Nh]
+                        if sp.wfold == "out":   # channels [0, cout) of dy are the dw = 0 slice = the plain output gradient
+                            tmp = torch.zeros(sp.cout_p, dtype=torch.float32, device=dev)
+                            ops.bias_grad(dyh, sp.cout_p, tmp)
+                            gh_[self.b_off[i]:self.b_off[i] + sp.cout] += tmp[:sp.cout]
+                        else:
+                            ops.bias_grad(dyh, sp.cout_p, gh_[self.b_off[i]:self.b_off[i] + sp.cout_p])
                 self.grad_dirty = True
+                if tw is not None:
+                    tw.grad_dirty = True
                 if final_pass:
                     self._maybe_reduce_bucket(i)
+                    if tw is not None:
+                        tw._maybe_reduce_bucket(i)
             # ---- data gradient ------------------------------------------------------------------------------------------
             if i > 0 or need_input_grad:
                 f = lw.dgrad_fold
-                dpack = pk["dpack"][pk["d_off"][i]:]
+                dpack = dpack_all[pk["d_off"][i]:]
                 g2n = skip.pop(i - 1, None)
                 fmode_n = sp.pad_mode if f else "reflect"
                 # the reduction pass of the previous layer's InstanceNorm backward rides in this launch's epilogue
@@ -620,13 +669,17 @@ class NativeNet:
         if not need_input_grad:
             return None
         gx, f, _, fmode = pending[:4]
-        g_in = torch.empty_like(s.x_img)
         sp0 = nodes[0].spec
-        if sp0.wfold == "in":
-            ops.image_unfold_backward(gx, g_in, sp0.k, sp0.pad, f, sp0.pad_mode)
-        else:
-            ops.image_to_act_backward(gx, g_in, fold=f, fold_mode=fmode)
-        return g_in
+        g_ins, n0 = [], 0
+        for xh in x_imgs:
+            g_in, gxh = torch.empty_like(xh), gx[n0:n0 + xh.shape[0]]
+            n0 += xh.shape[0]
+            if sp0.wfold == "in":
+                ops.image_unfold_backward(gxh, g_in, sp0.k, sp0.pad, f, sp0.pad_mode)
+            else:
+                ops.image_to_act_backward(gxh, g_in, fold=f, fold_mode=fmode)
+            g_ins.append(g_in)
+        return tuple(g_ins) if tw is not None else g_ins[0]
 
     # ---- data parallelism (reference: DistributedDataParallel per network, base.py:172-189) -------------
     def parallelize(self, process_group=None, bucket_bytes=8 << 20):
@@ -657,11 +710,18 @@ class NativeNet:
         self._reduce_handles.append(h)
         self._reduced_buckets.add(i)
 
+    def _flush_held(self, i, held):
+        wd, a_t, g_t, tw = held
+        grad = self.master.grad if tw is None else Twin(self.master.grad, tw.master.grad)
+        self.ops.wgrad(wd, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + self.nodes[i].spec.master_numel])
+
     def flush_deferred_wgrads(self):
         """weight gradients held back for a merged launch whose partner pass never came"""
-        for i, (wd, a_t, g_t) in sorted(self._deferred.items()):
-            sp = self.nodes[i].spec
-            self.ops.wgrad(wd, a_t, g_t, self.master.grad[self.w_off[i]:self.w_off[i] + sp.master_numel])
+        lead = getattr(self, "_twin_lead", None)      # second network of a TwinNet: its share is held by the first
+        if lead is not None:
+            lead.flush_deferred_wgrads()
+        for i, held in sorted(self._deferred.items()):
+            self._flush_held(i, held)
         self._deferred = {}
 
     def finish_grad_reduction(self) -> float:

@@ -14,10 +14,13 @@ patchgan2d.py:29,36-62), nn.InstanceNorm2d(eps=1e-5, affine=False) (nn/utils.py:
 Pinned against torch.nn.functional in tests/test_lowering_cpu.py and, through the network-level oracle
 (oracle/torch_ref.py), against golden vectors generated from the imported reference (tests/golden/).
 """
+import functools
 import math
 
 import torch
 import torch.nn.functional as F
+
+from ganslate_amd.nn.native.twin import TwinSplit, is_twin      # the oracle may import the product, never the reverse
 
 
 def _border(idx, n, mode):
@@ -73,8 +76,9 @@ def _fold(gpad, dims, fold, mode="reflect"):
     return out
 
 
-class RefOps:
-    """Same method names and argument conventions as HipOps, CPU tensors."""
+class RefOps(TwinSplit):
+    """Same method names and argument conventions as HipOps, CPU tensors. Twin arguments (two networks over one batch,
+    ganslate_amd/nn/native/twin.py) always run as the two halves."""
     name = "oracle"
     device = torch.device("cpu")
 
@@ -119,6 +123,10 @@ class RefOps:
                       stats_slots=0, stats_slot0s=None, accumulate=False, fuse=None):
         """the output-parity classes of one layer, one after the other (what gs_gconv_forward_multi merges); with `fuse`
         (gs_gconv_forward_multi_fused) followed by the consumer's norm-backward sums over the finished gradient"""
+        if is_twin(wpack, bias):
+            return self.twin_gconv(functools.partial(self.gconv_classes, classes), x, wpack, bias, out, in_co=in_co,
+                                   out_co=out_co, act=act, slope=slope, stats=stats, stats_slots=stats_slots,
+                                   stats_slot0s=stats_slot0s, accumulate=accumulate, fuse=fuse, C_=classes[0].Co)
         for i, g in enumerate(classes):
             self.gconv(g, x, wpack, bias, out, in_co=in_co, out_co=out_co, act=act, slope=slope, stats=stats,
                        stats_slots=stats_slots, stats_slot0=(stats_slot0s[i] if stats_slot0s else 0),
@@ -139,6 +147,11 @@ class RefOps:
 
     def gconv(self, g, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none", slope=0.2,
               stats=None, stats_slots=0, stats_slot0=0, accumulate=False, fuse=None):
+        if is_twin(wpack, bias):
+            return self.twin_gconv(functools.partial(self.gconv, g), x, wpack, bias, out, in_cs=in_cs, in_co=in_co,
+                                   out_cs=out_cs, out_co=out_co, act=act, slope=slope, stats=stats,
+                                   stats_slots=stats_slots, stats_slot0=stats_slot0, accumulate=accumulate, fuse=fuse,
+                                   C_=g.Co)
         N = x.shape[0]
         xin = _v5(x)[..., in_co:in_co + g.Ci].float()
         Wt = wpack[g.pack_offset:g.pack_offset + g.w_rows * g.Kp].view(g.w_rows, g.Kp).float()
@@ -199,6 +212,8 @@ class RefOps:
                     for k in range(3) for t in range(9)))
 
     def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
+        if is_twin(dw):
+            return self.twin_wgrad(w, a, g, dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co, pair=pair)
         if pair is not None:
             self.wgrad(w, pair[0], pair[1], dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co)
         av = _v5(a)[..., a_co:a_co + w.P].float()
@@ -216,6 +231,8 @@ class RefOps:
             d[:, t, :] += torch.einsum("nzijp,nzijq->pq", av, patch)
 
     def bias_grad(self, dy, C_, db, *, cs=None, co=0):
+        if is_twin(db):
+            return self.twin_bias_grad(dy, C_, db, cs=cs, co=co)
         db[:C_] += dy[..., co:co + C_].float().reshape(-1, C_).sum(0)
 
     # ---- InstanceNorm + activation -------------------------------------------------------------------
@@ -486,6 +503,8 @@ class RefOps:
             g_img.copy_(out)
 
     def shiftadd_to_image(self, z, bias, img, k, act="none"):
+        if is_twin(bias):
+            return self.twin_shiftadd_to_image(z, bias, img, k, act=act)
         Co, W = img.shape[1], img.shape[-1]
         acc = torch.zeros(*img.shape[:1], *img.shape[2:], Co)
         for dw in range(k):
