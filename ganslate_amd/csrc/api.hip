@@ -72,6 +72,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconvw_ring_waves", 16},  // 16 or 8 waves for the fused data gradient of the wide 3x3 layers (hconvw.hip RING)
     {"hstrip_persist", 0},      // hstrip.hip: smallest number of tiles the persistent double-buffered form takes, 0 = off (default:
                                 // measured 62-74 us against 42-55 for one workgroup per tile, two per CU)
+    {"hconvw_persist", 1},      // hconvw.hip: launches with more tiles than CUs run ceil(tiles / CUs) tiles per workgroup (0: one each)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -66,6 +66,16 @@ template <int N>
 __device__ __forceinline__ void gs_lgkm_wait_only() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ __forceinline__ void reg_fence(bf16x8& x) { asm volatile("" : "+v"(x)); }
 
+// Workgroup barrier for data exchanged through LDS that does NOT drain the vector-memory counter: __syncthreads() carries
+// a release fence, and with an LDS-DMA (or, in a persistent kernel, the previous tile's output stores) in flight that fence
+// waits vmcnt(0). This one waits for this wave's LDS operations only; the "memory" clobbers keep the compiler from moving
+// LDS accesses across it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // 64-bit transpose read (pixel-major operands of the weight-gradient kernels): 4 bf16 of one k-column per lane
 template <int OFF>
 __device__ __forceinline__ void lds_read64_tr(uint2& v, unsigned addr) {
@@ -153,7 +163,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum GsOpt {
   GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE, GS_OPT_HCONVW_WAVES,
   GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL,
-  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_HCONVX, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONV_PERSIST, GS_OPT_HCONVW_RING_WAVES, GS_OPT_HSTRIP_PERSIST,
+  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_HCONVX, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONV_PERSIST, GS_OPT_HCONVW_RING_WAVES, GS_OPT_HSTRIP_PERSIST, GS_OPT_HCONVW_PERSIST,
   GS_OPT_COUNT
 };
 int gs_opt(int id);

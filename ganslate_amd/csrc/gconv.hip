@@ -651,9 +651,9 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
 // hconvw.hip: halo-resident forward kernel for the wide 3x3 stride-1 layers
 int gs_hconvw_slots(const gs_gconv_desc* d);
 int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
-                  void* stream, int* handled);
+                  const gs_twin* tw, void* stream, int* handled);
 int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, void* out, const gs_gconv_fuse* fuse,
-                   void* stream);
+                   const gs_twin* tw, void* stream);
 // hstrip.hip: W-folded k7 boundary convs (vertical taps, <= 64 channels) out of a resident input strip
 int gs_hstrip_slots(const gs_gconv_desc* d);
 int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
@@ -679,7 +679,8 @@ extern "C" int gs_gconv_stat_slots(const gs_gconv_desc* d) {
 }
 
 static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
-                              float* stats, const gs_gconv_fuse* fuse, float* ws, int64_t ws_floats, void* stream);
+                              float* stats, const gs_gconv_fuse* fuse, float* ws, int64_t ws_floats, void* stream,
+                              const gs_twin* tw = nullptr);
 
 extern "C" int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                                 void* out, float* stats, void* stream) {
@@ -700,8 +701,30 @@ extern "C" int gs_gconv_forward_ws(const gs_gconv_desc* d, const void* in, const
   return gconv_forward_impl(d, in, w_pack, bias, out, stats, nullptr, ws, ws_floats, stream);
 }
 
+static int gconv_forward_fused_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                                    void* out, float* stats, const gs_gconv_fuse* fuse, void* stream, const gs_twin* tw);
 extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
                                       void* out, float* stats, const gs_gconv_fuse* fuse, void* stream) {
+  return gconv_forward_fused_impl(d, in, w_pack, bias, out, stats, fuse, stream, nullptr);
+}
+
+// ---- twin batches (gs_twin): which launches pick the weight set per image ------------------------------------------------
+extern "C" int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse* fuse) {
+  if (!d || gs_opt(GS_OPT_HCONVX)) return 0;
+  if (fuse) return fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy && gs_gconv_ring_slots(d) > 0;
+  return !gs_hconv_slots(d) && gs_hconvw_slots(d) > 0;
+}
+extern "C" int gs_gconv_forward_twin(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                                     float* stats, const gs_gconv_fuse* fuse, const gs_twin* tw, void* stream) {
+  GS_REQUIRE(d && tw && tw->n_split > 0 && tw->n_split < d->N, "gs_gconv_forward_twin: null argument / empty half");
+  GS_REQUIRE(gs_gconv_twin_native(d, fuse), "gs_gconv_forward_twin: this layer's kernel has no twin form "
+                                            "(gs_gconv_twin_native): run the two halves");
+  if (fuse) return gconv_forward_fused_impl(d, in, w_pack, bias, out, stats, fuse, stream, tw);
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, nullptr, nullptr, 0, stream, tw);
+}
+
+static int gconv_forward_fused_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias,
+                                    void* out, float* stats, const gs_gconv_fuse* fuse, void* stream, const gs_twin* tw) {
   GS_REQUIRE(d && fuse && fuse->y && fuse->mean_rstd && fuse->partial, "gs_gconv_forward_fused: null argument");
   // (si = 2: the data gradient of a transposed conv — a strided gather on the input side; the epilogue only sees output pixels)
   GS_REQUIRE(d->so == 1 && (d->si == 1 || d->si == 2) && !d->accumulate && d->stats_slots == 0 && d->act == GS_ACT_NONE &&
@@ -711,15 +734,17 @@ extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, co
   if (fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy) {
     // unpadded output domain: the launch applies the pad adjoint itself (hconvw.hip RING; gs_gconv_ring_slots says when)
     GS_REQUIRE(in && w_pack && out && !bias, "gs_gconv_forward_fused: null argument / bias on a data-gradient launch");
-    return gs_hconvw_ring(d, in, w_pack, out, fuse, stream);
+    return gs_hconvw_ring(d, in, w_pack, out, fuse, tw, stream);
   }
+  GS_REQUIRE(!tw, "gs_gconv_forward_twin: the padded-domain fused launch has no twin form");
   GS_REQUIRE(d->Do == fuse->Dy + 2 * fd && d->Ho == fuse->Hy + 2 * fuse->fold && d->Wo == fuse->Wy + 2 * fuse->fold,
              "gs_gconv_forward_fused: output domain must be the norm's domain padded by `fold`");
   return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, nullptr, 0, stream);
 }
 
 static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
-                              float* stats, const gs_gconv_fuse* fuse, float* ws, int64_t ws_floats, void* stream) {
+                              float* stats, const gs_gconv_fuse* fuse, float* ws, int64_t ws_floats, void* stream,
+                              const gs_twin* tw) {
   GS_REQUIRE(d && in && w_pack && out, "gs_gconv_forward: null argument");
   GS_REQUIRE(d->Ci >= 8 && (d->Ci & 7) == 0 && ((d->Ci >> 3) & ((d->Ci >> 3) - 1)) == 0,
              "gs_gconv_forward: Ci=%d must be 8*2^k", d->Ci);
@@ -737,10 +762,13 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
              "gs_gconv_forward: accumulate excludes bias, activation and statistics");
   if (!fuse) {
     int handled = 0;
-    if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
+    if (!tw) {
+      if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
+      if (handled) return 0;
+    }
+    if (int rc = gs_hconvw_try(d, in, w_pack, bias, out, stats, tw, stream, &handled)) return rc;
     if (handled) return 0;
-    if (int rc = gs_hconvw_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
-    if (handled) return 0;
+    GS_REQUIRE(!tw, "gs_gconv_forward_twin: this layer's kernel has no twin form");
     if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
     if (handled) return 0;
   }

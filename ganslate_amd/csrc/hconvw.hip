@@ -15,26 +15,6 @@
 
 #include "hconvw.hpp"
 
-#ifdef GS_TIMELINE
-// Debug build only (tools/probe/timeline.py, never the product library): s_memtime stamps of one workgroup's phases, kept in
-// the 9 KiB of LDS the kernel leaves free and dumped to a global buffer at the end. TLW waves x TLS slots of 32 bits.
-__device__ unsigned* g_tl_buf = nullptr;
-extern "C" int gs_debug_timeline(void* buf) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
-}
-constexpr int TLW = 8, TLS = 160;
-#define TL_STAMP(slot)                                                                            \
-  do {                                                                                            \
-    if (tl_on) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                      \
-      if (lane == 0) tl[tl_w * TLS + (slot)] = t_; }                                              \
-  } while (0)
-#else
-#define TL_STAMP(slot) do {} while (0)
-#endif
-
-// NW = 16: waves as 4 x 4, 64 pixels x 32 channels each; NW = 8: 4 x 2, 64 x 64 each (a third fewer fragment reads per
-// MFMA — the loop is bound by LDS reads — for half the latency hiding)
-//
 // RING: data gradient of a reflect-padded (pad 1) 3x3 conv on the UNPADDED domain (resnet2d.py:80-87 backward). With
 // C(u) = sum_t dY[u + off_t] W_t the zero-border conv on the extended domain u in [-1, H] x [-1, W], the gradient is
 // dX[v] = sum over {u : reflect(u) = v} C(u): the box itself plus, for boxes on the image border, the ring pixels one
@@ -46,8 +26,22 @@ constexpr int TLW = 8, TLS = 160;
 // gconv_kernel runs this layer on the 66 x 66 padded domain instead (+6 % pixels, 288-pixel im2col tiles: 59 us
 // vs 41 here) and leaves the fold to the consumer. The epilogue is gs_gconv_forward_fused's: per-box sums of the
 // consumer's InstanceNorm backward.
-template <int T, int NW = 16, bool RING = false>
-__global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
+//
+// PERSISTENT, SEVERAL TILES PER WORKGROUP (round 4). A launch over 2N images — the same layer of the two generators of a
+// CycleGAN phase as one twin batch, p.nsplit / p.w_delta / p.bias_delta select the weight set per image — has 512 tiles
+// for 256 CUs. Workgroup b walks tiles b, b + gridDim.x, ...: the K-step sequence simply continues — the weight ring and
+// the two halo buffers are fed with the NEXT tile's first chunk / first K-steps while the current tile's last chunk
+// computes — so only the first tile of a workgroup pays the 9k-cycle prologue, and a tile's stores are issued and never
+// waited for: they drain under the next tile's K loop (profiles/r03_hconvw_timeline.txt: prologue 9.2k + epilogue 10.2k of
+// 84k cycles per launch, plus the launch ramp between launches). At a tile boundary the two wave groups of the loop are
+// brought back into step (one barrier), the epilogue runs out of the ONE halo buffer that is free at that point (two
+// passes of 32 pixels through 40 KiB instead of one through 80), and the phase shift is set up again.
+// vmcnt bookkeeping across the boundary (per wave, VMEM retires in issue order): the epilogue's 4 output stores sit between
+// the next tile's K-step-2 weights (issued before them) and its chunk-1 halo (after); the first two waits of the new tile
+// leave exactly those younger operations outstanding.
+template <int T, bool RING = false>
+__global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
+  constexpr int NW = 16;
   constexpr int BM = 256, BN = 128, WM = 4, WN = NW / 4;
   constexpr int WT = BN * 128;                   // weight stage: 128 rows x 64 k
   constexpr int HP = 160;                        // halo voxel pitch: 8 channel pieces of 16 B + 2 pad pieces. 40 banks: the
@@ -61,143 +55,129 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
   constexpr int WPI = 16 / NW;                   // weight DMA instructions per wave per K-step (8 rows each)
   constexpr int TI = BN / WN / 16, TJ = 4;
   constexpr int CWV = TI * 16;                   // output channels per wave
+  constexpr int NST = 4;                         // output stores per wave per tile (a lower bound is all the waits need)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wring = smem;                            // 3 x 16 KiB
   char* hbuf = smem + 3 * WT;                    // 2 x 51 KiB
   char* sink = hbuf + 2 * HBUF;                  // 1 KiB
+  char* spare = sink + 1024;                     // 9 KiB: the halo source table (8 KiB)
   const gs_gconv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-#ifdef GS_TIMELINE
-  unsigned* tl = reinterpret_cast<unsigned*>(smem + 3 * WT + 2 * HBUF + 1024);
-  const int tl_w = NW == 8 ? wave : ((wave & 3) | ((wave >> 3) << 2));          // NW 16: waves 0-3 and 8-11
-  const bool tl_on = g_tl_buf != nullptr && (NW == 8 || (wave & 4) == 0);
-  TL_STAMP(0);
-#endif
-  int b;
+  // Workgroup b walks tiles b, b + gridDim.x, ...; the launcher makes gridDim.x a multiple of the tiles per image, so every
+  // tile of a workgroup is the SAME box and channel tile of another image: all per-lane state (DMA source offsets, ring
+  // jobs, epilogue coordinates) is built once, a tile only changes the image (two base pointers).
+  int b0;
+  const int nwg = gridDim.x;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    b0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
-  const int nt = b % p.tiles_n;
-  b /= p.tiles_n;
-  const int mt = b % p.tiles_m;
-  const int n = b / p.tiles_m;
+  const int ntl = (p.ntiles - b0 + nwg - 1) / nwg;          // tiles of this workgroup
+  const int tpi = p.tiles_m * p.tiles_n;
+  const int nt = b0 % p.tiles_n, mt = (b0 / p.tiles_n) % p.tiles_m, n0 = b0 / tpi;
+  const int nstep = nwg / tpi;                              // images between two tiles of a workgroup (ntl > 1 only)
   const int oy0 = (mt / p.nbw) * 16, ox0 = (mt % p.nbw) * 16;
 
-  // ---- halo pieces of this thread (box-invariant, resolved once): source byte offset of channel chunk 0, or -1 ----
-  const char* in_n = p.in + ((size_t)n * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
-  int hsrc[HPW];
-#pragma unroll
-  for (int i = 0; i < HPW; ++i) {
-    const int q = (i * NW + wave) * 64 + lane;   // wave-instruction i*16+wave covers pieces [inst*64, inst*64+64)
-    const int v = q / 10, part = q - v * 10;
-    const int hy = v / p.hw, hx = v - hy * p.hw;
-    bool ok = q < HPIECES && part < 8;
-    int iy = border_index(oy0 + hy + p.hmin, d.Hi, d.border, ok);
-    int ix = border_index(ox0 + hx + p.wmin, d.Wi, d.border, ok);
-    iy = min(max(iy, 0), d.Hi - 1);
-    ix = min(max(ix, 0), d.Wi - 1);
-    hsrc[i] = ok ? ((iy * d.Wi + ix) * d.in_cs + part * 8) * 2 : -1;
-  }
-  auto issue_halo = [&](int chunk, int buf) {
+  // ---- halo pieces of this thread (box-invariant, resolved once) --------------------------------------------------------
+  // piece = 16 B of one halo voxel; its source is pixel (ry, rx) of the 18 x 18 window around the box AFTER border handling
+  // (reflect / clamp keep it inside the window) and channel piece `part`. Kept as 4 x 16 bits per thread in LDS —
+  // ok << 15 | part << 10 | ry << 5 | rx — and read back once per chunk: four registers less in a loop that has none to spare.
+  const size_t img_bytes = (size_t)d.Hi * d.Wi * d.in_cs * 2;
+  {
+    unsigned short* htab = reinterpret_cast<unsigned short*>(spare) + tid * HPW;
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
-      unsigned off = (unsigned)hsrc[i] + (unsigned)chunk * 128u;
+      const int q = (i * NW + wave) * 64 + lane;   // wave-instruction i*16+wave covers pieces [inst*64, inst*64+64)
+      const int v = q / 10, part = q - v * 10;
+      const int hy = v / 18, hx = v - hy * 18;
+      bool ok = q < HPIECES && part < 8;
+      int iy = border_index(oy0 + hy + p.hmin, d.Hi, d.border, ok);
+      int ix = border_index(ox0 + hx + p.wmin, d.Wi, d.border, ok);
+      iy = min(max(iy, 0), d.Hi - 1) - (oy0 + p.hmin);
+      ix = min(max(ix, 0), d.Wi - 1) - (ox0 + p.wmin);
+      htab[i] = (unsigned short)(ok ? (0x8000 | (part << 10) | (iy << 5) | ix) : 0);
+    }
+  }
+  const unsigned htab0 = lds_addr(spare);
+  // window origin of the box (may lie one pixel outside the image: only added to offsets of pixels inside it)
+  const long long box0 = (((long long)(oy0 + p.hmin) * d.Wi + (ox0 + p.wmin)) * d.in_cs + d.in_co) * 2;
+  auto issue_halo = [&](int n, int chunk, int buf) {        // image n
+    const char* in_b = p.in + (size_t)n * img_bytes + box0 + chunk * 128;
+    uint2 e;
+    unsigned ta = (unsigned)tid;
+    asm volatile("" : "+v"(ta));                // (address rebuilt per use: one register less across the loop)
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(htab0 + ta * (HPW * 2)) : "memory");
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+      const unsigned ent = ((i & 2) ? e.y : e.x) >> ((i & 1) * 16) & 0xffffu;
+      unsigned off = (((ent >> 5) & 31u) * (unsigned)d.Wi + (ent & 31u)) * (unsigned)(d.in_cs * 2) + ((ent >> 10) & 15u) * 16u;
       asm volatile("" : "+v"(off));
-      const char* src = hsrc[i] >= 0 ? in_n + off : p.zero;
+      const char* src = (ent & 0x8000u) ? in_b + off : p.zero;
       const int inst = i * NW + wave;
       glds16(src, inst < HINSTR ? hbuf + buf * HBUF + inst * 1024 : sink);
     }
   };
   // ---- weight stage: one LDS-DMA instruction per wave (128 rows x 8 pieces), rows swizzled like gconv_kernel ----
-  const int lrow = lane >> 3;
-  const int wchunk = (lane & 7) ^ lrow;
-  const char* wsrc[WPI];
-  int winc[WPI];                                 // bytes per 8-k piece step
+  // (every row exists: Co is a multiple of 128 and the pack holds at least Co rows, see hconvw_eligible)
+  unsigned wsrc[WPI];                            // byte offset of this lane's 16-B piece of K-step 0 inside the pack
+  {
+    const int lrow = lane >> 3, wchunk = (lane & 7) ^ lrow;
 #pragma unroll
-  for (int i = 0; i < WPI; ++i) {
-    const int wco = nt * BN + (wave * WPI + i) * 8 + lrow;
-    const bool wv = wco < d.w_rows;
-    wsrc[i] = wv ? p.w + ((size_t)wco * d.Kp + wchunk * 8) * 2 : p.zero;
-    winc[i] = wv ? 16 : 0;
+    for (int i = 0; i < WPI; ++i)
+      wsrc[i] = (unsigned)(((nt * BN + (wave * WPI + i) * 8 + lrow) * d.Kp + wchunk * 8) * 2);
   }
-  auto issue_w = [&](int c, int t, int buf) {
-    const int q0 = (t * (d.Ci >> 3)) + c * 8;    // first 8-k piece of this K-step inside a pack row (tap-major pack)
+  auto issue_w = [&](int n, int c, int t, int buf) {        // image n picks the network in a twin batch
+    const char* wbase = p.w + (n >= p.nsplit ? p.w_delta : 0);
+    const unsigned q0 = (unsigned)((t * (d.Ci >> 3)) + c * 8) * 16u;   // first 8-k piece of this K-step (tap-major pack)
 #pragma unroll
-    for (int i = 0; i < WPI; ++i) glds16(wsrc[i] + (size_t)q0 * winc[i], wring + buf * WT + (wave * WPI + i) * 1024);
+    for (int i = 0; i < WPI; ++i) {
+      unsigned off = wsrc[i];
+      asm volatile("" : "+v"(off));             // (keeps the compiler from holding one address per tap in registers)
+      off += q0;
+      glds16(wbase + off, wring + buf * WT + (wave * WPI + i) * 1024);
+    }
   };
 
   const int wm = wave / WN, wn = wave % WN;
-  const int frow = lane & 15, fk = lane >> 4, swz = lane & 7;
-  int rowb[TJ];                                  // halo byte offset of this lane's pixel in box row wm*4+j, k-chunk fk
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) rowb[j] = ((wm * 4 + j) * p.hw + frow) * HP + fk * 16;
   int tb[T];                                     // tap byte offsets inside the halo
 #pragma unroll
-  for (int t = 0; t < T; ++t) tb[t] = (((int)d.dh[t] - p.hmin) * p.hw + ((int)d.dw[t] - p.wmin)) * HP;
+  for (int t = 0; t < T; ++t) tb[t] = (((int)d.dh[t] - p.hmin) * 18 + ((int)d.dw[t] - p.wmin)) * HP;
 
   f32x4 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // ---- RING: this wave's ring fragment (lane frow = one ring pixel), its taps and its slot in the ring buffer ----
-  // taps come in the data-gradient order t = 3*ry + rx with (dh, dw) = (1 - ry, 1 - rx) (checked by the launcher)
-  [[maybe_unused]] const bool e_top = oy0 == 0, e_bot = oy0 + 16 == d.Ho, e_lef = ox0 == 0, e_rig = ox0 + 16 == d.Wo;
-  [[maybe_unused]] unsigned e_mask = 0;          // wave-uniform: taps that reach the image from this wave's ring pixels
-  [[maybe_unused]] int e_rb = 0, e_slot = 0;
-  [[maybe_unused]] bool e_lane = true;           // false: this lane carries no ring pixel (reads the zero sink)
   [[maybe_unused]] f32x4 accE[TI];
-  if constexpr (RING) {
-#pragma unroll
-    for (int i = 0; i < TI; ++i) accE[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int py = 0, px = 0, sy = 0, sx = 0;          // ring pixel of lane frow: (py + sy*frow, px + sx*frow), box coordinates
-    const bool side = e_lef || e_rig;
-    if (wm == 0) {
-      if (e_top) { e_mask = 0x007u; py = -1; sx = 1; e_slot = 0; }
-      else if (e_bot && side) { e_mask = e_lef ? 0x040u : 0x100u; py = 16; px = e_lef ? -1 : 16; e_lane = frow == 0; e_slot = 4; }
-    } else if (wm == 3) {
-      if (e_bot) { e_mask = 0x1C0u; py = 16; sx = 1; e_slot = 1; }
-      else if (e_top && side) { e_mask = e_lef ? 0x001u : 0x004u; py = -1; px = e_lef ? -1 : 16; e_lane = frow == 0; e_slot = 4; }
-    } else if (wm == 1) {
-      if (e_lef) { e_mask = 0x049u; px = -1; sy = 1; e_slot = 2; }
-    } else {
-      if (e_rig) { e_mask = 0x124u; px = 16; sy = 1; e_slot = 3; }
-    }
-    e_mask = __builtin_amdgcn_readfirstlane(e_mask);
-    e_rb = ((py + sy * frow) * p.hw + (px + sx * frow)) * HP + fk * 16;
-  }
 
   // ---- main loop: chunks x taps, software-pipelined over half K-steps --------------------------------------------
-  // Weights run 3 K-steps ahead in a 3-slot ring, halo boxes 2 chunks ahead in 2 buffers. Inside a K-step the fragment
-  // reads of the second half are issued before the MFMAs of the first, and the reads of the NEXT step's first half
-  // (after the one barrier per K-step) before the MFMAs of the second: LDS latency hides under the matrix pipe.
+  // Weights run 3 K-steps ahead in a 3-slot ring, halo boxes 2 chunks ahead in 2 buffers. Fragment reads go through
+  // lds_read128 (common.hpp): the compiler would wait lgkmcnt(0) before every MFMA block because of the LDS-DMA in the loop.
   const int nk = p.chunks * T;
-  // Fragment reads go through lds_read128 (common.hpp): the compiler would wait lgkmcnt(0) before every MFMA block
-  // because of the LDS-DMA in the loop; here block A waits with lgkmcnt(TI + TJ), i.e. only for ITS fragments while the
-  // TI + TJ reads of block B issued after them are still in flight.
   const unsigned smem0 = lds_addr(smem);
-  const unsigned woff = (unsigned)((wn * CWV + frow) * 128);
-  const unsigned c0 = (unsigned)(((0 * 4 + fk) ^ swz) << 4), c1 = (unsigned)(((1 * 4 + fk) ^ swz) << 4);
+  // Fragment addresses and the ring job are derived from an opaque copy of the lane id at the top of every tile, the
+  // epilogue's coordinates from another one: the compiler then REBUILDS them (a few VALU) instead of keeping the K loop's
+  // address registers alive across the epilogue and the epilogue's across the loop — 128 registers per lane is all a
+  // 16-wave workgroup has, and a spill reload in the loop would wait vmcnt(0) behind the DMA stream.
+  int rowb;                                      // halo byte offset of this lane's pixel in box row wm*4, k-chunk fk (the
+                                                 // wave's other three rows and the second k-half are immediate offsets)
+  unsigned woff, c0;
+  int frow, fk;
+  static_assert(3 * 18 * HP + 64 + 16 <= 65535, "row offsets must fit the ds_read immediate");
   auto load_frags = [&](unsigned wb, unsigned xb, auto kk_tag, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
     constexpr int kk = decltype(kk_tag)::value;
-    const unsigned wa = wb + (kk ? c1 : c0);
+    const unsigned wa = wb + (kk ? (c0 ^ 64u) : c0);      // 16-B slot (kk * 4 + fk) ^ swz
     lds_read128<0>(wf[0], wa);
     lds_read128<2048>(wf[1], wa);
-    if constexpr (TI == 4) { lds_read128<4096>(wf[2], wa); lds_read128<6144>(wf[3], wa); }
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) lds_read128<kk * 64>(xf[j], xb + (unsigned)rowb[j]);
+    const unsigned xa = xb + (unsigned)rowb;
+    lds_read128<0 * 18 * HP + kk * 64>(xf[0], xa);
+    lds_read128<1 * 18 * HP + kk * 64>(xf[1], xa);
+    lds_read128<2 * 18 * HP + kk * 64>(xf[2], xa);
+    lds_read128<3 * 18 * HP + kk * 64>(xf[3], xa);
   };
-  auto wait_frags = [&](auto n_tag, bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
-    constexpr int n = decltype(n_tag)::value;
-    if constexpr (TI == 2) gs_lgkm_wait<n>(wf[0], wf[1], xf[0], xf[1], xf[2], xf[3]);
-    else gs_lgkm_wait<n>(wf[0], wf[1], wf[2], wf[3], xf[0], xf[1], xf[2], xf[3]);
+  auto wait_frags = [&](bf16x8 (&wf)[TI], bf16x8 (&xf)[TJ]) {
+    gs_lgkm_wait<0>(wf[0], wf[1], xf[0], xf[1], xf[2], xf[3]);
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
-  using NF = std::integral_constant<int, TI + TJ>;
   auto mma = [&](const bf16x8 (&wf)[TI], const bf16x8 (&xf)[TJ]) {
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -206,295 +186,367 @@ __global__ __launch_bounds__(NW * 64) void hconvw_kernel(const HConvWK p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   };
   auto ct_of = [&](int ks, int& c, int& t) { c = ks / T; t = ks - c * T; };
-  // ---- main loop: two wave groups, one phase apart ----------------------------------------------------------------
-  // Measured on the barrier-per-K-step loop this replaces (profiles/r01_hconvw_pmc.txt): matrix pipe busy 45 %, LDS
+  // ---- two wave groups, one phase apart ---------------------------------------------------------------------------
+  // Measured on the barrier-per-K-step loop this replaced (profiles/r01_hconvw_pmc.txt): matrix pipe busy 45 %, LDS
   // array busy 42 %, and a K-step took the SUM of its fragment-read time and its MFMA time — the barrier phase-locks all
-  // 16 waves, so everybody queues on the LDS (SQ_WAIT_INST_LDS 17 % of the wave cycles) and then everybody queues on the
-  // matrix pipe. Here a K-step is two phases separated by barriers, L = issue the 2*(TI+TJ) fragment reads of the step
-  // and wait for them, M = its 2*TI*TJ MFMAs, and the upper half of the waves executes ONE extra barrier up front: from
-  // then on one group is always in L while the other is in M (each SIMD hosts waves of both groups), the LDS and the
-  // matrix pipe work at the same time, and priority is raised for the M phase (cdna_hip_programming.md T3-T5).
+  // 16 waves, so everybody queues on the LDS and then everybody queues on the matrix pipe. Here a K-step is two phases
+  // separated by barriers, L = issue the 2*(TI+TJ) fragment reads of the step and wait for them, M = its 2*TI*TJ MFMAs,
+  // and the upper half of the waves executes ONE extra barrier up front: from then on one group is always in L while the
+  // other is in M (each SIMD hosts waves of both groups), and priority is raised for the M phase.
   // LDS-DMA: weights of step ks+2 go into the slot of step ks-1 at the start of L(ks) (that slot's last reader finished
   // a phase ago), the halo of chunk c+1 into the buffer of chunk c-1 at the first L of chunk c; a wave waits for its
   // share of step ks+1's weights at the end of the last phase before the first reader (group 0: end of M(ks), group 1:
   // end of L(ks)) and the barrier that follows publishes it.
   const bool grp = wave >= NW / 2;
-  issue_halo(0, 0);
-  if (p.chunks > 1) issue_halo(1, 1);
+  issue_halo(n0, 0, 0);
+  if (p.chunks > 1) issue_halo(n0, 1, 1);
 #pragma unroll
   for (int s0 = 0; s0 < 3; ++s0)
-    if (s0 < nk) { int c0_, t0; ct_of(s0, c0_, t0); issue_w(c0_, t0, s0); }
+    if (s0 < nk) { int c0_, t0; ct_of(s0, c0_, t0); issue_w(n0, c0_, t0, s0); }
   // halo 0 (and, in order, halo 1) and weights 0 landed; weights 1, 2 may still fly
   if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WPI) : "memory");
   else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  TL_STAMP(1);
   __builtin_amdgcn_s_barrier();
   if (grp) __builtin_amdgcn_s_barrier();
-  TL_STAMP(2);
-  const unsigned wring0 = smem0 + woff, hbuf0 = smem0 + 3 * WT;
+  const unsigned hbuf0 = smem0 + 3 * WT;
   bf16x8 wA[TI], xA[TJ], wB[TI], xB[TJ];
   [[maybe_unused]] bf16x8 xE0, xE1;
   [[maybe_unused]] const unsigned sink0 = smem0 + 3 * WT + 2 * HBUF;
-  int stage = 0;
-  for (int c = 0; c < p.chunks; ++c) {
-    const unsigned hb = hbuf0 + (unsigned)((c & 1) * HBUF);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int ks = c * T + t;
-      // ---- L(ks) ----
-      const bool halo_now = t == 0 && c >= 1 && c + 1 < p.chunks;
-      if (halo_now) issue_halo(c + 1, (c + 1) & 1);
-      if (ks >= 1 && ks + 2 < nk) { int c2, t2; ct_of(ks + 2, c2, t2); issue_w(c2, t2, stage == 0 ? 2 : stage - 1); }
-      load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K0{}, wA, xA);
-      load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K1{}, wB, xB);
-      [[maybe_unused]] const bool e_now = RING && ((e_mask >> t) & 1u);
-      if constexpr (RING) {
-        if (e_now) {
-          const unsigned ea = e_lane ? hb + (unsigned)tb[t] + (unsigned)e_rb : sink0;
-          lds_read128<0>(xE0, ea);
-          lds_read128<64>(xE1, ea);
-        }
-      }
-      wait_frags(std::integral_constant<int, 0>{}, wA, xA);
-      wait_frags(std::integral_constant<int, 0>{}, wB, xB);
-      if constexpr (RING) {
-        if (e_now) { reg_fence(xE0); reg_fence(xE1); }
-      }
-      TL_STAMP(8 + ks * 4 + 0);
-      auto wait_next_weights = [&]() {       // this wave's share of step ks+1's weights (and anything older) has landed
-        if (ks + 1 >= nk) return;
-        if (ks + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");     // w1 | w2 outstanding
-        else if (halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");
-      };
-      if (grp) wait_next_weights();
-      __builtin_amdgcn_s_barrier();
-      TL_STAMP(8 + ks * 4 + 1);
-      // ---- M(ks) ----
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      mma(wA, xA);
-      mma(wB, xB);
-      if constexpr (RING) {
-        if (e_now) {
-#pragma unroll
-          for (int i = 0; i < TI; ++i) accE[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[i], xE0, accE[i], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < TI; ++i) accE[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wB[i], xE1, accE[i], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      TL_STAMP(8 + ks * 4 + 2);
-      if (!grp) wait_next_weights();
-      __builtin_amdgcn_s_barrier();
-      TL_STAMP(8 + ks * 4 + 3);
-      stage = stage == 2 ? 0 : stage + 1;
-    }
-  }
-  if (!grp) __builtin_amdgcn_s_barrier();       // group 1 ran one barrier ahead of the loop: every wave has passed the same count
-  if constexpr (RING) {
-    // ---- RING epilogue: ring sums -> LDS -> added (fp32) to the pixels they fold onto, bf16 tile through the per-wave
-    // slabs, coalesced stores with the consumer's InstanceNorm-backward sums (same contract as gconv_kernel's fused
-    // epilogue: sums over the box of ghat = (g + g2) * act'(yhat), ghat * yhat, yhat; one slot per box) -------------
-    constexpr int CW = CWV, PW = 64, SROW = CW * 2 + 16;
-    constexpr int RED_BYTES = WM * BN * 3 * 4;
-    constexpr int SLAB0 = ((RED_BYTES + 255) / 256) * 256;
-    constexpr int RING0 = SLAB0 + NW * PW * SROW;            // [5 slots: top, bottom, left, right, corner][16 pixels][BN] fp32
-    float* ringbuf = reinterpret_cast<float*>(smem + RING0);
-    __syncthreads();                                         // the last K-step's operands have been read by every wave
-    if (e_mask) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-        *reinterpret_cast<f32x4*>(ringbuf + (e_slot * 16 + frow) * BN + wn * CWV + i * 16 + fk * 4) = accE[i];
-    }
-    __syncthreads();
-    const int cy = e_top ? 1 : 14, cx = e_lef ? 1 : 14;      // where this box's image corner (if it has one) folds onto
-    const bool corner = (e_top || e_bot) && (e_lef || e_rig);
-    char* slab = smem + SLAB0 + wave * (PW * SROW);
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int y = wm * 4 + j;
-#pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const int cl = wn * CWV + i * 16 + fk * 4;
-        f32x4 v = acc[i][j];
-        if (e_top && y == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (0 * 16 + frow) * BN + cl);
-        if (e_bot && y == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (1 * 16 + frow) * BN + cl);
-        if (e_lef && frow == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (2 * 16 + y) * BN + cl);
-        if (e_rig && frow == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (3 * 16 + y) * BN + cl);
-        if (corner && y == cy && frow == cx) v += *reinterpret_cast<const f32x4*>(ringbuf + (4 * 16 + 0) * BN + cl);
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(slab + (j * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
-      }
-    }
-    __syncthreads();
-    constexpr int LPR = CW / 8, PPI = 64 / LPR;            // 4 (16 waves: 32 channels per wave) or 8 (8 waves: 64) lanes per pixel
-    static_assert(LPR == 4 || LPR == 8, "ring epilogue: 32 or 64 channels per wave");
-    const int sub = lane % LPR, prow = lane / LPR;
-    const int co = nt * BN + wn * CW + sub * 8;
-    float fa1[8], fa2[8], fa3[8], fmu[8], frs[8];
+  int stage = 0;                                 // ring slot of the current K-step (runs on across tiles)
+  int hpar = 0;                                  // halo buffer of the current chunk (alternates across tiles too)
+  [[maybe_unused]] const bool e_top = oy0 == 0, e_bot = oy0 + 16 == d.Ho, e_lef = ox0 == 0, e_rig = ox0 + 16 == d.Wo;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < ntl; ++it) {
+    const int n = n0 + it * nstep;               // this tile's image; the next tile's is n + nstep
+    const bool has_next = it + 1 < ntl;
     {
-      const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { fa1[k] = fa2[k] = fa3[k] = 0.f; fmu[k] = mr[co + k]; frs[k] = mr[d.Co + co + k]; }
+      int ll = lane;
+      asm volatile("" : "+v"(ll));
+      frow = ll & 15; fk = ll >> 4;
+      const int swz = ll & 7;
+      rowb = ((wm * 4) * 18 + frow) * HP + fk * 16;
+      woff = (unsigned)((wn * CWV + frow) * 128);
+      c0 = (unsigned)((fk ^ swz) << 4);
     }
-#pragma unroll
-    for (int it = 0; it < PW / PPI; ++it) {
-      const int pl = it * PPI + prow;
-      const int ly = wm * 4 + (pl >> 4), lx = pl & 15;
-      const size_t opix = ((size_t)n * d.Ho + (oy0 + ly)) * d.Wo + (ox0 + lx);
-      const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
-      const uint4 yv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.y) + (opix * d.Co + co) * 2);
-      *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
-      float g[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y),
-                    bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
-      const float yr[8] = {bf_lo(yv.x), bf_hi(yv.x), bf_lo(yv.y), bf_hi(yv.y),
-                           bf_lo(yv.z), bf_hi(yv.z), bf_lo(yv.w), bf_hi(yv.w)};
-      if (p.f.g2) {
-        const uint4 gv = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.f.g2) + (opix * d.Co + co) * 2);
-        g[0] += bf_lo(gv.x); g[1] += bf_hi(gv.x); g[2] += bf_lo(gv.y); g[3] += bf_hi(gv.y);
-        g[4] += bf_lo(gv.z); g[5] += bf_hi(gv.z); g[6] += bf_lo(gv.w); g[7] += bf_hi(gv.w);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float yh = (yr[k] - fmu[k]) * frs[k];
-        const float gh = g[k] * act_grad_from_out(yh, p.f.act, p.f.slope);
-        fa1[k] += gh;
-        fa2[k] += gh * yh;
-        fa3[k] += yh;
-      }
-    }
-    float* red3 = reinterpret_cast<float*>(smem);            // [WM][BN][3]
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if constexpr (LPR == 4) {
-        fa1[k] = row_sum_stride4(fa1[k]); fa2[k] = row_sum_stride4(fa2[k]); fa3[k] = row_sum_stride4(fa3[k]);
+    const unsigned wring0 = smem0 + woff;
+    // RING: this wave's ring fragment (lane frow = one ring pixel), its taps and its slot in the ring buffer;
+    // taps come in the data-gradient order t = 3*ry + rx with (dh, dw) = (1 - ry, 1 - rx) (checked by the launcher)
+    [[maybe_unused]] unsigned e_mask = 0;        // wave-uniform: taps that reach the image from this wave's ring pixels
+    [[maybe_unused]] int e_rb = 0, e_slot = 0;
+    [[maybe_unused]] bool e_lane = true;         // false: this lane carries no ring pixel (reads the zero sink)
+    if constexpr (RING) {
+      int py = 0, px = 0, sy = 0, sx = 0;        // ring pixel of lane frow: (py + sy*frow, px + sx*frow), box coordinates
+      const bool side = e_lef || e_rig;
+      if (wm == 0) {
+        if (e_top) { e_mask = 0x007u; py = -1; sx = 1; e_slot = 0; }
+        else if (e_bot && side) { e_mask = e_lef ? 0x040u : 0x100u; py = 16; px = e_lef ? -1 : 16; e_lane = frow == 0; e_slot = 4; }
+      } else if (wm == 3) {
+        if (e_bot) { e_mask = 0x1C0u; py = 16; sx = 1; e_slot = 1; }
+        else if (e_top && side) { e_mask = e_lef ? 0x001u : 0x004u; py = -1; px = e_lef ? -1 : 16; e_lane = frow == 0; e_slot = 4; }
+      } else if (wm == 1) {
+        if (e_lef) { e_mask = 0x049u; px = -1; sy = 1; e_slot = 2; }
       } else {
-        fa1[k] = row_sum_stride8(fa1[k]); fa2[k] = row_sum_stride8(fa2[k]); fa3[k] = row_sum_stride8(fa3[k]);
+        if (e_rig) { e_mask = 0x124u; px = 16; sy = 1; e_slot = 3; }
       }
+      e_mask = __builtin_amdgcn_readfirstlane(e_mask);
+      e_rb = ((py + sy * frow) * 18 + (px + sx * frow)) * HP + fk * 16;
 #pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
-        fa1[k] += __shfl_xor(fa1[k], o, 64);
-        fa2[k] += __shfl_xor(fa2[k], o, 64);
-        fa3[k] += __shfl_xor(fa3[k], o, 64);
-      }
+      for (int i = 0; i < TI; ++i) accE[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (prow == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int cl = wn * CW + sub * 8 + k;
-        red3[(wm * BN + cl) * 3 + 0] = fa1[k];
-        red3[(wm * BN + cl) * 3 + 1] = fa2[k];
-        red3[(wm * BN + cl) * 3 + 2] = fa3[k];
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int c = nt * BN + tid;
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        t0 += red3[(w * BN + tid) * 3]; t1 += red3[(w * BN + tid) * 3 + 1]; t2 += red3[(w * BN + tid) * 3 + 2];
-      }
-      float* sp = p.f.partial + ((size_t)n * p.tiles_m + mt) * 3 * d.Co;
-      sp[c] = t0; sp[d.Co + c] = t1; sp[2 * d.Co + c] = t2;
-    }
-    return;
-  }
-  f32x4 bia[TI];                                // loaded after the loop: inside it they would spill (128-VGPR cap)
-#pragma unroll
-  for (int i = 0; i < TI; ++i) {
-    const int co = nt * BN + wn * CWV + i * 16 + fk * 4;
-    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  TL_STAMP(3);
-
-  // ---- epilogue: bias, partial statistics (slot = box), activation, LDS-staged coalesced NHWC stores ------------
-  const bool want_stats = d.stats_slots > 0;
-  float s1[TI][4], s2[TI][4];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
-  constexpr int CW = CWV, PW = 64, SROW = CW * 2 + 16;
-  constexpr int RED_BYTES = WM * BN * 2 * 4;
-  char* slab = smem + ((RED_BYTES + 255) / 256) * 256 + wave * (PW * SROW);
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][j][r] + bia[i][r];
-        s1[i][r] += v[r];
-        s2[i][r] += v[r] * v[r];
-        v[r] = apply_act(v[r], d.act, d.slope);
-      }
-      uint2 o;
-      o.x = pack_bf2(v[0], v[1]);
-      o.y = pack_bf2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(slab + (j * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
-    }
-  }
-  __syncthreads();
-  {
-    constexpr int LPR = CW / 8, PPI = 64 / LPR;   // 4 lanes per pixel, 16 pixels per store instruction
-    const int sub = lane % LPR, prow = lane / LPR;
-    const int co = nt * BN + wn * CW + sub * 8;
-#pragma unroll
-    for (int it = 0; it < PW / PPI; ++it) {
-      const int pl = it * PPI + prow;             // pixel inside the wave's 4 box rows
-      const int ly = wm * 4 + (pl >> 4), lx = pl & 15;
-      if (co < d.Co) {
-        const size_t opix = ((size_t)n * d.Ho + (oy0 + ly)) * d.Wo + (ox0 + lx);
-        const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
-        *reinterpret_cast<uint4*>(p.out + (opix * d.out_cs + d.out_co + co) * 2) = val;
-      }
-    }
-  }
-  TL_STAMP(4);
-  if (want_stats) {
-    float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[i][r], q = s2[i][r];
-        a = row16_sum(a);
-        q = row16_sum(q);
-        if (frow == 0) {
-          const int cl = wn * CW + i * 16 + fk * 4 + r;
-          red[(wm * BN + cl) * 2 + 0] = a;
-          red[(wm * BN + cl) * 2 + 1] = q;
-        }
-      }
-    __syncthreads();
-    if (tid < BN) {
-      const int co = nt * BN + tid;
-      if (co < d.Co) {
-        float a = 0.f, q = 0.f;
+      for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < p.chunks; ++c) {
+      const unsigned hb = hbuf0 + (unsigned)(hpar * HBUF);
+      const bool last_chunk = c + 1 == p.chunks;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
-        sp[co] = a;
-        sp[d.Co + co] = q;
+      for (int t = 0; t < T; ++t) {
+        // ---- L(ks), ks = c * T + t ----
+        // halo of the chunk after this one (of the NEXT tile behind the last chunk) into the other buffer; the first chunk
+        // of the launch finds chunk 1 issued by the prologue, the first chunk of a later tile finds the other buffer freed
+        // by the epilogue that just ran out of it
+        const bool halo_now = t == 0 && (c >= 1 || it > 0) && (!last_chunk || has_next);
+        if (halo_now) issue_halo(last_chunk ? n + nstep : n, last_chunk ? 0 : c + 1, hpar ^ 1);
+        // weights two K-steps ahead (K-steps 0 / 1 of the next tile behind this tile's last two; K-step 2 of a later tile
+        // is issued in front of the previous tile's epilogue stores)
+        const bool tail2 = last_chunk && t >= T - 2;          // K-step ks + 2 belongs to the next tile
+        const bool w_now = (c > 0 || t >= 1) && (!tail2 || has_next);
+        if (w_now) {
+          if (tail2) issue_w(n + nstep, 0, t - (T - 2), stage == 0 ? 2 : stage - 1);
+          else issue_w(n, t + 2 >= T ? c + 1 : c, t + 2 >= T ? t + 2 - T : t + 2, stage == 0 ? 2 : stage - 1);
+        }
+        load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K0{}, wA, xA);
+        load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K1{}, wB, xB);
+        [[maybe_unused]] const bool e_now = RING && ((e_mask >> t) & 1u);
+        if constexpr (RING) {
+          if (e_now) {
+            const unsigned ea = e_lane ? hb + (unsigned)tb[t] + (unsigned)e_rb : sink0;
+            lds_read128<0>(xE0, ea);
+            lds_read128<64>(xE1, ea);
+          }
+        }
+        wait_frags(wA, xA);
+        wait_frags(wB, xB);
+        if constexpr (RING) {
+          if (e_now) { reg_fence(xE0); reg_fence(xE1); }
+        }
+        auto wait_next_weights = [&]() {       // this wave's share of step ks+1's weights (and anything older) has landed
+          if (last_chunk && t == T - 1 && !has_next) return;
+          if (it > 0 && c == 0 && t <= 1) {
+            // first K-steps behind a tile boundary: the weights waited for are older than the previous tile's NST output
+            // stores and this tile's chunk-1 halo (ks 0: w2 | stores | halo outstanding; ks 1: stores | halo | w3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + NST + HPW) : "memory");
+            return;
+          }
+          if (!w_now && (c > 0 || t >= 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail of the last tile
+          else if (halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");               // (ks 0 of the launch: w1 | w2)
+        };
+        if (grp) wait_next_weights();
+        __builtin_amdgcn_s_barrier();
+        // ---- M(ks) ----
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(wA, xA);
+        mma(wB, xB);
+        if constexpr (RING) {
+          if (e_now) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) accE[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[i], xE0, accE[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) accE[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wB[i], xE1, accE[i], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!grp) wait_next_weights();
+        __builtin_amdgcn_s_barrier();
+        stage = stage == 2 ? 0 : stage + 1;
+      }
+      hpar ^= 1;
+    }
+    // ---- tile boundary -----------------------------------------------------------------------------------------------------
+    // Epilogue coordinates (rebuilt from the lane id, see above) and its GLOBAL operands first: the loads are issued before
+    // the barrier that brings the two wave groups back into step, so their latency runs under that wait; everything the
+    // epilogue reads from memory is in registers (or on its way) before the first output store is issued, and no wait
+    // behind the stores ever names them — they drain under the next tile's K loop.
+    {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      frow = le & 15; fk = le >> 4;
+    }
+    const int elane = fk * 16 + frow;             // (= lane, rebuilt)
+    const size_t pix0 = ((size_t)n * d.Ho + oy0) * d.Wo + ox0;
+    constexpr int SROW = CWV * 2 + 16, PH = 32;             // slab row pitch; pixels per pass (two of the wave's four box rows)
+    constexpr int LPR = CWV / 8, PPI = 64 / LPR;            // 4 lanes per pixel, 16 pixels per store instruction
+    constexpr int NQ = PH / PPI;                            // store instructions per pass (2)
+    const int sub = elane % LPR, prow = elane / LPR;
+    const int co = nt * BN + wn * CWV + sub * 8;
+    // pixel of store q of pass ph: two of the wave's four box rows per pass, 16 pixels per instruction
+    auto opix_of = [&](int ph, int q) {
+      const int pl = q * PPI + prow;
+      return pix0 + (size_t)(wm * 4 + ph * 2 + (pl >> 4)) * d.Wo + (pl & 15);
+    };
+    [[maybe_unused]] uint2 yv[TI][TJ], gv[TI][TJ];
+    [[maybe_unused]] f32x4 mrv;
+    [[maybe_unused]] f32x4 bia[TI];
+    // y / g2 of the consumer's norm backward in the ACCUMULATOR layout (pixel (wm*4 + j, frow), channels i*16 + fk*4 ..):
+    // the sums are then taken before the tile goes through the store slabs, i.e. before the first output store
+    auto load_yg = [&](int i) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const size_t o = ((pix0 + (size_t)(wm * 4 + j) * d.Wo + frow) * d.Co + nt * BN + wn * CWV + i * 16 + fk * 4) * 2;
+        yv[i][j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.f.y) + o);
+        gv[i][j] = p.f.g2 ? *reinterpret_cast<const uint2*>(static_cast<const char*>(p.f.g2) + o) : uint2{0u, 0u};
+      }
+    };
+    if constexpr (RING) {
+      load_yg(0);      // (the other channel half is fetched while this one is summed: registers)
+      // mean / rstd of this tile's 128 channels: 64 threads fetch 4 floats each, everybody reads them back from LDS
+      if (tid < 2 * BN / 4) {
+        const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co + (tid >= BN / 4 ? d.Co : 0) + nt * BN + (tid % (BN / 4)) * 4;
+        mrv = *reinterpret_cast<const f32x4*>(mr);
+      }
+    } else {
+      const float* bias_n = p.bias ? p.bias + (n >= p.nsplit ? p.bias_delta : 0) : nullptr;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int cb = nt * BN + wn * CWV + i * 16 + fk * 4;
+        bia[i] = bias_n ? *reinterpret_cast<const f32x4*>(bias_n + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    // both groups back in step; every LDS operand of this tile has been read
+    if (!grp) __builtin_amdgcn_s_barrier();       // group 1 ran one barrier ahead of the loop
+    if (has_next) {                               // K-step 2 of the next tile into the slot of this tile's last step,
+      int c2, t2;                                 // issued BEFORE the epilogue's stores (see the waits above)
+      ct_of(2, c2, t2);
+      issue_w(n + nstep, c2, t2, stage == 0 ? 2 : stage - 1);
+    }
+    // the epilogue works out of the halo buffer the next chunk does NOT use: hpar now names the next tile's chunk-0
+    // buffer (already filled), the other one is free
+    char* const ebuf = hbuf + (hpar ^ 1) * HBUF;
+    static_assert(NW * PH * SROW + WM * BN * 3 * 4 + 2 * BN * 4 <= HBUF, "epilogue scratch must fit one halo buffer");
+    char* const slab = ebuf + wave * (PH * SROW);            // 16 x 2560 B = 40 KiB
+    float* const red = reinterpret_cast<float*>(ebuf + NW * PH * SROW);                       // [WM][BN][2 | 3], behind the slabs
+    [[maybe_unused]] float* const mrs = reinterpret_cast<float*>(ebuf + NW * PH * SROW + WM * BN * 3 * 4);   // [2][BN]
+    if constexpr (RING) {
+      // ---- ring sums -> LDS -> added (fp32) to the pixels they fold onto; bf16 tile through the per-wave slabs; coalesced
+      // stores with the consumer's InstanceNorm-backward sums (contract of gconv_kernel's fused epilogue: sums over the
+      // box of ghat = (g + g2) * act'(yhat), ghat * yhat, yhat; one slot per box) -------------------------------------
+      float* ringbuf = reinterpret_cast<float*>(ebuf);       // [5 slots: top, bottom, left, right, corner][16 pixels][BN] fp32
+      if (e_mask) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          *reinterpret_cast<f32x4*>(ringbuf + (e_slot * 16 + frow) * BN + wn * CWV + i * 16 + fk * 4) = accE[i];
+      }
+      if (tid < 2 * BN / 4) *reinterpret_cast<f32x4*>(mrs + tid * 4) = mrv;
+      lds_barrier();
+      uint2 pk[TI][TJ];
+      const int cy = e_top ? 1 : 14, cx = e_lef ? 1 : 14;    // where this box's image corner (if it has one) folds onto
+      const bool corner = (e_top || e_bot) && (e_lef || e_rig);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        if (i + 1 < TI) load_yg(i + 1);
+        const int cl = wn * CWV + i * 16 + fk * 4;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mrs + cl), rs = *reinterpret_cast<const f32x4*>(mrs + BN + cl);
+        float s1[4], s2[4], s3[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[r] = s2[r] = s3[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int y = wm * 4 + j;
+          f32x4 v = acc[i][j];
+          if (e_top && y == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (0 * 16 + frow) * BN + cl);
+          if (e_bot && y == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (1 * 16 + frow) * BN + cl);
+          if (e_lef && frow == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (2 * 16 + y) * BN + cl);
+          if (e_rig && frow == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (3 * 16 + y) * BN + cl);
+          if (corner && y == cy && frow == cx) v += *reinterpret_cast<const f32x4*>(ringbuf + (4 * 16 + 0) * BN + cl);
+          pk[i][j].x = pack_bf2(v[0], v[1]);                 // rounded here: the sums see the gradient as it is stored
+          pk[i][j].y = pack_bf2(v[2], v[3]);
+          float g[4] = {bf_lo(pk[i][j].x), bf_hi(pk[i][j].x), bf_lo(pk[i][j].y), bf_hi(pk[i][j].y)};
+          const float yr[4] = {bf_lo(yv[i][j].x), bf_hi(yv[i][j].x), bf_lo(yv[i][j].y), bf_hi(yv[i][j].y)};
+          if (p.f.g2) {
+            g[0] += bf_lo(gv[i][j].x); g[1] += bf_hi(gv[i][j].x); g[2] += bf_lo(gv[i][j].y); g[3] += bf_hi(gv[i][j].y);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yh = (yr[r] - mu[r]) * rs[r];
+            const float gh = g[r] * act_grad_from_out(yh, p.f.act, p.f.slope);
+            s1[r] += gh;
+            s2[r] += gh * yh;
+            s3[r] += yh;
+          }
+        }
+        // per-wave sums over the 16 pixel columns, then over the four pixel-row groups of waves through LDS (fixed order)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(s1[r]), b2 = row16_sum(s2[r]), c3 = row16_sum(s3[r]);
+          if (frow == 0) {
+            red[(wm * BN + cl + r) * 3 + 0] = a;
+            red[(wm * BN + cl + r) * 3 + 1] = b2;
+            red[(wm * BN + cl + r) * 3 + 2] = c3;
+          }
+        }
+      }
+      lds_barrier();                                         // the ring sums have been read: the slabs may overwrite them
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+            *reinterpret_cast<uint2*>(slab + (jj * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = pk[i][ph * 2 + jj];
+        __builtin_amdgcn_wave_barrier();                     // wave-private slab: LDS operations of a wave complete in order
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int pl = q * PPI + prow;
+          const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
+          *reinterpret_cast<uint4*>(p.out + (opix_of(ph, q) * d.out_cs + d.out_co + co) * 2) = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      int tq = tid;
+      asm volatile("" : "+v"(tq));                           // (addresses below are built here, not carried through the tile)
+      if (tq < BN) {                                         // (red was published by the barrier in front of the slab passes)
+        const int cc = nt * BN + tq;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          t0 += red[(w * BN + tq) * 3]; t1 += red[(w * BN + tq) * 3 + 1]; t2 += red[(w * BN + tq) * 3 + 2];
+        }
+        float* sp = p.f.partial + ((size_t)n * p.tiles_m + mt) * 3 * d.Co;
+        sp[cc] = t0; sp[d.Co + cc] = t1; sp[2 * d.Co + cc] = t2;
+      }
+    } else {
+      // ---- bias, partial statistics (slot = box), activation, LDS-staged coalesced NHWC stores ------------------------
+      const bool want_stats = d.stats_slots > 0;
+      float s1[TI][4], s2[TI][4];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[i][ph * 2 + jj][r] + bia[i][r];
+              s1[i][r] += v[r];
+              s2[i][r] += v[r] * v[r];
+              v[r] = apply_act(v[r], d.act, d.slope);
+            }
+            uint2 o;
+            o.x = pack_bf2(v[0], v[1]);
+            o.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(slab + (jj * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
+          }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int pl = q * PPI + prow;             // pixel inside this pass's two box rows
+          const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
+          *reinterpret_cast<uint4*>(p.out + (opix_of(ph, q) * d.out_cs + d.out_co + co) * 2) = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float a = s1[i][r], q = s2[i][r];
+            a = row16_sum(a);
+            q = row16_sum(q);
+            if (frow == 0) {
+              const int cl = wn * CWV + i * 16 + fk * 4 + r;
+              red[(wm * BN + cl) * 2 + 0] = a;
+              red[(wm * BN + cl) * 2 + 1] = q;
+            }
+          }
+        lds_barrier();
+        if (tid < BN) {
+          const int cc = nt * BN + tid;
+          float a = 0.f, q = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+          float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+          sp[cc] = a;
+          sp[d.Co + cc] = q;
+        }
+      }
+    }
+    if (has_next) {
+      lds_barrier();                              // slabs and sums read by everybody: the next chunk-1 halo may land there
+      if (grp) __builtin_amdgcn_s_barrier();      // group 1 one barrier ahead again
+    }
   }
-#ifdef GS_TIMELINE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores have been accepted
-  TL_STAMP(5);
-  __syncthreads();
-  if (g_tl_buf != nullptr && (blockIdx.x == 0 || blockIdx.x == 101))
-    for (int i = tid; i < TLW * TLS; i += NW * 64) g_tl_buf[(blockIdx.x == 0 ? 0 : 1) * TLW * TLS + i] = tl[i];
-#endif
 }
 
 int gs_hconvx_launch(const HConvWK& k, long long blocks, void* stream);   // hconvx.hip
@@ -503,7 +555,7 @@ static bool hconvw_eligible(const gs_gconv_desc* d, int* lo) {
   const bool enabled = gs_opt(GS_OPT_HCONV_WIDE) != 0;
   if (!enabled || d->si != 1 || d->so != 1 || d->T != 9 || d->Ci % 64 != 0 || d->Co % 128 != 0 || d->accumulate) return false;
   if (d->Di != 1 || d->Do != 1 || d->Dc != 1 || d->Hc != d->Ho || d->Wc != d->Wo || d->py || d->px || d->pz) return false;
-  if (d->Ho % 16 != 0 || d->Wo % 16 != 0) return false;
+  if (d->Ho % 16 != 0 || d->Wo % 16 != 0 || d->w_rows < d->Co) return false;
   int hi[2] = {-128, -128};
   lo[0] = lo[1] = 127;
   for (int t = 0; t < d->T; ++t) {
@@ -524,9 +576,36 @@ int gs_hconvw_slots(const gs_gconv_desc* d) {
   return hconvw_eligible(d, lo) ? (d->Ho / 16) * (d->Wo / 16) : 0;
 }
 
+// Grid of a launch over `images` x `tpi` tiles (tpi = boxes x channel tiles of one image): one workgroup per tile while
+// they fit in one round of the chip (one workgroup per CU: 160 KiB of LDS); else the persistent form — G = floor(CUs / tpi)
+// images per round, ceil(images / G) tiles per workgroup, and a grid that is a MULTIPLE of tpi, so that all tiles of a
+// workgroup are the same box and channel tile of different images (the kernel builds its per-lane state once). It needs
+// >= 2 channel chunks (a tile's last chunk leaves one halo buffer for the next tile's first). Option hconvw_persist = 0:
+// always one tile per workgroup.
+static int hconvw_grid(int images, int tpi, int chunks) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  const long long tiles = (long long)images * tpi;
+  if (tiles <= cus || tpi > cus || chunks < 2 || gs_opt(GS_OPT_HCONVW_PERSIST) == 0) return (int)tiles;
+  const int G = cus / tpi;                                 // images per round
+  const int per = (images + G - 1) / G;                    // tiles per workgroup
+  return tpi * ((images + per - 1) / per);
+}
+
+static void hconvw_twin(HConvWK& k, const gs_twin* tw) {
+  k.nsplit = tw ? tw->n_split : 0x7fffffff;
+  k.w_delta = tw ? tw->w_delta : 0;
+  k.bias_delta = tw ? tw->bias_delta / 4 : 0;
+}
+
 // returns 0 and sets *handled when the layer ran here
 int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
-                  float* stats, void* stream, int* handled) {
+                  float* stats, const gs_twin* tw, void* stream, int* handled) {
   *handled = 0;
   int lo[2];
   if (!hconvw_eligible(d, lo)) return 0;
@@ -544,28 +623,21 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.nbw = d->Wo / 16;
   k.hh = 18; k.hw = 18; k.hmin = lo[0]; k.wmin = lo[1];
   k.chunks = d->Ci / 64;
+  k.ntiles = (int)blocks;
+  hconvw_twin(k, tw);
   k.d = *d;
   k.f = gs_gconv_fuse{};
-#ifdef GS_TIMELINE
-  const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024 + TLW * TLS * 4;
-#else
-  const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
-#endif
-  const int nw = gs_opt(GS_OPT_HCONVW_WAVES);
+  const int lds = 160 * 1024;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 16>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 8>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
   *handled = 1;
-  if (gs_opt(GS_OPT_HCONVX)) return gs_hconvx_launch(k, blocks, stream);
-  if (nw == 8)
-    hipLaunchKernelGGL((hconvw_kernel<9, 8>), dim3((unsigned)blocks), dim3(512), lds, static_cast<hipStream_t>(stream), k);
-  else
-    hipLaunchKernelGGL((hconvw_kernel<9, 16>), dim3((unsigned)blocks), dim3(1024), lds, static_cast<hipStream_t>(stream), k);
+  if (gs_opt(GS_OPT_HCONVX) && !tw) return gs_hconvx_launch(k, blocks, stream);
+  hipLaunchKernelGGL((hconvw_kernel<9>), dim3((unsigned)hconvw_grid(d->N, k.tiles_m * k.tiles_n, k.chunks)), dim3(1024), lds,
+                     static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -588,7 +660,7 @@ extern "C" int gs_gconv_ring_slots(const gs_gconv_desc* d) {
 }
 
 int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, void* out, const gs_gconv_fuse* fuse,
-                   void* stream) {
+                   const gs_twin* tw, void* stream) {
   GS_REQUIRE(hconvw_ring_eligible(d), "gs_gconv_forward_fused: layer is not eligible for the unpadded (ring) form, see "
                                       "gs_gconv_ring_slots");
   GS_REQUIRE(fuse->fold == 1 && fuse->fold_mode == GS_BORDER_REFLECT && fuse->Dy == 1,
@@ -609,22 +681,17 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   k.d = *d;
   k.f = *fuse;
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
-  const int lds = 3 * 128 * 128 + 2 * ((18 * 18 * 10 + 63) / 64) * 1024 + 1024;
+  k.ntiles = (int)blocks;
+  hconvw_twin(k, tw);
+  const int lds = 160 * 1024;
   static bool configured = false;
   if (!configured) {
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 16, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, 8, true>),
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     configured = true;
   }
-  // 8 waves of 64 x 64 (209 registers x 2 waves per SIMD) against 16 waves of 64 x 32 (127 x 4, the whole register file)
-  if (gs_opt(GS_OPT_HCONVW_RING_WAVES) == 8)
-    hipLaunchKernelGGL((hconvw_kernel<9, 8, true>), dim3((unsigned)blocks), dim3(512), lds,
-                       static_cast<hipStream_t>(stream), k);
-  else
-    hipLaunchKernelGGL((hconvw_kernel<9, 16, true>), dim3((unsigned)blocks), dim3(1024), lds,
-                       static_cast<hipStream_t>(stream), k);
+  hipLaunchKernelGGL((hconvw_kernel<9, true>), dim3((unsigned)hconvw_grid(d->N, k.tiles_m * k.tiles_n, k.chunks)), dim3(1024), lds,
+                     static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

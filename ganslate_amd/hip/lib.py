@@ -41,6 +41,12 @@ class GConvFuse(C.Structure):
         (n, C.c_int32) for n in ("Dy", "Hy", "Wy", "fold", "fold_mode", "act")] + [("slope", C.c_float)]
 
 
+class Twin(C.Structure):
+    """Mirror of gs_twin."""
+    _fields_ = [("n_split", C.c_int32), ("pad_", C.c_int32), ("w_delta", C.c_int64), ("bias_delta", C.c_int64),
+                ("dw_delta", C.c_int64)]
+
+
 class NormDbItem(C.Structure):
     """Mirror of gs_norm_db_item."""
     _fields_ = [("sums", C.c_void_p), ("mean_rstd", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("C", C.c_int32),
@@ -91,6 +97,9 @@ _PROTOS = {
                                                C.POINTER(GConvFuse), C.c_void_p]),
     "gs_gconv_forward_fused": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.POINTER(GConvFuse), C.c_void_p]),
+    "gs_gconv_twin_native": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p]),
+    "gs_gconv_forward_twin": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.POINTER(Twin), C.c_void_p]),
     "gs_wgrad_pair": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "gs_wgrad": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

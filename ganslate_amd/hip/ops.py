@@ -196,15 +196,31 @@ class HipOps(TwinSplit):
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
               slope=0.2, stats=None, stats_slots=0, stats_slot0=0, accumulate=False, fuse=None):
-        if is_twin(wpack, bias):      # two networks' weights over one batch (nn/native/twin.py)
-            return self.twin_gconv(functools.partial(self.gconv, g), x, wpack, bias, out, in_cs=in_cs, in_co=in_co,
-                                   out_cs=out_cs, out_co=out_co, act=act, slope=slope, stats=stats,
-                                   stats_slots=stats_slots, stats_slot0=stats_slot0, accumulate=accumulate, fuse=fuse,
-                                   C_=g.Co)
         N = x.shape[0]
         in_cs = in_cs if in_cs is not None else x.shape[-1]
         out_cs = out_cs if out_cs is not None else out.shape[-1]
         d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0, accumulate)
+        if is_twin(wpack, bias):      # two networks' weights over one batch (nn/native/twin.py)
+            f = self._fuse_struct(fuse) if fuse is not None else None
+            if os.environ.get("GS_TWIN_NATIVE", "1") != "0" and isinstance(wpack, Twin) and \
+                    self.lib.gs_gconv_twin_native(C.byref(d), C.byref(f) if f is not None else None):
+                # the kernel picks the weight set per image: one launch over both networks' images
+                tw = L.Twin()
+                tw.n_split, tw.w_delta = N // 2, wpack.delta()
+                tw.bias_delta = bias.delta() if isinstance(bias, Twin) else 0
+                b0 = bias.a if isinstance(bias, Twin) else bias
+                t_end = self._time_begin("gconv", g, fuse is not None)
+                L.check(self.lib.gs_gconv_forward_twin(C.byref(d), _ptr(x), C.c_void_p(wpack.a.data_ptr() + 2 * g.pack_offset),
+                                                       _ptr(b0), _ptr(out), _ptr(stats),
+                                                       C.byref(f) if f is not None else None, C.byref(tw), _stream()),
+                        "gs_gconv_forward_twin")
+                if t_end is not None:
+                    t_end.record()
+                return
+            return self.twin_gconv(functools.partial(self.gconv, g), x, wpack, bias, out, in_cs=in_cs, in_co=in_co,
+                                   out_cs=out_cs, out_co=out_co, act=act, slope=slope, stats=stats,
+                                   stats_slots=stats_slots, stats_slot0=stats_slot0, accumulate=accumulate, fuse=fuse,
+                                   C_=g.Co)
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
         t_end = self._time_begin("gconv", g, fuse is not None)
         if fuse is not None:     # data gradient + first pass of the consumer's InstanceNorm backward (fused_norm_plan)
@@ -230,6 +246,10 @@ class HipOps(TwinSplit):
         """every output-parity class of one layer (Lowered.fwd / .dgrad). More than one class: gs_gconv_forward_multi, one
         launch when the classes are mergeable (the library decides; it runs them one by one otherwise). Layers so small
         that even the merged grid leaves the chip empty keep the per-class launches, which split K."""
+        if is_twin(wpack, bias) and len(classes) == 1 and fuse is None:
+            return self.gconv(classes[0], x, wpack, bias, out, in_co=in_co, out_co=out_co, act=act, slope=slope, stats=stats,
+                              stats_slots=stats_slots, stats_slot0=(stats_slot0s[0] if stats_slot0s else 0),
+                              accumulate=accumulate)
         if is_twin(wpack, bias):
             return self.twin_gconv(functools.partial(self.gconv_classes, classes), x, wpack, bias, out, in_co=in_co,
                                    out_co=out_co, act=act, slope=slope, stats=stats, stats_slots=stats_slots,

@@ -83,6 +83,18 @@ typedef struct gs_wgrad_desc {
   int8_t  dd[GS_MAX_TAPS];
 } gs_wgrad_desc;
 
+/* Twin batch: two networks of IDENTICAL architecture over one batch — the two generators (discriminators) of a CycleGAN
+ * step see independent data in every phase (cyclegan.py:126-152: G_AB(real_A) next to G_BA(real_B), G_AB(fake_A) next to
+ * G_BA(fake_B); :154-189 for D_B / D_A), and with per-sample InstanceNorm nothing couples the images of a batch. Images
+ * [0, n_split) use the weights / bias / gradient buffers passed to the call, images [n_split, N) the same layouts
+ * `*_delta` BYTES further on (the second network's pack, master and gradient buffers have the first one's layout). */
+typedef struct gs_twin {
+  int32_t n_split, pad_;
+  int64_t w_delta;             /* bf16 weight pack */
+  int64_t bias_delta;          /* fp32 bias vector (master buffer) */
+  int64_t dw_delta;            /* fp32 weight-gradient buffer (gs_wgrad_ws_twin) */
+} gs_twin;
+
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
 int gs_init(int device);                 /* torch.cuda.set_device + lazy cuDNN handle (base.py:84-91) */
 void gs_shutdown(void);
@@ -150,6 +162,16 @@ int gs_gconv_forward_multi_fused(const gs_gconv_desc* const* descs, int32_t coun
  * slots = gs_gconv_ring_slots(d). Returns 0 slots when the layer / grid does not suit the halo kernel; the padded form
  * above is always available. */
 int gs_gconv_ring_slots(const gs_gconv_desc* d);
+/* Twin batches (gs_twin above). gs_gconv_twin_native: 1 when the kernel gs_gconv_forward (fuse == NULL) or
+ * gs_gconv_forward_fused (fuse != NULL) would pick for `d` — d->N = the whole batch of both networks — selects the weight
+ * set per image; 0: the caller runs the two halves as two launches (always possible: the halves are contiguous).
+ * gs_gconv_forward_twin is that launch (fuse == NULL: gs_gconv_forward, else gs_gconv_forward_fused) and fails where
+ * gs_gconv_twin_native says 0. The wide 3x3 residual convs (resnet2d.py:80-87) are native: a twin launch at batch 2 x 8 has
+ * 512 tiles for 256 CUs and every workgroup walks two of them, the second tile's operands arriving under the first one's
+ * K loop (csrc/hconvw.hip). */
+int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse* fuse);
+int gs_gconv_forward_twin(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                          float* stats, const gs_gconv_fuse* fuse, const gs_twin* tw, void* stream);
 /* Same launch as gs_gconv_forward with a caller-owned fp32 workspace for split-K: layers with few output tiles and a
  * long K loop (U-Net bottleneck convs unet2d.py:129-136, the PatchGAN 512->1 tail patchgan2d.py:62) run their K range
  * split over the chip and a second pass sums the partial results and applies bias / statistics / activation.

@@ -1,0 +1,162 @@
+"""Twin batches on the GPU (include/ganslate_hip.h gs_twin, csrc/hconvw.hip): ONE launch over the images of two networks —
+the kernel picks the weight set per image, and with more tiles than CUs every workgroup walks several tiles (persistent
+form) — must give, bit for bit, what the two separate launches give (and those are pinned to the oracle in
+tests/test_ops_gpu.py). Then the recipe level: CycleGAN iterations with twin passes against the two-pass form.
+resnet2d.py:80-87 (residual convs), cyclegan.py:126-189 (which passes are independent)."""
+import random
+
+import pytest
+import torch
+
+from ganslate_amd.nn.native.spec import ConvSpec
+from ganslate_amd.nn.native.twin import Twin
+from oracle.ops_ref import RefOps
+
+from .helpers import build_product_cyclegan, golden_inputs, load_golden_steps
+from .test_ops_gpu import close_bf16, close_f32, make_layer, stats_slots
+
+pytestmark = pytest.mark.gpu
+
+# (channels, images per network, H, W): the headline trunk (512 tiles: two per workgroup), three tiles per workgroup with
+# a ragged last round (and a persistent single launch), the smallest batch the kernel takes (6 x 32 = 192 tiles), a ragged
+# box grid (60 tiles per image: 4 images per round), a wide map (more tiles per image than a round: one tile per workgroup)
+TRUNK_CASES = [(256, 8, 64, 64), (256, 10, 64, 64), (256, 6, 64, 64), (128, 4, 96, 160), (256, 1, 256, 256)]
+
+
+def _two_layers(C, H, W):
+    spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
+    la = make_layer(spec, (H, W), 101)
+    lb = make_layer(spec, (H, W), 202)
+    return spec, la, lb
+
+
+@pytest.mark.parametrize("case", TRUNK_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_twin_forward_equals_two_launches(hip_ops, case):
+    C, N, H, W = case
+    dev = hip_ops.device
+    spec, (low, _, bias_a, fpack_a, _), (_, _, bias_b, fpack_b, _) = _two_layers(C, H, W)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    packs = torch.stack([fpack_a, fpack_b]).to(dev)           # one allocation: any delta works, this one is small
+    biases = torch.stack([bias_a, bias_b]).to(dev)
+    slots, offs = stats_slots(hip_ops, low, low.fwd, 2 * N)
+    assert slots == stats_slots(hip_ops, low, low.fwd, N)[0], "slot count per image must not depend on the batch"
+
+    def run(xs, pack, bias, n):
+        y = torch.zeros(n, H, W, C, dtype=torch.bfloat16, device=dev)
+        part = torch.full((n * slots * 2 * C,), float("nan"), dtype=torch.float32, device=dev)
+        hip_ops.gconv_classes(low.fwd, xs, pack, bias, y, act="none", stats=part, stats_slots=slots, stats_slot0s=offs)
+        return y, part
+    y_tw, p_tw = run(x, Twin(packs[0], packs[1]), Twin(biases[0], biases[1]), 2 * N)
+    y_a, p_a = run(x[:N], packs[0], biases[0], N)
+    y_b, p_b = run(x[N:], packs[1], biases[1], N)
+    torch.cuda.synchronize()
+    assert torch.equal(y_tw[:N], y_a) and torch.equal(y_tw[N:], y_b), "twin launch differs from the two launches"
+    assert torch.equal(p_tw, torch.cat([p_a, p_b])), "statistics slots differ"
+    assert not torch.isnan(p_tw).any()
+    # and against the oracle (first network's half; the other half is the same kernel with another pointer)
+    ref = RefOps()
+    y_ref = torch.zeros(N, H, W, C, dtype=torch.bfloat16)
+    ref.gconv(low.fwd[0], x[:N].cpu(), fpack_a, bias_a, y_ref)
+    close_bf16(y_tw[:N], y_ref, "twin forward vs oracle")
+
+
+@pytest.mark.parametrize("persist", [1, 0])
+def test_many_tiles_per_workgroup_equal_one_tile_each(hip_ops, persist):
+    """one network, batch 24 at the trunk shape: 768 tiles = three per workgroup in the persistent form (option
+    hconvw_persist), one each otherwise — same bits, and equal to the oracle"""
+    C, N, H, W = 256, 24, 64, 64
+    dev = hip_ops.device
+    spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
+    low, _, bias, fpack, _ = make_layer(spec, (H, W), 7)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    default = hip_ops.get_option("hconvw_persist")
+    try:
+        hip_ops.set_option("hconvw_persist", persist)
+        y = torch.zeros(N, H, W, C, dtype=torch.bfloat16, device=dev)
+        hip_ops.gconv(low.fwd[0], x.to(dev), fpack.to(dev), bias.to(dev), y, act="relu")
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.set_option("hconvw_persist", default)
+    ref = RefOps()
+    y_ref = torch.zeros(N, H, W, C, dtype=torch.bfloat16)
+    ref.gconv(low.fwd[0], x, fpack, bias, y_ref, act="relu")
+    close_bf16(y, y_ref, f"forward, hconvw_persist={persist}")
+    if persist == 1:
+        test_many_tiles_per_workgroup_equal_one_tile_each.y = y.cpu()
+    elif hasattr(test_many_tiles_per_workgroup_equal_one_tile_each, "y"):
+        assert torch.equal(y.cpu(), test_many_tiles_per_workgroup_equal_one_tile_each.y)
+
+
+@pytest.mark.parametrize("case", TRUNK_CASES[:4], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none")])
+def test_twin_ring_dgrad_equals_two_launches(hip_ops, case, with_g2, act):
+    """the fused data gradient on the unpadded domain (hconvw.hip RING) as a twin launch: gradient and the per-box sums of
+    the consumer's norm backward, bit for bit, and the first half against the oracle"""
+    C, N, H, W = case
+    dev = hip_ops.device
+    spec, (low, _, _, _, dpack_a), (_, _, _, _, dpack_b) = _two_layers(C, H, W)
+    g = torch.Generator().manual_seed(9)
+    gy = torch.randn(2 * N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    y = (torch.randn(2 * N, H, W, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16).to(dev)
+    g2 = torch.randn(2 * N, H, W, C, generator=g).to(torch.bfloat16).to(dev) if with_g2 else None
+    packs = torch.stack([dpack_a, dpack_b]).to(dev)
+    part = torch.stack([y.float().sum((1, 2)), (y.float() ** 2).sum((1, 2))], 1).reshape(-1).contiguous()
+    mr = torch.empty(2 * N * 2 * C, dtype=torch.float32, device=dev)
+    hip_ops.inorm_finalize(part, 2 * N, 1, C, H * W, mr)
+
+    def run(sl, pack, n):
+        ring = hip_ops.fused_ring_plan(low.dgrad_ring, n, C)
+        assert ring is not None
+        gx = torch.zeros(n, H, W, C, dtype=torch.bfloat16, device=dev)
+        fz = {"y": y[sl], "mean_rstd": mr[sl.start * 2 * C:sl.stop * 2 * C], "g2": None if g2 is None else g2[sl],
+              "partial": ring[1], "fold": 1, "fold_mode": "reflect", "act": act, "slope": 0.2}
+        hip_ops.gconv(low.dgrad_ring, gy[sl], pack, None, gx, fuse=fz)
+        return gx, ring[1][:n * ring[0] * 3 * C].clone(), ring
+    gx_tw, s_tw, ring_tw = run(slice(0, 2 * N), Twin(packs[0], packs[1]), 2 * N)
+    gx_a, s_a, _ = run(slice(0, N), packs[0], N)
+    gx_b, s_b, _ = run(slice(N, 2 * N), packs[1], N)
+    torch.cuda.synchronize()
+    assert torch.equal(gx_tw[:N], gx_a) and torch.equal(gx_tw[N:], gx_b), "twin ring launch differs from the two launches"
+    assert torch.equal(s_tw, torch.cat([s_a, s_b])), "norm-backward sums differ"
+    # oracle, first half
+    ref = RefOps()
+    ref.ring_min_blocks = 0
+    yc, mrc = y[:N].cpu(), mr[:N * 2 * C].cpu()
+    ring = ref.fused_ring_plan(low.dgrad_ring, N, C)
+    gx_ref = torch.zeros(N, H, W, C, dtype=torch.bfloat16)
+    ref.gconv(low.dgrad_ring, gy[:N].cpu(), dpack_a, None, gx_ref,
+              fuse={"y": yc, "mean_rstd": mrc, "g2": None if g2 is None else g2[:N].cpu(), "partial": ring[1], "fold": 1,
+                    "fold_mode": "reflect", "act": act, "slope": 0.2})
+    close_bf16(gx_tw[:N], gx_ref, "twin ring dgrad vs oracle")
+    sums = s_tw.view(2 * N, ring_tw[0], 3, C).sum(1)[:N]
+    close_f32(sums, ring[1][:N * 3 * C].view(N, 3, C), "ring partial sums vs oracle", rel=3e-3)
+
+
+@pytest.mark.parametrize("name", ["c64_default", "c64_idt_ssim"])
+def test_cyclegan_step_with_twin_passes_equals_the_two_pass_step(name, monkeypatch):
+    """whole iterations on the GPU: twin passes (generators and discriminators as one batch each) against GS_TWIN=0. The
+    convs of a twin batch are the kernels of the separate passes (same tiles, same order), so the first iteration's losses
+    agree to fp32 summation noise; weights after two Adam steps stay within sign-flip noise."""
+    c = load_golden_steps()[name]["config"]
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GS_TWIN", mode)
+        monkeypatch.setenv("GS_STEP_GRAPH", "0")
+        model = build_product_cyclegan(c)
+        assert (model.twin_G is not None) == (mode == "1")
+        random.seed(c["seed"])
+        out = []
+        for step in range(2):
+            a, b = golden_inputs(c, step)
+            model.set_input({"A": a, "B": b})
+            model.optimize_parameters()
+            out.append({k: float(v.detach()) for k, v in model.losses.items() if v is not None})
+        torch.cuda.synchronize()
+        runs[mode] = (out, {n: net.master.detach().float().cpu().clone() for n, net in model.networks.items()})
+    for s in range(2):
+        for k, v in runs["0"][0][s].items():
+            assert runs["1"][0][s][k] == pytest.approx(v, rel=2e-3 if s == 0 else 5e-2, abs=1e-5), (s, k)
+    for n, w in runs["0"][1].items():
+        assert (runs["1"][1][n] - w).abs().mean().item() <= 1e-4, n
