@@ -50,7 +50,6 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"splitk_target", 256},     // ... aiming at this many workgroups
     {"hconv", 1},               // halo-resident forward kernel for narrow stride-1 layers (hconv.hip)
     {"hconv_wide", 1},          // halo-resident forward kernel for the wide 3x3 layers (hconvw.hip)
-    {"hconvw_waves", 16},       // 16 or 8 (64 x 64 wave tiles) waves per workgroup: equal in an interleaved A/B (39.9 vs 40.5 us)
     {"hwgrad", 1},              // halo-resident weight-gradient kernels (hwgrad.hip)
     {"hwgrad_wide", 1},         // ... the wide 3x3 form
     {"hwgrad_planes", 1},       // ... 3x3x3 layers as three depth planes of it
@@ -62,14 +61,12 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconvt", 192},            // halo-resident kernel for the four parity classes of a stride-2 layer in one pass (hconvt.hip):
                                 // smallest grid (boxes x channel tiles x batch) it takes, 0 = off
     {"hstrip", 1024},           // halo-resident kernel for the W-folded k7 boundary convs (hstrip.hip): smallest grid, 0 = off
-    {"hconvx", 0},              // self-pipelined 8-wave form of the wide 3x3 kernels (hconvx.hip) instead of hconvw.hip's phase-locked loop
     {"wfold_rows", 1},          // row-staged forms of the four W-fold boundary transforms (wfold.hip) instead of one thread per pixel
     {"hwgrad_ft", 1},           // halo-resident weight gradient of narrow layers with few taps (hwgrad.hip: the 2-D k7 boundary convs)
     {"gconv_big", 192},         // smallest number of 256 x 128 im2col tiles that selects them (one workgroup per CU) over 128 x 128 (two)
     {"hconv_box8", 1},          // hconv.hip: 8 x 8 x 8 boxes on 8 waves for volumes (4 x 8 x 8 on 4 waves otherwise)
     {"hconv_persist", 0},       // hconv.hip: smallest number of boxes the persistent resident-weight form takes (16 -> 16 channel k5 volume
                                 // layers), 0 = off (default: 191 vs 204 us alone at 128^3, but 73.4 vs 72.6 ms in the brats step)
-    {"hconvw_ring_waves", 16},  // 16 or 8 waves for the fused data gradient of the wide 3x3 layers (hconvw.hip RING)
     {"hstrip_persist", 0},      // hstrip.hip: smallest number of tiles the persistent double-buffered form takes, 0 = off (default:
                                 // measured 62-74 us against 42-55 for one workgroup per tile, two per CU)
     {"hconvw_persist", 1},      // hconvw.hip: launches with more tiles than CUs run ceil(tiles / CUs) tiles per workgroup (0: one each)

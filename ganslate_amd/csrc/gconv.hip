@@ -710,7 +710,7 @@ extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, co
 
 // ---- twin batches (gs_twin): which launches pick the weight set per image ------------------------------------------------
 extern "C" int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse* fuse) {
-  if (!d || gs_opt(GS_OPT_HCONVX)) return 0;
+  if (!d) return 0;
   if (fuse) return fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy && gs_gconv_ring_slots(d) > 0;
   return !gs_hconv_slots(d) && gs_hconvw_slots(d) > 0;
 }

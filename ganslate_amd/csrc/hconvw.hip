@@ -350,6 +350,9 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       const int pl = q * PPI + prow;
       return pix0 + (size_t)(wm * 4 + ph * 2 + (pl >> 4)) * d.Wo + (pl & 15);
     };
+    static_assert(NQ == 2, "four store values per lane");
+    uint4 val0, val1, val2, val3;                  // the tile in store layout: 4 x 16 B per lane (named: an indexed array
+                                                   // ended up in scratch memory)
     [[maybe_unused]] uint2 yv[TI][TJ], gv[TI][TJ];
     [[maybe_unused]] f32x4 mrv;
     [[maybe_unused]] f32x4 bia[TI];
@@ -380,11 +383,6 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     }
     // both groups back in step; every LDS operand of this tile has been read
     if (!grp) __builtin_amdgcn_s_barrier();       // group 1 ran one barrier ahead of the loop
-    if (has_next) {                               // K-step 2 of the next tile into the slot of this tile's last step,
-      int c2, t2;                                 // issued BEFORE the epilogue's stores (see the waits above)
-      ct_of(2, c2, t2);
-      issue_w(n + nstep, c2, t2, stage == 0 ? 2 : stage - 1);
-    }
     // the epilogue works out of the halo buffer the next chunk does NOT use: hpar now names the next tile's chunk-0
     // buffer (already filled), the other one is free
     char* const ebuf = hbuf + (hpar ^ 1) * HBUF;
@@ -461,10 +459,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
             *reinterpret_cast<uint2*>(slab + (jj * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = pk[i][ph * 2 + jj];
         __builtin_amdgcn_wave_barrier();                     // wave-private slab: LDS operations of a wave complete in order
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int pl = q * PPI + prow;
-          const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
-          *reinterpret_cast<uint4*>(p.out + (opix_of(ph, q) * d.out_cs + d.out_co + co) * 2) = val;
+        for (int q = 0; q < NQ; ++q)
+        {
+          const uint4 v = *reinterpret_cast<const uint4*>(slab + (q * PPI + prow) * SROW + sub * 16);
+          if (ph == 0 && q == 0) val0 = v; else if (ph == 0) val1 = v; else if (q == 0) val2 = v; else val3 = v;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -509,10 +507,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
           }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int pl = q * PPI + prow;             // pixel inside this pass's two box rows
-          const uint4 val = *reinterpret_cast<const uint4*>(slab + pl * SROW + sub * 16);
-          *reinterpret_cast<uint4*>(p.out + (opix_of(ph, q) * d.out_cs + d.out_co + co) * 2) = val;
+        for (int q = 0; q < NQ; ++q)               // pixel q * PPI + prow of this pass's two box rows
+        {
+          const uint4 v = *reinterpret_cast<const uint4*>(slab + (q * PPI + prow) * SROW + sub * 16);
+          if (ph == 0 && q == 0) val0 = v; else if (ph == 0) val1 = v; else if (q == 0) val2 = v; else val3 = v;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -542,14 +540,23 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
         }
       }
     }
+    // Everything the epilogue reads from LDS or memory has been read. Now, in this order: K-step 2 of the next tile into the
+    // slot of this tile's last step (an LDS-DMA in front of any LDS access would make the compiler wait vmcnt(0) there),
+    // then the tile's four output stores, which nothing ever waits for (see the counted waits of the next tile's first
+    // K-steps: the stores are younger than these weights and older than the chunk-1 halo).
     if (has_next) {
       lds_barrier();                              // slabs and sums read by everybody: the next chunk-1 halo may land there
-      if (grp) __builtin_amdgcn_s_barrier();      // group 1 one barrier ahead again
+      int c2, t2;
+      ct_of(2, c2, t2);
+      issue_w(n + nstep, c2, t2, stage == 0 ? 2 : stage - 1);
     }
+    *reinterpret_cast<uint4*>(p.out + (opix_of(0, 0) * d.out_cs + d.out_co + co) * 2) = val0;
+    *reinterpret_cast<uint4*>(p.out + (opix_of(0, 1) * d.out_cs + d.out_co + co) * 2) = val1;
+    *reinterpret_cast<uint4*>(p.out + (opix_of(1, 0) * d.out_cs + d.out_co + co) * 2) = val2;
+    *reinterpret_cast<uint4*>(p.out + (opix_of(1, 1) * d.out_cs + d.out_co + co) * 2) = val3;
+    if (has_next && grp) __builtin_amdgcn_s_barrier();      // group 1 one barrier ahead again
   }
 }
-
-int gs_hconvx_launch(const HConvWK& k, long long blocks, void* stream);   // hconvx.hip
 
 static bool hconvw_eligible(const gs_gconv_desc* d, int* lo) {
   const bool enabled = gs_opt(GS_OPT_HCONV_WIDE) != 0;
@@ -635,7 +642,6 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
     configured = true;
   }
   *handled = 1;
-  if (gs_opt(GS_OPT_HCONVX) && !tw) return gs_hconvx_launch(k, blocks, stream);
   hipLaunchKernelGGL((hconvw_kernel<9>), dim3((unsigned)hconvw_grid(d->N, k.tiles_m * k.tiles_n, k.chunks)), dim3(1024), lds,
                      static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());

@@ -1,4 +1,4 @@
-// Kernel arguments shared by the halo-resident kernels of the wide 3x3 stride-1 layers (hconvw.hip, hconvx.hip)
+// Kernel arguments shared by the halo-resident kernels of the wide 3x3 stride-1 layers (hconvw.hip)
 #pragma once
 #include "common.hpp"
 

@@ -46,11 +46,11 @@ class HipOps(TwinSplit):
     # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
     # host side are mapped onto its options here, when the backend is created and whenever a model is built.
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
-                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_NW": "hconvw_waves",
+                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
                    "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
-                   "GS_HCONVX": "hconvx", "GS_WFOLD_ROWS": "wfold_rows", "GS_HWGRAD_FT": "hwgrad_ft", "GS_GCONV_BIG": "gconv_big", "GS_HCONV_BOX8": "hconv_box8", "GS_HCONV_PERSIST": "hconv_persist", "GS_HCONVW_RING_NW": "hconvw_ring_waves", "GS_HSTRIP_PERSIST": "hstrip_persist"}
+                   "GS_WFOLD_ROWS": "wfold_rows", "GS_HWGRAD_FT": "hwgrad_ft", "GS_GCONV_BIG": "gconv_big", "GS_HCONV_BOX8": "hconv_box8", "GS_HCONV_PERSIST": "hconv_persist", "GS_HSTRIP_PERSIST": "hstrip_persist"}
 
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")
@@ -130,17 +130,31 @@ class HipOps(TwinSplit):
         """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
         return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
-    def fused_norm_plan(self, g: GConv, N: int, C_: int, force: bool = False):
+    # ---- twin batches (nn/native/twin.py): which batch a launch sees --------------------------------------------
+    # Kernel choice — and with it the number of statistics / partial-sum slots per image — depends on the batch of the
+    # LAUNCH. A twin batch of N images is one launch of N where the kernel picks the weight set per image
+    # (gs_gconv_twin_native) and two launches of N / 2 otherwise; the planning calls below take `twin` and answer for the
+    # launches that will actually run, while their buffers are sized for all N images.
+    def twin_native(self, g: GConv, N: int, ring: bool = False) -> bool:
+        if os.environ.get("GS_TWIN_NATIVE", "1") == "0":
+            return False
+        d = self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
+        if ring:
+            return self.lib.gs_gconv_ring_slots(C.byref(d)) > 0
+        return bool(self.lib.gs_gconv_twin_native(C.byref(d), None))
+
+    def fused_norm_plan(self, g: GConv, N: int, C_: int, force: bool = False, twin: bool = False):
         """(slots, scratch) for fusing the reduction pass of the consumer's InstanceNorm backward into the data-gradient
         launch of class g, or None when this backend / layer shape does not fuse (narrow layers run on the halo kernel)"""
         if g.so != 1 or g.si not in (1, 2) or g.Co <= 64 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
             return None
         if g.si == 2 and os.environ.get("GS_FUSE_SI2", "1") == "0":     # (A/B switch: data gradients of transposed convs)
             return None
-        d = self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
+        Nl = N // 2 if twin else N         # (the padded-domain fused launch has no twin form: two launches)
+        d = self._gdesc(g, Nl, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
         if self._splitk_floats(d) and not force:   # few output tiles, long K: split-K wins over the fused epilogue
             return None
-        tm = self.tile_m(g, N)
+        tm = self.tile_m(g, Nl)
         slots = (g.pixels + tm - 1) // tm
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
@@ -165,7 +179,7 @@ class HipOps(TwinSplit):
             self._desc_cache[key] = ent
         return ent
 
-    def fused_multi_plan(self, classes, N: int, C_: int):
+    def fused_multi_plan(self, classes, N: int, C_: int, twin: bool = False):
         """(slots, scratch) when the output-parity classes of a stride-2 conv's data gradient run as ONE halo-resident launch
         that can carry the reduction pass of the consumer's InstanceNorm backward in its epilogue (hconvt.hip), else None"""
         # (GS_FUSE_MULTI=0: A/B switch. Worth 0.3 % once the fused instantiation stopped spilling, DESIGN.md §4.11)
@@ -173,25 +187,27 @@ class HipOps(TwinSplit):
         if len(classes) != 4 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0" or \
                 os.environ.get("GS_FUSE_MULTI", "1") == "0":
             return None
-        arr, _ = self._multi_descs(classes, N, g.Ci, g.Co)
+        arr, _ = self._multi_descs(classes, N // 2 if twin else N, g.Ci, g.Co)     # (no twin form: two launches)
         slots = self.lib.gs_gconv_multi_fused_slots(arr, len(classes))
         if slots <= 0:
             return None
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
-    def fused_ring_plan(self, g: GConv, N: int, C_: int):
+    def fused_ring_plan(self, g: GConv, N: int, C_: int, twin: bool = False):
         """(slots, scratch) when the fused data gradient of a reflect-padded 3x3 layer can run on the unpadded domain
         (class g = Lowered.dgrad_ring; the launch folds the ring itself, hconvw.hip RING), else None"""
         if g is None or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0":
             return None
-        slots = self.lib.gs_gconv_ring_slots(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+        Nl = N // 2 if (twin and not self.twin_native(g, N, ring=True)) else N
+        slots = self.lib.gs_gconv_ring_slots(C.byref(self._gdesc(g, Nl, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
         if slots <= 0:
             return None
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
-    def stat_slots(self, g: GConv, N: int) -> int:
+    def stat_slots(self, g: GConv, N: int, twin: bool = False) -> int:
         """partial-statistics slots per image the kernel writes for this class at batch N"""
-        return self.lib.gs_gconv_stat_slots(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+        Nl = N // 2 if (twin and not self.twin_native(g, N)) else N
+        return self.lib.gs_gconv_stat_slots(C.byref(self._gdesc(g, Nl, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
     # ---- convolution family -------------------------------------------------------------------------------
     def gconv(self, g: GConv, x, wpack, bias, out, *, in_cs=None, in_co=0, out_cs=None, out_co=0, act="none",
@@ -202,8 +218,8 @@ class HipOps(TwinSplit):
         d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0, accumulate)
         if is_twin(wpack, bias):      # two networks' weights over one batch (nn/native/twin.py)
             f = self._fuse_struct(fuse) if fuse is not None else None
-            if os.environ.get("GS_TWIN_NATIVE", "1") != "0" and isinstance(wpack, Twin) and \
-                    self.lib.gs_gconv_twin_native(C.byref(d), C.byref(f) if f is not None else None):
+            ring = f is not None and f.fold > 0 and tuple(fuse["y"].shape[-3:-1]) == (g.Ho, g.Wo)
+            if isinstance(wpack, Twin) and (f is None or ring) and not accumulate and self.twin_native(g, N, ring=ring):
                 # the kernel picks the weight set per image: one launch over both networks' images
                 tw = L.Twin()
                 tw.n_split, tw.w_delta = N // 2, wpack.delta()

@@ -453,7 +453,7 @@ class NativeNet:
                 slots, offs = 0, []
                 for g in lw.fwd:
                     offs.append(slots)
-                    slots += ops.stat_slots(g, N)
+                    slots += ops.stat_slots(g, N, twin=tw is not None)
                 part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=dev)
                 ops.gconv_classes(lw.fwd, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
                 mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=dev)
@@ -635,12 +635,12 @@ class NativeNet:
                 # (wide stride-1 layers; not when a tapped feature gradient is still to be added to gx)
                 plan = None
                 if i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 1 and (i - 1) not in inj_x and not nodes[i - 1].attn:
-                    plan = ops.fused_norm_plan(lw.dgrad[0], N, sp.cin_p)
+                    plan = ops.fused_norm_plan(lw.dgrad[0], N, sp.cin_p, twin=tw is not None)
                 elif i > 0 and nodes[i - 1].norm and len(lw.dgrad) == 4 and f == 0 and (i - 1) not in inj_x \
                         and not nodes[i - 1].attn:
                     # the four parity classes of a stride-2 conv's data gradient as one halo-resident launch (hconvt.hip)
-                    plan = ops.fused_multi_plan(lw.dgrad, N, sp.cin_p)
-                ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p) if plan is not None else None
+                    plan = ops.fused_multi_plan(lw.dgrad, N, sp.cin_p, twin=tw is not None)
+                ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p, twin=tw is not None) if plan is not None else None
                 if ring is None:
                     gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
                 if ring is not None:

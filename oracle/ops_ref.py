@@ -90,15 +90,15 @@ class RefOps(TwinSplit):
     def tile_m(self, g, N=1):
         return 1 << 30  # one statistics slot per class
 
-    def stat_slots(self, g, N=1):
+    def stat_slots(self, g, N=1, twin=False):
         return 1
 
-    def fused_norm_plan(self, g, N, C_, force=False):
+    def fused_norm_plan(self, g, N, C_, force=False, twin=False):
         if g.so != 1 or g.si not in (1, 2) or g.Co <= 64 or g.Co != C_:
             return None
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
-    def fused_ring_plan(self, g, N, C_):
+    def fused_ring_plan(self, g, N, C_, twin=False):
         """the layers the library's gs_gconv_ring_slots accepts (hconvw.hip hconvw_ring_eligible), restated"""
         if g is None or g.Co != C_ or g.T != 9 or g.Ci % 64 or g.Co % 128 or g.Ho % 16 or g.Wo % 16:
             return None
@@ -107,7 +107,7 @@ class RefOps(TwinSplit):
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
     # ---- convolution family ---------------------------------------------------------------------------
-    def fused_multi_plan(self, classes, N, C_):
+    def fused_multi_plan(self, classes, N, C_, twin=False):
         """the layers gs_gconv_multi_fused_slots accepts (hconvt.hip gs_hconvt_pattern), restated: the four parity classes of
         a 2-D stride-2 layer, 64-multiple channels, class grid a multiple of 16"""
         g = classes[0]

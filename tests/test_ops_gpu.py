@@ -164,19 +164,20 @@ def test_halo_resident_narrow_kernel_box_forms(hip_ops, case):
             hip_ops.set_option(o, v)
 
 
-@pytest.mark.parametrize("form", [1, 100], ids=["8-waves", "8+4-loader-waves"])
+@pytest.mark.parametrize("persist", [1, 0], ids=["persistent", "one-tile-per-workgroup"])
 @pytest.mark.parametrize("case", [
     (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 8, 64, 64),     # headline trunk conv (4 chunks x 9 taps)
     (ConvSpec("conv", 64, 128, 3, 1, 1, pad_mode="reflect"), 4, 128, 96),     # one chunk, one channel tile, border boxes
     (ConvSpec("conv", 128, 256, 3, 1, 1), 4, 64, 96),                         # zero border, two chunks
+    (ConvSpec("conv", 128, 256, 3, 1, 1), 12, 64, 96),                        # ... 576 tiles: three per workgroup, two chunks
+    (ConvSpec("conv", 64, 128, 3, 1, 1, pad_mode="reflect"), 12, 128, 96),    # ... one chunk: stays one tile per workgroup
 ], ids=_ids)
-def test_self_pipelined_wide_kernel(hip_ops, monkeypatch, case, form):
-    """hconvx.hip (gs_set_option("hconvx", 1 | 100): the self-pipelined 8-wave form of the wide 3x3 kernel on 32x32x16 MFMAs,
-    alone or with four loader waves; measured equal to hconvw.hip's phase-locked loop — the chip sustains a lower clock under
-    the denser loop, profiles/r03_power_probe.txt — and therefore off by default) against the oracle: same contract as the
-    default form (bias, one statistics slot per 16 x 16 box, bf16 NHWC output)."""
-    monkeypatch.setenv("GS_HCONVX", str(form))
-    hip_ops.sync_options()
+def test_wide_halo_kernel_forward(hip_ops, case, persist):
+    """hconvw.hip, forward form, against the oracle (bias, one statistics slot per 16 x 16 box, bf16 NHWC output): one tile per
+    workgroup and — more tiles than CUs, at least two channel chunks — several (option hconvw_persist); the chunk-count and
+    border edge cases of its DMA pipeline."""
+    default = hip_ops.get_option("hconvw_persist")
+    hip_ops.set_option("hconvw_persist", persist)
     spec, N, sizes = case[0], case[1], case[2:]
     low, master, bias, fpack, dpack = make_layer(spec, sizes, 11)
     assert hip_ops.stat_slots(low.fwd[0], N) == (sizes[0] // 16) * (sizes[1] // 16), "the wide halo kernel must take this layer"
@@ -189,6 +190,7 @@ def test_self_pipelined_wide_kernel(hip_ops, monkeypatch, case, form):
     C = spec.cout_p
     close_f32(mr_hip.view(N, 2, C)[:, 0], mr_ref.view(N, 2, C)[:, 0], "mean", rel=1e-3)
     close_f32(mr_hip.view(N, 2, C)[:, 1], mr_ref.view(N, 2, C)[:, 1], "rstd", rel=1e-3)
+    hip_ops.set_option("hconvw_persist", default)
 
 
 @pytest.mark.parametrize("case", [
@@ -525,16 +527,12 @@ def test_dgrad_with_fused_norm_reduction(hip_ops, case, with_g2, act):
 @pytest.mark.parametrize("case", [(256, 8, 64, 64), (256, 16, 32, 48), (128, 48, 32, 32), (256, 2, 96, 128)],
                          ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none")])
-@pytest.mark.parametrize("waves", [16, 8])
-def test_dgrad_ring_form(hip_ops, case, with_g2, act, waves):
-    """Both wave counts of the kernel (option hconvw_ring_waves: 16 waves of 64 x 32, or 8 of 64 x 64 that leave registers
-    for another stream's workgroups on the CU). Unpadded (ring) form of the fused data gradient of a reflect-padded 3x3 conv (gs_gconv_ring_slots, hconvw.hip
+def test_dgrad_ring_form(hip_ops, case, with_g2, act):
+    """Unpadded (ring) form of the fused data gradient of a reflect-padded 3x3 conv (gs_gconv_ring_slots, hconvw.hip
     RING): the finished input gradient equals the padded-domain launch folded by the consumer (same kernel family,
     fold in fp32 before the rounding here, after it there), the oracle's restatement, and the epilogue sums drive
     gs_inorm_act_backward to the same dy. resnet2d.py:80-87 backward."""
     C, N, H, W = case
-    default_waves = hip_ops.get_option("hconvw_ring_waves")
-    hip_ops.set_option("hconvw_ring_waves", waves)
     spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
     low, master, bias, fpack, dpack = make_layer(spec, (H, W), 31)
     assert low.dgrad_ring is not None
@@ -566,7 +564,6 @@ def test_dgrad_ring_form(hip_ops, case, with_g2, act, waves):
         sums_pad = plan[1][:N * plan[0] * 3 * C].view(N, plan[0], 3, C).sum(1)
         res[name] = (gx, dy_ring, dy_pad, sums, sums_pad, tot_pad)
     torch.cuda.synchronize()
-    hip_ops.set_option("hconvw_ring_waves", default_waves)
     close_bf16(res["hip"][0], res["ref"][0], "ring dgrad vs oracle")
     # the padded launch rounds every padded-domain pixel to bf16 before the consumer folds it: up to 4 roundings at a corner
     close_bf16(res["hip"][0], res["hip"][5].cpu() if not with_g2 else res["ref"][0], "ring dgrad vs padded launch folded")
