@@ -34,6 +34,11 @@ struct HWGradK {
   // on dw; wgrad_reduce_kernel then adds the slabs in a fixed order
   float* ws;
   long long ws_stride;
+  // twin batch (gs_twin; hwgrad_wide only): d.N = 2 x nimg images per operand tensor, images >= nimg belong to the second
+  // network, whose gradient buffer lies dw_delta floats behind dw. Workgroups blockIdx.x < gsplit walk the first network's
+  // boxes, the others the second's; slab = blockIdx.x either way. One network: nimg = d.N, gsplit = gridDim.x.
+  int nimg, gsplit;
+  long long dw_delta;
   gs_wgrad_desc d;
 };
 
@@ -385,17 +390,21 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
   }
   const bool ragged = (d.Ha % p.BH) != 0 || (d.Wa % p.BW) != 0;
 
-  auto issue_box = [&](int box, int b) {
+  // this workgroup's network (twin batch) and its place among the workgroups that share the (p, q) block
+  const int net = (int)blockIdx.x >= p.gsplit ? 1 : 0;
+  const int gx = (int)blockIdx.x - net * p.gsplit, gnum = net ? (int)gridDim.x - p.gsplit : p.gsplit;
+  auto issue_box = [&](int box, int b) {                 // box index among this network's boxes (first pair, then second)
     int bb = box;
     const int bx = bb % p.nbw; bb /= p.nbw;
     const int by = bb % p.nbh; bb /= p.nbh;
     const int bz = bb % p.nbd;
     int n = bb / p.nbd;
-    if (box >= p.nboxes1) n -= d.N;                      // image index inside the second pair
+    const bool second = box >= p.nboxes1;                // wave-uniform: the second operand pair
+    if (second) n -= p.nimg;                             // image index inside the second pair
+    n += net * p.nimg;                                   // ... of this network's half of the batch
     const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
     char* at = at_of(b);
     char* halo = halo_of(b);
-    const bool second = box >= p.nboxes1;                // wave-uniform
     const size_t pix0 = (((size_t)n * d.Da + oz0) * d.Ha + oy0) * d.Wa + ox0;
     const char* a_n = (second ? p.a2 : p.a) + (pix0 * d.a_cs + d.a_co) * 2;
     if (ragged) {                                        // wave-uniform: boxes that hang over the image edge
@@ -457,12 +466,12 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
   }
 
   int cur = 0;
-  int box = blockIdx.x;
+  int box = gx;
   if (box < p.nboxes) issue_box(box, 0);
-  for (; box < p.nboxes; box += gridDim.x) {
+  for (; box < p.nboxes; box += gnum) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this box landed (nothing else is outstanding)
     __syncthreads();                                     // ... for every wave; the other buffer is fully consumed
-    if (box + (int)gridDim.x < p.nboxes) issue_box(box + gridDim.x, cur ^ 1);
+    if (box + gnum < p.nboxes) issue_box(box + gnum, cur ^ 1);
     // ---- 8 K-steps x T taps as a rolling pipeline of "units" (one tap of one K-step = 2 transpose reads of the gathered
     // fragment, plus the 4 reads of the K-step's two dense fragments in front of tap 0; 2 MFMAs) ---------------------
     // The reads go through inline asm (common.hpp, lds_read128 family): with the LDS-DMA in this loop hipcc waits
@@ -517,7 +526,7 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
           const int pp = pt * 64 + wp * 32 + i * 16 + fk * 4 + r;
           const size_t e = (size_t)pp * d.dw_ld + t * d.Q + q;
           if (p.ws) p.ws[(size_t)blockIdx.x * p.ws_stride + e] = acc[t][i][r];
-          else unsafeAtomicAdd(p.dw + e, acc[t][i][r]);
+          else unsafeAtomicAdd(p.dw + net * p.dw_delta + e, acc[t][i][r]);
         }
     }
   }
@@ -542,11 +551,13 @@ int launch_hw(const HWGradK& k, dim3 grid, int lds, hipStream_t st) {
 // ws != nullptr: partial sums go to slabs of ws (see HWGradK) and *handled returns the number of slabs written (the caller
 // runs the reduction); plan_only: nothing is launched, *handled is what a launch would return.
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
-                   float* ws, int plan_only, void* stream, int* handled);
+                   float* ws, int plan_only, void* stream, int* handled, const gs_twin* tw);
 
-// a2/g2 != nullptr: a second operand pair of the same layer (only the wide kernel merges; otherwise *handled stays 0)
+// a2/g2 != nullptr: a second operand pair of the same layer (only the wide kernel merges; otherwise *handled stays 0).
+// tw != nullptr: twin batch (only the wide kernel takes it; *handled then is the number of slabs PER NETWORK, the second
+// network's slabs follow the first's)
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
-                   float* ws, int plan_only, void* stream, int* handled) {
+                   float* ws, int plan_only, void* stream, int* handled, const gs_twin* tw) {
   *handled = 0;
   const long long ws_stride = (long long)d->P * d->dw_ld;
   const bool enabled = gs_opt(GS_OPT_HWGRAD) != 0;
@@ -570,7 +581,7 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
         int h = 0;
         // (the plane's slab columns start 9 k Q floats into every slab row, like its columns of dw)
         if (int rc = gs_hwgrad_try2(&sub, a, g, a2, g2, dw + (size_t)9 * k * d->Q, ws ? ws + (size_t)9 * k * d->Q : nullptr,
-                                    plan_only, stream, &h)) return rc;
+                                    plan_only, stream, &h, tw)) return rc;
         if (!h) {
           GS_REQUIRE(k == 0, "gs_wgrad: depth plane %d of a 27-tap layer was refused after plane 0 ran", k);
           return 0;                                  // not eligible after all: the caller falls back for all 27 taps
@@ -594,8 +605,10 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     k.HD = k.BD + hi[0] - lo[0]; k.HH = k.BH + hi[1] - lo[1]; k.HW = k.BW + hi[2] - lo[2];
     k.dmin = lo[0]; k.hmin = lo[1]; k.wmin = lo[2];
     k.nbd = d->Da; k.nbh = (d->Ha + k.BH - 1) / k.BH; k.nbw = (d->Wa + k.BW - 1) / k.BW;   // BD = 1: a box per slice
-    const long long nboxes1 = (long long)d->N * k.nbd * k.nbh * k.nbw;
-    const long long nboxes = a2 ? 2 * nboxes1 : nboxes1;
+    const int nimg = tw ? tw->n_split : d->N;          // images per network and operand tensor
+    if (tw && 2 * nimg != d->N) return 0;
+    const long long nboxes1 = (long long)nimg * k.nbd * k.nbh * k.nbw;
+    const long long nboxes = a2 ? 2 * nboxes1 : nboxes1;  // per network
     const long long hv = (long long)k.HD * k.HH * k.HW;
     const int hbytes = (int)((hv * 144 + 1023) / 1024 * 1024 + 1024);
     const long long tab_bytes = ((long long)k.nbh * k.HH + (long long)k.nbw * k.HW) * 2;      // border tables, see the kernel
@@ -615,9 +628,12 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
       k.zero = static_cast<const char*>(gs_zero_page());
       GS_REQUIRE(k.zero || plan_only, "gs_wgrad: library not initialised (call gs_init)");
       k.d = *d;
-      long long groups = 256 / tiles;                    // one workgroup per CU
+      long long groups = 256 / (tiles * (tw ? 2 : 1));   // one workgroup per CU (twin: per network)
       if (groups < 1) groups = 1;
       if (groups > nboxes) groups = nboxes;
+      k.nimg = nimg;
+      k.gsplit = (int)groups;
+      k.dw_delta = tw ? tw->dw_delta / 4 : 0;
       static bool configured = false;
       if (!configured) {
         GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_wide_kernel<9>),
@@ -628,13 +644,13 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
       k.ws_stride = ws_stride;
       *handled = ws || plan_only ? (int)groups : 1;
       if (plan_only) return 0;
-      hipLaunchKernelGGL((hwgrad_wide_kernel<9>), dim3((unsigned)groups, (unsigned)tiles), dim3(512), lds,
+      hipLaunchKernelGGL((hwgrad_wide_kernel<9>), dim3((unsigned)(groups * (tw ? 2 : 1)), (unsigned)tiles), dim3(512), lds,
                          static_cast<hipStream_t>(stream), k);
       GS_CHECK_HIP(hipGetLastError());
       return 0;
     }
   }
-  if (a2) return 0;                                // only the wide kernel merges two passes
+  if (a2 || tw) return 0;                          // only the wide kernel merges two passes / takes twin batches
   // few taps, narrow on both sides (2-D W-folded k7 boundary convs): the (p, q)-split form
   if (enabled && gs_opt(GS_OPT_HWGRAD_FT) && d->si == 1 && d->T >= 2 && d->T <= 8 && d->Da == 1 && d->P <= 64 && d->Q <= 64 &&
       ((d->P + 15) / 16) * ((d->Q + 15) / 16) <= 8 && (long long)d->N * ((d->Ha + 15) / 16) * ((d->Wa + 15) / 16) >= 512) {

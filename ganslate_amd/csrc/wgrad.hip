@@ -339,7 +339,7 @@ static inline void launch_slab_reduce(const float* ws, float* dst, long long n4,
 
 // hwgrad.hip: halo-resident kernels for narrow stride-1 layers and the wide 3x3 layers
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
-                   float* ws, int plan_only, void* stream, int* handled);
+                   float* ws, int plan_only, void* stream, int* handled, const gs_twin* tw);
 
 namespace {
 // the im2col kernel for one operand pair; ws != nullptr: partial tiles to slabs, *slabs = how many
@@ -386,18 +386,26 @@ int wgrad_reduce(const gs_wgrad_desc* d, const float* ws, float* dw, int slabs, 
 
 // one implementation behind gs_wgrad / gs_wgrad_pair / gs_wgrad_ws / gs_wgrad_ws_floats
 int wgrad_impl(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
-               float* ws, int64_t ws_floats, int plan_only, void* stream, int64_t* need_floats) {
+               float* ws, int64_t ws_floats, int plan_only, void* stream, int64_t* need_floats, const gs_twin* tw = nullptr) {
   if (int rc = wgrad_check(d)) return rc;
   const long long slab = (long long)d->P * d->dw_ld;
   const bool det = ws != nullptr || plan_only;
   int handled = 0;
-  if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, det ? ws : nullptr, plan_only, stream, &handled)) return rc;
+  if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, det ? ws : nullptr, plan_only, stream, &handled, tw)) return rc;
   if (handled) {
-    if (need_floats) *need_floats = (int64_t)handled * slab;
+    const int nets = tw ? 2 : 1;                             // twin batch: `handled` slabs per network
+    if (need_floats) *need_floats = (int64_t)nets * handled * slab;
     if (plan_only || !det) return 0;
-    GS_REQUIRE(ws_floats >= (int64_t)handled * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
-               (long long)ws_floats, (long long)handled * slab);
-    return wgrad_reduce(d, ws, dw, handled, stream);
+    GS_REQUIRE(ws_floats >= (int64_t)nets * handled * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
+               (long long)ws_floats, (long long)nets * handled * slab);
+    if (int rc = wgrad_reduce(d, ws, dw, handled, stream)) return rc;
+    if (tw) return wgrad_reduce(d, ws + (size_t)handled * slab, dw + tw->dw_delta / 4, handled, stream);
+    return 0;
+  }
+  if (tw) {                                                  // no twin form for this layer: *need_floats = -1 says so
+    if (need_floats) *need_floats = -1;
+    GS_REQUIRE(plan_only, "gs_wgrad_ws_twin: this layer's kernel has no twin form (gs_wgrad_twin_native): run the two halves");
+    return 0;
   }
   // the im2col kernel: one launch (+ one reduction) per operand pair, the workspace is reused
   int64_t need = 0;
@@ -445,6 +453,34 @@ extern "C" int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g
   GS_REQUIRE(d && a1 && g1 && dw && (a2 == nullptr) == (g2 == nullptr), "gs_wgrad_ws: null argument");
   GS_REQUIRE(ws || gs_wgrad_ws_floats(d, a2 != nullptr) == 0, "gs_wgrad_ws: this layer needs a workspace (gs_wgrad_ws_floats)");
   return wgrad_impl(d, a1, g1, a2, g2, dw, ws, ws_floats, 0, stream, nullptr);
+}
+
+// Twin batches (gs_twin): the wide 3x3 residual convs (hwgrad.hip) take both networks' images in one launch — half the
+// pixel splits per network, so half the slab traffic per gradient, one launch and one prologue instead of two.
+static gs_twin twin_probe(const gs_wgrad_desc* d) { gs_twin t{}; t.n_split = d->N / 2; return t; }
+extern "C" int gs_wgrad_twin_native(const gs_wgrad_desc* d, int32_t pair) {
+  if (!d || d->N < 2 || (d->N & 1)) return 0;
+  int64_t need = 0;
+  static const char dummy = 0;
+  const gs_twin t = twin_probe(d);
+  if (wgrad_impl(d, &dummy, &dummy, pair ? &dummy : nullptr, pair ? &dummy : nullptr, nullptr, nullptr, 0, 1, nullptr, &need, &t))
+    return 0;
+  return need >= 0;
+}
+extern "C" int64_t gs_wgrad_ws_floats_twin(const gs_wgrad_desc* d, int32_t pair) {
+  if (!d) return -1;
+  int64_t need = 0;
+  static const char dummy = 0;
+  const gs_twin t = twin_probe(d);
+  if (wgrad_impl(d, &dummy, &dummy, pair ? &dummy : nullptr, pair ? &dummy : nullptr, nullptr, nullptr, 0, 1, nullptr, &need, &t))
+    return -1;
+  return need;
+}
+extern "C" int gs_wgrad_ws_twin(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2,
+                                float* dw, float* ws, int64_t ws_floats, const gs_twin* tw, void* stream) {
+  GS_REQUIRE(d && a1 && g1 && dw && ws && tw && (a2 == nullptr) == (g2 == nullptr), "gs_wgrad_ws_twin: null argument");
+  GS_REQUIRE(2 * tw->n_split == d->N, "gs_wgrad_ws_twin: the two networks take the same number of images");
+  return wgrad_impl(d, a1, g1, a2, g2, dw, ws, ws_floats, 0, stream, nullptr, tw);
 }
 
 // ---- bias gradient: db[c] += sum_pixels dy[pix][c] ---------------------------------------------------

@@ -106,6 +106,10 @@ _PROTOS = {
     "gs_wgrad_ws_floats": (C.c_int64, [C.POINTER(WGradDesc), C.c_int32]),
     "gs_wgrad_ws": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.c_void_p]),
+    "gs_wgrad_twin_native": (C.c_int, [C.POINTER(WGradDesc), C.c_int32]),
+    "gs_wgrad_ws_floats_twin": (C.c_int64, [C.POINTER(WGradDesc), C.c_int32]),
+    "gs_wgrad_ws_twin": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.POINTER(Twin), C.c_void_p]),
     "gs_bias_grad": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_bias_grad_ws_floats": (C.c_int64, [C.c_int64, C.c_int32]),
     "gs_bias_grad_ws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -326,7 +326,8 @@ class HipOps(TwinSplit):
                         for k in range(3) for t in range(9)))
 
     def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
-        if is_twin(dw):
+        twin = is_twin(dw)
+        if twin and (os.environ.get("GS_WGRAD_DET", "1") == "0" or os.environ.get("GS_TWIN_NATIVE", "1") == "0"):
             return self.twin_wgrad(w, a, g, dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co, pair=pair)
         key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)
         ent = self._desc_cache.get(key)
@@ -342,6 +343,25 @@ class HipOps(TwinSplit):
                 d.dh[i], d.dw_[i], d.dd[i] = p, q, r
             ent = (d, w)
             self._desc_cache[key] = ent
+        if twin:      # both networks' images in one launch where the layer's kernel has the form, else the two halves
+            wkey = ("wgrad_ws", id(ent[0]), pair is not None, "twin")
+            nws = self._desc_cache.get(wkey)
+            if nws is None:
+                nws = int(self.lib.gs_wgrad_ws_floats_twin(C.byref(ent[0]), int(pair is not None))) \
+                    if self.lib.gs_wgrad_twin_native(C.byref(ent[0]), int(pair is not None)) else -1
+                self._desc_cache[wkey] = nws
+            if nws <= 0:
+                return self.twin_wgrad(w, a, g, dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co, pair=pair)
+            tw = L.Twin()
+            tw.n_split, tw.dw_delta = a.shape[0] // 2, dw.delta()
+            ws = torch.empty(nws, dtype=torch.float32, device=self.device)
+            a2, g2 = pair if pair is not None else (None, None)
+            t_end = self._time_begin("wgrad", w, pair is not None)
+            L.check(self.lib.gs_wgrad_ws_twin(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(a2), _ptr(g2), _ptr(dw.a), _ptr(ws), nws,
+                                              C.byref(tw), _stream()), "gs_wgrad_ws_twin")
+            if t_end is not None:
+                t_end.record()
+            return
         t_end = self._time_begin("wgrad", w, pair is not None)
         if os.environ.get("GS_WGRAD_DET", "1") != "0":
             # deterministic accumulation (default): partial sums to a per-launch workspace, fixed-order second stage

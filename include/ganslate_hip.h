@@ -194,6 +194,15 @@ int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const 
 int64_t gs_wgrad_ws_floats(const gs_wgrad_desc* d, int32_t pair);
 int gs_wgrad_ws(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
                 float* ws, int64_t ws_floats, void* stream);
+/* Twin batches (gs_twin): d->N = all images of both networks (each operand tensor holds the first network's N / 2 images,
+ * then the second's); the second network's gradient goes to dw + tw->dw_delta bytes. gs_wgrad_twin_native: 1 when the
+ * layer's kernel takes both networks in one launch (the wide 3x3 residual convs, resnet2d.py:80-87 backward: half the pixel
+ * splits per network, half the slab traffic); else the caller runs gs_wgrad_ws on the two halves. Workspace:
+ * gs_wgrad_ws_floats_twin (both networks' slabs). Deterministic like gs_wgrad_ws. */
+int gs_wgrad_twin_native(const gs_wgrad_desc* d, int32_t pair);
+int64_t gs_wgrad_ws_floats_twin(const gs_wgrad_desc* d, int32_t pair);
+int gs_wgrad_ws_twin(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
+                     float* ws, int64_t ws_floats, const gs_twin* tw, void* stream);
 /* db[c] += sum over pixels of dy[pix, c]  (bias gradient of any conv) */
 int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, void* stream);
 /* deterministic form (per-chunk partial sums in a caller-owned workspace, added in chunk order) */

@@ -134,6 +134,38 @@ def test_twin_ring_dgrad_equals_two_launches(hip_ops, case, with_g2, act):
     close_f32(sums, ring[1][:N * 3 * C].view(N, 3, C), "ring partial sums vs oracle", rel=3e-3)
 
 
+@pytest.mark.parametrize("case", [(256, 8, 64, 64), (256, 3, 64, 64), (128, 2, 96, 160)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("pair", [True, False])
+def test_twin_weight_gradient_of_the_residual_convs(hip_ops, case, pair):
+    """hwgrad_wide as a twin launch (gs_wgrad_ws_twin): both networks' gradients out of one launch with half the pixel splits
+    per network — equal to the two separate launches up to the fp32 summation order, to the oracle, and bit-identical
+    between two runs (slabs added in a fixed order)"""
+    C, N, H, W = case
+    dev = hip_ops.device
+    spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
+    low = make_layer(spec, (H, W), 3)[0]
+    g = torch.Generator().manual_seed(4)
+    mk = lambda: torch.randn(2 * N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    dy, x, dy2, x2 = mk(), mk(), mk(), mk()
+    pr = (dy2, x2) if pair else None
+    ph = lambda h: None if pr is None else (dy2[h * N:(h + 1) * N], x2[h * N:(h + 1) * N])
+    n = spec.master_numel
+    runs = []
+    for _ in range(2):
+        dw = torch.zeros(2, n, device=dev)
+        hip_ops.wgrad(low.wgrad, dy, x, Twin(dw[0], dw[1]), pair=pr)
+        runs.append(dw)
+    sep = torch.zeros(2, n, device=dev)
+    for h in (0, 1):
+        hip_ops.wgrad(low.wgrad, dy[h * N:(h + 1) * N], x[h * N:(h + 1) * N], sep[h], pair=ph(h))
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0], runs[1]), "twin weight gradient is not reproducible"
+    close_f32(runs[0], sep.cpu(), "twin vs separate launches", rel=2e-4)
+    ref, dref = RefOps(), torch.zeros(n)
+    ref.wgrad(low.wgrad, dy[N:].cpu(), x[N:].cpu(), dref, pair=None if pr is None else (dy2[N:].cpu(), x2[N:].cpu()))
+    close_f32(runs[0][1], dref, "second network's gradient vs oracle", rel=2e-3)
+
+
 @pytest.mark.parametrize("name", ["c64_default", "c64_idt_ssim"])
 def test_cyclegan_step_with_twin_passes_equals_the_two_pass_step(name, monkeypatch):
     """whole iterations on the GPU: twin passes (generators and discriminators as one batch each) against GS_TWIN=0. The
