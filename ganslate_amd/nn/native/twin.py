@@ -76,25 +76,27 @@ class TwinSplit:
         f["partial"] = part[h * N * slots * 3 * C_:]
         return f
 
+    def run_halves(self, f):
+        """f(0), f(1): the two networks' halves of one op. They are independent; a backend with streams runs them side by
+        side (HipOps.run_halves)."""
+        f(0)
+        f(1)
+
     def twin_gconv(self, fn, x, wpack, bias, out, *, stats=None, fuse=None, C_=None, **kw):
         """fn = self.gconv or self.gconv_classes bound to its class argument"""
         N = x.shape[0] // 2
-        for h in (0, 1):
-            fn(bhalf(x, h), pick(wpack, h), pick(bias, h), bhalf(out, h), stats=fhalf(stats, h),
-               fuse=self._fuse_half(fuse, h, N, C_), **kw)
+        self.run_halves(lambda h: fn(bhalf(x, h), pick(wpack, h), pick(bias, h), bhalf(out, h), stats=fhalf(stats, h),
+                                     fuse=self._fuse_half(fuse, h, N, C_), **kw))
 
     def twin_wgrad(self, w, a, g, dw, *, pair=None, **kw):
-        for h in (0, 1):
-            self.wgrad(w, bhalf(a, h), bhalf(g, h), pick(dw, h),
-                       pair=None if pair is None else (bhalf(pair[0], h), bhalf(pair[1], h)), **kw)
+        self.run_halves(lambda h: self.wgrad(w, bhalf(a, h), bhalf(g, h), pick(dw, h),
+                                             pair=None if pair is None else (bhalf(pair[0], h), bhalf(pair[1], h)), **kw))
 
     def twin_bias_grad(self, dy, C_, db, **kw):
-        for h in (0, 1):
-            self.bias_grad(bhalf(dy, h), C_, pick(db, h), **kw)
+        self.run_halves(lambda h: self.bias_grad(bhalf(dy, h), C_, pick(db, h), **kw))
 
     def twin_shiftadd_to_image(self, z, bias, img, k, act="none"):
-        for h in (0, 1):
-            self.shiftadd_to_image(bhalf(z, h), pick(bias, h), bhalf(img, h), k, act=act)
+        self.run_halves(lambda h: self.shiftadd_to_image(bhalf(z, h), pick(bias, h), bhalf(img, h), k, act=act))
 
 
 class TwinNet:
