@@ -42,33 +42,6 @@ class HipOps(TwinSplit):
         self._timing_filter, self._timing_events = None, []
         self.sync_options()
 
-    # ---- twin passes: the two networks' halves of an op without a native twin form, side by side ------------------
-    # These launches (strided / transposed / boundary convs and their gradients) run at 0.2-0.45 of the HBM roofline one at a
-    # time — load, compute, store in series per workgroup, and a tail per launch — so the second network's half goes to a
-    # companion stream of the launching stream; in a captured step the fork and join are graph edges. Everything the halves
-    # touch was allocated on the launching stream before the fork and is released after the join.
-    def run_halves(self, f):
-        if os.environ.get("GS_TWIN_STREAMS", "1") == "0":
-            f(0)
-            f(1)
-            return
-        from ..utils.streams import new_event
-        cur = torch.cuda.current_stream()
-        if not hasattr(self, "_companions"):
-            self._companions = {}
-        side = self._companions.get(cur.cuda_stream)
-        if side is None:
-            side = self._companions[cur.cuda_stream] = torch.cuda.Stream(device=self.device)
-        fork = new_event()
-        fork.record(cur)
-        side.wait_event(fork)
-        f(0)
-        with torch.cuda.stream(side):
-            f(1)
-        join = new_event()
-        join.record(side)
-        cur.wait_event(join)
-
     # ---- kernel-selection switches ------------------------------------------------------------------------
     # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
     # host side are mapped onto its options here, when the backend is created and whenever a model is built.
