@@ -160,9 +160,19 @@ class NativeNet:
                 raise NotImplementedError(f"initialization method `{init_type}` is not implemented")
             flat[self.w_off[i]:self.w_off[i] + nd.spec.master_numel] = nd.spec.master_from_torch(w).reshape(-1)
         for ex in self.extras:
-            if ex.init is None:          # a conv weight kept as an Extra (SelfAttentionBlock's 1x1 convs); normal init only
-                assert init_type == "normal", "attention convs: only `normal` init is implemented"
-                flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = torch.empty(ex.size).normal_(0.0, gain)
+            if ex.init is None:          # a conv weight kept as an Extra (SelfAttentionBlock's 1x1 convs): same rule as above
+                w = torch.empty(ex.shape if ex.shape is not None else (ex.size,))
+                if init_type == "normal":
+                    init.normal_(w, 0.0, gain)
+                elif init_type == "xavier":
+                    init.xavier_normal_(w, gain=gain)
+                elif init_type == "kaiming":
+                    init.kaiming_normal_(w, a=0, mode="fan_in")
+                elif init_type == "orthogonal":
+                    init.orthogonal_(w, gain=gain)
+                else:
+                    raise NotImplementedError(f"initialization method `{init_type}` is not implemented")
+                flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = w.reshape(-1)
             else:
                 flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = ex.init
         with torch.no_grad():
@@ -690,14 +700,20 @@ class NativeNet:
         with torch.no_grad():
             dist.broadcast(self.master.data, 0, group=self._dist)
         self._packs_dirty = True
-        # buckets = contiguous [start, end) element ranges of whole layers, built from the LAST layer backwards
-        self._buckets, end, cur = [], self.numel, self.numel
+        # buckets = contiguous [start, end) element ranges of whole layers, built from the LAST layer backwards. The Extras at
+        # the tail of the flat buffer (SelfAttentionBlock parameters, whose gradients are written by the block's backward on
+        # an EARLIER node's output than the bucket boundary suggests) are a bucket of their own that no layer triggers:
+        # finish_grad_reduction reduces it, after the whole backward pass.
+        x_start = min(self.x_off.values()) if self.extras else self.numel
+        self._buckets, end, cur = [], x_start, x_start
         for i in range(len(self.nodes) - 1, -1, -1):
             cur = self.w_off[i]
             if (end - cur) * 4 >= bucket_bytes or i == 0:
                 self._buckets.append((i, cur, end))   # ready once node i's wgrad has been issued
                 end = cur
-        self._bucket_at = {i: (s, e) for i, s, e in self._buckets}
+        if self.extras:
+            self._buckets.append((-1, x_start, self.numel))
+        self._bucket_at = {i: (s, e) for i, s, e in self._buckets if i >= 0}
         return self
 
     def _maybe_reduce_bucket(self, i):

@@ -225,3 +225,70 @@ def test_multiscale_discriminators_two_ranks_stay_in_sync(tmp_path):
     assert sum(k.startswith("D_A.") for k in r0) == 2 and sum(k.startswith("D_B.") for k in r0) == 2
     for name in r0:
         assert torch.equal(r0[name], r1[name]), f"{name}: ranks diverged"
+
+
+def _attn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), GANSLATE_DIST_BACKEND="gloo")
+    torch.set_num_threads(2)
+    from ganslate_amd.nn.native import backend
+    from ganslate_amd.utils import communication
+    from oracle.ops_ref import RefOps
+    communication.init_distributed()
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    net, xs, gs = _attn_net_and_data(world)
+    net.parallelize(bucket_bytes=1 << 10)       # many small buckets: the tail bucket closes long before the attention blocks run
+    y = net(xs[rank])
+    y.backward(gs[rank])
+    fired = len(net._reduce_handles)
+    scale = net.finish_grad_reduction()
+    torch.save({"grad": net.master.grad.clone() * scale, "fired": fired}, Path(out_dir) / f"rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _attn_net_and_data(world):
+    from ganslate_amd.nn.discriminators import SelfAttentionPatchGAN3D
+    torch.manual_seed(21)
+    net = SelfAttentionPatchGAN3D(1, 8, 2, (4, 4, 4), "instance")
+    net.init_weights("normal", 0.05)
+    with torch.no_grad():       # gamma = 0 at init would silence the attention path: give it a value
+        for ex in net.extras:
+            if ex.name.endswith(".gamma"):
+                net.master[net.x_off[ex.name]] = 0.7
+    g = torch.Generator().manual_seed(22)
+    xs = [torch.rand(1, 1, 24, 24, 24, generator=g) * 2 - 1 for _ in range(world)]
+    with torch.no_grad():
+        shape = net(xs[0]).shape
+    gs = [torch.randn(shape, generator=g) for _ in range(world)]
+    return net, xs, gs
+
+
+@pytest.mark.timeout(600)
+def test_attention_parameters_are_reduced_after_their_backward(tmp_path):
+    """the SelfAttentionBlock parameters sit at the tail of the flat gradient; the bucket that holds them
+    must not be all-reduced before the block's backward has written them. Two ranks x one volume against the single-process
+    sum of the two gradients, attention parameters included."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_attn_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    assert r0["fired"] > 0, "bucketed all-reduce did not start during the backward pass"
+    assert torch.equal(r0["grad"], r1["grad"])
+    from ganslate_amd.nn.native import backend
+    from oracle.ops_ref import RefOps
+    backend.set_ops(RefOps(act_dtype=torch.float32))
+    try:
+        net, xs, gs = _attn_net_and_data(world)
+        for x, g in zip(xs, gs):
+            net(x).backward(g)
+        ref = net.master.grad / world
+        x0 = min(net.x_off.values())
+        assert ref[x0:].abs().max() > 0, "the case must exercise the attention parameters"
+        scale = ref.abs().max().item()
+        assert (ref - r0["grad"]).abs().max().item() <= 1e-5 * scale
+        tail = ref[x0:].abs().max().item()
+        assert (ref[x0:] - r0["grad"][x0:]).abs().max().item() <= 1e-5 * tail, "attention parameter gradients were not summed"
+    finally:
+        backend.set_ops(None)
