@@ -242,13 +242,25 @@ def make_conf_3d(c):
                                        "use_inverse": False, "first_layer_channels": c["vnet"]["first_layer_channels"],
                                        "down_blocks": c["vnet"]["down_blocks"], "up_blocks": c["vnet"]["up_blocks"],
                                        "is_separable": False, "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
+    elif "sa" in c:
+        # the self-attention networks (selfattention_vnet3d.py:44-181, selfattention_patchgan3d.py:18-79)
+        gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.SelfAttentionVnet3D", "use_memory_saving": False,
+                                       "use_inverse": False, "first_layer_channels": c["sa"]["first_layer_channels"],
+                                       "down_blocks": c["sa"]["down_blocks"], "up_blocks": c["sa"]["up_blocks"],
+                                       "is_separable": False, "enable_attention_block": c["sa"]["enable_attention_block"],
+                                       "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
     else:
         gan["generator"] = DictConfig({"_target_": "ganslate.nn.generators.Resnet3D",
                                        "n_residual_blocks": c["n_residual_blocks"],
                                        "in_out_channels": {"AB": [1, 1], "BA": [1, 1]}})
-    gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
-                                       "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
-                                       "in_channels": {"B": 1, "A": 1}})
+    if "sa" in c:
+        gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.SelfAttentionPatchGAN3D",
+                                           "ndf": c["sa"]["ndf"], "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                           "in_channels": {"B": 1, "A": 1}})
+    else:
+        gan["discriminator"] = DictConfig({"_target_": "ganslate.nn.discriminators.PatchGAN3D", "ndf": 64,
+                                           "n_layers": c["d_layers"], "kernel_size": [4, 4, 4],
+                                           "in_channels": {"B": 1, "A": 1}})
     return conf
 
 

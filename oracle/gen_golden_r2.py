@@ -8,7 +8,7 @@
     python -m oracle.gen_golden_r2 revgan      # tests/golden/revgan.json
     python -m oracle.gen_golden_r2 volpatch    # tests/golden/volume_patches.json
     python -m oracle.gen_golden_r2 multiscale  # tests/golden/multiscale_patchgan3d.json
-    python -m oracle.gen_golden_r2 recipegrads # tests/golden/recipe_grads.json
+    python -m oracle.gen_golden_r2 recipegrads [case ...] # tests/golden/recipe_grads.json (all cases, or only the named SA_CASES)
     python -m oracle.gen_golden_r2 selfattention # tests/golden/selfattention.json
 
 * cyclegan_grads.json — the parameter gradients `CycleGAN.optimize_parameters` (cyclegan.py:92-124) leaves in `.grad`
@@ -417,12 +417,40 @@ P2P_FULL = dict(size=[256, 512], batch=1, steps=1, n_iters=100, n_iters_decay=10
                 use_dropout=False, n_layers=4, lambda_pix2pix=30.0, seed=35)
 
 
-def recipegrads():
-    """one iteration of the reference's recipes; what it leaves in every parameter's .grad"""
+# CycleGAN over the self-attention networks (round 4): SelfAttentionVnet3D(8; down 1,2; up 2,1; a block on both down
+# levels) + SelfAttentionPatchGAN3D(ndf 16, 2 layers) — tests/configs/cyclegan_selfattention_synthetic.yaml
+SA_CASES = {
+    "sa_32x48x48": dict(size=[32, 48, 48], batch=1, steps=1, n_iters=100, n_iters_decay=100, pool_size=50,
+                        lambda_identity=0.0, proportion_ssim=0.0, d_layers=2, seed=81,
+                        sa=dict(first_layer_channels=8, down_blocks=[1, 2], up_blocks=[2, 1],
+                                enable_attention_block=[True, True], ndf=16)),
+}
+
+
+def recipegrads(only=()):
+    """one iteration of the reference's recipes; what it leaves in every parameter's .grad. `only`: case names to (re)generate
+    into the existing file (the others keep their recorded bytes)"""
     from oracle import gen_golden as G
     from oracle.torch_ref import seeded_state_dict
     torch.set_num_threads(8)
     out = {}
+    if only:
+        out = json.loads((OUT / "recipe_grads.json").read_text())
+        for name in only:
+            c = SA_CASES[name]
+            torch.manual_seed(c["seed"])
+            random.seed(c["seed"])
+            model = G.CycleGAN(G.make_conf_3d(c))
+            for k, (n, net) in enumerate(model.networks.items()):
+                net.load_state_dict(seeded_state_dict(net, c["seed"] + k))
+            random.seed(c["seed"])
+            model.set_input(dict(zip("AB", G.inputs_3d(c, 0))))
+            model.optimize_parameters()
+            out[name] = {"kind": "cyclegan3d", "config": c, "losses": _record(model)["losses"],
+                         "step0_grads": _grad_record(model)}
+            print(name, out[name]["losses"], flush=True)
+        (OUT / "recipe_grads.json").write_text(json.dumps(out, indent=1))
+        return
 
     def one_step(name, kind, c, model, A, B):
         if kind == "cut":
@@ -488,7 +516,7 @@ def main():
     if what == "multiscale":
         multiscale()
     elif what == "recipegrads":
-        recipegrads()
+        recipegrads(tuple(sys.argv[2:]))      # e.g. `recipegrads sa_32x48x48`: add / refresh single cases
     elif what == "selfattention":
         selfattention()
     elif what == "volpatch":

@@ -45,10 +45,17 @@ def oracle_step0(kind, c, frozen=False):
                                 n_iters_decay=c["n_iters_decay"], seed=c["seed"], **({"lr": 0.0} if frozen else {}))
         torch.manual_seed(1000)
     elif kind == "cyclegan3d":
+        mk = {}
+        if "sa" in c:       # the self-attention networks (SelfAttentionVnet3D / SelfAttentionPatchGAN3D)
+            sa = c["sa"]
+            mk = dict(make_G=lambda i, o: torch_ref.SelfAttentionVnet3D(i, o, sa["first_layer_channels"],
+                                                                       tuple(sa["down_blocks"]), tuple(sa["up_blocks"]), False,
+                                                                       tuple(sa["enable_attention_block"])),
+                      make_D=lambda i: torch_ref.SelfAttentionPatchGAN3D(i, sa["ndf"], c["d_layers"], 4))
         ref = torch_ref.CycleGANStep(in_ch=1, out_ch=1, n_blocks=c.get("n_residual_blocks", 0), n_layers=c["d_layers"],
                                      vnet=c.get("vnet"), n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"],
                                      pool_size=c["pool_size"], lambda_identity=c["lambda_identity"], proportion_ssim=0.0,
-                                     metrics_ssim=False, seed=c["seed"], dims=3)
+                                     metrics_ssim=False, seed=c["seed"], dims=3, **mk)
         random.seed(c["seed"])
     else:
         ref = torch_ref.RevGANStep(ch=1, n_layers=c["d_layers"], n_iters=c["n_iters"], n_iters_decay=c["n_iters_decay"],
@@ -64,6 +71,29 @@ def oracle_step0(kind, c, frozen=False):
     return losses, grads
 
 
+def build_product_sa_cyclegan(c, extra=()):
+    """CycleGAN over the self-attention networks from tests/configs/cyclegan_selfattention_synthetic.yaml with the case's
+    seeded weights (the oracle twins' state dicts: the reference's key names)"""
+    from pathlib import Path
+    from ganslate_amd.utils.builders import build_conf, build_gan
+    sa = c["sa"]
+    conf = build_conf([f"config={Path(__file__).parent / 'configs' / 'cyclegan_selfattention_synthetic.yaml'}",
+                       f"train.batch_size={c['batch']}", f"train.n_iters={c['n_iters']}",
+                       f"train.n_iters_decay={c['n_iters_decay']}", f"train.gan.pool_size={c['pool_size']}", *extra])
+    g, d = conf.train.gan.generator, conf.train.gan.discriminator
+    assert (g.first_layer_channels, list(g.down_blocks), list(g.up_blocks), list(g.enable_attention_block), d.ndf, d.n_layers) == \
+        (sa["first_layer_channels"], sa["down_blocks"], sa["up_blocks"], sa["enable_attention_block"], sa["ndf"], c["d_layers"])
+    torch.manual_seed(c["seed"])
+    model = build_gan(conf)
+    mkG = lambda: torch_ref.SelfAttentionVnet3D(1, 1, sa["first_layer_channels"], tuple(sa["down_blocks"]),
+                                                tuple(sa["up_blocks"]), False, tuple(sa["enable_attention_block"]))
+    mkD = lambda: torch_ref.SelfAttentionPatchGAN3D(1, sa["ndf"], c["d_layers"], 4)
+    for k, (name, mk) in enumerate((("G_AB", mkG), ("G_BA", mkG), ("D_B", mkD), ("D_A", mkD))):
+        model.networks[name].load_state_dict(torch_ref.seeded_state_dict(mk(), c["seed"] + k))
+    random.seed(c["seed"])
+    return model
+
+
 def product_step0(kind, name, c, extra=()):
     """the product's first iteration with frozen weights -> (losses, {network: {parameter name: gradient}})"""
     extra = tuple(extra) + FROZEN
@@ -72,6 +102,8 @@ def product_step0(kind, name, c, extra=()):
     elif kind == "cut":
         model = build_product_cut(c, extra)
         torch.manual_seed(1000)
+    elif kind == "cyclegan3d" and "sa" in c:
+        model = build_product_sa_cyclegan(c, extra)
     elif kind == "cyclegan3d":
         model = build_product_cyclegan3d(c, extra)
     else:

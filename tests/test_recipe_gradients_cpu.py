@@ -1,6 +1,6 @@
 """The oracle's step classes against the REAL reference's step-0 parameter gradients for every recipe besides 2-D CycleGAN
 (tests/golden/recipe_grads.json): Pix2Pix (incl. BASELINE configs[2] at full width), CUT (G, D and the patch MLP), 3-D
-CycleGAN (Resnet3D, the brats Vnet3D), RevGAN (Vnet3D and Piresnet3D used in both directions). What the GPU tests compare
+CycleGAN (Resnet3D, the brats Vnet3D, the self-attention networks), RevGAN (Vnet3D and Piresnet3D used in both directions). What the GPU tests compare
 the HIP gradients with (tests/test_recipe_gradients_gpu.py) is thereby pinned tensor by tensor: norm to 5e-4 and the 8
 recorded samples per tensor (2-D CycleGAN: tests/test_gradients_cpu.py)."""
 import pytest
@@ -9,7 +9,8 @@ import torch
 from .recipes import load_recipe_grads, oracle_step0
 from .test_gradients_cpu import check_against_golden
 
-CASES = ["p2p_64x128", "p2p_cfg3_full", "cut_64", "v32_default", "vnet_16x32x32", "rev3d_16x32x32", "rev3d_piresnet"]
+CASES = ["p2p_64x128", "p2p_cfg3_full", "cut_64", "v32_default", "vnet_16x32x32", "rev3d_16x32x32", "rev3d_piresnet",
+         "sa_32x48x48"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -25,7 +26,7 @@ def test_oracle_step0_gradients_match_reference(name):
     check_against_golden(grads, per_net, 5e-4, f"oracle {name}")
 
 
-@pytest.mark.parametrize("name", ["p2p_64x128", "cut_64", "rev3d_piresnet"])
+@pytest.mark.parametrize("name", ["p2p_64x128", "cut_64", "rev3d_piresnet", "sa_32x48x48"])
 def test_product_host_logic_step0_gradients(name):
     """the product's recipe + executor (hand-written backward, skip concatenations, feature taps and their gradient
     injection, the shared RevGAN generator used in both directions, flat Adam) on the fp32 op-level oracle backend against

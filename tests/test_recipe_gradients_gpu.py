@@ -33,7 +33,8 @@ pytestmark = pytest.mark.gpu
 
 # cosine floors per case: (generator-side networks, discriminators); see the module docstring
 COS = {"p2p_64x128": (0.90, 0.96), "p2p_cfg3_full": (0.90, 0.96), "cut_64": (0.90, 0.96), "v32_default": (0.90, 0.96),
-       "vnet_16x32x32": (0.90, 0.96), "rev3d_16x32x32": (0.90, 0.96), "rev3d_piresnet": (0.90, 0.96)}
+       "vnet_16x32x32": (0.90, 0.96), "rev3d_16x32x32": (0.90, 0.96), "rev3d_piresnet": (0.90, 0.96),
+       "sa_32x48x48": (0.90, 0.96)}
 
 
 # the generator's last conv (right behind tanh and the L1 loss) per recipe family
