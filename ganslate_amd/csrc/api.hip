@@ -65,10 +65,6 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hwgrad_ft", 1},           // halo-resident weight gradient of narrow layers with few taps (hwgrad.hip: the 2-D k7 boundary convs)
     {"gconv_big", 192},         // smallest number of 256 x 128 im2col tiles that selects them (one workgroup per CU) over 128 x 128 (two)
     {"hconv_box8", 1},          // hconv.hip: 8 x 8 x 8 boxes on 8 waves for volumes (4 x 8 x 8 on 4 waves otherwise)
-    {"hconv_persist", 0},       // hconv.hip: smallest number of boxes the persistent resident-weight form takes (16 -> 16 channel k5 volume
-                                // layers), 0 = off (default: 191 vs 204 us alone at 128^3, but 73.4 vs 72.6 ms in the brats step)
-    {"hstrip_persist", 0},      // hstrip.hip: smallest number of tiles the persistent double-buffered form takes, 0 = off (default:
-                                // measured 62-74 us against 42-55 for one workgroup per tile, two per CU)
     {"hconvw_persist", 1},      // hconvw.hip: launches with more tiles than CUs run ceil(tiles / CUs) tiles per workgroup (0: one each)
 };
 }  // namespace

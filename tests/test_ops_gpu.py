@@ -135,21 +135,19 @@ def test_gconv_forward_stats(hip_ops, case):
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0].k == 5 and c[0].dims == 3] +
                          [(ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 20, 8, 40)], ids=_ids)
 def test_halo_resident_narrow_kernel_box_forms(hip_ops, case):
-    """hconv.hip's three forms of a narrow volume layer against the oracle, ragged boxes on every axis: 4 x 8 x 8 boxes on 4
-    waves, 8 x 8 x 8 boxes on 8 waves (option hconv_box8; 16 output channels, depth >= 8), and the persistent form with the
-    weight block resident in LDS (option hconv_persist = smallest number of boxes it takes, default off; 16 -> 16 channels, k5) — forced here onto grids far below its default threshold, i.e. also with fewer boxes than CUs"""
+    """hconv.hip's two forms of a narrow volume layer against the oracle, ragged boxes on every axis: 4 x 8 x 8 boxes on 4
+    waves and 8 x 8 x 8 boxes on 8 waves (option hconv_box8; 16 output channels, depth >= 8)"""
     spec, N, sizes = case[0], case[1], case[2:]
     low, master, bias, fpack, dpack = make_layer(spec, sizes, 1)
     g = torch.Generator().manual_seed(2)
     xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
     xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
     y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N, act="relu")
-    defaults = {o: hip_ops.get_option(o) for o in ("hconv_box8", "hconv_persist")}
+    default = hip_ops.get_option("hconv_box8")
     try:
         slots = {}
-        for form, (box8, persist) in {"4x8x8": (0, 0), "8x8x8": (1, 0), "persistent": (0, 1)}.items():
+        for form, box8 in {"4x8x8": 0, "8x8x8": 1}.items():
             hip_ops.set_option("hconv_box8", box8)
-            hip_ops.set_option("hconv_persist", persist)
             slots[form] = hip_ops.stat_slots(low.fwd[0], N)
             y_hip, mr_hip = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N, act="relu")
             torch.cuda.synchronize()
@@ -157,11 +155,8 @@ def test_halo_resident_narrow_kernel_box_forms(hip_ops, case):
             close_f32(mr_hip, mr_ref, f"mean / rstd ({form})", rel=1e-3)
         if sizes[0] >= 8 and spec.cout <= 16:
             assert slots["8x8x8"] < slots["4x8x8"], slots          # the 8-deep boxes were really taken
-        if spec.cout <= 16 and spec.cin == 16:              # (1 -> 16 measured slower on it: hconv_kernel keeps that layer)
-            assert slots["persistent"] == 8 * slots["4x8x8"], slots   # one slot per (box, wave): the persistent form ran
     finally:
-        for o, v in defaults.items():
-            hip_ops.set_option(o, v)
+        hip_ops.set_option("hconv_box8", default)
 
 
 @pytest.mark.parametrize("persist", [1, 0], ids=["persistent", "one-tile-per-workgroup"])
@@ -210,17 +205,13 @@ def test_halo_resident_boundary_convs(hip_ops, case):
     xa = torch.zeros(N, *low.in_dims, low.fwd[0].Ci, dtype=torch.bfloat16)
     xa.copy_(torch.randn(xa.shape, generator=g).to(torch.bfloat16))
     gy = torch.randn(N, *low.out_dims, low.fwd[0].Co, generator=g).to(torch.bfloat16)
-    default, default_p = hip_ops.get_option("hstrip"), hip_ops.get_option("hstrip_persist")
+    default = hip_ops.get_option("hstrip")
     res = {}
     try:
-        # 1: every eligible layer whatever its grid (one workgroup per tile), 2: the same through the persistent form (one
-        # workgroup per CU walking over double-buffered tiles — here also with fewer tiles than CUs), 0: off
-        for on in (1, 2, 0):
-            hip_ops.set_option("hstrip", min(on, 1))
-            hip_ops.set_option("hstrip_persist", 1 if on == 2 else 0)
+        for on in (1, 0):       # 1: every eligible layer whatever its grid (one workgroup per tile), 0: off (im2col launches)
+            hip_ops.set_option("hstrip", on)
             if on and low.fwd[0].Ci in (32, 64):      # (the 1-channel stem folds to 8 channels: stays on the im2col kernel)
-                tiles = ((low.fwd[0].Ho + 31) // 32) * ((low.fwd[0].Wo + 7) // 8)
-                assert hip_ops.stat_slots(low.fwd[0], N) == tiles * (4 if on == 2 else 1)
+                assert hip_ops.stat_slots(low.fwd[0], N) == ((low.fwd[0].Ho + 31) // 32) * ((low.fwd[0].Wo + 7) // 8)
             y, mr = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N)
             gx = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16, device=hip_ops.device)
             hip_ops.gconv_classes(low.dgrad, gy.to(hip_ops.device), dpack.to(hip_ops.device), None, gx)
@@ -228,9 +219,6 @@ def test_halo_resident_boundary_convs(hip_ops, case):
             res[on] = (y.cpu(), mr.cpu(), gx.cpu())
     finally:
         hip_ops.set_option("hstrip", default)
-        hip_ops.set_option("hstrip_persist", default_p)
-    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][2], res[1][2]), "persistent form: same arithmetic, same bits"
-    close_f32(res[2][1], res[1][1], "persistent form: mean / rstd", rel=1e-4)
     y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N)
     gx_ref = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16)
     RefOps().gconv_classes(low.dgrad, gy, dpack, None, gx_ref)
