@@ -511,8 +511,29 @@ def selfattention():
     (OUT / "selfattention.json").write_text(json.dumps(nets, indent=1))
 
 
+def patchnce_class():
+    """the reference's stand-alone criterion (nn/losses/cut_losses.py:5-43) on seeded, L2-normalised features"""
+    from oracle import gen_golden as G          # imports the reference  # noqa: F401
+    from ganslate.nn.losses.cut_losses import PatchNCELoss
+    from omegaconf import DictConfig
+    out = {}
+    for name, (batch, patches, dim, T, seed) in {"b2_p16_d32": (2, 16, 32, 0.07, 91), "b3_p8_d256": (3, 8, 256, 0.1, 92)}.items():
+        conf = DictConfig({"train": {"batch_size": batch, "gan": {"optimizer": {"nce_T": T}}}})
+        g = torch.Generator().manual_seed(seed)
+        q = torch.nn.functional.normalize(torch.randn(batch * patches, dim, generator=g), dim=1).requires_grad_()
+        k = torch.nn.functional.normalize(torch.randn(batch * patches, dim, generator=g), dim=1)
+        loss = PatchNCELoss(conf)(q, k)
+        loss.sum().backward()
+        out[name] = {"batch": batch, "patches": patches, "dim": dim, "nce_T": T, "seed": seed,
+                     "loss": [float(v) for v in loss.detach()], "grad_q_norm": float(q.grad.norm()),
+                     "grad_q_samples": [float(v) for v in q.grad.flatten()[::max(1, q.grad.numel() // 8)][:8]]}
+    (OUT / "patchnce_class.json").write_text(json.dumps(out, indent=1))
+
+
 def main():
     what = sys.argv[1]
+    if what == "patchnce_class":
+        return patchnce_class()
     if what == "multiscale":
         multiscale()
     elif what == "recipegrads":
