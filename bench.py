@@ -24,20 +24,31 @@ sys.path.insert(0, str(ROOT))
 # algorithmic work (BASELINE.md §3 / SURVEY.md §8d): conv MACs x 2 of one CycleGAN step per image pair
 GFLOP_PER_IMAGE = 1289.9
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-# HBM bytes per launch of the three residual-conv kernels at the headline shape, from rocprofv3 PMC passes (bench.py
+# HBM bytes per launch of the three residual-conv kernels at the headline shape come from rocprofv3 PMC passes (bench.py
 # cannot run the profiler on itself): 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction of
-# MI355X_MICROARCH.md. Filled from profiles/ by name; None = not measured for this build.
-# HBM bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), profiles/r03_trunk_pmc.txt
-HBM_BYTES = {"rb_fwd": (42.6e6, "profiles/r03_trunk_pmc.txt"), "rb_dgrad": (67.3e6, "profiles/r03_trunk_pmc.txt"),
-             "rb_wgrad_pair": (109.2e6, "profiles/r03_trunk_pmc.txt")}
+# MI355X_MICROARCH.md. tools/pmc_hbm_json.py writes them to this file from the passes of tools/pmc_step.sh; bench.py only
+# READS it ({label: {"bytes_per_launch", "images_per_launch", ...}}); a missing file or label gives `traffic: null`.
+HBM_JSON = ROOT / "profiles" / "r04_trunk_hbm.json"
 
 
-def algorithmic_bytes(label, batch, hw, C=256, taps=9):
-    """HBM bytes one launch of a residual-conv form has to move at least (bf16 activations [batch, hw, C], fp32 dW):
+def hbm_bytes(label, images_per_launch):
+    """(bytes per launch, source) measured for this kernel form AT this launch size, or (None, None)"""
+    try:
+        rec = json.loads(HBM_JSON.read_text()).get(label)
+    except (OSError, ValueError):
+        return None, None
+    if not rec or abs(rec.get("images_per_launch", 0) - images_per_launch) > 0.5:
+        return None, None
+    return rec["bytes_per_launch"], f"profiles/{HBM_JSON.name} ({rec.get('source', 'tools/pmc_step.sh')})"
+
+
+def algorithmic_bytes(label, images, hw, C=256, taps=9, nets=1):
+    """HBM bytes one launch of a residual-conv form has to move at least (bf16 activations [images, hw, C], fp32 dW; a twin
+    launch carries the weights / weight gradients of `nets` = 2 networks):
     forward: x + y + W; fused data gradient: dY + y + g2 read, dX written, + W; weight-gradient pair: two (a, g) operand
     pairs read, dW [C][taps][C] fp32 written once"""
-    act = batch * hw * C * 2
-    w = C * taps * C * 2
+    act = int(images * hw * C * 2)
+    w = C * taps * C * 2 * nets
     return {"rb_fwd": 2 * act + w, "rb_dgrad": 4 * act + w, "rb_wgrad_pair": 4 * act + 2 * w,
             "rb_wgrad": 2 * act + 2 * w}.get(label)
 
@@ -493,10 +504,10 @@ def main():
                 "launch by launch: bucketed all-reduce overlapped with the last backward pass"
         if timing is not None:
             res = ops.kernel_timing_result()
+            imgs = ops.kernel_timing_images()                    # images per launch: a twin launch covers both generators
             hw = (args.size // 4) ** 2
-            flop1 = 2.0 * hw * args.batch * 256 * 2304           # 2*M*N*K of one 3x3 256->256 conv over the batch
-            names = {"rb_fwd": "hconvw_kernel<9, 16> (forward, halo-resident)",
-                     "rb_dgrad": ("hconvw_kernel<9, 16, RING> (data gradient on the unpadded domain, reflect ring "
+            names = {"rb_fwd": "hconvw_kernel<9> (forward, halo-resident)",
+                     "rb_dgrad": ("hconvw_kernel<9, RING> (data gradient on the unpadded domain, reflect ring "
                                   "folded in-launch, fused norm-backward reduction)" if (ops.get_option("hconvw_ring") and rb_taps == 9)
                                   else "gconv_kernel<288, 128> (data gradient on the padded domain + fused norm-backward "
                                        "reduction)"),
@@ -504,19 +515,26 @@ def main():
                      "rb_wgrad": "hwgrad_wide_kernel<9> (weight gradient, one pass)"}
             kernels = {}
             for label, (n, ms) in res.items():
-                flop = flop1 * (2 if label == "rb_wgrad_pair" else 1)
+                nimg = imgs.get(label) or args.batch
+                # 2*M*N*K of one 3x3 256->256 conv over the launch's images (x 2 operand pairs for a merged weight gradient)
+                flop = 2.0 * hw * nimg * 256 * 2304 * (2 if label == "rb_wgrad_pair" else 1)
                 kernels[label] = {"kernel": names[label], "launches_per_step": round(n / timing_steps, 1),
+                                  "images_per_launch": round(nimg, 1),
                                   "avg_ms": round(ms, 4), "ms_per_step": round(n / timing_steps * ms, 3),
+                                  "gflop_per_launch": round(flop / 1e9, 2),
                                   "tflops": round(flop / (ms * 1e-3) / 1e12, 1) if n else 0.0,
                                   "frac": round(flop / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if n else 0.0}
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-            hbm, hbm_src = HBM_BYTES.get(dom, (None, None)) if (args.batch == 8 and args.size == 256) else (None, None)
+            dimg = kernels[dom]["images_per_launch"]
+            hbm, hbm_src = hbm_bytes(dom, dimg) if args.size == 256 else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": kernels[dom]["frac"], "traffic": hbm,
                                "traffic_source": hbm_src,
-                               "algorithmic_bytes": algorithmic_bytes(dom, args.batch, hw),
-                               "kernel": f"{names[dom]}: 3x3 256->256 reflect conv, M={hw * args.batch} N=256 K=2304"
-                                         + (" x 2 passes" if dom == "rb_wgrad_pair" else ""),
+                               "algorithmic_bytes": algorithmic_bytes(dom, dimg, hw, nets=2 if dimg > args.batch else 1),
+                               "kernel": f"{names[dom]}: 3x3 256->256 reflect conv, M={int(hw * dimg)} N=256 K=2304"
+                                         + (" x 2 passes" if dom == "rb_wgrad_pair" else "")
+                                         + (f" (twin launch: {int(dimg)} images = both generators' batch {args.batch})"
+                                            if dimg > args.batch else ""),
                                "dominant_of": "the three residual-conv launch forms, by per-step total of their own "
                                               "HIP-event timings",
                                "launches_timed": res[dom][0], "avg_ms": kernels[dom]["avg_ms"],

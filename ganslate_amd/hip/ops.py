@@ -39,7 +39,7 @@ class HipOps(TwinSplit):
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         L.check(self.lib.gs_init(self.device.index or 0), "gs_init")
         self._desc_cache = {}
-        self._timing_filter, self._timing_events = None, []
+        self._timing_filter, self._timing_events, self._timing_images = None, {}, {}
         self.sync_options()
 
     # ---- kernel-selection switches ------------------------------------------------------------------------
@@ -75,13 +75,13 @@ class HipOps(TwinSplit):
         """select(kind, spec, flag) -> label or None. kind "gconv": spec = GConv class, flag = fused norm-backward
         epilogue; kind "wgrad": spec = WGrad, flag = merged pair launch. Launches with a label are bracketed by HIP
         events on the stream they are launched on."""
-        self._timing_filter, self._timing_events = select, {}
+        self._timing_filter, self._timing_events, self._timing_images = select, {}, {}
         return self._timing_events
 
     def disable_kernel_timing(self):
         self._timing_filter = None
 
-    def _time_begin(self, kind, spec, flag):
+    def _time_begin(self, kind, spec, flag, N=None):
         if self._timing_filter is None:
             return None
         label = self._timing_filter(kind, spec, flag)
@@ -90,6 +90,7 @@ class HipOps(TwinSplit):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self._timing_events.setdefault(label, []).append((e0, e1))
+        self._timing_images.setdefault(label, []).append(N)       # images per launch (a twin launch covers both networks)
         return e1
 
     def kernel_timing_result(self):
@@ -97,6 +98,10 @@ class HipOps(TwinSplit):
         torch.cuda.synchronize()
         return {label: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1))
                 for label, ev in self._timing_events.items()}
+
+    def kernel_timing_images(self):
+        """{label: average number of images per timed launch}"""
+        return {label: sum(v for v in ns if v) / max(sum(1 for v in ns if v), 1) for label, ns in self._timing_images.items()}
 
     # ---- descriptors ------------------------------------------------------------------------------------
     def _gdesc(self, g: GConv, N, in_cs, in_co, out_cs, out_co, act, slope, stats_slots, stats_slot0, accumulate=False):
@@ -225,7 +230,7 @@ class HipOps(TwinSplit):
                 tw.n_split, tw.w_delta = N // 2, wpack.delta()
                 tw.bias_delta = bias.delta() if isinstance(bias, Twin) else 0
                 b0 = bias.a if isinstance(bias, Twin) else bias
-                t_end = self._time_begin("gconv", g, fuse is not None)
+                t_end = self._time_begin("gconv", g, fuse is not None, N)
                 L.check(self.lib.gs_gconv_forward_twin(C.byref(d), _ptr(x), C.c_void_p(wpack.a.data_ptr() + 2 * g.pack_offset),
                                                        _ptr(b0), _ptr(out), _ptr(stats),
                                                        C.byref(f) if f is not None else None, C.byref(tw), _stream()),
@@ -238,7 +243,7 @@ class HipOps(TwinSplit):
                                    stats_slots=stats_slots, stats_slot0=stats_slot0, accumulate=accumulate, fuse=fuse,
                                    C_=g.Co)
         w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
-        t_end = self._time_begin("gconv", g, fuse is not None)
+        t_end = self._time_begin("gconv", g, fuse is not None, N)
         if fuse is not None:     # data gradient + first pass of the consumer's InstanceNorm backward (fused_norm_plan)
             f = self._fuse_struct(fuse)
             L.check(self.lib.gs_gconv_forward_fused(C.byref(d), _ptr(x), w, _ptr(bias), _ptr(out), _ptr(stats),
@@ -357,13 +362,13 @@ class HipOps(TwinSplit):
             tw.n_split, tw.dw_delta = a.shape[0] // 2, dw.delta()
             ws = torch.empty(nws, dtype=torch.float32, device=self.device)
             a2, g2 = pair if pair is not None else (None, None)
-            t_end = self._time_begin("wgrad", w, pair is not None)
+            t_end = self._time_begin("wgrad", w, pair is not None, a.shape[0])
             L.check(self.lib.gs_wgrad_ws_twin(C.byref(ent[0]), _ptr(a), _ptr(g), _ptr(a2), _ptr(g2), _ptr(dw.a), _ptr(ws), nws,
                                               C.byref(tw), _stream()), "gs_wgrad_ws_twin")
             if t_end is not None:
                 t_end.record()
             return
-        t_end = self._time_begin("wgrad", w, pair is not None)
+        t_end = self._time_begin("wgrad", w, pair is not None, a.shape[0])
         if os.environ.get("GS_WGRAD_DET", "1") != "0":
             # deterministic accumulation (default): partial sums to a per-launch workspace, fixed-order second stage
             wkey = ("wgrad_ws", id(ent[0]), pair is not None)        # (set_option drops these plans)

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""HBM bytes per launch of the three residual-conv kernel forms, from the FETCH_SIZE / WRITE_SIZE passes of
+tools/pmc_step.sh (separate rocprofv3 --pmc passes; kilobytes per dispatch), with the gfx950 correction of
+MI355X_MICROARCH.md: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1000. Writes the JSON bench.py reads its `roofline.traffic` from.
+
+    python tools/pmc_hbm_json.py gpurun_out/pmc/fetch.txt gpurun_out/pmc/write.txt --images 16 > profiles/r04_trunk_hbm.json
+"""
+import argparse
+import json
+import re
+
+LABELS = {"hconvw_kernel<9, false>": "rb_fwd", "hconvw_kernel<9, true>": "rb_dgrad", "hwgrad_wide_kernel<9>": "rb_wgrad_pair"}
+
+
+def parse(path, counter):
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = line.strip()
+            continue
+        m = re.match(r"\s+(\S+)\s+([0-9.]+) per dispatch \((\d+) dispatches\)", line)
+        if m and m.group(1) == counter and cur:
+            for key, label in LABELS.items():
+                if key in cur:
+                    out[label] = (float(m.group(2)), int(m.group(3)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch")
+    ap.add_argument("write")
+    ap.add_argument("--images", type=int, default=16, help="images per launch of the profiled run (twin launches: 2 x batch)")
+    ap.add_argument("--source", default="tools/pmc_step.sh, rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, launch-by-launch step")
+    a = ap.parse_args()
+    f, w = parse(a.fetch, "FETCH_SIZE"), parse(a.write, "WRITE_SIZE")
+    out = {}
+    for label in sorted(set(f) & set(w)):
+        out[label] = {"bytes_per_launch": round((2 * f[label][0] + w[label][0]) * 1e3), "fetch_kb": f[label][0],
+                      "write_kb": w[label][0], "dispatches": f[label][1], "images_per_launch": a.images, "source": a.source}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
