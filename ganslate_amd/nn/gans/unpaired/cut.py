@@ -184,7 +184,8 @@ class CUT(BaseGAN):
             patch_ids = self._pid_static[self._nce_call]
             self._nce_call += 1
         ids = patch_ids if patch_ids is not None else self.sample_patch_ids(H, W)
-        source_feats = G.extract_patch_features(source, self.nce_layers, ids)
+        # (keys are detached in the loss: read out of this iteration's recorded pass over `source` where there is one)
+        source_feats = G.extract_patch_features(source, self.nce_layers, ids, detached=True)
         tgt_ids = ids
         if self.is_flipped:       # target features are flipped back along W before sampling (cut.py:214-215)
             tgt_ids = []

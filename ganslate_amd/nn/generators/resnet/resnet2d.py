@@ -82,8 +82,12 @@ class Resnet2D(NativeNet):
         node = 3 + 2 * (e - 10) + 1
         return ("x", node), self.nodes[node].spec.cout
 
-    def extract_patch_features(self, x, layers, ids):
-        """features of `layers` sampled at pixel ids (one LongTensor per layer) -> list of [N, P, C] fp32"""
+    def extract_patch_features(self, x, layers, ids, detached=False):
+        """features of `layers` sampled at pixel ids (one LongTensor per layer) -> list of [N, P, C] fp32.
+        detached: the caller will not differentiate them (CUT's source / key patches, cut_losses.py:16): if a recorded pass
+        over this very tensor is still alive (fake_B = G(real_A) of the same iteration) they are read out of ITS activations
+        instead of running the encoder again; else the encoder runs without being recorded."""
+        import torch
         import torch.nn.functional as F
         taps, where = [], []
         for e in layers:
@@ -91,7 +95,20 @@ class Resnet2D(NativeNet):
             where.append(tap)
             if tap[0] != "pad":
                 taps.append(tap)
-        native = iter(self.forward_taps(x, taps, [i for i, t in zip(ids, where) if t[0] != "pad"])) if taps else iter(())
+        tap_ids = [i for i, t in zip(ids, where) if t[0] != "pad"]
+        if detached and taps:
+            xc = x.contiguous().float()
+            saved = self.recorded_pass(xc)
+            if saved is None:
+                with torch.no_grad():
+                    _, saved = self._forward(xc.detach(), save=True, stop=max(node for _, node in taps))
+            feats = []
+            for (kind, node), pid in zip(taps, tap_ids):
+                src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
+                feats.append(src.view(xc.shape[0], -1, src.shape[-1])[:, pid, :self.nodes[node].spec.cout].float())
+            native = iter(feats)
+        else:
+            native = iter(self.forward_taps(x, taps, tap_ids)) if taps else iter(())
         out = []
         for tap, pid in zip(where, ids):
             if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output: plain indexing of the boundary image

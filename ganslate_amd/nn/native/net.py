@@ -279,6 +279,26 @@ class NativeNet:
 
     def mark_packs_dirty(self):
         self._packs_dirty = True
+        self._recent_passes = {}          # (the weights moved: recorded activations no longer describe this network)
+
+    # A recorded pass keeps its activations until its backward pass has run. A recipe that needs DETACHED features of the
+    # same input again (CUT's source patches: the reference runs the encoder a second time on real_A / real_B,
+    # cut.py:205-211, 297-312) can read them out of that pass instead of launching it again: same weights, same input,
+    # same kernels — the same bits.
+    def _remember_pass(self, x, saved):
+        if not hasattr(self, "_recent_passes"):
+            self._recent_passes = {}
+        if len(self._recent_passes) >= 4:
+            self._recent_passes.pop(next(iter(self._recent_passes)))
+        self._recent_passes[(x.data_ptr(), tuple(x.shape))] = (x._version, saved)
+
+    def recorded_pass(self, x):
+        """the saved state of a recorded full pass over exactly this tensor (same storage, shape and version) whose
+        activations are still alive, or None"""
+        ent = getattr(self, "_recent_passes", {}).get((x.data_ptr(), tuple(x.shape)))
+        if ent is None or ent[0] != x._version or ent[1].acts is None or any(a is None for a in ent[1].acts):
+            return None
+        return ent[1]
 
     def refresh_packs(self, x):
         """bring the bf16 packs for inputs shaped like x up to date now (on the current stream), so that passes launched
@@ -819,6 +839,7 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, token, net: NativeNet):
         out, saved = net._forward(x.detach(), save=True)
+        net._remember_pass(x, saved)
         ctx.net, ctx.saved = net, saved
         ctx.need_x = ctx.needs_input_grad[0]
         ctx.want_w = net.requires_grad     # autograd semantics: decided when the graph is recorded
