@@ -285,20 +285,20 @@ class NativeNet:
     # same input again (CUT's source patches: the reference runs the encoder a second time on real_A / real_B,
     # cut.py:205-211, 297-312) can read them out of that pass instead of launching it again: same weights, same input,
     # same kernels — the same bits.
-    def _remember_pass(self, x, saved):
+    def _remember_pass(self, x, saved, n0=0):
         if not hasattr(self, "_recent_passes"):
             self._recent_passes = {}
         if len(self._recent_passes) >= 4:
             self._recent_passes.pop(next(iter(self._recent_passes)))
-        self._recent_passes[(x.data_ptr(), tuple(x.shape))] = (x._version, saved)
+        self._recent_passes[(x.data_ptr(), tuple(x.shape))] = (x._version, saved, n0)
 
     def recorded_pass(self, x):
-        """the saved state of a recorded full pass over exactly this tensor (same storage, shape and version) whose
-        activations are still alive, or None"""
+        """(saved state, first image) of a recorded full pass that contained exactly this tensor (same storage, shape and
+        version) and whose activations are still alive, or None"""
         ent = getattr(self, "_recent_passes", {}).get((x.data_ptr(), tuple(x.shape)))
         if ent is None or ent[0] != x._version or ent[1].acts is None or any(a is None for a in ent[1].acts):
             return None
-        return ent[1]
+        return ent[1], ent[2]
 
     def refresh_packs(self, x):
         """bring the bf16 packs for inputs shaped like x up to date now (on the current stream), so that passes launched
@@ -432,11 +432,31 @@ class NativeNet:
             return out
         return _NetFn.apply(x, self._token, self)
 
+    def forward_parts(self, xs):
+        """several batches through this network as ONE pass (they follow each other in the batch; per-sample InstanceNorm:
+        every image's output is what its own pass gives) -> one output per batch. CUT's G(real_A) and G(real_B),
+        cut.py:160-166."""
+        xs = tuple(t.contiguous().float() for t in xs)
+        assert all(t.shape[1:] == xs[0].shape[1:] for t in xs), "forward_parts: batches of one image shape"
+        record = torch.is_grad_enabled() and (self.requires_grad or any(t.requires_grad for t in xs))
+        if not record:
+            out, _ = self._forward(tuple(t.detach() for t in xs), save=False)
+            return _split_parts(out, xs)
+        return _PartsFn.apply(self._token, self, *xs)
+
     def forward_taps(self, x, taps, ids):
         """sampled features of intermediate nodes: taps = [("x"|"y", node)], ids = [LongTensor[P]] (pixel indices);
         returns a tuple of [N, P, C] fp32 tensors that autograd can differentiate into the network"""
         x = x.contiguous().float()
-        return _TapFn.apply(x, self._token, self, tuple(taps), tuple(ids))
+        return _TapFn.apply(self._token, self, tuple(taps), (tuple(ids),), x)
+
+    def forward_taps_parts(self, xs, taps, ids_per_part):
+        """forward_taps for several batches in ONE encoder pass, each with its own pixel ids -> per batch a tuple of
+        [N_p, P, C] tensors"""
+        xs = tuple(t.contiguous().float() for t in xs)
+        outs = _TapFn.apply(self._token, self, tuple(taps), tuple(tuple(i) for i in ids_per_part), *xs)
+        k = len(taps)
+        return [outs[p * k:(p + 1) * k] for p in range(len(xs))]
 
     def _forward(self, x, save, stop=None, tw=None):
         """stop = index of the last node to run (encoder-only passes of CUT, cut.py:297-312); None = whole net.
@@ -444,7 +464,8 @@ class NativeNet:
         as ONE batch of 2N images, images [0, N) through this network's weights and [N, 2N) through tw's."""
         ops, dev = self.ops, self.device
         # twin: x = (images of this network, images of tw), each a tuple of tensors that follow each other in the batch
-        xs = tuple(x[0]) + tuple(x[1]) if tw is not None else (x,)
+        # (one network: a tensor, or a tuple of batches that run as one pass — forward_parts)
+        xs = tuple(x[0]) + tuple(x[1]) if tw is not None else (tuple(x) if isinstance(x, (tuple, list)) else (x,))
         sizes = tuple(xs[0].shape[2:])
         N = sum(t.shape[0] for t in xs)
         if tw is not None:
@@ -513,7 +534,7 @@ class NativeNet:
         if not save:
             return out, None
         s = _Saved()
-        s.x_img, s.acts, s.ys, s.mrs, s.out_img, s.lows, s.N = (xs if tw is not None else x), acts, ys, mrs, out, lows, N
+        s.x_img, s.acts, s.ys, s.mrs, s.out_img, s.lows, s.N = (x if torch.is_tensor(x) else xs), acts, ys, mrs, out, lows, N
         s.attn = attn_saved
         return out, s
 
@@ -529,7 +550,8 @@ class NativeNet:
         inj_x, inj_y = inj_x or {}, inj_y or {}
         ops, dev = self.ops, self.device
         nodes, lows, N = self.nodes, s.lows, s.N
-        x_imgs = s.x_img if tw is not None else (s.x_img,)
+        parts = not torch.is_tensor(s.x_img)        # the pass took several batches (twin pass / forward_parts)
+        x_imgs = s.x_img if parts else (s.x_img,)
         Nh = N // 2 if tw is not None else N        # images per network
         for net in (self, tw):
             if net is not None and net.master.grad is None:
@@ -545,7 +567,7 @@ class NativeNet:
         if g_img is not None:
             ga = torch.empty_like(s.acts[-1])
             n0 = 0
-            for gh, xh in zip(g_img if tw is not None else (g_img,), x_imgs):     # one gradient per input part
+            for gh, xh in zip(g_img if parts else (g_img,), x_imgs):     # one gradient per input part
                 gah, outh = ga[n0:n0 + xh.shape[0]], s.out_img[n0:n0 + xh.shape[0]]
                 n0 += xh.shape[0]
                 if gh is None:           # this part's output took no part in the loss
@@ -709,7 +731,7 @@ class NativeNet:
             else:
                 ops.image_to_act_backward(gxh, g_in, fold=f, fold_mode=fmode)
             g_ins.append(g_in)
-        return tuple(g_ins) if tw is not None else g_ins[0]
+        return tuple(g_ins) if parts else g_ins[0]
 
     # ---- data parallelism (reference: DistributedDataParallel per network, base.py:172-189) -------------
     def parallelize(self, process_group=None, bucket_bytes=8 << 20):
@@ -785,26 +807,38 @@ class NativeNet:
         return 1.0 / dist.get_world_size(self._dist)
 
 
+def _split_parts(out, parts):
+    outs, n0 = [], 0
+    for t in parts:
+        outs.append(out[n0:n0 + t.shape[0]])
+        n0 += t.shape[0]
+    return tuple(outs)
+
+
 class _TapFn(torch.autograd.Function):
     """Encoder-only pass returning sampled feature patches [N, P, C] (fp32) of several nodes as one autograd node:
     forward gathers rows of the NHWC activations (a patch is one pixel's channel vector), backward scatters the patch
-    gradients back and runs the partial backward pass."""
+    gradients back and runs the partial backward pass. Several batches (each with its own pixel ids) ride in one pass;
+    outputs come batch by batch, tap by tap."""
 
     @staticmethod
-    def forward(ctx, x, token, net, taps, ids):
+    def forward(ctx, token, net, taps, ids, *xs):
         stop = max(node for _, node in taps)
-        _, saved = net._forward(x.detach(), save=True, stop=stop)
+        xs = tuple(t.detach() for t in xs)
+        _, saved = net._forward(xs if len(xs) > 1 else xs[0], save=True, stop=stop)
         ctx.net, ctx.saved, ctx.taps, ctx.ids, ctx.stop = net, saved, taps, ids, stop
-        ctx.need_x = ctx.needs_input_grad[0]
+        ctx.sizes = tuple(t.shape[0] for t in xs)
+        ctx.need_x = any(ctx.needs_input_grad[4:])
         ctx.want_w = net.requires_grad
         if ctx.want_w:
             net._fw_pending += 1
-        outs = []
-        N = x.shape[0]
-        for (kind, node), pid in zip(taps, ids):
-            src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
-            c = net.nodes[node].spec.cout
-            outs.append(src.view(N, -1, src.shape[-1])[:, pid, :c].float())
+        outs, n0 = [], 0
+        for np_, pids in zip(ctx.sizes, ids):
+            for (kind, node), pid in zip(taps, pids):
+                src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
+                c = net.nodes[node].spec.cout
+                outs.append(src[n0:n0 + np_].view(np_, -1, src.shape[-1])[:, pid, :c].float())
+            n0 += np_
         return tuple(outs)
 
     @staticmethod
@@ -813,24 +847,66 @@ class _TapFn(torch.autograd.Function):
         if ctx.want_w:
             net._fw_pending -= 1
         inj = {"x": {}, "y": {}}
-        N = s.N
-        for (kind, node), pid, g in zip(ctx.taps, ctx.ids, grads):
-            if g is None:
-                continue
-            src = s.ys[node] if kind == "y" else s.acts[node + 1]
-            dense = inj[kind].get(node)
-            if dense is None:
-                dense = torch.zeros_like(src)
-                inj[kind][node] = dense
-            c = net.nodes[node].spec.cout
-            dense.view(N, -1, src.shape[-1])[:, pid, :c] += g.to(dense.dtype)
+        k, n0 = len(ctx.taps), 0
+        for p, (np_, pids) in enumerate(zip(ctx.sizes, ctx.ids)):
+            for (kind, node), pid, g in zip(ctx.taps, pids, grads[p * k:(p + 1) * k]):
+                if g is None:
+                    continue
+                src = s.ys[node] if kind == "y" else s.acts[node + 1]
+                dense = inj[kind].get(node)
+                if dense is None:
+                    dense = torch.zeros_like(src)
+                    inj[kind][node] = dense
+                c = net.nodes[node].spec.cout
+                dense[n0:n0 + np_].view(np_, -1, src.shape[-1])[:, pid, :c] += g.to(dense.dtype)
+            n0 += np_
         if ctx.want_w:      # passes that write parameter gradients are ordered per network
             net._order_backward_begin()
         gx = net._backward(s, None, ctx.need_x, ctx.want_w, start=ctx.stop, inj_x=inj["x"], inj_y=inj["y"])
         if ctx.want_w:
             net._order_backward_end()
         ctx.saved = None
-        return gx, None, None, None, None
+        if gx is None:
+            return (None,) * (4 + len(ctx.sizes))
+        gx = gx if isinstance(gx, tuple) else (gx,)
+        return (None, None, None, None) + tuple(g if need else None for g, need in zip(gx, ctx.needs_input_grad[4:]))
+
+
+class _PartsFn(torch.autograd.Function):
+    """several batches through the whole network as one autograd node (NativeNet.forward_parts)"""
+
+    @staticmethod
+    def forward(ctx, token, net, *xs):
+        xs = tuple(t.detach() for t in xs)
+        out, saved = net._forward(xs, save=True)
+        n0 = 0
+        for t in xs:
+            net._remember_pass(t, saved, n0)
+            n0 += t.shape[0]
+        ctx.net, ctx.saved = net, saved
+        ctx.need = tuple(ctx.needs_input_grad[2:])
+        ctx.want_w = net.requires_grad
+        if ctx.want_w:
+            net._fw_pending += 1
+        ctx.set_materialize_grads(False)
+        return _split_parts(out, xs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        net = ctx.net
+        if ctx.want_w:
+            net._fw_pending -= 1
+            net._order_backward_begin()
+        for g in grads:
+            if g is not None and g.is_cuda:
+                g.record_stream(torch.cuda.current_stream())
+        gx = net._backward(ctx.saved, grads, any(ctx.need), ctx.want_w)
+        if ctx.want_w:
+            net._order_backward_end()
+        ctx.saved = None
+        if gx is None:
+            return (None,) * (2 + len(grads))
+        return (None, None) + tuple(g if need else None for g, need in zip(gx, ctx.need))
 
 
 class _NetFn(torch.autograd.Function):
