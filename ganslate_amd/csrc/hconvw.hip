@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
         // the same moment that is an exposed HBM burst (the loop itself leaves HBM idle: measured 21 us per twin launch over
         // the forward form). The last chunk's first 8 K-steps therefore pull those lines towards the chip, one 1-KB LDS-DMA
         // per wave and step into the sink (data discarded): the epilogue's loads then hit L2 / the memory-side cache.
-        const bool pf_now = RING && last_chunk && t < 8;
+        const bool pf_now = RING && last_chunk && t < 8 && p.prefetch;
         if constexpr (RING) {
           if (pf_now) {
             int tq = tid;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
             // stores and this tile's chunk-1 halo (ks 0: w2 | stores | halo outstanding; ks 1: stores | halo | w3)
             nv = WPI + NST + HPW;
           else if (!w_now && (c > 0 || t >= 1)) nv = 0;                                    // tail of the last tile
-          else nv = WPI + (halo_now ? HPW : 0) + (pf_now ? 1 : 0) + (RING && last_chunk && t >= 1 ? 1 : 0);
+          else nv = WPI + (halo_now ? HPW : 0) + (pf_now ? 1 : 0) + (RING && last_chunk && t >= 1 && p.prefetch ? 1 : 0);
           switch (nv) {        // (ks 0 of the launch: w1 | w2 -> WPI)
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             case WPI: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory"); break;
@@ -667,6 +667,7 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   hconvw_twin(k, tw);
   k.d = *d;
   k.f = gs_gconv_fuse{};
+  k.prefetch = 0;
   const int lds = 160 * 1024;
   static bool configured = false;
   if (!configured) {
@@ -719,6 +720,7 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   k.chunks = d->Ci / 64;
   k.d = *d;
   k.f = *fuse;
+  k.prefetch = gs_opt(GS_OPT_HCONVW_PREFETCH);
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   k.ntiles = (int)blocks;
   hconvw_twin(k, tw);

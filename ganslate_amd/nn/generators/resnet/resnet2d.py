@@ -98,14 +98,17 @@ class Resnet2D(NativeNet):
         tap_ids = [i for i, t in zip(ids, where) if t[0] != "pad"]
         if detached and taps:
             xc = x.contiguous().float()
-            saved = self.recorded_pass(xc)
-            if saved is None:
+            rec = self.recorded_pass(xc)
+            if rec is None:
                 with torch.no_grad():
                     _, saved = self._forward(xc.detach(), save=True, stop=max(node for _, node in taps))
-            feats = []
+                n0 = 0
+            else:
+                saved, n0 = rec            # (the pass may have carried other batches in front of this one)
+            feats, nb = [], xc.shape[0]
             for (kind, node), pid in zip(taps, tap_ids):
                 src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
-                feats.append(src.view(xc.shape[0], -1, src.shape[-1])[:, pid, :self.nodes[node].spec.cout].float())
+                feats.append(src[n0:n0 + nb].view(nb, -1, src.shape[-1])[:, pid, :self.nodes[node].spec.cout].float())
             native = iter(feats)
         else:
             native = iter(self.forward_taps(x, taps, tap_ids)) if taps else iter(())
