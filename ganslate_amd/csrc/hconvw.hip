@@ -433,6 +433,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       uint2 pk[TI][TJ];
       const int cy = e_top ? 1 : 14, cx = e_lef ? 1 : 14;    // where this box's image corner (if it has one) folds onto
       const bool corner = (e_top || e_bot) && (e_lef || e_rig);
+      // act'(yhat) without a branch per element (the mode is uniform): u * (yhat > 0 ? 1 : neg) + v * (1 - yhat^2) with
+      // (u, v) = (1, 0) and neg = 1 / 0 / slope for none / relu / lrelu, (0, 1) for tanh — exact in both cases
+      const float neg = p.f.act == GS_ACT_RELU ? 0.f : (p.f.act == GS_ACT_LRELU ? p.f.slope : 1.f);
+      const float au = p.f.act == GS_ACT_TANH ? 0.f : 1.f, av = 1.f - au;
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         if (i + 1 < TI) load_yg(i + 1);
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float yh = (yr[r] - mu[r]) * rs[r];
-            const float gh = g[r] * act_grad_from_out(yh, p.f.act, p.f.slope);
+            const float gh = g[r] * __builtin_fmaf(av, __builtin_fmaf(-yh, yh, 1.f), au * (yh > 0.f ? 1.f : neg));
             s1[r] += gh;
             s2[r] += gh * yh;
             s3[r] += yh;
@@ -514,6 +518,8 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+      // (the activation mode is uniform: the usual case — none, the norm follows — skips the per-element switch)
+      const bool plain = d.act == GS_ACT_NONE;
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
 #pragma unroll
@@ -526,7 +532,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
               v[r] = acc[i][ph * 2 + jj][r] + bia[i][r];
               s1[i][r] += v[r];
               s2[i][r] += v[r] * v[r];
-              v[r] = apply_act(v[r], d.act, d.slope);
+            }
+            if (!plain) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], d.act, d.slope);
             }
             uint2 o;
             o.x = pack_bf2(v[0], v[1]);
