@@ -278,23 +278,6 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
           if (tail2) issue_w(n + nstep, 0, t - (T - 2), stage == 0 ? 2 : stage - 1);
           else issue_w(n, t + 2 >= T ? c + 1 : c, t + 2 >= T ? t + 2 - T : t + 2, stage == 0 ? 2 : stage - 1);
         }
-        // RING: the epilogue reads this tile's y and g2 (64 KB each) — with every workgroup of the chip in its epilogue at
-        // the same moment that is an exposed HBM burst (the loop itself leaves HBM idle: measured 21 us per twin launch over
-        // the forward form). The last chunk's first 8 K-steps therefore pull those lines towards the chip, one 1-KB LDS-DMA
-        // per wave and step into the sink (data discarded): the epilogue's loads then hit L2 / the memory-side cache.
-        const bool pf_now = RING && last_chunk && t < 8 && p.prefetch;
-        if constexpr (RING) {
-          if (pf_now) {
-            int tq = tid;
-            asm volatile("" : "+v"(tq));              // (offset rebuilt per use: no register carried through the loop)
-            // piece q = (t / 2) * 1024 + tid of the tile's 256 pixels x 16 pieces: pixel q / 16, 16-B piece q % 16
-            const unsigned off = ((unsigned)(((t >> 1) * 4 + (tq >> 8)) * d.Wo + ((tq >> 4) & 15)) * (unsigned)d.Co +
-                                  (unsigned)(nt * BN + (tq & 15) * 8)) * 2u;
-            const char* base = (t & 1) ? static_cast<const char*>(p.f.g2) : static_cast<const char*>(p.f.y);
-            const char* src = base ? base + ((size_t)n * d.Ho + oy0) * d.Wo * d.Co * 2 + (size_t)ox0 * d.Co * 2 + off : p.zero;
-            glds16(src, sink);
-          }
-        }
         load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K0{}, wA, xA);
         load_frags(wring0 + (unsigned)(stage * WT), hb + (unsigned)tb[t], K1{}, wB, xB);
         [[maybe_unused]] const bool e_now = RING && ((e_mask >> t) & 1u);
@@ -310,28 +293,17 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
         if constexpr (RING) {
           if (e_now) { reg_fence(xE0); reg_fence(xE1); }
         }
-        // This wave's share of step ks+1's weights (and anything older) has landed: wait until at most the operations issued
-        // AFTER them are outstanding (VMEM retires in issue order) — this step's halo / weights / prefetch and the
-        // previous step's prefetch, which follows that step's weights.
-        auto wait_next_weights = [&]() {
+        auto wait_next_weights = [&]() {       // this wave's share of step ks+1's weights (and anything older) has landed
           if (last_chunk && t == T - 1 && !has_next) return;
-          int nv;
-          if (it > 0 && c == 0 && t <= 1)
+          if (it > 0 && c == 0 && t <= 1) {
             // first K-steps behind a tile boundary: the weights waited for are older than the previous tile's NST output
             // stores and this tile's chunk-1 halo (ks 0: w2 | stores | halo outstanding; ks 1: stores | halo | w3)
-            nv = WPI + NST + HPW;
-          else if (!w_now && (c > 0 || t >= 1)) nv = 0;                                    // tail of the last tile
-          else nv = WPI + (halo_now ? HPW : 0) + (pf_now ? 1 : 0) + (RING && last_chunk && t >= 1 && p.prefetch ? 1 : 0);
-          switch (nv) {        // (ks 0 of the launch: w1 | w2 -> WPI)
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case WPI: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory"); break;
-            case WPI + 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + 1) : "memory"); break;
-            case WPI + 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + 2) : "memory"); break;
-            case HPW + WPI: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI) : "memory"); break;
-            case HPW + WPI + 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI + 1) : "memory"); break;
-            case WPI + NST + HPW: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + NST + HPW) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + NST + HPW) : "memory");
+            return;
           }
+          if (!w_now && (c > 0 || t >= 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail of the last tile
+          else if (halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW + WPI) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI) : "memory");               // (ks 0 of the launch: w1 | w2)
         };
         if (grp) wait_next_weights();
         __builtin_amdgcn_s_barrier();
@@ -676,7 +648,6 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   hconvw_twin(k, tw);
   k.d = *d;
   k.f = gs_gconv_fuse{};
-  k.prefetch = 0;
   const int lds = 160 * 1024;
   static bool configured = false;
   if (!configured) {
@@ -729,7 +700,6 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   k.chunks = d->Ci / 64;
   k.d = *d;
   k.f = *fuse;
-  k.prefetch = gs_opt(GS_OPT_HCONVW_PREFETCH);
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   k.ntiles = (int)blocks;
   hconvw_twin(k, tw);

@@ -16,7 +16,6 @@ struct HConvWK {
   int nsplit;                  // twin batch: images >= nsplit use the second network's weights (INT_MAX: one network)
   long long w_delta;           // byte distance from the first network's pack to the second's
   long long bias_delta;        // the same for the bias vector, in floats
-  int prefetch;                // RING: pull the epilogue's y / g2 lines in during the last chunk (option hconvw_prefetch)
   gs_gconv_desc d;
   gs_gconv_fuse f;             // RING: the consumer's InstanceNorm backward sums ride in the epilogue (gs_gconv_forward_fused)
 };
