@@ -9,6 +9,7 @@ land in the same flat buffer and are all-reduced with it; the `mlp` optimiser st
 The encoder-only passes do not materialise NCHW feature maps: a "patch" is one pixel's channel vector, i.e. one
 contiguous row of the NHWC activation, so the sampled patches are gathered straight out of the executor's
 activations (Resnet2D.extract_patch_features) and their gradients scattered straight back."""
+import os
 from dataclasses import dataclass, field
 from typing import Tuple
 
@@ -114,9 +115,21 @@ class CUT(BaseGAN):
                 real_A = real_A.flip(-1)
                 if using_idt:
                     real_B = real_B.flip(-1)
-        self.visuals["fake_B"] = self.networks["G"](real_A)
+        G = self.networks["G"]
+        if using_idt and self._batched(G):
+            # G(real_A) and G(real_B) as one pass over both batches (per-sample InstanceNorm: same images out); the trunk
+            # launches then carry 2N images — two tiles per workgroup (csrc/hconvw.hip)
+            self.visuals["fake_B"], self.visuals["idt_B"] = G.forward_parts((real_A, real_B))
+            return
+        self.visuals["fake_B"] = G(real_A)
         if using_idt:
-            self.visuals["idt_B"] = self.networks["G"](real_B)
+            self.visuals["idt_B"] = G(real_B)
+
+    @staticmethod
+    def _batched(G):
+        """same-network passes over independent batches run as one pass (GS_CUT_BATCH=0: one pass each, as the reference)"""
+        return os.environ.get("GS_CUT_BATCH", "1") != "0" and hasattr(G, "forward_parts") and \
+            hasattr(G, "extract_patch_features_parts")
 
     def backward_D(self):
         real, fake = self.visuals["real_B"], self.visuals["fake_B"]
@@ -136,7 +149,14 @@ class CUT(BaseGAN):
             adversarial_loss = self.criterion_adv(pred_fake, True).mean() * self.lambda_adv
             self.losses["G"] = adversarial_loss
         nce_loss = 0
-        if self.lambda_nce > 0:
+        if self.lambda_nce > 0 and self.lambda_nce_idt > 0 and self._batched(self.networks["G"]):
+            # both PatchNCE terms out of ONE encoder pass over (fake_B, idt_B); ids drawn in the reference's order
+            nce_loss, nce_idt = self._calculate_nce_losses([(real_A, fake_B), (real_B, idt_B)])
+            self.losses["NCE"] = nce_loss
+            nce_idt_loss = self.lambda_nce_idt * nce_idt
+            nce_loss = (1 - self.lambda_nce_idt) * nce_loss + nce_idt_loss
+            self.losses["NCE_idt"] = nce_idt_loss
+        elif self.lambda_nce > 0:
             nce_loss = self._calculate_nce_loss(real_A, fake_B)
             self.losses["NCE"] = nce_loss
             if self.lambda_nce_idt > 0:
@@ -176,6 +196,26 @@ class CUT(BaseGAN):
                 for d, t in zip(dst, src):
                     d.copy_(t)
         self._nce_call = 0
+
+    def _calculate_nce_losses(self, pairs):
+        """_calculate_nce_loss for several (source, target) pairs with ONE encoder pass over all targets"""
+        G, mlp = self.networks["G"], self.networks["mlp"]
+        src_feats, tgt_ids = [], []
+        for source, _ in pairs:
+            H, W = source.shape[-2:]
+            if self.external_draw_ids:                        # captured / replayed iteration: ids are static tensors
+                ids = self._pid_static[self._nce_call]
+                self._nce_call += 1
+            else:
+                ids = self.sample_patch_ids(H, W)
+            src_feats.append(G.extract_patch_features(source, self.nce_layers, ids, detached=True))
+            if self.is_flipped:       # target features are flipped back along W before sampling (cut.py:214-215)
+                ids = [(pid // G.tap_dims(e, H, W)[1]) * G.tap_dims(e, H, W)[1] + (G.tap_dims(e, H, W)[1] - 1 - pid % G.tap_dims(e, H, W)[1])
+                       for e, pid in zip(self.nce_layers, ids)]
+            tgt_ids.append(ids)
+        tgt_feats = G.extract_patch_features_parts([t for _, t in pairs], self.nce_layers, tgt_ids)
+        return [mlp.nce_loss(tf, sf, source.shape[0], self.nce_T, self.lambda_nce)
+                for tf, sf, (source, _) in zip(tgt_feats, src_feats, pairs)]
 
     def _calculate_nce_loss(self, source, target, patch_ids=None):
         G, mlp = self.networks["G"], self.networks["mlp"]

@@ -121,6 +121,30 @@ class Resnet2D(NativeNet):
                 out.append(next(native))
         return out
 
+    def extract_patch_features_parts(self, xs, layers, ids_per_part):
+        """extract_patch_features for several batches in ONE encoder pass, each with its own pixel ids (CUT's target
+        patches of fake_B and idt_B) -> per batch a list of [N_p, P, C] fp32"""
+        import torch.nn.functional as F
+        taps, where = [], []
+        for e in layers:
+            tap, _ = self.encoder_tap(e)
+            where.append(tap)
+            if tap[0] != "pad":
+                taps.append(tap)
+        native = self.forward_taps_parts(xs, taps, [[i for i, t in zip(ids, where) if t[0] != "pad"]
+                                                     for ids in ids_per_part]) if taps else [() for _ in xs]
+        out = []
+        for x, ids, nat in zip(xs, ids_per_part, native):
+            nat, feats = iter(nat), []
+            for tap, pid in zip(where, ids):
+                if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output: plain indexing of the boundary image
+                    xp = F.pad(x.float(), (3, 3, 3, 3), mode="reflect")
+                    feats.append(xp.permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :])
+                else:
+                    feats.append(next(nat))
+            out.append(feats)
+        return out
+
     def tap_dims(self, e, H, W):
         """(rows, columns) of encoder layer e for an H x W input: the ReflectionPad2d(3) output, the k7 conv block, the two
         stride-2 blocks (k3 p1: ceil(n / 2)), the residual trunk"""
