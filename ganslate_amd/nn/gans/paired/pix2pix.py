@@ -76,8 +76,12 @@ class Pix2PixConditionalGAN(BaseGAN):
 
     def backward_D(self):
         real_A, real_B, fake_B = self.visuals["real_A"], self.visuals["real_B"], self.visuals["fake_B"]
-        self.pred_real = self.networks["D"](torch.cat([real_A, real_B], dim=1))
-        self.pred_fake = self.networks["D"](torch.cat([real_A, fake_B.detach()], dim=1))
+        D = self.networks["D"]
+        pair_real, pair_fake = torch.cat([real_A, real_B], dim=1), torch.cat([real_A, fake_B.detach()], dim=1)
+        if hasattr(D, "forward_parts"):      # D(real pair) and D(fake pair) as one pass over both batches (per-sample norm)
+            self.pred_real, self.pred_fake = D.forward_parts((pair_real, pair_fake))
+        else:
+            self.pred_real, self.pred_fake = D(pair_real), D(pair_fake)
         loss_real = self.criterion_adv(self.pred_real, target_is_real=True)
         loss_fake = self.criterion_adv(self.pred_fake, target_is_real=False)
         self.losses["D"] = loss_real + loss_fake

@@ -133,8 +133,11 @@ class CUT(BaseGAN):
 
     def backward_D(self):
         real, fake = self.visuals["real_B"], self.visuals["fake_B"]
-        pred_real = self.networks["D"](real)
-        pred_fake = self.networks["D"](fake.detach())
+        D = self.networks["D"]
+        if hasattr(D, "forward_parts") and os.environ.get("GS_CUT_BATCH", "1") != "0":
+            pred_real, pred_fake = D.forward_parts((real, fake.detach()))      # one pass over both batches (per-sample norm)
+        else:
+            pred_real, pred_fake = D(real), D(fake.detach())
         loss_real = self.criterion_adv(pred_real, True).mean()
         loss_fake = self.criterion_adv(pred_fake, False).mean()
         self.losses["D"] = loss_real + loss_fake

@@ -110,8 +110,11 @@ class RevGAN(BaseGAN):
             loss_id = 1
         else:
             raise ValueError('The discriminator has to be either "D_A" or "D_B".')
-        self.pred_real = self.networks[discriminator](real)
-        self.pred_fake = self.networks[discriminator](fake.detach())
+        D = self.networks[discriminator]
+        if hasattr(D, "forward_parts"):      # D(real) and D(fake) as one pass over both batches (InstanceNorm is per sample)
+            self.pred_real, self.pred_fake = D.forward_parts((real, fake.detach()))
+        else:
+            self.pred_real, self.pred_fake = D(real), D(fake.detach())
         loss_real = self.criterion_adv(self.pred_real, target_is_real=True)
         loss_fake = self.criterion_adv(self.pred_fake, target_is_real=False)
         self.losses[discriminator] = loss_real + loss_fake
