@@ -692,7 +692,8 @@ class NativeNet:
                         and not nodes[i - 1].attn:
                     # the four parity classes of a stride-2 conv's data gradient as one halo-resident launch (hconvt.hip)
                     plan = ops.fused_multi_plan(lw.dgrad, N, sp.cin_p, twin=tw is not None)
-                ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p, twin=tw is not None) if plan is not None else None
+                ring = ops.fused_ring_plan(lw.dgrad_ring, N, sp.cin_p, twin=tw is not None) \
+                    if (plan is not None and nodes[i - 1].act != "tanh") else None     # (the ring form has no tanh' path)
                 if ring is None:
                     gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
                 if ring is not None:
