@@ -462,3 +462,65 @@ extern "C" int gs_ssim_distance_backward(const float* x, const float* y, int32_t
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- scalar algebra of a recipe's loss assembly ----------------------------------------------------------------------------------
+// out[r] = c[r] + sum_k m[r][k] * x_k[0] for R <= 8 rows over K <= 16 device scalars (a null x_k counts as 0): the
+// "lambda_AB * (alpha * ssim + beta * l1)", "loss_real + loss_fake", "sum of the G losses" lines of the recipes
+// (cyclegan_losses.py:21-32,70-90, cyclegan.py:150,182) as ONE launch instead of one torch elementwise kernel per operator;
+// the backward of such a combination is the same launch with the transposed matrix over the rows' upstream gradients.
+struct ScalarAffineK {
+  const float* x[16];
+  float m[8][16];
+  float c[8];
+  float* out;
+  int K, R;
+};
+__global__ __launch_bounds__(64) void scalar_affine_kernel(const ScalarAffineK p) {
+  const int r = threadIdx.x;
+  if (r >= p.R) return;
+  float acc = p.c[r];
+  for (int k = 0; k < p.K; ++k)
+    if (p.x[k]) acc += p.m[r][k] * p.x[k][0];
+  p.out[r] = acc;
+}
+extern "C" int gs_scalar_affine(const float* const* x, int32_t K, const float* m, const float* c, int32_t R, float* out,
+                                void* stream) {
+  GS_REQUIRE(x && m && out && K > 0 && K <= 16 && R > 0 && R <= 8, "gs_scalar_affine: bad argument (K <= 16, R <= 8)");
+  ScalarAffineK p;
+  for (int k = 0; k < 16; ++k) p.x[k] = k < K ? x[k] : nullptr;
+  for (int r = 0; r < 8; ++r) {
+    p.c[r] = (c && r < R) ? c[r] : 0.f;
+    for (int k = 0; k < 16; ++k) p.m[r][k] = (r < R && k < K) ? m[r * K + k] : 0.f;
+  }
+  p.out = out; p.K = K; p.R = R;
+  hipLaunchKernelGGL(scalar_affine_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), p);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// out = a + b over n floats: the join of two gradients of one image (a generated image feeds a discriminator AND the
+// other generator, cyclegan.py:131-141 — autograd's own accumulation would be a torch kernel)
+__global__ __launch_bounds__(256) void sum2_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                   float4* __restrict__ out, long long n4, const float* as, const float* bs,
+                                                   float* os, int tail) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 u = a[i], v = b[i];
+    out[i] = float4{u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) os[threadIdx.x] = as[threadIdx.x] + bs[threadIdx.x];
+}
+extern "C" int gs_sum2_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  GS_REQUIRE(a && b && out && n > 0, "gs_sum2_f32: bad argument");
+  GS_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+             "gs_sum2_f32: buffers must be 16-byte aligned");
+  const long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sum2_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4,
+                     a + n4 * 4, b + n4 * 4, out + n4 * 4, (int)(n - n4 * 4));
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+

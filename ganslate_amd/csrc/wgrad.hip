@@ -520,8 +520,19 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy
   }
 }
 
+// db[c] += sum of the slabs' column c, slabs in order, for the first c_valid (< 8) channels only: the bias of a layer whose
+// real channel count is not a multiple of 8 sits in the flat gradient buffer with the next parameter right behind it
+__global__ __launch_bounds__(64) void bias_head_reduce_kernel(const float* __restrict__ ws, float* db, int slabs, int C,
+                                                              int c_valid) {
+  const int c = threadIdx.x;
+  if (c >= c_valid) return;
+  float s = 0.f;
+  for (int b = 0; b < slabs; ++b) s += ws[(size_t)b * C + c];
+  db[c] += s;
+}
+
 static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, float* ws,
-                          int64_t ws_floats, int plan_only, void* stream, int64_t* need) {
+                          int64_t ws_floats, int plan_only, void* stream, int64_t* need, int c_valid = -1) {
   GS_REQUIRE(pixels > 0 && C > 0 && (C & 7) == 0 && (cs & 7) == 0 && (co & 7) == 0,
              "gs_bias_grad: bad argument (C, cs, co must be multiples of 8)");
   const int C8 = C / 8;
@@ -539,7 +550,10 @@ static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs,
   else if (C8 >= 2) hipLaunchKernelGGL((bias_grad_kernel<2>), dim3(bx, (C8 + 1) / 2), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   else hipLaunchKernelGGL((bias_grad_kernel<1>), dim3(bx, C8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   GS_CHECK_HIP(hipGetLastError());
-  if (ws) {
+  if (ws && c_valid >= 0) {
+    hipLaunchKernelGGL(bias_head_reduce_kernel, dim3(1), dim3(64), 0, st, ws, db, (int)bx, C, c_valid);
+    GS_CHECK_HIP(hipGetLastError());
+  } else if (ws) {
     const long long n4 = C / 4;
     launch_slab_reduce(ws, db, n4, (int)bx, n4, st);
     GS_CHECK_HIP(hipGetLastError());
@@ -560,4 +574,11 @@ extern "C" int gs_bias_grad_ws(const void* dy, int64_t pixels, int32_t C, int32_
                                int64_t ws_floats, void* stream) {
   GS_REQUIRE(ws, "gs_bias_grad_ws: null workspace");
   return bias_grad_impl(dy, pixels, C, cs, co, db, ws, ws_floats, 0, stream, nullptr);
+}
+// the same over the first 8 channels of dy's channel window, adding only db[0 .. c_valid) (c_valid <= 8): db has exactly
+// c_valid floats (workspace: gs_bias_grad_ws_floats(pixels, 8))
+extern "C" int gs_bias_grad_head_ws(const void* dy, int64_t pixels, int32_t cs, int32_t co, int32_t c_valid, float* db,
+                                    float* ws, int64_t ws_floats, void* stream) {
+  GS_REQUIRE(ws && c_valid > 0 && c_valid <= 8, "gs_bias_grad_head_ws: null workspace or c_valid outside 1..8");
+  return bias_grad_impl(dy, pixels, 8, cs, co, db, ws, ws_floats, 0, stream, nullptr, c_valid);
 }

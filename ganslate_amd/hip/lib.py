@@ -172,6 +172,11 @@ _PROTOS = {
                               C.c_void_p, C.c_void_p]),
     "gs_l1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_mean": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gs_scalar_affine": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32,
+                                   C.c_void_p, C.c_void_p]),
+    "gs_sum2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gs_bias_grad_head_ws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_void_p]),
     "gs_ssim_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "gs_ssim_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -395,6 +395,16 @@ class HipOps(TwinSplit):
         if is_twin(db):
             return self.twin_bias_grad(dy, C_, db, cs=cs, co=co)
         pixels = dy.numel() // dy.shape[-1]
+        if C_ % 8:                                          # db has exactly C_ floats: whole octets, then a head of < 8
+            full = C_ // 8 * 8
+            cs_ = cs if cs is not None else dy.shape[-1]
+            if full:
+                self.bias_grad(dy, full, db[:full], cs=cs_, co=co)
+            nws = int(self.lib.gs_bias_grad_ws_floats(pixels, 8))
+            ws = torch.empty(nws, dtype=torch.float32, device=self.device)
+            L.check(self.lib.gs_bias_grad_head_ws(_ptr(dy), pixels, cs_, co + full, C_ - full, _ptr(db[full:]),
+                                                  _ptr(ws), nws, _stream()), "gs_bias_grad_head_ws")
+            return
         if os.environ.get("GS_WGRAD_DET", "1") != "0":      # deterministic: partial sums + fixed-order second stage
             nws = int(self.lib.gs_bias_grad_ws_floats(pixels, C_))
             ws = torch.empty(nws, dtype=torch.float32, device=self.device)
@@ -653,6 +663,21 @@ class HipOps(TwinSplit):
 
     def mean(self, x, out):
         L.check(self.lib.gs_mean(_ptr(x), x.numel(), _ptr(out), _stream()), "gs_mean")
+
+    def scalar_affine(self, xs, rows, consts=None):
+        """[c_r + sum_k rows[r][k] * xs[k]] as a fresh fp32 vector [R]; xs = 0-d fp32 device tensors or None (= 0)"""
+        K, R = len(xs), len(rows)
+        out = torch.empty(R, dtype=torch.float32, device=self.device)
+        px = (C.c_void_p * K)(*[(_ptr(x) if x is not None else None) for x in xs])
+        m = (C.c_float * (R * K))(*[float(v) for row in rows for v in row])
+        c = (C.c_float * R)(*[float(v) for v in consts]) if consts is not None else None
+        L.check(self.lib.gs_scalar_affine(px, K, m, c, R, _ptr(out), _stream()), "gs_scalar_affine")
+        return out
+
+    def sum2(self, a, b):
+        out = torch.empty_like(a)
+        L.check(self.lib.gs_sum2_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "gs_sum2_f32")
+        return out
 
     def ssim_distance(self, x, y, out):
         NC = x.numel() // (x.shape[-1] * x.shape[-2])

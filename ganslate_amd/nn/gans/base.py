@@ -320,7 +320,13 @@ class BaseGAN(ABC):
         self._replay()
 
     def backward(self, loss, optimizer, retain_graph=False, loss_id=0):
-        loss.backward(retain_graph=retain_graph)
+        # the root gradient is a constant kept for the run (loss.backward() alone fills a fresh one every time)
+        unit = getattr(self, "_unit_grad", None)
+        if unit is None or unit.device != loss.device or loss.dim() != 0 or loss.dtype != unit.dtype:
+            if loss.dim() != 0 or (loss.is_cuda and torch.cuda.is_current_stream_capturing()):
+                return loss.backward(retain_graph=retain_graph)
+            unit = self._unit_grad = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(gradient=unit, retain_graph=retain_graph)
 
     def parallelize_networks(self):
         if not torch.distributed.is_initialized():

@@ -18,6 +18,7 @@ import torch
 
 from .... import configs
 from ...losses.adversarial_loss import AdversarialLoss
+from ...losses.functional import scalar_affine, scalar_sum
 from ...optim import NativeAdam
 from ..base import BaseGAN
 
@@ -37,6 +38,11 @@ class CUTConfig(configs.base.BaseGANConfig):
     num_patches: int = 256
     use_equivariance_flip: bool = False
     optimizer: OptimizerConfig = field(default_factory=OptimizerConfig)
+
+
+def _mean0(x):
+    """`.mean()` of a criterion's result (cut.py:186-187,197): a 0-d loss is its own mean"""
+    return x if torch.is_tensor(x) and x.dim() == 0 else x.mean()
 
 
 class CUT(BaseGAN):
@@ -138,35 +144,45 @@ class CUT(BaseGAN):
             pred_real, pred_fake = D.forward_parts((real, fake.detach()))      # one pass over both batches (per-sample norm)
         else:
             pred_real, pred_fake = D(real), D(fake.detach())
-        loss_real = self.criterion_adv(pred_real, True).mean()
-        loss_fake = self.criterion_adv(pred_fake, False).mean()
-        self.losses["D"] = loss_real + loss_fake
+        loss_real = _mean0(self.criterion_adv(pred_real, True))
+        loss_fake = _mean0(self.criterion_adv(pred_fake, False))
+        self.losses["D"] = scalar_sum((loss_real, loss_fake))
         self.backward(loss=self.losses["D"], optimizer=self.optimizers["D"], loss_id=0)
 
     def backward_G_and_mlp(self):
         real_A, real_B = self.visuals["real_A"], self.visuals["real_B"]
         fake_B, idt_B = self.visuals["fake_B"], self.visuals["idt_B"]
-        adversarial_loss = 0
+        # every term with its weight in the combined loss (cut.py:193-227: adversarial * lambda_adv, and with the identity
+        # term (1 - lambda_nce_idt) * NCE + lambda_nce_idt * NCE_idt); the logged losses and the combined one are rows of
+        # ONE launch (losses/functional.py:scalar_affine)
+        xs, combined, named = [], [], {}
         if self.lambda_adv > 0:
             pred_fake = self.networks["D"](fake_B)
-            adversarial_loss = self.criterion_adv(pred_fake, True).mean() * self.lambda_adv
-            self.losses["G"] = adversarial_loss
-        nce_loss = 0
-        if self.lambda_nce > 0 and self.lambda_nce_idt > 0 and self._batched(self.networks["G"]):
-            # both PatchNCE terms out of ONE encoder pass over (fake_B, idt_B); ids drawn in the reference's order
-            nce_loss, nce_idt = self._calculate_nce_losses([(real_A, fake_B), (real_B, idt_B)])
-            self.losses["NCE"] = nce_loss
-            nce_idt_loss = self.lambda_nce_idt * nce_idt
-            nce_loss = (1 - self.lambda_nce_idt) * nce_loss + nce_idt_loss
-            self.losses["NCE_idt"] = nce_idt_loss
-        elif self.lambda_nce > 0:
-            nce_loss = self._calculate_nce_loss(real_A, fake_B)
-            self.losses["NCE"] = nce_loss
-            if self.lambda_nce_idt > 0:
-                nce_idt_loss = self.lambda_nce_idt * self._calculate_nce_loss(real_B, idt_B)
-                nce_loss = (1 - self.lambda_nce_idt) * nce_loss + nce_idt_loss
-                self.losses["NCE_idt"] = nce_idt_loss
-        combined_loss = adversarial_loss + nce_loss
+            xs.append(_mean0(self.criterion_adv(pred_fake, True)))
+            combined.append(self.lambda_adv)
+            named["G"] = {len(xs) - 1: self.lambda_adv}
+        if self.lambda_nce > 0:
+            with_idt = self.lambda_nce_idt > 0
+            if with_idt and self._batched(self.networks["G"]):
+                # both PatchNCE terms out of ONE encoder pass over (fake_B, idt_B); ids drawn in the reference's order
+                nce, nce_idt = self._calculate_nce_losses([(real_A, fake_B), (real_B, idt_B)])
+            else:
+                nce = self._calculate_nce_loss(real_A, fake_B)
+                nce_idt = self._calculate_nce_loss(real_B, idt_B) if with_idt else None
+            xs.append(nce)
+            combined.append(1 - self.lambda_nce_idt if with_idt else 1.0)
+            self.losses["NCE"] = nce
+            if with_idt:
+                xs.append(nce_idt)
+                combined.append(self.lambda_nce_idt)
+                named["NCE_idt"] = {len(xs) - 1: self.lambda_nce_idt}
+        if not xs:
+            combined_loss = 0
+        else:
+            rows = [[w.get(k, 0.0) for k in range(len(xs))] for w in named.values()] + [combined]
+            out = scalar_affine(xs, rows)
+            self.losses.update(zip(named, out))
+            combined_loss = out[-1]
         self.backward(loss=combined_loss, optimizer=(self.optimizers["G"], self.optimizers["mlp"]), loss_id=1)
 
     def sample_patch_ids(self, H, W):
@@ -252,7 +268,7 @@ class _PatchNCEFn(torch.autograd.Function):
                                                lambda_nce=lambda_nce)
         ctx.mlp, ctx.saved, ctx.n = mlp, saved, n
         ctx.needs = [ctx.needs_input_grad[6 + i] for i in range(n)]
-        return loss.sum()
+        return scalar_sum(loss.unbind(0)) if loss.numel() > 1 else loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):

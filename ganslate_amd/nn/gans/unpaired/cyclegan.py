@@ -12,6 +12,7 @@ from .... import configs
 from ....data.utils.image_pool import ImagePool
 from ...losses.adversarial_loss import AdversarialLoss
 from ...losses.cyclegan_losses import CycleGANLosses
+from ...losses.functional import fanout, scalar_affine, scalar_sum
 from ...native.twin import TwinNet
 from ...optim import NativeAdam
 from ..base import BaseGAN
@@ -114,7 +115,10 @@ class CycleGAN(BaseGAN):
         if self.twin_G is not None:
             # both generators as one batch per phase: (G_AB(real_A), G_BA(real_B)), then (G_AB(fake_A), G_BA(fake_B))
             fake_B, fake_A = self.twin_G(real_A, real_B)
-            rec_B, rec_A = self.twin_G(fake_A, fake_B)
+            # each generated image feeds the other generator now and its discriminator in the G step: two aliases whose
+            # gradients the library adds (losses/functional.py:fanout) instead of autograd's accumulation
+            (fake_B, fake_B2), (fake_A, fake_A2) = fanout(fake_B), fanout(fake_A)
+            rec_B, rec_A = self.twin_G(fake_A2, fake_B2)
             idt_B, idt_A = self.twin_G(real_B, real_A) if self.criterion_G.is_using_identity() else (None, None)
             self.visuals.update({"fake_B": fake_B, "rec_A": rec_A, "idt_A": idt_A,
                                  "fake_A": fake_A, "rec_B": rec_B, "idt_B": idt_B})
@@ -125,11 +129,11 @@ class CycleGAN(BaseGAN):
         use_idt = self.criterion_G.is_using_identity()
         idt_B, idt_A = None, None
         self.fork_side_work("cycle_B")
-        fake_B = self.networks["G_AB"](real_A)
-        rec_A = self.networks["G_BA"](fake_B)
+        fake_B, fake_B2 = fanout(self.networks["G_AB"](real_A))
+        rec_A = self.networks["G_BA"](fake_B2)
         with self.side_work("cycle_B"):
-            fake_A = self.networks["G_BA"](real_B)
-            rec_B = self.networks["G_AB"](fake_A)
+            fake_A, fake_A2 = fanout(self.networks["G_BA"](real_B))
+            rec_B = self.networks["G_AB"](fake_A2)
             if use_idt:
                 idt_B = self.networks["G_AB"](real_B)
         if use_idt:
@@ -152,7 +156,7 @@ class CycleGAN(BaseGAN):
             self.pred_real, self.pred_fake = D(real), D(fake.detach())
         loss_real = self.criterion_adv(self.pred_real, target_is_real=True)
         loss_fake = self.criterion_adv(self.pred_fake, target_is_real=False)
-        self.losses[discriminator] = loss_real + loss_fake
+        self.losses[discriminator] = scalar_sum((loss_real, loss_fake))
         self.backward(loss=self.losses[discriminator], optimizer=self.optimizers["D"], loss_id=2)
 
     def backward_D_twin(self):
@@ -163,13 +167,14 @@ class CycleGAN(BaseGAN):
         fake_B = self.fake_B_pool.query(self.visuals["fake_B"]).detach()      # pool order: D_B first (_step_pools)
         fake_A = self.fake_A_pool.query(self.visuals["fake_A"]).detach()
         pred_B, pred_A = self.twin_D((self.visuals["real_B"], fake_B), (self.visuals["real_A"], fake_A))
-        total = None
+        terms = []
         for name, pred in (("D_B", pred_B), ("D_A", pred_A)):
             self.pred_real, self.pred_fake = pred
-            self.losses[name] = self.criterion_adv(self.pred_real, target_is_real=True) + \
-                self.criterion_adv(self.pred_fake, target_is_real=False)
+            terms += [self.criterion_adv(self.pred_real, target_is_real=True),
+                      self.criterion_adv(self.pred_fake, target_is_real=False)]
             self.metrics.update(self.training_metrics.compute_metrics_D(name, self.pred_real, self.pred_fake))
-            total = self.losses[name] if total is None else total + self.losses[name]
+        # D_B = real + fake, D_A = real + fake (cyclegan.py:182) and their sum, one launch
+        self.losses["D_B"], self.losses["D_A"], total = scalar_affine(terms, [[1, 1, 0, 0], [0, 0, 1, 1], [1, 1, 1, 1]])
         self.backward(loss=total, optimizer=self.optimizers["D"], loss_id=2)
 
     def backward_G(self):
@@ -185,7 +190,7 @@ class CycleGAN(BaseGAN):
         self.losses["G_BA"] = self.criterion_adv(pred_A, target_is_real=True)
         losses_G = self.criterion_G(self.visuals)
         self.losses.update(losses_G)
-        combined_loss_G = sum(losses_G.values()) + self.losses["G_AB"] + self.losses["G_BA"]
+        combined_loss_G = scalar_sum(list(losses_G.values()) + [self.losses["G_AB"], self.losses["G_BA"]])
         self.backward(loss=combined_loss_G, optimizer=self.optimizers["G"], loss_id=0)
         self.join_side_work("cycle_B")      # the second cycle's backward ran on its own stream (see forward)
 

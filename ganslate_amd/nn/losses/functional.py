@@ -118,3 +118,75 @@ class _SSIMDistance(torch.autograd.Function):
 def ssim_distance_autograd(X, Y):
     """Differentiable SSIM distance for `proportion_ssim > 0` (cyclegan_losses.py:78-90; SSIMLoss on (x+1)/2)."""
     return _SSIMDistance.apply(X.float(), Y.float())
+
+
+class _ScalarAffine(torch.autograd.Function):
+    """out_r = c_r + sum_k rows[r][k] * x_k over 0-d losses, one launch (gs_scalar_affine); the backward is the same launch
+    with the transposed matrix over the rows' upstream gradients (an unused row contributes nothing)."""
+
+    @staticmethod
+    def forward(ctx, rows, consts, *xs):
+        out = get_ops().scalar_affine([x.detach() for x in xs], rows, consts)
+        ctx.rows = rows
+        ctx.set_materialize_grads(False)
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        rows, K = ctx.rows, len(ctx.rows[0])
+        gs = [None if g is None else g.contiguous().float() for g in gs]
+        gx = get_ops().scalar_affine(gs, [[rows[r][k] for r in range(len(rows))] for k in range(K)]).unbind(0)
+        return (None, None) + tuple(gx[k] if ctx.needs_input_grad[2 + k] else None for k in range(K))
+
+
+def scalar_affine(xs, rows, consts=None):
+    """[c_r + sum_k rows[r][k] * xs[k] for r] for 0-d fp32 losses `xs` — the scalar algebra of a loss assembly as one kernel
+    (forward) and one kernel (backward) instead of one torch elementwise launch per operator. Falls back to torch
+    operators in the written order when a term is not a 0-d fp32 tensor on the compute device (a user criterion returning
+    something else), or for more than 16 terms / 8 rows."""
+    ok = 0 < len(xs) <= 16 and 0 < len(rows) <= 8 and all(
+        torch.is_tensor(x) and x.dim() == 0 and x.dtype == torch.float32 and x.device == xs[0].device for x in xs)
+    if not ok:
+        out = []
+        for r, row in enumerate(rows):
+            acc = None
+            for w, x in zip(row, xs):
+                if w != 0:
+                    term = x if w == 1 else w * x
+                    acc = term if acc is None else acc + term
+            if consts is not None and consts[r] != 0:
+                acc = consts[r] if acc is None else acc + consts[r]
+            out.append(acc)
+        return out
+    rows = tuple(tuple(float(w) for w in row) for row in rows)
+    return list(_ScalarAffine.apply(rows, None if consts is None else tuple(float(c) for c in consts), *xs))
+
+
+def scalar_sum(xs):
+    """sum of 0-d losses (one launch)"""
+    return scalar_affine(list(xs), [[1.0] * len(xs)])[0]
+
+
+class _Fanout(torch.autograd.Function):
+    """Two aliases of one tensor whose gradients are joined by the library's own kernel (gs_sum2_f32): a generated image
+    that feeds both a discriminator and the other generator would otherwise have its two gradients added by autograd's
+    accumulation (a torch kernel)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view(x.shape), x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        if g1.dtype != torch.float32 or g2.dtype != torch.float32 or g1.data_ptr() % 16 or g2.data_ptr() % 16:
+            return g1 + g2
+        return get_ops().sum2(g1, g2)
+
+
+def fanout(x):
+    """(x, x) for two consumers that both send a gradient back"""
+    return _Fanout.apply(x) if (torch.is_tensor(x) and x.requires_grad) else (x, x)

@@ -665,9 +665,7 @@ class NativeNet:
                         gh_ = grad.half(h) if tw is not None else grad
                         dyh = dy[h * Nh:(h + 1) * Nh]
                         if sp.wfold == "out":   # channels [0, cout) of dy are the dw = 0 slice = the plain output gradient
-                            tmp = torch.zeros(sp.cout_p, dtype=torch.float32, device=dev)
-                            ops.bias_grad(dyh, sp.cout_p, tmp)
-                            gh_[self.b_off[i]:self.b_off[i] + sp.cout] += tmp[:sp.cout]
+                            ops.bias_grad(dyh, sp.cout, gh_[self.b_off[i]:self.b_off[i] + sp.cout])
                         else:
                             ops.bias_grad(dyh, sp.cout_p, gh_[self.b_off[i]:self.b_off[i] + sp.cout_p])
                 self.grad_dirty = True

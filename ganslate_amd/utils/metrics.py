@@ -2,7 +2,7 @@
 mean discriminator outputs and SSIM between real and cycle-reconstructed images, both on fused kernels."""
 import torch
 
-from ..nn.losses.functional import mean_nograd, ssim_distance_nograd
+from ..nn.losses.functional import mean_nograd, scalar_affine, ssim_distance_nograd
 
 
 class TrainingMetrics:
@@ -21,7 +21,9 @@ class TrainingMetrics:
         return mean_nograd(out) if out.dim() > 1 else out.detach()
 
     def get_SSIM_metric(self, input, target):
-        return 1 - ssim_distance_nograd(input, target) if self.ssim else None
+        if not self.ssim:
+            return None
+        return scalar_affine([ssim_distance_nograd(input, target)], [[-1.0]], [1.0])[0]      # 1 - distance, one launch
 
     def compute_metrics_D(self, discriminator, pred_real, pred_fake):
         return {f"{discriminator}_real": self.get_output_metric_D(pred_real),

@@ -209,6 +209,11 @@ int gs_bias_grad(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t 
 int64_t gs_bias_grad_ws_floats(int64_t pixels, int32_t C);
 int gs_bias_grad_ws(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, float* ws,
                     int64_t ws_floats, void* stream);
+/* the same over the first 8 channels of the window, adding only db[0 .. c_valid), c_valid <= 8: a bias whose channel count is
+ * not a multiple of 8 (the generators' 3-channel output conv, resnet2d.py:62-65) is followed by the next parameter in the flat
+ * gradient buffer. Workspace: gs_bias_grad_ws_floats(pixels, 8) */
+int gs_bias_grad_head_ws(const void* dy, int64_t pixels, int32_t cs, int32_t co, int32_t c_valid, float* db, float* ws,
+                         int64_t ws_floats, void* stream);
 
 /* ---- InstanceNorm + activation (nn.InstanceNorm2d eps=1e-5 affine=False, nn/utils.py:53-59) ------ */
 /* partial [N][slots][2][C] -> mean_rstd [N][2][C] */
@@ -406,6 +411,15 @@ int gs_l1(const float* a, const float* b, int64_t n, float* loss, float* grad_a,
           void* stream);
 /* out[0] = mean(x)  (train_metrics.py:27-33) */
 int gs_mean(const float* x, int64_t n, float* out, void* stream);
+/* out[r] = c[r] + sum_k m[r*K + k] * x[k][0], r < R <= 8, k < K <= 16: the scalar algebra of a recipe's loss assembly
+ * (lambda * (alpha * ssim + beta * l1), loss_real + loss_fake, the sum of the G losses: cyclegan_losses.py:21-32,70-90,
+ * cyclegan.py:150,182) as one launch. x = HOST array of K device pointers to fp32 scalars (a null entry counts as 0), m / c =
+ * host arrays (c may be null). The backward of a combination is the same call with the transposed matrix over the rows'
+ * upstream gradients. */
+int gs_scalar_affine(const float* const* x, int32_t K, const float* m, const float* c, int32_t R, float* out, void* stream);
+/* out = a + b over n floats (16-byte aligned): the join of the two gradients of a generated image that feeds a
+ * discriminator and the other generator (cyclegan.py:131-141) */
+int gs_sum2_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* SSIM distance of ganslate/nn/losses/utils/ssim.py:65-99 on (x+1)/2,(y+1)/2, window 11, sigma 1.5:
  * out[0] = mean(sqrt(relu(2 - S1 - S2))) over [N*C, H-10, W-10] */
 int gs_ssim_distance(const float* x, const float* y, int32_t NC, int32_t H, int32_t W, float* out,

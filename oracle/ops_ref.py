@@ -235,6 +235,20 @@ class RefOps(TwinSplit):
             return self.twin_bias_grad(dy, C_, db, cs=cs, co=co)
         db[:C_] += dy[..., co:co + C_].float().reshape(-1, C_).sum(0)
 
+    def scalar_affine(self, xs, rows, consts=None):
+        """gs_scalar_affine: [c_r + sum_k rows[r][k] * xs[k]] (None = 0), accumulated in k order in fp32"""
+        out = torch.zeros(len(rows), dtype=torch.float32)
+        for r, row in enumerate(rows):
+            acc = torch.tensor(float(consts[r]) if consts is not None else 0.0, dtype=torch.float32)
+            for w, x in zip(row, xs):
+                if x is not None:
+                    acc = acc + torch.tensor(float(w), dtype=torch.float32) * x.detach().float().reshape(())
+            out[r] = acc
+        return out
+
+    def sum2(self, a, b):
+        return a + b
+
     # ---- InstanceNorm + activation -------------------------------------------------------------------
     def inorm_finalize(self, partial, N, slots, Cc, hw, mean_rstd, eps=1e-5):
         p = partial.view(N, slots, 2, Cc).double().sum(1)

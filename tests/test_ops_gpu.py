@@ -896,6 +896,53 @@ def test_losses_and_metrics(hip_ops):
     close_f32(outs[1][2], outs[0][2], "mse grad", rel=1e-6)
 
 
+def test_scalar_algebra_of_the_loss_assembly(hip_ops):
+    """gs_scalar_affine (rows of weighted sums over device scalars, null entries, constants), its use as an autograd node
+    (forward values and the gradient each term receives, with one row unused) and gs_sum2_f32 (ragged length)."""
+    from ganslate_amd.nn.losses.functional import scalar_affine, scalar_sum
+    dev = hip_ops.device
+    vals = [0.731, -1.25, 3.5, 0.015625, 7.0]
+    rows = [[10.0 * 0.84, 10.0 * 0.16, 0, 0, 0], [0, 0, 1, 1, 0], [1, 1, 1, 1, 1]]
+    consts = [0.0, 1.0, -2.0]
+    outs = []
+    for ops, d in ((RefOps(), "cpu"), (hip_ops, dev)):
+        xs = [torch.tensor(v, device=d) for v in vals]
+        xs[3] = None
+        outs.append(ops.scalar_affine(xs, rows, consts).cpu())
+    assert torch.allclose(outs[1], outs[0], rtol=1e-6, atol=0), (outs[1], outs[0])
+    want = torch.tensor([c + sum(w * v for w, v, k in zip(r, vals, range(5)) if k != 3) for r, c in zip(rows, consts)])
+    assert torch.allclose(outs[1], want.float(), rtol=1e-6)
+
+    xs = [torch.tensor(v, device=dev, requires_grad=True) for v in vals]
+    a, b, c = scalar_affine(xs, rows)
+    (a * 1.0).backward(retain_graph=True)              # only row 0 sends a gradient
+    assert [None if x.grad is None else round(x.grad.item(), 5) for x in xs] == [8.4, 1.6, 0.0, 0.0, 0.0]
+    for x in xs:
+        x.grad = None
+    (scalar_sum([a, c]) + b).backward()
+    got = [x.grad.item() for x in xs]
+    assert got == pytest.approx([9.4, 2.6, 2.0, 2.0, 1.0], rel=1e-6)
+    assert a.item() == pytest.approx(8.4 * 0.731 - 1.6 * 1.25, rel=1e-6)
+
+    g = torch.Generator().manual_seed(3)
+    u, v = torch.randn(8 * 3 * 33 * 31 + 3, generator=g), torch.randn(8 * 3 * 33 * 31 + 3, generator=g)
+    assert torch.equal(hip_ops.sum2(u.to(dev), v.to(dev)).cpu(), u + v)
+
+
+def test_bias_gradient_of_a_channel_head(hip_ops):
+    """gs_bias_grad_head_ws: the bias of a 3-channel (and a 12-channel) layer accumulates into exactly that many floats"""
+    g = torch.Generator().manual_seed(4)
+    dy = torch.randn(2, 40, 24, 16, generator=g).bfloat16()
+    for cout, co in ((3, 0), (12, 0), (5, 8)):
+        outs = []
+        for ops, dev in ((RefOps(), "cpu"), (hip_ops, hip_ops.device)):
+            db = torch.full((cout + 4,), 0.5, device=dev)
+            ops.bias_grad(dy.to(dev), cout, db[:cout], co=co)
+            outs.append(db.cpu())
+        assert torch.equal(outs[1][cout:], torch.full((4,), 0.5)), "wrote past the bias"
+        close_f32(outs[1], outs[0], f"bias head {cout}", rel=1e-5)
+
+
 @pytest.mark.parametrize("mode", ["lsgan", "vanilla", "wgangp", "nonsaturating"])
 @pytest.mark.parametrize("real", [True, False])
 def test_adversarial_objectives(hip_ops, mode, real):
