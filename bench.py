@@ -496,12 +496,14 @@ def main():
             # the optimiser graph that the stream spends inside RCCL (rank 0's view)
             out["exposed_allreduce_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in rt) / max(len(rt), 1), 3) \
                 if rt else None
-            out["ddp_path"] = (("one graph per iteration with the bucketed RCCL all-reduces captured inside it (overlapped "
-                                "with the remaining backward; GS_DDP_GRAPH_COLLECTIVES=1)")
+            out["ddp_path"] = (("graph(forward + backward with the bucketed RCCL all-reduces captured inside it, overlapped "
+                                "with the remaining backward) | graph(Adam)")
                                if getattr(model, "_graph_collectives", False) else
                                ("graph(forward + backward) | one RCCL all-reduce per network on the flat gradient | "
                                 "graph(Adam)")) if graphed else \
                 "launch by launch: bucketed all-reduce overlapped with the last backward pass"
+            # both forms were built and compared on the second iteration (BaseGAN._ddp_self_check); None: a form was forced
+            out["ddp_self_check"] = getattr(model, "ddp_self_check", None)
         if timing is not None:
             res = ops.kernel_timing_result()
             imgs = ops.kernel_timing_images()                    # images per launch: a twin launch covers both generators

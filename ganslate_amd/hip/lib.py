@@ -175,6 +175,16 @@ _PROTOS = {
     "gs_scalar_affine": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32,
                                    C.c_void_p, C.c_void_p]),
     "gs_sum2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gs_tap_gather": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                C.c_void_p]),
+    "gs_tap_scatter_add": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gs_tap_rows_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gs_zero_bytes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "gs_image_tap_gather": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p]),
+    "gs_image_tap_scatter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     "gs_bias_grad_head_ws": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_void_p]),
     "gs_ssim_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

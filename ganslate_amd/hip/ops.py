@@ -674,6 +674,52 @@ class HipOps(TwinSplit):
         L.check(self.lib.gs_scalar_affine(px, K, m, c, R, _ptr(out), _stream()), "gs_scalar_affine")
         return out
 
+    # ---- feature taps (CUT) ------------------------------------------------------------------------------------
+    def tap_gather(self, src, pid, c):
+        """src [n, ..., cs] NHWC activations, pid int64 [P] flat pixel ids -> fp32 [n, P, c]"""
+        n, cs = src.shape[0], src.shape[-1]
+        pid = pid.contiguous()
+        out = torch.empty((n, pid.numel(), c), dtype=torch.float32, device=self.device)
+        L.check(self.lib.gs_tap_gather(_ptr(src), n, src.numel() // (n * cs), cs, _ptr(pid), pid.numel(), c, _ptr(out),
+                                       _stream()), "gs_tap_gather")
+        return out
+
+    def tap_scatter_add(self, dst, pid, g, W, f0=0):
+        """dst [n, Hp, Wp, cs] (a gradient on the domain padded by f0) += g [n, P, c] at the unpadded pixels pid"""
+        n, cs = dst.shape[0], dst.shape[-1]
+        pid, g = pid.contiguous(), g.contiguous().float()
+        L.check(self.lib.gs_tap_scatter_add(_ptr(dst), n, dst.numel() // (n * cs), cs, _ptr(pid), pid.numel(), g.shape[-1], W,
+                                            dst.shape[-2], f0, _ptr(g), _stream()), "gs_tap_scatter_add")
+
+    def tap_rows_sum(self, g, db):
+        g = g.contiguous().float()
+        L.check(self.lib.gs_tap_rows_sum(_ptr(g), g.numel() // g.shape[-1], g.shape[-1], _ptr(db), _stream()),
+                "gs_tap_rows_sum")
+
+    def zeros_like_act(self, t):
+        out = torch.empty_like(t)
+        nbytes = out.numel() * out.element_size()
+        if nbytes % 16 or out.data_ptr() % 16:
+            return out.zero_()
+        L.check(self.lib.gs_zero_bytes(_ptr(out), nbytes, _stream()), "gs_zero_bytes")
+        return out
+
+    def image_tap_gather(self, x, pid, pad):
+        N, Cc, H, W = x.shape
+        pid = pid.contiguous()
+        out = torch.empty((N, pid.numel(), Cc), dtype=torch.float32, device=self.device)
+        L.check(self.lib.gs_image_tap_gather(_ptr(x), N, Cc, H, W, pad, _ptr(pid), pid.numel(), _ptr(out), _stream()),
+                "gs_image_tap_gather")
+        return out
+
+    def image_tap_scatter(self, g, pid, shape, pad):
+        N, Cc, H, W = shape
+        pid, g = pid.contiguous(), g.contiguous().float()
+        gx = torch.empty(shape, dtype=torch.float32, device=self.device)
+        L.check(self.lib.gs_image_tap_scatter(_ptr(g), N, Cc, H, W, pad, _ptr(pid), pid.numel(), _ptr(gx), _stream()),
+                "gs_image_tap_scatter")
+        return gx
+
     def sum2(self, a, b):
         out = torch.empty_like(a)
         L.check(self.lib.gs_sum2_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "gs_sum2_f32")

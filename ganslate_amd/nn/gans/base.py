@@ -252,11 +252,18 @@ class BaseGAN(ABC):
     def _capture_step(self):
         """Record this iteration's launches (capture does not execute them), then run it as the first replay.
 
-        Data-parallel runs: collectives stay outside the graphs. The optimisers' step() calls made by the recipe are held
-        back while the first graph records forward, backward and everything else; the flat gradient of every network is
-        then all-reduced launch by launch (one collective per network, RCCL's own stream), and a second graph holds the
-        held-back Adam launches (the 1/world factor is folded into them). Nothing in an iteration reads the updated
-        weights before its end, so moving the updates behind the last backward pass changes no arithmetic."""
+        Data-parallel runs: the optimisers' step() calls made by the recipe are held back while the first graph records
+        forward, backward and everything else, and a second graph holds the held-back Adam launches (the 1/world factor
+        is folded into them). Nothing in an iteration reads the updated weights before its end, so moving the updates
+        behind the last backward pass changes no arithmetic. The gradient reduction comes in two forms:
+          "between"  collectives stay outside the graphs: the flat gradient of every network is all-reduced launch by
+                     launch between the two graphs (one collective per network on RCCL's own stream, not overlapped);
+          "captured" the bucketed all-reduces the executors issue during their last backward pass are CAPTURED into the
+                     first graph (RCCL's kernels become nodes on their own branch, joined by the event wait in
+                     finish_grad_reduction), so a replayed iteration overlaps the reduction of the upper buckets and of
+                     the discriminators with the remaining backward work.
+        GS_DDP_GRAPH_COLLECTIVES=0 / 1 forces one of them. Default: BOTH are built and checked against each other on this
+        very iteration before either is trusted (_ddp_self_check) — "captured" is kept when the two agree."""
         self.logger.info("capturing the training step into a hipGraph (GS_STEP_GRAPH=0 runs it launch by launch, "
                          "GS_SIDE_STREAM=0 on one stream)")
         self._static_inputs = {n: self.visuals[n].clone() for n in self.input_visuals}
@@ -264,18 +271,27 @@ class BaseGAN(ABC):
         self._set_external_host_state(True)
         self._prepare_host_state()
         dp_nets = self._data_parallel_nets()
-        # GS_DDP_GRAPH_COLLECTIVES=1 (opt-in, verified with a 1-rank RCCL group only): the bucketed all-reduces the executors
-        # issue during their last backward pass are CAPTURED into the step graph (RCCL's kernels become nodes on their own
-        # branch, joined by the event wait in finish_grad_reduction), so a replayed iteration overlaps the reduction of the
-        # upper buckets and of the discriminators with the remaining backward work, and the step stays one graph.
-        self._graph_collectives = bool(dp_nets) and os.environ.get("GS_DDP_GRAPH_COLLECTIVES", "0") == "1"
-        if self._graph_collectives:
-            dp_nets = []
+        want = os.environ.get("GS_DDP_GRAPH_COLLECTIVES", "auto") if dp_nets else "none"
+        if want in ("0", "1", "none"):
+            form = {"0": "between", "1": "captured", "none": None}[want]
+            chosen = self._capture_graphs(dp_nets, form)
+        else:
+            chosen = self._ddp_self_check(dp_nets)
+        self._graph, self._graph_update, self._graph_out, form = chosen
+        self._graph_collectives = form == "captured"
+        self._reduced_nets = dp_nets if form == "between" else []
+        self._graph_shapes = self._input_shapes()
+        self.visuals.update(self._graph_out[0]); self.losses.update(self._graph_out[1])
+        self.metrics.update(self._graph_out[2])
+        self._replay()
+
+    def _capture_graphs(self, dp_nets, form):
+        """-> (step graph, update graph or None, (visuals, losses, metrics) of the recorded step, form)"""
         pending = [] if dp_nets else None
         for optim in self.optimizers.values():
             optim.deferred_to = pending
         for net in dp_nets:
-            net.external_reduce = True
+            net.external_reduce = form == "between"
         torch.cuda.synchronize()
         graph, update = torch.cuda.CUDAGraph(), None
         # No garbage collection while the capture is open: a cyclic-garbage sweep that happens to run between two launches
@@ -289,12 +305,16 @@ class BaseGAN(ABC):
         try:
             # data parallel: RCCL's watchdog thread may poll events of earlier collectives while this thread captures;
             # only this thread's calls are policed then
-            mode = "thread_local" if (dp_nets or self._graph_collectives) else "global"
+            mode = "thread_local" if dp_nets else "global"
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 self._eager_step()
                 for net in dp_nets:
                     net.flush_deferred_wgrads()
+                    if form == "captured":       # buckets the backward passes did not reach, and the join of all of them
+                        net.finish_grad_reduction()
             if dp_nets:
+                for net in dp_nets:              # (reduced already, one way or the other: the update only scales)
+                    net.external_reduce = True
                 update = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(update, capture_error_mode=mode):
                     for optim in pending:
@@ -314,10 +334,57 @@ class BaseGAN(ABC):
             for net in dp_nets:
                 net.external_reduce = False
         streams.release_events()
-        self._graph, self._graph_update, self._graph_shapes = graph, update, self._input_shapes()
-        self._reduced_nets = dp_nets
-        self._graph_out = (dict(self.visuals), dict(self.losses), dict(self.metrics))
-        self._replay()
+        return graph, update, (dict(self.visuals), dict(self.losses), dict(self.metrics)), form
+
+    def _ddp_self_check(self, dp_nets):
+        """Build both reduction forms and make the first multi-GPU run explain itself: each form's step graph is replayed
+        once on THIS iteration's inputs with the weights frozen (the update graphs are not replayed; image pools are put
+        back, gradients zeroed in between), and the reduced flat gradients must agree — between the forms (bit for bit up
+        to 2 ranks, where a + b has one summation order; to 1e-5 of the largest gradient beyond, where a bucket's ring
+        order differs from the whole buffer's) and between the ranks (bit for bit: an all-reduce hands every rank the same
+        sums). All ranks take the same decision; the outcome is logged and kept in `ddp_self_check`."""
+        import torch.distributed as dist
+        group = dp_nets[0]._dist
+        world = dist.get_world_size(group)
+        forms = {"between": self._capture_graphs(dp_nets, "between"), "captured": self._capture_graphs(dp_nets, "captured")}
+        pools = [(p, p.images.clone()) for p in self._step_pools() if getattr(p, "images", None) is not None]
+        grads = {}
+        for name, (graph, _, _, _) in forms.items():
+            for net in dp_nets:
+                net.master.grad.zero_()
+            graph.replay()
+            if name == "between":
+                for net in dp_nets:
+                    dist.all_reduce(net.master.grad, op=dist.ReduceOp.SUM, group=net._dist)
+            grads[name] = [net.master.grad.clone() for net in dp_nets]
+            for pool, saved in pools:
+                pool.images.copy_(saved)
+        for net in dp_nets:
+            net.master.grad.zero_()
+        worst, scale = 0.0, 0.0
+        for ga, gb in zip(grads["between"], grads["captured"]):
+            worst = max(worst, (ga - gb).abs().max().item())
+            scale = max(scale, ga.abs().max().item())
+        agree = worst == 0.0 if world <= 2 else worst <= 1e-5 * scale
+        finite = all(torch.isfinite(g).all().item() for g in grads["captured"]) and scale > 0.0
+        # the same sums on every rank: compare a checksum of the captured form's gradients across the group
+        chk = torch.stack([g.double().sum() for g in grads["captured"]] + [g.double().abs().sum() for g in grads["captured"]])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        ranks_agree = bool(torch.equal(lo, hi))
+        verdict = torch.tensor([1.0 if (agree and finite and ranks_agree) else 0.0], device=chk.device)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+        ok = verdict.item() == 1.0
+        self.ddp_self_check = {"world": world, "forms_agree": bool(agree), "max_abs_diff": worst, "max_abs_grad": scale,
+                               "ranks_agree": ranks_agree, "finite": bool(finite), "kept": "captured" if ok else "between"}
+        (self.logger.info if ok else self.logger.warning)(
+            f"data-parallel self-check over {world} rank(s): forms {'agree' if agree else 'DISAGREE'} (max |diff| {worst:.3e} "
+            f"of max |grad| {scale:.3e}), ranks {'agree' if ranks_agree else 'DISAGREE'} -> keeping the "
+            f"{'captured (overlapped) collectives' if ok else 'all-reduce between the two graphs'}")
+        keep = forms.pop("captured" if ok else "between")
+        forms.clear()
+        return keep
 
     def backward(self, loss, optimizer, retain_graph=False, loss_id=0):
         # the root gradient is a constant kept for the run (loss.backward() alone fills a fresh one every time)

@@ -18,7 +18,7 @@ import torch
 
 from .... import configs
 from ...losses.adversarial_loss import AdversarialLoss
-from ...losses.functional import scalar_affine, scalar_sum
+from ...losses.functional import fanout, scalar_affine, scalar_sum
 from ...optim import NativeAdam
 from ..base import BaseGAN
 
@@ -152,6 +152,10 @@ class CUT(BaseGAN):
     def backward_G_and_mlp(self):
         real_A, real_B = self.visuals["real_A"], self.visuals["real_B"]
         fake_B, idt_B = self.visuals["fake_B"], self.visuals["idt_B"]
+        if self.lambda_adv > 0 and self.lambda_nce > 0:
+            fake_B, fake_B_nce = fanout(fake_B)     # D and the encoder both send a gradient back: joined by gs_sum2_f32
+        else:
+            fake_B_nce = fake_B
         # every term with its weight in the combined loss (cut.py:193-227: adversarial * lambda_adv, and with the identity
         # term (1 - lambda_nce_idt) * NCE + lambda_nce_idt * NCE_idt); the logged losses and the combined one are rows of
         # ONE launch (losses/functional.py:scalar_affine)
@@ -165,9 +169,9 @@ class CUT(BaseGAN):
             with_idt = self.lambda_nce_idt > 0
             if with_idt and self._batched(self.networks["G"]):
                 # both PatchNCE terms out of ONE encoder pass over (fake_B, idt_B); ids drawn in the reference's order
-                nce, nce_idt = self._calculate_nce_losses([(real_A, fake_B), (real_B, idt_B)])
+                nce, nce_idt = self._calculate_nce_losses([(real_A, fake_B_nce), (real_B, idt_B)])
             else:
-                nce = self._calculate_nce_loss(real_A, fake_B)
+                nce = self._calculate_nce_loss(real_A, fake_B_nce)
                 nce_idt = self._calculate_nce_loss(real_B, idt_B) if with_idt else None
             xs.append(nce)
             combined.append(1 - self.lambda_nce_idt if with_idt else 1.0)

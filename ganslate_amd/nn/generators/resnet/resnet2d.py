@@ -5,6 +5,8 @@ InstanceNorm2d(affine=False) + ReLU; ConvTranspose2d(3, s2, p1, op1) up-sampling
 import os
 from dataclasses import dataclass
 
+import torch
+
 from .... import configs
 from ...native.net import NativeNet, Node
 from ...native.spec import ConvSpec
@@ -53,6 +55,21 @@ def resnet_nodes(in_channels, out_channels, use_bias, n, dims=2, wfold=None):
     return nodes
 
 
+class _ImageTapFn(torch.autograd.Function):
+    """features of the ReflectionPad2d(pad) output of an fp32 NCHW image at sampled flat pixel ids -> [N, P, C]
+    (gs_image_tap_gather); backward scatters through the same reflection map (gs_image_tap_scatter)"""
+
+    @staticmethod
+    def forward(ctx, x, pid, pad, ops):
+        x = x.contiguous()
+        ctx.ops, ctx.pid, ctx.pad, ctx.shape = ops, pid, pad, tuple(x.shape)
+        return ops.image_tap_gather(x.detach(), pid, pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.ops.image_tap_scatter(g, ctx.pid, ctx.shape, ctx.pad), None, None, None
+
+
 class Resnet2D(NativeNet):
 
     def __init__(self, in_channels, out_channels, norm_type, n_residual_blocks=9):
@@ -88,7 +105,6 @@ class Resnet2D(NativeNet):
         over this very tensor is still alive (fake_B = G(real_A) of the same iteration) they are read out of ITS activations
         instead of running the encoder again; else the encoder runs without being recorded."""
         import torch
-        import torch.nn.functional as F
         taps, where = [], []
         for e in layers:
             tap, _ = self.encoder_tap(e)
@@ -96,6 +112,10 @@ class Resnet2D(NativeNet):
             if tap[0] != "pad":
                 taps.append(tap)
         tap_ids = [i for i, t in zip(ids, where) if t[0] != "pad"]
+        x_pad = x
+        if taps and len(taps) < len(where) and not detached:      # the image feeds the encoder AND the padded-image level
+            from ...losses.functional import fanout
+            x_pad, x = fanout(x)
         if detached and taps:
             xc = x.contiguous().float()
             rec = self.recorded_pass(xc)
@@ -108,15 +128,14 @@ class Resnet2D(NativeNet):
             feats, nb = [], xc.shape[0]
             for (kind, node), pid in zip(taps, tap_ids):
                 src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
-                feats.append(src[n0:n0 + nb].view(nb, -1, src.shape[-1])[:, pid, :self.nodes[node].spec.cout].float())
+                feats.append(self.ops.tap_gather(src[n0:n0 + nb], pid, self.nodes[node].spec.cout))
             native = iter(feats)
         else:
             native = iter(self.forward_taps(x, taps, tap_ids)) if taps else iter(())
         out = []
         for tap, pid in zip(where, ids):
-            if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output: plain indexing of the boundary image
-                xp = F.pad(x.float(), (3, 3, 3, 3), mode="reflect")
-                out.append(xp.permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :])
+            if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output of the boundary image
+                out.append(_ImageTapFn.apply(x_pad.float(), pid, 3, self.ops))
             else:
                 out.append(next(native))
         return out
@@ -124,22 +143,25 @@ class Resnet2D(NativeNet):
     def extract_patch_features_parts(self, xs, layers, ids_per_part):
         """extract_patch_features for several batches in ONE encoder pass, each with its own pixel ids (CUT's target
         patches of fake_B and idt_B) -> per batch a list of [N_p, P, C] fp32"""
-        import torch.nn.functional as F
         taps, where = [], []
         for e in layers:
             tap, _ = self.encoder_tap(e)
             where.append(tap)
             if tap[0] != "pad":
                 taps.append(tap)
+        xs_pad = xs
+        if taps and len(taps) < len(where):      # every image feeds the encoder AND the padded-image level
+            from ...losses.functional import fanout
+            pairs = [fanout(x) for x in xs]
+            xs_pad, xs = [p[0] for p in pairs], [p[1] for p in pairs]
         native = self.forward_taps_parts(xs, taps, [[i for i, t in zip(ids, where) if t[0] != "pad"]
                                                      for ids in ids_per_part]) if taps else [() for _ in xs]
         out = []
-        for x, ids, nat in zip(xs, ids_per_part, native):
+        for x, ids, nat in zip(xs_pad, ids_per_part, native):
             nat, feats = iter(nat), []
             for tap, pid in zip(where, ids):
-                if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output: plain indexing of the boundary image
-                    xp = F.pad(x.float(), (3, 3, 3, 3), mode="reflect")
-                    feats.append(xp.permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :])
+                if tap[0] == "pad":      # layer 0 = the ReflectionPad2d(3) output of the boundary image
+                    feats.append(_ImageTapFn.apply(x.float(), pid, 3, self.ops))
                 else:
                     feats.append(next(nat))
             out.append(feats)

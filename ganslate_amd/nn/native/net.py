@@ -542,8 +542,8 @@ class NativeNet:
     def _backward(self, s: _Saved, g_img, need_input_grad: bool, want_w: bool, start=None, inj_x=None, inj_y=None,
                   tw=None):
         """g_img = gradient of the output image, or None for a partial pass that starts at node `start` and is driven
-        only by injected gradients: inj_x[i] / inj_y[i] = dense gradients w.r.t. the output / raw conv output of
-        node i (feature taps of CUT's PatchNCE loss).
+        only by injected gradients: inj_x[i] / inj_y[i] = sparse gradients [(first image, images, pixel ids [P], g [images,
+        P, c])] w.r.t. the output / raw conv output of node i (feature taps of CUT's PatchNCE loss).
         tw: the pass recorded by _forward(..., tw) — g_img holds one gradient per input part (None = that part's output took
         no part in the loss), the gradients of images [N/2, N) go to tw's flat gradient buffer, and the input gradients come
         back as a tuple, one per part."""
@@ -585,13 +585,12 @@ class NativeNet:
         more_passes = want_w and self._fw_pending > 0 and start is None
         for i in range(last, -1, -1):
             nd, lw, sp = nodes[i], lows[i], nodes[i].spec
-            if i in inj_x:            # tapped feature gradient joins the gradient of this node's output
-                if pending is None:
-                    pending = (inj_x[i], 0, None, "reflect")
-                else:
-                    f0 = pending[1]
-                    inner = (slice(None),) + tuple(slice(f0, f0 + n) for n in lw.out_dims)
-                    pending[0][inner] += inj_x[i]   # the pad adjoint is linear
+            if i in inj_x:            # tapped feature gradients join the gradient of this node's output (the pad adjoint is
+                if pending is None:   # linear: they are added on the padded domain at their own pixels)
+                    pending = (ops.zeros_like_act(s.acts[i + 1]), 0, None, "reflect")
+                assert len(lw.out_dims) == 2, "feature taps: 2-D networks"
+                for n0, np_, pid, g in inj_x[i]:
+                    ops.tap_scatter_add(pending[0][n0:n0 + np_], pid, g, lw.out_dims[-1], f0=pending[1])
             if nd.attn:
                 # the gradient arrives w.r.t. the block's output; the block's backward turns it into the gradient w.r.t. this
                 # node's own output (and adds the block's parameter gradients)
@@ -638,11 +637,15 @@ class NativeNet:
             if need_total:
                 skip[nd.res] = total
             if i in inj_y:
-                dy = dy + inj_y[i]
-                if want_w and sp.bias and nd.norm:
-                    # a feature tapped from the RAW conv output (CUT's nce layer 4, cut.py:297-312) sees the bias: the norm's
-                    # reduction sums above give the (zero) bias gradient of the path through the norm only
-                    ops.bias_grad(inj_y[i], sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
+                assert tw is None, "feature taps: single-network passes"
+                if dy is g_pad or dy is total:      # (shared with the skip path: the taps go into a copy)
+                    dy = dy.clone()
+                for n0, np_, pid, g in inj_y[i]:
+                    ops.tap_scatter_add(dy[n0:n0 + np_], pid, g, lw.out_dims[-1])
+                    if want_w and sp.bias and nd.norm:
+                        # a feature tapped from the RAW conv output (CUT's nce layer 4, cut.py:297-312) sees the bias: the
+                        # norm's reduction sums above give the (zero) bias gradient of the path through the norm only
+                        ops.tap_rows_sum(g, grad[self.b_off[i]:self.b_off[i] + sp.cout])
             # ---- parameter gradients ---------------------------------------------------------------------------------
             if want_w:
                 dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
@@ -835,8 +838,7 @@ class _TapFn(torch.autograd.Function):
         for np_, pids in zip(ctx.sizes, ids):
             for (kind, node), pid in zip(taps, pids):
                 src = saved.ys[node] if kind == "y" else saved.acts[node + 1]
-                c = net.nodes[node].spec.cout
-                outs.append(src[n0:n0 + np_].view(np_, -1, src.shape[-1])[:, pid, :c].float())
+                outs.append(net.ops.tap_gather(src[n0:n0 + np_], pid, net.nodes[node].spec.cout))
             n0 += np_
         return tuple(outs)
 
@@ -849,15 +851,8 @@ class _TapFn(torch.autograd.Function):
         k, n0 = len(ctx.taps), 0
         for p, (np_, pids) in enumerate(zip(ctx.sizes, ctx.ids)):
             for (kind, node), pid, g in zip(ctx.taps, pids, grads[p * k:(p + 1) * k]):
-                if g is None:
-                    continue
-                src = s.ys[node] if kind == "y" else s.acts[node + 1]
-                dense = inj[kind].get(node)
-                if dense is None:
-                    dense = torch.zeros_like(src)
-                    inj[kind][node] = dense
-                c = net.nodes[node].spec.cout
-                dense[n0:n0 + np_].view(np_, -1, src.shape[-1])[:, pid, :c] += g.to(dense.dtype)
+                if g is not None:       # sparse: (first image, images, pixel ids, [images, P, c] gradient)
+                    inj[kind].setdefault(node, []).append((n0, np_, pid, g))
             n0 += np_
         if ctx.want_w:      # passes that write parameter gradients are ordered per network
             net._order_backward_begin()

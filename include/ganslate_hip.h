@@ -476,6 +476,28 @@ int gs_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float*
  * the host refreshes the learning rate and bias corrections between replays. */
 int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev,
                      float grad_scale, int32_t zero_grad, void* stream);
+/* ---- feature taps of CUT's PatchNCE loss (ganslate/nn/gans/unpaired/cut.py:229-312; FeaturePatchMLP.forward :262-277 reads
+ * `feat.permute(0, 2, 3, 1).flatten(1, 2)[:, patch_id, :]` per level) ------------------------------------------------------------
+ * ids_dev: int64 device array of P DISTINCT flat pixel indices (the head of a torch.randperm), shared by the n images.
+ * gs_tap_gather: out[n][p][ch] = src[n][ids[p]][ch] as fp32, ch < c; src = n images of `pixels` NHWC bf16 pixels, cs channels.
+ * gs_tap_scatter_add: the backward of it into a gradient buffer on a domain padded by f0: with (y, x) = divmod(ids[p], W),
+ *   dst[n][(y + f0) * Wp + x + f0][ch] += g[n][p][ch] (bf16 storage, fp32 add); `pixels` = pixels per image of dst.
+ * gs_tap_rows_sum: db[ch] += sum over rows of g[rows][c] in a fixed order (bias gradient seen by a tap of a raw conv output).
+ * gs_zero_bytes: zero a 16-byte aligned buffer (the start of a gradient that only taps feed).
+ * gs_image_tap_gather / _scatter: nce layer 0 is the ReflectionPad2d(pad) output of the fp32 NCHW image (resnet2d.py:24):
+ *   out[n][p][ch] = x[n][ch][r(yp - pad)][r(xp - pad)], (yp, xp) = divmod(ids[p], W + 2 pad), r = reflection; the scatter
+ *   zeroes gx [N][C][H][W] and adds g through the same map (fp32 atomics where samples reflect onto one pixel). */
+int gs_tap_gather(const void* src, int32_t n, int64_t pixels, int32_t cs, const int64_t* ids_dev, int32_t P, int32_t c, float* out,
+                  void* stream);
+int gs_tap_scatter_add(void* dst, int32_t n, int64_t pixels, int32_t cs, const int64_t* ids_dev, int32_t P, int32_t c, int32_t W,
+                       int32_t Wp, int32_t f0, const float* g, void* stream);
+int gs_tap_rows_sum(const float* g, int64_t rows, int32_t c, float* db, void* stream);
+int gs_zero_bytes(void* p, int64_t bytes, void* stream);
+int gs_image_tap_gather(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t pad, const int64_t* ids_dev, int32_t P,
+                        float* out, void* stream);
+int gs_image_tap_scatter(const float* g, int32_t N, int32_t C, int32_t H, int32_t W, int32_t pad, const int64_t* ids_dev,
+                         int32_t P, float* gx, void* stream);
+
 /* ImagePool.query (ganslate/data/utils/image_pool.py:31-60) with the host's coin flips uploaded as code_dev[B]:
  * < 0 pass image b through; slot: store image b in `slot`, return it (pool filling); slot | 0x40000000: return the
  * image stored in `slot`, store image b there. Images of a batch are handled in order (same-slot draws chain like the

@@ -249,6 +249,35 @@ class RefOps(TwinSplit):
     def sum2(self, a, b):
         return a + b
 
+    # ---- feature taps (CUT): torch indexing, as the reference does it (cut.py:262-277) -----------------------------
+    def tap_gather(self, src, pid, c):
+        n = src.shape[0]
+        return src.reshape(n, -1, src.shape[-1])[:, pid, :c].float()
+
+    def tap_scatter_add(self, dst, pid, g, W, f0=0):
+        n, Wp = dst.shape[0], dst.shape[-2]
+        y, x = torch.div(pid, W, rounding_mode="floor"), pid % W
+        flat = (y + f0) * Wp + x + f0
+        view = dst.view(n, -1, dst.shape[-1])
+        view[:, flat, :g.shape[-1]] = (view[:, flat, :g.shape[-1]].float() + g.float()).to(dst.dtype)
+
+    def tap_rows_sum(self, g, db):
+        db[:g.shape[-1]] += g.float().reshape(-1, g.shape[-1]).sum(0)
+
+    def zeros_like_act(self, t):
+        return torch.zeros_like(t)
+
+    def image_tap_gather(self, x, pid, pad):
+        xp = torch.nn.functional.pad(x.float(), (pad,) * 4, mode="reflect")
+        return xp.permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :]
+
+    def image_tap_scatter(self, g, pid, shape, pad):
+        with torch.enable_grad():       # (called from inside a backward pass)
+            x = torch.zeros(shape, dtype=torch.float32, requires_grad=True)
+            out = torch.nn.functional.pad(x, (pad,) * 4, mode="reflect").permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :]
+            gx, = torch.autograd.grad(out, x, g.float())
+        return gx
+
     # ---- InstanceNorm + activation -------------------------------------------------------------------
     def inorm_finalize(self, partial, N, slots, Cc, hw, mean_rstd, eps=1e-5):
         p = partial.view(N, slots, 2, Cc).double().sum(1)

@@ -19,8 +19,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch):
+@pytest.mark.parametrize("reduction", ["0", "auto"])
+def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch, reduction):
+    """reduction "0": the all-reduce between the two graphs; "auto" (the default): both forms are built, replayed once with
+    frozen weights (image pools restored in between) and compared, and the captured collectives are kept"""
     import datetime
+    monkeypatch.setenv("GS_DDP_GRAPH_COLLECTIVES", reduction)
     import torch.distributed as dist
     c = dict(load_golden_steps()["c64_default"]["config"])
     c["pool_size"] = 3
@@ -36,7 +40,13 @@ def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch):
         ddp = build_product_cyclegan(c, frozen)
         assert all(net._dist is not None for net in ddp.networks.values())
         got = _run(ddp, c, 5)
-        assert ddp._graph is not None and ddp._graph_update is not None and len(ddp._reduced_nets) == 4
+        assert ddp._graph is not None and ddp._graph_update is not None
+        if reduction == "0":
+            assert len(ddp._reduced_nets) == 4 and not ddp._graph_collectives
+        else:
+            chk = ddp.ddp_self_check
+            assert chk["forms_agree"] and chk["ranks_agree"] and chk["max_abs_diff"] == 0.0 and chk["max_abs_grad"] > 0.0
+            assert chk["kept"] == "captured" and ddp._graph_collectives and ddp._reduced_nets == []
         for s in range(5):
             for k, v in want[s][0].items():
                 assert got[s][0][k] == pytest.approx(v, rel=1e-4, abs=1e-6), (s, k)
@@ -66,8 +76,9 @@ def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch):
 # ---- two ranks over RCCL (runs the moment the box has >= 2 GPUs; the 1-GPU pool skips it) -----------------------------
 DDP_PATHS = {
     "launch_by_launch": {"GS_STEP_GRAPH": "0"},                     # bucketed all-reduce overlapped with the last backward pass
-    "two_graphs": {},                                              # graph | one all-reduce per network | graph (default)
+    "two_graphs": {"GS_DDP_GRAPH_COLLECTIVES": "0"},               # graph | one all-reduce per network | graph
     "captured_collectives": {"GS_DDP_GRAPH_COLLECTIVES": "1"},     # the bucketed all-reduces captured inside the step graph
+    "self_check": {},                                              # default: both built and compared, captured kept
 }
 
 
@@ -104,9 +115,12 @@ def _rccl_worker(rank, world, port, out_dir, path):
     if path == "launch_by_launch":
         assert model._graph is None
     elif path == "two_graphs":
-        assert model._graph is not None and model._graph_update is not None
+        assert model._graph is not None and model._graph_update is not None and not model._graph_collectives
     else:
-        assert model._graph is not None and model._graph_update is None and model._graph_collectives
+        assert model._graph is not None and model._graph_update is not None and model._graph_collectives
+        if path == "self_check":
+            chk = model.ddp_self_check
+            assert chk["world"] == world and chk["forms_agree"] and chk["ranks_agree"] and chk["kept"] == "captured", chk
     # (b) weights moving: four iterations on this rank's shard -> the replicas must stay identical bit for bit
     random.seed(c["seed"])
     live = build_product_cyclegan(c)
@@ -167,7 +181,7 @@ def _check_against_single_process(tmp_path, path, world):
 @pytest.mark.parametrize("path", list(DDP_PATHS))
 def test_data_parallel_paths_with_one_rank_over_rccl(hip_ops, tmp_path, path):
     """the worker of the 2-rank test below with a 1-rank RCCL group in a child process (what this single-GPU pool can run):
-    every one of the three data-parallel paths goes through its collectives and must reproduce the single-process run"""
+    every one of the data-parallel paths goes through its collectives and must reproduce the single-process run"""
     import torch.multiprocessing as mp
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), path), nprocs=1, join=True)
     _check_against_single_process(tmp_path, path, 1)
@@ -191,8 +205,8 @@ def test_two_ranks_over_rccl_average_to_the_big_batch_gradient(hip_ops, tmp_path
 
 @pytest.mark.timeout(600)
 def test_captured_collectives_mode_single_rank(hip_ops):
-    """GS_DDP_GRAPH_COLLECTIVES=1 (opt-in): the bucketed RCCL all-reduces issued during the last backward pass are captured
-    INTO the step graph (one graph per iteration, reduction overlapped with the remaining backward). Run in a child
+    """GS_DDP_GRAPH_COLLECTIVES=1: the bucketed RCCL all-reduces issued during the last backward pass are captured
+    INTO the step graph (reduction overlapped with the remaining backward; the Adam launches are a second graph). Run in a child
     process with a hard timeout (a capture problem in RCCL must not take the test session down); with one rank the
     replayed iterations must equal the single-process run bit for bit."""
     import subprocess

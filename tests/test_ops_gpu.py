@@ -929,6 +929,40 @@ def test_scalar_algebra_of_the_loss_assembly(hip_ops):
     assert torch.equal(hip_ops.sum2(u.to(dev), v.to(dev)).cpu(), u + v)
 
 
+def test_feature_tap_kernels(hip_ops):
+    """gs_tap_gather / gs_tap_scatter_add / gs_tap_rows_sum / gs_image_tap_gather / gs_image_tap_scatter against the torch
+    indexing the reference uses (cut.py:262-277): gathers bit-exact, scatter-adds to one bf16 ulp of the sum, image scatter
+    to fp32 summation order (samples that reflect onto one pixel)."""
+    g = torch.Generator().manual_seed(21)
+    dev = hip_ops.device
+    ref = RefOps()
+    n, H, W, cs, c, P = 3, 20, 28, 136, 130, 97
+    src = torch.randn(n, H, W, cs, generator=g).bfloat16()
+    pid = torch.randperm(H * W, generator=g)[:P]
+    assert torch.equal(hip_ops.tap_gather(src.to(dev), pid.to(dev), c).cpu(), ref.tap_gather(src, pid, c))
+    for f0 in (0, 1):
+        dst = torch.randn(n, H + 2 * f0, W + 2 * f0, cs, generator=g).bfloat16()
+        gg = torch.randn(n, P, c, generator=g)
+        want = dst.clone()
+        ref.tap_scatter_add(want, pid, gg, W, f0=f0)
+        got = dst.clone().to(dev)
+        hip_ops.tap_scatter_add(got, pid.to(dev), gg.to(dev), W, f0=f0)
+        assert torch.equal(got.cpu(), want), f"scatter add f0={f0}"
+    db, db_ref = torch.full((c + 2,), 0.25), torch.full((c + 2,), 0.25)
+    ref.tap_rows_sum(gg, db_ref[:c])
+    dbd = db.to(dev)
+    hip_ops.tap_rows_sum(gg.to(dev), dbd[:c])
+    close_f32(dbd.cpu(), db_ref, "tap rows sum", rel=1e-5)
+    z = hip_ops.zeros_like_act(src.to(dev))
+    assert z.dtype == src.dtype and not z.any()
+    x = torch.randn(2, 3, 24, 40, generator=g)
+    pidp = torch.randperm(30 * 46, generator=g)[:256]
+    assert torch.equal(hip_ops.image_tap_gather(x.to(dev), pidp.to(dev), 3).cpu(), ref.image_tap_gather(x, pidp, 3))
+    gi = torch.randn(2, 256, 3, generator=g)
+    close_f32(hip_ops.image_tap_scatter(gi.to(dev), pidp.to(dev), tuple(x.shape), 3).cpu(),
+              ref.image_tap_scatter(gi, pidp, tuple(x.shape), 3), "image tap scatter", rel=1e-6)
+
+
 def test_bias_gradient_of_a_channel_head(hip_ops):
     """gs_bias_grad_head_ws: the bias of a 3-channel (and a 12-channel) layer accumulates into exactly that many floats"""
     g = torch.Generator().manual_seed(4)

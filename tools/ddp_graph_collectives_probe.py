@@ -11,7 +11,7 @@ dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29588", rank=0, wor
 os.environ["GS_FORCE_DDP"] = "1"; os.environ["GS_DDP_GRAPH_COLLECTIVES"] = "1"
 ddp = build_product_cyclegan(c)
 got = _run(ddp, c, 5)
-print("graph", ddp._graph is not None, "update graph", ddp._graph_update, "collectives captured", ddp._graph_collectives)
+print("graph", ddp._graph is not None, "update graph", ddp._graph_update is not None, "collectives captured", ddp._graph_collectives)
 ok = all(torch.equal(got[s][2], want[s][2]) and got[s][0] == want[s][0] for s in range(5))
 print("bitwise equal to single process:", ok)
 for s in range(5):
