@@ -187,89 +187,127 @@ __global__ __launch_bounds__(512) void hwgrad_kernel(const HWGradK p) {
 // workgroup's boxes. wgrad_kernel gathered the shifted operand once per tap from L2 — 470 MB of L2 -> LDS traffic for a
 // 100 MB layer, 115 / 69 us per launch at 130 / 218 TFLOP/s (profiles/r02_conv_table_v5.txt) — this form reads both operands
 // once per box.
+// Round 4: (a) every thread stages the same pieces of every box, so their decode (five integer divisions and three border
+// rules per 16-byte piece: ~900 VALU instructions per thread per box next to 56 MFMAs per wave) happens once per workgroup,
+// with the border-resolved source rows / columns in two small LDS tables as in hwgrad_wide; (b) the voxel pitch of both
+// tiles is padded by one 16-byte piece (80 / 144 B for 32 / 64 channels; the pad piece of the lane-linear LDS-DMA image
+// fetches the zero page) and a lane's two transpose reads take pixels 2 frr / 2 frr + 1 of its 8-pixel run instead of frr /
+// frr + 4: a 32-lane read then touches 2 runs x 4 rows x 8 banks = all 64 banks once (64 / 128-byte pitches with rows
+// frr: 2- to 4-way conflicts, 66 % of the kernel's LDS cycles, profiles/r03_trunk_pmc.txt). Boxes are 16 x 16 (launcher).
 template <int TMAX>
 __global__ __launch_bounds__(512) void hwgrad_ft_kernel(const HWGradK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* toff = reinterpret_cast<int*>(smem);        // [TMAX] halo-linear tap offsets
   const gs_wgrad_desc& d = p.d;
   const int np = p.phalves, nq = p.qchunks;        // 16-channel blocks of the dense / gathered side
-  const int APITCH = np * 32, GPITCH = nq * 32;    // bytes per pixel / voxel
+  const int NPP = np * 2 + 1, NQP = nq * 2 + 1;    // 16-byte pieces per pixel / voxel incl. the pad piece
+  const int APITCH = NPP * 16, GPITCH = NQP * 16;  // bytes per pixel / voxel
+  const int HV = p.HH * p.HW;
+  const int apieces = 256 * NPP, hpieces = HV * NQP;
+  const int abytes = (apieces * 16 + 1023) / 1024 * 1024, hbytes = (hpieces * 16 + 1023) / 1024 * 1024 + 1024;
   char* at = smem + 256;
-  char* halo = at + 256 * APITCH;
+  char* halo = at + abytes;
+  unsigned short* ytab = reinterpret_cast<unsigned short*>(halo + hbytes);
+  unsigned short* xtab = ytab + p.nbh * p.HH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < TMAX)
-    toff[tid] = tid < d.T ? (((int)d.dd[tid] - p.dmin) * p.HH + ((int)d.dh[tid] - p.hmin)) * p.HW + ((int)d.dw_[tid] - p.wmin) : 0;
+    toff[tid] = tid < d.T ? (((int)d.dh[tid] - p.hmin) * p.HW + ((int)d.dw_[tid] - p.wmin)) * GPITCH : 0;
+  for (int e = tid; e < p.nbh * p.HH + p.nbw * p.HW; e += 512) {      // see hwgrad_wide_kernel
+    bool ok = true;
+    int v;
+    if (e < p.nbh * p.HH) {
+      const int by = e / p.HH, hy = e - by * p.HH;
+      v = border_index(by * 16 + hy + p.hmin, d.Hg, d.border, ok);
+      v = min(max(v, 0), d.Hg - 1);
+    } else {
+      const int e2 = e - p.nbh * p.HH;
+      const int bx = e2 / p.HW, hx = e2 - bx * p.HW;
+      v = border_index(bx * 16 + hx + p.wmin, d.Wg, d.border, ok);
+      v = min(max(v, 0), d.Wg - 1);
+    }
+    ytab[e] = ok ? (unsigned short)v : (unsigned short)0x8000;
+  }
   const bool active = wave < np * nq;
   const int pi = active ? wave / nq : 0, qi = active ? wave % nq : 0;
   f32x4 acc[TMAX];
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fk = lane >> 4, frr = (lane & 15) >> 2, fcc = lane & 3;
-  const int HV = p.HD * p.HH * p.HW, hhw = p.HH * p.HW;
-  const int apieces = 256 * np * 2, hpieces = HV * nq * 2;
+  // the pieces this thread stages of every box, decoded once
+  constexpr int NA = 5, NH = 7;                    // <= 2560 dense, <= 3584 halo pieces (launcher)
+  int a_rel[NA], a_yx[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = i * 512 + wave * 64 + lane;
+    const int px = q / NPP, part = q - px * NPP;
+    const int ly = px >> 4, lx = px & 15;
+    a_yx[i] = (q < apieces && part < np * 2 && part * 8 < d.P) ? (ly << 8 | lx) : -1;
+    a_rel[i] = (ly * d.Wa + lx) * d.a_cs + part * 8;
+  }
+  int h_y[NH], h_x[NH], h_c[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int q = i * 512 + wave * 64 + lane;
+    const int v = q / NQP, part = q - v * NQP;
+    const int hy = v / p.HW;
+    h_y[i] = min(hy, p.HH - 1); h_x[i] = v - hy * p.HW;
+    h_c[i] = (q < hpieces && part < nq * 2 && part * 8 < d.Q) ? part * 8 : -1;
+  }
+  const bool ragged = (d.Ha & 15) != 0 || (d.Wa & 15) != 0;
+  bool okz = true;
+  int izs = border_index(p.dmin, d.Dg, d.border, okz);      // Da == 1: one source slice for the whole launch
+  izs = min(max(izs, 0), d.Dg - 1);
+  int tbv[TMAX];
   for (int box = blockIdx.x; box < p.nboxes; box += gridDim.x) {
     int b = box;
     const int bx = b % p.nbw; b /= p.nbw;
-    const int by = b % p.nbh; b /= p.nbh;
-    const int bz = b % p.nbd;
-    const int n = b / p.nbd;
-    const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
-    __syncthreads();   // tap table visible / previous box consumed
-    for (int q0 = wave * 64; q0 < apieces; q0 += 8 * 64) {
-      const int q = q0 + lane;
-      const int px = q / (np * 2), part = q - px * (np * 2);
-      const int lz = px / (p.BH * p.BW), rem = px - lz * (p.BH * p.BW);
-      const int ly = rem / p.BW, lx = rem - ly * p.BW;
-      const int oz = oz0 + lz, oy = oy0 + ly, ox = ox0 + lx;
-      const bool ok = oz < d.Da && oy < d.Ha && ox < d.Wa && part * 8 < d.P;
-      const size_t pix = (((size_t)n * d.Da + oz) * d.Ha + oy) * d.Wa + ox;
-      const char* src = ok ? p.a + (pix * d.a_cs + d.a_co + part * 8) * 2 : p.zero;
-      glds16(src, at + (size_t)q0 * 16);
-    }
-    const char* g_n = p.g + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
-    for (int q0 = wave * 64; q0 < hpieces; q0 += 8 * 64) {
-      const int q = q0 + lane;
-      const int v = q / (nq * 2), part = q - v * (nq * 2);
-      const int hz = v / hhw, r2 = v - hz * hhw;
-      const int hy = r2 / p.HW, hx = r2 - hy * p.HW;
-      bool ok = q < hpieces && part * 8 < d.Q;
-      int iz = border_index(oz0 + hz + p.dmin, d.Dg, d.border, ok);
-      int iy = border_index(oy0 + hy + p.hmin, d.Hg, d.border, ok);
-      int ix = border_index(ox0 + hx + p.wmin, d.Wg, d.border, ok);
-      iz = min(max(iz, 0), d.Dg - 1);
-      iy = min(max(iy, 0), d.Hg - 1);
-      ix = min(max(ix, 0), d.Wg - 1);
-      unsigned off = ((unsigned)((iz * d.Hg + iy) * d.Wg + ix) * (unsigned)d.g_cs + (unsigned)(part * 8)) * 2u;
-      asm volatile("" : "+v"(off));
-      const char* src = ok ? g_n + off : p.zero;
-      glds16(src, halo + (size_t)q0 * 16);
-    }
+    const int by = b % p.nbh;
+    const int n = b / p.nbh;
+    const int oy0 = by * 16, ox0 = bx * 16;
+    __syncthreads();   // tables visible / previous box consumed
+    const char* a_n = p.a + ((((size_t)n * d.Ha + oy0) * d.Wa + ox0) * d.a_cs + d.a_co) * 2;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (i * 512 + wave * 64 < apieces) {           // wave-uniform
+        bool ok = a_yx[i] >= 0;
+        if (ragged) ok = ok && oy0 + (a_yx[i] >> 8) < d.Ha && ox0 + (a_yx[i] & 255) < d.Wa;
+        glds16(ok ? a_n + (size_t)a_rel[i] * 2 : p.zero, at + (size_t)(i * 512 + wave * 64) * 16);
+      }
+    const char* g_n = p.g + (((size_t)n * d.Dg + izs) * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+    const unsigned short* yrow = ytab + by * p.HH;
+    const unsigned short* xrow = xtab + bx * p.HW;
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+      if (i * 512 + wave * 64 < hpieces) {           // wave-uniform: whole 64-piece instructions inside the halo
+        const unsigned iy = yrow[h_y[i]], ix = xrow[h_x[i]];
+        const bool ok = okz && h_c[i] >= 0 && !((iy | ix) & 0x8000u);
+        unsigned off = ((iy * (unsigned)d.Wg + ix) * (unsigned)d.g_cs + (unsigned)h_c[i]) * 2u;
+        asm volatile("" : "+v"(off));
+        glds16(ok ? g_n + off : p.zero, halo + (size_t)(i * 512 + wave * 64) * 16);
+      }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (active) {
-      int tbv[TMAX];
 #pragma unroll
       for (int t = 0; t < TMAX; ++t) tbv[t] = toff[t];
 #pragma unroll 1
       for (int ks = 0; ks < 8; ++ks) {             // 8 K-steps of 32 pixels
-        const char* ap = at + (size_t)(ks * 32 + fk * 8 + frr) * APITCH + (pi * 16 + fcc * 4) * 2;
+        const int run = ks * 4 + fk;               // this lane's 8-pixel run: box row run / 2, columns 8 (run & 1) ...
+        const char* ap = at + (size_t)(run * 8 + 2 * frr) * APITCH + (pi * 16 + fcc * 4) * 2;
         const uint2 alo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)GS_LDS(ap)));
         const uint2 ahi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)GS_LDS(ap + 4 * APITCH)));
+            (__attribute__((address_space(3))) s16x4*)GS_LDS(ap + APITCH)));
         const bf16x8 af = __builtin_bit_cast(bf16x8, uint4{alo.x, alo.y, ahi.x, ahi.y});
-        const int px0 = (ks * 4 + fk) * 8;         // first pixel of this lane's 8-pixel run (BW is a multiple of 8)
-        const int lz = px0 / (p.BH * p.BW), rem = px0 - lz * (p.BH * p.BW);
-        const int ly = rem / p.BW, lx0 = rem - ly * p.BW;
-        const int rb = (lz * p.HH + ly) * p.HW + lx0 + frr;
+        const char* g0 = halo + (size_t)((run >> 1) * p.HW + (run & 1) * 8 + 2 * frr) * GPITCH + (qi * 16 + fcc * 4) * 2;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
-          const char* gp = halo + (size_t)(rb + tbv[t]) * GPITCH + (qi * 16 + fcc * 4) * 2;
+          const char* gp = g0 + tbv[t];
           const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)GS_LDS(gp)));
           const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)GS_LDS(gp + 4 * GPITCH)));
+              (__attribute__((address_space(3))) s16x4*)GS_LDS(gp + GPITCH)));
           const bf16x8 gf = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, gf, acc[t], 0, 0, 0);
         }
@@ -669,8 +707,13 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     k.qchunks = (d->Q + 15) / 16;                  // nq
     k.tgroups = 1;
     const long long hv = (long long)k.HD * k.HH * k.HW;
-    const int lds = 256 + 256 * k.phalves * 32 + (int)((hv * k.qchunks * 32 + 1023) / 1024 * 1024 + 1024);
-    if (k.HD == 1 && lds <= 96 * 1024 && nboxes < (1LL << 31) &&
+    // (pitches padded by one piece per pixel / voxel, border tables behind the tiles: see the kernel)
+    const long long apieces = 256LL * (k.phalves * 2 + 1), hpieces = hv * (k.qchunks * 2 + 1);
+    const long long tab_bytes = ((long long)k.nbh * k.HH + (long long)k.nbw * k.HW) * 2;
+    const int lds = 256 + (int)((apieces * 16 + 1023) / 1024 * 1024) + (int)((hpieces * 16 + 1023) / 1024 * 1024 + 1024) +
+                    (int)((tab_bytes + 15) / 16 * 16);
+    if (k.HD == 1 && lds <= 80 * 1024 && apieces <= 5 * 512 && hpieces <= 7 * 512 && tab_bytes < 8192 && d->Hg < 32768 &&
+        d->Wg < 32768 && nboxes < (1LL << 31) &&
         (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31)) {
       k.nboxes = (int)nboxes; k.nboxes1 = (int)nboxes;
       k.a2 = k.g2 = nullptr;

@@ -290,7 +290,9 @@ int launch_wgrad(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int plan_onl
 // float4 (a 64-channel bias gradient over 4096 pixel chunks took 44 us with 4 slab lanes walking 1024 slabs each).
 template <int EL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, float4* dw, long long n4, int slabs,
-                                                           long long stride4) {
+                                                           long long stride4, long long ws_y4, long long dw_y4) {
+  ws += (long long)blockIdx.y * ws_y4;             // blockIdx.y: the network of a twin launch (its slabs, its gradient buffer)
+  dw += (long long)blockIdx.y * dw_y4;
   constexpr int SL = 256 / EL;
   __shared__ float4 part[SL][EL];
   const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
@@ -322,18 +324,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* ws, flo
     __syncthreads();
   }
 }
+// nets = 2: the same reduction for the second network of a twin launch in the same launch (its slabs ws_y4, its gradient
+// buffer dw_y4 float4s further on)
 static inline void launch_slab_reduce(const float* ws, float* dst, long long n4, int slabs, long long stride4,
-                                      hipStream_t st) {
+                                      hipStream_t st, int nets = 1, long long ws_y4 = 0, long long dw_y4 = 0) {
   const float4* w4 = reinterpret_cast<const float4*>(ws);
   float4* d4 = reinterpret_cast<float4*>(dst);
+  const unsigned ny = (unsigned)nets;
   if (n4 <= 4 && slabs > 16)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(1), dim3(256), 0, st, w4, d4, n4, slabs, stride4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(1, ny), dim3(256), 0, st, w4, d4, n4, slabs, stride4, ws_y4, dw_y4);
   else if (n4 <= 16 && slabs > 16)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(1), dim3(256), 0, st, w4, d4, n4, slabs, stride4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(1, ny), dim3(256), 0, st, w4, d4, n4, slabs, stride4, ws_y4, dw_y4);
   else {
     long long blocks = (n4 + 63) / 64;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, w4, d4, n4, slabs, stride4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)blocks, ny), dim3(256), 0, st, w4, d4, n4, slabs, stride4, ws_y4,
+                       dw_y4);
   }
 }
 
@@ -398,6 +404,12 @@ int wgrad_impl(const gs_wgrad_desc* d, const void* a1, const void* g1, const voi
     if (plan_only || !det) return 0;
     GS_REQUIRE(ws_floats >= (int64_t)nets * handled * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
                (long long)ws_floats, (long long)nets * handled * slab);
+    if (tw && tw->dw_delta % 16 == 0 && ((size_t)handled * slab) % 4 == 0) {      // both networks in one launch
+      launch_slab_reduce(ws, dw, slab / 4, handled, slab / 4, static_cast<hipStream_t>(stream), 2, (long long)handled * slab / 4,
+                         tw->dw_delta / 16);
+      GS_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
     if (int rc = wgrad_reduce(d, ws, dw, handled, stream)) return rc;
     if (tw) return wgrad_reduce(d, ws + (size_t)handled * slab, dw + tw->dw_delta / 4, handled, stream);
     return 0;
