@@ -534,13 +534,30 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short* dy
 
 // db[c] += sum of the slabs' column c, slabs in order, for the first c_valid (< 8) channels only: the bias of a layer whose
 // real channel count is not a multiple of 8 sits in the flat gradient buffer with the next parameter right behind it
-__global__ __launch_bounds__(64) void bias_head_reduce_kernel(const float* __restrict__ ws, float* db, int slabs, int C,
-                                                              int c_valid) {
-  const int c = threadIdx.x;
-  if (c >= c_valid) return;
+__global__ __launch_bounds__(256) void bias_head_reduce_kernel(const float* __restrict__ ws, float* db, int slabs, int C,
+                                                               int c_valid) {
+  // 8 channel lanes x 32 slab lanes (slab lane l adds slabs l, l + 32, ... in order, four loads in flight), then the 32
+  // partial sums in lane order: the order never depends on timing
+  __shared__ float part[32][8];
+  const int c = threadIdx.x & 7, sl = threadIdx.x >> 3;
   float s = 0.f;
-  for (int b = 0; b < slabs; ++b) s += ws[(size_t)b * C + c];
-  db[c] += s;
+  int k = sl;
+  for (; k + 96 < slabs; k += 128) {
+    float t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = ws[(size_t)(k + 32 * u) * C + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += t[u];
+  }
+  for (; k < slabs; k += 32) s += ws[(size_t)k * C + c];
+  part[sl][c] = s;
+  __syncthreads();
+  if (threadIdx.x < c_valid) {
+    float o = db[threadIdx.x];
+#pragma unroll 4
+    for (int l = 0; l < 32; ++l) o += part[l][threadIdx.x];
+    db[threadIdx.x] = o;
+  }
 }
 
 static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs, int32_t co, float* db, float* ws,
@@ -563,7 +580,7 @@ static int bias_grad_impl(const void* dy, int64_t pixels, int32_t C, int32_t cs,
   else hipLaunchKernelGGL((bias_grad_kernel<1>), dim3(bx, C8), dim3(256), 0, st, p, (long long)pixels, C8, cs, co, db, ppb, ws);
   GS_CHECK_HIP(hipGetLastError());
   if (ws && c_valid >= 0) {
-    hipLaunchKernelGGL(bias_head_reduce_kernel, dim3(1), dim3(64), 0, st, ws, db, (int)bx, C, c_valid);
+    hipLaunchKernelGGL(bias_head_reduce_kernel, dim3(1), dim3(256), 0, st, ws, db, (int)bx, C, c_valid);
     GS_CHECK_HIP(hipGetLastError());
   } else if (ws) {
     const long long n4 = C / 4;
