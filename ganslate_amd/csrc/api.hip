@@ -66,6 +66,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"gconv_big", 192},         // smallest number of 256 x 128 im2col tiles that selects them (one workgroup per CU) over 128 x 128 (two)
     {"hconv_box8", 1},          // hconv.hip: 8 x 8 x 8 boxes on 8 waves for volumes (4 x 8 x 8 on 4 waves otherwise)
     {"hconvw_persist", 1},      // hconvw.hip: launches with more tiles than CUs run ceil(tiles / CUs) tiles per workgroup (0: one each)
+    {"hstrip_regs", 1},         // hstrip.hip: persistent form with the weights in registers for the k7 boundary convs (0: one tile per workgroup)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

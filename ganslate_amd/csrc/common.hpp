@@ -124,6 +124,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   if (act == GS_ACT_TANH) return tanhf(v);
   return v;
 }
+// The same with tanh as a CALL: inlined into an unrolled 64-128 element conv epilogue, tanhf's ~40 instructions per element
+// (skipped at run time for the other activations, but fetched around and allocated for) made hstrip's tile code longer than
+// the instruction cache and cost its kernels up to 127 registers (profiles/r04_hstrip_forms.txt).
+static __device__ __noinline__ float gs_tanh_call(float v) { return tanhf(v); }
+__device__ __forceinline__ float apply_act_small(float v, int act, float slope) {
+  if (act == GS_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GS_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == GS_ACT_TANH) return gs_tanh_call(v);
+  return v;
+}
 // derivative expressed through the activation OUTPUT o (valid for relu / lrelu with slope>0 / tanh)
 __device__ __forceinline__ float act_grad_from_out(float o, int act, float slope) {
   if (act == GS_ACT_RELU) return o > 0.f ? 1.f : 0.f;
@@ -163,7 +173,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum GsOpt {
   GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE,
   GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL,
-  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONVW_PERSIST,
+  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONVW_PERSIST, GS_OPT_HSTRIP_REGS,
   GS_OPT_COUNT
 };
 int gs_opt(int id);

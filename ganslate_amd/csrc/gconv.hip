@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] + bia[i][r];
         if (pv) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
-        v[r] = apply_act(v[r], d.act, d.slope);
+        v[r] = apply_act_small(v[r], d.act, d.slope);
       }
       uint2 o;
       o.x = pack_bf2(v[0], v[1]);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) void hconv_kernel(const HConvK p) {
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] + ((p.bias && co < d.Co) ? p.bias[co + r] : 0.f);
         if (pval[j]) { s1[i][r] += v[r]; s2[i][r] += v[r] * v[r]; }
-        v[r] = apply_act(v[r], d.act, d.slope);
+        v[r] = apply_act_small(v[r], d.act, d.slope);
       }
       if (pval[j] && co < d.Co) {
         uint2* dst = reinterpret_cast<uint2*>(p.out + (opix[j] * d.out_cs + d.out_co + co) * 2);

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
             v[r] = acc[c][i][j][r] + bia[i][r];
             s1[i][r] += v[r];
             s2[i][r] += v[r] * v[r];
-            v[r] = apply_act(v[r], d.act, d.slope);
+            v[r] = apply_act_small(v[r], d.act, d.slope);
           }
         }
         uint2 o;

@@ -205,29 +205,38 @@ def test_halo_resident_boundary_convs(hip_ops, case):
     xa = torch.zeros(N, *low.in_dims, low.fwd[0].Ci, dtype=torch.bfloat16)
     xa.copy_(torch.randn(xa.shape, generator=g).to(torch.bfloat16))
     gy = torch.randn(N, *low.out_dims, low.fwd[0].Co, generator=g).to(torch.bfloat16)
-    default = hip_ops.get_option("hstrip")
+    default, default_regs = hip_ops.get_option("hstrip"), hip_ops.get_option("hstrip_regs")
     res = {}
     try:
-        for on in (1, 0):       # 1: every eligible layer whatever its grid (one workgroup per tile), 0: off (im2col launches)
+        # "regs": the persistent form with the weights in registers (any grid: option value 2), "lds": one tile per workgroup
+        # with the weights staged in LDS (every eligible layer whatever its grid), "im2col": both off
+        for form, (on, regs) in (("regs", (1, 2)), ("lds", (1, 0)), ("im2col", (0, 0))):
             hip_ops.set_option("hstrip", on)
-            if on and low.fwd[0].Ci in (32, 64):      # (the 1-channel stem folds to 8 channels: stays on the im2col kernel)
-                assert hip_ops.stat_slots(low.fwd[0], N) == ((low.fwd[0].Ho + 31) // 32) * ((low.fwd[0].Wo + 7) // 8)
+            hip_ops.set_option("hstrip_regs", regs)
+            ci, co = low.fwd[0].Ci, low.fwd[0].Co
+            if on and ci in (32, 64):      # (the 1-channel stem folds to 8 channels: stays on the im2col kernel)
+                rows = 16 if (regs and ci == 64 and co <= 32) else 32
+                assert hip_ops.stat_slots(low.fwd[0], N) == ((low.fwd[0].Ho + rows - 1) // rows) * ((low.fwd[0].Wo + 7) // 8)
             y, mr = run_forward(hip_ops, hip_ops.device, low, bias, fpack, xa, N)
             gx = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16, device=hip_ops.device)
             hip_ops.gconv_classes(low.dgrad, gy.to(hip_ops.device), dpack.to(hip_ops.device), None, gx)
             torch.cuda.synchronize()
-            res[on] = (y.cpu(), mr.cpu(), gx.cpu())
+            res[form] = (y.cpu(), mr.cpu(), gx.cpu())
     finally:
         hip_ops.set_option("hstrip", default)
+        hip_ops.set_option("hstrip_regs", default_regs)
     y_ref, mr_ref = run_forward(RefOps(), "cpu", low, bias, fpack, xa, N)
     gx_ref = torch.zeros(N, *low.dgrad_dims, low.dgrad[0].Co, dtype=torch.bfloat16)
     RefOps().gconv_classes(low.dgrad, gy, dpack, None, gx_ref)
     C = low.fwd[0].Co
-    for other, what in ((res[0], "im2col launches"), ((y_ref, mr_ref, gx_ref), "oracle")):
-        close_bf16(res[1][0], other[0], f"forward vs {what}")
-        close_f32(res[1][1].view(N, 2, C)[:, 0], other[1].view(N, 2, C)[:, 0], f"mean vs {what}", rel=1e-3)
-        close_f32(res[1][1].view(N, 2, C)[:, 1], other[1].view(N, 2, C)[:, 1], f"rstd vs {what}", rel=1e-3)
-        close_bf16(res[1][2], other[2], f"data gradient vs {what}")
+    assert torch.equal(res["regs"][0], res["lds"][0]) and torch.equal(res["regs"][2], res["lds"][2]), \
+        "the two strip forms run the same taps in the same order"
+    for form in ("regs", "lds"):
+        for other, what in ((res["im2col"], "im2col launches"), ((y_ref, mr_ref, gx_ref), "oracle")):
+            close_bf16(res[form][0], other[0], f"{form}: forward vs {what}")
+            close_f32(res[form][1].view(N, 2, C)[:, 0], other[1].view(N, 2, C)[:, 0], f"{form}: mean vs {what}", rel=1e-3)
+            close_f32(res[form][1].view(N, 2, C)[:, 1], other[1].view(N, 2, C)[:, 1], f"{form}: rstd vs {what}", rel=1e-3)
+            close_bf16(res[form][2], other[2], f"{form}: data gradient vs {what}")
 
 
 @pytest.mark.parametrize("act", ["lrelu", "relu", "tanh"])
