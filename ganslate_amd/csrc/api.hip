@@ -67,6 +67,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconv_box8", 1},          // hconv.hip: 8 x 8 x 8 boxes on 8 waves for volumes (4 x 8 x 8 on 4 waves otherwise)
     {"hconvw_persist", 1},      // hconvw.hip: launches with more tiles than CUs run ceil(tiles / CUs) tiles per workgroup (0: one each)
     {"hstrip_regs", 1},         // hstrip.hip: persistent form with the weights in registers for the k7 boundary convs (0: one tile per workgroup)
+    {"gconv_twin", 1},          // gconv.hip: twin batches on the im2col kernel as one launch (0: the two halves as two launches)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -52,6 +52,9 @@ struct GConvK {
   int splits;
   float* partial;
   long long split_stride;      // floats per split = N * Do*Ho*Wo * Co
+  // twin batch (gs_twin): images [nsplit, N) read the weight pack / bias w_delta / bias_delta bytes further on
+  int nsplit;
+  long long w_delta, bias_delta;
   int n_cls;                   // > 0: merged launch over cls[0..n_cls) (their fields replace the per-class ones of p / d)
   GConvCls cls[GS_MULTI_MAX_CLS];
   gs_gconv_desc d;
@@ -99,9 +102,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   const int cpz = multi ? cl.pz : d.pz, cpy = multi ? cl.py : d.py, cpx = multi ? cl.px : d.px;
   const int cslot0 = multi ? cl.stats_slot0 : d.stats_slot0;
   const int cnh = multi ? cl.nh : p.nh, cnw = multi ? cl.nw : p.nw;
-  const char* cw = p.w + (multi ? cl.w_off : 0);
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
+  const bool second = n >= p.nsplit;                   // workgroup-uniform: a tile never straddles images
+  const char* cw = p.w + (multi ? cl.w_off : 0) + (second ? p.w_delta : 0);
+  const float* cbias = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) + (second ? p.bias_delta : 0))
+                              : nullptr;
 
   for (int t = tid; t < cT; t += NW * 64) {
     const int th = multi ? (int)cl.tap_h[t] : (int)p.tap_h[t], tw = multi ? (int)cl.tap_w[t] : (int)p.tap_w[t];
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int co = nt * BN + wn * (BN / WN) + i * 16 + fk * 4;
-    bia[i] = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bia[i] = (cbias && co < d.Co) ? *reinterpret_cast<const f32x4*>(cbias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // ---- epilogue: bias, InstanceNorm partial statistics, activation, bf16 NHWC store -----------------
   const bool want_stats = d.stats_slots > 0;
@@ -712,7 +718,14 @@ extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, co
 extern "C" int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse* fuse) {
   if (!d) return 0;
   if (fuse) return fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy && gs_gconv_ring_slots(d) > 0;
-  return !gs_hconv_slots(d) && gs_hconvw_slots(d) > 0;
+  if (gs_hconv_slots(d)) return 0;
+  if (gs_hconvw_slots(d) > 0) return 1;
+  // the im2col kernel picks the weight set per tile (tiles never straddle images) — unless a halo kernel without a twin form
+  // would take the halves (hstrip), or the halves would run split-K (few tiles, long K: kept, the caller owns that workspace)
+  if (!gs_opt(GS_OPT_GCONV_TWIN) || gs_hstrip_slots(d) > 0 || d->accumulate) return 0;
+  gs_gconv_desc half = *d;
+  half.N = d->N / 2;
+  return splitk_plan(&half, pick_tile(&half), false) <= 1;
 }
 extern "C" int gs_gconv_forward_twin(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
                                      float* stats, const gs_gconv_fuse* fuse, const gs_twin* tw, void* stream) {
@@ -768,10 +781,12 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     }
     if (int rc = gs_hconvw_try(d, in, w_pack, bias, out, stats, tw, stream, &handled)) return rc;
     if (handled) return 0;
-    GS_REQUIRE(!tw, "gs_gconv_forward_twin: this layer's kernel has no twin form");
-    if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
-    if (handled) return 0;
+    if (!tw) {
+      if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
+      if (handled) return 0;
+    }
   }
+  GS_REQUIRE(!tw || (!fuse && !ws), "gs_gconv_forward_twin: the fused / split-K launches have no twin form");
   const TileCfg tc = pick_tile(d);
   GConvK k;
   if (fuse) k.f = *fuse; else k.f = gs_gconv_fuse{};
@@ -806,6 +821,9 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     k.tap_w[t] = (unsigned char)w;
   }
   k.n_cls = 0;
+  k.nsplit = tw ? tw->n_split : 0x7fffffff;
+  k.w_delta = tw ? tw->w_delta : 0;
+  k.bias_delta = tw ? tw->bias_delta : 0;
   k.splits = 1;
   k.partial = nullptr;
   k.split_stride = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
@@ -919,6 +937,8 @@ extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t
   k.rcp_hc = 1.0f / (float)d->Hc;
   k.d = *d;
   k.nh = k.nw = 0;
+  k.nsplit = 0x7fffffff;     // (no twin form of the merged class launch)
+  k.w_delta = k.bias_delta = 0;
   k.n_cls = count;
   for (int c = 0; c < count; ++c) {
     const gs_gconv_desc* dc = descs[c];

@@ -61,6 +61,50 @@ def test_twin_forward_equals_two_launches(hip_ops, case):
     close_bf16(y_tw[:N], y_ref, "twin forward vs oracle")
 
 
+IM2COL_CASES = [      # PatchGAN layers (patchgan2d.py:29-62): the im2col kernel picks the weight set per pixel tile
+    (ConvSpec("conv", 64, 128, 4, 2, 1), 8, 128, 128),
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 16, 64, 64),
+    (ConvSpec("conv", 256, 512, 4, 1, 1), 3, 32, 32),       # 31 x 31 outputs: ragged last tile of every image
+    (ConvSpec("conv", 3, 64, 4, 2, 1), 2, 64, 64),
+]
+
+
+@pytest.mark.parametrize("case", IM2COL_CASES, ids=lambda c: f"{c[0].cin}to{c[0].cout}_k{c[0].k}s{c[0].stride}_n{c[1]}")
+def test_twin_forward_on_the_im2col_kernel(hip_ops, case):
+    """gconv_kernel with a gs_twin: conv outputs bit for bit those of the two launches (the K order does not depend on the
+    tile), statistics to summation order (a batch of 2N may pick a larger pixel tile: other slots), and the oracle."""
+    spec, N, H, W = case
+    dev = hip_ops.device
+    low, _, bias_a, fpack_a, _ = make_layer(spec, (H, W), 301)
+    _, _, bias_b, fpack_b, _ = make_layer(spec, (H, W), 302)
+    g0 = low.fwd[0]
+    if not hip_ops.twin_native(g0, 2 * N):      # (halves that would run split-K stay two launches)
+        pytest.skip("the halves of this layer run split-K: no twin launch")
+    g = torch.Generator().manual_seed(6)
+    x = torch.zeros(2 * N, H, W, g0.Ci, dtype=torch.bfloat16)
+    x[..., :spec.cin] = torch.randn(2 * N, H, W, spec.cin, generator=g).to(torch.bfloat16)
+    x = x.to(dev)
+    packs = torch.stack([fpack_a, fpack_b]).to(dev)
+    biases = torch.stack([bias_a, bias_b]).to(dev)
+
+    def run(xs, pack, bias, n, twin=False):
+        slots = hip_ops.stat_slots(g0, n, twin=twin) if twin else hip_ops.stat_slots(g0, n)
+        y = torch.zeros(n, *low.out_dims, g0.Co, dtype=torch.bfloat16, device=dev)
+        part = torch.zeros(n * slots * 2 * g0.Co, dtype=torch.float32, device=dev)
+        hip_ops.gconv(g0, xs, pack, bias, y, act="lrelu", stats=part, stats_slots=slots)
+        return y, part.view(n, slots, 2, g0.Co).double().sum(1)
+    y_tw, s_tw = run(x, Twin(packs[0], packs[1]), Twin(biases[0], biases[1]), 2 * N, twin=True)
+    y_a, s_a = run(x[:N], packs[0], biases[0], N)
+    y_b, s_b = run(x[N:], packs[1], biases[1], N)
+    torch.cuda.synchronize()
+    assert torch.equal(y_tw[:N], y_a) and torch.equal(y_tw[N:], y_b), "twin launch differs from the two launches"
+    want = torch.cat([s_a, s_b])
+    assert (s_tw - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    y_ref = torch.zeros(N, *low.out_dims, g0.Co, dtype=torch.bfloat16)
+    RefOps().gconv(g0, x[:N].cpu(), fpack_a, bias_a, y_ref, act="lrelu")
+    close_bf16(y_tw[:N], y_ref, "twin forward vs oracle")
+
+
 @pytest.mark.parametrize("persist", [1, 0])
 def test_many_tiles_per_workgroup_equal_one_tile_each(hip_ops, persist):
     """one network, batch 24 at the trunk shape: 768 tiles = three per workgroup in the persistent form (option
