@@ -68,6 +68,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconvw_persist", 1},      // hconvw.hip: launches with more tiles than CUs run ceil(tiles / CUs) tiles per workgroup (0: one each)
     {"hstrip_regs", 1},         // hstrip.hip: persistent form with the weights in registers for the k7 boundary convs (0: one tile per workgroup)
     {"gconv_twin", 1},          // gconv.hip: twin batches on the im2col kernel as one launch (0: the two halves as two launches)
+    {"wgrad_twin", 1},          // wgrad.hip: twin batches on the im2col weight-gradient kernel as one launch (0: two launches)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -22,6 +22,10 @@ struct WGradK {
   float rcp_wa, rcp_hw, rcp_da;
   float* ws;                  // != nullptr: split sp writes its partial tile to slab sp of ws ([splits][P * dw_ld] floats)
   long long ws_stride;        // instead of fp32 atomics on dw (deterministic accumulation, gs_wgrad_ws)
+  // twin batch (gs_twin): the pixel range of each network's images is split on its own (splits = nets * splits_net, no
+  // workgroup straddles the two), the second network's sums go to dw + dw_delta floats / its own slabs
+  int nets, splits_net, m_net;
+  long long dw_delta;
   gs_wgrad_desc d;
 };
 
@@ -57,8 +61,9 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
   b /= p.tiles_p;
   const int sp = b;                       // pixel range [k0, k1) of the batch-flattened pixel index
   const int HW = d.Ha * d.Wa;
-  const int k0 = sp * p.chunk;
-  const int k1 = min(d.N * d.Da * HW, k0 + p.chunk);
+  const int net = p.nets > 1 ? sp / p.splits_net : 0;
+  const int k0 = net * p.m_net + (sp - net * p.splits_net) * p.chunk;
+  const int k1 = min((net + 1) * p.m_net, k0 + p.chunk);
   if (k0 >= k1) return;
 
   for (int t = tid; t < d.T; t += NW * 64)
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     for (int r = 0; r < 4; ++r) {
       const int pp = tp * BP + wp * (BP / WP) + i * 16 + fk * 4 + r;
       if (pp < d.P) {
-        float* row = (p.ws ? p.ws + (size_t)sp * p.ws_stride : p.dw) + (size_t)pp * d.dw_ld;
+        float* row = (p.ws ? p.ws + (size_t)sp * p.ws_stride : p.dw + (size_t)net * p.dw_delta) + (size_t)pp * d.dw_ld;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int col = tq * BQ + wq * (BQ / WQ) + j * 16 + frow;
@@ -234,10 +239,11 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int pla
   k.tiles_q = (d->T * d->Q + BQ - 1) / BQ;
   // split-K over the batch-flattened pixel index: one workgroup per CU is resident (144 KiB of LDS), so aim for
   // a grid of (almost) exactly r * 256 workgroups with >= 16 K-steps each, preferring the smallest r
-  const long long M = (long long)d->N * d->Da * d->Ha * d->Wa;
-  GS_REQUIRE(M < (1 << 24) && M * d->a_cs < (1LL << 31) && (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31),
+  const long long M = (long long)d->N / k.nets * d->Da * d->Ha * d->Wa;      // pixels per network
+  GS_REQUIRE(M * k.nets < (1 << 24) && M * k.nets * d->a_cs < (1LL << 31) &&
+                 (long long)d->N * d->Dg * d->Hg * d->Wg * d->g_cs < (1LL << 31),
              "gs_wgrad: tensor too large for 32-bit offsets");
-  const long long tiles = (long long)k.tiles_p * k.tiles_q;
+  const long long tiles = (long long)k.tiles_p * k.tiles_q * k.nets;
   const long long max_splits = (M + 1023) / 1024 > 0 ? (M + 1023) / 1024 : 1;
   long long splits = 1;
   double best = 1e30;
@@ -253,7 +259,9 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int pla
   int chunk = (int)((M + splits - 1) / splits);
   chunk = (chunk + 63) / 64 * 64;
   splits = (M + chunk - 1) / chunk;
-  k.splits = (int)splits;
+  k.splits = (int)splits * k.nets;
+  k.splits_net = (int)splits;
+  k.m_net = (int)M;
   k.chunk = chunk;
   k.rcp_hw = 1.0f / (float)(d->Ha * d->Wa);
   const long long blocks = tiles * splits;
@@ -350,8 +358,10 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
 namespace {
 // the im2col kernel for one operand pair; ws != nullptr: partial tiles to slabs, *slabs = how many
 int wgrad_generic(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, float* ws, int plan_only,
-                  void* stream, int* slabs) {
+                  void* stream, int* slabs, const gs_twin* tw = nullptr) {
   WGradK k;
+  k.nets = tw ? 2 : 1;                                       // (*slabs: per network)
+  k.dw_delta = tw ? tw->dw_delta / 4 : 0;
   k.a = static_cast<const char*>(a);
   k.g = static_cast<const char*>(g);
   k.dw = dw;
@@ -414,23 +424,43 @@ int wgrad_impl(const gs_wgrad_desc* d, const void* a1, const void* g1, const voi
     if (tw) return wgrad_reduce(d, ws + (size_t)handled * slab, dw + tw->dw_delta / 4, handled, stream);
     return 0;
   }
-  if (tw) {                                                  // no twin form for this layer: *need_floats = -1 says so
-    if (need_floats) *need_floats = -1;
-    GS_REQUIRE(plan_only, "gs_wgrad_ws_twin: this layer's kernel has no twin form (gs_wgrad_twin_native): run the two halves");
-    return 0;
+  if (tw) {
+    // the im2col kernel splits each network's pixels on its own — unless one of the halo kernels without a twin form
+    // (hwgrad_kernel, hwgrad_ft) would take the halves, which is the better deal: *need_floats = -1 says "run the halves"
+    gs_wgrad_desc half = *d;
+    half.N = d->N / 2;
+    int hh = 0;
+    static const char dummy = 0;
+    if (int rc = gs_hwgrad_try2(&half, &dummy, &dummy, a2 ? &dummy : nullptr, a2 ? &dummy : nullptr, nullptr, nullptr, 1, nullptr,
+                                &hh, nullptr)) return rc;
+    if (hh || !gs_opt(GS_OPT_WGRAD_TWIN)) {
+      if (need_floats) *need_floats = -1;
+      GS_REQUIRE(plan_only, "gs_wgrad_ws_twin: this layer's kernel has no twin form (gs_wgrad_twin_native): run the two halves");
+      return 0;
+    }
   }
   // the im2col kernel: one launch (+ one reduction) per operand pair, the workspace is reused
+  const int nets = tw ? 2 : 1;
   int64_t need = 0;
   for (int pass = 0; pass < (a2 ? 2 : 1); ++pass) {
     int slabs = 0;
-    if (int rc = wgrad_generic(d, pass ? a2 : a1, pass ? g2 : g1, dw, det ? ws : nullptr, plan_only, stream, &slabs))
+    if (int rc = wgrad_generic(d, pass ? a2 : a1, pass ? g2 : g1, dw, det ? ws : nullptr, plan_only, stream, &slabs, tw))
       return rc;
-    if ((int64_t)slabs * slab > need) need = (int64_t)slabs * slab;
+    if ((int64_t)nets * slabs * slab > need) need = (int64_t)nets * slabs * slab;
     if (plan_only || !det) continue;
-    GS_REQUIRE(ws_floats >= (int64_t)slabs * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
-               (long long)ws_floats, (long long)slabs * slab);
-    if (slabs > 0)
+    GS_REQUIRE(ws_floats >= (int64_t)nets * slabs * slab, "gs_wgrad_ws: workspace of %lld floats, %lld needed",
+               (long long)ws_floats, (long long)nets * slabs * slab);
+    if (slabs > 0) {
+      if (tw && tw->dw_delta % 16 == 0 && ((size_t)slabs * slab) % 4 == 0) {       // both networks in one launch
+        launch_slab_reduce(ws, dw, slab / 4, slabs, slab / 4, static_cast<hipStream_t>(stream), 2, (long long)slabs * slab / 4,
+                           tw->dw_delta / 16);
+        GS_CHECK_HIP(hipGetLastError());
+        continue;
+      }
       if (int rc = wgrad_reduce(d, ws, dw, slabs, stream)) return rc;
+      if (tw)
+        if (int rc = wgrad_reduce(d, ws + (size_t)slabs * slab, dw + tw->dw_delta / 4, slabs, stream)) return rc;
+    }
   }
   if (need_floats) *need_floats = need;
   return 0;

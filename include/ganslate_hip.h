@@ -101,7 +101,7 @@ void gs_shutdown(void);
 const char* gs_last_error(void);
 /* Kernel-selection switches (A/B measurements, parity tests): the library reads NO environment variable; the host
  * side maps its GS_* variables onto these (ganslate_amd/hip/ops.py). Names: splitk, splitk_max_blocks, splitk_target,
- * hconv, hconv_wide, hconvw_persist, hstrip_regs, gconv_twin, hwgrad, hwgrad_wide, hwgrad_planes, norm_bwd_ppb, norm_apply_unroll, gconv_tile288,
+ * hconv, hconv_wide, hconvw_persist, hstrip_regs, gconv_twin, wgrad_twin, hwgrad, hwgrad_wide, hwgrad_planes, norm_bwd_ppb, norm_apply_unroll, gconv_tile288,
  * gconv_multi, hconvw_ring, hconvt (smallest grid the parity-class halo kernel takes, 0 = off), hstrip (same for the k7
  * boundary-conv kernel). Every setting computes the same function (up to the fp32 summation order and, for hconvw_ring,
  * where the bf16 rounding of the folded gradient happens); none skips work. Unknown name -> non-zero. */

@@ -210,6 +210,37 @@ def test_twin_weight_gradient_of_the_residual_convs(hip_ops, case, pair):
     close_f32(runs[0][1], dref, "second network's gradient vs oracle", rel=2e-3)
 
 
+@pytest.mark.parametrize("case", IM2COL_CASES + [(ConvSpec("convT", 256, 128, 3, 2, 1, 1), 4, 32, 32)],
+                         ids=lambda c: f"{c[0].kind}{c[0].cin}to{c[0].cout}_k{c[0].k}s{c[0].stride}_n{c[1]}")
+def test_twin_weight_gradient_on_the_im2col_kernel(hip_ops, case):
+    """wgrad_kernel as a twin launch: each network's pixel range is split on its own and lands in its own gradient buffer
+    — against the two separate launches (summation order), the oracle, and itself (reproducible)."""
+    spec, N, H, W = case
+    dev = hip_ops.device
+    low = make_layer(spec, (H, W), 7)[0]
+    w = low.wgrad
+    g = torch.Generator().manual_seed(8)
+    a_dims = low.out_dims if spec.kind == "conv" else (H, W)
+    g_dims = (H, W) if spec.kind == "conv" else low.out_dims
+    a = torch.randn(2 * N, *a_dims, w.P, generator=g).to(torch.bfloat16).to(dev)
+    gg = torch.randn(2 * N, *g_dims, w.Q, generator=g).to(torch.bfloat16).to(dev)
+    n = spec.P * spec.T * spec.Q
+    runs = []
+    for _ in range(2):
+        dw = torch.zeros(2, n, device=dev)
+        hip_ops.wgrad(w, a, gg, Twin(dw[0], dw[1]))
+        runs.append(dw)
+    sep = torch.zeros(2, n, device=dev)
+    for h in (0, 1):
+        hip_ops.wgrad(w, a[h * N:(h + 1) * N], gg[h * N:(h + 1) * N], sep[h])
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0], runs[1]), "twin weight gradient is not reproducible"
+    close_f32(runs[0], sep.cpu(), "twin vs separate launches", rel=2e-4)
+    dref = torch.zeros(n)
+    RefOps().wgrad(w, a[N:].cpu(), gg[N:].cpu(), dref)
+    close_f32(runs[0][1], dref, "second network's gradient vs oracle", rel=2e-3)
+
+
 @pytest.mark.parametrize("name", ["c64_default", "c64_idt_ssim"])
 def test_cyclegan_step_with_twin_passes_equals_the_two_pass_step(name, monkeypatch):
     """whole iterations on the GPU: twin passes (generators and discriminators as one batch each) against GS_TWIN=0. The
