@@ -71,6 +71,60 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, float* g, float
   adam_body(p, g, m, v, n, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], gscale, zero_grad);
 }
 
+// The same update that also writes the bf16 weight packs where a pack group of 8 elements IS a group of 8 consecutive
+// master elements (every row-major pack: a conv's forward pack, a transposed conv's data-gradient pack): inv_x[i] = pack
+// group of master elements 8 i .. 8 i + 7, or -1. The lane that updated elements 8 i + 4 h .. + 3 stores half h of the
+// group (8 bytes): the separate refresh launch read every such master element a second time (4 of its 6.5 bytes per weight;
+// 219 of 1630 us of Adam + refresh on the 167 M-parameter U-Net). Transposed packs stay with gs_repack_bf16_tiled_groups.
+__global__ __launch_bounds__(256) void adam_dev_packs_kernel(float* p, float* g, float* m, float* v, long long n,
+                                                             const float* __restrict__ hyper, float gscale, int zero_grad,
+                                                             const int* __restrict__ inv_f, uint2* __restrict__ fpack,
+                                                             const int* __restrict__ inv_d, uint2* __restrict__ dpack) {
+  const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc2_sqrt = hyper[5];
+  const float step_size = hyper[0] / hyper[4];
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  const long long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  auto upd = [&](float4& P, float4& G, float4& M, float4& V) {
+    adam_one(P.x, G.x, M.x, V.x, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+    adam_one(P.y, G.y, M.y, V.y, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+    adam_one(P.z, G.z, M.z, V.z, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+    adam_one(P.w, G.w, M.w, V.w, b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+  };
+  auto packs = [&](long long i, const float4& P) {
+    const uint2 o = {pack_bf2(P.x, P.y), pack_bf2(P.z, P.w)};
+    const long long grp = i >> 1;
+    const int jf = inv_f ? inv_f[grp] : -1, jd = inv_d ? inv_d[grp] : -1;
+    if (jf >= 0) fpack[(long long)jf * 2 + (i & 1)] = o;
+    if (jd >= 0) dpack[(long long)jd * 2 + (i & 1)] = o;
+  };
+  long long i = tid;
+  for (; i + nth < n4; i += 2 * nth) {
+    const long long j = i + nth;
+    float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i];
+    float4 P1 = p4[j], G1 = g4[j], M1 = m4[j], V1 = v4[j];
+    upd(P0, G0, M0, V0);
+    upd(P1, G1, M1, V1);
+    p4[i] = P0; m4[i] = M0; v4[i] = V0;
+    p4[j] = P1; m4[j] = M1; v4[j] = V1;
+    if (zero_grad) { g4[i] = G0; g4[j] = G1; }
+    packs(i, P0);
+    packs(j, P1);
+  }
+  for (; i < n4; i += nth) {
+    float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i];
+    upd(P0, G0, M0, V0);
+    p4[i] = P0; m4[i] = M0; v4[i] = V0;
+    if (zero_grad) g4[i] = G0;
+    packs(i, P0);
+  }
+  // (a tail of n % 4 elements belongs to no complete group: plain update)
+  for (long long e = n4 * 4 + tid; e < n; e += nth) adam_one(p[e], g[e], m[e], v[e], b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
+}
+
 static long long adam_blocks(int64_t n) {
   long long blocks = (n / 4 + 511) / 512;         // two 16-byte vectors per thread per pass
   if (blocks < 1) blocks = 1;
@@ -83,6 +137,23 @@ extern "C" int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t 
   GS_REQUIRE(p && g && m && v && hyper_dev && n > 0, "gs_adam_step_dev: bad argument");
   hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)adam_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
                      m, v, (long long)n, hyper_dev, grad_scale, zero_grad);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_adam_step_dev_packs(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                                      float grad_scale, int32_t zero_grad, const int32_t* inv_f, void* fpack,
+                                      const int32_t* inv_d, void* dpack, void* stream) {
+  GS_REQUIRE(p && g && m && v && hyper_dev && n > 0, "gs_adam_step_dev_packs: bad argument");
+  GS_REQUIRE((inv_f == nullptr) == (fpack == nullptr) && (inv_d == nullptr) == (dpack == nullptr),
+             "gs_adam_step_dev_packs: an inverse table comes with its pack");
+  GS_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+               reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(fpack) | reinterpret_cast<uintptr_t>(dpack)) & 15) == 0,
+             "gs_adam_step_dev_packs: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_dev_packs_kernel, dim3((unsigned)adam_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
+                     m, v, (long long)n, hyper_dev, grad_scale, zero_grad, inv_f, static_cast<uint2*>(fpack), inv_d,
+                     static_cast<uint2*>(dpack));
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

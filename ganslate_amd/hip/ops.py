@@ -740,8 +740,16 @@ class HipOps(TwinSplit):
         L.check(self.lib.gs_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), hyper, float(grad_scale),
                                       int(zero_grad), _stream()), "gs_adam_step")
 
-    def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True):
-        """hyper_dev: device float32[6] = lr, beta1, beta2, eps, 1-beta1^t, sqrt(1-beta2^t) (see NativeAdam.prepare)"""
+    def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True, packs=None):
+        """hyper_dev: device float32[6] = lr, beta1, beta2, eps, 1-beta1^t, sqrt(1-beta2^t) (see NativeAdam.prepare).
+        packs = (inv_f, fpack, inv_d, dpack): the update also writes the pack groups that are 8 consecutive master elements
+        (NativeNet.fused_pack_targets)"""
+        if packs is not None:
+            inv_f, fpack, inv_d, dpack = packs
+            L.check(self.lib.gs_adam_step_dev_packs(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev),
+                                                    float(grad_scale), int(zero_grad), _ptr(inv_f), _ptr(fpack), _ptr(inv_d),
+                                                    _ptr(dpack), _stream()), "gs_adam_step_dev_packs")
+            return
         L.check(self.lib.gs_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev),
                                           float(grad_scale), int(zero_grad), _stream()), "gs_adam_step_dev")
 

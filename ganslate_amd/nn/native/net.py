@@ -277,9 +277,46 @@ class NativeNet:
         with torch.no_grad():
             flat.copy_(host.to(flat.device))
 
-    def mark_packs_dirty(self):
+    def mark_packs_dirty(self, ident_fresh=None):
+        """the master moved. ident_fresh: the pack set whose row-major groups the optimiser wrote with the update itself
+        (fused_pack_targets) — that set only needs its transposed segments refreshed"""
         self._packs_dirty = True
+        for pk in self._packs.values():
+            pk["ident_fresh"] = pk is ident_fresh
         self._recent_passes = {}          # (the weights moved: recorded activations no longer describe this network)
+
+    def fused_pack_targets(self):
+        """(pack set, (inv_f, fpack, inv_d, dpack)) for gs_adam_step_dev_packs, or None: inv_x[i] = the group of 8 pack
+        elements that IS master elements 8 i .. 8 i + 7 (-1: none). Built once per pack set; only for a network with ONE pack
+        set (one input size) — with several, every set refreshes from the master as before. GS_ADAM_PACKS=0 switches it off."""
+        if os.environ.get("GS_ADAM_PACKS", "1") == "0" or len(self._packs) != 1 or self.master.data_ptr() % 16:
+            return None
+        (pk,) = self._packs.values()
+        if "fused" not in pk:
+            n8 = (self.numel + 7) // 8
+            out, any_fused = [], False
+            for which in ("f", "d"):
+                plan = pk[which + "_plan"]
+                groups = plan["groups"].cpu().numpy()
+                inv = np.full(n8, -1, np.int32)
+                j = np.nonzero((groups >= 0) & (groups % 8 == 0) & (groups + 8 <= self.numel // 4 * 4))[0]
+                i = groups[j] // 8
+                first = np.unique(i, return_index=True)[1]          # (a master group feeds at most one pack group here)
+                j, i = j[first], i[first]
+                inv[i] = j
+                rest = groups.copy()
+                rest[j] = -3                                          # the leftover launch skips them
+                left = int(((rest >= 0) | (rest == -2)).sum())
+                any_fused = any_fused or len(j) > 0
+                out.append((torch.from_numpy(inv).to(self.device) if len(j) else None,
+                            torch.from_numpy(rest).to(self.device) if left else None, left))
+                if pk[which + "pack"].data_ptr() % 16:
+                    any_fused = False
+            pk["fused"] = out if any_fused else None
+        if pk["fused"] is None:
+            return None
+        (inv_f, _, _), (inv_d, _, _) = pk["fused"]
+        return pk, (inv_f, pk["fpack"] if inv_f is not None else None, inv_d, pk["dpack"] if inv_d is not None else None)
 
     # A recorded pass keeps its activations until its backward pass has run. A recipe that needs DETACHED features of the
     # same input again (CUT's source patches: the reference runs the encoder a second time on real_A / real_B,
@@ -412,13 +449,18 @@ class NativeNet:
             self._packs_dirty = False
         if not pk["fresh"]:
             m = self.master.detach()
-            for which in ("f", "d"):
+            ident = pk.get("ident_fresh") and pk.get("fused")         # row-major groups written by the optimiser's launch
+            for k, which in enumerate(("f", "d")):
                 plan, pack = pk[which + "_plan"], pk[which + "pack"]
                 n8 = plan["groups"].numel()
-                self.ops.repack_groups(m, plan["groups"], pack[:n8 * 8], plan["index"])
+                if ident and ident[k][0] is not None:
+                    if ident[k][2]:                                   # groups the fused launch could not take
+                        self.ops.repack_groups(m, ident[k][1], pack[:n8 * 8], plan["index"])
+                else:
+                    self.ops.repack_groups(m, plan["groups"], pack[:n8 * 8], plan["index"])
                 if plan["tiles"]:
                     self.ops.repack_tiled_groups(m, plan["tgroups"], pack, plan["seg"], plan["tiles"])
-            pk["fresh"] = True
+            pk["fresh"], pk["ident_fresh"] = True, False
         return pk
 
     # ---- forward ----------------------------------------------------------------------------------------------------------

@@ -58,10 +58,15 @@ class NativeAdam(torch.optim.Optimizer):
                     continue
                 scale = net.finish_grad_reduction()
                 st = self.state[p]
+                # the update writes the row-major bf16 weight packs as it goes where the network has one pack set
+                tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
                 ops.adam_step_dev(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["hyper"], grad_scale=scale,
-                                  zero_grad=True)
+                                  zero_grad=True, packs=tgt[1] if tgt else None)
                 net.grad_dirty = False
-                net.mark_packs_dirty()
+                if tgt:
+                    net.mark_packs_dirty(ident_fresh=tgt[0])
+                else:
+                    net.mark_packs_dirty()
 
     def state_dict(self):
         sd = super().state_dict()       # the hyper vectors are derived state: rebuilt by the next prepare()

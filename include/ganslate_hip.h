@@ -476,6 +476,14 @@ int gs_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float*
  * the host refreshes the learning rate and bias corrections between replays. */
 int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev,
                      float grad_scale, int32_t zero_grad, void* stream);
+/* gs_adam_step_dev that also refreshes the bf16 weight packs where 8 consecutive pack elements are 8 consecutive, 8-aligned
+ * master elements (row-major packs: a conv's forward pack, a transposed conv's data-gradient pack; nn/native/net.py builds
+ * the tables): inv_x[i] = pack group (of 8 elements) holding master elements 8 i .. 8 i + 7, or -1; tables of ceil(n / 8)
+ * int32. Either table / pack pair may be NULL. The transposed packs keep gs_repack_bf16_tiled_groups. Buffers 16-byte
+ * aligned. (torch.optim.Adam.step + the weight cast a bf16 autocast run would do per use, pix2pix.py:61-66) */
+int gs_adam_step_dev_packs(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev, float grad_scale,
+                           int32_t zero_grad, const int32_t* inv_f, void* fpack, const int32_t* inv_d, void* dpack,
+                           void* stream);
 /* ---- feature taps of CUT's PatchNCE loss (ganslate/nn/gans/unpaired/cut.py:229-312; FeaturePatchMLP.forward :262-277 reads
  * `feat.permute(0, 2, 3, 1).flatten(1, 2)[:, patch_id, :]` per level) ------------------------------------------------------------
  * ids_dev: int64 device array of P DISTINCT flat pixel indices (the head of a torch.randperm), shared by the n images.

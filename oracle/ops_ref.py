@@ -675,7 +675,7 @@ class RefOps(TwinSplit):
         if zero_grad:
             g.zero_()
 
-    def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True):
+    def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True, packs=None):
         """hyper_dev = float32[6]: lr, beta1, beta2, eps, 1-beta1^t, sqrt(1-beta2^t) — the update of adam_step with the
         scalars taken from the tensor (they were rounded to fp32 when it was written, like the kernel's arguments)"""
         lr, beta1, beta2, eps, bc1, bc2s = (float(h) for h in hyper_dev.tolist())
@@ -685,6 +685,14 @@ class RefOps(TwinSplit):
         p.addcdiv_(m, (v.sqrt() / bc2s).add_(eps), value=-lr / bc1)
         if zero_grad:
             g.zero_()
+        if packs is not None:       # gs_adam_step_dev_packs: identity pack groups refreshed with the update
+            for inv, pack in ((packs[0], packs[1]), (packs[2], packs[3])):
+                if inv is None:
+                    continue
+                n8 = p.numel() // 8
+                src = torch.nonzero(inv[:n8] >= 0).flatten()
+                dst = inv[:n8][src].long()
+                pack[:pack.numel() // 8 * 8].view(-1, 8)[dst] = p[:n8 * 8].view(-1, 8)[src].to(pack.dtype)
 
     def pool_query(self, pool, images, out, code_dev):
         """ganslate/data/utils/image_pool.py:31-60 with the coin flips given as codes (see gs_pool_query)"""

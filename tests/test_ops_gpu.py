@@ -6,6 +6,8 @@ Tolerances (stated per ISSUE ③): conv outputs are rounded to bf16 -> |err| <= 
 the max-abs of the oracle result (one bf16 ulp of the largest value, accumulation noise is far below that);
 fp32 outputs (weight gradients, statistics, losses) rel 2e-3 of max-abs (fp32 atomics / reduction order).
 """
+import os
+
 import pytest
 import torch
 
@@ -1245,6 +1247,42 @@ def test_network_pack_refresh_matches_elementwise(hip_ops):
         ref = torch.empty(full.numel(), dtype=torch.bfloat16, device=hip_ops.device)
         hip_ops.repack(net.master.detach(), full, ref)
         assert torch.equal(ref, pk[which + "pack"][:full.numel()]), which
+
+    # the optimiser's launch writes the row-major pack groups with the update (gs_adam_step_dev_packs); the next use only
+    # refreshes the transposed segments: packs bit-identical to the element-wise refresh of the UPDATED master, and the
+    # update itself bit-identical to the plain launch's
+    from ganslate_amd.nn.optim import NativeAdam
+    twin = NativeNet(nodes, 8, 8, ops=hip_ops)
+    twin.load_state_dict(net.state_dict())
+    twin.refresh_packs(x)
+    outs = []
+    for fused, nn_ in ((True, net), (False, twin)):
+        os.environ["GS_ADAM_PACKS"] = "1" if fused else "0"
+        opt = NativeAdam(nn_.parameters(), lr=2e-4, betas=(0.5, 0.999))
+        for step in range(2):
+            g = torch.Generator(device="cpu").manual_seed(40 + step)
+            nn_.master.grad = (torch.randn(nn_.numel, generator=g) * 1e-2).to(hip_ops.device)
+            nn_.grad_dirty = True
+            opt.step()
+            tgt = nn_.fused_pack_targets()
+            assert (tgt is not None) == fused
+            nn_.refresh_packs(x)
+        outs.append((nn_.master.detach().clone(), nn_._packs[(16, 16)]["fpack"].clone(), nn_._packs[(16, 16)]["dpack"].clone()))
+    os.environ.pop("GS_ADAM_PACKS")
+    pkf = net._packs[(16, 16)]["fused"]
+    assert pkf is not None and pkf[0][0] is not None and pkf[1][0] is not None, "both packs have row-major groups here"
+    for a, b, what in zip(outs[0], outs[1], ("master", "forward pack", "data-gradient pack")):
+        assert torch.equal(a, b), what
+    for which, name in (("f", "fwd_index"), ("d", "dgrad_index")):
+        idx = []
+        for i, lw in enumerate(lows):
+            t = getattr(lw, name).astype(np.int64)
+            t[t >= 0] += net.w_off[i]
+            idx.append(t.reshape(-1))
+        full = torch.from_numpy(np.concatenate(idx).astype(np.int32)).to(hip_ops.device)
+        ref = torch.empty(full.numel(), dtype=torch.bfloat16, device=hip_ops.device)
+        hip_ops.repack(net.master.detach(), full, ref)
+        assert torch.equal(ref, net._packs[(16, 16)][which + "pack"][:full.numel()]), which
 
 
 @pytest.mark.parametrize("case", [c for c in WGRAD_PAIR_CASES] + [
