@@ -14,6 +14,7 @@
 // out[2i + py][2j + px].
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 constexpr int NC = 4;
@@ -257,27 +258,32 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
+    // (the activation is chosen once per class, not per element: the switch inside these loops was 3800 scalar instructions)
+    auto to_slab = [&](auto none_tag) {
+      constexpr bool ACT_NONE = decltype(none_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        float v[4];
+        for (int i = 0; i < TI; ++i) {
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (PLAIN || FUSED) {
-            v[r] = acc[c][i][j][r];
-          } else {
-            v[r] = acc[c][i][j][r] + bia[i][r];
-            s1[i][r] += v[r];
-            s2[i][r] += v[r] * v[r];
-            v[r] = apply_act_small(v[r], d.act, d.slope);
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (PLAIN || FUSED) {
+              v[r] = acc[c][i][j][r];
+            } else {
+              v[r] = acc[c][i][j][r] + bia[i][r];
+              s1[i][r] += v[r];
+              s2[i][r] += v[r] * v[r];
+              if constexpr (!ACT_NONE) v[r] = apply_act_small(v[r], d.act, d.slope);
+            }
           }
+          uint2 o;
+          o.x = pack_bf2(v[0], v[1]);
+          o.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(slab + ((wm * 4 + j) * 16 + frow) * SROW + (wn * 32 + i * 16 + fk * 4) * 2) = o;
         }
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(slab + ((wm * 4 + j) * 16 + frow) * SROW + (wn * 32 + i * 16 + fk * 4) * 2) = o;
-      }
+    };
+    if (PLAIN || FUSED || d.act == GS_ACT_NONE) to_slab(std::true_type{}); else to_slab(std::false_type{});
     __syncthreads();
     {
       const int piece = tid & 7;                             // 8 lanes x 16 B = the 64 channels of a pixel: 128-B stores
