@@ -562,15 +562,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       ct_of(2, c2, t2);
       issue_w(n + nstep, c2, t2, stage == 0 ? 2 : stage - 1);
     }
-#ifdef GS_ABL_NOSTORE
-    if (!has_next)
-#endif
-    {
     *reinterpret_cast<uint4*>(p.out + (opix_of(0, 0) * d.out_cs + d.out_co + co) * 2) = val0;
     *reinterpret_cast<uint4*>(p.out + (opix_of(0, 1) * d.out_cs + d.out_co + co) * 2) = val1;
     *reinterpret_cast<uint4*>(p.out + (opix_of(1, 0) * d.out_cs + d.out_co + co) * 2) = val2;
     *reinterpret_cast<uint4*>(p.out + (opix_of(1, 1) * d.out_cs + d.out_co + co) * 2) = val3;
-    }
     if (has_next && grp) __builtin_amdgcn_s_barrier();      // group 1 one barrier ahead again
   }
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Interleaved A/B of library options on one kernel case, in ONE process (run-to-run and box-to-box scatter of the
 micro-benchmark is +-3 %; cdna_hip_programming.md rule 24):
-    python tools/ab_kernels.py --case rb --kind fwd --opt hconvw_waves=8,16 [--opt ...] --rounds 7 --iters 40
+    python tools/ab_kernels.py --case rb --kind fwd --opt hconvw_persist=0,1 [--opt ...] --rounds 7 --iters 40
 Prints median / min microseconds per setting."""
 import argparse
 import itertools
