@@ -259,11 +259,15 @@ __global__ __launch_bounds__(512) void hwgrad_ft_kernel(const HWGradK p) {
   int izs = border_index(p.dmin, d.Dg, d.border, okz);      // Da == 1: one source slice for the whole launch
   izs = min(max(izs, 0), d.Dg - 1);
   int tbv[TMAX];
-  for (int box = blockIdx.x; box < p.nboxes; box += gridDim.x) {
+  // twin batch: workgroups [0, gsplit) walk the first network's boxes, the rest the second's (its images follow, its sums go
+  // to its own slabs / dw + dw_delta); nboxes counts ONE network's boxes
+  const int net = (int)blockIdx.x >= p.gsplit ? 1 : 0;
+  const int gx = (int)blockIdx.x - net * p.gsplit, gnum = net ? (int)gridDim.x - p.gsplit : p.gsplit;
+  for (int box = gx; box < p.nboxes; box += gnum) {
     int b = box;
     const int bx = b % p.nbw; b /= p.nbw;
     const int by = b % p.nbh;
-    const int n = b / p.nbh;
+    const int n = b / p.nbh + net * p.nimg;
     const int oy0 = by * 16, ox0 = bx * 16;
     __syncthreads();   // tables visible / previous box consumed
     const char* a_n = p.a + ((((size_t)n * d.Ha + oy0) * d.Wa + ox0) * d.a_cs + d.a_co) * 2;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(512) void hwgrad_ft_kernel(const HWGradK p) {
         if (pp < d.P) {
           const size_t e = (size_t)pp * d.dw_ld + t * d.Q + q;
           if (p.ws) p.ws[(size_t)blockIdx.x * p.ws_stride + e] = acc[t][r];
-          else unsafeAtomicAdd(p.dw + e, acc[t][r]);
+          else unsafeAtomicAdd(p.dw + (size_t)net * p.dw_delta + e, acc[t][r]);
         }
       }
     }
@@ -688,10 +692,12 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
       return 0;
     }
   }
-  if (a2 || tw) return 0;                          // only the wide kernel merges two passes / takes twin batches
+  if (a2) return 0;                                // only the wide kernel merges two passes
+  const int nimg_ft = tw ? tw->n_split : d->N;     // images per network
+  if (tw && 2 * nimg_ft != d->N) return 0;
   // few taps, narrow on both sides (2-D W-folded k7 boundary convs): the (p, q)-split form
   if (enabled && gs_opt(GS_OPT_HWGRAD_FT) && d->si == 1 && d->T >= 2 && d->T <= 8 && d->Da == 1 && d->P <= 64 && d->Q <= 64 &&
-      ((d->P + 15) / 16) * ((d->Q + 15) / 16) <= 8 && (long long)d->N * ((d->Ha + 15) / 16) * ((d->Wa + 15) / 16) >= 512) {
+      ((d->P + 15) / 16) * ((d->Q + 15) / 16) <= 8 && (long long)nimg_ft * ((d->Ha + 15) / 16) * ((d->Wa + 15) / 16) >= 512) {
     int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
     for (int t = 0; t < d->T; ++t) {
       const int o[3] = {d->dd[t], d->dh[t], d->dw_[t]};
@@ -702,7 +708,7 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     k.HD = 1 + hi[0] - lo[0]; k.HH = k.BH + hi[1] - lo[1]; k.HW = k.BW + hi[2] - lo[2];
     k.dmin = lo[0]; k.hmin = lo[1]; k.wmin = lo[2];
     k.nbd = 1; k.nbh = (d->Ha + 15) / 16; k.nbw = (d->Wa + 15) / 16;
-    const long long nboxes = (long long)d->N * k.nbh * k.nbw;
+    const long long nboxes = (long long)nimg_ft * k.nbh * k.nbw;      // per network
     k.phalves = (d->P + 15) / 16;                  // np
     k.qchunks = (d->Q + 15) / 16;                  // nq
     k.tgroups = 1;
@@ -725,8 +731,12 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
       k.d = *d;
       // 512 = two co-resident workgroups per CU (<= 78 KB of LDS each): 61 + 12.6 us (kernel + slab reduction) against 69 + 7.4
       // with 256 and 81.6 + 6.1 for the im2col form (rocprofv3 averages over both k7 layers, profiles/r03_hwgrad_ft.txt)
-      const long long gmax = gs_opt(GS_OPT_HWGRAD_FT) > 1 ? gs_opt(GS_OPT_HWGRAD_FT) : 512;
+      long long gmax = gs_opt(GS_OPT_HWGRAD_FT) > 1 ? gs_opt(GS_OPT_HWGRAD_FT) : 512;
+      if (tw) gmax /= 2;                                         // (per network)
       const long long groups = nboxes < gmax ? nboxes : gmax;    // workgroups walking nboxes / groups boxes each
+      k.nimg = nimg_ft;
+      k.gsplit = (int)groups;
+      k.dw_delta = tw ? tw->dw_delta / 4 : 0;
       k.ws = ws;
       k.ws_stride = ws_stride;
       *handled = ws || plan_only ? (int)groups : 1;
@@ -737,11 +747,13 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         configured = true;
       }
-      hipLaunchKernelGGL((hwgrad_ft_kernel<8>), dim3((unsigned)groups), dim3(512), lds, static_cast<hipStream_t>(stream), k);
+      hipLaunchKernelGGL((hwgrad_ft_kernel<8>), dim3((unsigned)(groups * (tw ? 2 : 1))), dim3(512), lds,
+                         static_cast<hipStream_t>(stream), k);
       GS_CHECK_HIP(hipGetLastError());
       return 0;
     }
   }
+  if (tw) return 0;                                // hwgrad_kernel below has no twin form
   if (!enabled || d->si != 1 || d->P > 64 || d->Q > 64 || d->T < 9) return 0;
   if (d->Q > 32 && d->P > 16) return 0;            // wide on both sides: the im2col kernel is the better fit (measured)
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};

@@ -210,7 +210,11 @@ def test_twin_weight_gradient_of_the_residual_convs(hip_ops, case, pair):
     close_f32(runs[0][1], dref, "second network's gradient vs oracle", rel=2e-3)
 
 
-@pytest.mark.parametrize("case", IM2COL_CASES + [(ConvSpec("convT", 256, 128, 3, 2, 1, 1), 4, 32, 32)],
+@pytest.mark.parametrize("case", IM2COL_CASES + [
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 4, 32, 32),
+    # the W-folded k7 boundary convs: hwgrad_ft's twin form (workgroups split between the networks)
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 256, 256),
+    (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 256, 256)],
                          ids=lambda c: f"{c[0].kind}{c[0].cin}to{c[0].cout}_k{c[0].k}s{c[0].stride}_n{c[1]}")
 def test_twin_weight_gradient_on_the_im2col_kernel(hip_ops, case):
     """wgrad_kernel as a twin launch: each network's pixel range is split on its own and lands in its own gradient buffer
@@ -220,11 +224,9 @@ def test_twin_weight_gradient_on_the_im2col_kernel(hip_ops, case):
     low = make_layer(spec, (H, W), 7)[0]
     w = low.wgrad
     g = torch.Generator().manual_seed(8)
-    a_dims = low.out_dims if spec.kind == "conv" else (H, W)
-    g_dims = (H, W) if spec.kind == "conv" else low.out_dims
-    a = torch.randn(2 * N, *a_dims, w.P, generator=g).to(torch.bfloat16).to(dev)
-    gg = torch.randn(2 * N, *g_dims, w.Q, generator=g).to(torch.bfloat16).to(dev)
-    n = spec.P * spec.T * spec.Q
+    a = torch.randn(2 * N, w.Ha, w.Wa, w.P, generator=g).to(torch.bfloat16).to(dev)      # dense side, gathered side
+    gg = torch.randn(2 * N, w.Hg, w.Wg, w.Q, generator=g).to(torch.bfloat16).to(dev)
+    n = w.P * w.T * w.Q
     runs = []
     for _ in range(2):
         dw = torch.zeros(2, n, device=dev)
