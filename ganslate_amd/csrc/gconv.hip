@@ -663,7 +663,7 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
 // hstrip.hip: W-folded k7 boundary convs (vertical taps, <= 64 channels) out of a resident input strip
 int gs_hstrip_slots(const gs_gconv_desc* d);
 int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
-                  void* stream, int* handled);
+                  void* stream, int* handled, const gs_twin* tw);
 // hconvt.hip: the four parity classes of a stride-2 layer out of one halo-resident pass
 int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count);
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
@@ -720,9 +720,11 @@ extern "C" int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse*
   if (fuse) return fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy && gs_gconv_ring_slots(d) > 0;
   if (gs_hconv_slots(d)) return 0;
   if (gs_hconvw_slots(d) > 0) return 1;
-  // the im2col kernel picks the weight set per tile (tiles never straddle images) — unless a halo kernel without a twin form
-  // would take the halves (hstrip), or the halves would run split-K (few tiles, long K: kept, the caller owns that workspace)
-  if (!gs_opt(GS_OPT_GCONV_TWIN) || gs_hstrip_slots(d) > 0 || d->accumulate) return 0;
+  // the im2col kernel picks the weight set per tile (tiles never straddle images) — unless the halves would run split-K (few
+  // tiles, long K: kept, the caller owns that workspace)
+  if (d->accumulate) return 0;
+  if (gs_hstrip_slots(d) > 0) return 1;           // hstrip.hip picks the weight set per tile / per persistent workgroup
+  if (!gs_opt(GS_OPT_GCONV_TWIN)) return 0;
   gs_gconv_desc half = *d;
   half.N = d->N / 2;
   return splitk_plan(&half, pick_tile(&half), false) <= 1;
@@ -781,10 +783,8 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     }
     if (int rc = gs_hconvw_try(d, in, w_pack, bias, out, stats, tw, stream, &handled)) return rc;
     if (handled) return 0;
-    if (!tw) {
-      if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
-      if (handled) return 0;
-    }
+    if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled, tw)) return rc;
+    if (handled) return 0;
   }
   GS_REQUIRE(!tw || (!fuse && !ws), "gs_gconv_forward_twin: the fused / split-K launches have no twin form");
   const TileCfg tc = pick_tile(d);

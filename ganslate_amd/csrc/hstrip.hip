@@ -28,6 +28,9 @@ struct HStripK {
   float* stats;
   const char* zero;
   int tiles_y, tiles_x, hmin, span, dwc;   // span = rows of the input window beyond the tile (max dh - min dh)
+  int nsplit;                              // twin batch (gs_twin): images [nsplit, N) use the weights / bias w_delta /
+  long long w_delta, bias_delta;           // bias_delta bytes further on; gsplit: workgroups of the first network
+  int gsplit;                              // (persistent form: a workgroup keeps ONE network's weights in registers)
   int toff[8];                             // tap -> row offset inside the window (dh - hmin)
   gs_gconv_desc d;
 };
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void hstrip_kernel(const HStripK p) {
       const int q = inst * 64 + lane;
       const int r = q / rp1, piece = q - r * rp1;
       const bool ok = r < CO && r < d.w_rows && piece < rp1 - 2;
-      const char* src = ok ? p.w + ((size_t)r * d.Kp + piece * 8) * 2 : p.zero;
+      const char* src = ok ? p.w + (n >= p.nsplit ? p.w_delta : 0) + ((size_t)r * d.Kp + piece * 8) * 2 : p.zero;
       glds16(src, wl + inst * 1024);
     }
   }
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(256, 2) void hstrip_kernel(const HStripK p) {
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int co = i * 16 + fk * 4;
-    const f32x4 bia = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* bias_n = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) +
+                                                                  (n >= p.nsplit ? p.bias_delta : 0)) : nullptr;
+    const f32x4 bia = (bias_n && co < d.Co) ? *reinterpret_cast<const f32x4*>(bias_n + co) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 #pragma unroll
@@ -232,6 +237,12 @@ __global__ __launch_bounds__(256, 2) void hstripr_kernel(const HStripK p) {
     }
     ytab[e] = ok ? (unsigned short)v : (unsigned short)0x8000;
   }
+  // twin batch: workgroups [0, gsplit) serve the first network's images, the others the second's
+  const int net = (int)blockIdx.x >= p.gsplit ? 1 : 0;
+  const int gx = (int)blockIdx.x - net * p.gsplit, gnum = net ? (int)gridDim.x - p.gsplit : p.gsplit;
+  const char* wnet = p.w + (net ? p.w_delta : 0);
+  const float* bias_net = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) + (net ? p.bias_delta : 0))
+                                 : nullptr;
   // the layer's weights: fragment (t, kk, i) = rows i*16 + frow, k = t*CI + kk*32 + fk*8 .. + 8 of the [rows][Kp] pack
   bf16x8 wf[T][KK][TI];
 #pragma unroll
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void hstripr_kernel(const HStripK p) {
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         const int r = i * 16 + frow;
-        wf[t][kk][i] = r < d.w_rows ? *reinterpret_cast<const bf16x8*>(p.w + ((size_t)r * d.Kp + t * CI + kk * 32 + fk * 8) * 2)
+        wf[t][kk][i] = r < d.w_rows ? *reinterpret_cast<const bf16x8*>(wnet + ((size_t)r * d.Kp + t * CI + kk * 32 + fk * 8) * 2)
                                     : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
   // the strip pieces this thread stages of every tile
@@ -255,7 +266,9 @@ __global__ __launch_bounds__(256, 2) void hstripr_kernel(const HStripK p) {
     h_p[i] = (v < hpx && part < CI / 8) ? (hy << 8 | (v - hy * TC) << 4 | part) : -1;
   }
   const int per_img = p.tiles_y * p.tiles_x;
-  const int ntiles = d.N * per_img;
+  const int nimg_net = p.gsplit < (int)gridDim.x ? p.nsplit : d.N;       // images of this workgroup's network
+  const int tile0 = net * p.nsplit * per_img;                            // its first tile, its tile count
+  const int ntiles = tile0 + nimg_net * per_img;
   auto issue_strip = [&](int tile, char* buf) {
     const int n = tile / per_img, r = tile - n * per_img;
     const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
@@ -276,13 +289,13 @@ __global__ __launch_bounds__(256, 2) void hstripr_kernel(const HStripK p) {
   };
   __syncthreads();                                     // tables
   int cur = 0;
-  if ((int)blockIdx.x < ntiles) issue_strip(blockIdx.x, buf0);
+  if (tile0 + gx < ntiles) issue_strip(tile0 + gx, buf0);
   const bool want_stats = d.stats_slots > 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = tile0 + gx; tile < ntiles; tile += gnum) {
     char* buf = buf0 + (size_t)cur * bbytes;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's strip (and the previous tile's stores, older)
     __syncthreads();                                   // ... for every wave; the other buffer's slab has been read
-    if (tile + (int)gridDim.x < ntiles) issue_strip(tile + gridDim.x, buf0 + (size_t)(cur ^ 1) * bbytes);
+    if (tile + gnum < ntiles) issue_strip(tile + gnum, buf0 + (size_t)(cur ^ 1) * bbytes);
     const int n = tile / per_img, rr = tile - n * per_img;
     const int ty = rr / p.tiles_x, tx = rr - ty * p.tiles_x;
     const int oy0 = ty * TRr, ox0 = tx * TC;
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void hstripr_kernel(const HStripK p) {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int co = i * 16 + fk * 4;
-      const f32x4 bia = (p.bias && co < d.Co) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 bia = (bias_net && co < d.Co) ? *reinterpret_cast<const f32x4*>(bias_net + co) : f32x4{0.f, 0.f, 0.f, 0.f};
       float s1[4], s2[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) s1[r] = s2[r] = 0.f;
@@ -453,16 +466,21 @@ int launch_r(const HStripK& k, long long groups, int lds, hipStream_t st) {
 
 // statistics slots per image when the class runs here (one per 32 x 8 tile), 0 when it does not
 int gs_hstrip_slots(const gs_gconv_desc* d) {
-  const Plan h = plan(d);
+  gs_gconv_desc q = *d;
+  q.stats_slots = 1;            // the question is about a launch WITH statistics (the forms differ in their tile rows)
+  const Plan h = plan(&q);
   return h.ok ? ((d->Ho + h.tr - 1) / h.tr) * ((d->Wo + TC - 1) / TC) : 0;
 }
 
 int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
-                  void* stream, int* handled) {
+                  void* stream, int* handled, const gs_twin* tw) {
   *handled = 0;
   const Plan h = plan(d);
   if (!h.ok) return 0;
   HStripK k;
+  k.nsplit = tw ? tw->n_split : 0x7fffffff;
+  k.w_delta = tw ? tw->w_delta : 0;
+  k.bias_delta = tw ? tw->bias_delta : 0;
   k.in = static_cast<const char*>(in);
   k.w = static_cast<const char*>(w_pack);
   k.bias = bias;
@@ -478,8 +496,17 @@ int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   const long long blocks = (long long)d->N * k.tiles_y * k.tiles_x;
   hipStream_t st = static_cast<hipStream_t>(stream);
   *handled = 1;
+  k.gsplit = 0x7fffffff;
   if (h.regs) {
-    const long long groups = blocks < 512 ? blocks : 512;      // two persistent workgroups per CU
+    long long groups = blocks < 512 ? blocks : 512;            // two persistent workgroups per CU
+    if (tw) {                                                  // ... half of them per network
+      const long long per_net = (long long)tw->n_split * k.tiles_y * k.tiles_x;
+      groups = per_net < 256 ? per_net : 256;
+      k.gsplit = (int)groups;
+      groups *= 2;
+    } else {
+      k.gsplit = (int)groups;
+    }
     if (h.ci == 32) return launch_r<32, 64, 32>(k, groups, h.lds, st);
     return launch_r<64, 32, 16>(k, groups, h.lds, st);
   }

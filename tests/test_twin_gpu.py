@@ -105,6 +105,54 @@ def test_twin_forward_on_the_im2col_kernel(hip_ops, case):
     close_bf16(y_tw[:N], y_ref, "twin forward vs oracle")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 3, 64, 7, 1, 3, pad_mode="reflect", wfold="in"), 2, 256, 256),
+    (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 2, 256, 256),
+], ids=["stem", "out"])
+@pytest.mark.parametrize("regs", [0, 2])
+def test_twin_boundary_convs_on_the_strip_kernels(hip_ops, case, regs):
+    """hstrip.hip with a gs_twin — one tile per workgroup (weights chosen per tile) and the persistent register-weight form
+    (workgroups split between the networks; option value 2 takes every launch): forward and data gradient, with and
+    without statistics, bit for bit the two separate launches"""
+    spec, N, H, W = case
+    dev = hip_ops.device
+    low, _, bias_a, fpack_a, dpack_a = make_layer(spec, (H, W), 311)
+    _, _, bias_b, fpack_b, dpack_b = make_layer(spec, (H, W), 312)
+    default = hip_ops.get_option("hstrip_regs")
+    hip_ops.set_option("hstrip_regs", regs)
+    try:
+        g = torch.Generator().manual_seed(9)
+        for cls, pa, pb, ba, bb, with_stats in ((low.fwd[0], fpack_a, fpack_b, bias_a, bias_b, True),
+                                                (low.fwd[0], fpack_a, fpack_b, bias_a, bias_b, False),
+                                                (low.dgrad[0], dpack_a, dpack_b, None, None, False)):
+            if len(low.dgrad) != 1 and cls is low.dgrad[0]:
+                continue
+            assert hip_ops.twin_native(cls, 2 * N), "the strip kernels take twin batches"
+            x = torch.randn(2 * N, cls.Hi, cls.Wi, cls.Ci, generator=g).to(torch.bfloat16).to(dev)
+            packs = torch.stack([pa, pb]).to(dev)
+            biases = torch.stack([ba, bb]).to(dev) if ba is not None else None
+
+            def run(xs, pack, bias, n, twin=False):
+                slots = hip_ops.stat_slots(cls, n, twin=twin) if with_stats else 0
+                y = torch.zeros(n, cls.Ho, cls.Wo, cls.Co, dtype=torch.bfloat16, device=dev)
+                part = torch.zeros(max(n * slots * 2 * cls.Co, 1), dtype=torch.float32, device=dev)
+                hip_ops.gconv(cls, xs, pack, bias, y, stats=part if with_stats else None, stats_slots=slots)
+                # (per-image totals: a half of N images may run on another kernel — fewer tiles than the strip kernel's
+                # minimum — with other slots)
+                return y, (part.view(n, slots, 2, cls.Co).double().sum(1) if with_stats else part)
+            y_tw, p_tw = run(x, Twin(packs[0], packs[1]), Twin(biases[0], biases[1]) if biases is not None else None,
+                             2 * N, twin=True)
+            y_a, p_a = run(x[:N], packs[0], biases[0] if biases is not None else None, N)
+            y_b, p_b = run(x[N:], packs[1], biases[1] if biases is not None else None, N)
+            torch.cuda.synchronize()
+            assert torch.equal(y_tw[:N], y_a) and torch.equal(y_tw[N:], y_b), "twin launch differs from the two launches"
+            if with_stats:
+                want = torch.cat([p_a, p_b])
+                assert (p_tw - want).abs().max().item() <= 1e-5 * want.abs().max().item(), "statistics differ"
+    finally:
+        hip_ops.set_option("hstrip_regs", default)
+
+
 @pytest.mark.parametrize("persist", [1, 0])
 def test_many_tiles_per_workgroup_equal_one_tile_each(hip_ops, persist):
     """one network, batch 24 at the trunk shape: 768 tiles = three per workgroup in the persistent form (option
