@@ -209,9 +209,11 @@ class HipOps(TwinSplit):
             return None
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
-    def stat_slots(self, g: GConv, N: int, twin: bool = False) -> int:
-        """partial-statistics slots per image the kernel writes for this class at batch N"""
-        Nl = N // 2 if (twin and not self.twin_native(g, N)) else N
+    def stat_slots(self, g: GConv, N: int, twin: bool = False, multi: bool = False) -> int:
+        """partial-statistics slots per image the kernel writes for this class at batch N. multi: the class is one of
+        several output-parity classes of its layer (gconv_classes): a twin batch of those runs as two launches of N / 2
+        whatever a single-class launch of the same class would do"""
+        Nl = N // 2 if (twin and (multi or not self.twin_native(g, N))) else N
         return self.lib.gs_gconv_stat_slots(C.byref(self._gdesc(g, Nl, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
     # ---- convolution family -------------------------------------------------------------------------------

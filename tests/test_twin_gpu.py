@@ -153,6 +153,42 @@ def test_twin_boundary_convs_on_the_strip_kernels(hip_ops, case, regs):
         hip_ops.set_option("hstrip_regs", default)
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1, dims=3), 1, 16, 32, 32),    # 8 classes; N = 1 / 2 pick different pixel tiles
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1, dims=3), 1, 24, 24, 24),
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 3, 32, 32),                # 2-D: the halo-resident class kernel
+], ids=lambda c: f"{c[0].dims}d_{c[0].cin}to{c[0].cout}_n{c[1]}")
+def test_twin_batch_of_a_multi_class_layer(hip_ops, case):
+    """the output-parity classes of a transposed conv with a twin batch run as two launches of N images each: the statistics
+    slots must be planned for THAT batch (stat_slots(..., multi=True)) — a slot count taken from the 2N batch, whose launch
+    would pick another pixel tile, scrambles the statistics. Outputs and per-image totals against the two separate launches."""
+    spec, N, sizes = case[0], case[1], case[2:]
+    dev = hip_ops.device
+    low, _, bias_a, fpack_a, _ = make_layer(spec, sizes, 321)
+    _, _, bias_b, fpack_b, _ = make_layer(spec, sizes, 322)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2 * N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16).to(dev)
+    packs = torch.stack([fpack_a, fpack_b]).to(dev)
+    biases = torch.stack([bias_a, bias_b]).to(dev)
+
+    def run(xs, pack, bias, n, twin):
+        slots, offs = 0, []
+        for cls in low.fwd:
+            offs.append(slots)
+            slots += hip_ops.stat_slots(cls, n, twin=twin, multi=True)
+        y = torch.zeros(n, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+        part = torch.zeros(n * slots * 2 * spec.cout_p, dtype=torch.float32, device=dev)
+        hip_ops.gconv_classes(low.fwd, xs, pack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
+        return y, part.view(n, slots, 2, spec.cout_p).double().sum(1)
+    y_tw, s_tw = run(x, Twin(packs[0], packs[1]), Twin(biases[0], biases[1]), 2 * N, True)
+    y_a, s_a = run(x[:N], packs[0], biases[0], N, False)
+    y_b, s_b = run(x[N:], packs[1], biases[1], N, False)
+    torch.cuda.synchronize()
+    assert torch.equal(y_tw[:N], y_a) and torch.equal(y_tw[N:], y_b), "twin batch differs from the two launches"
+    want = torch.cat([s_a, s_b])
+    assert (s_tw - want).abs().max().item() <= 1e-5 * want.abs().max().item(), "statistics differ"
+
+
 @pytest.mark.parametrize("persist", [1, 0])
 def test_many_tiles_per_workgroup_equal_one_tile_each(hip_ops, persist):
     """one network, batch 24 at the trunk shape: 768 tiles = three per workgroup in the persistent form (option
