@@ -667,7 +667,8 @@ int gs_hstrip_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
 // hconvt.hip: the four parity classes of a stride-2 layer out of one halo-resident pass
 int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count);
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
-                     const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream);
+                     const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream,
+                     const gs_twin* tw = nullptr);
 
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
 
@@ -869,6 +870,30 @@ extern "C" int gs_gconv_forward_multi_fused(const gs_gconv_desc* const* descs, i
   GS_REQUIRE(fuse->fold == 0 && fuse->Dy <= 1 && fuse->Hy == d->Ho && fuse->Wy == d->Wo,
              "gs_gconv_forward_multi_fused: the consumer's tensor must be the unpadded output domain");
   return gs_hconvt_launch(descs, gs_hconvt_pattern(descs, count), in, w_packs, nullptr, out, nullptr, fuse, stream);
+}
+
+// Twin batches of a multi-class layer (gs_twin): the halo-resident class kernel (hconvt.hip) picks the packs per box.
+// gs_gconv_multi_twin_native: 1 when the layer — descs carry the whole batch of both networks — runs there;
+// gs_gconv_forward_multi_twin is that launch (fuse == NULL: gs_gconv_forward_multi, else gs_gconv_forward_multi_fused).
+extern "C" int gs_gconv_multi_twin_native(const gs_gconv_desc* const* descs, int32_t count) {
+  if (!descs || count < 1 || !descs[0] || (descs[0]->N & 1)) return 0;
+  return gs_hconvt_pattern(descs, count) >= 0;
+}
+extern "C" int gs_gconv_forward_multi_twin(const gs_gconv_desc* const* descs, int32_t count, const void* in,
+                                           const void* const* w_packs, const float* bias, void* out, float* stats,
+                                           const gs_gconv_fuse* fuse, const gs_twin* tw, void* stream) {
+  GS_REQUIRE(descs && w_packs && in && out && tw && count >= 1 && descs[0], "gs_gconv_forward_multi_twin: null argument");
+  GS_REQUIRE(2 * tw->n_split == descs[0]->N, "gs_gconv_forward_multi_twin: the two networks take the same number of images");
+  const int pat = gs_hconvt_pattern(descs, count);
+  GS_REQUIRE(pat >= 0, "gs_gconv_forward_multi_twin: this layer has no twin form (gs_gconv_multi_twin_native): run the halves");
+  if (fuse) {
+    GS_REQUIRE(fuse->y && fuse->mean_rstd && fuse->partial && !bias && !stats && gs_gconv_multi_fused_slots(descs, count) > 0,
+               "gs_gconv_forward_multi_twin: bad fused launch (contract of gs_gconv_forward_multi_fused)");
+    const gs_gconv_desc* d = descs[0];
+    GS_REQUIRE(fuse->fold == 0 && fuse->Dy <= 1 && fuse->Hy == d->Ho && fuse->Wy == d->Wo,
+               "gs_gconv_forward_multi_twin: the consumer's tensor must be the unpadded output domain");
+  }
+  return gs_hconvt_launch(descs, pat, in, w_packs, bias, out, stats, fuse, stream, tw);
 }
 
 // ---- merged launch over the output-parity classes of one layer ---------------------------------------------------------

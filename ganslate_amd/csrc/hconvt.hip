@@ -30,6 +30,8 @@ struct HConvTK {
   int tb[16];                  // halo byte offset of K-step s of a chunk (tap offset relative to the window's corner)
   int wtap[16];                // tap index inside its class of K-step s (k offset = wtap * Ci + chunk * 64)
   int tiles_m, tiles_n, nbw, hmin, wmin, chunks;
+  int nsplit;                  // twin batch (gs_twin): images [nsplit, N) take the packs / bias w_delta / bias_delta bytes
+  long long w_delta, bias_delta;   // further on (a box never straddles images)
   gs_gconv_desc d;             // class 0's descriptor (shared fields)
   gs_gconv_fuse f;             // fused != 0: the reduction pass of the consumer's InstanceNorm backward rides in the epilogue
   int fused;                   // (gs_gconv_forward_multi_fused; contract of gs_gconv_forward_fused, one slot per box)
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
   b /= p.tiles_n;
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
+  const char* wnet = p.w + (n >= p.nsplit ? p.w_delta : 0);
   const int oy0 = (mt / p.nbw) * 16, ox0 = (mt % p.nbw) * 16;      // class-grid coordinates of the box
 
   // ---- halo pieces of this thread: source byte offset of channel chunk 0, or -1 (zero border) ----
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
     const int c = cls_of<PAT>(s);
     int wr = wrow0;
     asm volatile("" : "+v"(wr));                             // keep the 18 per-step addresses out of loop-invariant registers
-    const char* base = p.w + (p.w_off[c] + ((long long)p.wtap[s] * d.Ci + chunk * 64) * 2);
+    const char* base = wnet + (p.w_off[c] + ((long long)p.wtap[s] * d.Ci + chunk * 64) * 2);
 #pragma unroll
     for (int i = 0; i < WPI; ++i)
       glds16(base + (unsigned)(((wr + i * 8) * p.kp[c] + wpiece * 8) * 2), wring + stage * WT + (wave * WPI + i) * 1024);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
     const int c = ks / NS, s = ks - c * NS;
     // (runtime s: the class tables are indexed dynamically here, three times per launch)
     const int cl = PAT == 0 ? (s < 1 ? 0 : (s < 3 ? 1 : (s < 5 ? 2 : 3))) : (s >> 2);
-    const char* base = p.w + (p.w_off[cl] + ((long long)p.wtap[s] * d.Ci + c * 64) * 2);
+    const char* base = wnet + (p.w_off[cl] + ((long long)p.wtap[s] * d.Ci + c * 64) * 2);
 #pragma unroll
     for (int i = 0; i < WPI; ++i)
       glds16(base + (unsigned)(((wrow0 + i * 8) * p.kp[cl] + wpiece * 8) * 2), wring + (pr % 3) * WT + (wave * WPI + i) * 1024);
@@ -234,7 +237,9 @@ __global__ __launch_bounds__(512) void hconvt_kernel(const HConvTK p) {
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int co = nt * BN + wn * 32 + i * 16 + fk * 4;
-    bia[i] = (!PLAIN && !FUSED && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* bias_n = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) +
+                                                                  (n >= p.nsplit ? p.bias_delta : 0)) : nullptr;
+    bia[i] = (!PLAIN && !FUSED && bias_n) ? *reinterpret_cast<const f32x4*>(bias_n + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool want_stats = !FUSED && !PLAIN && d.stats_slots > 0;
   float s1[TI][4], s2[TI][4];
@@ -438,9 +443,12 @@ int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count) {
 }
 
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
-                     const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream) {
+                     const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream, const gs_twin* tw) {
   const gs_gconv_desc* d = descs[0];
   HConvTK k;   // a plain local: autograd issues launches from its own host threads
+  k.nsplit = tw ? tw->n_split : 0x7fffffff;
+  k.w_delta = tw ? tw->w_delta : 0;
+  k.bias_delta = tw ? tw->bias_delta : 0;
   k.in = static_cast<const char*>(in);
   k.w = static_cast<const char*>(w_packs[0]);
   k.bias = bias;

@@ -100,6 +100,9 @@ _PROTOS = {
     "gs_gconv_twin_native": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p]),
     "gs_gconv_forward_twin": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.POINTER(Twin), C.c_void_p]),
+    "gs_gconv_multi_twin_native": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gs_gconv_forward_multi_twin": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "gs_wgrad_pair": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "gs_wgrad": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

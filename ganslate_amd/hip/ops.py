@@ -192,7 +192,8 @@ class HipOps(TwinSplit):
         if len(classes) != 4 or g.Co != C_ or os.environ.get("GS_FUSE_NORM", "1") == "0" or \
                 os.environ.get("GS_FUSE_MULTI", "1") == "0":
             return None
-        arr, _ = self._multi_descs(classes, N // 2 if twin else N, g.Ci, g.Co)     # (no twin form: two launches)
+        Nl = N // 2 if (twin and not self.multi_twin_native(classes, N)) else N      # the batch of the launch(es)
+        arr, _ = self._multi_descs(classes, Nl, g.Ci, g.Co)
         slots = self.lib.gs_gconv_multi_fused_slots(arr, len(classes))
         if slots <= 0:
             return None
@@ -209,11 +210,28 @@ class HipOps(TwinSplit):
             return None
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
 
-    def stat_slots(self, g: GConv, N: int, twin: bool = False, multi: bool = False) -> int:
-        """partial-statistics slots per image the kernel writes for this class at batch N. multi: the class is one of
-        several output-parity classes of its layer (gconv_classes): a twin batch of those runs as two launches of N / 2
-        whatever a single-class launch of the same class would do"""
-        Nl = N // 2 if (twin and (multi or not self.twin_native(g, N))) else N
+    def multi_twin_native(self, classes, N: int) -> bool:
+        """a twin batch of N images over the output-parity classes of one layer runs as ONE launch (the halo-resident class
+        kernel picks the packs per box, gs_gconv_multi_twin_native) — else as two launches of N / 2"""
+        if os.environ.get("GS_TWIN_NATIVE", "1") == "0" or os.environ.get("GS_TWIN_MULTI", "1") == "0" or N % 2:
+            return False
+        g = classes[0]
+        key = ("multi_twin", tuple(id(c) for c in classes), N)
+        v = self._desc_cache.get(key)
+        if v is None:
+            arr, _ = self._multi_descs(classes, N, g.Ci, g.Co)
+            v = bool(self.lib.gs_gconv_multi_twin_native(arr, len(classes)))
+            self._desc_cache[key] = v
+        return v
+
+    def stat_slots(self, g: GConv, N: int, twin: bool = False, multi=None) -> int:
+        """partial-statistics slots per image the kernel writes for this class at batch N. multi: the classes of the layer
+        when g is one of several output-parity classes (gconv_classes): a twin batch of those runs as ONE launch where
+        multi_twin_native says so and as two launches of N / 2 otherwise, whatever a single-class launch of g would do"""
+        if twin and multi:
+            Nl = N if self.multi_twin_native(multi, N) else N // 2
+        else:
+            Nl = N // 2 if (twin and not self.twin_native(g, N)) else N
         return self.lib.gs_gconv_stat_slots(C.byref(self._gdesc(g, Nl, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
 
     # ---- convolution family -------------------------------------------------------------------------------
@@ -274,6 +292,24 @@ class HipOps(TwinSplit):
                               stats_slots=stats_slots, stats_slot0=(stats_slot0s[0] if stats_slot0s else 0),
                               accumulate=accumulate)
         if is_twin(wpack, bias):
+            N2 = x.shape[0]
+            if isinstance(wpack, Twin) and not accumulate and in_co == 0 and out_co == 0 and \
+                    self.multi_twin_native(classes, N2):
+                # the class kernel picks the packs per box: one launch over both networks' images
+                descs = [self._gdesc(g, N2, x.shape[-1], 0, out.shape[-1], 0, act, float(slope), stats_slots,
+                                     (stats_slot0s[i] if stats_slot0s else 0)) for i, g in enumerate(classes)]
+                arr = (C.POINTER(L.GConvDesc) * len(descs))(*[C.pointer(d) for d in descs])
+                ws = (C.c_void_p * len(classes))(*[wpack.a.data_ptr() + 2 * g.pack_offset for g in classes])
+                tw = L.Twin()
+                tw.n_split, tw.w_delta = N2 // 2, wpack.delta()
+                tw.bias_delta = bias.delta() if isinstance(bias, Twin) else 0
+                b0 = bias.a if isinstance(bias, Twin) else bias
+                f = self._fuse_struct(fuse) if fuse is not None else None
+                L.check(self.lib.gs_gconv_forward_multi_twin(arr, len(classes), _ptr(x), ws, _ptr(None if f is not None else b0),
+                                                             _ptr(out), _ptr(None if f is not None else stats),
+                                                             C.byref(f) if f is not None else None, C.byref(tw), _stream()),
+                        "gs_gconv_forward_multi_twin")
+                return
             return self.twin_gconv(functools.partial(self.gconv_classes, classes), x, wpack, bias, out, in_co=in_co,
                                    out_co=out_co, act=act, slope=slope, stats=stats, stats_slots=stats_slots,
                                    stats_slot0s=stats_slot0s, accumulate=accumulate, fuse=fuse, C_=classes[0].Co)

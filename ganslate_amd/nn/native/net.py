@@ -546,7 +546,7 @@ class NativeNet:
                 slots, offs = 0, []
                 for g in lw.fwd:
                     offs.append(slots)
-                    slots += ops.stat_slots(g, N, twin=tw is not None, multi=len(lw.fwd) > 1)
+                    slots += ops.stat_slots(g, N, twin=tw is not None, multi=lw.fwd if len(lw.fwd) > 1 else None)
                 part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=dev)
                 ops.gconv_classes(lw.fwd, acts[-1], fpack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
                 mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=dev)

@@ -170,6 +170,14 @@ int gs_gconv_ring_slots(const gs_gconv_desc* d);
  * 512 tiles for 256 CUs and every workgroup walks two of them, the second tile's operands arriving under the first one's
  * K loop (csrc/hconvw.hip). */
 int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse* fuse);
+/* The same for the output-parity classes of one layer (gs_gconv_forward_multi / _multi_fused): native where the classes run on
+ * the halo-resident class kernel (2-D k3 / k4 stride-2 layers with 64-multiple channels, csrc/hconvt.hip), which picks the
+ * packs per 16 x 16 box; the descriptors carry the whole batch of both networks. fuse == NULL: bias / stats as in
+ * gs_gconv_forward_multi; else the contract of gs_gconv_forward_multi_fused (bias = stats = NULL). */
+int gs_gconv_multi_twin_native(const gs_gconv_desc* const* descs, int32_t count);
+int gs_gconv_forward_multi_twin(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
+                                const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, const gs_twin* tw,
+                                void* stream);
 int gs_gconv_forward_twin(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
                           float* stats, const gs_gconv_fuse* fuse, const gs_twin* tw, void* stream);
 /* Same launch as gs_gconv_forward with a caller-owned fp32 workspace for split-K: layers with few output tiles and a

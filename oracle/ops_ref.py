@@ -90,7 +90,7 @@ class RefOps(TwinSplit):
     def tile_m(self, g, N=1):
         return 1 << 30  # one statistics slot per class
 
-    def stat_slots(self, g, N=1, twin=False, multi=False):
+    def stat_slots(self, g, N=1, twin=False, multi=None):
         return 1
 
     def fused_norm_plan(self, g, N, C_, force=False, twin=False):

@@ -156,8 +156,10 @@ def test_twin_boundary_convs_on_the_strip_kernels(hip_ops, case, regs):
 @pytest.mark.parametrize("case", [
     (ConvSpec("convT", 256, 128, 3, 2, 1, 1, dims=3), 1, 16, 32, 32),    # 8 classes; N = 1 / 2 pick different pixel tiles
     (ConvSpec("convT", 128, 64, 3, 2, 1, 1, dims=3), 1, 24, 24, 24),
-    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 3, 32, 32),                # 2-D: the halo-resident class kernel
-], ids=lambda c: f"{c[0].dims}d_{c[0].cin}to{c[0].cout}_n{c[1]}")
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 3, 32, 32),                # 2-D, small grid: two launches
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 4, 64, 64),                # 2-D: the halo-resident class kernel, ONE launch
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 2, 128, 128),
+], ids=lambda c: f"{c[0].dims}d_{c[0].cin}to{c[0].cout}_n{c[1]}_{c[2]}")
 def test_twin_batch_of_a_multi_class_layer(hip_ops, case):
     """the output-parity classes of a transposed conv with a twin batch run as two launches of N images each: the statistics
     slots must be planned for THAT batch (stat_slots(..., multi=True)) — a slot count taken from the 2N batch, whose launch
@@ -175,11 +177,13 @@ def test_twin_batch_of_a_multi_class_layer(hip_ops, case):
         slots, offs = 0, []
         for cls in low.fwd:
             offs.append(slots)
-            slots += hip_ops.stat_slots(cls, n, twin=twin, multi=True)
+            slots += hip_ops.stat_slots(cls, n, twin=twin, multi=low.fwd)
         y = torch.zeros(n, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
         part = torch.zeros(n * slots * 2 * spec.cout_p, dtype=torch.float32, device=dev)
         hip_ops.gconv_classes(low.fwd, xs, pack, bias, y, stats=part, stats_slots=slots, stats_slot0s=offs)
         return y, part.view(n, slots, 2, spec.cout_p).double().sum(1)
+    if spec.dims == 2 and sizes[0] >= 64:
+        assert hip_ops.multi_twin_native(low.fwd, 2 * N), "the class kernel takes this twin batch as one launch"
     y_tw, s_tw = run(x, Twin(packs[0], packs[1]), Twin(biases[0], biases[1]), 2 * N, True)
     y_a, s_a = run(x[:N], packs[0], biases[0], N, False)
     y_b, s_b = run(x[N:], packs[1], biases[1], N, False)
