@@ -718,7 +718,10 @@ extern "C" int gs_gconv_forward_fused(const gs_gconv_desc* d, const void* in, co
 // ---- twin batches (gs_twin): which launches pick the weight set per image ------------------------------------------------
 extern "C" int gs_gconv_twin_native(const gs_gconv_desc* d, const gs_gconv_fuse* fuse) {
   if (!d) return 0;
-  if (fuse) return fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy && gs_gconv_ring_slots(d) > 0;
+  if (fuse) {
+    if (fuse->fold > 0 && d->Do == fuse->Dy && d->Ho == fuse->Hy && d->Wo == fuse->Wy) return gs_gconv_ring_slots(d) > 0;
+    return gs_opt(GS_OPT_GCONV_TWIN) != 0;        // padded-domain fused launch: always the im2col kernel (no split-K there)
+  }
   if (gs_hconv_slots(d)) return 0;
   if (gs_hconvw_slots(d) > 0) return 1;
   // the im2col kernel picks the weight set per tile (tiles never straddle images) — unless the halves would run split-K (few
@@ -752,10 +755,9 @@ static int gconv_forward_fused_impl(const gs_gconv_desc* d, const void* in, cons
     GS_REQUIRE(in && w_pack && out && !bias, "gs_gconv_forward_fused: null argument / bias on a data-gradient launch");
     return gs_hconvw_ring(d, in, w_pack, out, fuse, tw, stream);
   }
-  GS_REQUIRE(!tw, "gs_gconv_forward_twin: the padded-domain fused launch has no twin form");
   GS_REQUIRE(d->Do == fuse->Dy + 2 * fd && d->Ho == fuse->Hy + 2 * fuse->fold && d->Wo == fuse->Wy + 2 * fuse->fold,
              "gs_gconv_forward_fused: output domain must be the norm's domain padded by `fold`");
-  return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, nullptr, 0, stream);
+  return gconv_forward_impl(d, in, w_pack, bias, out, stats, fuse, nullptr, 0, stream, tw);
 }
 
 static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
@@ -787,7 +789,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     if (int rc = gs_hstrip_try(d, in, w_pack, bias, out, stats, stream, &handled, tw)) return rc;
     if (handled) return 0;
   }
-  GS_REQUIRE(!tw || (!fuse && !ws), "gs_gconv_forward_twin: the fused / split-K launches have no twin form");
+  GS_REQUIRE(!tw || !ws, "gs_gconv_forward_twin: the split-K launch has no twin form");
   const TileCfg tc = pick_tile(d);
   GConvK k;
   if (fuse) k.f = *fuse; else k.f = gs_gconv_fuse{};

@@ -140,12 +140,18 @@ class HipOps(TwinSplit):
     # LAUNCH. A twin batch of N images is one launch of N where the kernel picks the weight set per image
     # (gs_gconv_twin_native) and two launches of N / 2 otherwise; the planning calls below take `twin` and answer for the
     # launches that will actually run, while their buffers are sized for all N images.
-    def twin_native(self, g: GConv, N: int, ring: bool = False) -> bool:
+    def twin_native(self, g: GConv, N: int, ring: bool = False, fused: bool = False) -> bool:
+        """ring: the fused data gradient on the unpadded domain (hconvw RING); fused: the padded-domain fused launch"""
         if os.environ.get("GS_TWIN_NATIVE", "1") == "0":
             return False
         d = self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
         if ring:
             return self.lib.gs_gconv_ring_slots(C.byref(d)) > 0
+        if fused:
+            if os.environ.get("GS_TWIN_FUSED", "1") == "0":
+                return False
+            f = L.GConvFuse()           # (fold 0 on a padded output domain: not the ring form)
+            return bool(self.lib.gs_gconv_twin_native(C.byref(d), C.byref(f)))
         return bool(self.lib.gs_gconv_twin_native(C.byref(d), None))
 
     def fused_norm_plan(self, g: GConv, N: int, C_: int, force: bool = False, twin: bool = False):
@@ -155,7 +161,7 @@ class HipOps(TwinSplit):
             return None
         if g.si == 2 and os.environ.get("GS_FUSE_SI2", "1") == "0":     # (A/B switch: data gradients of transposed convs)
             return None
-        Nl = N // 2 if twin else N         # (the padded-domain fused launch has no twin form: two launches)
+        Nl = N // 2 if (twin and not self.twin_native(g, N, fused=True)) else N        # the batch of the launch(es)
         d = self._gdesc(g, Nl, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
         if self._splitk_floats(d) and not force:   # few output tiles, long K: split-K wins over the fused epilogue
             return None
@@ -244,7 +250,8 @@ class HipOps(TwinSplit):
         if is_twin(wpack, bias):      # two networks' weights over one batch (nn/native/twin.py)
             f = self._fuse_struct(fuse) if fuse is not None else None
             ring = f is not None and f.fold > 0 and tuple(fuse["y"].shape[-3:-1]) == (g.Ho, g.Wo)
-            if isinstance(wpack, Twin) and (f is None or ring) and not accumulate and self.twin_native(g, N, ring=ring):
+            if isinstance(wpack, Twin) and not accumulate and \
+                    self.twin_native(g, N, ring=ring, fused=f is not None and not ring):
                 # the kernel picks the weight set per image: one launch over both networks' images
                 tw = L.Twin()
                 tw.n_split, tw.w_delta = N // 2, wpack.delta()
