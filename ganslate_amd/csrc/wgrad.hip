@@ -351,6 +351,12 @@ static inline void launch_slab_reduce(const float* ws, float* dst, long long n4,
   }
 }
 
+// (cout1.hip)
+void gs_launch_slab_reduce(const float* ws, float* dst, long long n4, int slabs, long long stride4, hipStream_t st, int nets,
+                           long long ws_y4, long long dw_y4) {
+  launch_slab_reduce(ws, dst, n4, slabs, stride4, st, nets, ws_y4, dw_y4);
+}
+
 // hwgrad.hip: halo-resident kernels for narrow stride-1 layers and the wide 3x3 layers
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
                    float* ws, int plan_only, void* stream, int* handled, const gs_twin* tw);

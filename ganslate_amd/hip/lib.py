@@ -178,6 +178,12 @@ _PROTOS = {
     "gs_scalar_affine": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32,
                                    C.c_void_p, C.c_void_p]),
     "gs_sum2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gs_conv_cout1_eligible": (C.c_int, [C.c_void_p]),
+    "gs_conv_cout1_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_wgrad_cout1_eligible": (C.c_int, [C.c_void_p]),
+    "gs_wgrad_cout1_ws_floats": (C.c_int64, [C.c_void_p]),
+    "gs_wgrad_cout1_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p]),
     "gs_tap_gather": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                 C.c_void_p]),
     "gs_tap_scatter_add": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

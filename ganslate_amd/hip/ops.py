@@ -131,6 +131,17 @@ class HipOps(TwinSplit):
             self._desc_cache[key] = n
         return n
 
+    def _cout1(self, d) -> bool:
+        """the dot-product kernels of the one-output-channel layer take this launch (GS_COUT1=0: A/B switch)"""
+        if os.environ.get("GS_COUT1", "1") == "0":
+            return False
+        key = ("cout1", id(d))
+        v = self._desc_cache.get(key)
+        if v is None:
+            v = bool(self.lib.gs_conv_cout1_eligible(C.byref(d)))
+            self._desc_cache[key] = v
+        return v
+
     def tile_m(self, g: GConv, N: int) -> int:
         """pixel-tile height the kernel will pick for this class at batch N (the choice depends on the grid size)"""
         return self.lib.gs_tile_m(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
@@ -147,6 +158,8 @@ class HipOps(TwinSplit):
         d = self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)
         if ring:
             return self.lib.gs_gconv_ring_slots(C.byref(d)) > 0
+        if not fused and getattr(g, "co_real", 0) == 1 and self._cout1(d):
+            return True
         if fused:
             if os.environ.get("GS_TWIN_FUSED", "1") == "0":
                 return False
@@ -247,6 +260,19 @@ class HipOps(TwinSplit):
         in_cs = in_cs if in_cs is not None else x.shape[-1]
         out_cs = out_cs if out_cs is not None else out.shape[-1]
         d = self._gdesc(g, N, in_cs, in_co, out_cs, out_co, act, float(slope), stats_slots, stats_slot0, accumulate)
+        if getattr(g, "co_real", 0) == 1 and fuse is None and stats is None and self._cout1(d):
+            # one output channel (the PatchGAN's last layer): the dot-product kernel on the vector ALUs (csrc/cout1.hip)
+            tw = None
+            if is_twin(wpack, bias):
+                tw = L.Twin()
+                tw.n_split, tw.w_delta = N // 2, wpack.delta()
+                tw.bias_delta = bias.delta() if isinstance(bias, Twin) else 0
+            w0 = wpack.a if isinstance(wpack, Twin) else wpack
+            b0 = bias.a if isinstance(bias, Twin) else bias
+            L.check(self.lib.gs_conv_cout1_forward(C.byref(d), _ptr(x), C.c_void_p(w0.data_ptr() + 2 * g.pack_offset),
+                                                   _ptr(b0), _ptr(out), C.byref(tw) if tw is not None else None, _stream()),
+                    "gs_conv_cout1_forward")
+            return
         if is_twin(wpack, bias):      # two networks' weights over one batch (nn/native/twin.py)
             f = self._fuse_struct(fuse) if fuse is not None else None
             ring = f is not None and f.fold > 0 and tuple(fuse["y"].shape[-3:-1]) == (g.Ho, g.Wo)
@@ -394,6 +420,25 @@ class HipOps(TwinSplit):
                 d.dh[i], d.dw_[i], d.dd[i] = p, q, r
             ent = (d, w)
             self._desc_cache[key] = ent
+        if getattr(w, "p_real", 0) == 1 and os.environ.get("GS_COUT1", "1") != "0" and \
+                os.environ.get("GS_WGRAD_DET", "1") != "0":
+            ckey = ("cout1_w", id(ent[0]))
+            nws = self._desc_cache.get(ckey)
+            if nws is None:
+                nws = int(self.lib.gs_wgrad_cout1_ws_floats(C.byref(ent[0])))
+                self._desc_cache[ckey] = nws
+            if nws > 0 and (not twin or dw.delta() % 16 == 0):
+                # one output channel: x[q] times the 4 x 4 patch of dy around q on the vector ALUs (csrc/cout1.hip)
+                tw = None
+                if twin:
+                    tw = L.Twin()
+                    tw.n_split, tw.dw_delta = a.shape[0] // 2, dw.delta()
+                dw0 = dw.a if twin else dw
+                for aa, gg in ((a, g),) + ((tuple(pair),) if pair is not None else ()):
+                    ws = torch.empty(nws, dtype=torch.float32, device=self.device)
+                    L.check(self.lib.gs_wgrad_cout1_ws(C.byref(ent[0]), _ptr(aa), _ptr(gg), _ptr(dw0), _ptr(ws), nws,
+                                                       C.byref(tw) if tw is not None else None, _stream()), "gs_wgrad_cout1_ws")
+                return
         if twin:      # both networks' images in one launch where the layer's kernel has the form, else the two halves
             wkey = ("wgrad_ws", id(ent[0]), pair is not None, "twin")
             nws = self._desc_cache.get(wkey)

@@ -118,6 +118,7 @@ class GConv:
     border: str
     pack_offset: int = 0          # element offset of this class's [w_rows][Kp] block in the layer's pack
     w_rows: int = 0
+    co_real: int = 0              # a Conv's forward class: output channels before padding to 8 (1: the PatchGAN's last layer)
     Di: int = 1
     Do: int = 1
     Dc: int = 1
@@ -146,6 +147,7 @@ class WGrad:
     Da: int = 1
     Dg: int = 1
     dd: Optional[List[int]] = None
+    p_real: int = 0               # a Conv's weight gradient: rows of the dense side before padding (its output channels)
 
     def __post_init__(self):
         if self.dd is None:
@@ -286,6 +288,10 @@ def lower(spec: ConvSpec, *sizes) -> Lowered:
             low.dgrad, low.dgrad_index = parity_classes(ins, spec.cin_p, spec.cout_p, m_tr, outs)
         dd, dh, dw = fwd_offs
         low.wgrad = WGrad(Ho, Wo, spec.cout_p, Hi, Wi, spec.cin_p, s, dh, dw, spec.pad_mode, Da=Do, Dg=Di, dd=dd)
+        if not spec.wfold:
+            low.wgrad.p_real = spec.cout
+            for g in low.fwd:
+                g.co_real = spec.cout
     else:
         assert s == 2 and spec.pad_mode == "zero", "ConvTranspose: stride 2, zero padding"
         # forward = parity classes; pack[co][t*cin+ci] = master[ci][t][co]

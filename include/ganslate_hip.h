@@ -492,6 +492,22 @@ int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const fl
 int gs_adam_step_dev_packs(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev, float grad_scale,
                            int32_t zero_grad, const int32_t* inv_f, void* fpack, const int32_t* inv_d, void* dpack,
                            void* stream);
+/* ---- the PatchGAN's last layer: Conv2d(8 ndf, 1, k4, s1, p1) (patchgan2d.py:62) — one output channel -------------------------
+ * A dot product per pixel: on the vector ALUs (v_dot2c_f32_bf16) with the filter in registers and a sliding 4 x 4 window of
+ * input pixels, instead of an eighth of an MFMA tile behind a 16-fold im2col gather (csrc/cout1.hip). Same descriptors,
+ * packs (row 0 is the filter; the other rows of the 8-row pack are zero) and results as gs_gconv_forward / gs_wgrad_ws for
+ * this layer: out channel 0 = conv + bias, channels 1..7 = 0; dw row 0 += the gradient (rows 1..7 belong to channels whose
+ * output gradient is zero). _eligible: 2-D, 16 taps forming a 4 x 4 grid, stride 1, zero border, Co = 8, Ci <= 512, no
+ * statistics / accumulate. tw may be NULL. Workspace of the weight gradient: gs_wgrad_cout1_ws_floats (-1: not eligible);
+ * partial sums per workgroup are added in a fixed order. */
+int gs_conv_cout1_eligible(const gs_gconv_desc* d);
+int gs_conv_cout1_forward(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out,
+                          const gs_twin* tw, void* stream);
+int gs_wgrad_cout1_eligible(const gs_wgrad_desc* d);
+int64_t gs_wgrad_cout1_ws_floats(const gs_wgrad_desc* d);
+int gs_wgrad_cout1_ws(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, float* ws, int64_t ws_floats,
+                      const gs_twin* tw, void* stream);
+
 /* ---- feature taps of CUT's PatchNCE loss (ganslate/nn/gans/unpaired/cut.py:229-312; FeaturePatchMLP.forward :262-277 reads
  * `feat.permute(0, 2, 3, 1).flatten(1, 2)[:, patch_id, :]` per level) ------------------------------------------------------------
  * ids_dev: int64 device array of P DISTINCT flat pixel indices (the head of a torch.randperm), shared by the n images.

@@ -974,6 +974,53 @@ def test_feature_tap_kernels(hip_ops):
               ref.image_tap_scatter(gi, pidp, tuple(x.shape), 3), "image tap scatter", rel=1e-6)
 
 
+@pytest.mark.parametrize("case", [(512, 4, 31, 31), (256, 3, 17, 20), (64, 2, 9, 33)], ids=lambda c: "x".join(map(str, c)))
+def test_one_output_channel_layer_on_the_vector_alus(hip_ops, case, monkeypatch):
+    """csrc/cout1.hip (the PatchGAN's Conv2d(C, 1, k4, s1, p1), patchgan2d.py:62): forward and weight gradient against the
+    oracle and against the matrix-core kernels of the same library (GS_COUT1=0), single network and twin batch"""
+    Ci, N, H, W = case
+    dev = hip_ops.device
+    spec = ConvSpec("conv", Ci, 1, 4, 1, 1)
+    low, _, bias_a, fpack_a, _ = make_layer(spec, (H, W), 61)
+    _, _, bias_b, fpack_b, _ = make_layer(spec, (H, W), 62)
+    g0, w = low.fwd[0], low.wgrad
+    assert g0.co_real == 1 and w.p_real == 1
+    g = torch.Generator().manual_seed(63)
+    x = torch.randn(2 * N, H, W, spec.cin_p, generator=g).to(torch.bfloat16)
+    gy = torch.zeros(2 * N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., 0] = torch.randn(2 * N, *low.out_dims, generator=g).to(torch.bfloat16)
+    packs, biases = torch.stack([fpack_a, fpack_b]).to(dev), torch.stack([bias_a, bias_b]).to(dev)
+
+    def run():
+        y1 = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+        hip_ops.gconv(g0, x[:N].to(dev), packs[0], biases[0], y1, act="none")
+        y2 = torch.zeros(2 * N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+        hip_ops.gconv(g0, x.to(dev), Twin(packs[0], packs[1]), Twin(biases[0], biases[1]), y2, act="none")
+        n = spec.P * spec.T * spec.Q
+        dw1 = torch.full((n,), 0.5, device=dev)
+        hip_ops.wgrad(w, gy[:N].to(dev), x[:N].to(dev), dw1)
+        dw2 = torch.zeros(2, n, device=dev)
+        hip_ops.wgrad(w, gy.to(dev), x.to(dev), Twin(dw2[0], dw2[1]), pair=(gy.to(dev), x.to(dev)))
+        torch.cuda.synchronize()
+        return y1.cpu(), y2.cpu(), dw1.cpu(), dw2.cpu()
+    from ganslate_amd.nn.native.twin import Twin
+    new = run()
+    monkeypatch.setenv("GS_COUT1", "0")
+    old = run()
+    ref = RefOps()
+    y_ref = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    ref.gconv(g0, x[:N], fpack_a, bias_a, y_ref, act="none")
+    dw_ref = torch.full((spec.P * spec.T * spec.Q,), 0.5)
+    ref.wgrad(w, gy[:N], x[:N], dw_ref)
+    for res, what in ((new, "vector-ALU kernels"), (old, "matrix-core kernels")):
+        close_bf16(res[0], y_ref, f"{what}: forward vs oracle")
+        close_f32(res[2], dw_ref, f"{what}: weight gradient vs oracle")
+    close_bf16(new[1], old[1], "twin forward: the two kernel families")
+    assert torch.equal(new[1][:N], new[0]), "twin forward: first network's half"
+    close_f32(new[3], old[3], "twin weight gradient (pair): the two kernel families", rel=2e-3)
+    assert not new[0][..., 1:].any() and not new[1][..., 1:].any(), "padding channels stay zero"
+
+
 def test_bias_gradient_of_a_channel_head(hip_ops):
     """gs_bias_grad_head_ws: the bias of a 3-channel (and a 12-channel) layer accumulates into exactly that many floats"""
     g = torch.Generator().manual_seed(4)
