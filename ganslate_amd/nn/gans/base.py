@@ -346,21 +346,42 @@ class BaseGAN(ABC):
         import torch.distributed as dist
         group = dp_nets[0]._dist
         world = dist.get_world_size(group)
-        forms = {"between": self._capture_graphs(dp_nets, "between"), "captured": self._capture_graphs(dp_nets, "captured")}
+        forms = {"between": self._capture_graphs(dp_nets, "between")}
         pools = [(p, p.images.clone()) for p in self._step_pools() if getattr(p, "images", None) is not None]
-        grads = {}
-        for name, (graph, _, _, _) in forms.items():
+
+        def replay(name):
             for net in dp_nets:
                 net.master.grad.zero_()
-            graph.replay()
+            forms[name][0].replay()
             if name == "between":
                 for net in dp_nets:
                     dist.all_reduce(net.master.grad, op=dist.ReduceOp.SUM, group=net._dist)
-            grads[name] = [net.master.grad.clone() for net in dp_nets]
+            out = [net.master.grad.clone() for net in dp_nets]
             for pool, saved in pools:
                 pool.images.copy_(saved)
+            return out
+        grads = {"between": replay("between")}
+        # the captured form is an offer, not a requirement: a runtime that cannot record or replay the collectives inside a
+        # graph (an exception, on every rank alike) leaves the run on the between form
+        failed = None
+        try:
+            forms["captured"] = self._capture_graphs(dp_nets, "captured")
+            grads["captured"] = replay("captured")
+        except Exception as e:      # noqa: BLE001 — whatever the runtime raises here, the other form is complete
+            failed = e
+            forms.pop("captured", None)
+            self._graph_broken = False
+            self._set_external_host_state(True)
+            torch.cuda.synchronize()
         for net in dp_nets:
             net.master.grad.zero_()
+        if failed is not None:
+            for pool, saved in pools:
+                pool.images.copy_(saved)
+            self.ddp_self_check = {"world": world, "forms_agree": False, "kept": "between", "error": str(failed)[:300]}
+            self.logger.warning(f"data-parallel self-check over {world} rank(s): the collectives could not be captured into the "
+                                f"step graph ({failed}); keeping the all-reduce between the two graphs")
+            return forms["between"]
         worst, scale = 0.0, 0.0
         for ga, gb in zip(grads["between"], grads["captured"]):
             worst = max(worst, (ga - gb).abs().max().item())

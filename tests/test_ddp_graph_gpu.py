@@ -73,6 +73,38 @@ def test_data_parallel_graph_step_matches_single_process(hip_ops, monkeypatch, r
         dist.destroy_process_group()
 
 
+def test_self_check_falls_back_when_the_collectives_cannot_be_captured(hip_ops, monkeypatch):
+    """a runtime that refuses to record the collectives inside a graph (simulated: the capture of that form raises, leaving
+    the state a failed capture leaves) must not take the run down: the all-reduce-between-graphs form is kept"""
+    import datetime
+    import torch.distributed as dist
+    from ganslate_amd.nn.gans.base import BaseGAN
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    c["pool_size"] = 3
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("GS_FORCE_DDP", "1")
+    real = BaseGAN._capture_graphs
+
+    def refusing(self, dp_nets, form):
+        if form == "captured":
+            self._graph_broken = True
+            self._set_external_host_state(False)
+            raise RuntimeError("simulated: collectives are not capturable")
+        return real(self, dp_nets, form)
+    monkeypatch.setattr(BaseGAN, "_capture_graphs", refusing)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            timeout=datetime.timedelta(minutes=2))
+    try:
+        ddp = build_product_cyclegan(c)
+        got = _run(ddp, c, 4)
+        assert ddp._graph is not None and ddp._graph_update is not None and not ddp._graph_collectives
+        assert ddp.ddp_self_check["kept"] == "between" and "simulated" in ddp.ddp_self_check["error"]
+        assert len(ddp._reduced_nets) == 4 and not ddp._graph_broken
+        assert all(v == v and abs(v) < 1e3 for s in got for v in s[0].values())
+    finally:
+        dist.destroy_process_group()
+
+
 # ---- two ranks over RCCL (runs the moment the box has >= 2 GPUs; the 1-GPU pool skips it) -----------------------------
 DDP_PATHS = {
     "launch_by_launch": {"GS_STEP_GRAPH": "0"},                     # bucketed all-reduce overlapped with the last backward pass
