@@ -140,3 +140,26 @@ extern "C" int gs_image_tap_scatter(const float* g, int32_t N, int32_t C, int32_
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- FastCUT's flip-equivariance coin (cut.py:146-152): x.flip(-1) or x, decided by a flag in DEVICE memory so that a captured
+// step replays either way ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flip_w_if_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int W,
+                                                        const int* __restrict__ flag) {
+  const bool f = flag[0] != 0;
+  const long long n = rows * W;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / W;
+    const int w = (int)(e - r * W);
+    out[e] = x[r * W + (f ? W - 1 - w : w)];
+  }
+}
+extern "C" int gs_flip_w_if(const float* x, float* out, int64_t rows, int32_t W, const int32_t* flag_dev, void* stream) {
+  GS_REQUIRE(x && out && flag_dev && rows > 0 && W > 0 && x != out, "gs_flip_w_if: bad argument (not in place)");
+  long long blocks = (rows * W + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(flip_w_if_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, out,
+                     (long long)rows, W, flag_dev);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+

@@ -190,6 +190,7 @@ _PROTOS = {
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_tap_rows_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_zero_bytes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "gs_flip_w_if": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gs_image_tap_gather": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_void_p]),
     "gs_image_tap_scatter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,

@@ -810,6 +810,14 @@ class HipOps(TwinSplit):
                 "gs_image_tap_scatter")
         return gx
 
+    def flip_w_if(self, x, flag):
+        """x.flip(-1) where the int32 device flag is set, x otherwise (a copy either way)"""
+        x = x.contiguous().float()
+        out = torch.empty_like(x)
+        L.check(self.lib.gs_flip_w_if(_ptr(x), _ptr(out), x.numel() // x.shape[-1], x.shape[-1], _ptr(flag), _stream()),
+                "gs_flip_w_if")
+        return out
+
     def sum2(self, a, b):
         out = torch.empty_like(a)
         L.check(self.lib.gs_sum2_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "gs_sum2_f32")

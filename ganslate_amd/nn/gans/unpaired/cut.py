@@ -49,13 +49,14 @@ class CUT(BaseGAN):
     # The launch sequence of an iteration is fixed once the patch ids are data: they are drawn on the host in the reference's
     # order before a replay and copied into static index tensors (see _prepare_host_state). With the round-2 kernels a CUT
     # iteration is ~17 ms of GPU work but ~22 ms of launch-by-launch enqueueing, so the captured step is what the GPU's
-    # pace is. `use_equivariance_flip` draws a host coin that changes the graph (a flip kernel or none): not captured.
+    # pace is. `use_equivariance_flip` (FastCUT) draws a host coin: the flip itself reads it from device memory
+    # (gs_flip_w_if) and the flipped target ids are prepared with the other host state, so the step is captured either way.
     graph_capturable = True
 
     def __init__(self, conf):
         super().__init__(conf)
-        self.graph_capturable = not conf.train.gan.use_equivariance_flip
         self.external_draw_ids, self._pid_static, self._nce_call = False, None, 0
+        self._flip_flag, self._tid_static = None, None
         opt = conf.train.gan.optimizer
         self.lambda_adv, self.lambda_nce, self.lambda_nce_idt = opt.lambda_adv, opt.lambda_nce, opt.lambda_nce_idt
         self.nce_layers = list(conf.train.gan.nce_layers)
@@ -116,11 +117,12 @@ class CUT(BaseGAN):
         real_A = self.visuals["real_A"]
         real_B = self.visuals["real_B"] if using_idt else None
         if self.use_equivariance_flip and self.is_train:
-            self.is_flipped = np.random.random() > 0.5
-            if self.is_flipped:
-                real_A = real_A.flip(-1)
-                if using_idt:
-                    real_B = real_B.flip(-1)
+            if not self.external_draw_ids:              # (a captured / replayed iteration drew it in _prepare_host_state)
+                self._draw_flip()
+            ops = self.networks["G"].ops
+            real_A = ops.flip_w_if(real_A, self._flip_flag)
+            if using_idt:
+                real_B = ops.flip_w_if(real_B, self._flip_flag)
         G = self.networks["G"]
         if using_idt and self._batched(G):
             # G(real_A) and G(real_B) as one pass over both batches (per-sample InstanceNorm: same images out); the trunk
@@ -208,14 +210,36 @@ class CUT(BaseGAN):
         super()._set_external_host_state(on)
         self.external_draw_ids = on
 
+    def _draw_flip(self):
+        """the iteration's coin (cut.py:147), kept on the host for the target ids and uploaded for the flip kernel"""
+        self.is_flipped = bool(np.random.random() > 0.5)
+        if self._flip_flag is None:
+            self._flip_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        host = torch.tensor([int(self.is_flipped)], dtype=torch.int32)
+        self._flip_flag.copy_(host.pin_memory() if self._flip_flag.is_cuda else host, non_blocking=True)
+
+    def _flipped_ids(self, ids, H, W):
+        """patch ids of the target features when the inputs were flipped along W (cut.py:213-215 flips the features back)"""
+        G, out = self.networks["G"], []
+        for e, pid in zip(self.nce_layers, ids):
+            w = G.tap_dims(e, H, W)[1]          # the generator knows its own feature widths
+            out.append((pid // w) * w + (w - 1 - pid % w))
+        return out
+
     def _prepare_host_state(self):
         super()._prepare_host_state()
+        if self.use_equivariance_flip and self.is_train:
+            self._draw_flip()
         H, W = self.visuals["real_A"].shape[-2:]
         drawn = [self.sample_patch_ids(H, W) for _ in range(self._nce_calls_per_step())]      # the step's own draw order
+        # (the targets' ids: the same, or mirrored along W when this iteration's inputs are flipped — data of static tensors
+        # either way, so the captured launches do not change)
+        tgt = [self._flipped_ids(c, H, W) if (self.use_equivariance_flip and self.is_flipped) else c for c in drawn]
         if self._pid_static is None or [[t.shape for t in c] for c in self._pid_static] != [[t.shape for t in c] for c in drawn]:
             self._pid_static = [[t.clone() for t in c] for c in drawn]
+            self._tid_static = [[t.clone() for t in c] for c in tgt]
         else:
-            for dst, src in zip(self._pid_static, drawn):
+            for dst, src in zip(self._pid_static + self._tid_static, drawn + tgt):
                 for d, t in zip(dst, src):
                     d.copy_(t)
         self._nce_call = 0
@@ -227,15 +251,14 @@ class CUT(BaseGAN):
         for source, _ in pairs:
             H, W = source.shape[-2:]
             if self.external_draw_ids:                        # captured / replayed iteration: ids are static tensors
-                ids = self._pid_static[self._nce_call]
+                ids, tids = self._pid_static[self._nce_call], self._tid_static[self._nce_call]
                 self._nce_call += 1
             else:
                 ids = self.sample_patch_ids(H, W)
+                # target features are flipped back along W before sampling (cut.py:214-215)
+                tids = self._flipped_ids(ids, H, W) if self.is_flipped else ids
             src_feats.append(G.extract_patch_features(source, self.nce_layers, ids, detached=True))
-            if self.is_flipped:       # target features are flipped back along W before sampling (cut.py:214-215)
-                ids = [(pid // G.tap_dims(e, H, W)[1]) * G.tap_dims(e, H, W)[1] + (G.tap_dims(e, H, W)[1] - 1 - pid % G.tap_dims(e, H, W)[1])
-                       for e, pid in zip(self.nce_layers, ids)]
-            tgt_ids.append(ids)
+            tgt_ids.append(tids)
         tgt_feats = G.extract_patch_features_parts([t for _, t in pairs], self.nce_layers, tgt_ids)
         return [mlp.nce_loss(tf, sf, source.shape[0], self.nce_T, self.lambda_nce)
                 for tf, sf, (source, _) in zip(tgt_feats, src_feats, pairs)]
@@ -243,18 +266,15 @@ class CUT(BaseGAN):
     def _calculate_nce_loss(self, source, target, patch_ids=None):
         G, mlp = self.networks["G"], self.networks["mlp"]
         H, W = source.shape[-2:]
+        tgt_ids = None
         if patch_ids is None and self.external_draw_ids:          # captured / replayed iteration: ids are static tensors
-            patch_ids = self._pid_static[self._nce_call]
+            patch_ids, tgt_ids = self._pid_static[self._nce_call], self._tid_static[self._nce_call]
             self._nce_call += 1
         ids = patch_ids if patch_ids is not None else self.sample_patch_ids(H, W)
         # (keys are detached in the loss: read out of this iteration's recorded pass over `source` where there is one)
         source_feats = G.extract_patch_features(source, self.nce_layers, ids, detached=True)
-        tgt_ids = ids
-        if self.is_flipped:       # target features are flipped back along W before sampling (cut.py:214-215)
-            tgt_ids = []
-            for e, pid in zip(self.nce_layers, ids):
-                w = G.tap_dims(e, H, W)[1]          # the generator knows its own feature widths
-                tgt_ids.append((pid // w) * w + (w - 1 - pid % w))
+        if tgt_ids is None:       # target features are flipped back along W before sampling (cut.py:214-215)
+            tgt_ids = self._flipped_ids(ids, H, W) if self.is_flipped else ids
         target_feats = G.extract_patch_features(target, self.nce_layers, tgt_ids)
         # both MLP passes, the logits, the cross-entropy and the mean over patches and levels: one autograd node
         return mlp.nce_loss(target_feats, source_feats, source.shape[0], self.nce_T, self.lambda_nce)

@@ -529,6 +529,9 @@ int gs_image_tap_gather(const float* x, int32_t N, int32_t C, int32_t H, int32_t
                         float* out, void* stream);
 int gs_image_tap_scatter(const float* g, int32_t N, int32_t C, int32_t H, int32_t W, int32_t pad, const int64_t* ids_dev,
                          int32_t P, float* gx, void* stream);
+/* FastCUT's flip-equivariance coin (cut.py:146-152: `real_A.flip(-1)` on a host coin): out = flag_dev[0] ? x.flip(-1) : x over
+ * [rows][W] fp32, the flag in device memory so that a captured step replays either way. Not in place. */
+int gs_flip_w_if(const float* x, float* out, int64_t rows, int32_t W, const int32_t* flag_dev, void* stream);
 
 /* ImagePool.query (ganslate/data/utils/image_pool.py:31-60) with the host's coin flips uploaded as code_dev[B]:
  * < 0 pass image b through; slot: store image b in `slot`, return it (pool filling); slot | 0x40000000: return the

@@ -246,6 +246,9 @@ class RefOps(TwinSplit):
             out[r] = acc
         return out
 
+    def flip_w_if(self, x, flag):
+        return x.flip(-1).contiguous() if int(flag.reshape(-1)[0]) else x.clone()
+
     def sum2(self, a, b):
         return a + b
 

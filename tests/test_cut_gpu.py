@@ -66,3 +66,31 @@ def test_cut_step_at_headline_shape_matches_reference_golden(hip_ops):
         for k, v in gold["steps"][s]["losses"].items():
             tol = step_tolerance(k, s, {"adv": 2e-2, "cycle": 2e-2})
             assert got[s]["losses"][k] == pytest.approx(v, rel=tol), (s, k, got[s]["losses"][k], v)
+
+
+def test_flip_equivariance_coin_is_data_of_the_captured_step(hip_ops, monkeypatch):
+    """FastCUT's `use_equivariance_flip` (cut.py:146-152, 213-215): the coin is drawn on the host per iteration, the flip of the
+    inputs reads it from device memory (gs_flip_w_if) and the mirrored target ids are prepared with the other host state,
+    so the step is captured — and must equal the launch-by-launch run, iteration by iteration, for a coin sequence that has
+    both outcomes."""
+    import numpy as np
+    x = torch.randn(2, 3, 5, 7, device=hip_ops.device)
+    for f in (0, 1):
+        flag = torch.tensor([f], dtype=torch.int32, device=hip_ops.device)
+        assert torch.equal(hip_ops.flip_w_if(x, flag), x.flip(-1) if f else x)
+    c = load_golden_cut()["cut_64"]["config"]
+    runs = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("GS_STEP_GRAPH", graph)
+        np.random.seed(7)
+        torch.manual_seed(c["seed"])
+        model = build_product_cut(c, extra=("train.gan.use_equivariance_flip=true",))
+        assert model.use_equivariance_flip and model.graph_capturable
+        got, flips = run_product_cut_steps(model, c, 5), []
+        runs[graph] = got
+        assert (model._graph is not None) == (graph == "1")
+    coins = np.random.RandomState(7).random_sample(5) > 0.5
+    assert coins.any() and not coins.all(), "pick a seed with both outcomes"
+    for s, (a, b) in enumerate(zip(runs["1"], runs["0"])):
+        for k in b:
+            assert a[k] == pytest.approx(b[k], rel=2e-3, abs=1e-5), (s, k)
