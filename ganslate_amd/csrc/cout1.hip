@@ -193,7 +193,9 @@ extern "C" int gs_wgrad_cout1_eligible(const gs_wgrad_desc* d) {
   int hh, ww;
   return d->si == 1 && d->Da == 1 && d->Dg == 1 && d->P == 8 && d->Q % 8 == 0 && d->Q <= 512 && d->Ha <= 32 && d->Wa <= 32 &&
          d->border == GS_BORDER_ZERO && d->dw_ld == d->T * d->Q && cout1_grid(d->dh, d->dw_, d->T, &hh, &ww) &&
-         hh >= -3 && hh <= 0 && ww >= -3 && ww <= 0;
+         hh >= -3 && hh <= 0 && ww >= -3 && ww <= 0 &&
+         // a wave per input row: below half a chip of workgroups (batch 1-2) the matrix-core kernel's pixel split is ahead
+         (long long)d->N * ((d->Hg + 3) / 4) >= 128;
 }
 // 4 input rows per workgroup = one per wave (8 rows left half of the chip idle at batch 16-32: 57 -> 3x us)
 static constexpr int kCout1Rows = 4;
