@@ -34,20 +34,27 @@ __global__ __launch_bounds__(256) void zero16_kernel(uint4* p, long long n16) {
     p[i] = uint4{0u, 0u, 0u, 0u};
 }
 
-// db[ch] += sum over rows of g[row][ch] (fixed order): the bias gradient a tap of a RAW conv output carries
-__global__ __launch_bounds__(256) void tap_rows_sum_kernel(const float* __restrict__ g, long long rows, int c, float* db) {
-  __shared__ float red[8][33];
+// db[ch] += sum over rows of g[row][ch] (fixed order): the bias gradient a tap of a RAW conv output carries. 32 row lanes x 32
+// channels per workgroup, four rows in flight per lane (8 row lanes walking 2048 rows one load at a time took 66 us)
+__global__ __launch_bounds__(1024) void tap_rows_sum_kernel(const float* __restrict__ g, long long rows, int c, float* db) {
+  __shared__ float red[32][33];
   const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int ch = blockIdx.x * 32 + lane;
   float s = 0.f;
-  if (ch < c)
-    for (long long r = part; r < rows; r += 8) s += g[r * c + ch];
+  if (ch < c) {
+    long long r = part;
+    for (; r + 96 < rows; r += 128) {
+      const float a0 = g[r * c + ch], a1 = g[(r + 32) * c + ch], a2 = g[(r + 64) * c + ch], a3 = g[(r + 96) * c + ch];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; r < rows; r += 32) s += g[r * c + ch];
+  }
   red[part][lane] = s;
   __syncthreads();
   if (part == 0 && ch < c) {
     float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][lane];
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) t += red[k][lane];
     db[ch] += t;
   }
 }
@@ -86,7 +93,7 @@ extern "C" int gs_zero_bytes(void* p, int64_t bytes, void* stream) {
 
 extern "C" int gs_tap_rows_sum(const float* g, int64_t rows, int32_t c, float* db, void* stream) {
   GS_REQUIRE(g && db && rows > 0 && c > 0, "gs_tap_rows_sum: bad argument");
-  hipLaunchKernelGGL(tap_rows_sum_kernel, dim3((unsigned)((c + 31) / 32)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
+  hipLaunchKernelGGL(tap_rows_sum_kernel, dim3((unsigned)((c + 31) / 32)), dim3(1024), 0, static_cast<hipStream_t>(stream), g,
                      (long long)rows, c, db);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
