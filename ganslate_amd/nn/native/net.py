@@ -25,6 +25,7 @@ from .twin import Twin
 
 
 import os
+import weakref
 _BWD_ORDER = os.environ.get("GS_BWD_ORDER", "1") != "0"
 
 
@@ -71,7 +72,7 @@ def attention_extras(prefix: str, C: int, dims: int = 3) -> List["Extra"]:
 
 
 class _Saved:
-    __slots__ = ("x_img", "acts", "ys", "mrs", "out_img", "lows", "N", "attn")
+    __slots__ = ("x_img", "acts", "ys", "mrs", "out_img", "lows", "N", "attn", "__weakref__")
 
 
 class NativeNet:
@@ -327,15 +328,19 @@ class NativeNet:
             self._recent_passes = {}
         if len(self._recent_passes) >= 4:
             self._recent_passes.pop(next(iter(self._recent_passes)))
-        self._recent_passes[(x.data_ptr(), tuple(x.shape))] = (x._version, saved, n0)
+        # (a weak reference: the autograd node owns the pass; remembering it must not keep its activations alive past the
+        # backward pass — the V-Net executors do not clear theirs, and use_memory_saving exists to hold less, not more)
+        self._recent_passes[(x.data_ptr(), tuple(x.shape))] = (x._version, weakref.ref(saved), n0)
 
     def recorded_pass(self, x):
         """(saved state, first image) of a recorded full pass that contained exactly this tensor (same storage, shape and
         version) and whose activations are still alive, or None"""
         ent = getattr(self, "_recent_passes", {}).get((x.data_ptr(), tuple(x.shape)))
-        if ent is None or ent[0] != x._version or ent[1].acts is None or any(a is None for a in ent[1].acts):
+        saved = ent[1]() if ent is not None else None
+        acts = getattr(saved, "acts", None)
+        if saved is None or ent[0] != x._version or acts is None or any(a is None for a in acts):
             return None
-        return ent[1], ent[2]
+        return saved, ent[2]
 
     def refresh_packs(self, x):
         """bring the bf16 packs for inputs shaped like x up to date now (on the current stream), so that passes launched
