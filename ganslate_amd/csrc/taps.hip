@@ -112,17 +112,29 @@ __global__ __launch_bounds__(64) void image_tap_gather_kernel(const float* __res
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x)
     out[((size_t)n * P + p) * C + ch] = x[(((size_t)n * C + ch) * H + y) * W + xx];
 }
-// gx[n][ch][y][x] += g[n][p][ch] through the same map (gx zeroed by the caller; padded positions that reflect onto one
-// pixel add up: fp32 atomics, a handful of collisions among P samples)
+// gx[n][ch][y][x] += g[n][p][ch] through the same map (gx zeroed by the caller). Padded positions that reflect onto one
+// pixel (up to 4) add up in SAMPLE ORDER: the first sample of a pixel owns it and adds its later colliders itself, the others
+// leave — no atomics, so two runs (and the two reduction forms of the data-parallel self-check) agree bit for bit.
 __global__ __launch_bounds__(64) void image_tap_scatter_kernel(float* gx, int C, int H, int W, int pad,
                                                                const long long* __restrict__ ids, int P,
                                                                const float* __restrict__ g) {
+  extern __shared__ int tap_tgt[];          // [P] target pixel of every sample
   const int p = blockIdx.x, n = blockIdx.y, Wp = W + 2 * pad;
-  const long long id = ids[p];
-  const int yp = (int)(id / Wp), xp = (int)(id - (long long)yp * Wp);
-  const int y = reflect_idx(yp - pad, H), xx = reflect_idx(xp - pad, W);
-  for (int ch = threadIdx.x; ch < C; ch += blockDim.x)
-    unsafeAtomicAdd(gx + (((size_t)n * C + ch) * H + y) * W + xx, g[((size_t)n * P + p) * C + ch]);
+  for (int q = threadIdx.x; q < P; q += blockDim.x) {
+    const long long id = ids[q];
+    const int yp = (int)(id / Wp), xp = (int)(id - (long long)yp * Wp);
+    tap_tgt[q] = reflect_idx(yp - pad, H) * W + reflect_idx(xp - pad, W);
+  }
+  __syncthreads();
+  const int mine = tap_tgt[p];
+  for (int q = 0; q < p; ++q)
+    if (tap_tgt[q] == mine) return;          // (block-uniform) an earlier sample owns this pixel
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    float acc = g[((size_t)n * P + p) * C + ch];
+    for (int q = p + 1; q < P; ++q)
+      if (tap_tgt[q] == mine) acc += g[((size_t)n * P + q) * C + ch];
+    gx[((size_t)n * C + ch) * H * W + mine] = acc;
+  }
 }
 
 extern "C" int gs_image_tap_gather(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t pad,
@@ -135,14 +147,15 @@ extern "C" int gs_image_tap_gather(const float* x, int32_t N, int32_t C, int32_t
 }
 extern "C" int gs_image_tap_scatter(const float* g, int32_t N, int32_t C, int32_t H, int32_t W, int32_t pad,
                                     const int64_t* ids_dev, int32_t P, float* gx, void* stream) {
-  GS_REQUIRE(g && ids_dev && gx && N > 0 && C > 0 && H > pad && W > pad && pad >= 0 && P > 0, "gs_image_tap_scatter: bad argument");
+  GS_REQUIRE(g && ids_dev && gx && N > 0 && C > 0 && H > pad && W > pad && pad >= 0 && P > 0 && P <= 16384,
+             "gs_image_tap_scatter: bad argument");
   const long long bytes = (long long)N * C * H * W * 4;
   if (bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0) {
     if (int rc = gs_zero_bytes(gx, bytes, stream)) return rc;
   } else {
     GS_CHECK_HIP(hipMemsetAsync(gx, 0, (size_t)bytes, static_cast<hipStream_t>(stream)));
   }
-  hipLaunchKernelGGL(image_tap_scatter_kernel, dim3((unsigned)P, (unsigned)N), dim3(64), 0, static_cast<hipStream_t>(stream), gx,
+  hipLaunchKernelGGL(image_tap_scatter_kernel, dim3((unsigned)P, (unsigned)N), dim3(64), (size_t)P * 4, static_cast<hipStream_t>(stream), gx,
                      C, H, W, pad, reinterpret_cast<const long long*>(ids_dev), P, g);
   GS_CHECK_HIP(hipGetLastError());
   return 0;

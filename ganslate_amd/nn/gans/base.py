@@ -209,6 +209,10 @@ class BaseGAN(ABC):
             if hasattr(net, "prepare_host_state"):
                 net.prepare_host_state()
 
+    def _rewind_host_state(self):
+        """re-arm the per-step host cursors over what _prepare_host_state drew (no new draws): the same iteration is
+        about to be recorded again"""
+
     def _graph_set_input(self, input):
         self._eager_set_input(input)
         if self._graph is not None:
@@ -236,6 +240,7 @@ class BaseGAN(ABC):
 
     def _replay(self):
         self._graph.replay()
+        self._mark_replayed_updates()
         if self._graph_update is not None:       # data parallel: sum the flat gradients, then the optimiser launches
             import torch.distributed as dist
             timing = getattr(self, "reduce_timing", None)      # bench.py: [(event, event)] around the exposed reduction
@@ -248,6 +253,15 @@ class BaseGAN(ABC):
                 e1.record()
                 timing.append((e0, e1))
             self._graph_update.replay()
+
+    def _mark_replayed_updates(self):
+        """a replay moved the masters behind the host's back: the packs an eager pass (validation, inference) between two
+        replays finds are a mix — row-major groups written by the captured fused Adam, transposed segments and leftover
+        groups from the start of that replay. Tell the executors, so that such a pass refreshes what the update did not."""
+        for optim in self.optimizers.values():
+            mark = getattr(optim, "mark_updated", None)
+            if mark is not None:
+                mark()
 
     def _capture_step(self):
         """Record this iteration's launches (capture does not execute them), then run it as the first replay.
@@ -288,6 +302,7 @@ class BaseGAN(ABC):
     def _capture_graphs(self, dp_nets, form):
         """-> (step graph, update graph or None, (visuals, losses, metrics) of the recorded step, form)"""
         pending = [] if dp_nets else None
+        self._rewind_host_state()            # (the self-check records the step twice on one set of draws)
         for optim in self.optimizers.values():
             optim.deferred_to = pending
         for net in dp_nets:
@@ -363,16 +378,27 @@ class BaseGAN(ABC):
         grads = {"between": replay("between")}
         # the captured form is an offer, not a requirement: a runtime that cannot record or replay the collectives inside a
         # graph (an exception, on every rank alike) leaves the run on the between form
+        # a rank decides locally whether its capture worked (an out-of-memory condition hits one rank, not all), so the
+        # ranks AGREE on the outcome before any of them replays a graph that holds collectives: a rank that fell back
+        # would sit in the between form's all-reduce while the others wait inside the captured one.
         failed = None
         try:
             forms["captured"] = self._capture_graphs(dp_nets, "captured")
-            grads["captured"] = replay("captured")
-        except Exception as e:      # noqa: BLE001 — whatever the runtime raises here, the other form is complete
+        except Exception as e:      # noqa: BLE001
+            if isinstance(e.__cause__, _HOST_LOGIC_ERRORS):      # a bug in the recipe's host code is not "not capturable"
+                raise
             failed = e
             forms.pop("captured", None)
             self._graph_broken = False
             self._set_external_host_state(True)
             torch.cuda.synchronize()
+        flag = torch.tensor([0.0 if failed is not None else 1.0], device=dp_nets[0].master.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() != 1.0 and failed is None:
+            failed = RuntimeError("another rank could not capture the collectives")
+            forms.pop("captured", None)
+        if failed is None:
+            grads["captured"] = replay("captured")
         for net in dp_nets:
             net.master.grad.zero_()
         if failed is not None:
@@ -477,6 +503,9 @@ class BaseGAN(ABC):
     def get_loggable_data(self):
         learning_rates = {f"lr_{name}": optim.param_groups[0]["lr"] for name, optim in self.optimizers.items()}
         return learning_rates, self.losses, self.visuals, self.metrics
+
+
+_HOST_LOGIC_ERRORS = (IndexError, KeyError, TypeError, AttributeError, AssertionError, NameError, ValueError)
 
 
 def _is_native_optimizer_state(state, optim):

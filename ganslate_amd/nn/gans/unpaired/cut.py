@@ -244,6 +244,10 @@ class CUT(BaseGAN):
                     d.copy_(t)
         self._nce_call = 0
 
+    def _rewind_host_state(self):
+        super()._rewind_host_state()
+        self._nce_call = 0          # (the static id tensors keep this iteration's draws)
+
     def _calculate_nce_losses(self, pairs):
         """_calculate_nce_loss for several (source, target) pairs with ONE encoder pass over all targets"""
         G, mlp = self.networks["G"], self.networks["mlp"]

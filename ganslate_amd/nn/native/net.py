@@ -178,7 +178,7 @@ class NativeNet:
                 flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = ex.init
         with torch.no_grad():
             self.master.copy_(flat.to(self.device))
-        self._packs_dirty = True
+        self.mark_packs_dirty()
 
     def attn_tensors(self, prefix, grad=False):
         """the SelfAttentionBlock `prefix`'s parameters (or their gradients) as views of the flat buffer, keyed like
@@ -228,7 +228,7 @@ class NativeNet:
             flat[self.x_off[ex.name]:self.x_off[ex.name] + ex.size] = sd[ex.name].detach().float().cpu().reshape(-1)
         with torch.no_grad():
             self.master.copy_(flat.to(self.device))
-        self._packs_dirty = True
+        self.mark_packs_dirty()
 
     def grads_state_dict(self) -> Dict[str, torch.Tensor]:
         """gradients in torch layout (for parity tests / inspection)."""
@@ -790,7 +790,7 @@ class NativeNet:
         self._dist = process_group if process_group is not None else dist.group.WORLD
         with torch.no_grad():
             dist.broadcast(self.master.data, 0, group=self._dist)
-        self._packs_dirty = True
+        self.mark_packs_dirty()
         # buckets = contiguous [start, end) element ranges of whole layers, built from the LAST layer backwards. The Extras at
         # the tail of the flat buffer (SelfAttentionBlock parameters, whose gradients are written by the block's backward on
         # an EARLIER node's output than the bucket boundary suggests) are a bucket of their own that no layer triggers:

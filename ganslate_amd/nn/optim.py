@@ -68,6 +68,16 @@ class NativeAdam(torch.optim.Optimizer):
                 else:
                     net.mark_packs_dirty()
 
+    def mark_updated(self):
+        """a captured launch() was replayed: same host bookkeeping as launch(), no launches"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                net = p._owner_net
+                if p.grad is None:
+                    continue
+                tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
+                net.mark_packs_dirty(**({"ident_fresh": tgt[0]} if tgt else {}))
+
     def state_dict(self):
         sd = super().state_dict()       # the hyper vectors are derived state: rebuilt by the next prepare()
         sd["state"] = {k: {kk: vv for kk, vv in st.items() if kk != "hyper"} for k, st in sd["state"].items()}

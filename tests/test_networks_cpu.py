@@ -331,3 +331,36 @@ def test_selfattention_vnet3d_forward_backward(fp32_oracle_backend, inverse):
                 assert grads[n].abs().max().item() <= 1e-4 * shadow.get_parameter(n.replace("key", "query")).grad.abs().max().item()
                 continue
             assert (p.grad - grads[n]).abs().max().item() <= tol * scale + 1e-7, (n, memory_saving)
+
+
+def test_load_state_dict_after_an_optimiser_step_refreshes_every_pack(fp32_oracle_backend):
+    """the fused Adam launch marks the row-major pack groups as written by itself (ident_fresh); a
+    master write from OUTSIDE (load_state_dict, init_weights, the data-parallel broadcast) must drop that mark, or the
+    next pass skips those groups and runs on the pre-load weights."""
+    from ganslate_amd.nn.generators import Resnet2D
+    from ganslate_amd.nn.optim import NativeAdam
+    net = Resnet2D(3, 3, "instance", 2)
+    sd0 = torch_ref.seeded_state_dict(torch_ref.Resnet2D(3, 3, 2), 77)
+    net.load_state_dict(sd0)
+    x = torch.rand((1, 3, 32, 32), generator=torch.Generator().manual_seed(5)) * 2 - 1
+    with torch.no_grad():
+        y0 = net(x).clone()
+    opt = NativeAdam(net.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    for _ in range(2):
+        net(x).square().mean().backward()
+        opt.step()
+    # (no pass between the update and the load: a pass would refresh the packs and clear the mark by itself)
+    net.load_state_dict(sd0)
+    fresh = Resnet2D(3, 3, "instance", 2)
+    fresh.load_state_dict(sd0)
+    with torch.no_grad():
+        assert torch.equal(net(x), fresh(x)) and torch.equal(net(x), y0)
+    net(x).square().mean().backward()
+    opt.step()
+    # the same through init_weights: a re-initialised network computes with the re-drawn weights
+    torch.manual_seed(3)
+    net.init_weights()
+    torch.manual_seed(3)
+    fresh.init_weights()
+    with torch.no_grad():
+        assert torch.equal(net(x), fresh(x))
