@@ -9,6 +9,7 @@ namespace {
 thread_local char g_err[512] = "";   // per host thread: autograd runs backward launches on its own threads, and a caller
                                       // reads the message right after the failing call on the thread that made it
 void* g_zero = nullptr;      // 256-byte zero page: source of masked LDS-DMA lanes
+void* g_dump = nullptr;      // 256 writable bytes nobody reads
 // Loss reductions: 1024 partials + 1 arrival counter per workspace. Launches on one stream are ordered and share a
 // workspace; launches on different streams may overlap (the discriminator pass runs beside the generators' backward),
 // so every stream that ever launched a reduction owns one of GS_WS_SLOTS workspaces.
@@ -27,6 +28,7 @@ void gs_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const void* gs_zero_page() { return g_zero; }
+void* gs_dump_page() { return g_dump; }
 float* gs_reduce_workspace(void* stream) {
   if (!g_reduce_ws) return nullptr;
   std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -69,6 +71,10 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hstrip_regs", 1},         // hstrip.hip: persistent form with the weights in registers for the k7 boundary convs (0: one tile per workgroup)
     {"gconv_twin", 1},          // gconv.hip: twin batches on the im2col kernel as one launch (0: the two halves as two launches)
     {"wgrad_twin", 1},          // wgrad.hip: twin batches on the im2col weight-gradient kernel as one launch (0: two launches)
+    {"gconv_smallk", 0},        // gconv.hip: layers with at most this many K-steps take 128 x 128 tiles on 8 waves (two workgroups per
+                                // CU overlap each other's prologue / epilogue) instead of one 256 x 128 tile per CU; 0 = off
+    {"gconv_persist", 16},      // pconv.hip: 256 x 128 im2col launches with more tiles than CUs and at most this many K-steps run as
+                                // persistent workgroups (the K-step stream continues across tiles); 0 = off
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }
@@ -94,6 +100,7 @@ extern "C" int gs_init(int device) {
     GS_CHECK_HIP(hipMalloc(&g_zero, 256));
     GS_CHECK_HIP(hipMemset(g_zero, 0, 256));
   }
+  if (!g_dump) GS_CHECK_HIP(hipMalloc(&g_dump, 256));
   if (!g_reduce_ws) {
     GS_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_reduce_ws), GS_WS_SLOTS * GS_WS_FLOATS * sizeof(float)));
     GS_CHECK_HIP(hipMemset(g_reduce_ws, 0, GS_WS_SLOTS * GS_WS_FLOATS * sizeof(float)));
@@ -107,5 +114,6 @@ extern "C" int gs_init(int device) {
 
 extern "C" void gs_shutdown(void) {
   if (g_zero) { (void)hipFree(g_zero); g_zero = nullptr; }
+  if (g_dump) { (void)hipFree(g_dump); g_dump = nullptr; }
   if (g_reduce_ws) { (void)hipFree(g_reduce_ws); g_reduce_ws = nullptr; g_ws_used = 0; }
 }

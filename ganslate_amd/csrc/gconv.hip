@@ -20,45 +20,7 @@
 #include "common.hpp"
 #include <cstdlib>
 
-// What differs between the output-parity classes of one stride-2 transposed conv / stride-2 data gradient (same tensors,
-// same class extent, same Co): weight block, taps, output phase, statistics slot. Up to 8 classes (3-D) of up to 8 taps
-// ride in one launch (gs_gconv_forward_multi): workgroup -> (class, image, pixel tile, channel tile).
-constexpr int GS_MULTI_MAX_CLS = 8, GS_MULTI_MAX_TAPS = 8;
-struct GConvCls {
-  long long w_off;             // byte offset of this class's [w_rows][Kp] block from GConvK::w
-  int T, Kp, pz, py, px, stats_slot0, nh, nw;
-  signed char ud[GS_MULTI_MAX_TAPS], uh[GS_MULTI_MAX_TAPS], uw[GS_MULTI_MAX_TAPS];
-  unsigned char tap_h[GS_MULTI_MAX_TAPS], tap_w[GS_MULTI_MAX_TAPS];
-};
-
-struct GConvK {
-  const char* in;
-  const char* w;
-  const float* bias;
-  char* out;
-  float* stats;
-  const char* zero;
-  int tiles_m, tiles_n, ci_shift;
-  float rcp_wc, rcp_hc;
-  // taps factored into distinct (depth, row) / column offsets (every lowering produces a product grid of taps)
-  int nh, nw;
-  signed char ud[64], uh[64], uw[16];
-  unsigned char tap_h[GS_MAX_TAPS], tap_w[GS_MAX_TAPS];
-  gs_gconv_fuse f;             // f.partial != nullptr: first pass of the consumer's InstanceNorm backward in the epilogue
-  int fuse_slots;
-  // split-K (few output tiles, long K: the deep U-Net / PatchGAN-tail layers): workgroup (tile, sp) runs K-steps
-  // [sp*nk/splits, (sp+1)*nk/splits) and writes raw fp32 sums to partial[sp][output pixel][Co]; gconv_splitk_finalize
-  // adds them up and applies the usual epilogue
-  int splits;
-  float* partial;
-  long long split_stride;      // floats per split = N * Do*Ho*Wo * Co
-  // twin batch (gs_twin): images [nsplit, N) read the weight pack / bias w_delta / bias_delta bytes further on
-  int nsplit;
-  long long w_delta, bias_delta;
-  int n_cls;                   // > 0: merged launch over cls[0..n_cls) (their fields replace the per-class ones of p / d)
-  GConvCls cls[GS_MULTI_MAX_CLS];
-  gs_gconv_desc d;
-};
+#include "gconv.hpp"
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
@@ -585,10 +547,14 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
 
 // ---- host side ------------------------------------------------------------------------------------
 namespace {
-struct TileCfg { int bm, bn; };
+struct TileCfg { int bm, bn; int waves = 16; };
 TileCfg pick_tile(const gs_gconv_desc* d) {
   if (d->Co <= 16) return {256, 16};
   if (d->Co <= 64) return {128, 64};
+  // few K-steps: a tile's fixed cost (tables, ring fill, epilogue) is most of its time, and one 150-KB workgroup per CU pays it
+  // in series. 128 x 128 tiles on 8 waves need 64 KB and <= 128 registers: two workgroups per CU, one's loop under the other's
+  // prologue / epilogue (the 16-wave 128 x 128 tile holds 96 registers per lane: one workgroup per CU whatever its LDS)
+  if ((d->Kp >> 6) <= gs_opt(GS_OPT_GCONV_SMALLK)) return {128, 128, 8};
   // big tile (8 waves, 3 stages, 1 workgroup per CU) once it still fills the chip; else the 4-wave 128x128 tile
   const long long pix = (long long)d->Dc * d->Hc * d->Wc;
   const long long big = (long long)d->N * ((pix + 255) / 256) * ((d->Co + 127) / 128);
@@ -642,6 +608,7 @@ int launch(const GConvK& k, int blocks, hipStream_t st) {
 int launch_tile(const TileCfg& tc, const GConvK& k, int blocks, hipStream_t st) {
   if (tc.bn == 16) return launch<256, 16, 8, 1, 2>(k, blocks, st);
   if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, blocks, st);
+  if (tc.bm == 128 && tc.waves == 8) return launch<128, 128, 2, 4, 2>(k, blocks, st);
   if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, blocks, st);
   if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, blocks, st);
   if (tc.bm == 288) return launch<288, 128, 6, 2, 2>(k, blocks, st);
@@ -669,6 +636,9 @@ int gs_hconvt_pattern(const gs_gconv_desc* const* descs, int count);
 int gs_hconvt_launch(const gs_gconv_desc* const* descs, int pat, const void* in, const void* const* w_packs,
                      const float* bias, void* out, float* stats, const gs_gconv_fuse* fuse, void* stream,
                      const gs_twin* tw = nullptr);
+// pconv.hip: persistent form of the 256 x 128 im2col tile for launches of several tiles per CU with a short K loop
+bool gs_pconv_eligible(const GConvK& k, bool fused);
+int gs_pconv_launch(const GConvK& k, bool fused, hipStream_t st);
 
 extern "C" int gs_tile_m(const gs_gconv_desc* d) { return pick_tile(d).bm; }
 
@@ -850,6 +820,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     GS_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  if (tc.bm == 256 && tc.bn == 128 && gs_pconv_eligible(k, fuse != nullptr)) return gs_pconv_launch(k, fuse != nullptr, st);
   return launch_tile(tc, k, (int)blocks, st);
 }
 

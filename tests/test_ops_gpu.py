@@ -1484,3 +1484,102 @@ def test_self_attention_block_forward_backward(hip_ops, B, dims, C):
             assert got.norm().item() <= 5e-2 * pr["bq"].grad.norm().item(), (got.norm().item(), pr["bq"].grad.norm().item())
             continue
         assert rel(got, pr[k].grad) <= 3e-2, (k, rel(got, pr[k].grad))
+
+
+PERSIST_CASES = [       # (spec, images, H, W): launches of several 256 x 128 tiles per CU with a short K loop
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 16, 256, 256),            # d128 at a twin batch: 1024 tiles, 9 K-steps
+    (ConvSpec("conv", 128, 256, 3, 2, 1), 16, 128, 128),           # d256: 512 tiles, two channel tiles, 18 K-steps
+    (ConvSpec("conv", 64, 128, 4, 2, 1), 32, 128, 128),            # PatchGAN k4 stride 2: 16 K-steps
+    (ConvSpec("conv", 256, 512, 4, 1, 1), 20, 32, 32),             # 31 x 31 outputs: ragged last tile of every image, 64 K-steps
+    (ConvSpec("conv", 64, 192, 3, 2, 1), 10, 200, 168),            # Co not a multiple of 128, ragged pixel tiles, uneven tile counts
+    (ConvSpec("conv", 64, 128, 3, 1, 1, pad_mode="reflect"), 2, 200, 264),     # reflect border, rows wider than a tile
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=_ids)
+def test_persistent_im2col_kernel(hip_ops, case):
+    """pconv.hip: workgroups that walk several tiles with the K-step stream running on across tiles must give, bit for bit,
+    the outputs AND statistics slots of the one-tile-per-workgroup kernel (same tile, same K order, same summation order) —
+    single batches and twin batches (weights / bias per image) — and agree with the oracle."""
+    from ganslate_amd.nn.native.twin import Twin
+    spec, N, H, W = case
+    dev = hip_ops.device
+    low, _, bias_a, fpack_a, _ = make_layer(spec, (H, W), 701)
+    _, _, bias_b, fpack_b, _ = make_layer(spec, (H, W), 702)
+    g0 = low.fwd[0]
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(N, H, W, g0.Ci, generator=g).to(torch.bfloat16).to(dev)
+    packs = torch.stack([fpack_a, fpack_b]).to(dev)
+    biases = torch.stack([bias_a, bias_b]).to(dev)
+    default = hip_ops.get_option("gconv_persist")
+
+    def run(persist, twin, act, with_stats):
+        hip_ops.set_option("gconv_persist", persist)
+        slots = hip_ops.stat_slots(g0, N, twin=twin) if twin else hip_ops.stat_slots(g0, N)
+        y = torch.full((N, *low.out_dims, g0.Co), 7.0, dtype=torch.bfloat16, device=dev)
+        part = torch.full((N * slots * 2 * g0.Co,), float("nan"), dtype=torch.float32, device=dev)
+        pack, bias = (Twin(packs[0], packs[1]), Twin(biases[0], biases[1])) if twin else (packs[0], biases[0])
+        if with_stats:
+            hip_ops.gconv(g0, x, pack, bias, y, act=act, stats=part, stats_slots=slots)
+        else:
+            hip_ops.gconv(g0, x, pack, bias, y, act=act)
+        torch.cuda.synchronize()
+        return y, part
+    try:
+        for twin in (False, True):
+            if twin and not hip_ops.twin_native(g0, N):
+                continue
+            for act, with_stats in (("none", True), ("lrelu", False), ("relu", True)):
+                y0, p0 = run(0, twin, act, with_stats)
+                y1, p1 = run(1000, twin, act, with_stats)
+                assert torch.equal(y0, y1), (twin, act, "outputs differ from the one-tile-per-workgroup kernel")
+                if with_stats:
+                    assert not torch.isnan(p1).any() and torch.equal(p0, p1), (twin, act, "statistics slots differ")
+        y_ref = torch.zeros(N, *low.out_dims, g0.Co, dtype=torch.bfloat16)
+        RefOps().gconv(g0, x.cpu(), fpack_a, bias_a, y_ref)
+        y1, _ = run(1000, False, "none", False)
+        close_bf16(y1, y_ref, "persistent kernel vs oracle")
+    finally:
+        hip_ops.set_option("gconv_persist", default)
+
+
+@pytest.mark.parametrize("case", [
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 16, 128, 128),        # u64's data gradient (a strided gather, si = 2): 1024 tiles
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 16, 64, 64),         # u128's
+    (ConvSpec("conv", 128, 128, 4, 1, 1), 24, 67, 83),             # zero padding, ragged tiles
+], ids=_ids)
+@pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none")])
+def test_persistent_im2col_kernel_fused_sums(hip_ops, case, with_g2, act):
+    """the fused data-gradient launches (gs_gconv_forward_fused: sums of the consumer's InstanceNorm backward in the epilogue)
+    on the persistent kernel: gradient and per-tile sums bit for bit those of the one-tile-per-workgroup kernel"""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 75)
+    assert len(low.dgrad) == 1
+    gc, f = low.dgrad[0], low.dgrad_fold
+    C = spec.cin_p
+    dev = hip_ops.device
+    g = torch.Generator().manual_seed(76)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16).to(dev)
+    y = (torch.randn(N, *sizes, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16).to(dev)
+    g2 = torch.randn(N, *sizes, C, generator=g).to(torch.bfloat16).to(dev) if with_g2 else None
+    part = torch.stack([y.float().sum((1, 2)), (y.float() ** 2).sum((1, 2))], 1).reshape(-1).contiguous()
+    mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+    hip_ops.inorm_finalize(part, N, 1, C, y.numel() // (N * C), mr)
+    default = hip_ops.get_option("gconv_persist")
+    res = []
+    try:
+        for persist in (0, 1000):
+            hip_ops.set_option("gconv_persist", persist)
+            plan = hip_ops.fused_norm_plan(gc, N, C, force=True)
+            assert plan is not None
+            plan[1].fill_(float("nan"))
+            gx = torch.zeros(N, *low.dgrad_dims, C, dtype=torch.bfloat16, device=dev)
+            hip_ops.gconv(gc, gy, dpack.to(dev), None, gx,
+                          fuse={"y": y, "mean_rstd": mr, "g2": g2, "partial": plan[1], "fold": f,
+                                "fold_mode": spec.pad_mode if f else "reflect", "act": act, "slope": 0.2})
+            torch.cuda.synchronize()
+            res.append((gx, plan[1][:N * plan[0] * 3 * C].clone()))
+    finally:
+        hip_ops.set_option("gconv_persist", default)
+    assert torch.equal(res[0][0], res[1][0]), "data gradient differs"
+    assert not torch.isnan(res[1][1]).any() and torch.equal(res[0][1], res[1][1]), "fused sums differ"

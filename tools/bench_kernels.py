@@ -27,6 +27,8 @@ CASES = {
     "outw": (ConvSpec("conv", 64, 3, 7, 1, 3, pad_mode="reflect", wfold="out"), 8, 256, 256),
     "u2": (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 8, 128, 128),
     "dc4": (ConvSpec("conv", 256, 512, 4, 1, 1), 8, 32, 32),
+    "dc2": (ConvSpec("conv", 64, 128, 4, 2, 1), 8, 128, 128),       # PatchGAN k4 stride-2 layers
+    "dc3": (ConvSpec("conv", 128, 256, 4, 2, 1), 8, 64, 64),
     # 3-D: Resnet3D residual conv at 128^3 / 4, Vnet3D coupling convs (halo-resident kernel)
     "rb3": (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),
     "v16": (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 128, 128, 128),
@@ -39,11 +41,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
+    ap.add_argument("--batch", type=int, default=0, help="override the batch of every case (16 = a twin launch's geometry)")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (gs_set_option), repeatable")
     args = ap.parse_args()
     ops = HipOps()
+    for o in args.opt:
+        k, v = o.split("=")
+        ops.set_option(k, int(v))
     dev = ops.device
     for name, case in CASES.items():
-        spec, N, sizes = case[0], case[1], case[2:]
+        spec, N, sizes = case[0], args.batch or case[1], case[2:]
         if args.only and not any(args.only in f"{name}_{k}" for k in ("fwd", "dgrad", "wgrad", "dgradf")):
             continue
         low = lower(spec, *sizes)
