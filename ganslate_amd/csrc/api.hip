@@ -75,6 +75,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
                                 // CU overlap each other's prologue / epilogue) instead of one 256 x 128 tile per CU; 0 = off
     {"gconv_persist", 16},      // pconv.hip: 256 x 128 im2col launches with more tiles than CUs and at most this many K-steps run as
                                 // persistent workgroups (the K-step stream continues across tiles); 0 = off
+    {"hconvt_persist", 1},      // hconvt.hip: launches with more tiles than CUs run as persistent workgroups (0: one tile each)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

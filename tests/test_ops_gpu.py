@@ -1583,3 +1583,82 @@ def test_persistent_im2col_kernel_fused_sums(hip_ops, case, with_g2, act):
         hip_ops.set_option("gconv_persist", default)
     assert torch.equal(res[0][0], res[1][0]), "data gradient differs"
     assert not torch.isnan(res[1][1]).any() and torch.equal(res[0][1], res[1][1]), "fused sums differ"
+
+
+@pytest.mark.parametrize("case", [
+    (ConvSpec("convT", 128, 64, 3, 2, 1, 1), 16, 128, 128),       # u64 at a twin batch: 1024 boxes, one super-chunk per tile
+    (ConvSpec("convT", 256, 128, 3, 2, 1, 1), 10, 64, 64),        # u128: 2 channel tiles, two super-chunks, uneven tile counts
+    (ConvSpec("conv", 64, 128, 3, 2, 1), 12, 256, 256),           # d128's data gradient (plain and with fused sums)
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 40, 64, 64),            # PatchGAN k4 gradient: 4 chunks of 16 K-steps
+    (ConvSpec("conv", 64, 128, 4, 2, 1), 24, 128, 128),           # ... 2 chunks
+], ids=_ids)
+def test_persistent_parity_class_kernel(hip_ops, monkeypatch, case):
+    """hconvt.hip as persistent workgroups (more tiles than CUs: the K-step stream, the weight ring and the halo buffers run
+    on across tiles, the epilogue works out of the buffer the last chunk left, output stores are never waited for) must give,
+    bit for bit, what one workgroup per tile gives: forward with bias + statistics + activation, plain data gradient, data
+    gradient with the fused norm-backward sums; single and twin batches."""
+    from ganslate_amd.nn.native.twin import Twin
+    monkeypatch.setenv("GS_FUSE_MULTI", "1")
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, _, bias_a, fpack_a, dpack_a = make_layer(spec, sizes, 81)
+    _, _, bias_b, fpack_b, dpack_b = make_layer(spec, sizes, 82)
+    dev = hip_ops.device
+    g = torch.Generator().manual_seed(83)
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16).to(dev)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16).to(dev)
+    C = spec.cin_p
+    yprev = (torch.randn(N, *sizes, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16).to(dev)
+    g2 = torch.randn(N, *sizes, C, generator=g).to(torch.bfloat16).to(dev)
+    part0 = torch.stack([yprev.float().sum((1, 2)), (yprev.float() ** 2).sum((1, 2))], 1).reshape(-1).contiguous()
+    mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+    hip_ops.inorm_finalize(part0, N, 1, C, yprev.numel() // (N * C), mr)
+    fpacks, dpacks = torch.stack([fpack_a, fpack_b]).to(dev), torch.stack([dpack_a, dpack_b]).to(dev)
+    biases = torch.stack([bias_a, bias_b]).to(dev)
+    fwd_multi, dg_multi = len(low.fwd) == 4, len(low.dgrad) == 4
+    assert fwd_multi or dg_multi
+    defaults = {k: hip_ops.get_option(k) for k in ("hconvt", "hconvt_persist")}
+    res = {}
+    try:
+        hip_ops.set_option("hconvt", 1)
+        for persist in (0, 1):
+            hip_ops.set_option("hconvt_persist", persist)
+            out = []
+            for twin in (False, True):
+                if fwd_multi:
+                    if twin and not hip_ops.multi_twin_native(low.fwd, N):
+                        continue
+                    slots, offs = 0, []
+                    for cl in low.fwd:
+                        offs.append(slots)
+                        slots += hip_ops.stat_slots(cl, N, twin=twin, multi=low.fwd)
+                    y = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+                    part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
+                    pack, bias = (Twin(fpacks[0], fpacks[1]), Twin(biases[0], biases[1])) if twin else (fpacks[0], biases[0])
+                    hip_ops.gconv_classes(low.fwd, xa, pack, bias, y, act="relu", stats=part, stats_slots=slots, stats_slot0s=offs)
+                    assert not torch.isnan(part).any()
+                    out += [y, part]
+                if dg_multi:
+                    if twin and not hip_ops.multi_twin_native(low.dgrad, N):
+                        continue
+                    pack = Twin(dpacks[0], dpacks[1]) if twin else dpacks[0]
+                    gx = torch.zeros(N, *low.dgrad_dims, C, dtype=torch.bfloat16, device=dev)
+                    hip_ops.gconv_classes(low.dgrad, gy, pack, None, gx)
+                    out.append(gx)
+                    plan = hip_ops.fused_multi_plan(low.dgrad, N, C, twin=twin)
+                    assert plan is not None
+                    plan[1].fill_(float("nan"))
+                    gxf = torch.zeros_like(gx)
+                    hip_ops.gconv_classes(low.dgrad, gy, pack, None, gxf,
+                                          fuse={"y": yprev, "mean_rstd": mr, "g2": g2, "partial": plan[1], "fold": 0,
+                                                "fold_mode": "reflect", "act": "lrelu", "slope": 0.2})
+                    sums = plan[1][:N * plan[0] * 3 * C].clone()
+                    assert not torch.isnan(sums).any()
+                    out += [gxf, sums]
+            torch.cuda.synchronize()
+            res[persist] = out
+    finally:
+        for k, v in defaults.items():
+            hip_ops.set_option(k, v)
+    assert len(res[0]) == len(res[1]) and len(res[0]) >= 2
+    for i, (a, b) in enumerate(zip(res[0], res[1])):
+        assert torch.equal(a, b), f"result {i} differs between one tile per workgroup and the persistent form"
