@@ -76,6 +76,9 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"gconv_persist", 16},      // pconv.hip: 256 x 128 im2col launches with more tiles than CUs and at most this many K-steps run as
                                 // persistent workgroups (the K-step stream continues across tiles); 0 = off
     {"hconvt_persist", 1},      // hconvt.hip: launches with more tiles than CUs run as persistent workgroups (0: one tile each)
+    {"ring_apply", 0},          // hconvw.hip: gs_gconv_ring_apply is offered (the consumer's norm backward inside the fused data gradient).
+                                // OFF: the in-launch rendezvous costs more than the launch it saves (profiles/r05_ring_apply.txt);
+                                // bits 2 / 4 / 8 / 16 are timing ablations (wrong results)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

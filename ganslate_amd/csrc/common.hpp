@@ -142,6 +142,15 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act, float slope
   return 1.f;
 }
 
+// dy of the InstanceNorm backward, dy = rstd * (ghat - mean ghat - yhat * mean(ghat * yhat)) with ghat = g * act'(yhat), from the
+// pieces both of its homes hold — norm.hip's apply pass by channel group and hconvw.hip's in-launch apply (gs_gconv_ring_apply)
+// — with explicit roundings: left to the compiler the two sites contract it differently (an fma here, a select there), and the
+// one-launch form must reproduce the two-launch form bit for bit
+__device__ __forceinline__ float inorm_dy(float g, float yh, float m, float s1, float s2, float rs) {
+  const float gh = __fmul_rn(g, m);
+  return __fmul_rn(rs, __fsub_rn(__fsub_rn(gh, s1), __fmul_rn(yh, s2)));
+}
+
 // ---- lane reductions on the DPP path -----------------------------------------------------------------------------
 // __shfl_xor compiles to ds_bpermute_b32: an LDS instruction with ~100 cycles of latency per step. The statistics
 // epilogue of the conv kernels ran 64 of them per wave in dependent chains of four (4.5 us of a 44 us launch, measured
@@ -173,7 +182,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum GsOpt {
   GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE,
   GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL,
-  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONVW_PERSIST, GS_OPT_HSTRIP_REGS, GS_OPT_GCONV_TWIN, GS_OPT_WGRAD_TWIN, GS_OPT_GCONV_SMALLK, GS_OPT_GCONV_PERSIST, GS_OPT_HCONVT_PERSIST,
+  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONVW_PERSIST, GS_OPT_HSTRIP_REGS, GS_OPT_GCONV_TWIN, GS_OPT_WGRAD_TWIN, GS_OPT_GCONV_SMALLK, GS_OPT_GCONV_PERSIST, GS_OPT_HCONVT_PERSIST, GS_OPT_RING_APPLY,
   GS_OPT_COUNT
 };
 int gs_opt(int id);

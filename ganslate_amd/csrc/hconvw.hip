@@ -39,8 +39,17 @@
 // vmcnt bookkeeping across the boundary (per wave, VMEM retires in issue order): the epilogue's 4 output stores sit between
 // the next tile's K-step-2 weights (issued before them) and its chunk-1 halo (after); the first two waits of the new tile
 // leave exactly those younger operations outstanding.
-template <int T, bool RING = false>
+// APPLY (round 5, RING only): the apply pass of the consumer's InstanceNorm backward rides in the epilogue too. The sums it needs
+// are over the whole image — the 16 boxes of an image sit on 16 workgroups that run the same tile index at the same time (one
+// persistent workgroup per CU, all resident) — so a box writes its partial sums through to memory (agent-scope stores),
+// arrives at a per-(image, channel tile) counter, waits for the others (bounded spin), adds the 16 slots up in slot order
+// (the arithmetic of inorm_bwd_apply_cg_kernel: double accumulation, then dy = rstd * (ghat - mean ghat - yhat * mean ghat yhat)
+// on the bf16-rounded gradient) and stores dy — and the total gradient gx + g2 for the skip path — instead of gx: the
+// 23-us apply launch, its re-read of y / g2 and the write + read of gx are gone. Bit-identical to the two launches
+// (tests/test_ops_gpu.py::test_ring_form_with_the_norm_backward_applied_in_the_launch).
+template <int T, bool RING = false, bool APPLY = false>
 __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
+  static_assert(RING || !APPLY, "the in-launch norm backward belongs to the fused data gradient");
   constexpr int NW = 16;
   constexpr int BM = 256, BN = 128, WM = 4, WN = NW / 4;
   constexpr int WT = BN * 128;                   // weight stage: 128 rows x 64 k
@@ -298,7 +307,8 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
           if (it > 0 && c == 0 && t <= 1) {
             // first K-steps behind a tile boundary: the weights waited for are older than the previous tile's NST output
             // stores and this tile's chunk-1 halo (ks 0: w2 | stores | halo outstanding; ks 1: stores | halo | w3)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + NST + HPW) : "memory");
+            if (APPLY && p.out2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + 2 * NST + HPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + NST + HPW) : "memory");
             return;
           }
           if (!w_now && (c > 0 || t >= 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail of the last tile
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     static_assert(NQ == 2, "four store values per lane");
     uint4 val0, val1, val2, val3;                  // the tile in store layout: 4 x 16 B per lane (named: an indexed array
                                                    // ended up in scratch memory)
+    [[maybe_unused]] uint4 tot0, tot1, tot2, tot3; // APPLY: the total gradient gx + g2 of the same four pixels
     [[maybe_unused]] uint2 yv[TI][TJ], gv[TI][TJ];
     [[maybe_unused]] f32x4 mrv;
     [[maybe_unused]] f32x4 bia[TI];
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     // the epilogue works out of the halo buffer the next chunk does NOT use: hpar now names the next tile's chunk-0
     // buffer (already filled), the other one is free
     char* const ebuf = hbuf + (hpar ^ 1) * HBUF;
-    static_assert(NW * PH * SROW + WM * BN * 3 * 4 + 2 * BN * 4 <= HBUF, "epilogue scratch must fit one halo buffer");
+    static_assert(NW * PH * SROW + WM * BN * 3 * 4 + 4 * BN * 4 <= HBUF, "epilogue scratch must fit one halo buffer");
     char* const slab = ebuf + wave * (PH * SROW);            // 16 x 2560 B = 40 KiB
     float* const red = reinterpret_cast<float*>(ebuf + NW * PH * SROW);                       // [WM][BN][2 | 3], behind the slabs
     [[maybe_unused]] float* const mrs = reinterpret_cast<float*>(ebuf + NW * PH * SROW + WM * BN * 3 * 4);   // [2][BN]
@@ -483,7 +494,124 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
           t0 += red[(w * BN + tq) * 3]; t1 += red[(w * BN + tq) * 3 + 1]; t2 += red[(w * BN + tq) * 3 + 2];
         }
         float* sp = p.f.partial + ((size_t)n * p.tiles_m + mt) * 3 * d.Co;
-        sp[cc] = t0; sp[d.Co + cc] = t1; sp[2 * d.Co + cc] = t2;
+        if constexpr (APPLY) {     // written through (sc1): read by the other boxes' workgroups of this launch
+          __hip_atomic_store(sp + cc, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp + d.Co + cc, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp + 2 * d.Co + cc, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          sp[cc] = t0; sp[d.Co + cc] = t1; sp[2 * d.Co + cc] = t2;
+        }
+      }
+      if constexpr (APPLY) {
+        // ---- rendezvous of the boxes of (image n, channel tile nt), then the norm backward on this box ------------------------
+        float* const tots = mrs + 2 * BN;                     // [2][BN]: mean ghat, mean ghat * yhat
+        // y / g2 of this lane's four stores (8 channels of one pixel each, coalesced) are requested before the rendezvous: their
+        // latency runs under it
+        uint4 y0, y1, y2, y3, q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+        {
+          const char* yb = static_cast<const char*>(p.f.y);
+          const char* gb = static_cast<const char*>(p.f.g2);
+          // (the offsets are built from an opaque copy of the lane id: shared with the store addresses below they stayed live —
+          // and went to scratch memory — through the whole apply pass)
+          int l2 = lane;
+          asm volatile("" : "+v"(l2));
+          const int sub2 = l2 % LPR, prow2 = l2 / LPR;
+          auto eoff = [&](int ph, int q) {
+            const int pl = q * PPI + prow2;
+            const size_t px = pix0 + (size_t)(wm * 4 + ph * 2 + (pl >> 4)) * d.Wo + (pl & 15);
+            return (px * d.Co + nt * BN + wn * CWV + sub2 * 8) * 2;
+          };
+          const size_t e0 = eoff(0, 0), e1 = eoff(0, 1), e2 = eoff(1, 0), e3 = eoff(1, 1);
+          y0 = *reinterpret_cast<const uint4*>(yb + e0); y1 = *reinterpret_cast<const uint4*>(yb + e1);
+          y2 = *reinterpret_cast<const uint4*>(yb + e2); y3 = *reinterpret_cast<const uint4*>(yb + e3);
+          if (has_g2) {
+            q0 = *reinterpret_cast<const uint4*>(gb + e0); q1 = *reinterpret_cast<const uint4*>(gb + e1);
+            q2 = *reinterpret_cast<const uint4*>(gb + e2); q3 = *reinterpret_cast<const uint4*>(gb + e3);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial sums are on their way out of the CU ...
+        lds_barrier();                                        // ... and so are everybody's
+        if (tid == 0 && (p.dbg & 16)) {                        // debug: arrival time of this tile (tools/probe/e8_ring_skew.py)
+          const unsigned long long t = __builtin_amdgcn_s_memrealtime();      // (100 MHz, one clock for all XCDs)
+          const int tile = (n * p.tiles_m + mt) * p.tiles_n + nt;
+          p.sync[256 + 2 * tile] = (int)(t & 0xffffffffu);
+          p.sync[256 + 2 * tile + 1] = (int)(t >> 32);
+        }
+        if (tid == 0 && !(p.dbg & 8)) {
+          int* cnt = p.sync + 2 * (n * p.tiles_n + nt);
+          __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while (!(p.dbg & 2) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.tiles_m) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) {                        // a grid that is not fully resident: flag it and go on (wrong
+              __hip_atomic_store(p.sync + 2 * d.N * p.tiles_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // results,
+              break;                                          // no hang)
+            }
+          }
+          // the last one to leave puts the counters back for the next launch
+          if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.tiles_m - 1) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        lds_barrier();
+        if (tid < 3 * BN && !(p.dbg & 4)) {
+          const int r = tid / BN, ch = tid - r * BN;
+          const float* src = p.f.partial + ((size_t)n * p.tiles_m * 3 + r) * d.Co + nt * BN + ch;
+          double acc2 = 0.0;                                  // slot order, double accumulation: inorm_bwd_apply_cg_kernel's sum
+          int sl = 0;
+          for (; sl + 8 <= p.tiles_m; sl += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              v[k] = __hip_atomic_load(src + (size_t)(sl + k) * 3 * d.Co, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc2 += (double)v[k];
+          }
+          for (; sl < p.tiles_m; ++sl)
+            acc2 += (double)__hip_atomic_load(src + (size_t)sl * 3 * d.Co, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float tot = (float)acc2;
+          if (r < 2) tots[r * BN + ch] = tot * p.inv_hw;
+          // per-image totals for the bias gradient of the conv in front of the norm (gs_norm_bias_grads), once per image
+          if (mt == 0) p.f.partial[((size_t)d.N * p.tiles_m + n) * 3 * d.Co + (size_t)r * d.Co + nt * BN + ch] = tot;
+        }
+        lds_barrier();
+        // dy (into the val registers) and the total gradient gx + g2 (into the q registers) of the four stores: the arithmetic
+        // of the apply pass, pixel by pixel
+        {
+          const int cl8 = wn * CWV + sub * 8;
+          auto apply4 = [&](uint4& v, const uint4& yv4, uint4& gq) {
+            const int c8 = cl8;
+            unsigned vw[4] = {v.x, v.y, v.z, v.w};
+            unsigned gw[4] = {gq.x, gq.y, gq.z, gq.w};
+            const unsigned yw[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {                     // two channels at a time: the constants come from LDS as they are used
+              const f32x2 mu2 = *reinterpret_cast<const f32x2*>(mrs + c8 + 2 * h), rs2 = *reinterpret_cast<const f32x2*>(mrs + BN + c8 + 2 * h);
+              const f32x2 a2 = *reinterpret_cast<const f32x2*>(tots + c8 + 2 * h), b2 = *reinterpret_cast<const f32x2*>(tots + BN + c8 + 2 * h);
+              float g[2] = {bf_lo(vw[h]), bf_hi(vw[h])};
+              if (has_g2) {
+                g[0] += bf_lo(gw[h]); g[1] += bf_hi(gw[h]);
+                gw[h] = pack_bf2(g[0], g[1]);
+              }
+              const float yy[2] = {bf_lo(yw[h]), bf_hi(yw[h])};
+              float dd[2];
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                const float yh = (yy[k] - mu2[k]) * rs2[k];
+                dd[k] = inorm_dy(g[k], yh, yh > 0.f ? 1.f : neg, a2[k], b2[k], rs2[k]);   // (inorm_bwd_apply_cg_kernel's arithmetic)
+              }
+              vw[h] = pack_bf2(dd[0], dd[1]);
+            }
+            v.x = vw[0]; v.y = vw[1]; v.z = vw[2]; v.w = vw[3];
+            gq.x = gw[0]; gq.y = gw[1]; gq.z = gw[2]; gq.w = gw[3];
+          };
+          apply4(val0, y0, q0);
+          apply4(val1, y1, q1);
+          apply4(val2, y2, q2);
+          apply4(val3, y3, q3);
+          tot0 = q0; tot1 = q1; tot2 = q2; tot3 = q3;
+        }
       }
     } else {
       // ---- bias, partial statistics (slot = box), activation, LDS-staged coalesced NHWC stores ------------------------
@@ -562,10 +690,34 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       ct_of(2, c2, t2);
       issue_w(n + nstep, c2, t2, stage == 0 ? 2 : stage - 1);
     }
-    *reinterpret_cast<uint4*>(p.out + (opix_of(0, 0) * d.out_cs + d.out_co + co) * 2) = val0;
-    *reinterpret_cast<uint4*>(p.out + (opix_of(0, 1) * d.out_cs + d.out_co + co) * 2) = val1;
-    *reinterpret_cast<uint4*>(p.out + (opix_of(1, 0) * d.out_cs + d.out_co + co) * 2) = val2;
-    *reinterpret_cast<uint4*>(p.out + (opix_of(1, 1) * d.out_cs + d.out_co + co) * 2) = val3;
+    if constexpr (!APPLY) {
+      *reinterpret_cast<uint4*>(p.out + (opix_of(0, 0) * d.out_cs + d.out_co + co) * 2) = val0;
+      *reinterpret_cast<uint4*>(p.out + (opix_of(0, 1) * d.out_cs + d.out_co + co) * 2) = val1;
+      *reinterpret_cast<uint4*>(p.out + (opix_of(1, 0) * d.out_cs + d.out_co + co) * 2) = val2;
+      *reinterpret_cast<uint4*>(p.out + (opix_of(1, 1) * d.out_cs + d.out_co + co) * 2) = val3;
+    } else {
+      // (store offsets from a fresh opaque lane id: computed up front they lived — in scratch memory — through the apply pass;
+      // dy and the total gradient are dense [pixel][Co] tensors)
+      int l3 = lane;
+      asm volatile("" : "+v"(l3));
+      const int sub3 = l3 % LPR, prow3 = l3 / LPR;
+      auto soff = [&](int ph, int q) {
+        const int pl = q * PPI + prow3;
+        const size_t px = pix0 + (size_t)(wm * 4 + ph * 2 + (pl >> 4)) * d.Wo + (pl & 15);
+        return (px * d.Co + nt * BN + wn * CWV + sub3 * 8) * 2;
+      };
+      const size_t o0 = soff(0, 0), o1 = soff(0, 1), o2 = soff(1, 0), o3 = soff(1, 1);
+      *reinterpret_cast<uint4*>(p.out + o0) = val0;
+      *reinterpret_cast<uint4*>(p.out + o1) = val1;
+      *reinterpret_cast<uint4*>(p.out + o2) = val2;
+      *reinterpret_cast<uint4*>(p.out + o3) = val3;
+      if (p.out2) {                                           // (uniform: four more stores per lane, see the counted waits)
+        *reinterpret_cast<uint4*>(p.out2 + o0) = tot0;
+        *reinterpret_cast<uint4*>(p.out2 + o1) = tot1;
+        *reinterpret_cast<uint4*>(p.out2 + o2) = tot2;
+        *reinterpret_cast<uint4*>(p.out2 + o3) = tot3;
+      }
+    }
     if (has_next && grp) __builtin_amdgcn_s_barrier();      // group 1 one barrier ahead again
   }
 }
@@ -646,6 +798,7 @@ int gs_hconvw_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   hconvw_twin(k, tw);
   k.d = *d;
   k.f = gs_gconv_fuse{};
+  k.out2 = nullptr; k.sync = nullptr; k.inv_hw = 0.f; k.dbg = 0;
   const int lds = 160 * 1024;
   static bool configured = false;
   if (!configured) {
@@ -700,6 +853,7 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   k.chunks = d->Ci / 64;
   k.d = *d;
   k.f = *fuse;
+  k.out2 = nullptr; k.sync = nullptr; k.inv_hw = 0.f; k.dbg = 0;
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   k.ntiles = (int)blocks;
   hconvw_twin(k, tw);
@@ -712,6 +866,65 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   }
   hipLaunchKernelGGL((hconvw_kernel<9, true>), dim3((unsigned)hconvw_grid(d->N, k.tiles_m * k.tiles_n, k.chunks)), dim3(1024), lds,
                      static_cast<hipStream_t>(stream), k);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- RING + APPLY: the fused data gradient with the consumer's whole InstanceNorm backward in the launch -----------------------
+// int32 words of the rendezvous buffer the launch wants (zero-filled once by the caller, left zero by every launch), 0 when the
+// launch cannot run in this form: it needs every workgroup resident at once (a persistent grid of at most one workgroup per CU)
+extern "C" int gs_gconv_ring_apply_words(const gs_gconv_desc* d) {
+  if (!d || !gs_opt(GS_OPT_RING_APPLY) || !hconvw_ring_eligible(d)) return 0;
+  const int tpi = (d->Ho / 16) * (d->Wo / 16) * (d->Co / 128);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  if (hconvw_grid(d->N, tpi, d->Ci / 64) > cus) return 0;
+  return 2 * d->N * (d->Co / 128) + 1;
+}
+
+extern "C" int gs_gconv_ring_apply(const gs_gconv_desc* d, const void* in, const void* w_pack, const gs_gconv_fuse* fuse, void* dy,
+                                   void* total, int32_t* sync, const gs_twin* tw, void* stream) {
+  GS_REQUIRE(d && in && w_pack && fuse && dy && sync && fuse->y && fuse->mean_rstd && fuse->partial, "gs_gconv_ring_apply: null argument");
+  GS_REQUIRE(gs_gconv_ring_apply_words(d) > 0, "gs_gconv_ring_apply: the launch does not qualify (gs_gconv_ring_apply_words)");
+  GS_REQUIRE(fuse->fold == 1 && fuse->fold_mode == GS_BORDER_REFLECT && fuse->Dy == 1 && fuse->Hy == d->Ho && fuse->Wy == d->Wo,
+             "gs_gconv_ring_apply: the unpadded form folds a reflect padding of 1");
+  GS_REQUIRE(fuse->act != GS_ACT_TANH, "gs_gconv_ring_apply: none / relu / lrelu in front of the consumer's norm");
+  GS_REQUIRE(!total || fuse->g2, "gs_gconv_ring_apply: the total gradient is gx + g2 (without g2 it is not produced: dy only)");
+  HConvWK k;
+  k.in = static_cast<const char*>(in);
+  k.w = static_cast<const char*>(w_pack);
+  k.bias = nullptr;
+  k.out = static_cast<char*>(dy);
+  k.out2 = static_cast<char*>(total);
+  k.sync = sync;
+  k.stats = nullptr;
+  k.zero = static_cast<const char*>(gs_zero_page());
+  GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
+  k.tiles_m = (d->Ho / 16) * (d->Wo / 16);
+  k.tiles_n = d->Co / 128;
+  k.nbw = d->Wo / 16;
+  k.hh = 18; k.hw = 18; k.hmin = -1; k.wmin = -1;
+  k.chunks = d->Ci / 64;
+  k.inv_hw = 1.0f / (float)(d->Ho * d->Wo);
+  k.dbg = gs_opt(GS_OPT_RING_APPLY);
+  k.d = *d;
+  k.f = *fuse;
+  k.ntiles = d->N * k.tiles_m * k.tiles_n;
+  hconvw_twin(k, tw);
+  const int lds = 160 * 1024;
+  static bool configured = false;
+  if (!configured) {
+    GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvw_kernel<9, true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((hconvw_kernel<9, true, true>), dim3((unsigned)hconvw_grid(d->N, k.tiles_m * k.tiles_n, k.chunks)), dim3(1024),
+                     lds, static_cast<hipStream_t>(stream), k);
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -18,4 +18,10 @@ struct HConvWK {
   long long bias_delta;        // the same for the bias vector, in floats
   gs_gconv_desc d;
   gs_gconv_fuse f;             // RING: the consumer's InstanceNorm backward sums ride in the epilogue (gs_gconv_forward_fused)
+  // APPLY (gs_gconv_ring_apply): the consumer's whole InstanceNorm backward rides in the epilogue — after an in-launch
+  // rendezvous of the boxes of an image the kernel writes dy (to `out`) and, with a residual-join gradient, the total gradient
+  char* out2;                  // total gradient gx + g2 (NULL: not wanted / no g2)
+  int* sync;                   // [2 * N * tiles_n + 1] arrival / departure counters per (image, channel tile), zero between launches
+  float inv_hw;
+  int dbg;                     // timing ablations of the rendezvous (option ring_apply > 1; results are wrong then)
 };

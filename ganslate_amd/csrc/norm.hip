@@ -599,8 +599,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float yh = (yy[k] - mu[k]) * rs[k];
-      const float gh = g[k] * act_grad_from_out(yh, act, slope);
-      d[k] = rs[k] * (gh - s1[k] - yh * s2[k]);
+      d[k] = inorm_dy(g[k], yh, act_grad_from_out(yh, act, slope), s1[k], s2[k], rs[k]);
     }
     uint4 o;
     o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);

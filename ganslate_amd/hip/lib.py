@@ -85,6 +85,9 @@ _PROTOS = {
     "gs_tile_m": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_stat_slots": (C.c_int, [C.POINTER(GConvDesc)]),
     "gs_gconv_ring_slots": (C.c_int, [C.POINTER(GConvDesc)]),
+    "gs_gconv_ring_apply_words": (C.c_int, [C.POINTER(GConvDesc)]),
+    "gs_gconv_ring_apply": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.POINTER(GConvFuse), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.POINTER(Twin), C.c_void_p]),
     "gs_gconv_forward": (C.c_int, [C.POINTER(GConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "gs_gconv_splitk_ws_floats": (C.c_int64, [C.POINTER(GConvDesc)]),

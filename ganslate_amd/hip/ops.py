@@ -46,7 +46,7 @@ class HipOps(TwinSplit):
     # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
     # host side are mapped onto its options here, when the backend is created and whenever a model is built.
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
-                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_WGRAD_TWIN": "wgrad_twin",
+                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_WGRAD_TWIN": "wgrad_twin",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
                    "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
@@ -228,6 +228,45 @@ class HipOps(TwinSplit):
         if slots <= 0:
             return None
         return slots, torch.empty(N * (slots + 1) * 3 * C_, dtype=torch.float32, device=self.device)
+
+    def ring_apply_plan(self, g: GConv, N: int, C_: int, twin: bool = False):
+        """the rendezvous buffer (zero int32 words, one per launching stream, left zero by every launch) when the ring-form
+        launch of class g can also carry the consumer's whole InstanceNorm backward (gs_gconv_ring_apply: dy and the total
+        gradient come out of the data-gradient launch, no gs_inorm_act_backward behind it), else None. Twin batches only
+        where the launch is one launch. GS_RING_APPLY=0 switches it off."""
+        if g is None or g.Co != C_:
+            return None
+        if twin and not self.twin_native(g, N, ring=True):
+            return None
+        words = self.lib.gs_gconv_ring_apply_words(C.byref(self._gdesc(g, N, g.Ci, 0, g.Co, 0, "none", 0.0, 0, 0)))
+        if words <= 0:
+            return None
+        if not hasattr(self, "_ring_sync"):
+            self._ring_sync = {}
+        key = int(_stream().value or 0)                        # one buffer per launching stream
+        buf = self._ring_sync.get(key)
+        if buf is None or buf.numel() < words:
+            buf = torch.zeros(max(words, 4096), dtype=torch.int32, device=self.device)
+            self._ring_sync[key] = buf
+        return buf
+
+    def gconv_ring_apply(self, g: GConv, x, wpack, dy, total, fuse, sync):
+        """the ring-form fused data gradient with the norm backward applied in the launch: writes dy (and total = gx + g2)"""
+        N = x.shape[0]
+        d = self._gdesc(g, N, x.shape[-1], 0, dy.shape[-1], 0, "none", 0.0, 0, 0, False)
+        f = self._fuse_struct(fuse)
+        tw = None
+        if isinstance(wpack, Twin):
+            tw = L.Twin()
+            tw.n_split, tw.w_delta, tw.bias_delta = N // 2, wpack.delta(), 0
+            w = C.c_void_p(wpack.a.data_ptr() + 2 * g.pack_offset)
+        else:
+            w = C.c_void_p(wpack.data_ptr() + 2 * g.pack_offset)
+        t_end = self._time_begin("gconv", g, True, N)
+        L.check(self.lib.gs_gconv_ring_apply(C.byref(d), _ptr(x), w, C.byref(f), _ptr(dy), _ptr(total), _ptr(sync),
+                                             C.byref(tw) if tw is not None else None, _stream()), "gs_gconv_ring_apply")
+        if t_end is not None:
+            t_end.record()
 
     def multi_twin_native(self, classes, N: int) -> bool:
         """a twin batch of N images over the output-parity classes of one layer runs as ONE launch (the halo-resident class

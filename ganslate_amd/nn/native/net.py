@@ -650,10 +650,28 @@ class NativeNet:
                     self.grad_dirty = True
             g_pad, fold, g2, fmode = pending[:4]
             pre = pending[4] if len(pending) > 4 else None
+            applied = pending[5] if len(pending) > 5 else None
             x_out = s.acts[i + 1]
             # ---- gradient w.r.t. the conv output y ---------------------------------------------------------------
             need_total = nd.res is not None
-            if nd.norm or nd.act != "none" or fold > 0 or g2 is not None:
+            if applied is not None:
+                # the data-gradient launch of the layer above already ran this norm's backward (gs_gconv_ring_apply): dy, the
+                # total gradient for the skip path and the per-image totals for the bias gradient are there
+                dy, total = applied["dy"], applied["total"]
+                if want_w and sp.bias:
+                    db = grad[self.b_off[i]:self.b_off[i] + sp.cout_p]
+                    holder, off = pre[1], pre[1].numel() - N * 3 * sp.cout_p
+                    if tw is None:
+                        items = [(holder, off, s.mrs[i], db, N, sp.cout_p, lw.out_pixels)]
+                    else:
+                        hm = s.mrs[i].numel() // 2
+                        items = [(holder, off + h * Nh * 3 * sp.cout_p, s.mrs[i][h * hm:(h + 1) * hm], db.half(h), Nh,
+                                  sp.cout_p, lw.out_pixels) for h in (0, 1)]
+                    if final_pass:
+                        ops.norm_bias_grads(items)
+                    else:
+                        db_items += items
+            elif nd.norm or nd.act != "none" or fold > 0 or g2 is not None:
                 dy = torch.empty_like(x_out)
                 gsum = torch.empty_like(x_out) if (need_total and (fold > 0 or g2 is not None)) else None
                 if nd.norm:
@@ -744,7 +762,21 @@ class NativeNet:
                     if (plan is not None and nodes[i - 1].act != "tanh") else None     # (the ring form has no tanh' path)
                 if ring is None:
                     gx = torch.empty(N, *lw.dgrad_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
-                if ring is not None:
+                # ... and where every workgroup of that launch is resident at once, the WHOLE norm backward does: the launch
+                # writes the previous layer's dy (and the total gradient its skip path wants) instead of gx. Passes of this
+                # network on several streams could run two such launches at once (each waits for its own workgroups): not then.
+                sync = ops.ring_apply_plan(lw.dgrad_ring, N, sp.cin_p, twin=tw is not None) \
+                    if (ring is not None and not self.multi_stream_passes and (i - 1) not in inj_y) else None
+                if sync is not None:
+                    fz = {"y": s.ys[i - 1], "mean_rstd": s.mrs[i - 1], "g2": g2n, "partial": ring[1], "fold": f,
+                          "fold_mode": fmode_n, "act": nodes[i - 1].act, "slope": nodes[i - 1].slope}
+                    dy_prev = torch.empty(N, *lw.in_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)
+                    want_total = nodes[i - 1].res is not None and g2n is not None
+                    tot_prev = torch.empty_like(dy_prev) if want_total else None
+                    ops.gconv_ring_apply(lw.dgrad_ring, dy, dpack, dy_prev, tot_prev, fz, sync)
+                    assert nodes[i - 1].res is None or g2n is not None, "a residual join always brings its skip gradient"
+                    pending = (None, 0, g2n, fmode_n, ring, {"dy": dy_prev, "total": tot_prev})
+                elif ring is not None:
                     # reflect-padded wide 3x3 layer: the launch folds the ring of padded-domain pixels itself, the gradient
                     # arrives on the unpadded domain
                     gx = torch.empty(N, *lw.in_dims, sp.cin_p, dtype=self.ops.act_dtype, device=dev)

@@ -162,6 +162,20 @@ int gs_gconv_forward_multi_fused(const gs_gconv_desc* const* descs, int32_t coun
  * slots = gs_gconv_ring_slots(d). Returns 0 slots when the layer / grid does not suit the halo kernel; the padded form
  * above is always available. */
 int gs_gconv_ring_slots(const gs_gconv_desc* d);
+/* The same launch with the consumer's WHOLE InstanceNorm backward inside it (round 5): where gs_inorm_act_backward(pre_slots)
+ * would follow the ring-form launch — ganslate/nn/generators/resnet/resnet2d.py:80-93 backward: conv <- ReflectionPad <-
+ * [ReLU <-] InstanceNorm2d (ganslate/nn/utils.py:53-59) — the boxes of an image meet inside the launch (their partial sums
+ * written through to memory, one arrival counter per image and channel tile), add the slots up in slot order and write
+ * dy = rstd * (ghat - mean ghat - yhat * mean(ghat * yhat)) instead of the input gradient; with a residual-join gradient
+ * fuse->g2 and total != NULL also the total gradient gx + g2 the skip path wants. Bit for bit the results of the two launches;
+ * fuse->partial keeps its layout ([N][slots][3][C] partial sums, then [N][3][C] per-image totals for gs_norm_bias_grads).
+ * gs_gconv_ring_apply_words(d): int32 words of the rendezvous buffer `sync` (zero-filled once by the caller, left zero by every
+ * launch; one buffer per stream), 0 when the launch cannot run in this form — every workgroup must be resident at once, so
+ * only persistent grids of at most one workgroup per CU qualify, and the caller must not run two such launches concurrently
+ * on different streams. */
+int gs_gconv_ring_apply_words(const gs_gconv_desc* d);
+int gs_gconv_ring_apply(const gs_gconv_desc* d, const void* in, const void* w_pack, const gs_gconv_fuse* fuse, void* dy,
+                        void* total, int32_t* sync, const gs_twin* tw, void* stream);
 /* Twin batches (gs_twin above). gs_gconv_twin_native: 1 when the kernel gs_gconv_forward (fuse == NULL) or
  * gs_gconv_forward_fused (fuse != NULL) would pick for `d` — d->N = the whole batch of both networks — selects the weight
  * set per image; 0: the caller runs the two halves as two launches (always possible: the halves are contiguous).

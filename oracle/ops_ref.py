@@ -98,6 +98,11 @@ class RefOps(TwinSplit):
             return None
         return 1, torch.zeros(N * 2 * 3 * C_, dtype=torch.float32)
 
+    def ring_apply_plan(self, g, N, C_, twin=False):
+        """(the in-launch norm backward of gs_gconv_ring_apply is an execution form of the HIP library: the oracle backend
+        always runs the two steps)"""
+        return None
+
     def fused_ring_plan(self, g, N, C_, twin=False):
         """the layers the library's gs_gconv_ring_slots accepts (hconvw.hip hconvw_ring_eligible), restated"""
         if g is None or g.Co != C_ or g.T != 9 or g.Ci % 64 or g.Co % 128 or g.Ho % 16 or g.Wo % 16:

@@ -1662,3 +1662,63 @@ def test_persistent_parity_class_kernel(hip_ops, monkeypatch, case):
     assert len(res[0]) == len(res[1]) and len(res[0]) >= 2
     for i, (a, b) in enumerate(zip(res[0], res[1])):
         assert torch.equal(a, b), f"result {i} differs between one tile per workgroup and the persistent form"
+
+
+@pytest.mark.parametrize("case", [(256, 8, 64, 64), (256, 16, 64, 64), (128, 48, 32, 32), (256, 2, 96, 128), (256, 10, 64, 64)],
+                         ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("with_g2,act", [(False, "relu"), (True, "none"), (True, "lrelu")])
+def test_ring_form_with_the_norm_backward_applied_in_the_launch(hip_ops, case, with_g2, act):
+    """gs_gconv_ring_apply (hconvw.hip RING + APPLY): the boxes of an image meet inside the data-gradient launch and write dy
+    (and the total gradient gx + g2) themselves. Must equal, bit for bit, the ring-form launch followed by
+    gs_inorm_act_backward on its sums — dy, total gradient and the per-image totals the bias gradient reads — for single and
+    twin batches (persistent grids: two or three tiles per workgroup), leave its rendezvous counters at zero and never hit
+    the spin bound. resnet2d.py:80-93 backward."""
+    from ganslate_amd.nn.native.twin import Twin
+    C, N, H, W = case
+    spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
+    low, _, _, _, dpack_a = make_layer(spec, (H, W), 91)
+    _, _, _, _, dpack_b = make_layer(spec, (H, W), 92)
+    dev = hip_ops.device
+    g = torch.Generator().manual_seed(93)
+    gy = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    y = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.2).to(torch.bfloat16).to(dev)
+    g2 = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16).to(dev) if with_g2 else None
+    part = torch.stack([y.float().sum((1, 2)), (y.float() ** 2).sum((1, 2))], 1).reshape(-1).contiguous()
+    mr = torch.empty(N * 2 * C, dtype=torch.float32, device=dev)
+    hip_ops.inorm_finalize(part, N, 1, C, H * W, mr)
+    dpacks = torch.stack([dpack_a, dpack_b]).to(dev)
+    ran = 0
+    default = hip_ops.get_option("ring_apply")
+    hip_ops.set_option("ring_apply", 1)          # (off by default: measured slower than the two launches, DESIGN.md)
+    for twin in (False, True):
+        if twin and (N % 2 or not hip_ops.twin_native(low.dgrad_ring, N, ring=True)):
+            continue
+        pack = Twin(dpacks[0], dpacks[1]) if twin else dpacks[0]
+        ring = hip_ops.fused_ring_plan(low.dgrad_ring, N, C, twin=twin)
+        assert ring is not None, "case must be eligible for the ring form"
+        sync = hip_ops.ring_apply_plan(low.dgrad_ring, N, C, twin=twin)
+        assert sync is not None, "case must qualify for the in-launch norm backward"
+        fz = lambda partial: {"y": y, "mean_rstd": mr, "g2": g2, "partial": partial, "fold": 1, "fold_mode": "reflect",
+                              "act": act, "slope": 0.2}
+        # the two launches
+        ring[1].fill_(float("nan"))
+        gx = torch.zeros(N, H, W, C, dtype=torch.bfloat16, device=dev)
+        hip_ops.gconv(low.dgrad_ring, gy, pack, None, gx, fuse=fz(ring[1]))
+        dy_ref, tot_ref = torch.empty_like(y), torch.empty_like(y)
+        sums = hip_ops.inorm_act_backward(gx, g2, y, mr, dy_ref, tot_ref if with_g2 else None, fold=0, act=act, pre=ring)
+        totals_ref = sums[0][sums[1]:].clone()
+        # one launch, twice (the second run finds the counters the first one left)
+        for rep in range(2):
+            scratch = torch.full_like(ring[1], float("nan"))
+            dy = torch.full_like(y, 3.0)
+            tot = torch.full_like(y, 3.0) if with_g2 else None
+            hip_ops.gconv_ring_apply(low.dgrad_ring, gy, pack, dy, tot, fz(scratch), sync)
+            torch.cuda.synchronize()
+            assert int(sync.abs().sum().item()) == 0, "rendezvous counters not back at zero / spin bound hit"
+            assert torch.equal(dy, dy_ref), (twin, rep, "dy differs from the two launches")
+            if with_g2:
+                assert torch.equal(tot, tot_ref), (twin, rep, "total gradient differs")
+            assert torch.equal(scratch[sums[1]:], totals_ref), (twin, rep, "per-image totals differ")
+        ran += 1
+    hip_ops.set_option("ring_apply", default)
+    assert ran >= 1

@@ -67,12 +67,37 @@ def main():
               "act": "relu", "slope": 0.2}
         return lambda: ops.gconv(low.dgrad_ring, gy[:n], w, None, out[:n], fuse=fz)
 
-    for label, make in (("forward", fwd), ("dgrad (ring, fused sums)", ring)):
+    dy_out, tot_out = torch.empty_like(out), torch.empty_like(out)
+
+    def ring_then_apply(n, twin):        # the two launches: fused data gradient, then the norm backward's apply pass on its sums
+        w = Twin(packs_d[0], packs_d[1]) if twin else packs_d[0]
+        plan = ops.fused_ring_plan(low.dgrad_ring, n, C, twin=twin)
+        fz = {"y": y[:n], "mean_rstd": mr[:n * 2 * C], "g2": g2[:n], "partial": plan[1], "fold": 1, "fold_mode": "reflect",
+              "act": "none", "slope": 0.2}
+
+        def run():
+            ops.gconv(low.dgrad_ring, gy[:n], w, None, out[:n], fuse=fz)
+            ops.inorm_act_backward(out[:n], g2[:n], y[:n], mr[:n * 2 * C], dy_out[:n], tot_out[:n], fold=0, act="none", pre=plan)
+        return run
+
+    def ring_apply(n, twin):             # one launch (gs_gconv_ring_apply)
+        w = Twin(packs_d[0], packs_d[1]) if twin else packs_d[0]
+        plan = ops.fused_ring_plan(low.dgrad_ring, n, C, twin=twin)
+        sync = ops.ring_apply_plan(low.dgrad_ring, n, C, twin=twin)
+        fz = {"y": y[:n], "mean_rstd": mr[:n * 2 * C], "g2": g2[:n], "partial": plan[1], "fold": 1, "fold_mode": "reflect",
+              "act": "none", "slope": 0.2}
+        return lambda: ops.gconv_ring_apply(low.dgrad_ring, gy[:n], w, dy_out[:n], tot_out[:n], fz, sync)
+
+    for label, make in (("forward", fwd), ("dgrad (ring, fused sums)", ring), ("dgrad + norm apply, 2 launches", ring_then_apply),
+                        ("dgrad with the apply inside", ring_apply)):
         t1 = timed(make(N, False), args.iters)
         t2 = timed(make(2 * N, True), args.iters)
-        ops.set_option("hconvw_persist", 0)
-        t3 = timed(make(2 * N, True), args.iters)
-        ops.set_option("hconvw_persist", 1)
+        if make is ring_apply:           # (needs the persistent grid: every workgroup resident)
+            t3 = float("nan")
+        else:
+            ops.set_option("hconvw_persist", 0)
+            t3 = timed(make(2 * N, True), args.iters)
+            ops.set_option("hconvw_persist", 1)
         rows.append((label, t1, t2, t3))
         print(f"{label:28s} single batch {N}: {t1:6.1f} us ({flop / t1 * 1e-6:5.0f} TFLOP/s) | twin 2 x {N}: {t2:6.1f} us = "
               f"{t2 / 2:5.1f} per network ({2 * flop / t2 * 1e-6:5.0f} TFLOP/s) | twin, one tile per workgroup: {t3:6.1f} us = "
