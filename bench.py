@@ -156,26 +156,42 @@ def make_conf(batch, size, n_iters):
     return init_config(y, Config)
 
 
-def cpu_baseline(size=256, steps=3):
+def cpu_baseline(size=256, steps=5):
     """The reference step restated in stock torch fp32 (oracle/torch_ref.py) on the host cores: BASELINE config 1
-    shape (batch 1). Bounded sample: 1 warm-up + `steps` timed steps."""
+    shape (batch 1). Bounded sample: 1 warm-up + `steps` >= 5 timed steps, with torch.set_num_threads at
+    os.cpu_count() — and, where the box has more hardware threads than torch's CPU convs scale to, also at 64, one probe step
+    each; the faster setting is the one timed and reported (`cores` = the threads actually used)."""
+    import platform
     import torch
     from oracle.torch_ref import CycleGANStep
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)            # torch CPU convs stop scaling (and oversubscribe) far below 256 threads
-    torch.set_num_threads(threads)
     model = CycleGANStep(seed=0)
     g = torch.Generator().manual_seed(1234)
     A = torch.rand(1, 3, size, size, generator=g) * 2 - 1
     B = torch.rand(1, 3, size, size, generator=g) * 2 - 1
-    model.step(A, B)
+    probe = {}
+    for threads in sorted({cores, min(cores, 64)}, reverse=True):
+        torch.set_num_threads(threads)
+        model.step(A, B)                     # warm-up at this setting
+        t0 = time.perf_counter()
+        model.step(A, B)
+        probe[threads] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
     for _ in range(steps):
         model.step(A, B)
     dt = (time.perf_counter() - t0) / steps
+    cpu = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu)
+    except OSError:
+        pass
+    probes = ", ".join(f"{t} threads {1.0 / v:.3f} img/s" for t, v in probe.items())
     return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
             "sample": f"oracle/torch_ref.CycleGANStep (stock torch fp32), batch 1, {size}x{size}, 1 warm-up + "
-                      f"{steps} timed steps, {threads} threads of {cores} host cpus"}
+                      f"{steps} timed steps, {threads} threads of {cores} host cpus ({cpu}); one-step probes: {probes}"}
 
 
 # BASELINE configs[2..4] (per-GPU shapes, SURVEY.md §8 GFLOP per unit): timed for a few steps behind the headline so that the
@@ -188,6 +204,59 @@ SECONDARY = {
     "brats": {"config": "brats 3-D CycleGAN (BASELINE configs[4]): Vnet3D + PatchGAN3D-2, 128^3 patches, batch 1",
               "unit": "vol/s", "gflop_per_unit": 27692.0},
 }
+
+
+def _trunk_roofline(model, step, batch, size, timing_steps=3):
+    """`roofline` block of a 2-D ResNet-9 recipe: HIP events around every launch of the three residual-conv forms in a few
+    launch-by-launch single-stream steps (the way main() times the headline's), the form with the largest per-step total"""
+    import torch
+    from ganslate_amd.nn.native import backend
+    ops = backend.get_ops()
+
+    def select(kind, spec, flag):
+        if kind == "gconv" and spec.T == 9 and spec.Ci == 256 and spec.Co == 256 and spec.si == 1 and spec.so == 1:
+            return "rb_dgrad" if (flag or spec.border == "zero") else "rb_fwd"
+        if kind == "wgrad" and spec.T == 9 and spec.P == 256 and spec.Q == 256 and spec.si == 1:
+            return "rb_wgrad_pair" if flag else "rb_wgrad"
+        return None
+    graphed = bool(getattr(model, "_graph", None) is not None and model.step_graph_enabled)
+    ops.enable_kernel_timing(select)
+    model.step_graph_enabled = False
+    side = os.environ.get("GS_SIDE_STREAM")
+    os.environ["GS_SIDE_STREAM"] = "0"
+    try:
+        for _ in range(timing_steps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        ops.disable_kernel_timing()
+        if side is None:
+            del os.environ["GS_SIDE_STREAM"]
+        else:
+            os.environ["GS_SIDE_STREAM"] = side
+        model.step_graph_enabled = graphed
+    res, imgs = ops.kernel_timing_result(), ops.kernel_timing_images()
+    hw = (size // 4) ** 2
+    rows = {}
+    for label, (n, ms) in res.items():
+        if not n:
+            continue
+        nimg = imgs.get(label) or batch
+        flop = 2.0 * hw * nimg * 256 * 2304 * (2 if label == "rb_wgrad_pair" else 1)
+        rows[label] = {"launches_per_step": round(n / timing_steps, 1), "images_per_launch": round(nimg, 1), "avg_ms": round(ms, 4),
+                       "ms_per_step": round(n / timing_steps * ms, 3), "tflops": round(flop / (ms * 1e-3) / 1e12, 1)}
+    if not rows:
+        return None
+    dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
+    names = {"rb_fwd": "hconvw_kernel<9> (forward)", "rb_dgrad": "hconvw_kernel<9, RING> (fused data gradient)",
+             "rb_wgrad_pair": "hwgrad_wide_kernel<9> (two passes)", "rb_wgrad": "hwgrad_wide_kernel<9> (one pass)"}
+    dimg = rows[dom]["images_per_launch"]
+    return {"bound": "mfma", "achieved": rows[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(rows[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "algorithmic_bytes": algorithmic_bytes(dom, dimg, hw),
+            "kernel": f"{names[dom]}: 3x3 256->256 reflect conv over {int(dimg)} images per launch", "avg_ms": rows[dom]["avg_ms"],
+            "launches_timed": res[dom][0], "residual_conv_kernels": rows,
+            "timed_in": f"{timing_steps} launch-by-launch single-stream steps behind the timed region"}
 
 
 def run_secondary(dev, steps=10, warmup=4):
@@ -227,6 +296,8 @@ def run_secondary(dev, steps=10, warmup=4):
                      "ms_per_step": round(1e3 * dt / steps, 3),
                      "step_tflops": round(value * meta["gflop_per_unit"] / 1e3, 1),
                      "step_mfma_frac": round(value * meta["gflop_per_unit"] / 1e3 / PEAK_BF16_TFLOPS, 4)}
+        if name == "cut":
+            out[name]["roofline"] = _trunk_roofline(model, step, batch, shape[-1])
         del model, data, step
         gc.collect()
         torch.cuda.empty_cache()
@@ -532,6 +603,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": kernels[dom]["frac"], "traffic": hbm,
                                "traffic_source": hbm_src,
+                               "traffic_note": "PMC bytes of the same kernel at the same launch size, measured on another box of "
+                                               "the pool than this run's `achieved` (HIP events here)" if hbm is not None else None,
                                "algorithmic_bytes": algorithmic_bytes(dom, dimg, hw, nets=2 if dimg > args.batch else 1),
                                "kernel": f"{names[dom]}: 3x3 256->256 reflect conv, M={int(hw * dimg)} N=256 K=2304"
                                          + (" x 2 passes" if dom == "rb_wgrad_pair" else "")

@@ -16,6 +16,10 @@
 // data / weight / bias gradients; dgamma = sum(dout o O) reduced in a fixed order (deterministic).
 #include "common.hpp"
 
+// wgrad.hip: dst[e] += slab 0 [e] + slab 1 [e] + ... in slab order
+void gs_launch_slab_reduce(const float* ws, float* dst, long long n4, int slabs, long long stride4, hipStream_t st, int nets,
+                           long long ws_y4, long long dw_y4);
+
 namespace {
 constexpr int GT = 64;                 // output tile per workgroup (GT x GT), 4 waves of 32 x 32
 constexpr int GK = 32;                 // K-step
@@ -278,12 +282,22 @@ __global__ __launch_bounds__(256) void attn_colsum_kernel(const unsigned short* 
   if (threadIdx.x == 0 && c < n) db[c] += red[0];
 }
 
+// zero the pad columns behind the q and the k block of dqkv [rows][ct] (widths that are not a multiple of 8)
+__global__ __launch_bounds__(256) void attn_zero_cols_kernel(unsigned short* m, long long rows, int ld, int c0, int n, int block) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r < rows)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < n; ++c) m[(size_t)r * ld + b * block + c0 + c] = 0;
+}
+
 constexpr int DOUT_BLOCKS = 512;
 int rup(int v, int m) { return (v + m - 1) / m * m; }
 struct Plan {
   int dp, ct;                           // padded q / k width, channels of the stacked projection [q | k | v]
   long long rows;                       // B * N
-  size_t qk, qkv, O, P, S, dqkv, dO, dS, part, end; // byte offsets into `work`
+  size_t qk, qkv, O, P, S, fwd_end, dqkv, dO, dS, part, wcat, dws, end; // byte offsets into `work`
+  int splits;                           // K splits of the projections' weight gradients (rows = splits * kc)
+  long long kc;
 };
 Plan plan(const gs_attn_desc* d) {
   Plan p;
@@ -298,10 +312,19 @@ Plan plan(const gs_attn_desc* d) {
   p.O = take((size_t)p.rows * d->C * 2);
   p.P = take(nn * 2);
   p.S = take(nn * 4);                   // logits (forward), dP (backward)
+  p.fwd_end = o;                        // (a pass that will never run backward needs nothing behind this point)
   p.dqkv = take((size_t)p.rows * p.ct * 2);
   p.dO = take((size_t)p.rows * d->C * 2);
   p.dS = take(nn * 2);
   p.part = take(DOUT_BLOCKS * 4);
+  p.wcat = take((size_t)p.ct * d->C * 4);          // [Wq; Wk; Wv] stacked along k for the ONE launch that forms dx
+  // weight gradients: K = all voxels of the batch over a handful of output tiles — split over up to 32 ranges whose partial
+  // products go to slabs, added in slab order afterwards (deterministic)
+  p.splits = 1;
+  for (int sp = 32; sp > 1; sp >>= 1)
+    if (p.rows % sp == 0 && p.rows / sp >= 128) { p.splits = sp; break; }
+  p.kc = p.rows / p.splits;
+  p.dws = take(p.splits > 1 ? (size_t)p.splits * d->C * d->C * 4 : 0);
   p.end = o;
   return p;
 }
@@ -315,6 +338,12 @@ int check(const gs_attn_desc* d) {
 extern "C" int64_t gs_attn_work_bytes(const gs_attn_desc* d) {
   if (!d || d->B < 1 || d->N < 1 || d->C < 8) return -1;
   return (int64_t)plan(d).end;
+}
+// the same for a forward pass whose state is never handed to gs_attn_backward (inference): q / k / v, logits, probabilities and
+// the attention output only — without the backward's buffers (at N = 4096: 134 MB less per block)
+extern "C" int64_t gs_attn_forward_work_bytes(const gs_attn_desc* d) {
+  if (!d || d->B < 1 || d->N < 1 || d->C < 8) return -1;
+  return (int64_t)plan(d).fwd_end;
 }
 
 extern "C" int gs_attn_forward(const gs_attn_desc* d, const void* x, const gs_attn_params* w, void* out, void* work,
@@ -411,27 +440,42 @@ extern "C" int gs_attn_backward(const gs_attn_desc* d, const void* x, const void
   e.A = dS; e.lda = N; e.sa = sNN; e.B = qk; e.ldb = 2 * p.dp; e.sb = sqk; e.C = dqkv + p.dp; e.ldc = p.ct; e.sc = sq;
   e.M = N; e.N = dq; e.K = N; e.alpha = 1.f;
   if (int rc = bgemm<true, true, unsigned short, float, true>(e, d->B, st)) return rc;
-  // projections: dx = dout + dq Wq + dk Wk + dv Wv (three accumulating passes through a fp32 scratch would round three times;
-  // here the sum runs in ONE launch per operand with the running bf16 result as the residual of the next)
-  const float* Ws[3] = {w->wq, w->wk, w->wv};
+  // projections: dx = dout + [dq | dk | dv] [Wq; Wk; Wv] as ONE launch over the stacked k axis: one fp32 accumulation, one
+  // rounding (three launches, each taking the previous bf16 result as its residual, rounded three times). The stacked fp32
+  // weights are built in the scratch (pad rows between the blocks zero, like the pad columns of dqkv).
   const int cols[3] = {dq, dq, C}, c0[3] = {0, p.dp, 2 * p.dp};
-  const unsigned short* res = static_cast<const unsigned short*>(dout);
-  for (int i = 0; i < 3; ++i) {
+  {
+    const float* Ws[3] = {w->wq, w->wk, w->wv};
+    float* wcat = reinterpret_cast<float*>(wk + p.wcat);
+    if (p.dp != dq) {
+      GS_CHECK_HIP(hipMemsetAsync(wcat, 0, (size_t)p.ct * C * 4, st));
+      // (dq / dk are written column by column range: their pad columns would multiply the zero rows with whatever the scratch held)
+      hipLaunchKernelGGL(attn_zero_cols_kernel, dim3((unsigned)((p.rows + 255) / 256)), dim3(256), 0, st, dqkv, p.rows, p.ct, dq,
+                         p.dp - dq, p.dp);
+    }
+    for (int i = 0; i < 3; ++i)
+      GS_CHECK_HIP(hipMemcpyAsync(wcat + (size_t)c0[i] * C, Ws[i], (size_t)cols[i] * C * 4, hipMemcpyDeviceToDevice, st));
     BGemmK f{};
-    f.A = dqkv + c0[i]; f.lda = p.ct; f.B = Ws[i]; f.ldb = C; f.C = dx; f.ldc = C; f.M = (int)p.rows; f.N = C; f.K = cols[i];
-    f.alpha = 1.f; f.res = res;
+    f.A = dqkv; f.lda = p.ct; f.B = wcat; f.ldb = C; f.C = dx; f.ldc = C; f.M = (int)p.rows; f.N = C; f.K = p.ct;
+    f.alpha = 1.f; f.res = static_cast<const unsigned short*>(dout);
     if (int rc = bgemm<false, true, unsigned short, float, true>(f, 1, st)) return rc;
-    res = static_cast<const unsigned short*>(dx);
   }
   if (gw) {
     float* dWs[3] = {gw->wq, gw->wk, gw->wv};
     float* dbs[3] = {gw->bq, gw->bk, gw->bv};
+    float* slabs = reinterpret_cast<float*>(wk + p.dws);
     for (int i = 0; i < 3; ++i) {
       if (dWs[i]) {       // dW[o][c] += sum_rows dproj[row][o] x[row][c]
         BGemmK h{};
-        h.A = dqkv + c0[i]; h.lda = p.ct; h.B = x; h.ldb = C; h.C = dWs[i]; h.ldc = C; h.M = cols[i]; h.N = C; h.K = (int)p.rows;
-        h.alpha = 1.f; h.accumulate = 1;
-        if (int rc = bgemm<true, true, unsigned short, unsigned short, false>(h, 1, st)) return rc;
+        h.A = dqkv + c0[i]; h.lda = p.ct; h.B = x; h.ldb = C; h.ldc = C; h.M = cols[i]; h.N = C; h.alpha = 1.f;
+        if (p.splits > 1) {       // K ranges as the batch axis: slab sp = the partial product over voxels [sp * kc, (sp + 1) * kc)
+          h.K = (int)p.kc; h.sa = p.kc * p.ct; h.sb = p.kc * C; h.C = slabs; h.sc = (long long)cols[i] * C; h.accumulate = 0;
+          if (int rc = bgemm<true, true, unsigned short, unsigned short, false>(h, p.splits, st)) return rc;
+          gs_launch_slab_reduce(slabs, dWs[i], (long long)cols[i] * C / 4, p.splits, (long long)cols[i] * C / 4, st, 1, 0, 0);
+        } else {
+          h.K = (int)p.rows; h.C = dWs[i]; h.accumulate = 1;
+          if (int rc = bgemm<true, true, unsigned short, unsigned short, false>(h, 1, st)) return rc;
+        }
       }
       if (dbs[i])
         hipLaunchKernelGGL(attn_colsum_kernel, dim3(cols[i]), dim3(256), 0, st, dqkv, p.rows, p.ct, c0[i], cols[i], dbs[i]);

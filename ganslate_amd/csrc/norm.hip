@@ -203,6 +203,28 @@ __device__ __forceinline__ double slot_sum_ordered(const float* __restrict__ src
   return s;
 }
 
+// Workgroup -> (channel group, pixel chunk, image) of the channel-group norm kernels from a 1-D grid. Default: channel group
+// fastest, then pixel chunk, then image. xcd_affine (option norm_xcd, N a multiple of 8): workgroup L runs on XCD L % 8
+// (observed dispatch order; speed only) and takes an image n with n % 8 == L % 8 — the XCD whose workgroups wrote that image in
+// the persistent conv launch in front of this kernel and will read it in the one behind (hconvw.hip: XCD x owns the tiles of
+// images x, x + 8, ...), so its lines are served by that XCD's L2 instead of the fabric — the image written LAST first.
+__device__ __forceinline__ void norm_block_decode(int& cg, int& chunk, int& n, int CG, int nchunks, int N, int xcd_affine) {
+  const int L = blockIdx.x;
+  const int per_img = CG * nchunks;
+  if (xcd_affine && (N & 7) == 0) {
+    const int x = L & 7, j = L >> 3;
+    const int k = j / per_img, r = j - k * per_img;
+    n = x + 8 * (xcd_affine == 2 ? k : (N / 8 - 1 - k));
+    cg = r % CG;
+    chunk = r / CG;
+  } else {
+    cg = L % CG;
+    const int t = L / CG;
+    chunk = t % nchunks;
+    n = t / nchunks;
+  }
+}
+
 // ---- forward apply with the statistics finalised in the prologue ---------------------------------------------------
 // The producing conv leaves per-tile partial sums [N][slots][2][C]; the old path ran slot_sum_kernel (a ~5 us launch of
 // 128 tiny workgroups, ~200 of them per training step) and then the apply kernel. Here the apply kernel is laid out by
@@ -212,12 +234,13 @@ __device__ __forceinline__ double slot_sum_ordered(const float* __restrict__ src
 __global__ __launch_bounds__(256) void inorm_stats_act_fwd_kernel(const uint4* y, const float* partial, int slots,
                                                                   float eps, float* mean_rstd, const uint4* res,
                                                                   uint4* x, int hw, int C8, int act, float slope,
-                                                                  int pix_per_block) {
+                                                                  int pix_per_block, int nchunks, int N, int xcd_affine) {
   __shared__ double tot[2][64];
   __shared__ float mrs[2][64];
   // channel group fastest in dispatch order: the C/64 workgroups that together cover whole 2*C-byte pixel rows of one
   // pixel chunk run side by side (DRAM pages are walked once, not C/64 times at different moments)
-  const int cg = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;
+  int cg, chunk, n;
+  norm_block_decode(cg, chunk, n, C8 / 8, nchunks, N, xcd_affine);
   const int tid = threadIdx.x;
   const int C = C8 * 8;
   // the first two pixels of this thread do not depend on the statistics: their loads go out before the slot sums
@@ -289,9 +312,11 @@ extern "C" int gs_inorm_stats_act_forward(const void* y, const float* partial, i
   // occupancy), while the slot sums (<= 64 slots x 128 floats) stay a short prologue
   int ppb = 64;
   while ((hw + ppb - 1) / ppb > 1024) ppb *= 2;
-  hipLaunchKernelGGL(inorm_stats_act_fwd_kernel, dim3(C / 64, (unsigned)((hw + ppb - 1) / ppb), N), dim3(256), 0,
+  const int nchunks = (int)((hw + ppb - 1) / ppb);
+  hipLaunchKernelGGL(inorm_stats_act_fwd_kernel, dim3((unsigned)(C / 64) * nchunks * N), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const uint4*>(y), partial, slots, eps, mean_rstd,
-                     static_cast<const uint4*>(res), static_cast<uint4*>(x), (int)hw, C / 8, act, slope, ppb);
+                     static_cast<const uint4*>(res), static_cast<uint4*>(x), (int)hw, C / 8, act, slope, ppb, nchunks, N,
+                     gs_opt(GS_OPT_NORM_XCD));
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -547,9 +572,10 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_cg_kernel(const uint4* gp
                                                                  const float* mean_rstd, const float* partial,
                                                                  int slots, uint4* dy, uint4* gsum, float* sums, int D,
                                                                  int H, int W, int C8, int fold, int act, float slope,
-                                                                 int pix_per_block) {
+                                                                 int pix_per_block, int nchunks, int N, int xcd_affine) {
   __shared__ float tot[3][64];
-  const int cg = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;      // channel group fastest, see the forward kernel
+  int cg, chunk, n;
+  norm_block_decode(cg, chunk, n, C8 / 8, nchunks, N, xcd_affine);     // channel group fastest, see the forward kernel
   const int tid = threadIdx.x;
   const int C = C8 * 8;
   const int HW = D * H * W;
@@ -746,10 +772,11 @@ extern "C" int gs_inorm_act_backward(const void* g_pad, const void* g2, const vo
         while (ppb < 256 && per * ((HW + ppb - 1) / ppb) > slots && per * ((HW + ppb + 31) / (ppb + 32)) >= slots / 2) ppb += 32;
       }
 #define GS_LAUNCH_APPLY_CG(FM)                                                                                      \
-  hipLaunchKernelGGL((inorm_bwd_apply_cg_kernel<FM>), dim3(C / 64, (unsigned)((HW + ppb - 1) / ppb), N), dim3(256), 0, \
+  hipLaunchKernelGGL((inorm_bwd_apply_cg_kernel<FM>), dim3((unsigned)(C / 64) * (unsigned)((HW + ppb - 1) / ppb) * N), dim3(256), 0, \
                      st, static_cast<const uint4*>(g_pad), static_cast<const uint4*>(g2),                            \
                      static_cast<const uint4*>(y), mean_rstd, scratch, chunks, static_cast<uint4*>(dy),              \
-                     static_cast<uint4*>(gsum), sums, D, H, W, C8, fold, act, slope, ppb)
+                     static_cast<uint4*>(gsum), sums, D, H, W, C8, fold, act, slope, ppb, (int)((HW + ppb - 1) / ppb), N, \
+                     gs_opt(GS_OPT_NORM_XCD))
       if (fm == 0) GS_LAUNCH_APPLY_CG(0);
       else if (fm == 1) GS_LAUNCH_APPLY_CG(1);
       else if (fm == 2) GS_LAUNCH_APPLY_CG(2);

@@ -224,6 +224,7 @@ _PROTOS = {
     "gs_repack_bf16_groups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_repack_bf16_tiled_groups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "gs_attn_work_bytes": (C.c_int64, [C.POINTER(AttnDesc)]),
+    "gs_attn_forward_work_bytes": (C.c_int64, [C.POINTER(AttnDesc)]),
     "gs_attn_forward": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.POINTER(AttnParams), C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "gs_attn_backward": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p, C.POINTER(AttnParams),

@@ -46,7 +46,7 @@ class HipOps(TwinSplit):
     # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
     # host side are mapped onto its options here, when the backend is created and whenever a model is built.
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
-                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_WGRAD_TWIN": "wgrad_twin",
+                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_NORM_XCD": "norm_xcd", "GS_WGRAD_TWIN": "wgrad_twin",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
                    "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
@@ -937,18 +937,23 @@ class HipOps(TwinSplit):
             setattr(p, k, t.data_ptr() if t is not None else None)
         return d, p
 
-    def attn_forward(self, x, params):
+    def attn_forward(self, x, params, need_backward=None):
         """x: NDHWC activation [B, ..., C]; params: {gamma [1], wq [C/8, C], bq, wk, bk, wv [C, C], bv} fp32 (torch layout)
         -> (out like x, saved state for attn_backward)"""
         assert x.is_contiguous() and x.dtype == self.act_dtype
         d, p = self._attn_args(x, params)
-        work = torch.empty(int(self.lib.gs_attn_work_bytes(C.byref(d))), dtype=torch.uint8, device=self.device)
+        # (a pass that will not run backward — inference, validation — takes the forward part of the scratch only)
+        need_bwd = True if need_backward is None else bool(need_backward)     # (callers inside an autograd Function say so)
+        size = self.lib.gs_attn_work_bytes(C.byref(d)) if need_bwd else self.lib.gs_attn_forward_work_bytes(C.byref(d))
+        work = torch.empty(int(size), dtype=torch.uint8, device=self.device)
         out = torch.empty_like(x)
         L.check(self.lib.gs_attn_forward(C.byref(d), _ptr(x), C.byref(p), _ptr(out), _ptr(work), _stream()), "gs_attn_forward")
-        return out, (x, work)
+        return out, ((x, work) if need_bwd else None)
 
     def attn_backward(self, saved, dout, params, grads):
         """-> dx; parameter gradients are ADDED into the tensors of `grads` (same keys as params; None: skipped)"""
+        if saved is None:
+            raise RuntimeError("attn_backward: this forward pass kept no state (it ran under no_grad / need_backward=False)")
         x, work = saved
         d, p = self._attn_args(x, params)
         _, g = self._attn_args(x, grads)

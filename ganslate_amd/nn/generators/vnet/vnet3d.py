@@ -331,7 +331,7 @@ class Vnet3D(NativeNet):
             ops.pnorm_forward(rec.Xn, None, rec.out, C=blk.C, slope=self._slope(blk.tail_slope), res=rec.D0, res_mode=1)
             rec.attn = None
             if self.attention[len(s.down)]:      # the attended map feeds the next down block AND the skip connection
-                rec.out, rec.attn = ops.attn_forward(rec.out, self.attn_tensors(f"attn_blocks.{len(s.down)}"))
+                rec.out, rec.attn = ops.attn_forward(rec.out, self.attn_tensors(f"attn_blocks.{len(s.down)}"), need_backward=bool(save))
             s.down.append(rec)
             cur = rec.out
         # UpBlocks

@@ -540,7 +540,7 @@ class NativeNet:
             if stop is not None and i > stop:
                 break
             if i > 0 and self.nodes[i - 1].attn:       # SelfAttentionBlock on the previous node's output
-                xo, sv = ops.attn_forward(acts[-1], self.attn_tensors(self.nodes[i - 1].attn))
+                xo, sv = ops.attn_forward(acts[-1], self.attn_tensors(self.nodes[i - 1].attn), need_backward=bool(save))
                 attn_saved[i - 1] = sv if save else None
                 acts[-1] = xo
             sp = nd.spec

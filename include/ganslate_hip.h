@@ -485,6 +485,9 @@ int gs_patchnce_backward(const gs_patchnce_desc* d, const float* const* xq, floa
 typedef struct gs_attn_desc { int32_t B, N, C; } gs_attn_desc;
 typedef struct gs_attn_params { float *gamma, *wq, *bq, *wk, *bk, *wv, *bv; } gs_attn_params;
 int64_t gs_attn_work_bytes(const gs_attn_desc* d);
+/* ... and for a forward pass whose state is never handed to gs_attn_backward (inference, attention.py:26-47 under no_grad):
+ * without the backward's buffers */
+int64_t gs_attn_forward_work_bytes(const gs_attn_desc* d);
 int gs_attn_forward(const gs_attn_desc* d, const void* x, const gs_attn_params* params, void* out, void* work, void* stream);
 int gs_attn_backward(const gs_attn_desc* d, const void* x, const void* dout, const gs_attn_params* params,
                      const gs_attn_params* grads, void* work, void* dx, void* stream);

@@ -718,7 +718,7 @@ class RefOps(TwinSplit):
 
     # ---- PatchNCE + patch MLP: torch autograd of the reference composition --------------------------------------
     # ---- SelfAttentionBlock (ganslate/nn/attention.py:26-47 on NDHWC activations) ------------------------------------
-    def attn_forward(self, x, params):
+    def attn_forward(self, x, params, need_backward=None):
         with torch.enable_grad():
             x_ = x.detach().float().clone().requires_grad_()
             p_ = {k: v.detach().clone().requires_grad_() for k, v in params.items()}
