@@ -9,7 +9,7 @@ import argparse
 import json
 import re
 
-LABELS = {"hconvw_kernel<9, false>": "rb_fwd", "hconvw_kernel<9, true>": "rb_dgrad", "hwgrad_wide_kernel<9>": "rb_wgrad_pair"}
+LABELS = {"hconvw_kernel<9, false": "rb_fwd", "hconvw_kernel<9, true, false": "rb_dgrad", "hwgrad_wide_kernel<9>": "rb_wgrad_pair"}
 
 
 def parse(path, counter):
