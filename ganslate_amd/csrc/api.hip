@@ -80,6 +80,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
                                 // OFF: the in-launch rendezvous costs more than the launch it saves (profiles/r05_ring_apply.txt);
                                 // bits 2 / 4 / 8 / 16 are timing ablations (wrong results)
     {"norm_xcd", 0},            // norm.hip: the channel-group norm kernels take image n on XCD n % 8 (1: last image first, 2: in order)
+    {"wgrad_rows", 1},          // wgrad.hip: the im2col weight gradient stores whole tile rows through LDS; one split adds without atomics
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

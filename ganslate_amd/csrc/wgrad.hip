@@ -25,6 +25,7 @@ struct WGradK {
   // twin batch (gs_twin): the pixel range of each network's images is split on its own (splits = nets * splits_net, no
   // workgroup straddles the two), the second network's sums go to dw + dw_delta floats / its own slabs
   int nets, splits_net, m_net;
+  int vec, rmw;               // vec: every row of dw / ws starts on a 16-byte boundary; rmw: one split per network (see the epilogue)
   long long dw_delta;
   gs_wgrad_desc d;
 };
@@ -209,16 +210,58 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
     nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
   }
 
-  // ---- epilogue: C[p][n'] accumulated with fp32 atomics -------------------------------------------
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------
+  // C[p][n'] goes to its slab (p.ws), or — one split per network: this workgroup is the only contributor of its elements —
+  // is added to dw with plain loads and stores (p.rmw), or is accumulated with fp32 atomics (several splits without slabs).
+  // The first two go through LDS so that every instruction moves whole rows of the tile: 16 B per lane, BQ * 4 contiguous
+  // bytes per row. (The accumulator layout gives 4-byte accesses in 64-byte runs; as fp32 atomics on a 134 MB gradient —
+  // the U-Net's 2048 -> 1024 transposed convolutions, one split — that ran at 1.2 TB/s.)
   const int frow = lane & 15;
   const int TQ = d.T * d.Q;
+  float* const obase = p.ws ? p.ws + (size_t)sp * p.ws_stride : p.dw + (size_t)net * p.dw_delta;
+  if (p.vec && (p.ws || p.rmw)) {          // (uniform)
+    constexpr int CP = BQ + 4;             // floats per LDS row: the four 4-row groups of a write land on distinct banks
+    static_assert(BP * CP * 4 <= NSTAGE * STAGE, "the output tile must fit the stage buffers");
+    static_assert(BQ % 4 == 0 && BQ / 4 <= 64 && 64 % (BQ / 4) == 0, "row = a whole number of 16-byte lanes");
+    float* ct = reinterpret_cast<float*>(smem);
+    __syncthreads();                       // every wave has read its last fragments
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          ct[(wp * (BP / WP) + i * 16 + fk * 4 + r) * CP + wq * (BQ / WQ) + j * 16 + frow] = acc[i][j][r];
+    __syncthreads();
+    constexpr int LPR = BQ / 4, RPI = 64 / LPR;      // lanes per row, rows per instruction
+    constexpr int NR = (BP + NW * RPI - 1) / (NW * RPI);
+    const int c4 = (lane % LPR) * 4, rsub = lane / LPR;
+    const int col = tq * BQ + c4;
+    const bool rmw = p.ws == nullptr;
+    f32x4 old[NR];
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+      const int rr = (it * NW + wave) * RPI + rsub, pp = tp * BP + rr;
+      old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rmw && rr < BP && pp < d.P && col < TQ) old[it] = *reinterpret_cast<const f32x4*>(obase + (size_t)pp * d.dw_ld + col);
+    }
+#pragma unroll
+    for (int it = 0; it < NR; ++it) {
+      const int rr = (it * NW + wave) * RPI + rsub, pp = tp * BP + rr;
+      if (rr < BP && pp < d.P && col < TQ) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ct + rr * CP + c4);
+        *reinterpret_cast<f32x4*>(obase + (size_t)pp * d.dw_ld + col) = old[it] + v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int pp = tp * BP + wp * (BP / WP) + i * 16 + fk * 4 + r;
       if (pp < d.P) {
-        float* row = (p.ws ? p.ws + (size_t)sp * p.ws_stride : p.dw + (size_t)net * p.dw_delta) + (size_t)pp * d.dw_ld;
+        float* row = obase + (size_t)pp * d.dw_ld;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int col = tq * BQ + wq * (BQ / WQ) + j * 16 + frow;
@@ -271,6 +314,9 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int pla
   // layers (1-128 pixels, 16.8 M weights) paid 4 x 67 MB of traffic per weight gradient for a slab of one.
   *slabs = splits == 1 ? 0 : (int)splits;
   if (splits == 1) k.ws = nullptr;
+  k.rmw = splits == 1 && gs_opt(GS_OPT_WGRAD_ROWS) != 0;
+  k.vec = gs_opt(GS_OPT_WGRAD_ROWS) != 0 && (reinterpret_cast<uintptr_t>(k.dw) & 15) == 0 && (k.dw_delta & 3) == 0 &&
+          (reinterpret_cast<uintptr_t>(k.ws) & 15) == 0 && (k.ws_stride & 3) == 0;
   if (plan_only) return 0;
   constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 4 + 1024;
   static bool configured = false;

@@ -7,6 +7,7 @@ the max-abs of the oracle result (one bf16 ulp of the largest value, accumulatio
 fp32 outputs (weight gradients, statistics, losses) rel 2e-3 of max-abs (fp32 atomics / reduction order).
 """
 import os
+import numpy as np
 
 import pytest
 import torch
@@ -1356,6 +1357,49 @@ def test_wgrad_is_bitwise_reproducible(hip_ops, case):
         outs.append(dw.cpu())
     assert torch.equal(outs[0], outs[1]), "two runs of the deterministic weight gradient differ"
     close_f32(outs[2] - 0.5, 2 * (outs[0] - 0.5), "pair of identical operands = twice the single pass", rel=1e-5)
+
+
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 1024, 1024, 4, 2, 1), 1, 8, 8),                 # U-Net bottleneck: 16 pixels, one split -> dw += in place
+    (ConvSpec("convT", 512, 256, 4, 2, 1), 1, 8, 8),                  # its transposed sibling
+    (ConvSpec("conv", 256, 40, 4, 2, 1), 1, 16, 16),                  # P <= 64 instantiation, ragged tile columns
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 4, 32, 32),                 # several splits -> slabs
+    (ConvSpec("conv", 64, 128, 3, 1, 1, dims=3), 1, 6, 8, 8),         # volume instantiation
+], ids=_ids)
+@pytest.mark.parametrize("misalign", [0, 1])
+def test_weight_gradient_rows_through_lds(hip_ops, case, misalign):
+    """wgrad_kernel's epilogue (option wgrad_rows): the tile goes through LDS and out in whole rows, 16 B per lane; with one
+    split per network it is ADDED to dw with plain loads / stores instead of fp32 atomics. Bit-identical to the accumulator
+    -layout epilogue (same sums, same single addition per element), accumulate semantics kept; a dw that does not start on
+    a 16-byte boundary takes the old epilogue."""
+    spec, N, sizes = case[0], case[1], case[2:]
+    if misalign and N * int(np.prod(sizes)) > 256:
+        pytest.skip("the slab reduction itself needs a 16-byte aligned dw")
+    low = lower(spec, *sizes)
+    g = torch.Generator().manual_seed(41)
+    dev = hip_ops.device
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16).to(dev)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16).to(dev)
+    a, gt = (gy, xa) if spec.kind == "conv" else (xa, gy)
+    n = spec.P * spec.T * spec.Q
+    pre = torch.randn(n + 4, generator=g)
+    outs = {}
+    default = hip_ops.get_option("wgrad_rows")
+    try:
+        for on in (1, 0):
+            hip_ops.set_option("wgrad_rows", on)
+            buf = pre.clone().to(dev)
+            dw = buf[misalign:misalign + n]
+            hip_ops.wgrad(low.wgrad, a, gt, dw)
+            torch.cuda.synchronize()
+            outs[on] = buf.cpu()
+    finally:
+        hip_ops.set_option("wgrad_rows", default)
+    assert torch.equal(outs[1], outs[0]), "row epilogue vs accumulator-layout epilogue"
+    assert torch.equal(outs[1][:misalign], pre[:misalign]) and torch.equal(outs[1][misalign + n:], pre[misalign + n:])
+    ref = pre.clone()
+    RefOps().wgrad(low.wgrad, a.cpu(), gt.cpu(), ref[misalign:misalign + n])
+    close_f32(outs[1], ref, "vs oracle")
 
 
 @pytest.mark.parametrize("shape,slots", [((8, 64, 64, 256), 16), ((2, 17, 13, 64), 3), ((1, 30, 30, 512), 1),
