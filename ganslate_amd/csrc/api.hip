@@ -81,6 +81,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
                                 // bits 2 / 4 / 8 / 16 are timing ablations (wrong results)
     {"norm_xcd", 0},            // norm.hip: the channel-group norm kernels take image n on XCD n % 8 (1: last image first, 2: in order)
     {"wgrad_rows", 1},          // wgrad.hip: the im2col weight gradient stores whole tile rows through LDS; one split adds without atomics
+    {"splitk_multi", 1},        // gconv.hip: split-K over the merged parity classes of a small stride-2 layer (one launch + one finalize)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "gconv.hpp"
+#include <algorithm>
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
@@ -467,6 +468,9 @@ struct SplitFinK {
   long long split_stride;
   int splits, tiles_m, bm;
   float rcp_wc, rcp_hc;
+  // merged parity classes (gs_gconv_forward_multi_ws): class c's output parity and first statistics slot; n_cls = 0: d's own
+  int n_cls;
+  int cpz[GS_MULTI_MAX_CLS], cpy[GS_MULTI_MAX_CLS], cpx[GS_MULTI_MAX_CLS], cslot0[GS_MULTI_MAX_CLS];
   gs_gconv_desc d;
 };
 
@@ -479,6 +483,11 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
   int b = blockIdx.x;
   const int cg = b % cgroups;
   b /= cgroups;
+  const int ncls = p.n_cls > 0 ? p.n_cls : 1;
+  const int ci = b % ncls;
+  b /= ncls;
+  const int cpz = p.n_cls > 0 ? p.cpz[ci] : d.pz, cpy = p.n_cls > 0 ? p.cpy[ci] : d.py, cpx = p.n_cls > 0 ? p.cpx[ci] : d.px;
+  const int cslot0 = p.n_cls > 0 ? p.cslot0[ci] : d.stats_slot0;
   const int mt = b % p.tiles_m;
   const int n = b / p.tiles_m;
   const int tx = threadIdx.x & 3, py = threadIdx.x >> 2;     // channel quad, pixel lane (0..63)
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
     const int jj = m - zi * d.Wc;
     const int zz = div_small(zi, d.Hc, p.rcp_hc);
     const int ii = zi - zz * d.Hc;
-    const size_t opix = (((size_t)n * d.Do + (zz * d.so + d.pz)) * d.Ho + (ii * d.so + d.py)) * d.Wo + (jj * d.so + d.px);
+    const size_t opix = (((size_t)n * d.Do + (zz * d.so + cpz)) * d.Ho + (ii * d.so + cpy)) * d.Wo + (jj * d.so + cpx);
     f32x4 v = bia;
     const float* src = p.partial + opix * d.Co + co;
     int sp = 0;                                  // fixed order: reproducible; four splits' loads in flight
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(256) void gconv_splitk_finalize_kernel(const SplitF
       if (c < d.Co) {
         float a = 0.f, q = 0.f;
         for (int y = 0; y < 64; ++y) { a += red[y][threadIdx.x][0]; q += red[y][threadIdx.x][1]; }
-        float* spt = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + mt) * 2) * d.Co;
+        float* spt = p.stats + (((size_t)n * d.stats_slots + cslot0 + mt) * 2) * d.Co;
         spt[c] = a;
         spt[d.Co + c] = q;
       }
@@ -814,7 +823,7 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     SplitFinK f;
     f.partial = ws; f.bias = bias; f.out = static_cast<char*>(out); f.stats = stats;
     f.split_stride = k.split_stride; f.splits = k.splits; f.tiles_m = k.tiles_m; f.bm = tc.bm;
-    f.rcp_wc = k.rcp_wc; f.rcp_hc = k.rcp_hc; f.d = *d;
+    f.rcp_wc = k.rcp_wc; f.rcp_hc = k.rcp_hc; f.d = *d; f.n_cls = 0;
     const int fblocks = d->N * k.tiles_m * ((d->Co + 15) / 16);
     hipLaunchKernelGGL(gconv_splitk_finalize_kernel, dim3(fblocks), dim3(256), 0, st, f);
     GS_CHECK_HIP(hipGetLastError());
@@ -874,29 +883,83 @@ extern "C" int gs_gconv_forward_multi_twin(const gs_gconv_desc* const* descs, in
 // (k3: 1/2/2/4 taps, k4: 4 each), 8 in 3-D, each of them a quarter of the layer's pixels — at batch 8 the 32x32 / 64x64
 // PatchGAN gradients are 64-256 workgroups of a few K-steps per launch, paid four times with a split-K pass behind each
 // (profiles/r02_conv_table.txt: 100-250 TFLOP/s). Merged, the classes are one grid: fixed costs once, 4x the workgroups.
-extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t count, const void* in,
-                                      const void* const* w_packs, const float* bias, void* out, float* stats,
-                                      void* stream) {
-  GS_REQUIRE(descs && w_packs && count >= 1 && in && out, "gs_gconv_forward_multi: null argument");
+namespace {
+// classes of one shape (even extents), short tap lists, at least two of them: they can share a grid
+bool multi_mergeable(const gs_gconv_desc* const* descs, int count) {
   const gs_gconv_desc* d0 = descs[0];
   bool merge = count >= 2 && count <= GS_MULTI_MAX_CLS && gs_opt(GS_OPT_GCONV_MULTI) != 0;
   for (int c = 0; c < count && merge; ++c) {
     const gs_gconv_desc* d = descs[c];
-    GS_REQUIRE(d && w_packs[c], "gs_gconv_forward_multi: null class %d", c);
-    merge = d->T >= 1 && d->T <= GS_MULTI_MAX_TAPS && !d->accumulate && d->N == d0->N && d->Hi == d0->Hi &&
+    merge = d && d->T >= 1 && d->T <= GS_MULTI_MAX_TAPS && !d->accumulate && d->N == d0->N && d->Hi == d0->Hi &&
             d->Wi == d0->Wi && d->Ci == d0->Ci && d->Di == d0->Di && d->Do == d0->Do && d->Dc == d0->Dc &&
             d->in_cs == d0->in_cs && d->in_co == d0->in_co && d->Ho == d0->Ho && d->Wo == d0->Wo && d->Co == d0->Co &&
             d->out_cs == d0->out_cs && d->out_co == d0->out_co && d->Hc == d0->Hc && d->Wc == d0->Wc && d->so == d0->so &&
             d->si == d0->si && d->w_rows == d0->w_rows && d->border == d0->border && d->act == d0->act &&
             d->slope == d0->slope && d->stats_slots == d0->stats_slots && !gs_hconv_slots(d) && !gs_hconvw_slots(d);
   }
-  if (!merge) {      // classes of different shapes (odd extents), long tap lists, a single class: one launch each
+  return merge;
+}
+// Split-K plan of the merged launch: the U-Net's bottleneck transposed convs / data gradients are four classes of 1-128
+// pixels with K = 4 x 1024..2048 each; one class at a time they are four launches of a few K-steps per workgroup plus four
+// finalize passes, and each launch pays its fixed cost (tables, first DMA latency, drain) for 8 MB of weights. Merged, the
+// classes fill the chip with a quarter of the splits each. Returns 1 = no split.
+int splitk_plan_multi(const gs_gconv_desc* const* descs, int count, const TileCfg& tc) {
+  const gs_gconv_desc* d = descs[0];
+  if (!gs_opt(GS_OPT_SPLITK) || !gs_opt(GS_OPT_SPLITK_MULTI) || (tc.bm != 128 && tc.bn != 16)) return 1;
+  const long long pix = (long long)d->Dc * d->Hc * d->Wc;
+  const long long blocks = (long long)count * d->N * ((pix + tc.bm - 1) / tc.bm) * ((d->Co + tc.bn - 1) / tc.bn);
+  int nk = descs[0]->Kp >> 6;
+  for (int c = 1; c < count; ++c) nk = std::min(nk, descs[c]->Kp >> 6);
+  if (blocks > gs_opt(GS_OPT_SPLITK_MAX_BLOCKS) || nk < 16) return 1;
+  long long splits = gs_opt(GS_OPT_SPLITK_TARGET) / blocks;
+  if (splits > nk / 4) splits = nk / 4;
+  const long long out_floats = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
+  while (splits > 1 && splits * out_floats > (64LL << 20)) --splits;     // <= 256 MiB of partial sums
+  return splits < 2 ? 1 : (int)splits;
+}
+int gconv_forward_multi_impl(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
+                             const float* bias, void* out, float* stats, float* ws, int64_t ws_floats, void* stream);
+}  // namespace
+
+extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t count, const void* in,
+                                      const void* const* w_packs, const float* bias, void* out, float* stats,
+                                      void* stream) {
+  return gconv_forward_multi_impl(descs, count, in, w_packs, bias, out, stats, nullptr, 0, stream);
+}
+
+// floats of workspace gs_gconv_forward_multi_ws wants for the merged launch of these classes (0: it would not split K —
+// the classes do not merge, the halo-resident class kernel takes them, or the merged grid is large enough as it is)
+extern "C" int64_t gs_gconv_multi_splitk_ws_floats(const gs_gconv_desc* const* descs, int32_t count) {
+  if (!descs || count < 2 || !descs[0]) return 0;
+  for (int c = 0; c < count; ++c)
+    if (!descs[c] || descs[c]->Dc < 1 || descs[c]->Hc < 1 || descs[c]->Wc < 1 || descs[c]->Co < 1) return 0;
+  if (!multi_mergeable(descs, count) || gs_hconvt_pattern(descs, count) >= 0) return 0;
+  const gs_gconv_desc* d = descs[0];
+  const int splits = splitk_plan_multi(descs, count, pick_tile(d));
+  return splits > 1 ? (int64_t)splits * d->N * d->Do * d->Ho * d->Wo * d->Co : 0;
+}
+
+// gs_gconv_forward_multi with a split-K workspace: the merged grid is (classes x tiles x splits), the partial sums of all
+// classes share one dense [split][output pixel][Co] buffer (the classes partition the output pixels) and ONE finalize pass
+// applies bias / activation / statistics for every class. ws == NULL or too small: gs_gconv_forward_multi.
+extern "C" int gs_gconv_forward_multi_ws(const gs_gconv_desc* const* descs, int32_t count, const void* in,
+                                         const void* const* w_packs, const float* bias, void* out, float* stats,
+                                         float* ws, int64_t ws_floats, void* stream) {
+  return gconv_forward_multi_impl(descs, count, in, w_packs, bias, out, stats, ws, ws_floats, stream);
+}
+
+namespace {
+int gconv_forward_multi_impl(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
+                             const float* bias, void* out, float* stats, float* ws, int64_t ws_floats, void* stream) {
+  GS_REQUIRE(descs && w_packs && count >= 1 && in && out, "gs_gconv_forward_multi: null argument");
+  for (int c = 0; c < count; ++c) GS_REQUIRE(descs[c] && w_packs[c], "gs_gconv_forward_multi: null class %d", c);
+  if (!multi_mergeable(descs, count)) {      // classes of different shapes (odd extents), long tap lists, a single class: one launch each
     for (int c = 0; c < count; ++c)
-      if (int rc = gconv_forward_impl(descs[c], in, w_packs[c], bias, out, stats, nullptr, nullptr, 0, stream)) return rc;
+      if (int rc = gconv_forward_impl(descs[c], in, w_packs[c], bias, out, stats, nullptr, ws, ws_floats, stream)) return rc;
     return 0;
   }
   // validate through the single-class checks, then build the shared arguments from class 0
-  const gs_gconv_desc* d = d0;
+  const gs_gconv_desc* d = descs[0];
   GS_REQUIRE(d->Ci >= 8 && (d->Ci & 7) == 0 && ((d->Ci >> 3) & ((d->Ci >> 3) - 1)) == 0,
              "gs_gconv_forward_multi: Ci=%d must be 8*2^k", d->Ci);
   GS_REQUIRE((d->Co & 7) == 0 && d->Co > 0, "gs_gconv_forward_multi: Co=%d must be a multiple of 8", d->Co);
@@ -959,8 +1022,30 @@ extern "C" int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t
   }
   k.splits = 1;
   k.partial = nullptr;
-  k.split_stride = 0;
-  const long long blocks = (long long)count * d->N * k.tiles_m * k.tiles_n;
+  k.split_stride = (long long)d->N * d->Do * d->Ho * d->Wo * d->Co;
+  if (ws) {
+    const int splits = splitk_plan_multi(descs, count, tc);
+    if (splits > 1 && ws_floats >= (int64_t)splits * k.split_stride) { k.splits = splits; k.partial = ws; }
+  }
+  const long long blocks = (long long)count * d->N * k.tiles_m * k.tiles_n * k.splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward_multi: bad grid %lld", blocks);
-  return launch_tile(tc, k, (int)blocks, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (k.splits > 1) {
+    int rc = tc.bn == 16 ? launch<256, 16, 8, 1, 2>(k, (int)blocks, st)
+           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
+    if (rc) return rc;
+    SplitFinK f;
+    f.partial = ws; f.bias = bias; f.out = static_cast<char*>(out); f.stats = stats;
+    f.split_stride = k.split_stride; f.splits = k.splits; f.tiles_m = k.tiles_m; f.bm = tc.bm;
+    f.rcp_wc = k.rcp_wc; f.rcp_hc = k.rcp_hc; f.d = *d; f.n_cls = count;
+    for (int c = 0; c < count; ++c) {
+      f.cpz[c] = descs[c]->pz; f.cpy[c] = descs[c]->py; f.cpx[c] = descs[c]->px; f.cslot0[c] = descs[c]->stats_slot0;
+    }
+    const int fblocks = count * d->N * k.tiles_m * ((d->Co + 15) / 16);
+    hipLaunchKernelGGL(gconv_splitk_finalize_kernel, dim3(fblocks), dim3(256), 0, st, f);
+    GS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  return launch_tile(tc, k, (int)blocks, st);
 }
+}  // namespace

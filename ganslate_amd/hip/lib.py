@@ -95,6 +95,9 @@ _PROTOS = {
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_gconv_forward_multi": (C.c_int, [C.POINTER(C.POINTER(GConvDesc)), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_gconv_multi_splitk_ws_floats": (C.c_int64, [C.POINTER(C.POINTER(GConvDesc)), C.c_int32]),
+    "gs_gconv_forward_multi_ws": (C.c_int, [C.POINTER(C.POINTER(GConvDesc)), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gs_gconv_multi_fused_slots": (C.c_int, [C.c_void_p, C.c_int32]),
     "gs_gconv_forward_multi_fused": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(GConvFuse), C.c_void_p]),

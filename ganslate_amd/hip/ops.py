@@ -46,7 +46,7 @@ class HipOps(TwinSplit):
     # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
     # host side are mapped onto its options here, when the backend is created and whenever a model is built.
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
-                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_NORM_XCD": "norm_xcd", "GS_WGRAD_ROWS": "wgrad_rows", "GS_WGRAD_TWIN": "wgrad_twin",
+                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_NORM_XCD": "norm_xcd", "GS_WGRAD_ROWS": "wgrad_rows", "GS_SPLITK_MULTI": "splitk_multi", "GS_WGRAD_TWIN": "wgrad_twin",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
                    "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
@@ -55,7 +55,7 @@ class HipOps(TwinSplit):
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")
         self._desc_cache = {k: v for k, v in self._desc_cache.items()
-                            if not (isinstance(k, tuple) and k[0] in ("splitk", "wgrad_ws"))}
+                            if not (isinstance(k, tuple) and k[0] in ("splitk", "wgrad_ws", "multi"))}
 
     def get_option(self, name):
         v = C.c_int(0)
@@ -412,7 +412,9 @@ class HipOps(TwinSplit):
                 blocks = len(classes) * N * ((g0.pixels + tm - 1) // tm) * ((g0.Co + tn - 1) // tn)
                 use = blocks >= 128 or not any(self._splitk_floats(d) for d in descs)
                 arr = (C.POINTER(L.GConvDesc) * len(descs))(*[C.pointer(d) for d in descs])
-                ent = (arr, descs, use)
+                # a merged grid that still leaves the chip empty: split K over it (one launch + one finalize for all classes)
+                nws = 0 if use else int(self.lib.gs_gconv_multi_splitk_ws_floats(arr, len(descs)))
+                ent = (arr, descs, use or nws > 0, nws)
                 self._desc_cache[key] = ent
             merged = ent[2]
         if not merged:
@@ -423,8 +425,13 @@ class HipOps(TwinSplit):
         base = wpack.data_ptr()
         ws = (C.c_void_p * len(classes))(*[base + 2 * g.pack_offset for g in classes])
         t_end = self._time_begin("gconv_multi", classes, False)
-        L.check(self.lib.gs_gconv_forward_multi(ent[0], len(classes), _ptr(x), ws, _ptr(bias), _ptr(out), _ptr(stats),
-                                                _stream()), "gs_gconv_forward_multi")
+        if ent[3]:
+            part = torch.empty(ent[3], dtype=torch.float32, device=self.device)
+            L.check(self.lib.gs_gconv_forward_multi_ws(ent[0], len(classes), _ptr(x), ws, _ptr(bias), _ptr(out), _ptr(stats),
+                                                       _ptr(part), ent[3], _stream()), "gs_gconv_forward_multi_ws")
+        else:
+            L.check(self.lib.gs_gconv_forward_multi(ent[0], len(classes), _ptr(x), ws, _ptr(bias), _ptr(out), _ptr(stats),
+                                                    _stream()), "gs_gconv_forward_multi")
         if t_end is not None:
             t_end.record()
 

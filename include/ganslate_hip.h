@@ -127,6 +127,16 @@ int gs_gconv_forward(const gs_gconv_desc* d, const void* in, const void* w_pack,
  * classes while the others are written as zeros — consumers sum the slots, as gs_inorm_finalize does. */
 int gs_gconv_forward_multi(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
                            const float* bias, void* out, float* stats, void* stream);
+/* The same with split-K over the MERGED grid (unet2d.py:110-157: the U-Net's inner stride-2 transposed convs and the data
+ * gradients of its inner stride-2 convs — four classes of 1-512 pixels each with K = 4 x 256..2048): (classes x tiles x
+ * splits) workgroups write fp32 partial sums to ws[split][output pixel][Co] (the classes partition the output pixels) and
+ * one finalize pass applies bias / activation / statistics for all classes. gs_gconv_multi_splitk_ws_floats: floats of ws
+ * the call wants, 0 when it would not split (classes that do not merge, a layer the halo-resident class kernel takes, a
+ * merged grid that is large enough). ws == NULL or smaller than that: exactly gs_gconv_forward_multi. Deterministic (fixed
+ * summation order); per-class launches through gs_gconv_forward_ws give the same sums in another split. */
+int64_t gs_gconv_multi_splitk_ws_floats(const gs_gconv_desc* const* descs, int32_t count);
+int gs_gconv_forward_multi_ws(const gs_gconv_desc* const* descs, int32_t count, const void* in, const void* const* w_packs,
+                              const float* bias, void* out, float* stats, float* ws, int64_t ws_floats, void* stream);
 
 /* Data-gradient launch of a stride-1 conv with the first pass of the consumer's InstanceNorm backward fused into its
  * epilogue: while the tile of the (padded-domain) gradient g is stored, the per-tile sums of ghat = (fold(g) + g2) *

@@ -6,12 +6,14 @@ Tolerances (stated per ISSUE ③): conv outputs are rounded to bf16 -> |err| <= 
 the max-abs of the oracle result (one bf16 ulp of the largest value, accumulation noise is far below that);
 fp32 outputs (weight gradients, statistics, losses) rel 2e-3 of max-abs (fp32 atomics / reduction order).
 """
+import ctypes as C
 import os
 import numpy as np
 
 import pytest
 import torch
 
+from ganslate_amd.hip import lib as L
 from ganslate_amd.nn.native.spec import ConvSpec, lower
 from oracle.ops_ref import RefOps
 
@@ -317,6 +319,70 @@ def test_merged_parity_classes_equal_separate_launches(hip_ops, case):
     assert not torch.isnan(res[1][1]).any()
     for a, b, what in zip(res[1], res[0], ("forward", "statistics", "data gradient")):
         assert torch.equal(a, b), what
+
+
+@pytest.mark.parametrize("case", [
+    (ConvSpec("convT", 1024, 1024, 4, 2, 1, 0), 1, 2, 4),           # U-Net innermost up-conv: 8 pixels per class, K = 4 x 1024
+    (ConvSpec("convT", 1024, 512, 4, 2, 1, 0), 1, 8, 16),           # 128 pixels per class, four channel tiles
+    (ConvSpec("conv", 512, 1024, 4, 2, 1), 1, 16, 32),              # data gradient of a down conv (4 x 4 taps, 128 pixels per class)
+    (ConvSpec("convT", 256, 40, 4, 2, 1, 0), 2, 4, 4),              # 64-channel tile, two images, ragged channels
+], ids=_ids)
+def test_split_k_over_merged_parity_classes(hip_ops, case):
+    """gs_gconv_forward_multi_ws: the four parity classes of a small stride-2 layer as ONE split-K launch + ONE finalize pass
+    (bias, activation, statistics for all classes) against the per-class split-K launches of the same library (another split
+    of K: bf16 rounding / fp32 summation order) and the oracle; deterministic."""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 23)
+    g = torch.Generator().manual_seed(24)
+    dev = hip_ops.device
+    xa = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
+    xa[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
+    gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., :spec.cout] = torch.randn(N, *low.out_dims, spec.cout, generator=g).to(torch.bfloat16)
+    fwd_multi, dg_multi = len(low.fwd) == 4, len(low.dgrad) == 4
+    assert fwd_multi or dg_multi
+
+    def run(ops, d):
+        out = {}
+        if fwd_multi:
+            slots, offs = stats_slots(hip_ops, low, low.fwd, N)
+            ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=d)
+            part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=d)
+            ops.gconv_classes(low.fwd, xa.to(d), fpack.to(d), bias.to(d), ya, act="lrelu", stats=part, stats_slots=slots,
+                              stats_slot0s=offs)
+            out["y"], out["stats"] = ya.cpu(), part.view(N, slots, 2, spec.cout_p).sum(1).cpu()
+        if dg_multi:
+            gx = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16, device=d)
+            ops.gconv_classes(low.dgrad, gy.to(d), dpack.to(d), None, gx)
+            out["gx"] = gx.cpu()
+        return out
+
+    res = {}
+    try:
+        for on in (1, 1, 0):
+            hip_ops.set_option("splitk_multi", on)
+            classes = low.fwd if fwd_multi else low.dgrad
+            descs = [hip_ops._gdesc(c, N, (xa if fwd_multi else gy).shape[-1], 0, (spec.cout_p if fwd_multi else spec.cin_p), 0,
+                                    "none", 0.2, 0, 0) for c in classes]
+            arr = (C.POINTER(L.GConvDesc) * 4)(*[C.pointer(d) for d in descs])
+            nws = int(hip_ops.lib.gs_gconv_multi_splitk_ws_floats(arr, 4))
+            assert (nws > 0) == bool(on), "the merged split-K launch is what this test is about"
+            r = run(hip_ops, dev)
+            torch.cuda.synchronize()
+            res.setdefault(on, []).append(r)
+    finally:
+        hip_ops.set_option("splitk_multi", 1)
+    ref = run(RefOps(), "cpu")
+    a, a2, b = res[1][0], res[1][1], res[0][0]
+    for k in a:
+        assert torch.equal(a[k], a2[k]), f"{k}: two runs of the merged split-K launch differ"
+        if k == "stats":
+            assert not torch.isnan(a[k]).any()
+            close_f32(a[k], b[k], "statistics vs per-class split-K", rel=2e-3)
+            close_f32(a[k], ref[k], "statistics vs oracle", rel=2e-3)
+        else:
+            close_bf16(a[k], b[k], f"{k} vs per-class split-K")
+            close_bf16(a[k], ref[k], f"{k} vs oracle")
 
 
 @pytest.mark.parametrize("case", [

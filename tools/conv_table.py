@@ -24,14 +24,20 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix"])
     args = ap.parse_args()
     from ganslate_amd.utils.builders import build_gan
     torch.manual_seed(0)
-    model = build_gan(bench.make_conf(args.batch, args.size, 1000))
+    if args.workload == "pix2pix":          # BASELINE configs[2]: batch 1, 256 x 512
+        args.batch = 1 if args.batch == 8 else args.batch
+        model = build_gan(bench.make_pix2pix_conf(args.batch, 1000))
+        shape = (args.batch, 3, 256, 512)
+    else:
+        model = build_gan(bench.make_conf(args.batch, args.size, 1000))
+        shape = (args.batch, 3, args.size, args.size)
     model.step_graph_enabled = False
     dev = model.device
     g = torch.Generator().manual_seed(1234)
-    shape = (args.batch, 3, args.size, args.size)
     batch = {"A": (torch.rand(shape, generator=g) * 2 - 1).to(dev), "B": (torch.rand(shape, generator=g) * 2 - 1).to(dev)}
 
     def step():
@@ -67,7 +73,7 @@ def main():
     ops.disable_kernel_timing()
     rows = sorted(((n / args.steps * ms, lab, n / args.steps, ms) for lab, (n, ms) in res.items()), reverse=True)
     tot = sum(r[0] for r in rows)
-    print(f"# conv launches of one training step, batch {args.batch} {args.size}x{args.size}: {sum(r[2] for r in rows):.0f} "
+    print(f"# conv launches of one {args.workload} training step, batch {args.batch} {shape[2]}x{shape[3]}: {sum(r[2] for r in rows):.0f} "
           f"launches, {tot:.3f} ms (HIP events, one stream; includes the deterministic second-stage reductions of wgrad)")
     print(f"# {'ms/step':>8s} {'n/step':>6s} {'avg us':>8s} {'TFLOP/s':>8s}  class")
     for t, lab, n, ms in rows:

@@ -1,0 +1,8 @@
+# split-K over merged parity classes: parity tests, then same-box A/B on pix2pix (GS_SPLITK_MULTI=1 / 0)
+cd "$GRAFT_REPO_ROOT"
+python -m pytest tests/test_ops_gpu.py -q -x -m gpu -k "split_k_over or merged_parity or halo_resident_parity" 2>&1 | tail -5
+for r in 1 2 3; do for v in 1 0; do
+  echo -n "pix2pix GS_SPLITK_MULTI=$v "
+  GS_SPLITK_MULTI=$v python bench.py --workload pix2pix --no-cpu-baseline --no-kernel-timing --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done; done
+python tools/conv_table.py --workload pix2pix 2>&1 | grep -v amdgpu.ids | head -40
