@@ -36,7 +36,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   constexpr bool W_UNIFORM = (BN / 8) % NW == 0;
   constexpr int LOADS = NXI + NWI;      // DMA instructions per stage per wave (when W_UNIFORM)
   static_assert(BM % (8 * NW) == 0, "pixel tile must split evenly over the waves");
-  static_assert(NSTAGE == 2 || (NSTAGE == 3 && W_UNIFORM), "3 stages need a uniform DMA count per wave");
+  static_assert(NSTAGE == 2 || ((NSTAGE == 3 || NSTAGE == 4) && W_UNIFORM), "3 / 4 stages need a uniform DMA count per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   short* taps = reinterpret_cast<short*>(smem + NSTAGE * STAGE);
 
@@ -52,21 +52,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
     b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
-  const int sp = b % p.splits;
-  b /= p.splits;
-  const int nt = b % p.tiles_n;
-  b /= p.tiles_n;
   // merged parity classes: the classes of one pixel tile are neighbours in the grid (they gather the same input rows)
   const bool multi = p.n_cls > 0;
-  const int ci = multi ? b % p.n_cls : 0;
-  if (multi) b /= p.n_cls;
+  int sp, nt, ci, mt, n;
+  if (p.wmajor) {
+    // weight-heavy launch (more weights than im2col pixels: the inner U-Net layers): the pixel tiles that read one weight tile are
+    // neighbours instead — same XCD, same moment, one trip to HBM for the four of them
+    mt = b % p.tiles_m; b /= p.tiles_m;
+    n = b % d.N; b /= d.N;
+    sp = b % p.splits; b /= p.splits;
+    nt = b % p.tiles_n; b /= p.tiles_n;
+    ci = b;
+  } else {
+    sp = b % p.splits; b /= p.splits;
+    nt = b % p.tiles_n; b /= p.tiles_n;
+    ci = multi ? b % p.n_cls : 0;
+    if (multi) b /= p.n_cls;
+    mt = b % p.tiles_m;
+    n = b / p.tiles_m;
+  }
   const GConvCls& cl = p.cls[ci];
   const int cT = multi ? cl.T : d.T, cKp = multi ? cl.Kp : d.Kp;
   const int cpz = multi ? cl.pz : d.pz, cpy = multi ? cl.py : d.py, cpx = multi ? cl.px : d.px;
   const int cslot0 = multi ? cl.stats_slot0 : d.stats_slot0;
   const int cnh = multi ? cl.nh : p.nh, cnw = multi ? cl.nw : p.nw;
-  const int mt = b % p.tiles_m;
-  const int n = b / p.tiles_m;
   const bool second = n >= p.nsplit;                   // workgroup-uniform: a tile never straddles images
   const char* cw = p.w + (multi ? cl.w_off : 0) + (second ? p.w_delta : 0);
   const float* cbias = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) + (second ? p.bias_delta : 0))
@@ -193,6 +202,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     if (ks_begin + 1 < ks_end) prep(ks_begin + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  } else if constexpr (NSTAGE == 4) {
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2)
+      if (ks_begin + s2 < ks_end) issue(ks_begin + s2, s2);
   } else {
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -229,6 +242,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed (this wave's share)
       __syncthreads();
     }
+  } else if constexpr (NSTAGE == 4) {
+    // 4-stage ring over this split's K range, DMA three K-steps ahead: the split-K launches stream COLD weights (every
+    // byte once, from HBM), so a K-step lasts as long as the memory latency divided by the stages in flight — with the
+    // 2-stage loop above that was one stage per workgroup, 1.5-2 us per K-step for 0.2 us of MFMA work.
+    int cur = 0, nxt3 = 3;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const int ahead = ks_end - 1 - ks;               // K-steps behind this one that have been issued: min(ahead, 2)
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (ks + 3 < ks_end) issue(ks + 3, nxt3);
+      compute(cur);
+      cur = cur == 3 ? 0 : cur + 1;
+      nxt3 = nxt3 == 3 ? 0 : nxt3 + 1;
+    }
+    __syncthreads();
   } else {
     // 3-stage ring, DMA two K-steps ahead; one raw barrier per K-step; counted vmcnt keeps the younger stage in
     // flight across the barrier (a __syncthreads() here would drain it: LDS-DMA counts as a pending LDS write)
@@ -245,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
     __syncthreads();
   }
 
-  if constexpr (NSTAGE == 2) {
+  if constexpr (NSTAGE == 2 || NSTAGE == 4) {
     if (p.splits > 1) {       // raw partial sums, dense [output pixel][Co] per split; the epilogue runs in the finalize pass
       float* part = p.partial + (size_t)sp * p.split_stride;
 #pragma unroll
@@ -813,12 +843,15 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     const int splits = splitk_plan(d, tc, fuse != nullptr);
     if (splits > 1 && ws_floats >= (int64_t)splits * k.split_stride) { k.splits = splits; k.partial = ws; }
   }
+  k.wmajor = k.splits > 1 && k.tiles_m * d->N > 1 && gs_opt(GS_OPT_SPLITK_WMAJOR) &&
+             (long long)d->Co > (long long)d->N * d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n * k.splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (k.splits > 1) {
     int rc = tc.bn == 16 ? launch<256, 16, 8, 1, 2>(k, (int)blocks, st)
-           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
+           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st)
+           : gs_opt(GS_OPT_SPLITK_RING) ? launch<128, 128, 4, 4, 4>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
     if (rc) return rc;
     SplitFinK f;
     f.partial = ws; f.bias = bias; f.out = static_cast<char*>(out); f.stats = stats;
@@ -1027,12 +1060,15 @@ int gconv_forward_multi_impl(const gs_gconv_desc* const* descs, int32_t count, c
     const int splits = splitk_plan_multi(descs, count, tc);
     if (splits > 1 && ws_floats >= (int64_t)splits * k.split_stride) { k.splits = splits; k.partial = ws; }
   }
+  k.wmajor = k.splits > 1 && k.tiles_m * d->N > 1 && gs_opt(GS_OPT_SPLITK_WMAJOR) &&
+             (long long)d->Co > (long long)d->N * d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)count * d->N * k.tiles_m * k.tiles_n * k.splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward_multi: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (k.splits > 1) {
     int rc = tc.bn == 16 ? launch<256, 16, 8, 1, 2>(k, (int)blocks, st)
-           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
+           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st)
+           : gs_opt(GS_OPT_SPLITK_RING) ? launch<128, 128, 4, 4, 4>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
     if (rc) return rc;
     SplitFinK f;
     f.partial = ws; f.bias = bias; f.out = static_cast<char*>(out); f.stats = stats;

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix"])
+    ap.add_argument("--workload", default="cyclegan", choices=["cyclegan", "pix2pix", "brats"])
     args = ap.parse_args()
     from ganslate_amd.utils.builders import build_gan
     torch.manual_seed(0)
@@ -32,6 +32,11 @@ def main():
         args.batch = 1 if args.batch == 8 else args.batch
         model = build_gan(bench.make_pix2pix_conf(args.batch, 1000))
         shape = (args.batch, 3, 256, 512)
+    elif args.workload == "brats":          # BASELINE configs[4]: V-Net CycleGAN on 128^3 patches, batch 1
+        args.batch = 1 if args.batch == 8 else args.batch
+        args.size = 128 if args.size == 256 else args.size
+        model = build_gan(bench.make_volume_conf(args.batch, args.size, 1000, "vnet"))
+        shape = (args.batch, 1, args.size, args.size, args.size)
     else:
         model = build_gan(bench.make_conf(args.batch, args.size, 1000))
         shape = (args.batch, 3, args.size, args.size)
@@ -73,7 +78,8 @@ def main():
     ops.disable_kernel_timing()
     rows = sorted(((n / args.steps * ms, lab, n / args.steps, ms) for lab, (n, ms) in res.items()), reverse=True)
     tot = sum(r[0] for r in rows)
-    print(f"# conv launches of one {args.workload} training step, batch {args.batch} {shape[2]}x{shape[3]}: {sum(r[2] for r in rows):.0f} "
+    dims = "x".join(str(v) for v in shape[2:])
+    print(f"# conv launches of one {args.workload} training step, batch {args.batch} {dims}: {sum(r[2] for r in rows):.0f} "
           f"launches, {tot:.3f} ms (HIP events, one stream; includes the deterministic second-stage reductions of wgrad)")
     print(f"# {'ms/step':>8s} {'n/step':>6s} {'avg us':>8s} {'TFLOP/s':>8s}  class")
     for t, lab, n, ms in rows:
