@@ -83,7 +83,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"wgrad_rows", 1},          // wgrad.hip: the im2col weight gradient stores whole tile rows through LDS; one split adds without atomics
     {"splitk_multi", 1},        // gconv.hip: split-K over the merged parity classes of a small stride-2 layer (one launch + one finalize)
     {"splitk_ring", 1},         // gconv.hip: split-K launches of the 128 x 128 tile run a 4-stage ring (three K-steps of cold weights in flight)
-    {"splitk_wmajor", 1},       // gconv.hip: split-K launches with more weights than pixels order their grid so that the pixel tiles sharing a weight tile are neighbours
+    {"gconv_ring4", 16},        // gconv.hip: 128-pixel im2col tiles in a grid of <= 2 workgroups per CU with at least this many K-steps run a 4-stage ring; 0 = off
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

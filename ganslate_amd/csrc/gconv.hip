@@ -54,23 +54,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_kernel(const GConvK p) {
   }
   // merged parity classes: the classes of one pixel tile are neighbours in the grid (they gather the same input rows)
   const bool multi = p.n_cls > 0;
-  int sp, nt, ci, mt, n;
-  if (p.wmajor) {
-    // weight-heavy launch (more weights than im2col pixels: the inner U-Net layers): the pixel tiles that read one weight tile are
-    // neighbours instead — same XCD, same moment, one trip to HBM for the four of them
-    mt = b % p.tiles_m; b /= p.tiles_m;
-    n = b % d.N; b /= d.N;
-    sp = b % p.splits; b /= p.splits;
-    nt = b % p.tiles_n; b /= p.tiles_n;
-    ci = b;
-  } else {
-    sp = b % p.splits; b /= p.splits;
-    nt = b % p.tiles_n; b /= p.tiles_n;
-    ci = multi ? b % p.n_cls : 0;
-    if (multi) b /= p.n_cls;
-    mt = b % p.tiles_m;
-    n = b / p.tiles_m;
-  }
+  int b2 = b;
+  const int sp = b2 % p.splits; b2 /= p.splits;
+  const int nt = b2 % p.tiles_n; b2 /= p.tiles_n;
+  const int ci = multi ? b2 % p.n_cls : 0;
+  if (multi) b2 /= p.n_cls;
+  const int mt = b2 % p.tiles_m;
+  const int n = b2 / p.tiles_m;
+  // (a weight-major order — the pixel tiles that read one weight tile as neighbours — measured 1 % slower on the U-Net's
+  // weight-heavy split-K launches: profiles/r05_ab_splitk_wmajor.txt)
   const GConvCls& cl = p.cls[ci];
   const int cT = multi ? cl.T : d.T, cKp = multi ? cl.Kp : d.Kp;
   const int cpz = multi ? cl.pz : d.pz, cpy = multi ? cl.py : d.py, cpx = multi ? cl.px : d.px;
@@ -646,9 +638,14 @@ int launch(const GConvK& k, int blocks, hipStream_t st) {
 // wave counts per tile picked by measurement (tools/bench_kernels.py): more waves hide the LDS-DMA issue latency
 int launch_tile(const TileCfg& tc, const GConvK& k, int blocks, hipStream_t st) {
   if (tc.bn == 16) return launch<256, 16, 8, 1, 2>(k, blocks, st);
-  if (tc.bn == 64) return launch<128, 64, 4, 2, 2>(k, blocks, st);
+  // A grid of at most two workgroups per CU with a long K loop is latency-bound on the 2-stage loop (one K-step in flight per
+  // workgroup: the V-Net's 32^3 x 64-channel k5 convs ran 125 K-steps of 0.8 us for 0.05 us of MFMA work each): 4-stage ring
+  int nk = k.d.Kp >> 6;
+  for (int c = 0; c < k.n_cls; ++c) nk = std::min(nk, k.cls[c].Kp >> 6);
+  const bool ring4 = gs_opt(GS_OPT_GCONV_RING4) != 0 && blocks <= 2 * 256 && nk >= gs_opt(GS_OPT_GCONV_RING4);
+  if (tc.bn == 64) return ring4 ? launch<128, 64, 4, 2, 4>(k, blocks, st) : launch<128, 64, 4, 2, 2>(k, blocks, st);
   if (tc.bm == 128 && tc.waves == 8) return launch<128, 128, 2, 4, 2>(k, blocks, st);
-  if (tc.bm == 128) return launch<128, 128, 4, 4, 2>(k, blocks, st);
+  if (tc.bm == 128) return ring4 ? launch<128, 128, 4, 4, 4>(k, blocks, st) : launch<128, 128, 4, 4, 2>(k, blocks, st);
   if (tc.bm == 320) return launch<320, 128, 5, 2, 2>(k, blocks, st);
   if (tc.bm == 288) return launch<288, 128, 6, 2, 2>(k, blocks, st);
   if (tc.bm == 256) return launch<256, 128, 4, 4, 3>(k, blocks, st);   // 16 waves: best measured (8 and 4 lose)
@@ -843,14 +840,12 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
     const int splits = splitk_plan(d, tc, fuse != nullptr);
     if (splits > 1 && ws_floats >= (int64_t)splits * k.split_stride) { k.splits = splits; k.partial = ws; }
   }
-  k.wmajor = k.splits > 1 && k.tiles_m * d->N > 1 && gs_opt(GS_OPT_SPLITK_WMAJOR) &&
-             (long long)d->Co > (long long)d->N * d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n * k.splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (k.splits > 1) {
     int rc = tc.bn == 16 ? launch<256, 16, 8, 1, 2>(k, (int)blocks, st)
-           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st)
+           : tc.bn == 64 ? (gs_opt(GS_OPT_SPLITK_RING) ? launch<128, 64, 4, 2, 4>(k, (int)blocks, st) : launch<128, 64, 4, 2, 2>(k, (int)blocks, st))
            : gs_opt(GS_OPT_SPLITK_RING) ? launch<128, 128, 4, 4, 4>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
     if (rc) return rc;
     SplitFinK f;
@@ -1060,14 +1055,12 @@ int gconv_forward_multi_impl(const gs_gconv_desc* const* descs, int32_t count, c
     const int splits = splitk_plan_multi(descs, count, tc);
     if (splits > 1 && ws_floats >= (int64_t)splits * k.split_stride) { k.splits = splits; k.partial = ws; }
   }
-  k.wmajor = k.splits > 1 && k.tiles_m * d->N > 1 && gs_opt(GS_OPT_SPLITK_WMAJOR) &&
-             (long long)d->Co > (long long)d->N * d->Dc * d->Hc * d->Wc;
   const long long blocks = (long long)count * d->N * k.tiles_m * k.tiles_n * k.splits;
   GS_REQUIRE(blocks > 0 && blocks < (1LL << 31), "gs_gconv_forward_multi: bad grid %lld", blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (k.splits > 1) {
     int rc = tc.bn == 16 ? launch<256, 16, 8, 1, 2>(k, (int)blocks, st)
-           : tc.bn == 64 ? launch<128, 64, 4, 2, 2>(k, (int)blocks, st)
+           : tc.bn == 64 ? (gs_opt(GS_OPT_SPLITK_RING) ? launch<128, 64, 4, 2, 4>(k, (int)blocks, st) : launch<128, 64, 4, 2, 2>(k, (int)blocks, st))
            : gs_opt(GS_OPT_SPLITK_RING) ? launch<128, 128, 4, 4, 4>(k, (int)blocks, st) : launch<128, 128, 4, 4, 2>(k, (int)blocks, st);
     if (rc) return rc;
     SplitFinK f;

@@ -37,7 +37,6 @@ struct GConvK {
   // twin batch (gs_twin): images [nsplit, N) read the weight pack / bias w_delta / bias_delta bytes further on
   int nsplit;
   long long w_delta, bias_delta;
-  int wmajor;                  // block order: pixel tiles of one (class, channel tile, split) adjacent (see the kernel's decode)
   int n_cls;                   // > 0: merged launch over cls[0..n_cls) (their fields replace the per-class ones of p / d)
   GConvCls cls[GS_MULTI_MAX_CLS];
   gs_gconv_desc d;

@@ -46,7 +46,7 @@ class HipOps(TwinSplit):
     # The library reads no environment variable (gs_set_option, include/ganslate_hip.h); the GS_* variables of the
     # host side are mapped onto its options here, when the backend is created and whenever a model is built.
     ENV_OPTIONS = {"GS_SPLITK": "splitk", "GS_SPLITK_MAXB": "splitk_max_blocks", "GS_SPLITK_TARGET": "splitk_target",
-                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_NORM_XCD": "norm_xcd", "GS_WGRAD_ROWS": "wgrad_rows", "GS_SPLITK_MULTI": "splitk_multi", "GS_SPLITK_RING": "splitk_ring", "GS_SPLITK_WMAJOR": "splitk_wmajor", "GS_WGRAD_TWIN": "wgrad_twin",
+                   "GS_HCONV": "hconv", "GS_HCONV_WIDE": "hconv_wide", "GS_HCONVW_PERSIST": "hconvw_persist", "GS_HSTRIP_REGS": "hstrip_regs", "GS_GCONV_TWIN": "gconv_twin", "GS_GCONV_SMALLK": "gconv_smallk", "GS_GCONV_PERSIST": "gconv_persist", "GS_HCONVT_PERSIST": "hconvt_persist", "GS_RING_APPLY": "ring_apply", "GS_NORM_XCD": "norm_xcd", "GS_WGRAD_ROWS": "wgrad_rows", "GS_SPLITK_MULTI": "splitk_multi", "GS_SPLITK_RING": "splitk_ring", "GS_GCONV_RING4": "gconv_ring4", "GS_WGRAD_TWIN": "wgrad_twin",
                    "GS_HWGRAD": "hwgrad", "GS_HWGRAD_WIDE": "hwgrad_wide", "GS_HWGRAD_PLANES": "hwgrad_planes",
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
                    "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
