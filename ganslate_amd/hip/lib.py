@@ -24,7 +24,7 @@ class WGradDesc(C.Structure):
     """Mirror of gs_wgrad_desc."""
     _fields_ = [(n, C.c_int32) for n in (
         "N", "Ha", "Wa", "P", "a_cs", "a_co", "Hg", "Wg", "Q", "g_cs", "g_co", "Da", "Dg", "si", "T", "border",
-        "dw_ld")] + [
+        "dw_ld", "dw_fresh")] + [
         ("dh", C.c_int8 * GS_MAX_TAPS), ("dw_", C.c_int8 * GS_MAX_TAPS), ("dd", C.c_int8 * GS_MAX_TAPS)]
 
 

@@ -447,15 +447,19 @@ class HipOps(TwinSplit):
                 and all(w.dd[9 * k + t] == w.dd[9 * k] and w.dh[9 * k + t] == w.dh[t] and w.dw[9 * k + t] == w.dw[t]
                         for k in range(3) for t in range(9)))
 
-    def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
+    def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None, fresh=False):
+        """dw += the weight gradient. fresh: the caller guarantees that dw holds zeros (the layer's first weight gradient since
+        the optimiser cleared the buffer, NativeNet.wgrad_fresh) — a hint (gs_wgrad_desc.dw_fresh), never a requirement"""
         twin = is_twin(dw)
+        fresh = bool(fresh) and not twin and pair is None and os.environ.get("GS_WGRAD_FRESH", "1") != "0"     # (A/B switch)
         if twin and (os.environ.get("GS_WGRAD_DET", "1") == "0" or os.environ.get("GS_TWIN_NATIVE", "1") == "0"
                      or os.environ.get("GS_TWIN_WGRAD", "1") == "0"):       # (A/B switch)
             return self.twin_wgrad(w, a, g, dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co, pair=pair)
-        key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co)
+        key = ("w", id(w), a.shape[0], a_cs, a_co, g_cs, g_co, fresh)
         ent = self._desc_cache.get(key)
         if ent is None:
             d = L.WGradDesc()
+            d.dw_fresh = int(fresh)
             d.N, d.Ha, d.Wa, d.P = a.shape[0], w.Ha, w.Wa, w.P
             d.Da, d.Dg = w.Da, w.Dg
             d.a_cs, d.a_co = (a_cs if a_cs is not None else a.shape[-1]), a_co

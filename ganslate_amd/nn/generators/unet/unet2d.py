@@ -176,7 +176,7 @@ class Unet2D(NativeNet):
     def _param_grads(self, i, lw, x_in, dy, has_norm):
         ops, sp, grad = self.ops, self.nodes[i].spec, self.master.grad
         a_t, g_t = (dy, x_in) if sp.kind == "conv" else (x_in, dy)
-        ops.wgrad(lw.wgrad, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + sp.master_numel])
+        ops.wgrad(lw.wgrad, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + sp.master_numel], fresh=self.wgrad_fresh(i))
         if sp.bias and not has_norm:
             ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
         self.grad_dirty = True

@@ -116,6 +116,7 @@ class NativeNet:
         self._reduce_handles = []
         self._reduced_buckets = set()
         self.grad_dirty = False
+        self._wgrad_seen = set()           # layers whose weight gradient has been written since the buffer was cleared
         self._deferred = {}          # node -> (wgrad desc, dense, gathered) held back for a merged launch
         self.multi_stream_passes = False   # set by a recipe that runs passes of this network on several streams
         self.external_reduce = False       # data-parallel gradients are reduced by the caller (BaseGAN graph runner)
@@ -727,7 +728,7 @@ class NativeNet:
                 elif more_passes and ops.can_merge_wgrad(lw.wgrad):
                     self._deferred[i] = (lw.wgrad, a_t, g_t, tw)
                 else:
-                    ops.wgrad(lw.wgrad, a_t, g_t, dw)
+                    ops.wgrad(lw.wgrad, a_t, g_t, dw, fresh=tw is None and self.wgrad_fresh(i))
                 if sp.bias and not nd.norm:
                     for h in range(N // Nh):
                         gh_ = grad.half(h) if tw is not None else grad
@@ -848,6 +849,17 @@ class NativeNet:
         h = dist.all_reduce(self.master.grad[s:e], op=dist.ReduceOp.SUM, group=self._dist, async_op=True)
         self._reduce_handles.append(h)
         self._reduced_buckets.add(i)
+
+    def wgrad_fresh(self, i) -> bool:
+        """True for the first weight gradient of layer i since the optimiser cleared the gradient buffer (grad_dirty is
+        dropped by the update / zero_grad and raised by every executor behind its writes): its slice still holds zeros, which
+        a single-contributor weight-gradient launch may use to store instead of read-add-store (gs_wgrad_desc.dw_fresh; the
+        U-Net's 17-34 M-weight layers are pure output traffic). Call exactly once per weight-gradient launch, before it."""
+        if not self.grad_dirty:
+            self._wgrad_seen.clear()
+        fresh = i not in self._wgrad_seen
+        self._wgrad_seen.add(i)
+        return fresh
 
     def _flush_held(self, i, held):
         wd, a_t, g_t, tw = held

@@ -78,6 +78,9 @@ typedef struct gs_wgrad_desc {
   int32_t Da, Dg;
   int32_t si, T, border;
   int32_t dw_ld;                    /* leading dimension of dw rows = T*Q */
+  int32_t dw_fresh;                 /* hint: the caller guarantees that dw holds zeros (first weight gradient of this layer since
+                                     * the optimiser cleared the buffer): a launch that is the only contributor of its elements
+                                     * stores instead of read-add-store. 0 is always valid. */
   int8_t  dh[GS_MAX_TAPS];
   int8_t  dw_[GS_MAX_TAPS];
   int8_t  dd[GS_MAX_TAPS];

@@ -216,9 +216,11 @@ class RefOps(TwinSplit):
                 all(w.dd[9 * k + t] == w.dd[9 * k] and w.dh[9 * k + t] == w.dh[t] and w.dw[9 * k + t] == w.dw[t]
                     for k in range(3) for t in range(9)))
 
-    def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None):
+    def wgrad(self, w, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None, fresh=False):
         if is_twin(dw):
             return self.twin_wgrad(w, a, g, dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co, pair=pair)
+        if fresh:      # the caller's guarantee behind gs_wgrad_desc.dw_fresh, checked here: the host logic is under test
+            assert not bool(dw.any()), "wgrad(fresh=True): the gradient slice does not hold zeros"
         if pair is not None:
             self.wgrad(w, pair[0], pair[1], dw, a_cs=a_cs, a_co=a_co, g_cs=g_cs, g_co=g_co)
         av = _v5(a)[..., a_co:a_co + w.P].float()

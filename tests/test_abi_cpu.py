@@ -33,7 +33,7 @@ def test_descriptor_layouts_match_header():
     # gs_gconv_desc: 26 int32 + float + 3 int32 + 3 * GS_MAX_TAPS int8
     assert ctypes.sizeof(L.GConvDesc) == 26 * 4 + 4 + 3 * 4 + 3 * L.GS_MAX_TAPS
     assert ctypes.sizeof(L.PNormDesc) == 8 + 18 * 4
-    assert ctypes.sizeof(L.WGradDesc) == 17 * 4 + 3 * L.GS_MAX_TAPS
+    assert ctypes.sizeof(L.WGradDesc) == 18 * 4 + 3 * L.GS_MAX_TAPS
     assert int(re.search(r"#define GS_MAX_TAPS (\d+)", HEADER).group(1)) == L.GS_MAX_TAPS
     for name, val in (("GS_BORDER_REFLECT", L.BORDER["reflect"]), ("GS_BORDER_REPLICATE", L.BORDER["replicate"]),
                       ("GS_ACT_RELU", L.ACT["relu"]), ("GS_ACT_LRELU", L.ACT["lrelu"]), ("GS_ACT_TANH", L.ACT["tanh"])):

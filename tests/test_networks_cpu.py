@@ -364,3 +364,45 @@ def test_load_state_dict_after_an_optimiser_step_refreshes_every_pack(fp32_oracl
     fresh.init_weights()
     with torch.no_grad():
         assert torch.equal(net(x), fresh(x))
+
+
+@pytest.mark.parametrize("arch", ["patchgan", "unet"])
+def test_first_weight_gradient_since_the_clear_is_flagged_fresh(fp32_oracle_backend, arch):
+    """gs_wgrad_desc.dw_fresh (round 5): NativeNet.wgrad_fresh says "this layer's gradient slice still holds the optimiser's
+    zeros" exactly for the first weight-gradient launch of a layer between two clears — two backward passes before an update
+    flag the first only, the pass after the update flags again, and so does the pass after zero_grad. The oracle's wgrad
+    asserts the guarantee itself (the slice IS zero whenever fresh is passed)."""
+    from ganslate_amd.nn.optim import NativeAdam
+    if arch == "unet":
+        from ganslate_amd.nn.generators import Unet2D
+        net = Unet2D(3, 3, 5, "instance", ngf=8)
+    else:
+        from ganslate_amd.nn.discriminators import PatchGAN2D
+        net = PatchGAN2D(3, 8, 2, (4, 4), "instance")
+    x = torch.rand((1, 3, 32, 32), generator=torch.Generator().manual_seed(9)) * 2 - 1
+    opt = NativeAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    seen = []
+    real = net.ops.wgrad
+
+    def spy(w, a, g, dw, **kw):
+        seen.append(bool(kw.get("fresh", False)))
+        return real(w, a, g, dw, **kw)
+    net.ops.wgrad = spy
+    try:
+        net(x).square().mean().backward()
+        first = list(seen)
+        seen.clear()
+        net(x).square().mean().backward()          # accumulates into the same slices
+        second = list(seen)
+        seen.clear()
+        opt.step()                                  # consumes and clears
+        net(x).square().mean().backward()
+        third = list(seen)
+        seen.clear()
+        opt.zero_grad()
+        net(x).square().mean().backward()
+        fourth = list(seen)
+    finally:
+        net.ops.wgrad = real
+    assert first and all(first) and third == first and fourth == first
+    assert len(second) == len(first) and not any(second)

@@ -1468,6 +1468,32 @@ def test_weight_gradient_rows_through_lds(hip_ops, case, misalign):
     close_f32(outs[1], ref, "vs oracle")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 1024, 1024, 4, 2, 1), 1, 8, 8),                 # one split: the launch stores instead of read-add-store
+    (ConvSpec("convT", 512, 256, 4, 2, 1), 1, 8, 8),
+    (ConvSpec("conv", 128, 256, 4, 2, 1), 4, 32, 32),                 # several splits: the hint changes nothing
+    (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="reflect"), 2, 32, 32),   # halo-resident kernel: ignores the hint
+], ids=_ids)
+def test_weight_gradient_into_a_fresh_buffer(hip_ops, case):
+    """gs_wgrad_desc.dw_fresh: with the caller's guarantee that dw holds zeros, the result is bit-identical to the
+    accumulating launch on the same zeros — whatever kernel the layer runs on"""
+    spec, N, sizes = case[0], case[1], case[2:]
+    low = lower(spec, *sizes)
+    g = torch.Generator().manual_seed(43)
+    dev = hip_ops.device
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16).to(dev)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16).to(dev)
+    a, gt = (gy, xa) if spec.kind == "conv" else (xa, gy)
+    outs = []
+    for fresh in (False, True):
+        dw = torch.zeros(spec.P * spec.T * spec.Q, dtype=torch.float32, device=dev)
+        hip_ops.wgrad(low.wgrad, a, gt, dw, fresh=fresh)
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].abs().max() > 0
+
+
 @pytest.mark.parametrize("shape,slots", [((8, 64, 64, 256), 16), ((2, 17, 13, 64), 3), ((1, 30, 30, 512), 1),
                                          ((2, 9, 11, 24), 2)])
 @pytest.mark.parametrize("res", [False, True])
