@@ -724,11 +724,12 @@ class NativeNet:
                     if dev.type == "cuda":      # the other pass may have run (and allocated) on another stream
                         held[1].record_stream(torch.cuda.current_stream())
                         held[2].record_stream(torch.cuda.current_stream())
+                    self._wgrad_written(i, tw)
                     ops.wgrad(lw.wgrad, a_t, g_t, dw, pair=(held[1], held[2]))
                 elif more_passes and ops.can_merge_wgrad(lw.wgrad):
-                    self._deferred[i] = (lw.wgrad, a_t, g_t, tw)
+                    self._deferred[i] = (lw.wgrad, a_t, g_t, tw)      # (noted as written when it is launched)
                 else:
-                    ops.wgrad(lw.wgrad, a_t, g_t, dw, fresh=tw is None and self.wgrad_fresh(i))
+                    ops.wgrad(lw.wgrad, a_t, g_t, dw, fresh=self._wgrad_written(i, tw))
                 if sp.bias and not nd.norm:
                     for h in range(N // Nh):
                         gh_ = grad.half(h) if tw is not None else grad
@@ -861,9 +862,19 @@ class NativeNet:
         self._wgrad_seen.add(i)
         return fresh
 
+    def _wgrad_written(self, i, tw=None) -> bool:
+        """EVERY weight-gradient launch of layer i goes through here (merged pairs, flushed holds and twin launches included:
+        a launch that is not noted would make a later one look like the first): notes the write in this network (and its twin
+        partner) and says whether the slice was fresh in all of them"""
+        fresh = self.wgrad_fresh(i)
+        if tw is not None:
+            fresh = tw.wgrad_fresh(i) and fresh
+        return fresh
+
     def _flush_held(self, i, held):
         wd, a_t, g_t, tw = held
         grad = self.master.grad if tw is None else Twin(self.master.grad, tw.master.grad)
+        self._wgrad_written(i, tw)
         self.ops.wgrad(wd, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + self.nodes[i].spec.master_numel])
 
     def flush_deferred_wgrads(self):
