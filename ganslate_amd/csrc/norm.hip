@@ -65,6 +65,12 @@ __global__ __launch_bounds__(256) void slot_sum_kernel(const float* in, float* o
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) out[((size_t)n * R + r) * C + c] = (float)red[r][0][col];
+      if (R == 3 && gridDim.y == 1 && db && mean_rstd) {
+        // one image: its totals give the bias gradient right here — norm_param_grads_kernel's arithmetic with its sum over one
+        // image (gs_launch_slot_sum3 then skips that launch)
+        const float t1 = (float)red[1][0][col], t2 = (float)red[2][0][col];
+        db[c] = __fadd_rn(db[c], __fmul_rn(__fmul_rn(__fmul_rn(-mean_rstd[C + c], t1), t2), inv_hw));
+      }
     }
   }
 }
@@ -650,6 +656,7 @@ int gs_launch_slot_sum3(const float* in, float* out, int N, int slots, int C, fl
     hipLaunchKernelGGL((slot_sum_kernel<3>), dim3((C + 15) / 16, N), dim3(256), 0, st, in, out, slots, C, inv_hw, 0.f,
                        mean_rstd, db);
   GS_CHECK_HIP(hipGetLastError());
+  if (N == 1) return 0;      // (one image: the bias gradient was added by the kernel above)
   return gs_launch_norm_param_grads(out, 3, mean_rstd, db, nullptr, N, C, inv_hw, st);
 }
 

@@ -226,6 +226,13 @@ __global__ __launch_bounds__(256) void pnorm_bwd_finalize_kernel(const float* pa
   if (lane == 0 && c < C) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) sums[((size_t)n * 4 + r) * C + c] = tot[r][col];
+    if (gridDim.y == 1) {
+      // one image: its totals ARE the parameter gradients — norm_param_grads_kernel's arithmetic (norm.hip) with its sum over
+      // one image, here instead of a launch of one workgroup behind this one (184 such launches per V-Net step at batch 1)
+      if (db && mean_rstd)
+        db[c] = __fadd_rn(db[c], __fmul_rn(__fmul_rn(__fmul_rn(-mean_rstd[C + c], tot[1][col]), tot[2][col]), inv_hw));
+      if (dslope) dslope[c] = __fadd_rn(dslope[c], tot[3][col]);
+    }
   }
 }
 
@@ -342,8 +349,9 @@ extern "C" int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const vo
                          chunks, d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
     GS_CHECK_HIP(hipGetLastError());
     // slope and bias gradients: per-image totals added in image order (norm.hip), not by atomics
-    if (int rc = gs_launch_norm_param_grads(sums, 4, mean_rstd, bias_grad, slope ? dslope : nullptr, d->N, d->C,
-                                            1.0f / (float)d->pixels, st)) return rc;
+    if (d->N > 1)     // (one image: done by the finalize pass)
+      if (int rc = gs_launch_norm_param_grads(sums, 4, mean_rstd, bias_grad, slope ? dslope : nullptr, d->N, d->C,
+                                              1.0f / (float)d->pixels, st)) return rc;
   }
   long long bx = ((long long)k.HW * k.C8 + 255) / 256;
   if (bx > 1024) bx = 1024;
