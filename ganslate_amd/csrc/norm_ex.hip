@@ -80,21 +80,58 @@ __global__ __launch_bounds__(256) void norm_ex_fwd_kernel(const NormExK p, const
   }
 }
 
-// ghat for one 8-channel group of one pixel
-__device__ __forceinline__ void ex_ghat(const NormExK& p, int n, unsigned px, int c8, const unsigned short* g1,
-                                        const unsigned short* g2, const float* yh, float* gh) {
+// ghat for one 8-channel group of one pixel. The activations of these graphs are none / ReLU / LeakyReLU: act'(yhat) is then a
+// select between 1 and a per-launch constant (0, the slope, 1) — as a run-time switch per element the compiler turned the two
+// activations of eight channels into a chain of scalar branches that nothing could be scheduled across (the reduction pass
+// took its pixels one memory round trip at a time). tanh keeps the general form.
+__device__ __forceinline__ float ex_neg(int act, float slope) {
+  return act == GS_ACT_RELU ? 0.f : (act == GS_ACT_LRELU ? slope : 1.f);
+}
+__device__ __forceinline__ void ex_ghat_load(const NormExK& p, int n, unsigned px, int c8, const unsigned short* g1,
+                                             const unsigned short* g2, uint4& av, uint4& bv) {
   const gs_norm_ex_desc& d = p.d;
   const size_t pix = (size_t)n * p.HW + px;
+  av = *reinterpret_cast<const uint4*>(g1 + pix * d.g1_cs + d.g1_co + c8 * 8);
+  if (g2) bv = *reinterpret_cast<const uint4*>(g2 + pix * d.g2_cs + d.g2_co + c8 * 8);
+}
+__device__ __forceinline__ void ex_ghat_from(const NormExK& p, int n, unsigned px, int c8, const uint4& av, const uint4& bv,
+                                             bool g2, const float* yh, float* gh) {
+  const gs_norm_ex_desc& d = p.d;
   float a[8], b[8];
-  ex_unpack8(a, *reinterpret_cast<const uint4*>(g1 + pix * d.g1_cs + d.g1_co + c8 * 8));
-  if (g2) ex_unpack8(b, *reinterpret_cast<const uint4*>(g2 + pix * d.g2_cs + d.g2_co + c8 * 8));
+  ex_unpack8(a, av);
+  if (g2) ex_unpack8(b, bv);
   const unsigned e8 = (px * (unsigned)p.C8 + (unsigned)c8) * 8u;
+  float t[8];
+  if (d.act1 != GS_ACT_TANH && d.act2 != GS_ACT_TANH) {      // (uniform)
+    const float n1 = ex_neg(d.act1, d.slope), n2 = ex_neg(d.act2, d.slope);
+    if (g2) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float t = a[k] * act_grad_from_out(yh[k], d.act1, d.slope);
-    if (g2) t += b[k] * act_grad_from_out(yh[k], d.act2, d.slope);
-    gh[k] = t * drop_scale(d, n, e8 + k);
+      for (int k = 0; k < 8; ++k)
+        t[k] = __fadd_rn(__fmul_rn(a[k], yh[k] > 0.f ? 1.f : n1), __fmul_rn(b[k], yh[k] > 0.f ? 1.f : n2));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = __fmul_rn(a[k], yh[k] > 0.f ? 1.f : n1);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      t[k] = __fmul_rn(a[k], act_grad_from_out(yh[k], d.act1, d.slope));
+      if (g2) t[k] = __fadd_rn(t[k], __fmul_rn(b[k], act_grad_from_out(yh[k], d.act2, d.slope)));
+    }
   }
+  if (d.drop_p <= 0.f) {                                      // (uniform)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gh[k] = t[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gh[k] = t[k] * drop_scale(d, n, e8 + k);
+  }
+}
+__device__ __forceinline__ void ex_ghat(const NormExK& p, int n, unsigned px, int c8, const unsigned short* g1,
+                                        const unsigned short* g2, const float* yh, float* gh) {
+  uint4 av, bv = {0u, 0u, 0u, 0u};
+  ex_ghat_load(p, n, px, c8, g1, g2, av, bv);
+  ex_ghat_from(p, n, px, c8, av, bv, g2 != nullptr, yh, gh);
 }
 
 template <int COLS>
@@ -119,14 +156,32 @@ __global__ __launch_bounds__(256) void norm_ex_bwd_reduce_kernel(const NormExK p
     float mu[8], rs[8];
     ex_load8(mu, mr + c8 * 8);
     ex_load8(rs, mr + d.C + c8 * 8);
-    for (unsigned px = p0 + row; px < p1; px += ROWS) {
-      float yh[8], gh[8];
-      ex_unpack8(yh, y_n[(size_t)px * p.C8 + c8]);
+    // Four pixels' operands are requested before the first is used: taken one at a time, the 16-workgroup launches of the inner
+    // U-Net levels spent 13-17 us on eight serial trips to memory. (Sums in pixel order, as before.)
+    constexpr int U = 4;
+    for (unsigned pb = p0 + row; pb < p1; pb += ROWS * U) {
+      uint4 yv[U], av[U], bv[U];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) yh[k] = (yh[k] - mu[k]) * rs[k];
-      ex_ghat(p, n, px, c8, g1, g2, yh, gh);
+      for (int u = 0; u < U; ++u) {
+        const unsigned px = pb + u * ROWS;
+        const unsigned pc = px < p1 ? px : pb;               // (a valid pixel: loaded, not used)
+        yv[u] = y_n[(size_t)pc * p.C8 + c8];
+        bv[u] = uint4{0u, 0u, 0u, 0u};
+        ex_ghat_load(p, n, pc, c8, g1, g2, av[u], bv[u]);
+      }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { a1[k] += gh[k]; a2[k] += gh[k] * yh[k]; a3[k] += yh[k]; }
+      for (int u = 0; u < U; ++u) {
+        const unsigned px = pb + u * ROWS;
+        if (px < p1) {
+          float yh[8], gh[8];
+          ex_unpack8(yh, yv[u]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) yh[k] = (yh[k] - mu[k]) * rs[k];
+          ex_ghat_from(p, n, px, c8, av[u], bv[u], g2 != nullptr, yh, gh);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { a1[k] += gh[k]; a2[k] += gh[k] * yh[k]; a3[k] += yh[k]; }
+        }
+      }
     }
   }
 #pragma unroll
