@@ -167,8 +167,8 @@ def cpu_baseline(size=256, steps=5):
     g = torch.Generator().manual_seed(1234)
     A = torch.rand(1, 3, size, size, generator=g) * 2 - 1
     B = torch.rand(1, 3, size, size, generator=g) * 2 - 1
-    # BASELINE.md §4 plans torch.set_num_threads(os.cpu_count()); on the 256-thread hosts of this pool that setting runs torch's
-    # CPU convs at 0.002 img/s (500 s per step, measured in round 5: oversubscription), so the count is capped at 64
+    # BASELINE.md §4 plans torch.set_num_threads(os.cpu_count()); why the count is capped at 64 on the 256-thread hosts of
+    # this pool (oversubscription, measured in round 5) is recorded in BASELINE.md §4 — the line reports only what this run did
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     model.step(A, B)                         # warm-up
@@ -184,8 +184,7 @@ def cpu_baseline(size=256, steps=5):
         pass
     return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
             "sample": f"oracle/torch_ref.CycleGANStep (stock torch fp32), batch 1, {size}x{size}, 1 warm-up + "
-                      f"{steps} timed steps, {threads} threads of {cores} host cpus ({cpu})"
-                      + (f"; with all {cores} threads the same step ran at 0.002 img/s (measured once, round 5)" if cores > 64 else "")}
+                      f"{steps} timed steps, {threads} threads of {cores} host cpus ({cpu})"}
 
 
 # BASELINE configs[2..4] (per-GPU shapes, SURVEY.md §8 GFLOP per unit): timed for a few steps behind the headline so that the
@@ -555,6 +554,9 @@ def main():
             "step_tflops": round(value * GFLOP_PER_IMAGE / 1e3, 1),
             "step_mfma_frac": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }
+        if world == 1:
+            out["ddp_path"] = "single process: no gradient reduction"
+            out["ddp_self_check"] = None
         if world > 1:
             rt = getattr(model, "reduce_timing", None) or []
             # the reduction is NOT overlapped on this path: everything between the end of the backward graph and the start of
@@ -569,6 +571,7 @@ def main():
                 "launch by launch: bucketed all-reduce overlapped with the last backward pass"
             # both forms were built and compared on the second iteration (BaseGAN._ddp_self_check); None: a form was forced
             out["ddp_self_check"] = getattr(model, "ddp_self_check", None)
+            out["ddp_form_requested"] = getattr(model, "ddp_form_requested", None)   # "0" (default, world > 1) | "1" | "auto"
         if timing is not None:
             res = ops.kernel_timing_result()
             imgs = ops.kernel_timing_images()                    # images per launch: a twin launch covers both generators

@@ -494,9 +494,13 @@ int wgrad_impl(const gs_wgrad_desc* d, const void* a1, const void* g1, const voi
   // the im2col kernel: one launch (+ one reduction) per operand pair, the workspace is reused
   const int nets = tw ? 2 : 1;
   int64_t need = 0;
+  // dw_fresh holds for ONE contributor of dw: the second operand pair adds to what the first one stored
+  gs_wgrad_desc second = *d;
+  second.dw_fresh = 0;
   for (int pass = 0; pass < (a2 ? 2 : 1); ++pass) {
     int slabs = 0;
-    if (int rc = wgrad_generic(d, pass ? a2 : a1, pass ? g2 : g1, dw, det ? ws : nullptr, plan_only, stream, &slabs, tw))
+    if (int rc = wgrad_generic(pass ? &second : d, pass ? a2 : a1, pass ? g2 : g1, dw, det ? ws : nullptr, plan_only, stream,
+                               &slabs, tw))
       return rc;
     if ((int64_t)nets * slabs * slab > need) need = (int64_t)nets * slabs * slab;
     if (plan_only || !det) continue;

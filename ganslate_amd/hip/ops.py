@@ -377,10 +377,13 @@ class HipOps(TwinSplit):
                 tw.bias_delta = bias.delta() if isinstance(bias, Twin) else 0
                 b0 = bias.a if isinstance(bias, Twin) else bias
                 f = self._fuse_struct(fuse) if fuse is not None else None
+                t_end = self._time_begin("gconv_multi", classes, f is not None, N2)
                 L.check(self.lib.gs_gconv_forward_multi_twin(arr, len(classes), _ptr(x), ws, _ptr(None if f is not None else b0),
                                                              _ptr(out), _ptr(None if f is not None else stats),
                                                              C.byref(f) if f is not None else None, C.byref(tw), _stream()),
                         "gs_gconv_forward_multi_twin")
+                if t_end is not None:
+                    t_end.record()
                 return
             return self.twin_gconv(functools.partial(self.gconv_classes, classes), x, wpack, bias, out, in_co=in_co,
                                    out_co=out_co, act=act, slope=slope, stats=stats, stats_slots=stats_slots,
@@ -390,7 +393,7 @@ class HipOps(TwinSplit):
             arr, _ = self._multi_descs(classes, N, x.shape[-1], out.shape[-1])
             base = wpack.data_ptr()
             ws = (C.c_void_p * len(classes))(*[base + 2 * g.pack_offset for g in classes])
-            t_end = self._time_begin("gconv_multi", classes, True)
+            t_end = self._time_begin("gconv_multi", classes, True, N)
             L.check(self.lib.gs_gconv_forward_multi_fused(arr, len(classes), _ptr(x), ws, _ptr(out),
                                                           C.byref(self._fuse_struct(fuse)), _stream()),
                     "gs_gconv_forward_multi_fused")
@@ -424,7 +427,7 @@ class HipOps(TwinSplit):
             return
         base = wpack.data_ptr()
         ws = (C.c_void_p * len(classes))(*[base + 2 * g.pack_offset for g in classes])
-        t_end = self._time_begin("gconv_multi", classes, False)
+        t_end = self._time_begin("gconv_multi", classes, False, N)
         if ent[3]:
             part = torch.empty(ent[3], dtype=torch.float32, device=self.device)
             L.check(self.lib.gs_gconv_forward_multi_ws(ent[0], len(classes), _ptr(x), ws, _ptr(bias), _ptr(out), _ptr(stats),

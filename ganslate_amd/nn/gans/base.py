@@ -276,8 +276,11 @@ class BaseGAN(ABC):
                      first graph (RCCL's kernels become nodes on their own branch, joined by the event wait in
                      finish_grad_reduction), so a replayed iteration overlaps the reduction of the upper buckets and of
                      the discriminators with the remaining backward work.
-        GS_DDP_GRAPH_COLLECTIVES=0 / 1 forces one of them. Default: BOTH are built and checked against each other on this
-        very iteration before either is trusted (_ddp_self_check) — "captured" is kept when the two agree."""
+        Default for world > 1: "between" — the form with nothing of RCCL inside a graph; a multi-rank hang inside a replayed
+        collective has no fallback, and no multi-GPU box has run the captured form yet. GS_DDP_GRAPH_COLLECTIVES=auto opts
+        into the self-check (BOTH forms are built and checked against each other on this very iteration before either is
+        trusted, _ddp_self_check: "captured" is kept when the two agree); =0 / =1 force a form. A single-rank group
+        (GS_FORCE_DDP tests) defaults to auto: there is nobody to hang with."""
         self.logger.info("capturing the training step into a hipGraph (GS_STEP_GRAPH=0 runs it launch by launch, "
                          "GS_SIDE_STREAM=0 on one stream)")
         self._static_inputs = {n: self.visuals[n].clone() for n in self.input_visuals}
@@ -285,7 +288,13 @@ class BaseGAN(ABC):
         self._set_external_host_state(True)
         self._prepare_host_state()
         dp_nets = self._data_parallel_nets()
-        want = os.environ.get("GS_DDP_GRAPH_COLLECTIVES", "auto") if dp_nets else "none"
+        if dp_nets:
+            import torch.distributed as dist
+            default = "0" if dist.get_world_size(dp_nets[0]._dist) > 1 else "auto"
+            want = os.environ.get("GS_DDP_GRAPH_COLLECTIVES", default)
+        else:
+            want = "none"
+        self.ddp_form_requested = want
         if want in ("0", "1", "none"):
             form = {"0": "between", "1": "captured", "none": None}[want]
             chosen = self._capture_graphs(dp_nets, form)
@@ -381,19 +390,26 @@ class BaseGAN(ABC):
         # a rank decides locally whether its capture worked (an out-of-memory condition hits one rank, not all), so the
         # ranks AGREE on the outcome before any of them replays a graph that holds collectives: a rank that fell back
         # would sit in the between form's all-reduce while the others wait inside the captured one.
-        failed = None
+        failed, fatal = None, None
         try:
             forms["captured"] = self._capture_graphs(dp_nets, "captured")
         except Exception as e:      # noqa: BLE001
-            if isinstance(e.__cause__, _HOST_LOGIC_ERRORS):      # a bug in the recipe's host code is not "not capturable"
-                raise
+            if isinstance(e.__cause__, _HOST_LOGIC_ERRORS):      # a bug in the recipe's host code is not "not capturable":
+                fatal = e                                        # raised on EVERY rank, after the agreement below
             failed = e
             forms.pop("captured", None)
             self._graph_broken = False
             self._set_external_host_state(True)
             torch.cuda.synchronize()
-        flag = torch.tensor([0.0 if failed is not None else 1.0], device=dp_nets[0].master.device)
+        # 1: captured here, 0: not capturable here, -1: host-logic error here. MIN over the ranks: every rank learns the worst
+        # outcome BEFORE any of them raises or replays (a rank-local raise in front of this collective would leave the others
+        # blocked in it until the timeout)
+        flag = torch.tensor([-1.0 if fatal is not None else (0.0 if failed is not None else 1.0)], device=dp_nets[0].master.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() < 0.0:
+            if fatal is not None:
+                raise fatal
+            raise RuntimeError("data-parallel self-check: another rank hit a host-logic error while capturing the step")
         if flag.item() != 1.0 and failed is None:
             failed = RuntimeError("another rank could not capture the collectives")
             forms.pop("captured", None)

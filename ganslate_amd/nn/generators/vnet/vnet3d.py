@@ -367,6 +367,7 @@ class Vnet3D(NativeNet):
         """parameter gradients of node i: dense side / gathered side by layer kind; x_in may be a channel slice"""
         ops, sp, lw, grad = self.ops, self.nodes[i].spec, s.lows[i], self.master.grad
         dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
+        self._wgrad_written(i)      # (every weight-gradient launch is noted, NativeNet._wgrad_written; no fresh= hint is taken here)
         if sp.kind == "conv":
             ops.wgrad(lw.wgrad, dy, x_in, dw, g_co=x_co)
         else:

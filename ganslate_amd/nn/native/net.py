@@ -26,7 +26,9 @@ from .twin import Twin
 
 import os
 import weakref
-_BWD_ORDER = os.environ.get("GS_BWD_ORDER", "1") != "0"
+# (GS_BWD_ORDER=0 — backward passes of one network unordered across streams — is gone: since the one-split weight-gradient
+# launches add to dw with plain loads / stores (gs_wgrad_desc.dw_fresh note in ganslate_hip.h), overlapping them loses updates)
+_BWD_ORDER = True
 
 
 @dataclass

@@ -80,7 +80,11 @@ typedef struct gs_wgrad_desc {
   int32_t dw_ld;                    /* leading dimension of dw rows = T*Q */
   int32_t dw_fresh;                 /* hint: the caller guarantees that dw holds zeros (first weight gradient of this layer since
                                      * the optimiser cleared the buffer): a launch that is the only contributor of its elements
-                                     * stores instead of read-add-store. 0 is always valid. */
+                                     * stores instead of read-add-store. 0 is always valid. The hint covers the FIRST operand
+                                     * pair of a call only (gs_wgrad_pair / gs_wgrad_ws with a2: the second pair always adds).
+                                     * One-split launches add to dw with plain loads / stores, not atomics: two weight-gradient
+                                     * launches of the same layer must not overlap on different streams (order them with an
+                                     * event, as NativeNet does between the backward passes of a network). */
   int8_t  dh[GS_MAX_TAPS];
   int8_t  dw_[GS_MAX_TAPS];
   int8_t  dd[GS_MAX_TAPS];
@@ -548,7 +552,9 @@ int gs_wgrad_cout1_ws(const gs_wgrad_desc* d, const void* a, const void* g, floa
  * gs_zero_bytes: zero a 16-byte aligned buffer (the start of a gradient that only taps feed).
  * gs_image_tap_gather / _scatter: nce layer 0 is the ReflectionPad2d(pad) output of the fp32 NCHW image (resnet2d.py:24):
  *   out[n][p][ch] = x[n][ch][r(yp - pad)][r(xp - pad)], (yp, xp) = divmod(ids[p], W + 2 pad), r = reflection; the scatter
- *   zeroes gx [N][C][H][W] and adds g through the same map (fp32 atomics where samples reflect onto one pixel). */
+ *   zeroes gx [N][C][H][W] and adds g through the same map, colliding samples (reflected onto one pixel) in sample order:
+ *   deterministic, at the price of an O(P^2) scan of the ids in LDS — P <= 16384 samples per image (the reference draws
+ *   256, cut.py:46), larger P is refused with an error. */
 int gs_tap_gather(const void* src, int32_t n, int64_t pixels, int32_t cs, const int64_t* ids_dev, int32_t P, int32_t c, float* out,
                   void* stream);
 int gs_tap_scatter_add(void* dst, int32_t n, int64_t pixels, int32_t cs, const int64_t* ids_dev, int32_t P, int32_t c, int32_t W,

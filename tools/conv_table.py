@@ -59,31 +59,33 @@ def main():
         if kind == "gconv":
             label = (f"conv{'+normsum' if flag else ''} in {s.Di}x{s.Hi}x{s.Wi}x{s.Ci} -> dom {s.Dc}x{s.Hc}x{s.Wc}x{s.Co} "
                      f"T={s.T} so={s.so} si={s.si} {s.border}")
-            flops[label] = 2.0 * args.batch * s.pixels * s.Co * s.T * s.Ci
+            flops[label] = 2.0 * s.pixels * s.Co * s.T * s.Ci              # per image
         elif kind == "gconv_multi":
             c = s[0]
             taps = "/".join(str(g.T) for g in s)
-            label = (f"conv x{len(s)} classes in {c.Di}x{c.Hi}x{c.Wi}x{c.Ci} -> dom {c.Dc}x{c.Hc}x{c.Wc}x{c.Co} "
+            label = (f"conv{'+normsum' if flag else ''} x{len(s)} classes in {c.Di}x{c.Hi}x{c.Wi}x{c.Ci} -> dom {c.Dc}x{c.Hc}x{c.Wc}x{c.Co} "
                      f"T={taps} so={c.so} si={c.si} {c.border}")
-            flops[label] = sum(2.0 * args.batch * g.pixels * g.Co * g.T * g.Ci for g in s)
+            flops[label] = sum(2.0 * g.pixels * g.Co * g.T * g.Ci for g in s)
         else:
             label = (f"wgrad{' pair' if flag else ''} a {s.Da}x{s.Ha}x{s.Wa}x{s.P} g {s.Dg}x{s.Hg}x{s.Wg}x{s.Q} T={s.T} "
                      f"si={s.si} {s.border}")
-            flops[label] = 2.0 * args.batch * s.Dg * s.Hg * s.Wg * s.Q * s.T * s.P * (2 if flag else 1)
+            flops[label] = 2.0 * s.Dg * s.Hg * s.Wg * s.Q * s.T * s.P * (2 if flag else 1)
         return label
     ops.enable_kernel_timing(select)
     for _ in range(args.steps):
         step()
     res = ops.kernel_timing_result()
-    ops.disable_kernel_timing()
+    imgs = ops.kernel_timing_images()        # average images per launch of a class: a twin launch covers both networks' images,
+    ops.disable_kernel_timing()              # the D step's launches real + fake of both discriminators
     rows = sorted(((n / args.steps * ms, lab, n / args.steps, ms) for lab, (n, ms) in res.items()), reverse=True)
     tot = sum(r[0] for r in rows)
     dims = "x".join(str(v) for v in shape[2:])
     print(f"# conv launches of one {args.workload} training step, batch {args.batch} {dims}: {sum(r[2] for r in rows):.0f} "
           f"launches, {tot:.3f} ms (HIP events, one stream; includes the deterministic second-stage reductions of wgrad)")
-    print(f"# {'ms/step':>8s} {'n/step':>6s} {'avg us':>8s} {'TFLOP/s':>8s}  class")
+    print(f"# {'ms/step':>8s} {'n/step':>6s} {'avg us':>8s} {'img/launch':>10s} {'TFLOP/s':>8s}  class")
     for t, lab, n, ms in rows:
-        print(f"  {t:8.3f} {n:6.1f} {ms * 1e3:8.1f} {flops[lab] / (ms * 1e-3) / 1e12:8.1f}  {lab}")
+        ni = imgs.get(lab) or args.batch
+        print(f"  {t:8.3f} {n:6.1f} {ms * 1e3:8.1f} {ni:10.1f} {flops[lab] * ni / (ms * 1e-3) / 1e12:8.1f}  {lab}")
 
 
 if __name__ == "__main__":
