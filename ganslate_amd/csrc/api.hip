@@ -84,6 +84,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"splitk_multi", 1},        // gconv.hip: split-K over the merged parity classes of a small stride-2 layer (one launch + one finalize)
     {"splitk_ring", 1},         // gconv.hip: split-K launches of the 128 x 128 tile run a 4-stage ring (three K-steps of cold weights in flight)
     {"gconv_ring4", 16},        // gconv.hip: 128-pixel im2col tiles in a grid of <= 2 workgroups per CU with at least this many K-steps run a 4-stage ring; 0 = off
+    {"ring_dbg", 0},            // hconvw.hip RING: timing ablations (wrong results): 1 no ring MFMAs, 2 no y / g2 loads, 4 no sums, 8 no ring adds
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

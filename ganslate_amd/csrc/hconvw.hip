@@ -224,7 +224,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   [[maybe_unused]] const unsigned sink0 = smem0 + 3 * WT + 2 * HBUF;
   int stage = 0;                                 // ring slot of the current K-step (runs on across tiles)
   int hpar = 0;                                  // halo buffer of the current chunk (alternates across tiles too)
-  [[maybe_unused]] const bool e_top = oy0 == 0, e_bot = oy0 + 16 == d.Ho, e_lef = ox0 == 0, e_rig = ox0 + 16 == d.Wo;
+  // which image borders this box touches, as ONE scalar: every tile re-derives its flags from an opaque copy (the compiler
+  // otherwise hoists each derived select out of the tile loop and runs out of scalar registers, then of vector ones)
+  [[maybe_unused]] const int e_flags = __builtin_amdgcn_readfirstlane(
+      (oy0 == 0 ? 1 : 0) | (oy0 + 16 == d.Ho ? 2 : 0) | (ox0 == 0 ? 4 : 0) | (ox0 + 16 == d.Wo ? 8 : 0));
 #pragma clang loop unroll(disable)
   for (int it = 0; it < ntl; ++it) {
     const int n = n0 + it * nstep;               // this tile's image; the next tile's is n + nstep
@@ -245,6 +248,9 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     [[maybe_unused]] int e_rb = 0, e_slot = 0;
     [[maybe_unused]] bool e_lane = true;         // false: this lane carries no ring pixel (reads the zero sink)
     if constexpr (RING) {
+      int ef = e_flags;
+      asm volatile("" : "+s"(ef));
+      const bool e_top = ef & 1, e_bot = ef & 2, e_lef = ef & 4, e_rig = ef & 8;
       int py = 0, px = 0, sy = 0, sx = 0;        // ring pixel of lane frow: (py + sy*frow, px + sx*frow), box coordinates
       const bool side = e_lef || e_rig;
       if (wm == 0) {
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       } else {
         if (e_rig) { e_mask = 0x124u; px = 16; sy = 1; e_slot = 3; }
       }
+      if (p.dbg & 1) e_mask = 0;
       e_mask = __builtin_amdgcn_readfirstlane(e_mask);
       e_rb = ((py + sy * frow) * 18 + (px + sx * frow)) * HP + fk * 16;
 #pragma unroll
@@ -354,12 +361,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     constexpr int LPR = CWV / 8, PPI = 64 / LPR;            // 4 lanes per pixel, 16 pixels per store instruction
     constexpr int NQ = PH / PPI;                            // store instructions per pass (2)
     const int sub = elane % LPR, prow = elane / LPR;
-    const int co = nt * BN + wn * CWV + sub * 8;
-    // pixel of store q of pass ph: two of the wave's four box rows per pass, 16 pixels per instruction
-    auto opix_of = [&](int ph, int q) {
-      const int pl = q * PPI + prow;
-      return pix0 + (size_t)(wm * 4 + ph * 2 + (pl >> 4)) * d.Wo + (pl & 15);
-    };
+    // (store q of pass ph covers two of the wave's four box rows per pass, 16 pixels per instruction: see the stores below)
     static_assert(NQ == 2, "four store values per lane");
     uint4 val0, val1, val2, val3;                  // the tile in store layout: 4 x 16 B per lane (named: an indexed array
                                                    // ended up in scratch memory)
@@ -369,12 +371,19 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     [[maybe_unused]] f32x4 bia[TI];
     // y / g2 of the consumer's norm backward in the ACCUMULATOR layout (pixel (wm*4 + j, frow), channels i*16 + fk*4 ..):
     // the sums are then taken before the tile goes through the store slabs, i.e. before the first output store
+    // (32-bit lane offsets from a wave-uniform per-image base: the 64-bit form cost ~20 VALU instructions per load)
+    const size_t oimg = (size_t)n * d.Ho * d.Wo * d.Co * 2;
     auto load_yg = [&](int i) {
+      const char* yb = static_cast<const char*>(p.f.y) + oimg;
+      const char* gb = static_cast<const char*>(p.f.g2) + oimg;
+      const unsigned o0 = (unsigned)(((oy0 + wm * 4) * d.Wo + ox0 + frow) * d.Co + nt * BN + wn * CWV + i * 16 + fk * 4) * 2u;
+      const unsigned rowb2 = (unsigned)(d.Wo * d.Co) * 2u;
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
-        const size_t o = ((pix0 + (size_t)(wm * 4 + j) * d.Wo + frow) * d.Co + nt * BN + wn * CWV + i * 16 + fk * 4) * 2;
-        yv[i][j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.f.y) + o);
-        gv[i][j] = p.f.g2 ? *reinterpret_cast<const uint2*>(static_cast<const char*>(p.f.g2) + o) : uint2{0u, 0u};
+        const unsigned o = o0 + (unsigned)j * rowb2;
+        if (!APPLY && (p.dbg & 2)) { yv[i][j] = uint2{o, o}; gv[i][j] = uint2{o0, o}; continue; }
+        yv[i][j] = *reinterpret_cast<const uint2*>(yb + o);
+        gv[i][j] = p.f.g2 ? *reinterpret_cast<const uint2*>(gb + o) : uint2{0u, 0u};
       }
     };
     if constexpr (RING) {
@@ -401,6 +410,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     char* const slab = ebuf + wave * (PH * SROW);            // 16 x 2560 B = 40 KiB
     float* const red = reinterpret_cast<float*>(ebuf + NW * PH * SROW);                       // [WM][BN][2 | 3], behind the slabs
     [[maybe_unused]] float* const mrs = reinterpret_cast<float*>(ebuf + NW * PH * SROW + WM * BN * 3 * 4);   // [2][BN]
+    // RING: zeros behind everything else — what the lanes that are NOT on a fold column read in the ring pre-pass
+    constexpr int ZPAD = ((TJ - 1) * BN + (TI - 1) * 16 + 4) * 4;
+    static_assert(NW * PH * SROW + WM * BN * 3 * 4 + 4 * BN * 4 + (ZPAD + 15) / 16 * 16 <= HBUF, "zero pad must fit the halo buffer");
+    [[maybe_unused]] float* const zpad = reinterpret_cast<float*>(ebuf + NW * PH * SROW + WM * BN * 3 * 4 + 4 * BN * 4);
     if constexpr (RING) {
       // ---- ring sums -> LDS -> added (fp32) to the pixels they fold onto; bf16 tile through the per-wave slabs; coalesced
       // stores with the consumer's InstanceNorm-backward sums (contract of gconv_kernel's fused epilogue: sums over the
@@ -412,10 +425,47 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
           *reinterpret_cast<f32x4*>(ringbuf + (e_slot * 16 + frow) * BN + wn * CWV + i * 16 + fk * 4) = accE[i];
       }
       if (tid < 2 * BN / 4) *reinterpret_cast<f32x4*>(mrs + tid * 4) = mrv;
+      if (tid >= 512 && tid < 512 + (ZPAD + 15) / 16) *reinterpret_cast<f32x4*>(zpad + (tid - 512) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       lds_barrier();
       uint2 pk[TI][TJ];
-      const int cy = e_top ? 1 : 14, cx = e_lef ? 1 : 14;    // where this box's image corner (if it has one) folds onto
-      const bool corner = (e_top || e_bot) && (e_lef || e_rig);
+      // Ring sums onto the pixels they fold onto, in place in the accumulators (fp32, fixed order: row, column, corner). Which
+      // wave / box row takes what is wave-uniform — top row: wm 0, j 1; bottom row: wm 3, j 2; the corner lands on the same
+      // row as the row job — so these are scalar branches; the column (pixel column 1 or 14 of every box row) is one read per
+      // box row whose ADDRESS selects the lane's column: the other lanes read zeros (zpad). (They were five exec-masked
+      // conditional reads per (i, j), each with its own LDS round trip.)
+      {
+        int ef = e_flags;
+        asm volatile("" : "+s"(ef));
+        const bool e_top = ef & 1, e_bot = ef & 2, e_lef = ef & 4, e_rig = ef & 8;
+        const bool rowtop = e_top && wm == 0 && !(p.dbg & 8), rowbot = e_bot && wm == 3 && !(p.dbg & 8);
+        const bool colside = (e_lef || e_rig) && !(p.dbg & 8);
+        const bool oncol = frow == (e_lef ? 1 : 14);
+        const float* colp = oncol ? ringbuf + ((e_lef ? 2 : 3) * 16 + wm * 4) * BN + wn * CWV + fk * 4 : zpad;
+        const float* corp = oncol ? ringbuf + (4 * 16) * BN + wn * CWV + fk * 4 : zpad;
+        const float* rowp = ringbuf + ((rowtop ? 0 : 1) * 16 + frow) * BN + wn * CWV + fk * 4;
+        if (rowtop) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) acc[i][1] += *reinterpret_cast<const f32x4*>(rowp + i * 16);
+        }
+        if (rowbot) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) acc[i][2] += *reinterpret_cast<const f32x4*>(rowp + i * 16);
+        }
+        if (colside) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(colp + j * BN + i * 16);
+          if (rowtop) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acc[i][1] += *reinterpret_cast<const f32x4*>(corp + i * 16);
+          }
+          if (rowbot) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acc[i][2] += *reinterpret_cast<const f32x4*>(corp + i * 16);
+          }
+        }
+      }
       // The sums are VALU work of every lane (16 waves x 32 elements each) with nothing else running on the CU: the
       // instruction count IS the time (measured: 2400 -> 1100 instructions took the launch from 97 to 90 us). Two channels
       // per instruction where the ISA has packed fp32 (v_pk_add / v_pk_mul / v_pk_fma), act'(yhat) as one compare + select:
@@ -433,15 +483,10 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
         f32x2 s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, s3[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-          const int y = wm * 4 + j;
-          f32x4 v = acc[i][j];
-          if (e_top && y == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (0 * 16 + frow) * BN + cl);
-          if (e_bot && y == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (1 * 16 + frow) * BN + cl);
-          if (e_lef && frow == 1) v += *reinterpret_cast<const f32x4*>(ringbuf + (2 * 16 + y) * BN + cl);
-          if (e_rig && frow == 14) v += *reinterpret_cast<const f32x4*>(ringbuf + (3 * 16 + y) * BN + cl);
-          if (corner && y == cy && frow == cx) v += *reinterpret_cast<const f32x4*>(ringbuf + (4 * 16 + 0) * BN + cl);
+          const f32x4 v = acc[i][j];
           pk[i][j].x = pack_bf2(v[0], v[1]);                 // rounded here: the sums see the gradient as it is stored
           pk[i][j].y = pack_bf2(v[2], v[3]);
+          if (!APPLY && (p.dbg & 4)) { s1[0].x += bf_lo(yv[i][j].x ^ gv[i][j].y); continue; }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const unsigned pw = h ? pk[i][j].y : pk[i][j].x, yw = h ? yv[i][j].y : yv[i][j].x, gw = h ? gv[i][j].y : gv[i][j].x;
@@ -691,10 +736,20 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       issue_w(n + nstep, c2, t2, stage == 0 ? 2 : stage - 1);
     }
     if constexpr (!APPLY) {
-      *reinterpret_cast<uint4*>(p.out + (opix_of(0, 0) * d.out_cs + d.out_co + co) * 2) = val0;
-      *reinterpret_cast<uint4*>(p.out + (opix_of(0, 1) * d.out_cs + d.out_co + co) * 2) = val1;
-      *reinterpret_cast<uint4*>(p.out + (opix_of(1, 0) * d.out_cs + d.out_co + co) * 2) = val2;
-      *reinterpret_cast<uint4*>(p.out + (opix_of(1, 1) * d.out_cs + d.out_co + co) * 2) = val3;
+      // (32-bit lane offsets from the image's base, rebuilt here from an opaque lane id: nothing of them lives through the tile)
+      char* const ob = p.out + (size_t)n * d.Ho * d.Wo * d.out_cs * 2;
+      int ls = lane;
+      asm volatile("" : "+v"(ls));
+      const int prow_s = ls / LPR, sub_s = ls % LPR;
+      auto ooff = [&](int ph, int q) {
+        const int pl = q * PPI + prow_s;
+        const int px = (oy0 + wm * 4 + ph * 2 + (pl >> 4)) * d.Wo + ox0 + (pl & 15);
+        return (unsigned)(px * d.out_cs + d.out_co + nt * BN + wn * CWV + sub_s * 8) * 2u;
+      };
+      *reinterpret_cast<uint4*>(ob + ooff(0, 0)) = val0;
+      *reinterpret_cast<uint4*>(ob + ooff(0, 1)) = val1;
+      *reinterpret_cast<uint4*>(ob + ooff(1, 0)) = val2;
+      *reinterpret_cast<uint4*>(ob + ooff(1, 1)) = val3;
     } else {
       // (store offsets from a fresh opaque lane id: computed up front they lived — in scratch memory — through the apply pass;
       // dy and the total gradient are dense [pixel][Co] tensors)
@@ -738,6 +793,7 @@ static bool hconvw_eligible(const gs_gconv_desc* d, int* lo) {
   const long long blocks = (long long)d->N * (d->Ho / 16) * (d->Wo / 16) * (d->Co / 128);
   if (blocks < 192 || blocks >= (1LL << 31)) return false;        // small grids: the 128-pixel tiles fill the chip better
   if ((long long)d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 31)) return false;
+  if ((long long)d->Ho * d->Wo * (d->out_cs > d->Co ? d->out_cs : d->Co) * 2 >= (1LL << 31)) return false;   // 32-bit offsets per image
   return true;
 }
 
@@ -853,7 +909,7 @@ int gs_hconvw_ring(const gs_gconv_desc* d, const void* in, const void* w_pack, v
   k.chunks = d->Ci / 64;
   k.d = *d;
   k.f = *fuse;
-  k.out2 = nullptr; k.sync = nullptr; k.inv_hw = 0.f; k.dbg = 0;
+  k.out2 = nullptr; k.sync = nullptr; k.inv_hw = 0.f; k.dbg = gs_opt(GS_OPT_RING_DBG);
   const long long blocks = (long long)d->N * k.tiles_m * k.tiles_n;
   k.ntiles = (int)blocks;
   hconvw_twin(k, tw);

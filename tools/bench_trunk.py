@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--size", type=int, default=64)
     args = ap.parse_args()
     ops = HipOps()
+    import os
+    if os.environ.get("GS_RING_DBG"):
+        ops.set_option("ring_dbg", int(os.environ["GS_RING_DBG"]))
     dev = ops.device
     C, N, H = 256, args.batch, args.size
     spec = ConvSpec("conv", C, C, 3, 1, 1, pad_mode="reflect")
