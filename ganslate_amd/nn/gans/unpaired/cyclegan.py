@@ -58,6 +58,9 @@ class CycleGAN(BaseGAN):
         stream); GS_TWIN=2d does so for volumes only (their launches fill the chip already: twin passes are worth +2.9 % on
         the Resnet3D recipe, nothing on the V-Net one, whose generators run on their own executor)."""
         self.twin_G = self.twin_D = None
+        for name in ("G_AB", "G_BA"):      # (GS_WGRAD_STREAM=1: their weight gradients beside the data-gradient chain, net.py)
+            if name in self.networks and self.networks[name] is not None:
+                self.networks[name].wgrad_side_stream = True
         mode = os.environ.get("GS_TWIN", "1")
         if not self.is_train or mode == "0":
             return

@@ -29,6 +29,11 @@ import weakref
 # (GS_BWD_ORDER=0 — backward passes of one network unordered across streams — is gone: since the one-split weight-gradient
 # launches add to dw with plain loads / stores (gs_wgrad_desc.dw_fresh note in ganslate_hip.h), overlapping them loses updates)
 _BWD_ORDER = True
+# GS_WGRAD_STREAM=1: networks a recipe marks (wgrad_side_stream) launch their weight-gradient kernels on a stream of their own.
+# Nothing inside a backward pass waits for a weight gradient — the chain is apply -> data gradient -> apply -> ... — so the
+# (compute-bound, long) weight-gradient launches can fill in beside the chain's memory-bound norm passes
+_WGRAD_STREAM = os.environ.get("GS_WGRAD_STREAM", "0") == "1"
+_wgrad_streams = {}
 
 
 @dataclass
@@ -630,6 +635,29 @@ class NativeNet:
         skip: Dict[int, torch.Tensor] = {}
         db_items = []        # bias gradients of the convs in front of norms: one batched launch at the end of the pass
         final_pass = want_w and self._dist is not None and self._fw_pending == 0 and not self.external_reduce
+        # weight gradients on their own stream (see _WGRAD_STREAM): not when this pass reduces buckets as it goes
+        wst = None
+        if _WGRAD_STREAM and want_w and dev.type == "cuda" and getattr(self, "wgrad_side_stream", False) and not final_pass:
+            wst = _wgrad_streams.get(dev.index)
+            if wst is None:
+                wst = _wgrad_streams[dev.index] = torch.cuda.Stream(device=dev)
+        wst_used = False
+
+        def on_wgrad_stream(fn, *tensors):
+            """fn() behind everything launched so far, on the weight-gradient stream; `tensors` are its operands"""
+            nonlocal wst_used
+            if wst is None:
+                return fn()
+            from ...utils.streams import new_event
+            ev = new_event()
+            ev.record()
+            wst.wait_event(ev)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(wst)
+            wst_used = True
+            with torch.cuda.stream(wst):
+                return fn()
         # another recorded forward of this net still awaits its backward (G_AB(real_A) and G_AB(fake_A) in one step):
         # hold the weight gradients of mergeable layers back and issue both passes as one launch then
         more_passes = want_w and self._fw_pending > 0 and start is None
@@ -727,11 +755,13 @@ class NativeNet:
                         held[1].record_stream(torch.cuda.current_stream())
                         held[2].record_stream(torch.cuda.current_stream())
                     self._wgrad_written(i, tw)
-                    ops.wgrad(lw.wgrad, a_t, g_t, dw, pair=(held[1], held[2]))
+                    on_wgrad_stream(lambda: ops.wgrad(lw.wgrad, a_t, g_t, dw, pair=(held[1], held[2])),
+                                    a_t, g_t, held[1], held[2])
                 elif more_passes and ops.can_merge_wgrad(lw.wgrad):
                     self._deferred[i] = (lw.wgrad, a_t, g_t, tw)      # (noted as written when it is launched)
                 else:
-                    ops.wgrad(lw.wgrad, a_t, g_t, dw, fresh=self._wgrad_written(i, tw))
+                    fresh = self._wgrad_written(i, tw)
+                    on_wgrad_stream(lambda: ops.wgrad(lw.wgrad, a_t, g_t, dw, fresh=fresh), a_t, g_t)
                 if sp.bias and not nd.norm:
                     for h in range(N // Nh):
                         gh_ = grad.half(h) if tw is not None else grad
@@ -803,6 +833,9 @@ class NativeNet:
                 s.acts[i + 1] = None  # release as we go
         if db_items:
             ops.norm_bias_grads(db_items)
+        if wst_used:           # whatever follows this pass (the optimiser, another pass of this network) sees its weight gradients
+            from ...utils.streams import wait_stream
+            wait_stream(torch.cuda.current_stream(), wst)
         if not need_input_grad:
             return None
         gx, f, _, fmode = pending[:4]
