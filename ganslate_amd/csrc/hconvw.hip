@@ -132,10 +132,15 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
   // (every row exists: Co is a multiple of 128 and the pack holds at least Co rows, see hconvw_eligible)
   unsigned wsrc[WPI];                            // byte offset of this lane's 16-B piece of K-step 0 inside the pack
   {
-    const int lrow = lane >> 3, wchunk = (lane & 7) ^ lrow;
+    // stage row r (= output channel nt*BN + r) keeps its 16-B pieces at slot ^ swz(r), swz(r) = bits 1, 3, 4 of r: with the
+    // fragment rows below (a lane's 8 output channels contiguous) every ds_read_b128 lane group covers all 64 banks
+    const int lrow = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < WPI; ++i)
-      wsrc[i] = (unsigned)(((nt * BN + (wave * WPI + i) * 8 + lrow) * d.Kp + wchunk * 8) * 2);
+    for (int i = 0; i < WPI; ++i) {
+      const int r = (wave * WPI + i) * 8 + lrow;
+      const int wchunk = (lane & 7) ^ (((r >> 1) & 1) | (((r >> 3) & 1) << 1) | (((r >> 4) & 1) << 2));
+      wsrc[i] = (unsigned)(((nt * BN + r) * d.Kp + wchunk * 8) * 2);
+    }
   }
   auto issue_w = [&](int n, int c, int t, int buf) {        // image n picks the network in a twin batch
     const char* wbase = p.w + (n >= p.nsplit ? p.w_delta : 0);
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     constexpr int kk = decltype(kk_tag)::value;
     const unsigned wa = wb + (kk ? (c0 ^ 64u) : c0);      // 16-B slot (kk * 4 + fk) ^ swz
     lds_read128<0>(wf[0], wa);
-    lds_read128<2048>(wf[1], wa);
+    lds_read128<512>(wf[1], wa);
     const unsigned xa = xb + (unsigned)rowb;
     lds_read128<0 * 18 * HP + kk * 64>(xf[0], xa);
     lds_read128<1 * 18 * HP + kk * 64>(xf[1], xa);
@@ -236,9 +241,12 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       int ll = lane;
       asm volatile("" : "+v"(ll));
       frow = ll & 15; fk = ll >> 4;
-      const int swz = ll & 7;
+      // MFMA row m of channel tile i is output channel wn*CWV + (m >> 2) * 8 + i * 4 + (m & 3): lane (fk = m >> 2 of the
+      // accumulator rows it holds) ends up with the 8 CONTIGUOUS channels wn*CWV + fk*8 .. +8 over i = 0, 1 — 16-byte loads of
+      // y / g2 in the fused epilogue, 16-byte slab writes — at no cost in the loop
+      const int swz = (ll >> 1) & 7;
       rowb = ((wm * 4) * 18 + frow) * HP + fk * 16;
-      woff = (unsigned)((wn * CWV + frow) * 128);
+      woff = (unsigned)((wn * CWV + (frow >> 2) * 8 + (frow & 3)) * 128);
       c0 = (unsigned)((fk ^ swz) << 4);
     }
     const unsigned wring0 = smem0 + woff;
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       } else {
         if (e_rig) { e_mask = 0x124u; px = 16; sy = 1; e_slot = 3; }
       }
-      if (p.dbg & 1) e_mask = 0;
+      if (!APPLY && (p.dbg & 1)) e_mask = 0;      // (ring_dbg ablation; APPLY's dbg bits mean something else)
       e_mask = __builtin_amdgcn_readfirstlane(e_mask);
       e_rb = ((py + sy * frow) * 18 + (px + sx * frow)) * HP + fk * 16;
 #pragma unroll
@@ -366,28 +374,28 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     uint4 val0, val1, val2, val3;                  // the tile in store layout: 4 x 16 B per lane (named: an indexed array
                                                    // ended up in scratch memory)
     [[maybe_unused]] uint4 tot0, tot1, tot2, tot3; // APPLY: the total gradient gx + g2 of the same four pixels
-    [[maybe_unused]] uint2 yv[TI][TJ], gv[TI][TJ];
+    [[maybe_unused]] uint4 yv[TJ], gv[TJ];         // y / g2 of the lane's 8 channels (.x .y: tile i = 0, .z .w: i = 1), per box row
     [[maybe_unused]] f32x4 mrv;
     [[maybe_unused]] f32x4 bia[TI];
     // y / g2 of the consumer's norm backward in the ACCUMULATOR layout (pixel (wm*4 + j, frow), channels i*16 + fk*4 ..):
     // the sums are then taken before the tile goes through the store slabs, i.e. before the first output store
     // (32-bit lane offsets from a wave-uniform per-image base: the 64-bit form cost ~20 VALU instructions per load)
     const size_t oimg = (size_t)n * d.Ho * d.Wo * d.Co * 2;
-    auto load_yg = [&](int i) {
+    auto load_yg = [&]() {
       const char* yb = static_cast<const char*>(p.f.y) + oimg;
       const char* gb = static_cast<const char*>(p.f.g2) + oimg;
-      const unsigned o0 = (unsigned)(((oy0 + wm * 4) * d.Wo + ox0 + frow) * d.Co + nt * BN + wn * CWV + i * 16 + fk * 4) * 2u;
+      const unsigned o0 = (unsigned)(((oy0 + wm * 4) * d.Wo + ox0 + frow) * d.Co + nt * BN + wn * CWV + fk * 8) * 2u;
       const unsigned rowb2 = (unsigned)(d.Wo * d.Co) * 2u;
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const unsigned o = o0 + (unsigned)j * rowb2;
-        if (!APPLY && (p.dbg & 2)) { yv[i][j] = uint2{o, o}; gv[i][j] = uint2{o0, o}; continue; }
-        yv[i][j] = *reinterpret_cast<const uint2*>(yb + o);
-        gv[i][j] = p.f.g2 ? *reinterpret_cast<const uint2*>(gb + o) : uint2{0u, 0u};
+        if (!APPLY && (p.dbg & 2)) { yv[j] = uint4{o, o, o0, o}; gv[j] = uint4{o0, o, o, o0}; continue; }
+        yv[j] = *reinterpret_cast<const uint4*>(yb + o);
+        gv[j] = p.f.g2 ? *reinterpret_cast<const uint4*>(gb + o) : uint4{0u, 0u, 0u, 0u};
       }
     };
     if constexpr (RING) {
-      load_yg(0);      // (the other channel half is fetched while this one is summed: registers)
+      load_yg();
       // mean / rstd of this tile's 128 channels: 64 threads fetch 4 floats each, everybody reads them back from LDS
       if (tid < 2 * BN / 4) {
         const float* mr = p.f.mean_rstd + (size_t)n * 2 * d.Co + (tid >= BN / 4 ? d.Co : 0) + nt * BN + (tid % (BN / 4)) * 4;
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       const float* bias_n = p.bias ? p.bias + (n >= p.nsplit ? p.bias_delta : 0) : nullptr;
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
-        const int cb = nt * BN + wn * CWV + i * 16 + fk * 4;
+        const int cb = nt * BN + wn * CWV + fk * 8 + i * 4;
         bia[i] = bias_n ? *reinterpret_cast<const f32x4*>(bias_n + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
     float* const red = reinterpret_cast<float*>(ebuf + NW * PH * SROW);                       // [WM][BN][2 | 3], behind the slabs
     [[maybe_unused]] float* const mrs = reinterpret_cast<float*>(ebuf + NW * PH * SROW + WM * BN * 3 * 4);   // [2][BN]
     // RING: zeros behind everything else — what the lanes that are NOT on a fold column read in the ring pre-pass
-    constexpr int ZPAD = ((TJ - 1) * BN + (TI - 1) * 16 + 4) * 4;
+    constexpr int ZPAD = ((TJ - 1) * BN + (TI - 1) * 4 + 4) * 4;
     static_assert(NW * PH * SROW + WM * BN * 3 * 4 + 4 * BN * 4 + (ZPAD + 15) / 16 * 16 <= HBUF, "zero pad must fit the halo buffer");
     [[maybe_unused]] float* const zpad = reinterpret_cast<float*>(ebuf + NW * PH * SROW + WM * BN * 3 * 4 + 4 * BN * 4);
     if constexpr (RING) {
@@ -422,10 +430,14 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       if (e_mask) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
-          *reinterpret_cast<f32x4*>(ringbuf + (e_slot * 16 + frow) * BN + wn * CWV + i * 16 + fk * 4) = accE[i];
+          *reinterpret_cast<f32x4*>(ringbuf + (e_slot * 16 + frow) * BN + wn * CWV + fk * 8 + i * 4) = accE[i];
       }
       if (tid < 2 * BN / 4) *reinterpret_cast<f32x4*>(mrs + tid * 4) = mrv;
-      if (tid >= 512 && tid < 512 + (ZPAD + 15) / 16) *reinterpret_cast<f32x4*>(zpad + (tid - 512) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tid >= 512 && tid < 512 + (ZPAD + 15) / 16) {
+        float z0;                                  // (made here: a zero vector hoisted out of the tile loop went to scratch memory)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
+        *reinterpret_cast<f32x4*>(zpad + (tid - 512) * 4) = f32x4{z0, z0, z0, z0};
+      }
       lds_barrier();
       uint2 pk[TI][TJ];
       // Ring sums onto the pixels they fold onto, in place in the accumulators (fp32, fixed order: row, column, corner). Which
@@ -437,32 +449,33 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
         int ef = e_flags;
         asm volatile("" : "+s"(ef));
         const bool e_top = ef & 1, e_bot = ef & 2, e_lef = ef & 4, e_rig = ef & 8;
-        const bool rowtop = e_top && wm == 0 && !(p.dbg & 8), rowbot = e_bot && wm == 3 && !(p.dbg & 8);
-        const bool colside = (e_lef || e_rig) && !(p.dbg & 8);
+        const bool noadd = !APPLY && (p.dbg & 8);
+        const bool rowtop = e_top && wm == 0 && !noadd, rowbot = e_bot && wm == 3 && !noadd;
+        const bool colside = (e_lef || e_rig) && !noadd;
         const bool oncol = frow == (e_lef ? 1 : 14);
-        const float* colp = oncol ? ringbuf + ((e_lef ? 2 : 3) * 16 + wm * 4) * BN + wn * CWV + fk * 4 : zpad;
-        const float* corp = oncol ? ringbuf + (4 * 16) * BN + wn * CWV + fk * 4 : zpad;
-        const float* rowp = ringbuf + ((rowtop ? 0 : 1) * 16 + frow) * BN + wn * CWV + fk * 4;
+        const float* colp = oncol ? ringbuf + ((e_lef ? 2 : 3) * 16 + wm * 4) * BN + wn * CWV + fk * 8 : zpad;
+        const float* corp = oncol ? ringbuf + (4 * 16) * BN + wn * CWV + fk * 8 : zpad;
+        const float* rowp = ringbuf + ((rowtop ? 0 : 1) * 16 + frow) * BN + wn * CWV + fk * 8;
         if (rowtop) {
 #pragma unroll
-          for (int i = 0; i < TI; ++i) acc[i][1] += *reinterpret_cast<const f32x4*>(rowp + i * 16);
+          for (int i = 0; i < TI; ++i) acc[i][1] += *reinterpret_cast<const f32x4*>(rowp + i * 4);
         }
         if (rowbot) {
 #pragma unroll
-          for (int i = 0; i < TI; ++i) acc[i][2] += *reinterpret_cast<const f32x4*>(rowp + i * 16);
+          for (int i = 0; i < TI; ++i) acc[i][2] += *reinterpret_cast<const f32x4*>(rowp + i * 4);
         }
         if (colside) {
 #pragma unroll
           for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(colp + j * BN + i * 16);
+            for (int j = 0; j < TJ; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(colp + j * BN + i * 4);
           if (rowtop) {
 #pragma unroll
-            for (int i = 0; i < TI; ++i) acc[i][1] += *reinterpret_cast<const f32x4*>(corp + i * 16);
+            for (int i = 0; i < TI; ++i) acc[i][1] += *reinterpret_cast<const f32x4*>(corp + i * 4);
           }
           if (rowbot) {
 #pragma unroll
-            for (int i = 0; i < TI; ++i) acc[i][2] += *reinterpret_cast<const f32x4*>(corp + i * 16);
+            for (int i = 0; i < TI; ++i) acc[i][2] += *reinterpret_cast<const f32x4*>(corp + i * 4);
           }
         }
       }
@@ -476,8 +489,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       const bool has_g2 = p.f.g2 != nullptr;
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
-        if (i + 1 < TI) load_yg(i + 1);
-        const int cl = wn * CWV + i * 16 + fk * 4;
+        const int cl = wn * CWV + fk * 8 + i * 4;
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mrs + cl), rs = *reinterpret_cast<const f32x4*>(mrs + BN + cl);
         const f32x2 mu2[2] = {{mu[0], mu[1]}, {mu[2], mu[3]}}, rs2[2] = {{rs[0], rs[1]}, {rs[2], rs[3]}};
         f32x2 s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, s3[2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -486,10 +498,12 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
           const f32x4 v = acc[i][j];
           pk[i][j].x = pack_bf2(v[0], v[1]);                 // rounded here: the sums see the gradient as it is stored
           pk[i][j].y = pack_bf2(v[2], v[3]);
-          if (!APPLY && (p.dbg & 4)) { s1[0].x += bf_lo(yv[i][j].x ^ gv[i][j].y); continue; }
+          if (!APPLY && (p.dbg & 4)) { s1[0].x += bf_lo(yv[j].x ^ gv[j].y); continue; }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const unsigned pw = h ? pk[i][j].y : pk[i][j].x, yw = h ? yv[i][j].y : yv[i][j].x, gw = h ? gv[i][j].y : gv[i][j].x;
+            const unsigned pw = h ? pk[i][j].y : pk[i][j].x;
+            const unsigned yw = i ? (h ? yv[j].w : yv[j].z) : (h ? yv[j].y : yv[j].x);
+            const unsigned gw = i ? (h ? gv[j].w : gv[j].z) : (h ? gv[j].y : gv[j].x);
             f32x2 g = {bf_lo(pw), bf_hi(pw)};
             const f32x2 yq = {bf_lo(yw), bf_hi(yw)};
             if (has_g2) g += f32x2{bf_lo(gw), bf_hi(gw)};
@@ -515,11 +529,11 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
       lds_barrier();                                         // the ring sums have been read: the slabs may overwrite them
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
+        static_assert(TI == 2, "a lane's two channel tiles make one 16-byte slab write");
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int i = 0; i < TI; ++i)
-            *reinterpret_cast<uint2*>(slab + (jj * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = pk[i][ph * 2 + jj];
+          *reinterpret_cast<uint4*>(slab + (jj * 16 + frow) * SROW + fk * 16) =
+              uint4{pk[0][ph * 2 + jj].x, pk[0][ph * 2 + jj].y, pk[1][ph * 2 + jj].x, pk[1][ph * 2 + jj].y};
         __builtin_amdgcn_wave_barrier();                     // wave-private slab: LDS operations of a wave complete in order
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -688,7 +702,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
             uint2 o;
             o.x = pack_bf2(v[0], v[1]);
             o.y = pack_bf2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(slab + (jj * 16 + frow) * SROW + (i * 16 + fk * 4) * 2) = o;
+            *reinterpret_cast<uint2*>(slab + (jj * 16 + frow) * SROW + (fk * 8 + i * 4) * 2) = o;
           }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
             a = row16_sum(a);
             q = row16_sum(q);
             if (frow == 0) {
-              const int cl = wn * CWV + i * 16 + fk * 4 + r;
+              const int cl = wn * CWV + fk * 8 + i * 4 + r;
               red[(wm * BN + cl) * 2 + 0] = a;
               red[(wm * BN + cl) * 2 + 1] = q;
             }
