@@ -326,7 +326,12 @@ int launch_h(const HConvK& k, int blocks, int cog, int lds, hipStream_t st) {
 }  // namespace
 
 // number of partial-statistics slots per image this class writes if it runs on the halo kernel, 0 if it does not
+int gs_hconv5_slots(const gs_gconv_desc* d);
+int gs_hconv5_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
+                  void* stream, int* handled);
+
 int gs_hconv_slots(const gs_gconv_desc* d) {
+  if (const int s5 = gs_hconv5_slots(d)) return s5;       // the 16 -> 16 k5 volume layers: hconv5.hip
   const HPlan h = plan(d);
   return h.ok ? h.nbd * h.nbh * h.nbw : 0;
 }
@@ -335,6 +340,8 @@ int gs_hconv_slots(const gs_gconv_desc* d) {
 int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
                  void* stream, int* handled) {
   *handled = 0;
+  if (int rc = gs_hconv5_try(d, in, w_pack, bias, out, stats, stream, handled)) return rc;
+  if (*handled) return 0;
   const HPlan h = plan(d);
   if (!h.ok) return 0;
   HConvK k;

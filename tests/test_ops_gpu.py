@@ -856,6 +856,49 @@ def test_gconv_accumulate_into_slice(hip_ops):
     close_bf16(outs[1], outs[0], "accumulated dgrad")
 
 
+@pytest.mark.parametrize("sizes", [(8, 16, 16), (16, 32, 48)], ids=lambda s: "x".join(map(str, s)))
+def test_register_resident_k5_kernel(hip_ops, sizes):
+    """hconv5.hip (the 16 -> 16 channel k5 volume convs of the V-Net couplings with the layer's weights in registers) against the
+    oracle and against hconv_kernel: forward with bias / statistics / activation out of a channel slice of a 32-channel buffer,
+    and the data gradient accumulated into a slice; one box (all faces are borders) and 2 x 2 x 3 boxes; 2 images"""
+    ops = hip_ops
+    spec, N = ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 2
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 31)
+    g = torch.Generator().manual_seed(32)
+    x32 = torch.randn(N, *sizes, 32, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, *sizes, 16, generator=g).to(torch.bfloat16)
+    base = torch.randn(N, *sizes, 32, generator=g).to(torch.bfloat16)
+
+    def run(o, dev):
+        ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+        slots, offs = stats_slots(o, low, low.fwd, N)
+        part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
+        o.gconv_classes(low.fwd, x32.to(dev), fpack.to(dev), bias.to(dev), ya, in_co=16, act="lrelu", slope=0.25, stats=part,
+                        stats_slots=slots, stats_slot0s=offs)
+        mr = torch.empty(N * 2 * spec.cout_p, dtype=torch.float32, device=dev)
+        o.inorm_finalize(part, N, slots, spec.cout_p, low.out_pixels, mr)
+        G = base.clone().to(dev)
+        for gc in low.dgrad:
+            o.gconv(gc, gy.to(dev), dpack.to(dev), None, G, out_co=16, accumulate=True)
+        return ya, mr, G, slots
+    y_ref, mr_ref, G_ref, _ = run(RefOps(), "cpu")
+    default = ops.get_option("hconv5")
+    try:
+        ops.set_option("hconv5", 1)           # (any number of boxes: the test volumes are small)
+        y5, mr5, G5, slots5 = run(ops, ops.device)
+        ops.set_option("hconv5", 0)
+        y0, mr0, G0, slots0 = run(ops, ops.device)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("hconv5", default)
+    assert slots5 == (sizes[0] // 8) * (sizes[1] // 16) * (sizes[2] // 16) and slots0 > slots5, (slots5, slots0)
+    close_bf16(y5, y_ref, "forward (hconv5)")
+    close_bf16(y5, y0.cpu(), "forward, hconv5 vs hconv_kernel")
+    close_f32(mr5, mr_ref, "mean / rstd (hconv5)", rel=1e-3)
+    assert torch.equal(G5[..., :16].cpu(), base[..., :16]), "the other half must be untouched"
+    close_bf16(G5, G_ref, "accumulated data gradient (hconv5)")
+
+
 def test_gconv_accumulate_with_split_k(hip_ops):
     """the accumulate-into form on a layer that runs split-K (64 -> 64 channel k5 coupling conv of the V-Net at 16^3: 32 output
     tiles, K = 8000): the finalize pass does the bf16 read-modify-write of gconv_kernel's own accumulate epilogue"""
