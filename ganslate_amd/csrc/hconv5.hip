@@ -9,12 +9,16 @@
 // fragment feeds every tap that can use it:
 //   * K = 32 of one MFMA = two y-adjacent taps x 16 input channels: tap pairs (dy -2,-1), (0,1) and (2, none: zero weights,
 //     partner = the same row so that the padding operand is finite data) for each (dz, dx) -> 15 "units" per dx, 75 in all;
-//   * a wave owns 4 x 8 rows (z, y) of 16 voxels in x: 32 accumulator tiles = 128 registers. A fragment of the input rows
-//     (z', y' | y'+1) at x window dx contributes to the rows (z' - dz, y' - dy0) for up to 5 dz x 2 dy0: 3.3 MFMAs per
-//     fragment read on average (2400 MFMAs against 720 ds_read_b128 per wave and tile) — the loop is MFMA-issue bound.
-// Workgroup = 4 waves (one per SIMD) on one 8 x 16 x 16 box: halo box 12 x 20 x 20 voxels x 32 B = 150 KB of LDS, staged once per
-// tile by LDS-DMA (border handling in the per-lane source address); persistent workgroups walk tiles b, b + grid, ... and load
-// the weights once. Everything is statically unrolled (the accumulator a fragment feeds is a compile-time register).
+//   * a fragment of the input rows (z', y' | y'+1) at x window dx contributes to the output rows (z' - dz, y' - dy0) a wave
+//     owns for up to 5 dz x 2 dy0: 3 MFMAs per fragment read on average — the loop is MFMA-issue bound, not LDS-read bound.
+// Workgroup = 4 waves (one per SIMD) on a COLUMN of 16 x 16 voxels in (y, x) that walks along z, four output planes per step:
+// a ring of 12 input planes (20 x 20 halo voxels x 32 B each, 150 KB of LDS) holds the 8 planes a step reads while the 4 planes
+// the next step adds are staged by LDS-DMA under the step's MFMA stream (border handling in the source address) — nothing of the
+// staging is exposed after a column's first step, and the z halo is read once per column segment instead of once per box (input
+// re-read 1.7x instead of 2.3x). A wave owns the 4 planes x 4 rows (its quarter of y) of a step: 16 accumulator tiles, 400
+// fragment reads for 1200 MFMAs. The volume's columns are cut into z segments so that every CU gets a workgroup; persistent
+// workgroups walk segments b, b + grid, ... and load the weights once. The MFMA stream is statically unrolled (the accumulator
+// a fragment feeds is a compile-time register).
 // Epilogue contract of hconv_kernel: bias, per-box InstanceNorm partial sums (one slot per box), activation, accumulate-into,
 // channel-slice views.
 #include "common.hpp"
@@ -29,22 +33,21 @@ struct HConv5K {
   char* out;
   float* stats;
   const char* zero;
-  int nbd, nbh, nbw;     // boxes per axis
-  int ntiles;            // N * nbd * nbh * nbw
+  int nbh, nbw;          // columns per axis
+  int nseg, seg_steps;   // z segments per column, steps (of 4 planes) per segment
+  int nwork;             // N * nbh * nbw * nseg
   gs_gconv_desc d;
 };
 
-constexpr int BZ = 8, BY = 16, BX = 16;          // output box of a workgroup
-constexpr int HZ = BZ + 4, HY = BY + 4, HX = BX + 4;
+constexpr int SZ = 4, BY = 16, BX = 16;          // output planes per step, column footprint
+constexpr int HY = BY + 4, HX = BX + 4;
 constexpr int VP = 32;                           // bytes per halo voxel (16 channels)
 constexpr int ROWB = HX * VP;                    // 640
 constexpr int PLANEB = HY * ROWB;                // 12800
-constexpr int HALO_BYTES = HZ * PLANEB;          // 153600
-constexpr int HPIECES = HZ * HY * HX * 2;        // 16-B pieces
-constexpr int HINSTR = HPIECES / 64;             // 150 (exact)
-static_assert(HPIECES % 64 == 0, "whole LDS-DMA instructions");
-constexpr int LZ = 4, LY = 8;                    // rows of a wave
-constexpr int NRING = 6;                         // voxel fragments in flight
+constexpr int NSLOT = 12;                        // ring of input planes: 8 in use + 4 arriving
+constexpr int HALO_BYTES = NSLOT * PLANEB;       // 153600
+constexpr int LZ = 4, LY = 4;                    // rows of a wave: all planes of the step x its quarter of y
+constexpr int NRING = 8;                         // voxel fragments in flight
 
 // MFMA through inline asm with the A operand's register class spelled out: the weights must live in BOTH halves of the
 // unified register file (64 of the 75 fragments in accumulation registers, the rest beside the accumulators in the
@@ -60,7 +63,11 @@ __device__ __forceinline__ void mfma_v(f32x4& acc, const bf16x8& a, const bf16x8
 }
 template <int U>
 __device__ __forceinline__ void mfma_u(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#ifdef HCONV5_BUILTIN
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#else
   if constexpr (U < A_IN_AGPR) mfma_a(acc, a, b); else mfma_v(acc, a, b);
+#endif
 }
 
 template <int... I, class F>
@@ -68,25 +75,27 @@ __device__ __forceinline__ void unroll_seq(std::integer_sequence<int, I...>, F&&
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-// fragment f of a wave's walk: x window dxi, input plane zp (0..7 = wave z base - 2 ..), kind / row
-constexpr int FR_PER_PLANE = (LY + 2) + LY;      // 10 paired fragments (y' = -2 .. LY-1) + 8 single ones (y' = 2 .. LY+1)
+// fragment f of a wave's walk through a step: x window dxi, input plane zp (0..7 = first output plane - 2 ..), kind / row
+constexpr int FR_PER_PLANE = (LY + 2) + LY;      // 6 paired fragments (y' = -2 .. LY-1) + 4 single ones (y' = 2 .. LY+1)
 constexpr int NFRAG = 5 * (LZ + 4) * FR_PER_PLANE;
 struct FragId { int dxi, zp, single, yp; };
+// (plane index fastest: the planes at the ends of a step's window feed one or two output planes, the middle ones four — walking a
+// whole plane at a time left the fragment prefetch a few MFMAs ahead on the light planes, far less than the LDS latency)
 constexpr FragId frag_of(int f) {
-  const int k = f % FR_PER_PLANE, r = f / FR_PER_PLANE;
-  return FragId{r / (LZ + 4), r % (LZ + 4), k >= LY + 2 ? 1 : 0, k >= LY + 2 ? (k - (LY + 2)) + 2 : k - 2};
+  const int zp = f % (LZ + 4), r = f / (LZ + 4);
+  const int k = r % FR_PER_PLANE;
+  return FragId{r / FR_PER_PLANE, zp, k >= LY + 2 ? 1 : 0, k >= LY + 2 ? (k - (LY + 2)) + 2 : k - 2};
 }
 
 __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;                                           // [HZ][HY][HX][32 B]
+  char* halo = smem;                                           // [NSLOT][HY][HX][32 B]
   int* lut = reinterpret_cast<int*>(smem + HALO_BYTES);        // [125] tap index of (dz, dy, dx), -1 = absent
   float* red = reinterpret_cast<float*>(smem + HALO_BYTES + 512);   // [4 waves][16 channels][2]
   const gs_gconv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
-  const int zq = wave >> 1, yq = wave & 1;
 
   for (int t = tid; t < 125; t += 256) lut[t] = -1;
   __syncthreads();
@@ -95,11 +104,12 @@ __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
   __syncthreads();
 
   // ---- the layer's weights: 75 A fragments, lane (row co = col, k group kg): tap member kg >> 1 of the pair, channels
-  // (kg & 1) * 8 .. + 8 of pack row co (tap-major K: t * Ci + ci) ------------------------------------------------------------
+  // (kg & 1) * 8 .. + 8 of pack row co (tap-major K: t * Ci + ci). All tap lookups first, then the 75 loads back to back. ---------
   bf16x8 A[5][3][5];                               // [dz][dy pair][dx]
   {
     const bool row_ok = col < d.w_rows;
     const char* wrow = p.w + ((size_t)col * d.Kp + (kg & 1) * 8) * 2;
+    int tt[5][3][5];
 #pragma unroll
     for (int a = 0; a < 5; ++a)
 #pragma unroll
@@ -107,152 +117,241 @@ __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
           const int dy = b * 2 + (kg >> 1);        // 0..5 (5: the missing partner of dy = +2)
-          const int t = dy < 5 ? lut[a * 25 + dy * 5 + c] : -1;
+          tt[a][b][c] = dy < 5 ? lut[a * 25 + dy * 5 + c] : -1;
+        }
+    // (two batches with a wait behind each: vmcnt counts to 63 — with all 75 loads and the first planes' 40 staging instructions
+    // in flight the counter wrapped and the first step's vmcnt(0) let the MFMAs start on weights that had not arrived)
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const int t = tt[a][b][c];
           const char* src = (row_ok && t >= 0) ? wrow + (size_t)t * d.Ci * 2 : p.zero;
           A[a][b][c] = *reinterpret_cast<const bf16x8*>(src);
         }
+      if (a == 2 || a == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
+  // per-lane byte offset of a fragment read inside a plane: voxel column col (+ window), channel half kg & 1, row of the wave's
+  // quarter (+ the partner row for kg >= 2 of a paired fragment)
+  const unsigned halo0 = lds_addr(halo);
+  const unsigned lane_single = (unsigned)((wave * LY) * ROWB + col * VP + (kg & 1) * 16);
+  const unsigned lane_pair = lane_single + (unsigned)((kg >> 1) * ROWB);
 
-  // per-lane halo byte offsets of a fragment read: voxel column col (+ window), channel half kg & 1, partner row for kg >= 2
-  const unsigned lane_b = (unsigned)(col * VP + (kg & 1) * 16);
-  const unsigned halo0 = lds_addr(halo) + (unsigned)((zq * LZ) * PLANEB + (yq * LY) * ROWB);
-  // (two bases per kind: planes 0-4 and 5-7 of the wave's window, so that the rest of the offset fits the ds_read immediate)
-  const unsigned a_pair = halo0 + lane_b + (unsigned)((kg >> 1) * ROWB), a_pair_hi = a_pair + 5 * PLANEB;
-  const unsigned a_single = halo0 + lane_b, a_single_hi = a_single + 5 * PLANEB;
-
-  const int tiles_per_img = p.nbd * p.nbh * p.nbw;
+  const int cols_per_img = p.nbh * p.nbw;
 #pragma clang loop unroll(disable)
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int n = tile / tiles_per_img;
-    int b = tile - n * tiles_per_img;
-    const int box = b;
+  for (int work = blockIdx.x; work < p.nwork; work += gridDim.x) {
+    int b = work;
+    const int seg = b % p.nseg; b /= p.nseg;
     const int bx = b % p.nbw; b /= p.nbw;
     const int by = b % p.nbh;
-    const int bz = b / p.nbh;
-    const int oz0 = bz * BZ, oy0 = by * BY, ox0 = bx * BX;
-    // ---- stage the halo box: one 16-B piece per lane per LDS-DMA instruction --------------------------------------------------
-    __syncthreads();                              // the previous tile's reads are done
+    const int n = b / p.nbh;
+    const int oy0 = by * BY, ox0 = bx * BX;
+    const int zs0 = seg * p.seg_steps * SZ;                              // first output plane of the segment
+    const int nsteps = min(p.seg_steps, (d.Do - zs0 + SZ - 1) / SZ);
+    const char* in_n = p.in + ((size_t)n * d.Di * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
+    // ---- staging: a halo row = 40 lanes x 16 B (voxel hx = lane >> 1, half lane & 1) by one LDS-DMA instruction; this wave stages
+    // rows wave, wave + 4, ... of every plane. Source = plane offset + row offset + lane offset, each resolved once: the lane's
+    // x at the top of the column, the wave's five rows too, a plane's z when it is staged. 0xffffffff = outside a zero border.
+    const bool x_lane = lane < 2 * HX;
+    unsigned x_off;
     {
-      const char* in_n = p.in + ((size_t)n * d.Di * d.Hi * d.Wi * d.in_cs + d.in_co) * 2;
-      for (int inst = wave; inst < HINSTR; inst += 4) {
-        const int q = inst * 64 + lane;
-        const int v = q >> 1, part = q & 1;
-        const int hz = v / (HY * HX), r2 = v - hz * (HY * HX);
-        const int hy = r2 / HX, hx = r2 - hy * HX;
-        bool ok = true;
-        int iz = border_index(oz0 + hz - 2, d.Di, d.border, ok);
-        int iy = border_index(oy0 + hy - 2, d.Hi, d.border, ok);
-        int ix = border_index(ox0 + hx - 2, d.Wi, d.border, ok);
-        iz = min(max(iz, 0), d.Di - 1);
-        iy = min(max(iy, 0), d.Hi - 1);
-        ix = min(max(ix, 0), d.Wi - 1);
-        unsigned off = ((unsigned)((iz * d.Hi + iy) * d.Wi + ix) * (unsigned)d.in_cs + (unsigned)(part * 8)) * 2u;
-        asm volatile("" : "+v"(off));
-        const char* src = ok ? in_n + off : p.zero;
-        glds16(src, halo + inst * 1024);
-      }
+      bool ok = true;
+      int ix = border_index(ox0 + (lane >> 1) - 2, d.Wi, d.border, ok);
+      ix = min(max(ix, 0), d.Wi - 1);
+      x_off = ok ? (unsigned)(ix * d.in_cs + (lane & 1) * 8) * 2u : 0xffffffffu;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    f32x4 acc[LZ][LY];
+    unsigned row_off[HY / 4];
 #pragma unroll
-    for (int z = 0; z < LZ; ++z)
-#pragma unroll
-      for (int y = 0; y < LY; ++y) acc[z][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- all taps out of registers: fragment f is read NRING fragments ahead of its MFMAs --------------------------------------
-    bf16x8 ring[NRING];
-    auto issue = [&](auto f_tag) {
-      constexpr int f = decltype(f_tag)::value;
-      if constexpr (f < NFRAG) {
-        constexpr FragId id = frag_of(f);
-        // halo row of the fragment: plane zp, row yp + 2 (halo coordinates of the wave's window), x window dxi
-        constexpr int off = (id.zp % 5) * PLANEB + (id.yp + 2) * ROWB + id.dxi * VP;
-        static_assert(off >= 0 && off < 65536 - 16, "ds_read immediate");
-        lds_read128<off>(ring[f % NRING], id.zp < 5 ? (id.single ? a_single : a_pair) : (id.single ? a_single_hi : a_pair_hi));
-      }
+    for (int j = 0; j < HY / 4; ++j) {
+      bool ok = true;
+      int iy = border_index(oy0 + wave + 4 * j - 2, d.Hi, d.border, ok);
+      iy = min(max(iy, 0), d.Hi - 1);
+      row_off[j] = ok ? (unsigned)(iy * d.Wi * d.in_cs) * 2u : 0xffffffffu;
+    }
+    auto plane_off = [&](int pl) {                 // input plane number pl of the segment: z = zs0 - 2 + pl
+      bool ok = true;
+      int iz = border_index(zs0 - 2 + pl, d.Di, d.border, ok);
+      iz = min(max(iz, 0), d.Di - 1);
+      return ok ? (unsigned)(iz * d.Hi * d.Wi * d.in_cs) * 2u : 0xffffffffu;
     };
-    unroll_seq(std::make_integer_sequence<int, NRING - 1>{}, issue);
-    unroll_seq(std::make_integer_sequence<int, NFRAG>{}, [&](auto f_tag) {
-      constexpr int f = decltype(f_tag)::value;
-      constexpr FragId id = frag_of(f);
-      issue(std::integral_constant<int, f + NRING - 1>{});
-      // fragments are consumed in issue order: at most NRING - 1 younger reads may still be in flight
-      constexpr int younger = (NFRAG - 1 - f) < (NRING - 1) ? (NFRAG - 1 - f) : (NRING - 1);
-      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % NRING]) : "i"(younger) : "memory");
-      constexpr int zi = id.zp - 2;                // input plane relative to the wave's first output plane
-      unroll_seq(std::make_integer_sequence<int, 5>{}, [&](auto a_tag) {      // dz = a - 2: output plane zi - dz
-        constexpr int a = decltype(a_tag)::value;
-        constexpr int zr = zi - (a - 2);
-        if constexpr (zr >= 0 && zr < LZ) {
-          if constexpr (id.single) {               // dy0 = +2: output row yp - 2
-            mfma_u<(a * 3 + 2) * 5 + id.dxi>(acc[zr][id.yp - 2], A[a][2][id.dxi], ring[f % NRING]);
-          } else {
-            if constexpr (id.yp + 2 >= 0 && id.yp + 2 < LY)    // dy0 = -2: output row yp + 2
-              mfma_u<(a * 3 + 0) * 5 + id.dxi>(acc[zr][id.yp + 2], A[a][0][id.dxi], ring[f % NRING]);
-            if constexpr (id.yp >= 0 && id.yp < LY)            // dy0 = 0: output row yp
-              mfma_u<(a * 3 + 1) * 5 + id.dxi>(acc[zr][id.yp], A[a][1][id.dxi], ring[f % NRING]);
+    auto stage_row = [&](unsigned poff, int slot, auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+      const bool ok = poff != 0xffffffffu && row_off[j] != 0xffffffffu && x_off != 0xffffffffu;
+      const char* src = ok ? in_n + (poff + row_off[j] + x_off) : p.zero;
+      if (x_lane) glds16(src, halo + slot * PLANEB + (wave + 4 * j) * ROWB);
+    };
+    __syncthreads();                              // the previous segment's reads are done
+    for (int pl = 0; pl < 8; ++pl) {
+      const unsigned poff = plane_off(pl);
+      unroll_seq(std::make_integer_sequence<int, HY / 4>{}, [&](auto j_tag) { stage_row(poff, pl % NSLOT, j_tag); });
+    }
+
+    bool counted = false;                         // the previous step issued exactly NST output stores behind its staging
+#pragma clang loop unroll(disable)
+    for (int step = 0; step < nsteps; ++step) {
+      // this step's planes have landed (this wave's share): everything but the previous step's output stores, which are younger
+      // than its staging instructions and drain under this step (VMEM retires in issue order)
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LZ * LY) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                          // ... everybody's; the previous step's reads are done
+      asm volatile("" ::: "memory");
+      // the 4 planes the next step adds go into the slots this step does not read; their 20 row instructions are spread over
+      // the first half of the MFMA stream
+      const bool stage_next = step + 1 < nsteps;
+      unsigned npoff[4];
+      int nslot[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { npoff[k] = plane_off(4 * step + 8 + k); nslot[k] = (4 * step + 8 + k) % NSLOT; }
+      // plane bases of this step: input plane zp of the step sits in slot (4 * step + zp) % NSLOT
+      unsigned pbase[LZ + 4];
+#pragma unroll
+      for (int zp = 0; zp < LZ + 4; ++zp) pbase[zp] = halo0 + (unsigned)(((4 * step + zp) % NSLOT) * PLANEB);
+
+      f32x4 acc[LZ][LY];
+#pragma unroll
+      for (int z = 0; z < LZ; ++z)
+#pragma unroll
+        for (int y = 0; y < LY; ++y) {
+          acc[z][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+          asm volatile("" : "+v"(acc[z][y]));       // (materialised HERE: the hazard recognizer does not see the inline-asm MFMAs, and a
+        }                                          // v_mov sunk in front of the first MFMA that reads it as SrcC raced with it)
+      asm volatile("s_nop 7" ::: "memory");
+
+      // ---- all taps out of registers: fragment f is read NRING - 1 fragments ahead of its MFMAs ------------------------------
+      bf16x8 ring[NRING];
+      auto issue = [&](auto f_tag) {
+        constexpr int f = decltype(f_tag)::value;
+        if constexpr (f < NFRAG) {
+          constexpr FragId id = frag_of(f);
+          // row yp + 2 of the wave's quarter (halo coordinates), x window dxi
+          constexpr int off = (id.yp + 2) * ROWB + id.dxi * VP;
+          lds_read128<off>(ring[f % NRING], pbase[id.zp] + (id.single ? lane_single : lane_pair));
+        }
+      };
+      unroll_seq(std::make_integer_sequence<int, NRING - 1>{}, issue);
+      unroll_seq(std::make_integer_sequence<int, NFRAG>{}, [&](auto f_tag) {
+        constexpr int f = decltype(f_tag)::value;
+        constexpr FragId id = frag_of(f);
+        issue(std::integral_constant<int, f + NRING - 1>{});
+        if constexpr (f % 10 == 5 && f / 10 < 4 * (HY / 4)) {      // staging row f / 10 of the next step: plane r / 5, row r % 5
+          constexpr int r = f / 10;
+          if (stage_next) stage_row(npoff[r / (HY / 4)], nslot[r / (HY / 4)], std::integral_constant<int, r % (HY / 4)>{});
+        }
+        // fragments are consumed in issue order: at most NRING - 1 younger reads may still be in flight
+        constexpr int younger = (NFRAG - 1 - f) < (NRING - 1) ? (NFRAG - 1 - f) : (NRING - 1);
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % NRING]) : "i"(younger) : "memory");
+        constexpr int zi = id.zp - 2;                // input plane relative to the step's first output plane
+        unroll_seq(std::make_integer_sequence<int, 5>{}, [&](auto a_tag) {      // dz = a - 2: output plane zi - dz
+          constexpr int a = decltype(a_tag)::value;
+          constexpr int zr = zi - (a - 2);
+          if constexpr (zr >= 0 && zr < LZ) {
+            if constexpr (id.single) {               // dy0 = +2: output row yp - 2
+              mfma_u<(a * 3 + 2) * 5 + id.dxi>(acc[zr][id.yp - 2], A[a][2][id.dxi], ring[f % NRING]);
+            } else {
+              if constexpr (id.yp + 2 >= 0 && id.yp + 2 < LY)    // dy0 = -2: output row yp + 2
+                mfma_u<(a * 3 + 0) * 5 + id.dxi>(acc[zr][id.yp + 2], A[a][0][id.dxi], ring[f % NRING]);
+              if constexpr (id.yp >= 0 && id.yp < LY)            // dy0 = 0: output row yp
+                mfma_u<(a * 3 + 1) * 5 + id.dxi>(acc[zr][id.yp], A[a][1][id.dxi], ring[f % NRING]);
+            }
+          }
+        });
+      });
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMA's result is architecturally visible to VALU
+
+      // ---- epilogue: bias, partial statistics (one slot per step of a column), activation, [accumulate], 8-B NDHWC stores ---
+      // A wave alone on its SIMD hides nothing: the epilogue is kept to ~15 instructions per row — the activation mode, the
+      // accumulate form and the volume's end are wave-uniform and decided ONCE (they were three scalar branches per element),
+      // statistics and bias as packed fp32, store addresses = a scalar row base + one lane offset.
+      const bool want_stats = d.stats_slots > 0;
+      const int co = kg * 4;
+      f32x2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+      if (p.bias) {
+        b01 = f32x2{co + 0 < d.Co ? p.bias[co + 0] : 0.f, co + 1 < d.Co ? p.bias[co + 1] : 0.f};
+        b23 = f32x2{co + 2 < d.Co ? p.bias[co + 2] : 0.f, co + 3 < d.Co ? p.bias[co + 3] : 0.f};
+      }
+      f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
+      const int oz0 = zs0 + step * SZ;
+      char* out_c = p.out + ((size_t)n * d.Do * d.Ho * d.Wo + (size_t)(oy0 + wave * LY) * d.Wo) * d.out_cs * 2;
+      const unsigned lane_o = (unsigned)((ox0 + col) * d.out_cs + d.out_co + co) * 2u;
+      const bool st_lane = co < d.Co;
+      const int nz = min(LZ, d.Do - oz0);          // (a segment's last step may hang over the volume)
+      auto rows = [&](auto act_tag, auto acc_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool ACCUM = decltype(acc_tag)::value;
+#pragma unroll
+        for (int z = 0; z < LZ; ++z) {
+          if (z >= nz) break;
+#pragma unroll
+          for (int y = 0; y < LY; ++y) {
+            f32x2 v01 = f32x2{acc[z][y][0], acc[z][y][1]} + b01, v23 = f32x2{acc[z][y][2], acc[z][y][3]} + b23;
+            s1a += v01; s1b += v23;
+            s2a += v01 * v01; s2b += v23 * v23;
+            if constexpr (ACT == GS_ACT_RELU) {
+              v01 = f32x2{fmaxf(v01.x, 0.f), fmaxf(v01.y, 0.f)}; v23 = f32x2{fmaxf(v23.x, 0.f), fmaxf(v23.y, 0.f)};
+            } else if constexpr (ACT == GS_ACT_LRELU) {
+              v01 = f32x2{v01.x > 0.f ? v01.x : v01.x * d.slope, v01.y > 0.f ? v01.y : v01.y * d.slope};
+              v23 = f32x2{v23.x > 0.f ? v23.x : v23.x * d.slope, v23.y > 0.f ? v23.y : v23.y * d.slope};
+            } else if constexpr (ACT == GS_ACT_TANH) {
+              v01 = f32x2{gs_tanh_call(v01.x), gs_tanh_call(v01.y)}; v23 = f32x2{gs_tanh_call(v23.x), gs_tanh_call(v23.y)};
+            }
+            uint2 o;
+            o.x = pack_bf2(v01.x, v01.y);
+            o.y = pack_bf2(v23.x, v23.y);
+            char* rowp = out_c + ((size_t)(oz0 + z) * d.Ho + y) * d.Wo * d.out_cs * 2;      // wave-uniform
+            uint2* dst = reinterpret_cast<uint2*>(rowp + lane_o);
+            if (st_lane) {
+              if constexpr (ACCUM) {     // bf16 read-modify-write, same rounding points as gconv_kernel / hconv_kernel
+                const uint2 old = *dst;
+                o.x = pack_bf2(bf_lo(o.x) + bf_lo(old.x), bf_hi(o.x) + bf_hi(old.x));
+                o.y = pack_bf2(bf_lo(o.y) + bf_lo(old.y), bf_hi(o.y) + bf_hi(old.y));
+              }
+              *dst = o;
+            }
           }
         }
-      });
-    });
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMA's result is architecturally visible to VALU
-
-    // ---- epilogue: bias, partial statistics (one slot per box), activation, [accumulate], 8-B NDHWC stores ------------------------
-    const bool want_stats = d.stats_slots > 0;
-    const int co = kg * 4;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = co + r < d.Co ? p.bias[co + r] : 0.f;
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    char* out_n = p.out + (size_t)n * d.Do * d.Ho * d.Wo * d.out_cs * 2;
-#pragma unroll
-    for (int z = 0; z < LZ; ++z)
-#pragma unroll
-      for (int y = 0; y < LY; ++y) {
-        const int oz = oz0 + zq * LZ + z, oy = oy0 + yq * LY + y, ox = ox0 + col;
-        float v[4];
+      };
+      using T_ = std::true_type; using F_ = std::false_type;
+      if (d.accumulate) rows(std::integral_constant<int, GS_ACT_NONE>{}, T_{});        // (no bias / activation / statistics then)
+      else if (d.act == GS_ACT_NONE) rows(std::integral_constant<int, GS_ACT_NONE>{}, F_{});
+      else if (d.act == GS_ACT_RELU) rows(std::integral_constant<int, GS_ACT_RELU>{}, F_{});
+      else if (d.act == GS_ACT_LRELU) rows(std::integral_constant<int, GS_ACT_LRELU>{}, F_{});
+      else rows(std::integral_constant<int, GS_ACT_TANH>{}, F_{});
+      const float s1[4] = {s1a.x, s1a.y, s1b.x, s1b.y}, s2[4] = {s2a.x, s2a.y, s2b.x, s2b.y};
+      if (want_stats) {
+        // (the LDS-DMA of the next step's planes is in flight: LDS accesses the compiler sees would wait for it — raw stores /
+        // loads through inline asm, ordered by lgkmcnt and a bare barrier)
+        const unsigned red0 = lds_addr(red);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = acc[z][y][r] + bv[r];
-          s1[r] += v[r];
-          s2[r] += v[r] * v[r];
-          v[r] = apply_act_small(v[r], d.act, d.slope);
-        }
-        if (co < d.Co) {
-          uint2* dst = reinterpret_cast<uint2*>(out_n + ((size_t)((oz * d.Ho + oy) * d.Wo + ox) * d.out_cs + d.out_co + co) * 2);
-          uint2 o;
-          o.x = pack_bf2(v[0], v[1]);
-          o.y = pack_bf2(v[2], v[3]);
-          if (d.accumulate) {     // bf16 read-modify-write, same rounding points as gconv_kernel / hconv_kernel
-            const uint2 old = *dst;
-            o.x = pack_bf2(bf_lo(o.x) + bf_lo(old.x), bf_hi(o.x) + bf_hi(old.x));
-            o.y = pack_bf2(bf_lo(o.y) + bf_lo(old.y), bf_hi(o.y) + bf_hi(old.y));
+          const float a = row16_sum(s1[r]), q = row16_sum(s2[r]);
+          if (col == 0) {
+            const unsigned ad = red0 + (unsigned)((wave * 16 + co + r) * 8);
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4" ::"v"(ad), "v"(a), "v"(q) : "memory");
           }
-          *dst = o;
         }
-      }
-    if (want_stats) {
+        lds_barrier();
+        if (tid < 16 && tid < d.Co) {
+          float a = 0.f, q = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = row16_sum(s1[r]), q = row16_sum(s2[r]);
-        if (col == 0) {
-          red[(wave * 16 + co + r) * 2 + 0] = a;
-          red[(wave * 16 + co + r) * 2 + 1] = q;
+          for (int w = 0; w < 4; ++w) {
+            float ra, rq;
+            const unsigned ad = red0 + (unsigned)((w * 16 + tid) * 8);
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)" : "=v"(ra), "=v"(rq) : "v"(ad) : "memory");
+            a += ra; q += rq;
+          }
+          const int slot = ((oz0 / SZ) * p.nbh + by) * p.nbw + bx;
+          float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + slot) * 2) * d.Co;
+          sp[tid] = a;
+          sp[d.Co + tid] = q;
         }
+        lds_barrier();                               // red may be rewritten by the next step
       }
-      __syncthreads();
-      if (tid < 16 && tid < d.Co) {
-        float a = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { a += red[(w * 16 + tid) * 2]; q += red[(w * 16 + tid) * 2 + 1]; }
-        float* sp = p.stats + (((size_t)n * d.stats_slots + d.stats_slot0 + box) * 2) * d.Co;
-        sp[tid] = a;
-        sp[d.Co + tid] = q;
-      }
+      // (counted wait of the next step: valid when every row's store was issued and nothing else — statistics stores of wave 0 only
+      // make the count stricter)
+      counted = oz0 + SZ <= d.Do;
     }
   }
 }
@@ -261,20 +360,21 @@ bool hconv5_eligible(const gs_gconv_desc* d) {
   if (!gs_opt(GS_OPT_HCONV5)) return false;
   if (d->T != 125 || d->Ci != 16 || d->Co > 16 || d->Co < 8 || d->si != 1 || d->so != 1) return false;
   if (d->Dc != d->Do || d->Hc != d->Ho || d->Wc != d->Wo || d->pz || d->py || d->px) return false;
-  if (d->Do % BZ || d->Ho % BY || d->Wo % BX || d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return false;
+  if (d->Do % SZ || d->Ho % BY || d->Wo % BX || d->Di != d->Do || d->Hi != d->Ho || d->Wi != d->Wo) return false;
   for (int t = 0; t < 125; ++t)
     if (d->dd[t] < -2 || d->dd[t] > 2 || d->dh[t] < -2 || d->dh[t] > 2 || d->dw[t] < -2 || d->dw[t] > 2) return false;
-  const long long tiles = (long long)d->N * (d->Do / BZ) * (d->Ho / BY) * (d->Wo / BX);
-  if (tiles < gs_opt(GS_OPT_HCONV5) || tiles >= (1LL << 31)) return false;      // small volumes: hconv_kernel's 512-voxel boxes fill the chip
+  // voxels in units of 2048 (= the work of a CU-filling step pair): small volumes stay on hconv_kernel's 512-voxel boxes
+  const long long units = (long long)d->N * d->Do * d->Ho * d->Wo / 2048;
+  if (units < gs_opt(GS_OPT_HCONV5) || units >= (1LL << 31)) return false;
   if ((long long)d->Di * d->Hi * d->Wi * d->in_cs * 2 >= (1LL << 32)) return false;
   if ((long long)d->Do * d->Ho * d->Wo >= (1LL << 31)) return false;
   return true;
 }
 }  // namespace
 
-// partial-statistics slots per image when the layer runs here (one per 8 x 16 x 16 box), 0 when it does not
+// partial-statistics slots per image when the layer runs here (one per step of a column: 4 x 16 x 16 voxels), 0 when it does not
 int gs_hconv5_slots(const gs_gconv_desc* d) {
-  return hconv5_eligible(d) ? (d->Do / BZ) * (d->Ho / BY) * (d->Wo / BX) : 0;
+  return hconv5_eligible(d) ? (d->Do / SZ) * (d->Ho / BY) * (d->Wo / BX) : 0;
 }
 
 // returns 0 and sets *handled when the layer ran here
@@ -290,9 +390,7 @@ int gs_hconv5_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
   k.stats = stats;
   k.zero = static_cast<const char*>(gs_zero_page());
   GS_REQUIRE(k.zero, "gs_gconv_forward: library not initialised (call gs_init)");
-  k.nbd = d->Do / BZ; k.nbh = d->Ho / BY; k.nbw = d->Wo / BX;
-  k.ntiles = d->N * k.nbd * k.nbh * k.nbw;
-  k.d = *d;
+  k.nbh = d->Ho / BY; k.nbw = d->Wo / BX;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -300,9 +398,17 @@ int gs_hconv5_try(const gs_gconv_desc* d, const void* in, const void* w_pack, co
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
-  // persistent: equal shares of whole tiles (1024 tiles on 256 CUs: 4 each)
-  const int per = (k.ntiles + cus - 1) / cus;
-  const int grid = (k.ntiles + per - 1) / per;
+  // columns are cut into z segments until every CU has a workgroup (a segment re-reads 4 planes of z halo: keep them long)
+  const int columns = d->N * k.nbh * k.nbw, steps = d->Do / SZ;
+  int nseg = gs_opt(GS_OPT_HCONV5_SEG) > 0 ? gs_opt(GS_OPT_HCONV5_SEG) : (cus + columns - 1) / columns;
+  if (nseg > steps) nseg = steps;
+  if (nseg < 1) nseg = 1;
+  k.seg_steps = (steps + nseg - 1) / nseg;
+  k.nseg = (steps + k.seg_steps - 1) / k.seg_steps;
+  k.nwork = columns * k.nseg;
+  k.d = *d;
+  const int per = (k.nwork + cus - 1) / cus;               // persistent: equal shares of whole segments
+  const int grid = (k.nwork + per - 1) / per;
   constexpr int lds = HALO_BYTES + 512 + 4 * 16 * 2 * 4;
   static bool configured = false;
   if (!configured) {

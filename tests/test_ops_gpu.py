@@ -856,12 +856,15 @@ def test_gconv_accumulate_into_slice(hip_ops):
     close_bf16(outs[1], outs[0], "accumulated dgrad")
 
 
-@pytest.mark.parametrize("sizes", [(8, 16, 16), (16, 32, 48)], ids=lambda s: "x".join(map(str, s)))
-def test_register_resident_k5_kernel(hip_ops, sizes):
+@pytest.mark.parametrize("seg", [0, 1, 2], ids=["auto-segments", "one-segment", "two-segments"])
+@pytest.mark.parametrize("sizes", [(8, 16, 16), (36, 32, 48)], ids=lambda s: "x".join(map(str, s)))
+def test_register_resident_k5_kernel(hip_ops, sizes, seg):
     """hconv5.hip (the 16 -> 16 channel k5 volume convs of the V-Net couplings with the layer's weights in registers) against the
     oracle and against hconv_kernel: forward with bias / statistics / activation out of a channel slice of a 32-channel buffer,
-    and the data gradient accumulated into a slice; one box (all faces are borders) and 2 x 2 x 3 boxes; 2 images"""
+    and the data gradient accumulated into a slice; one column of two steps and 2 x 3 columns of nine steps (the ring of input
+    planes turns over twice; with two segments the second one is a step shorter); 2 images"""
     ops = hip_ops
+    ops.set_option("hconv5_seg", seg)
     spec, N = ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 2
     low, master, bias, fpack, dpack = make_layer(spec, sizes, 31)
     g = torch.Generator().manual_seed(32)
@@ -891,7 +894,8 @@ def test_register_resident_k5_kernel(hip_ops, sizes):
         torch.cuda.synchronize()
     finally:
         ops.set_option("hconv5", default)
-    assert slots5 == (sizes[0] // 8) * (sizes[1] // 16) * (sizes[2] // 16) and slots0 > slots5, (slots5, slots0)
+        ops.set_option("hconv5_seg", 0)
+    assert slots5 == (sizes[0] // 4) * (sizes[1] // 16) * (sizes[2] // 16) and slots0 != slots5, (slots5, slots0)
     close_bf16(y5, y_ref, "forward (hconv5)")
     close_bf16(y5, y0.cpu(), "forward, hconv5 vs hconv_kernel")
     close_f32(mr5, mr_ref, "mean / rstd (hconv5)", rel=1e-3)
