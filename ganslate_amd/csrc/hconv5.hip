@@ -75,17 +75,28 @@ __device__ __forceinline__ void unroll_seq(std::integer_sequence<int, I...>, F&&
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-// fragment f of a wave's walk through a step: x window dxi, input plane zp (0..7 = first output plane - 2 ..), kind / row
-constexpr int FR_PER_PLANE = (LY + 2) + LY;      // 6 paired fragments (y' = -2 .. LY-1) + 4 single ones (y' = 2 .. LY+1)
-constexpr int NFRAG = 5 * (LZ + 4) * FR_PER_PLANE;
-struct FragId { int dxi, zp, single, yp; };
-// (plane index fastest: the planes at the ends of a step's window feed one or two output planes, the middle ones four — walking a
-// whole plane at a time left the fragment prefetch a few MFMAs ahead on the light planes, far less than the LDS latency)
+// Fragments of a wave's walk through a step, per x window: K = 32 of an MFMA is two taps x 16 channels, and the 25 (dz, dy) taps
+// of an x offset pair up into 13 units (96 % of the K slots used; 15 units with y pairs only):
+//   kind P  rows (z', y') | (z', y'+1):  units (dz, dy pair) for dy in (-2,-1), (0,+1)        10 units, 48 fragments
+//   kind Z  rows (z', y') | (z'+1, y'):  the dy = +2 taps paired along z, dz in (-2,-1), (0,+1)   2 units, 24 fragments
+//   kind S  row  (z', y') twice:         the tap (dz, dy) = (+2, +2) (partner weights zero)        1 unit,  16 fragments
+// zp = input plane (0..7 = first output plane - 2 ..), yp = input row relative to the wave's first output row. Heavy (P) and
+// light (Z, S: one or two MFMAs) fragments alternate, P fragments with the plane index fastest: any 8 consecutive fragments carry
+// >= 16 MFMAs, which keeps the fragment prefetch (NRING - 1 reads ahead) beyond the LDS latency.
+struct FragId { int dxi, kind, zp, yp; };
+constexpr int NP = (LZ + 4) * (LY + 2), NZ = (LZ + 2) * LY, NS = LZ * LY, FR_PER_DX = NP + NZ + NS;   // 48 + 24 + 16
+constexpr int NFRAG = 5 * FR_PER_DX;
 constexpr FragId frag_of(int f) {
-  const int zp = f % (LZ + 4), r = f / (LZ + 4);
-  const int k = r % FR_PER_PLANE;
-  return FragId{r / FR_PER_PLANE, zp, k >= LY + 2 ? 1 : 0, k >= LY + 2 ? (k - (LY + 2)) + 2 : k - 2};
+  const int dxi = f / FR_PER_DX, r = f % FR_PER_DX;
+  constexpr int NL = NZ + NS;                      // light fragments: after each of the first NL heavy ones
+  int heavy = r - NL, light = 0;
+  bool is_light = false;
+  if (r < 2 * NL) { heavy = r / 2; light = r / 2; is_light = r & 1; }
+  if (!is_light) return FragId{dxi, 0, heavy % (LZ + 4), heavy / (LZ + 4) - 2};
+  if (light < NZ) return FragId{dxi, 1, light % (LZ + 2), light / (LZ + 2) + 2};
+  return FragId{dxi, 2, (light - NZ) % LZ + 4, (light - NZ) / LZ + 2};
 }
+constexpr int NUNIT = 13 * 5;                      // A fragments
 
 __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,37 +114,38 @@ __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
     lut[((int)d.dd[t] + 2) * 25 + ((int)d.dh[t] + 2) * 5 + ((int)d.dw[t] + 2)] = t;
   __syncthreads();
 
-  // ---- the layer's weights: 75 A fragments, lane (row co = col, k group kg): tap member kg >> 1 of the pair, channels
-  // (kg & 1) * 8 .. + 8 of pack row co (tap-major K: t * Ci + ci). All tap lookups first, then the 75 loads back to back. ---------
-  bf16x8 A[5][3][5];                               // [dz][dy pair][dx]
+  // ---- the layer's weights: 65 A fragments, lane (row co = col, k group kg): tap member kg >> 1 of the pair, channels
+  // (kg & 1) * 8 .. + 8 of pack row co (tap-major K: t * Ci + ci). All tap lookups first, then the loads back to back. -----------
+  bf16x8 A[13][5];                                 // [unit][dx]: units 0-9 = P (dz * 2 + dy pair), 10-11 = Z (dz pair), 12 = S
   {
     const bool row_ok = col < d.w_rows;
     const char* wrow = p.w + ((size_t)col * d.Kp + (kg & 1) * 8) * 2;
-    int tt[5][3][5];
+    const int m = kg >> 1;                         // member of the tap pair this lane's k group belongs to
+    int tt[13][5];
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int u = 0; u < 13; ++u)
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-          const int dy = b * 2 + (kg >> 1);        // 0..5 (5: the missing partner of dy = +2)
-          tt[a][b][c] = dy < 5 ? lut[a * 25 + dy * 5 + c] : -1;
-        }
-    // (two batches with a wait behind each: vmcnt counts to 63 — with all 75 loads and the first planes' 40 staging instructions
+      for (int c = 0; c < 5; ++c) {
+        int dzi, dyi;                              // tap (dz + 2, dy + 2) of this lane's member; dzi = -1: none (zero weights)
+        if (u < 10) { dzi = u >> 1; dyi = (u & 1) * 2 + m; }
+        else if (u < 12) { dzi = (u - 10) * 2 + m; dyi = 4; }
+        else { dzi = m ? -1 : 4; dyi = 4; }
+        tt[u][c] = dzi >= 0 ? lut[dzi * 25 + dyi * 5 + c] : -1;
+      }
+    // (two batches with a wait behind each: vmcnt counts to 63 — with all the loads and the first planes' 40 staging instructions
     // in flight the counter wrapped and the first step's vmcnt(0) let the MFMAs start on weights that had not arrived)
 #pragma unroll
-    for (int a = 0; a < 5; ++a) {
+    for (int u = 0; u < 13; ++u) {
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-          const int t = tt[a][b][c];
-          const char* src = (row_ok && t >= 0) ? wrow + (size_t)t * d.Ci * 2 : p.zero;
-          A[a][b][c] = *reinterpret_cast<const bf16x8*>(src);
-        }
-      if (a == 2 || a == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int c = 0; c < 5; ++c) {
+        const int t = tt[u][c];
+        const char* src = (row_ok && t >= 0) ? wrow + (size_t)t * d.Ci * 2 : p.zero;
+        A[u][c] = *reinterpret_cast<const bf16x8*>(src);
+      }
+      if (u == 6 || u == 12) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
+
   // per-lane byte offset of a fragment read inside a plane: voxel column col (+ window), channel half kg & 1, row of the wave's
   // quarter (+ the partner row for kg >= 2 of a paired fragment)
   const unsigned halo0 = lds_addr(halo);
@@ -206,9 +218,12 @@ __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { npoff[k] = plane_off(4 * step + 8 + k); nslot[k] = (4 * step + 8 + k) % NSLOT; }
       // plane bases of this step: input plane zp of the step sits in slot (4 * step + zp) % NSLOT
-      unsigned pbase[LZ + 4];
+      unsigned pbase[LZ + 4], zbase[LZ + 2];        // zbase: plane zp for the pair's first member, zp + 1 for its second (k groups 2, 3)
 #pragma unroll
       for (int zp = 0; zp < LZ + 4; ++zp) pbase[zp] = halo0 + (unsigned)(((4 * step + zp) % NSLOT) * PLANEB);
+#pragma unroll
+      for (int zp = 0; zp < LZ + 2; ++zp)           // (arithmetic select: `cond ? pbase[zp + 1] : pbase[zp]` became an indexed scratch array)
+        zbase[zp] = pbase[zp] + (unsigned)(kg >> 1) * (pbase[zp + 1] - pbase[zp]);
 
       f32x4 acc[LZ][LY];
 #pragma unroll
@@ -228,7 +243,9 @@ __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
           constexpr FragId id = frag_of(f);
           // row yp + 2 of the wave's quarter (halo coordinates), x window dxi
           constexpr int off = (id.yp + 2) * ROWB + id.dxi * VP;
-          lds_read128<off>(ring[f % NRING], pbase[id.zp] + (id.single ? lane_single : lane_pair));
+          if constexpr (id.kind == 0) lds_read128<off>(ring[f % NRING], pbase[id.zp] + lane_pair);
+          else if constexpr (id.kind == 1) lds_read128<off>(ring[f % NRING], zbase[id.zp] + lane_single);
+          else lds_read128<off>(ring[f % NRING], pbase[id.zp] + lane_single);
         }
       };
       unroll_seq(std::make_integer_sequence<int, NRING - 1>{}, issue);
@@ -243,21 +260,26 @@ __global__ __launch_bounds__(256) void hconv5_kernel(const HConv5K p) {
         // fragments are consumed in issue order: at most NRING - 1 younger reads may still be in flight
         constexpr int younger = (NFRAG - 1 - f) < (NRING - 1) ? (NFRAG - 1 - f) : (NRING - 1);
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % NRING]) : "i"(younger) : "memory");
-        constexpr int zi = id.zp - 2;                // input plane relative to the step's first output plane
-        unroll_seq(std::make_integer_sequence<int, 5>{}, [&](auto a_tag) {      // dz = a - 2: output plane zi - dz
-          constexpr int a = decltype(a_tag)::value;
-          constexpr int zr = zi - (a - 2);
-          if constexpr (zr >= 0 && zr < LZ) {
-            if constexpr (id.single) {               // dy0 = +2: output row yp - 2
-              mfma_u<(a * 3 + 2) * 5 + id.dxi>(acc[zr][id.yp - 2], A[a][2][id.dxi], ring[f % NRING]);
-            } else {
-              if constexpr (id.yp + 2 >= 0 && id.yp + 2 < LY)    // dy0 = -2: output row yp + 2
-                mfma_u<(a * 3 + 0) * 5 + id.dxi>(acc[zr][id.yp + 2], A[a][0][id.dxi], ring[f % NRING]);
-              if constexpr (id.yp >= 0 && id.yp < LY)            // dy0 = 0: output row yp
-                mfma_u<(a * 3 + 1) * 5 + id.dxi>(acc[zr][id.yp], A[a][1][id.dxi], ring[f % NRING]);
+        if constexpr (id.kind == 0) {
+          constexpr int zi = id.zp - 2;              // input plane relative to the step's first output plane
+          unroll_seq(std::make_integer_sequence<int, 5>{}, [&](auto a_tag) {      // dz = a - 2: output plane zi - dz
+            constexpr int a = decltype(a_tag)::value;
+            constexpr int zr = zi - (a - 2);
+            if constexpr (zr >= 0 && zr < LZ) {
+              if constexpr (id.yp + 2 >= 0 && id.yp + 2 < LY)    // dy pair (-2, -1): output row yp + 2
+                mfma_u<(a * 2 + 0) * 5 + id.dxi>(acc[zr][id.yp + 2], A[a * 2 + 0][id.dxi], ring[f % NRING]);
+              if constexpr (id.yp >= 0 && id.yp < LY)            // dy pair (0, +1): output row yp
+                mfma_u<(a * 2 + 1) * 5 + id.dxi>(acc[zr][id.yp], A[a * 2 + 1][id.dxi], ring[f % NRING]);
             }
-          }
-        });
+          });
+        } else if constexpr (id.kind == 1) {         // dy = +2, planes (zp, zp + 1): output row yp - 2 of plane zp (dz pair -2, -1)
+          if constexpr (id.zp < LZ)                  // ... and of plane zp - 2 (dz pair 0, +1)
+            mfma_u<10 * 5 + id.dxi>(acc[id.zp][id.yp - 2], A[10][id.dxi], ring[f % NRING]);
+          if constexpr (id.zp >= 2)
+            mfma_u<11 * 5 + id.dxi>(acc[id.zp - 2][id.yp - 2], A[11][id.dxi], ring[f % NRING]);
+        } else {                                     // (dz, dy) = (+2, +2): output plane zp - 4, row yp - 2
+          mfma_u<12 * 5 + id.dxi>(acc[id.zp - 4][id.yp - 2], A[12][id.dxi], ring[f % NRING]);
+        }
       });
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMA's result is architecturally visible to VALU
 

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(1024) void hconvw_kernel(const HConvWK p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial sums are on their way out of the CU ...
         lds_barrier();                                        // ... and so are everybody's
-        if (tid == 0 && (p.dbg & 16)) {                        // debug: arrival time of this tile (tools/probe/e8_ring_skew.py)
+        if (tid == 0 && (p.dbg & 16)) {                        // debug: arrival time of this tile (tools/probe/archive/e8_ring_skew.py)
           const unsigned long long t = __builtin_amdgcn_s_memrealtime();      // (100 MHz, one clock for all XCDs)
           const int tile = (n * p.tiles_m + mt) * p.tiles_n + nt;
           p.sync[256 + 2 * tile] = (int)(t & 0xffffffffu);

@@ -292,3 +292,96 @@ def test_attention_parameters_are_reduced_after_their_backward(tmp_path):
         assert (ref[x0:] - r0["grad"][x0:]).abs().max().item() <= 1e-5 * tail, "attention parameter gradients were not summed"
     finally:
         backend.set_ops(None)
+
+
+# ---- four ranks: odd bucket splits, CUT + mlp, sampler shards ------------------------------------------------
+def _worker4(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), GANSLATE_DIST_BACKEND="gloo")
+    torch.set_num_threads(1)
+    from ganslate_amd.utils import communication
+    from ganslate_amd.data.samplers import InfiniteSampler
+    import itertools
+    communication.init_distributed()
+    # sampler: every rank walks the same seed-shared permutation, strided by rank (samplers.py:20-58)
+    sampler = InfiniteSampler(10, shuffle=True)
+    shard = [int(i) for i in itertools.islice(iter(sampler), 15)]
+    model = _build(1, seed=5 + rank)       # different init per rank: parallelize() must broadcast rank 0's weights
+    # re-bucket with a small, odd bucket size: many buckets of uneven length, the last one a remainder
+    for net in model.networks.values():
+        net.parallelize(bucket_bytes=(3 << 10) + 4)
+    nb = {n: len(net._buckets) for n, net in model.networks.items()}
+    A, B = _inputs(world)
+    model.set_input({"A": A[rank:rank + 1], "B": B[rank:rank + 1]})
+    model.forward()
+    model.set_requires_grad([model.networks["D_B"], model.networks["D_A"]], False)
+    model.backward_G()
+    grads = {}
+    for name in ("G_AB", "G_BA"):
+        net = model.networks[name]
+        fired_async = len(net._reduce_handles) > 0
+        scale = net.finish_grad_reduction()
+        grads[name] = (net.master.grad.clone() * scale, fired_async)
+    model.optimizers["G"].zero_grad()
+    for _ in range(2):
+        model.optimize_parameters()
+    weights = {n: net.master.detach().clone() for n, net in model.networks.items()}
+    torch.save({"grads": grads, "weights": weights, "shard": shard, "seed": sampler._seed, "buckets": nb},
+               Path(out_dir) / f"w4_rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_odd_buckets_gradient_and_sampler_shards(tmp_path):
+    """4 ranks x batch 1 = the single-process gradient on the concatenated batch of 4 (1/world folded in by
+    finish_grad_reduction), with ~3 KiB buckets (dozens per generator, uneven, a remainder bucket); weights identical on all
+    ranks after two steps; the sampler's shards share the seed, are disjoint within an epoch and together cover it"""
+    world = 4
+    port = _free_port()
+    mp.spawn(_worker4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"w4_rank{r}.pt") for r in range(world)]
+    assert rs[0]["buckets"]["G_AB"] > 8, rs[0]["buckets"]
+    for r in rs[1:]:
+        assert r["seed"] == rs[0]["seed"]
+        for name in rs[0]["weights"]:
+            assert torch.equal(rs[0]["weights"][name], r["weights"][name]), f"{name}: ranks diverged"
+        for name in ("G_AB", "G_BA"):
+            assert torch.equal(rs[0]["grads"][name][0], r["grads"][name][0])
+    assert all(r["grads"]["G_AB"][1] for r in rs), "bucketed all-reduce did not start during the last backward pass"
+    # shards: position k of rank r is element r + 4k of the shared stream — the first 40 stream elements are 4 epochs of 10
+    stream = [None] * 60
+    for r, res in enumerate(rs):
+        for k, idx in enumerate(res["shard"]):
+            stream[r + 4 * k] = idx
+    for e in range(6):
+        assert sorted(stream[10 * e:10 * e + 10]) == list(range(10)), (e, stream)
+    os.environ.pop("WORLD_SIZE", None)
+    from ganslate_amd.nn.native import backend
+    single = _build(4, seed=5)
+    A, B = _inputs(4)
+    single.set_input({"A": A, "B": B})
+    single.forward()
+    single.set_requires_grad([single.networks["D_B"], single.networks["D_A"]], False)
+    single.backward_G()
+    try:
+        for name in ("G_AB", "G_BA"):
+            ref = single.networks[name].master.grad
+            got = rs[0]["grads"][name][0]
+            scale = ref.abs().max().item()
+            assert (ref - got).abs().max().item() <= 1e-4 * scale, name
+    finally:
+        backend.set_ops(None)
+
+
+@pytest.mark.timeout(900)
+def test_cut_four_ranks_stay_in_sync(tmp_path):
+    """CUT (generator, discriminator, patch mlp) on four ranks: identical weights on every rank after two steps"""
+    world = 4
+    port = _free_port()
+    mp.spawn(_cut_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"cut_rank{r}.pt") for r in range(world)]
+    for r in rs[1:]:
+        for name in rs[0]:
+            assert torch.equal(rs[0][name], r[name]), f"{name}: ranks diverged"

@@ -173,3 +173,41 @@ def test_adam_dev_matches_host_scalars(hip_ops):
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), "device-scalar Adam must be bit-identical"
     assert (res[1][0] - res[2][0]).abs().max().item() <= 1e-6 * res[2][0].abs().max().item()
     assert res[1][3].abs().max().item() == 0.0
+
+
+def test_gradient_accumulation_between_replays(hip_ops):
+    """`dw_fresh` (gs_wgrad_desc: the first weight gradient of a layer since the optimiser cleared the buffer STORES instead of
+    adding) is a contract carried by host bookkeeping (NativeNet.wgrad_fresh) and baked into captured graphs. Between two replays
+    a user recipe may accumulate: two eager backward passes WITHOUT an optimiser step in between must leave exactly g + g in
+    the flat gradients (a stale `fresh = True` would leave g), and the replays around them must be unaffected."""
+    c = dict(load_golden_steps()["c64_default"]["config"])
+    c["pool_size"] = 0
+    frozen = ("train.gan.optimizer.lr_G=0.0", "train.gan.optimizer.lr_D=0.0")
+    model = build_product_cyclegan(c, frozen)
+    before = _run(model, c, 4)                      # iterations 2.. are replays
+    assert model._graph is not None
+    A, B = golden_inputs(c, 0)
+    Ds = [model.networks["D_B"], model.networks["D_A"]]
+
+    def eager_backward_G(times):
+        model._eager_set_input({"A": A, "B": B})
+        model.set_requires_grad(Ds, False)
+        model.optimizers["G"].zero_grad(set_to_none=True)
+        for _ in range(times):
+            model.forward()
+            model.backward_G()
+        for net in (model.networks["G_AB"], model.networks["G_BA"]):
+            net.flush_deferred_wgrads()
+        torch.cuda.synchronize()
+        return [model.networks[n].master.grad.clone() for n in ("G_AB", "G_BA")]
+    g1 = eager_backward_G(1)
+    g2 = eager_backward_G(2)
+    for a, b in zip(g1, g2):
+        assert a.abs().max().item() > 0.0
+        # every kernel either stores g into zeros and then adds g, or reduces slabs in a fixed order: g + g is exact
+        assert torch.equal(b, a + a), (b - 2 * a).abs().max().item()
+    model.set_requires_grad(Ds, True)
+    after = _run(model, c, 4)                       # replays again (weights frozen: the same losses as before, step for step)
+    for s in range(2, 4):
+        for k, v in before[s][0].items():
+            assert after[s][0][k] == pytest.approx(v, rel=1e-5, abs=1e-7), (s, k)
