@@ -85,7 +85,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"splitk_ring", 1},         // gconv.hip: split-K launches of the 128 x 128 tile run a 4-stage ring (three K-steps of cold weights in flight)
     {"gconv_ring4", 16},        // gconv.hip: 128-pixel im2col tiles in a grid of <= 2 workgroups per CU with at least this many K-steps run a 4-stage ring; 0 = off
     {"ring_dbg", 0},            // hconvw.hip RING: timing ablations (wrong results): 1 no ring MFMAs, 2 no y / g2 loads, 4 no sums, 8 no ring adds
-    {"hconv5", 256},            // hconv5.hip: register-resident-weights kernel for the 16 -> 16 channel k5 volume convs; smallest volume
+    {"hconv5", 64},             // hconv5.hip: register-resident-weights kernel for the 16 -> 16 channel k5 volume convs; smallest volume
                                 // (batch x voxels / 2048) it takes (0 = off)
     {"hconv5_seg", 0},          // ... z segments per column (0 = as many as fill the chip; tests force long segments with 1 / 2)
 };

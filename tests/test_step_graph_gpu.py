@@ -204,8 +204,10 @@ def test_gradient_accumulation_between_replays(hip_ops):
     g2 = eager_backward_G(2)
     for a, b in zip(g1, g2):
         assert a.abs().max().item() > 0.0
-        # every kernel either stores g into zeros and then adds g, or reduces slabs in a fixed order: g + g is exact
-        assert torch.equal(b, a + a), (b - 2 * a).abs().max().item()
+        # g + g up to the summation order (two passes' operands may share one merged weight-gradient launch); a stale
+        # `fresh` would leave g, i.e. an error of |g|
+        scale = a.abs().max().item()
+        assert (b - 2 * a).abs().max().item() <= 1e-4 * scale, ((b - 2 * a).abs().max().item(), scale)
     model.set_requires_grad(Ds, True)
     after = _run(model, c, 4)                       # replays again (weights frozen: the same losses as before, step for step)
     for s in range(2, 4):

@@ -32,6 +32,7 @@ CASES = {
     # 3-D: Resnet3D residual conv at 128^3 / 4, Vnet3D coupling convs (halo-resident kernel)
     "rb3": (ConvSpec("conv", 256, 256, 3, 1, 1, pad_mode="replicate", dims=3), 1, 32, 32, 32),
     "v16": (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 128, 128, 128),
+    "v16s": (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 64, 64, 64),
     "v32": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 64, 64, 64),
     "v64": (ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, 32, 32, 32),
 }
