@@ -652,6 +652,9 @@ class HipOps(TwinSplit):
 
     def pnorm_forward(self, y, mean_rstd, out, *, C, slope=None, res=None, res_mode=0, res_mod=0, y_co=0, res_co=0,
                       out_co=0):
+        if is_twin(slope):
+            return self.twin_pnorm_forward(y, mean_rstd, out, C=C, slope=slope, res=res, res_mode=res_mode, res_mod=res_mod,
+                                           y_co=y_co, res_co=res_co, out_co=out_co)
         d = self._pdesc(y, C, y_co, res, res_mode, res_mod, res_co)
         d.out_cs, d.out_co = out.shape[-1], out_co
         L.check(self.lib.gs_pnorm_forward(L.C.byref(d), _ptr(y), _ptr(mean_rstd), _ptr(res), _ptr(slope), _ptr(out),
@@ -659,6 +662,10 @@ class HipOps(TwinSplit):
 
     def pnorm_backward(self, g, y, mean_rstd, dy, *, C, slope=None, dslope=None, g2=None, res=None, res_mode=0,
                        res_mod=0, gres=None, bias_grad=None, g_co=0, g2_co=0, y_co=0, res_co=0, dy_co=0, gres_co=0):
+        if is_twin(slope, dslope, bias_grad):
+            return self.twin_pnorm_backward(g, y, mean_rstd, dy, C=C, slope=slope, dslope=dslope, g2=g2, res=res,
+                                            res_mode=res_mode, res_mod=res_mod, gres=gres, bias_grad=bias_grad, g_co=g_co,
+                                            g2_co=g2_co, y_co=y_co, res_co=res_co, dy_co=dy_co, gres_co=gres_co)
         d = self._pdesc(y, C, y_co, res, res_mode, res_mod, res_co)
         d.g_cs, d.g_co = g.shape[-1], g_co
         if g2 is not None:

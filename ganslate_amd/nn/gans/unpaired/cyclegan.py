@@ -55,8 +55,10 @@ class CycleGAN(BaseGAN):
         """The two generators (and the two discriminators) have the same layer list and see independent data: each pair
         runs lock-step as ONE batch of 2N images with per-image-range weights (nn/native/twin.py) — half the launches, and
         512 instead of 256 tiles per residual-conv launch. GS_TWIN=0 keeps the two passes apart (second cycle on its own
-        stream); GS_TWIN=2d does so for volumes only (their launches fill the chip already: twin passes are worth +2.9 % on
-        the Resnet3D recipe, nothing on the V-Net one, whose generators run on their own executor)."""
+        stream); GS_TWIN=2d does so for volumes only. Volumes: twin passes are worth +2.9 % on the Resnet3D recipe; the V-Net
+        executor runs them too since round 6 (Vnet3D._forward(..., tw)) but LOSES 2.2 % on the brats recipe (its launches fill
+        the chip at batch 1 and the per-network PReLU-norm launches stay halves: profiles/r06_ab_vnet_twin.txt) — executors
+        that set twin_default = False pair up only with GS_TWIN=all."""
         self.twin_G = self.twin_D = None
         for name in ("G_AB", "G_BA"):      # (GS_WGRAD_STREAM=1: their weight gradients beside the data-gradient chain, net.py)
             if name in self.networks and self.networks[name] is not None:
@@ -64,7 +66,8 @@ class CycleGAN(BaseGAN):
         mode = os.environ.get("GS_TWIN", "1")
         if not self.is_train or mode == "0":
             return
-        ok = lambda a, b: TwinNet.compatible(a, b) and (a.dims == 2 or mode != "2d")
+        ok = lambda a, b: TwinNet.compatible(a, b) and (a.dims == 2 or mode != "2d") and \
+            (getattr(a, "twin_default", True) or mode == "all")
         if ok(self.networks["G_AB"], self.networks["G_BA"]):
             self.twin_G = TwinNet(self.networks["G_AB"], self.networks["G_BA"])
         if ok(self.networks["D_B"], self.networks["D_A"]):

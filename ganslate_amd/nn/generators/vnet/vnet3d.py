@@ -34,6 +34,7 @@ import torch
 
 from .... import configs
 from ...native.net import Extra, NativeNet, Node, attention_extras
+from ...native.twin import Twin
 from ...native.spec import ConvSpec, lower
 from ...utils import is_bias_before_norm, require_instance_norm
 
@@ -67,6 +68,11 @@ class _Block:
 
 class Vnet3D(NativeNet):
     dims = 3
+    twin_extras_ok = True        # TwinNet: the PReLU slopes (extras) are handled per network (see _tw below)
+    twin_default = False         # ... but recipes pair V-Nets only on request (GS_TWIN=all): measured slower on the brats recipe
+    _tw = None                   # the second network of a twin pass while that pass is being launched: every per-network
+                                 # tensor (master, packs, gradient buffer, slopes) is then a Twin and the batch holds both
+                                 # networks' images, first this network's (nn/native/twin.py)
 
     def __init__(self, in_channels, out_channels, norm_type, first_layer_channels=16, down_blocks=(1, 2, 3, 2),
                  up_blocks=(2, 2, 1, 1), use_memory_saving=True, use_inverse=True, is_separable=False, attention=()):
@@ -219,9 +225,10 @@ class Vnet3D(NativeNet):
     def _conv(self, s, i, x, in_co=0, stats=True, out=None):
         """raw output of node i (+ mean/rstd of its InstanceNorm) reading channels [in_co, in_co + cin) of x"""
         ops, sp, lw, N = self.ops, self.nodes[i].spec, s.lows[i], s.N
-        m = self.master.detach()
+        tw = self._tw
+        m = self.master.detach() if tw is None else Twin(self.master.detach(), tw.master.detach())
         bias = m[self.b_off[i]:self.b_off[i] + sp.cout_p]
-        fpack = s.pk["fpack"][s.pk["f_off"][i]:]
+        fpack = (s.pk["fpack"] if tw is None else Twin(s.pk["fpack"], s.pk_tw["fpack"]))[s.pk["f_off"][i]:]
         y = out if out is not None else self._new(N, lw.out_dims, sp.cout_p)
         if not stats:
             ops.gconv_classes(lw.fwd, x, fpack, bias, y, in_co=in_co)
@@ -229,7 +236,7 @@ class Vnet3D(NativeNet):
         slots, offs = 0, []
         for g in lw.fwd:
             offs.append(slots)
-            slots += ops.stat_slots(g, N)
+            slots += ops.stat_slots(g, N, twin=tw is not None, multi=lw.fwd if len(lw.fwd) > 1 else None)
         part = torch.empty(N * slots * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
         ops.gconv_classes(lw.fwd, x, fpack, bias, y, in_co=in_co, stats=part, stats_slots=slots, stats_slot0s=offs)
         mr = torch.empty(N * 2 * sp.cout_p, dtype=torch.float32, device=self.device)
@@ -237,7 +244,11 @@ class Vnet3D(NativeNet):
         return y, mr
 
     def _slope(self, name, grad=False):
-        return self.extra(name, grad=grad)
+        t = self.extra(name, grad=grad)
+        return t if self._tw is None else Twin(t, self._tw.extra(name, grad=grad))
+
+    def _grad_buf(self):
+        return self.master.grad if self._tw is None else Twin(self.master.grad, self._tw.master.grad)
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def _couplings_forward(self, s, blk, X):
@@ -293,11 +304,24 @@ class Vnet3D(NativeNet):
 
     __call__ = forward
 
-    def _forward(self, x, save, stop=None):
+    def _forward(self, x, save, stop=None, tw=None):
+        """tw: a second Vnet3D of identical architecture (TwinNet) — x is then ((this network's batches), (tw's batches)) and
+        the pass runs as ONE batch, this network's images first"""
         assert stop is None, "feature taps are not implemented for Vnet3D"
+        self._tw = tw
+        try:
+            return self._forward_impl(x, save)
+        finally:
+            self._tw = None
+
+    def _forward_impl(self, x, save):
         ops, c, L = self.ops, self.c, self.L
-        N, sizes = x.shape[0], tuple(x.shape[2:])
+        tw = self._tw
+        xs = (tuple(x[0]) + tuple(x[1])) if tw is not None else (x,)
+        N, sizes = sum(t.shape[0] for t in xs), tuple(xs[0].shape[2:])
         s = _Saved()
+        s.tw = tw
+        assert tw is None or not getattr(self, "_next_inverse", False), "twin passes run A -> B"
         inv = s.inverse = bool(getattr(self, "_next_inverse", False))
         s.recompute = bool(save and self.use_memory_saving)
         n_in, s_in = (self.n_in_ba, self.s_in_ba) if inv else (self.n_in, self.s_in)
@@ -306,9 +330,14 @@ class Vnet3D(NativeNet):
         core = self._couplings_inverse if inv else self._couplings_forward
         s.x_img, s.N, s.sizes = x, N, sizes
         s.lows, s.pk = self._lowered(*sizes), self._get_packs(*sizes)
+        s.pk_tw = tw._get_packs(*sizes) if tw is not None else None
         lv = lambda k: tuple(v >> k for v in sizes)
         a0 = self._new(N, sizes, self.nodes[0].spec.cin_p)
-        ops.image_to_act(x, a0)
+        n0 = 0
+        for xh in xs:
+            ops.image_to_act(xh, a0[n0:n0 + xh.shape[0]])
+            n0 += xh.shape[0]
+        s.xs = xs
         s.a0 = a0
         # InputBlock
         s.y_in, s.mr_in = self._conv(s, n_in, a0)
@@ -365,23 +394,25 @@ class Vnet3D(NativeNet):
     # ---- backward ----------------------------------------------------------------------------------------------------
     def _wgrad(self, s, i, x_in, dy, x_co=0):
         """parameter gradients of node i: dense side / gathered side by layer kind; x_in may be a channel slice"""
-        ops, sp, lw, grad = self.ops, self.nodes[i].spec, s.lows[i], self.master.grad
+        ops, sp, lw, grad = self.ops, self.nodes[i].spec, s.lows[i], self._grad_buf()
         dw = grad[self.w_off[i]:self.w_off[i] + sp.master_numel]
-        self._wgrad_written(i)      # (every weight-gradient launch is noted, NativeNet._wgrad_written; no fresh= hint is taken here)
+        self._wgrad_written(i, self._tw)    # (every weight-gradient launch is noted, NativeNet._wgrad_written; no fresh= hint here)
         if sp.kind == "conv":
             ops.wgrad(lw.wgrad, dy, x_in, dw, g_co=x_co)
         else:
             ops.wgrad(lw.wgrad, x_in, dy, dw, a_co=x_co)
         self.grad_dirty = True
+        if self._tw is not None:
+            self._tw.grad_dirty = True
 
     def _bias_slice(self, i, want_w):
         sp = self.nodes[i].spec
-        return self.master.grad[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
+        return self._grad_buf()[self.b_off[i]:self.b_off[i] + sp.cout_p] if (want_w and sp.bias) else None
 
     def _dgrad(self, s, i, dy, out=None, out_co=0, accumulate=False):
         sp, lw = self.nodes[i].spec, s.lows[i]
         gx = out if out is not None else self._new(s.N, lw.in_dims, sp.cin_p)
-        dpack = s.pk["dpack"][s.pk["d_off"][i]:]
+        dpack = (s.pk["dpack"] if self._tw is None else Twin(s.pk["dpack"], s.pk_tw["dpack"]))[s.pk["d_off"][i]:]
         self.ops.gconv_classes(lw.dgrad, dy, dpack, None, gx, out_co=out_co, accumulate=accumulate)
         return gx
 
@@ -444,12 +475,23 @@ class Vnet3D(NativeNet):
         ops.add_views(G, gu, blk.C, accumulate=True)     # out = core(D0) + D0
         return G
 
-    def _backward(self, s, g_img, need_input_grad, want_w, start=None, inj_x=None, inj_y=None):
+    def _backward(self, s, g_img, need_input_grad, want_w, start=None, inj_x=None, inj_y=None, tw=None):
+        """tw: the pass recorded by _forward(..., tw) — g_img holds one gradient per input batch (None: that output took no part
+        in the loss) and the input gradients come back as a tuple"""
         assert start is None and not inj_x and not inj_y, "feature taps are not implemented for Vnet3D"
+        assert tw is s.tw, "twin pass: backward with the partner the forward pass ran with"
+        self._tw = tw
+        try:
+            return self._backward_impl(s, g_img, need_input_grad, want_w)
+        finally:
+            self._tw = None
+
+    def _backward_impl(self, s, g_img, need_input_grad, want_w):
         ops, c, L, N = self.ops, self.c, self.L, s.N
-        if self.master.grad is None:
-            self.master.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
-        grad = self.master.grad
+        for net in (self, self._tw):
+            if net is not None and net.master.grad is None:
+                net.master.grad = torch.zeros(net.numel, dtype=torch.float32, device=self.device)
+        grad = self._grad_buf()
         dsl = (lambda name: self._slope(name, grad=True)) if want_w else (lambda name: None)
         inv = s.inverse
         n_in, s_in = (self.n_in_ba, self.s_in_ba) if inv else (self.n_in, self.s_in)
@@ -457,7 +499,17 @@ class Vnet3D(NativeNet):
         bconv = (lambda b: (b.conv_ba, b.conv_slope_ba)) if inv else (lambda b: (b.conv, b.conv_slope))
         # OutBlock
         gz = torch.empty_like(s.z)
-        ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, gz, act="tanh")
+        if self._tw is None:
+            ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, gz, act="tanh")
+        else:
+            n0 = 0
+            for gh, xh in zip(g_img, s.xs):      # one gradient per input batch
+                n1 = n0 + xh.shape[0]
+                if gh is None:
+                    gz[n0:n1].zero_()
+                else:
+                    ops.act_to_image_backward(gh.contiguous().float(), s.out_img[n0:n1], gz[n0:n1], act="tanh")
+                n0 = n1
         if want_w:
             self._wgrad(s, n_o2, s.t, gz)
             sp = self.nodes[n_o2].spec
@@ -520,10 +572,20 @@ class Vnet3D(NativeNet):
         if not need_input_grad:
             return None
         gx = self._dgrad(s, n_in, dy)
-        g_in = torch.empty_like(s.x_img)
-        ops.image_to_act_backward(gx, g_in, fold=0)
-        ops.repeat_backward(gres, g_in, c)               # adjoint of x.repeat (vnet3d.py:165-166)
-        return g_in
+        if self._tw is None:
+            g_in = torch.empty_like(s.x_img)
+            ops.image_to_act_backward(gx, g_in, fold=0)
+            ops.repeat_backward(gres, g_in, c)               # adjoint of x.repeat (vnet3d.py:165-166)
+            return g_in
+        g_ins, n0 = [], 0
+        for xh in s.xs:
+            n1 = n0 + xh.shape[0]
+            g_in = torch.empty_like(xh)
+            ops.image_to_act_backward(gx[n0:n1], g_in, fold=0)
+            ops.repeat_backward(gres[n0:n1], g_in, c)
+            g_ins.append(g_in)
+            n0 = n1
+        return tuple(g_ins)
 
 
 @dataclass

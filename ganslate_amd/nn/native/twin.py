@@ -99,6 +99,19 @@ class TwinSplit:
     def twin_shiftadd_to_image(self, z, bias, img, k, act="none"):
         self.run_halves(lambda h: self.shiftadd_to_image(bhalf(z, h), pick(bias, h), bhalf(img, h), k, act=act))
 
+    # InstanceNorm + PReLU of the V-Nets: the slopes (and their gradients, and the bias gradient of the conv in front) are
+    # per network — the two halves of the batch as two launches, every batched operand sliced alike
+    def twin_pnorm_forward(self, y, mean_rstd, out, *, C, slope=None, res=None, **kw):
+        self.run_halves(lambda h: self.pnorm_forward(bhalf(y, h), fhalf(mean_rstd, h), bhalf(out, h), C=C, slope=pick(slope, h),
+                                                     res=bhalf(res, h), **kw))
+
+    def twin_pnorm_backward(self, g, y, mean_rstd, dy, *, C, slope=None, dslope=None, g2=None, res=None, gres=None,
+                            bias_grad=None, **kw):
+        self.run_halves(lambda h: self.pnorm_backward(bhalf(g, h), bhalf(y, h), fhalf(mean_rstd, h), bhalf(dy, h), C=C,
+                                                      slope=pick(slope, h), dslope=pick(dslope, h), g2=bhalf(g2, h),
+                                                      res=bhalf(res, h), gres=bhalf(gres, h), bias_grad=pick(bias_grad, h),
+                                                      **kw))
+
 
 class TwinNet:
     """Two `NativeNet`s of identical architecture behind one call: `(ya, yb) = twin(xa, xb)` = `(a(xa), b(xb))`, recorded
@@ -117,8 +130,14 @@ class TwinNet:
         from .net import NativeNet
         if not (isinstance(a, NativeNet) and isinstance(b, NativeNet)) or a is b:
             return False
-        if type(a) is not type(b) or a.numel != b.numel or len(a.nodes) != len(b.nodes) or a.extras or b.extras:
+        if type(a) is not type(b) or a.numel != b.numel or len(a.nodes) != len(b.nodes):
             return False
+        if a.extras or b.extras:      # extra parameter vectors: only executors that run them per network (Vnet3D's PReLU slopes)
+            if not getattr(a, "twin_extras_ok", False) or [(e.name, e.size) for e in a.extras] != [(e.name, e.size) for e in b.extras]:
+                return False
+            if getattr(a, "use_inverse", False) or getattr(b, "use_inverse", False) or any(getattr(a, "attention", ())) \
+                    or any(getattr(b, "attention", ())):
+                return False
         if a.out_act != b.out_act or a.in_channels != b.in_channels or a.out_channels != b.out_channels:
             return False
         for na, nb in zip(a.nodes, b.nodes):

@@ -442,6 +442,9 @@ class RefOps(TwinSplit):
 
     def pnorm_forward(self, y, mean_rstd, out, *, C, slope=None, res=None, res_mode=0, res_mod=0, y_co=0, res_co=0,
                       out_co=0):
+        if is_twin(slope):
+            return self.twin_pnorm_forward(y, mean_rstd, out, C=C, slope=slope, res=res, res_mode=res_mode, res_mod=res_mod,
+                                           y_co=y_co, res_co=res_co, out_co=out_co)
         yh, u, r = self._p_preact(y, mean_rstd, res, res_mode, res_mod, C, y_co, res_co)
         v = torch.where(u > 0, u, u * slope[:C]) if slope is not None else u
         if res_mode == 2:
@@ -452,6 +455,10 @@ class RefOps(TwinSplit):
 
     def pnorm_backward(self, g, y, mean_rstd, dy, *, C, slope=None, dslope=None, g2=None, res=None, res_mode=0,
                        res_mod=0, gres=None, bias_grad=None, g_co=0, g2_co=0, y_co=0, res_co=0, dy_co=0, gres_co=0):
+        if is_twin(slope, dslope, bias_grad):
+            return self.twin_pnorm_backward(g, y, mean_rstd, dy, C=C, slope=slope, dslope=dslope, g2=g2, res=res,
+                                            res_mode=res_mode, res_mod=res_mod, gres=gres, bias_grad=bias_grad, g_co=g_co,
+                                            g2_co=g2_co, y_co=y_co, res_co=res_co, dy_co=dy_co, gres_co=gres_co)
         yh, u, _ = self._p_preact(y, mean_rstd, res, res_mode, res_mod, C, y_co, res_co)
         gt = g[..., g_co:g_co + C].float()
         if g2 is not None:
