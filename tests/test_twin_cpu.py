@@ -145,3 +145,30 @@ def test_cyclegan_iterations_with_and_without_twin_passes_agree(fp32_oracle_back
             assert runs["1"][0][s][k] == pytest.approx(v, rel=1e-4 if s == 0 else 2e-2, abs=1e-6), (s, k)
     for n, w in runs["0"][1].items():       # two Adam steps: +-lr per step on every weight (sign noise flips a few)
         assert (runs["1"][1][n] - w).abs().mean().item() <= 2e-5, n
+
+
+@pytest.mark.parametrize("memory_saving", [False, True], ids=["plain", "recompute"])
+def test_twin_vnets_equal_the_two_separate_passes(fp32_oracle_backend, memory_saving):
+    """Vnet3D._forward / _backward with a twin partner (round 6): the PReLU slopes, their gradients and the bias gradients out of
+    the norm reductions are per network (pnorm launches as halves), everything else one batch. Outputs, input gradients and the
+    whole flat gradient of BOTH networks against the two separate passes."""
+    from ganslate_amd.nn.generators import Vnet3D
+    make = lambda: Vnet3D(1, 1, "instance", first_layer_channels=8, down_blocks=(1, 1), up_blocks=(1, 1),
+                          use_memory_saving=memory_saving, use_inverse=False)
+    a, b = _pair(make, 11)
+    assert TwinNet.compatible(a, b)
+    a1, b1 = _clone(make, a), _clone(make, b)
+    g = torch.Generator().manual_seed(12)
+    xa, xb = (torch.rand(1, 1, 8, 8, 8, generator=g) * 2 - 1 for _ in range(2))
+    ga, gb = (torch.randn(1, 1, 8, 8, 8, generator=g) for _ in range(2))
+    xs = [t.clone().requires_grad_() for t in (xa, xb, xa, xb)]
+    ya, yb = TwinNet(a, b)(xs[0], xs[1])
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+    ya1, yb1 = a1(xs[2]), b1(xs[3])
+    ((ya1 * ga).sum() + (yb1 * gb).sum()).backward()
+    for got, ref in ((ya, ya1), (yb, yb1), (xs[0].grad, xs[2].grad), (xs[1].grad, xs[3].grad),
+                     (a.master.grad, a1.master.grad), (b.master.grad, b1.master.grad)):
+        _close(got.detach(), ref.detach())
+    # a network with the inverse path (RevGAN's shared V-Net) does not pair up
+    inv = lambda: Vnet3D(1, 1, "instance", first_layer_channels=8, down_blocks=(1, 1), up_blocks=(1, 1), use_inverse=True)
+    assert not TwinNet.compatible(*_pair(inv, 13))

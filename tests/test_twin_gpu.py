@@ -357,3 +357,38 @@ def test_cyclegan_step_with_twin_passes_equals_the_two_pass_step(name, monkeypat
             assert runs["1"][0][s][k] == pytest.approx(v, rel=2e-3 if s == 0 else 5e-2, abs=1e-5), (s, k)
     for n, w in runs["0"][1].items():
         assert (runs["1"][1][n] - w).abs().mean().item() <= 1e-4, n
+
+
+def test_twin_vnets_on_the_hip_kernels(hip_ops):
+    """the twin form of the V-Net executor (GS_TWIN=all in the recipes; off by default: slower on the brats recipe) on the HIP
+    backend: outputs, input gradients and flat gradients of both networks against the two separate passes — the same kernels
+    run either way for the per-network launches, the twin-native conv / weight-gradient launches are pinned at op level above"""
+    from ganslate_amd.nn.generators import Vnet3D
+    from ganslate_amd.nn.native.twin import TwinNet
+    make = lambda: Vnet3D(1, 1, "instance", first_layer_channels=16, down_blocks=(1, 2), up_blocks=(2, 1),
+                          use_memory_saving=False, use_inverse=False)
+    torch.manual_seed(21)
+    a, b = make(), make()
+    a.init_weights("normal", 0.05); b.init_weights("normal", 0.05)
+    a1, b1 = make(), make()
+    a1.load_state_dict(a.state_dict()); b1.load_state_dict(b.state_dict())
+    assert TwinNet.compatible(a, b)
+    dev = hip_ops.device
+    g = torch.Generator().manual_seed(22)
+    xa, xb = ((torch.rand(1, 1, 16, 32, 32, generator=g) * 2 - 1).to(dev) for _ in range(2))
+    ga, gb = (torch.randn(1, 1, 16, 32, 32, generator=g).to(dev) for _ in range(2))
+    xs = [t.clone().requires_grad_() for t in (xa, xb, xa, xb)]
+    ya, yb = TwinNet(a, b)(xs[0], xs[1])
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+    ya1, yb1 = a1(xs[2]), b1(xs[3])
+    ((ya1 * ga).sum() + (yb1 * gb).sum()).backward()
+    torch.cuda.synchronize()
+
+    def close(x, y, tol):
+        scale = max(y.abs().max().item(), 1e-12)
+        assert (x - y).abs().max().item() <= tol * scale, ((x - y).abs().max().item(), scale)
+    close(ya.detach(), ya1.detach(), 2e-2); close(yb.detach(), yb1.detach(), 2e-2)
+    close(xs[0].grad, xs[2].grad, 5e-2); close(xs[1].grad, xs[3].grad, 5e-2)
+    for net, ref in ((a, a1), (b, b1)):
+        cos = torch.nn.functional.cosine_similarity(net.master.grad, ref.master.grad, dim=0).item()
+        assert cos > 0.995, cos
