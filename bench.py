@@ -28,7 +28,7 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROAR
 # cannot run the profiler on itself): 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 correction of
 # MI355X_MICROARCH.md. tools/pmc_hbm_json.py writes them to this file from the passes of tools/pmc_step.sh; bench.py only
 # READS it ({label: {"bytes_per_launch", "images_per_launch", ...}}); a missing file or label gives `traffic: null`.
-HBM_JSON = ROOT / "profiles" / "r05_trunk_hbm.json"
+HBM_JSON = ROOT / "profiles" / "r06_trunk_hbm.json"
 
 
 def hbm_bytes(label, images_per_launch):

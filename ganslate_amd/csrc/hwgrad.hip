@@ -574,6 +574,220 @@ __global__ __launch_bounds__(512) void hwgrad_wide_kernel(const HWGradK p) {
   }
 }
 
+// ---- hwgrad_kernel's 16-taps-per-wave volume form, rebuilt on hwgrad_wide's recipe (round 6) ---------------------------------
+// hwgrad_kernel<*, 16> ran the V-Net's k5 weight gradients (16 -> 16 at 128^3: 176 us, 0.31 of the MFMA peak; 12.6 ms of the
+// brats step with the 32-channel form) the way round 1 left it: (i) every box decoded its ~7 pieces per thread from scratch —
+// five integer divisions and three border rules per 16-byte piece; (ii) ONE buffer: stage, wait, barrier, compute — and with
+// 146 registers per lane only one workgroup fits a CU, so nothing ran under the staging; (iii) compiler-issued transpose reads,
+// which hipcc serialises as read - wait - MFMA whenever an LDS-DMA is in the loop. Here: pieces decoded once per workgroup with
+// the border-resolved source planes / rows / columns in three small LDS tables, two buffers (the next box is staged under the
+// current one's MFMAs), and the rolling read pipeline of hwgrad_wide (inline-asm transpose reads D units ahead, counted lgkmcnt).
+// Same LDS images, same accumulation order per workgroup: per-workgroup sums are bit-identical to hwgrad_kernel's.
+template <int TI>
+__global__ __launch_bounds__(512) void hwgrad2_kernel(const HWGradK p) {
+  constexpr int NW = 8, TPW = 16;
+  constexpr int APITCH = TI * 32;                  // bytes per pixel row of the dense tile
+  constexpr int ABYTES = 256 * APITCH;             // 8 / 16 KiB
+  constexpr int NA = 256 * TI * 2 / 512;           // dense pieces per thread
+  constexpr int NH = 5;                            // halo pieces per thread (<= 2560 pieces, launcher)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* toff = reinterpret_cast<int*>(smem);        // [128] halo-linear tap offsets
+  const gs_wgrad_desc& d = p.d;
+  const int HV = p.HD * p.HH * p.HW, hhw = p.HH * p.HW;
+  const int hpieces = HV * 2;
+  const int hbytes = (HV * 32 + 1023) / 1024 * 1024 + 1024;
+  char* bufs = smem + 512;
+  auto at_of = [&](int b) { return bufs + (size_t)b * (ABYTES + hbytes); };
+  auto halo_of = [&](int b) { return bufs + (size_t)b * (ABYTES + hbytes) + ABYTES; };
+  unsigned short* ztab = reinterpret_cast<unsigned short*>(bufs + 2 * (size_t)(ABYTES + hbytes));
+  unsigned short* ytab = ztab + p.nbd * p.HD;
+  unsigned short* xtab = ytab + p.nbh * p.HH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int y = blockIdx.y;
+  const int qc = y % p.qchunks; y /= p.qchunks;
+  const int ph = y % p.phalves;
+  const int pch0 = ph * TI * 16;                   // first dense channel of this workgroup
+  for (int t = tid; t < NW * TPW; t += 512)
+    toff[t] = t < d.T ? (((int)d.dd[t] - p.dmin) * p.HH + ((int)d.dh[t] - p.hmin)) * p.HW + ((int)d.dw_[t] - p.wmin) : 0;
+  const int ntab = p.nbd * p.HD + p.nbh * p.HH + p.nbw * p.HW;
+  for (int e = tid; e < ntab; e += 512) {          // border-resolved source index of every halo plane / row / column of every box
+    bool ok = true;
+    int v;
+    if (e < p.nbd * p.HD) {
+      const int bz = e / p.HD, hz = e - bz * p.HD;
+      v = border_index(bz * p.BD + hz + p.dmin, d.Dg, d.border, ok);
+      v = min(max(v, 0), d.Dg - 1);
+    } else if (e < p.nbd * p.HD + p.nbh * p.HH) {
+      const int e2 = e - p.nbd * p.HD;
+      const int by = e2 / p.HH, hy = e2 - by * p.HH;
+      v = border_index(by * p.BH + hy + p.hmin, d.Hg, d.border, ok);
+      v = min(max(v, 0), d.Hg - 1);
+    } else {
+      const int e2 = e - p.nbd * p.HD - p.nbh * p.HH;
+      const int bx = e2 / p.HW, hx = e2 - bx * p.HW;
+      v = border_index(bx * p.BW + hx + p.wmin, d.Wg, d.border, ok);
+      v = min(max(v, 0), d.Wg - 1);
+    }
+    ztab[e] = ok ? (unsigned short)v : (unsigned short)0x8000;
+  }
+  __syncthreads();
+  const int ntaps = min(TPW, d.T - wave * TPW);    // taps this wave owns (may be <= 0)
+  // tap byte offsets of this wave (tap 0 stands in for the ones past T: their accumulators are dropped at the end)
+  int tb[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) tb[t] = __builtin_amdgcn_readfirstlane(toff[wave * TPW + (t < ntaps ? t : 0)] * 32);
+
+  f32x4 acc[TPW][TI];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fk = lane >> 4, frr = (lane & 15) >> 2, fcc = lane & 3;
+
+  // the pieces this thread stages of every box, decoded once
+  int a_rel[NA], a_zyx[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = i * 512 + tid;
+    const int px = q / (TI * 2), part = q - px * (TI * 2);
+    const int lz = px / (p.BH * p.BW), rem = px - lz * (p.BH * p.BW);
+    const int ly = rem / p.BW, lx = rem - ly * p.BW;
+    a_zyx[i] = pch0 + part * 8 < d.P ? (lz << 16 | ly << 8 | lx) : -1;
+    a_rel[i] = ((lz * d.Ha + ly) * d.Wa + lx) * d.a_cs + pch0 + part * 8;
+  }
+  int h_z[NH], h_y[NH], h_x[NH], h_c[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int q = i * 512 + tid;
+    const int v = q >> 1, part = q & 1;
+    const int hz = min(v / hhw, p.HD - 1), r2 = v % hhw;
+    const int hy = r2 / p.HW;
+    h_z[i] = hz; h_y[i] = hy; h_x[i] = r2 - hy * p.HW;
+    h_c[i] = (q < hpieces && qc * 16 + part * 8 < d.Q) ? qc * 16 + part * 8 : -1;
+  }
+  const bool ragged = (d.Da % p.BD) != 0 || (d.Ha % p.BH) != 0 || (d.Wa % p.BW) != 0;
+
+  auto issue_box = [&](int box, int b) {
+    int bb = box;
+    const int bx = bb % p.nbw; bb /= p.nbw;
+    const int by = bb % p.nbh; bb /= p.nbh;
+    const int bz = bb % p.nbd;
+    const int n = bb / p.nbd;
+    const int oz0 = bz * p.BD, oy0 = by * p.BH, ox0 = bx * p.BW;
+    char* at = at_of(b);
+    char* halo = halo_of(b);
+    const char* a_n = p.a + (((((size_t)n * d.Da + oz0) * d.Ha + oy0) * d.Wa + ox0) * d.a_cs + d.a_co) * 2;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      bool ok = a_zyx[i] >= 0;
+      if (ragged) ok = ok && oz0 + (a_zyx[i] >> 16) < d.Da && oy0 + ((a_zyx[i] >> 8) & 255) < d.Ha && ox0 + (a_zyx[i] & 255) < d.Wa;
+      glds16(ok ? a_n + (size_t)a_rel[i] * 2 : p.zero, at + (size_t)(i * 512 + wave * 64) * 16);
+    }
+    const char* g_n = p.g + ((size_t)n * d.Dg * d.Hg * d.Wg * d.g_cs + d.g_co) * 2;
+    const unsigned short* zrow = ztab + bz * p.HD;
+    const unsigned short* yrow = ytab + by * p.HH;
+    const unsigned short* xrow = xtab + bx * p.HW;
+    unsigned iz[NH], iy[NH], ix[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+      if (i * 512 + wave * 64 < hpieces) { iz[i] = zrow[h_z[i]]; iy[i] = yrow[h_y[i]]; ix[i] = xrow[h_x[i]]; }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      if (i * 512 + wave * 64 < hpieces) {         // wave-uniform: whole 64-piece instructions inside the halo
+        const bool ok = h_c[i] >= 0 && !((iz[i] | iy[i] | ix[i]) & 0x8000u);
+        unsigned off = (((iz[i] * (unsigned)d.Hg + iy[i]) * (unsigned)d.Wg + ix[i]) * (unsigned)d.g_cs + (unsigned)h_c[i]) * 2u;
+        asm volatile("" : "+v"(off));
+        glds16(ok ? g_n + off : p.zero, halo + (size_t)(i * 512 + wave * 64) * 16);
+      }
+    }
+  };
+  // byte offsets of this lane's transpose reads: dense fragments (rows = channels, k = the 8 pixels of box row ks*4 + fk) ...
+  int aoff[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) aoff[i] = (fk * 8 + frr) * APITCH + (i * 16 + fcc * 4) * 2;
+  // ... and the halo row base of this lane's 8-pixel run, per K-step
+  int rbk[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int px0 = (ks * 4 + fk) * 8;             // first pixel of this lane's 8-pixel run (BW is a multiple of 8)
+    const int lz = px0 / (p.BH * p.BW), rem = px0 - lz * (p.BH * p.BW);
+    const int ly = rem / p.BW, lx0 = rem - ly * p.BW;
+    rbk[ks] = ((lz * p.HH + ly) * p.HW + lx0 + frr) * 32 + fcc * 8;
+  }
+
+  int cur = 0;
+  int box = blockIdx.x;
+  if (box < p.nboxes) issue_box(box, 0);
+  for (; box < p.nboxes; box += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this box landed (nothing else is outstanding)
+    __syncthreads();                                     // ... for every wave; the other buffer is fully consumed
+    if (box + (int)gridDim.x < p.nboxes) issue_box(box + gridDim.x, cur ^ 1);
+    if (ntaps > 0) {
+      // 8 K-steps x 16 taps as a rolling pipeline of units (one tap of one K-step: 2 transpose reads of the gathered fragment,
+      // plus the 2 TI reads of the K-step's dense fragments in front of tap 0; TI MFMAs); reads of unit u + D go out before the
+      // MFMAs of unit u, the wait in front of those counts the reads issued after unit u's own
+      const unsigned at_a = lds_addr(at_of(cur)), ha = lds_addr(halo_of(cur));
+      constexpr int D = TI == 1 ? 6 : 5, NU = 8 * TPW;      // (lgkmcnt counts to 15: 2 D + 2 TI reads may be younger)
+      uint2 glo[D + 1], ghi[D + 1], alo[2][TI], ahi[2][TI];
+      auto issue_unit = [&](auto uu) {
+        constexpr int u = decltype(uu)::value, ks = u / TPW, t = u % TPW, slot = u % (D + 1);
+        if constexpr (t == 0) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            lds_read64_tr<ks * 32 * APITCH>(alo[ks & 1][i], at_a + (unsigned)aoff[i]);
+            lds_read64_tr<ks * 32 * APITCH + 4 * APITCH>(ahi[ks & 1][i], at_a + (unsigned)aoff[i]);
+          }
+        }
+        const unsigned g0 = ha + (unsigned)(rbk[ks] + tb[t]);
+        lds_read64_tr<0>(glo[slot], g0);
+        lds_read64_tr<4 * 32>(ghi[slot], g0);
+      };
+      static_for<0, D>(issue_unit);
+      static_for<0, NU>([&](auto uu) {
+        constexpr int u = decltype(uu)::value, ks = u / TPW, t = u % TPW, slot = u % (D + 1);
+        if constexpr (u + D < NU) issue_unit(std::integral_constant<int, u + D>{});
+        constexpr int last = u + D < NU ? u + D : NU - 1;
+        constexpr int newer = 2 * (last - u) + 2 * TI * ((last / TPW) - ks);      // reads issued after unit u's
+        gs_lgkm_wait_only<newer>();
+        asm volatile("" : "+v"(glo[slot]), "+v"(ghi[slot]));
+        if constexpr (t == 0) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) asm volatile("" : "+v"(alo[ks & 1][i]), "+v"(ahi[ks & 1][i]));
+        }
+        const bf16x8 gf = __builtin_bit_cast(bf16x8, uint4{glo[slot].x, glo[slot].y, ghi[slot].x, ghi[slot].y});
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const bf16x8 af = __builtin_bit_cast(bf16x8, uint4{alo[ks & 1][i].x, alo[ks & 1][i].y, ahi[ks & 1][i].x, ahi[ks & 1][i].y});
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, gf, acc[t][i], 0, 0, 0);
+        }
+      });
+    }
+    cur ^= 1;
+  }
+
+  // ---- one slab row (or atomic) per output element per workgroup ------------------------------------------------------------
+  const int col = lane & 15;
+  const int q = qc * 16 + col;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave * TPW + t;
+    if (t < ntaps && q < d.Q) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = pch0 + i * 16 + fk * 4 + r;
+          if (pp < d.P) {
+            const size_t e = (size_t)pp * d.dw_ld + tap * d.Q + q;
+            if (p.ws) p.ws[(size_t)blockIdx.x * p.ws_stride + e] = acc[t][i][r];
+            else unsafeAtomicAdd(p.dw + e, acc[t][i][r]);
+          }
+        }
+    }
+  }
+}
+
 namespace {
 template <int TI, int TPW>
 int launch_hw(const HWGradK& k, dim3 grid, int lds, hipStream_t st) {
@@ -788,6 +1002,38 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
   k.d = *d;
   // one workgroup per CU (its registers hold 16 taps per wave); ~2 rounds of box groups keep the tail short
   const int per_y = k.qchunks * k.phalves * k.tgroups;
+  // volumes with 65..128 taps: the double-buffered form (hwgrad2_kernel) — one workgroup per CU walks its boxes with the next one
+  // staged under the current one's MFMAs
+  const long long tab_bytes2 = ((long long)k.nbd * k.HD + (long long)k.nbh * k.HH + (long long)k.nbw * k.HW) * 2;
+  const int lds2 = 512 + 2 * (256 * TI * 32 + (int)((hv * 32 + 1023) / 1024 * 1024 + 1024)) + (int)((tab_bytes2 + 15) / 16 * 16);
+  if (gs_opt(GS_OPT_HWGRAD2) && TPW == 16 && k.tgroups == 1 && d->Da > 1 && hv * 2 <= 5 * 512 && lds2 <= 160 * 1024 &&
+      tab_bytes2 < 16384 && d->Dg < 32768 && d->Hg < 32768 && d->Wg < 32768) {
+    long long groups2 = 256 / per_y;
+    if (groups2 < 1) groups2 = 1;
+    if (groups2 > nboxes) groups2 = nboxes;
+    k.ws = ws;
+    k.ws_stride = ws_stride;
+    *handled = ws || plan_only ? (int)groups2 : 1;
+    if (plan_only) return 0;
+    const dim3 grid2((unsigned)groups2, (unsigned)per_y);
+    hipStream_t st2 = static_cast<hipStream_t>(stream);
+    static bool configured2[2] = {false, false};
+    if (TI == 1) {
+      if (!configured2[0]) {
+        GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured2[0] = true;
+      }
+      hipLaunchKernelGGL((hwgrad2_kernel<1>), grid2, dim3(512), lds2, st2, k);
+    } else {
+      if (!configured2[1]) {
+        GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured2[1] = true;
+      }
+      hipLaunchKernelGGL((hwgrad2_kernel<2>), grid2, dim3(512), lds2, st2, k);
+    }
+    GS_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   long long groups = 512 / per_y;
   if (groups < 1) groups = 1;
   if (groups > nboxes) groups = nboxes;
@@ -795,8 +1041,9 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
   k.ws_stride = ws_stride;
   *handled = ws || plan_only ? (int)groups : 1;
   if (plan_only) return 0;
-  const dim3 grid((unsigned)groups, (unsigned)per_y);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)st;
+  const dim3 grid((unsigned)groups, (unsigned)per_y);
   if (TI == 1) return TPW == 8 ? launch_hw<1, 8>(k, grid, lds, st) : launch_hw<1, 16>(k, grid, lds, st);
   return TPW == 8 ? launch_hw<2, 8>(k, grid, lds, st) : launch_hw<2, 16>(k, grid, lds, st);
 }
