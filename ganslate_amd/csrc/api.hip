@@ -88,7 +88,8 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconv5", 64},             // hconv5.hip: register-resident-weights kernel for the 16 -> 16 channel k5 volume convs; smallest volume
                                 // (batch x voxels / 2048) it takes (0 = off)
     {"hconv5_seg", 0},          // ... z segments per column (0 = as many as fill the chip; tests force long segments with 1 / 2)
-    {"hwgrad2", 1},             // hwgrad.hip: double-buffered, decode-once form of the narrow volume weight gradient with 65..128 taps
+    {"hwgrad2", 2},             // hwgrad.hip: double-buffered, decode-once form of the narrow volume weight gradient with 65..128 taps
+                                // (>= 2: also for layers wide on both sides, 33..64 x 17..64 channels, instead of the im2col kernel)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -969,7 +969,9 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
   }
   if (tw) return 0;                                // hwgrad_kernel below has no twin form
   if (!enabled || d->si != 1 || d->P > 64 || d->Q > 64 || d->T < 9) return 0;
-  if (d->Q > 32 && d->P > 16) return 0;            // wide on both sides: the im2col kernel is the better fit (measured)
+  // wide on both sides: the im2col kernel was the better fit for hwgrad_kernel (measured, round 1); the double-buffered form
+  // takes 64 <-> 64 channel volume layers too (option hwgrad2 >= 2)
+  if (d->Q > 32 && d->P > 16 && !(gs_opt(GS_OPT_HWGRAD2) >= 2 && d->Da > 1 && d->T > 64 && d->T <= 128)) return 0;
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
   for (int t = 0; t < d->T; ++t) {
     const int o[3] = {d->dd[t], d->dh[t], d->dw_[t]};
