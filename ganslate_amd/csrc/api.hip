@@ -90,6 +90,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconv5_seg", 0},          // ... z segments per column (0 = as many as fill the chip; tests force long segments with 1 / 2)
     {"hwgrad2", 2},             // hwgrad.hip: double-buffered, decode-once form of the narrow volume weight gradient with 65..128 taps
                                 // (>= 2: also for layers wide on both sides, 33..64 x 17..64 channels, instead of the im2col kernel)
+    {"hconv2", 1},              // hconv.hip: persistent double-buffered form of the narrow volume forward / data-gradient kernel (17..64 output channels)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -34,6 +34,7 @@ CASES = {
     "v16": (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 128, 128, 128),
     "v16s": (ConvSpec("conv", 16, 16, 5, 1, 2, dims=3), 1, 64, 64, 64),
     "v32": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 64, 64, 64),
+    "v32b": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 128, 128, 128),
     "v64": (ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, 32, 32, 32),
 }
 
