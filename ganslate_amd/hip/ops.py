@@ -65,8 +65,15 @@ class HipOps(TwinSplit):
 
     def sync_options(self):
         if not hasattr(self, "_option_defaults"):
-            self._option_defaults = {opt: self.get_option(opt) for opt in self.ENV_OPTIONS.values()}
+            self._option_defaults = {}
+            for opt in self.ENV_OPTIONS.values():      # (an older build of the library — GANSLATE_HIP_LIB in an A/B — may not know
+                try:                                   # the newest switches: those are skipped)
+                    self._option_defaults[opt] = self.get_option(opt)
+                except L.HipError:
+                    pass
         for env, opt in self.ENV_OPTIONS.items():
+            if opt not in self._option_defaults:
+                continue
             want = int(os.environ[env]) if env in os.environ else self._option_defaults[opt]
             if want != self.get_option(opt):
                 self.set_option(opt, want)
