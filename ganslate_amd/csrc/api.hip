@@ -91,6 +91,7 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hwgrad2", 2},             // hwgrad.hip: double-buffered, decode-once form of the narrow volume weight gradient with 65..128 taps
                                 // (>= 2: also for layers wide on both sides, 33..64 x 17..64 channels, instead of the im2col kernel)
     {"hconv2", 1},              // hconv.hip: persistent double-buffered form of the narrow volume forward / data-gradient kernel (17..64 output channels)
+    {"pwise", 8},               // pwise.hip: register-operand kernels for one-tap layers with <= 8 channels on one side (smallest volume in 2048-voxel units, 0 = off)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

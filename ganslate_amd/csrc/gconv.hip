@@ -655,6 +655,8 @@ int launch_tile(const TileCfg& tc, const GConvK& k, int blocks, hipStream_t st) 
 
 // hconv.hip: halo-resident kernel for narrow stride-1 layers
 int gs_hconv_slots(const gs_gconv_desc* d);
+int gs_pwise_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, void* stream,
+                 int* handled);                   // (pwise.hip)
 int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
                  void* stream, int* handled);
 // hconvw.hip: halo-resident forward kernel for the wide 3x3 stride-1 layers
@@ -787,6 +789,8 @@ static int gconv_forward_impl(const gs_gconv_desc* d, const void* in, const void
   if (!fuse) {
     int handled = 0;
     if (!tw) {
+      if (int rc = gs_pwise_try(d, in, w_pack, bias, out, stream, &handled)) return rc;
+      if (handled) return 0;
       if (int rc = gs_hconv_try(d, in, w_pack, bias, out, stats, stream, &handled)) return rc;
       if (handled) return 0;
     }

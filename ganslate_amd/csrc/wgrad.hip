@@ -407,6 +407,10 @@ void gs_launch_slab_reduce(const float* ws, float* dst, long long n4, int slabs,
 int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const void* a2, const void* g2, float* dw,
                    float* ws, int plan_only, void* stream, int* handled, const gs_twin* tw);
 
+// pwise.hip: one-tap layers with 8 channels on one side
+int gs_pwise_wgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, float* ws, int plan_only, void* stream,
+                       int* handled);
+
 namespace {
 // the im2col kernel for one operand pair; ws != nullptr: partial tiles to slabs, *slabs = how many
 int wgrad_generic(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, float* ws, int plan_only,
@@ -459,7 +463,10 @@ int wgrad_impl(const gs_wgrad_desc* d, const void* a1, const void* g1, const voi
   const long long slab = (long long)d->P * d->dw_ld;
   const bool det = ws != nullptr || plan_only;
   int handled = 0;
-  if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, det ? ws : nullptr, plan_only, stream, &handled, tw)) return rc;
+  if (!a2 && !tw)
+    if (int rc = gs_pwise_wgrad_try(d, a1, g1, dw, det ? ws : nullptr, plan_only, stream, &handled)) return rc;
+  if (!handled)
+    if (int rc = gs_hwgrad_try2(d, a1, g1, a2, g2, dw, det ? ws : nullptr, plan_only, stream, &handled, tw)) return rc;
   if (handled) {
     const int nets = tw ? 2 : 1;                             // twin batch: `handled` slabs per network
     if (need_floats) *need_floats = (int64_t)nets * handled * slab;

@@ -51,7 +51,7 @@ class HipOps(TwinSplit):
                    "GS_BWD_PPB": "norm_bwd_ppb", "GS_APPLY_U": "norm_apply_unroll", "GS_GCONV_TILE288": "gconv_tile288", "GS_GCONV_MULTI": "gconv_multi",
                    "GS_HCONVW_RING": "hconvw_ring", "GS_HCONVT": "hconvt", "GS_HSTRIP": "hstrip",
                    "GS_WFOLD_ROWS": "wfold_rows", "GS_HWGRAD_FT": "hwgrad_ft", "GS_GCONV_BIG": "gconv_big", "GS_HCONV_BOX8": "hconv_box8",
-                   "GS_HCONV5": "hconv5", "GS_RING_DBG": "ring_dbg", "GS_HWGRAD2": "hwgrad2", "GS_HCONV2": "hconv2"}
+                   "GS_HCONV5": "hconv5", "GS_RING_DBG": "ring_dbg", "GS_HWGRAD2": "hwgrad2", "GS_HCONV2": "hconv2", "GS_PWISE": "pwise"}
 
     def set_option(self, name, value):
         L.check(self.lib.gs_set_option(name.encode(), int(value)), "gs_set_option")

@@ -110,8 +110,13 @@ const char* gs_last_error(void);
  * side maps its GS_* variables onto these (ganslate_amd/hip/ops.py). Names: splitk, splitk_max_blocks, splitk_target,
  * hconv, hconv_wide, hconvw_persist, hstrip_regs, gconv_twin, wgrad_twin, hwgrad, hwgrad_wide, hwgrad_planes, norm_bwd_ppb, norm_apply_unroll, gconv_tile288,
  * gconv_multi, hconvw_ring, hconvt (smallest grid the parity-class halo kernel takes, 0 = off), hstrip (same for the k7
- * boundary-conv kernel). Every setting computes the same function (up to the fp32 summation order and, for hconvw_ring,
- * where the bf16 rounding of the folded gradient happens); none skips work. Unknown name -> non-zero. */
+ * boundary-conv kernel); round 5 / 6: gconv_persist, hconvt_persist, wgrad_rows, splitk_multi, splitk_ring, gconv_ring4,
+ * hconv5 (register-resident-weights kernel for the 16 -> 16 channel k5 volume convs: smallest volume in units of 2048 voxels,
+ * 0 = off), hconv5_seg (z segments per column, 0 = auto), hwgrad2 / hconv2 (double-buffered volume forms of the narrow weight
+ * gradient / forward kernels), pwise (one-tap layers with <= 8 channels on one side — the V-Net's 32 -> 1 output conv — on
+ * register-operand kernels: smallest volume in units of 2048 voxels, 0 = off). Every setting computes the same function (up to the fp32 summation order and, for hconvw_ring,
+ * where the bf16 rounding of the folded gradient happens); none skips work — EXCEPT the timing ablations ring_apply > 1 and
+ * ring_dbg != 0, which produce wrong results by design and exist for profiles/ only. Unknown name -> non-zero. */
 int gs_set_option(const char* name, int value);
 int gs_get_option(const char* name, int* value);
 int gs_tile_m(const gs_gconv_desc* d);   /* pixel-tile height of the im2col kernel for this class */

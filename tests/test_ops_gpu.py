@@ -903,6 +903,51 @@ def test_register_resident_k5_kernel(hip_ops, sizes, seg):
     close_bf16(G5, G_ref, "accumulated data gradient (hconv5)")
 
 
+@pytest.mark.parametrize("sizes", [(16, 32, 48), (17, 33, 35)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("chans", [(32, 1), (1, 32), (64, 3), (16, 12)], ids=lambda c: "%dto%d" % c)
+def test_pointwise_kernels(hip_ops, chans, sizes):
+    """pwise.hip (one-tap layers with few channels on one side — the V-Net's 32 -> 1 output conv, vnet3d.py:246-268): forward with
+    bias and activation, data gradient and weight gradient against the oracle and against the im2col kernels of the same
+    library; a voxel count that is not a multiple of the 16-voxel tile; the weight gradient twice (bit-identical)"""
+    ops = hip_ops
+    spec, N = ConvSpec("conv", chans[0], chans[1], 1, 1, 0, dims=3), 2
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 41)
+    g = torch.Generator().manual_seed(42)
+    x = torch.zeros(N, *sizes, spec.cin_p, dtype=torch.bfloat16)
+    x[..., :spec.cin] = torch.randn(N, *sizes, spec.cin, generator=g).to(torch.bfloat16)
+    gy = torch.zeros(N, *sizes, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., :spec.cout] = torch.randn(N, *sizes, spec.cout, generator=g).to(torch.bfloat16)
+
+    def run(o, dev):
+        y = torch.full((N, *sizes, spec.cout_p), 7.0, dtype=torch.bfloat16, device=dev)
+        o.gconv_classes(low.fwd, x.to(dev), fpack.to(dev), bias.to(dev), y, act="lrelu", slope=0.25)
+        gx = torch.full((N, *sizes, spec.cin_p), 7.0, dtype=torch.bfloat16, device=dev)
+        o.gconv_classes(low.dgrad, gy.to(dev), dpack.to(dev), None, gx)
+        dws = []
+        for _ in range(2):
+            dw = torch.full((spec.P * spec.T * spec.Q,), 0.5, dtype=torch.float32, device=dev)
+            o.wgrad(low.wgrad, gy.to(dev), x.to(dev), dw)
+            dws.append(dw)
+        return y, gx, dws
+    y_ref, gx_ref, dw_ref = run(RefOps(), "cpu")
+    default = ops.get_option("pwise")
+    try:
+        ops.set_option("pwise", 1)
+        y1, gx1, dw1 = run(ops, ops.device)
+        ops.set_option("pwise", 0)
+        y0, gx0, dw0 = run(ops, ops.device)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("pwise", default)
+    close_bf16(y1, y_ref, "forward (pwise)")
+    close_bf16(y1, y0.cpu(), "forward, pwise vs im2col")
+    close_bf16(gx1, gx_ref, "data gradient (pwise)")
+    close_bf16(gx1, gx0.cpu(), "data gradient, pwise vs im2col")
+    assert torch.equal(dw1[0], dw1[1]), "two runs of the weight gradient must be bit-identical"
+    close_f32(dw1[0], dw_ref[0], "weight gradient (pwise)")
+    close_f32(dw1[0], dw0[0].cpu(), "weight gradient, pwise vs im2col", rel=1e-3)
+
+
 def test_gconv_accumulate_with_split_k(hip_ops):
     """the accumulate-into form on a layer that runs split-K (64 -> 64 channel k5 coupling conv of the V-Net at 16^3: 32 output
     tiles, K = 8000): the finalize pass does the bf16 read-modify-write of gconv_kernel's own accumulate epilogue"""

@@ -69,7 +69,9 @@ def main():
         else:
             label = (f"wgrad{' pair' if flag else ''} a {s.Da}x{s.Ha}x{s.Wa}x{s.P} g {s.Dg}x{s.Hg}x{s.Wg}x{s.Q} T={s.T} "
                      f"si={s.si} {s.border}")
-            flops[label] = 2.0 * s.Dg * s.Hg * s.Wg * s.Q * s.T * s.P * (2 if flag else 1)
+            # the contraction runs over the DENSE side's pixels (for a stride-2 layer the gathered side has 4x as many, of which a
+            # tap touches every fourth)
+            flops[label] = 2.0 * s.Da * s.Ha * s.Wa * s.Q * s.T * s.P * (2 if flag else 1)
         return label
     ops.enable_kernel_timing(select)
     for _ in range(args.steps):
