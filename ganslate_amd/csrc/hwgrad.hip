@@ -968,7 +968,10 @@ int gs_hwgrad_try2(const gs_wgrad_desc* d, const void* a, const void* g, const v
     }
   }
   if (tw) return 0;                                // hwgrad_kernel below has no twin form
-  if (!enabled || d->si != 1 || d->P > 64 || d->Q > 64 || d->T < 9) return 0;
+  // one-channel volume layers (PatchGAN3D's last conv: P = 8, Q = 256, 64 taps): 16 channel chunks of the gathered side, each
+  // with its own workgroups (option hwgrad2 >= 2) — the im2col kernel gathered 64 taps x 512 bytes per voxel through L2 (715 us)
+  const bool thin = gs_opt(GS_OPT_HWGRAD2) >= 2 && d->P <= 16 && d->Da > 1 && d->T >= 27 && d->Q <= 512;
+  if (!enabled || d->si != 1 || d->P > 64 || (d->Q > 64 && !thin) || d->T < 9) return 0;
   // wide on both sides: the im2col kernel was the better fit for hwgrad_kernel (measured, round 1); the double-buffered form
   // takes 64 <-> 64 channel volume layers too (option hwgrad2 >= 2)
   if (d->Q > 32 && d->P > 16 && !(gs_opt(GS_OPT_HWGRAD2) >= 2 && d->Da > 1 && d->T > 64 && d->T <= 128)) return 0;

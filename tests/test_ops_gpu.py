@@ -948,6 +948,34 @@ def test_pointwise_kernels(hip_ops, chans, sizes):
     close_f32(dw1[0], dw0[0].cpu(), "weight gradient, pwise vs im2col", rel=1e-3)
 
 
+def test_one_channel_volume_weight_gradient(hip_ops):
+    """PatchGAN3D's last conv (patchgan3d.py:57-60: Conv3d(256, 1, k4, s1, p1)): its weight gradient on the halo-resident kernel
+    with 16 channel chunks of the gathered side (hwgrad2 >= 2) against the im2col kernel and the oracle; ragged boxes"""
+    ops = hip_ops
+    spec, N, sizes = ConvSpec("conv", 256, 1, 4, 1, 1, dims=3), 2, (11, 15, 19)
+    low = lower(spec, *sizes)
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16)
+    gy = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+    gy[..., :1] = torch.randn(N, *low.out_dims, 1, generator=g).to(torch.bfloat16)
+    ref = torch.full((spec.P * spec.T * spec.Q,), 0.5, dtype=torch.float32)
+    RefOps().wgrad(low.wgrad, gy, x, ref)
+    out = {}
+    default = ops.get_option("hwgrad2")
+    try:
+        for v in (2, 2, 1):
+            ops.set_option("hwgrad2", v)
+            dw = torch.full((spec.P * spec.T * spec.Q,), 0.5, dtype=torch.float32, device=ops.device)
+            ops.wgrad(low.wgrad, gy.to(ops.device), x.to(ops.device), dw)
+            torch.cuda.synchronize()
+            out.setdefault(v, []).append(dw.cpu())
+    finally:
+        ops.set_option("hwgrad2", default)
+    assert torch.equal(out[2][0], out[2][1]), "two runs must be bit-identical"
+    close_f32(out[2][0], ref, "one-channel volume weight gradient vs oracle")
+    close_f32(out[2][0], out[1][0], "vs the im2col kernel", rel=1e-3)
+
+
 def test_gconv_accumulate_with_split_k(hip_ops):
     """the accumulate-into form on a layer that runs split-K (64 -> 64 channel k5 coupling conv of the V-Net at 16^3: 32 output
     tiles, K = 8000): the finalize pass does the bf16 read-modify-write of gconv_kernel's own accumulate epilogue"""
