@@ -612,7 +612,9 @@ HPlan plan(const gs_gconv_desc* d) {
   if (!enabled) return h;
   // T < 9: the W-folded boundary convs (7 taps) measured slower here than on the im2col kernel (stem fwd 93 vs 74 us)
   if (d->si != 1 || d->so != 1 || d->Co > 64 || d->Ci > 64 || d->T < 9) return h;
-  if (d->Ci > 32 && d->Co > 16) return h;          // wide on both sides: the im2col kernel is the better fit (measured)
+  // wide on both sides: the im2col kernel is the better fit (measured) — hconv2 >= 2 tries the persistent form on volumes
+  const bool wide2 = gs_opt(GS_OPT_HCONV2) >= 2 && d->Do >= 8;
+  if (d->Ci > 32 && d->Co > 16 && !wide2) return h;
   if (d->Dc != d->Do || d->Hc != d->Ho || d->Wc != d->Wo || d->pz || d->py || d->px) return h;
   int lo[3] = {127, 127, 127}, hi[3] = {-128, -128, -128};
   for (int t = 0; t < d->T; ++t) {
@@ -650,6 +652,7 @@ HPlan plan(const gs_gconv_desc* d) {
       return h;
     }
     // (does not fit: the 4-wave form below)
+    if (d->Ci > 32 && d->Co > 16) return h;
     h.v2 = false;
     h.NW = 4;
     h.BD = 4;

@@ -976,6 +976,52 @@ def test_one_channel_volume_weight_gradient(hip_ops):
     close_f32(out[2][0], out[1][0], "vs the im2col kernel", rel=1e-3)
 
 
+@pytest.mark.parametrize("case", [((32, 32), (32, 32, 32)), ((64, 64), (32, 32, 32)), ((16, 32), (33, 32, 40))],
+                         ids=lambda c: "%dto%d-%s" % (c[0] + ("x".join(map(str, c[1])),)))
+def test_persistent_narrow_volume_kernel(hip_ops, case):
+    """hconv2_kernel (hconv.hip: persistent workgroups on 8 x 8 x 8 boxes, the next box's halo staged under the tap loop) for the
+    V-Net's k5 coupling convs with 32 / 64 channels (option hconv2 >= 2: 64 -> 64 too, two output-channel groups per box):
+    forward with bias, activation and statistics, and the data gradient accumulated into a channel slice — against the oracle and
+    against the kernels that run with hconv2 = 0; 64 boxes and a ragged 5 x 4 x 5 grid of boxes"""
+    ops = hip_ops
+    (cin, cout), sizes = case
+    spec, N = ConvSpec("conv", cin, cout, 5, 1, 2, dims=3), 1
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 61)
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(N, *sizes, 2 * cin, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, *sizes, cout, generator=g).to(torch.bfloat16)
+    base = torch.randn(N, *sizes, 2 * cin, generator=g).to(torch.bfloat16)
+
+    def run(o, dev):
+        ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+        slots, offs = stats_slots(o, low, low.fwd, N)
+        part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
+        o.gconv_classes(low.fwd, x.to(dev), fpack.to(dev), bias.to(dev), ya, in_co=cin, act="lrelu", slope=0.25, stats=part,
+                        stats_slots=slots, stats_slot0s=offs)
+        mr = torch.empty(N * 2 * spec.cout_p, dtype=torch.float32, device=dev)
+        o.inorm_finalize(part, N, slots, spec.cout_p, low.out_pixels, mr)
+        G = base.clone().to(dev)
+        for gc in low.dgrad:
+            o.gconv(gc, gy.to(dev), dpack.to(dev), None, G, out_co=cin, accumulate=True)
+        return ya, mr, G
+    y_ref, mr_ref, G_ref = run(RefOps(), "cpu")
+    default = ops.get_option("hconv2")
+    try:
+        ops.set_option("hconv2", 2)
+        y2, mr2, G2 = run(ops, ops.device)
+        ops.set_option("hconv2", 0)
+        y0, mr0, G0 = run(ops, ops.device)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("hconv2", default)
+    close_bf16(y2, y_ref, "forward (hconv2)")
+    close_bf16(y2, y0.cpu(), "forward, hconv2 vs hconv2 = 0")
+    close_f32(mr2, mr_ref, "mean / rstd (hconv2)", rel=1e-3)
+    assert torch.equal(G2[..., :cin].cpu(), base[..., :cin]), "the other half must be untouched"
+    close_bf16(G2, G_ref, "accumulated data gradient (hconv2)")
+    close_bf16(G2, G0.cpu(), "data gradient, hconv2 vs hconv2 = 0")
+
+
 def test_gconv_accumulate_with_split_k(hip_ops):
     """the accumulate-into form on a layer that runs split-K (64 -> 64 channel k5 coupling conv of the V-Net at 16^3: 32 output
     tiles, K = 8000): the finalize pass does the bf16 read-modify-write of gconv_kernel's own accumulate epilogue"""
