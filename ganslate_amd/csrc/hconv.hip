@@ -635,6 +635,8 @@ HPlan plan(const gs_gconv_desc* d) {
   h.nbd = (d->Do + h.BD - 1) / h.BD; h.nbh = (d->Ho + h.BH - 1) / h.BH; h.nbw = (d->Wo + h.BW - 1) / h.BW;
   h.CC = d->Ci < 16 ? d->Ci : 16;
   h.TI = d->Co <= 16 ? 1 : 2;                      // 16 or 32 output channels per workgroup,
+  // (persistent form on a small volume: 16 channels per workgroup put a 32-channel layer's 64 boxes on 128 workgroups)
+  if (h.v2 && gs_opt(GS_OPT_HCONV2) >= 3 && d->Co == 32 && (long long)d->N * h.nbd * h.nbh * h.nbw * 2 <= 256) h.TI = 1;
   h.cog = (d->Co + h.TI * 16 - 1) / (h.TI * 16);   // wider layers split over blockIdx.y (each stages its own halo)
   const long long hv = (long long)h.HD * h.HH * h.HW;
   const long long halo_bytes = (hv * h.CC * 2 + 1023) / 1024 * 1024 + 1024;
@@ -733,7 +735,16 @@ int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, con
       GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       configured2 = true;
     }
-    hipLaunchKernelGGL((hconv2_kernel<2>), dim3(groups, h.cog), dim3(512), h.lds, st, k);
+    if (h.TI == 1) {
+      static bool configured1 = false;
+      if (!configured1) {
+        GS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured1 = true;
+      }
+      hipLaunchKernelGGL((hconv2_kernel<1>), dim3(groups, h.cog), dim3(512), h.lds, st, k);
+    } else {
+      hipLaunchKernelGGL((hconv2_kernel<2>), dim3(groups, h.cog), dim3(512), h.lds, st, k);
+    }
     GS_CHECK_HIP(hipGetLastError());
     return 0;
   }

@@ -36,6 +36,8 @@ CASES = {
     "v32": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 64, 64, 64),
     "v32b": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 128, 128, 128),
     "v64": (ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, 32, 32, 32),
+    "v32s": (ConvSpec("conv", 32, 32, 5, 1, 2, dims=3), 1, 32, 32, 32),
+    "v64s": (ConvSpec("conv", 64, 64, 5, 1, 2, dims=3), 1, 16, 16, 16),
     # PatchGAN3D's last two layers (patchgan3d.py:50-60) on the 4 images of a discriminator update
     "p3l": (ConvSpec("conv", 256, 1, 4, 1, 1, dims=3), 4, 31, 31, 31),
     "p3m": (ConvSpec("conv", 128, 256, 4, 1, 1, dims=3), 4, 32, 32, 32),
