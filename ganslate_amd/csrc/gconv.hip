@@ -657,6 +657,8 @@ int launch_tile(const TileCfg& tc, const GConvK& k, int blocks, hipStream_t st) 
 int gs_hconv_slots(const gs_gconv_desc* d);
 int gs_pwise_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, void* stream,
                  int* handled);                   // (pwise.hip)
+int gs_pwise_multi_try(const gs_gconv_desc* const* descs, int count, const void* in, const void* const* w_packs, const float* bias,
+                       void* out, float* stats, void* stream, int* handled);
 int gs_hconv_try(const gs_gconv_desc* d, const void* in, const void* w_pack, const float* bias, void* out, float* stats,
                  void* stream, int* handled);
 // hconvw.hip: halo-resident forward kernel for the wide 3x3 stride-1 layers
@@ -1005,6 +1007,11 @@ int gconv_forward_multi_impl(const gs_gconv_desc* const* descs, int32_t count, c
   for (int c = 0; c < count; ++c)
     GS_REQUIRE(descs[c]->Kp % 64 == 0 && descs[c]->Kp >= descs[c]->T * descs[c]->Ci, "gs_gconv_forward_multi: bad Kp=%d",
                descs[c]->Kp);
+  {                                                       // k2 stride-2 volume layers: 8 one-tap classes (pwise.hip)
+    int handled = 0;
+    if (int rc = gs_pwise_multi_try(descs, count, in, w_packs, bias, out, stats, stream, &handled)) return rc;
+    if (handled) return 0;
+  }
   {
     const int pat = gs_hconvt_pattern(descs, count);      // 2-D k3 / k4 stride-2 layers with 64-multiple channels: one pass
     if (pat >= 0) return gs_hconvt_launch(descs, pat, in, w_packs, bias, out, stats, nullptr, stream);

@@ -149,6 +149,125 @@ __global__ __launch_bounds__(256) void pwise_wgrad_kernel(const PwWK p) {
     else p.dst[(size_t)blockIdx.x * p.P * p.Q + (size_t)pa * p.Q + qb] = s;
   }
 }
+// ---- the 8 output-parity classes of a k2 stride-2 layer (V-Net up convs: ConvTranspose3d(k2, s2), vnet3d.py:190-215; the data
+// gradient of its k2 s2 down convs): every class is a one-tap layer over the SAME input voxels, writing output voxel
+// 2 v + (pz, py, px). A workgroup takes one pixel tile of the im2col kernel (bm class voxels of an image = one statistics slot
+// per class, so the slot layout of gs_gconv_stat_slots stays what it is) for all classes; wave w computes classes w and w + 4
+// from its own copy of the input fragment (the four waves' loads of a tile hit L1).
+struct PwMK {
+  const char* in;
+  const char* w[8];
+  const float* bias;
+  char* out;
+  float* stats;
+  int N, Dc, Hc, Wc, Do, Ho, Wo, Ci, Co, in_cs, in_co, out_cs, out_co, Kp, w_rows, act;
+  float slope, rcp_wc, rcp_hc;
+  int bm, tiles_m, stats_slots;
+  int cpz[8], cpy[8], cpx[8], cslot0[8];
+};
+
+template <int KS, int CT>
+__global__ __launch_bounds__(256) void pwise_multi_kernel(const PwMK p) {
+  const int lane = threadIdx.x & 63, col = lane & 15, ko = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x / p.tiles_m, mt = blockIdx.x - n * p.tiles_m;
+  const int pix = p.Dc * p.Hc * p.Wc;
+  bf16x8 wa[2][CT][KS];
+  float bs[CT][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const char* wc = p.w[wave + 4 * c];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int row = ct * 16 + col;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int ci = (s * 4 + ko) * 8;
+        uint4 v{0u, 0u, 0u, 0u};
+        if (row < p.Co && row < p.w_rows && ci < p.Ci) v = *reinterpret_cast<const uint4*>(wc + ((size_t)row * p.Kp + ci) * 2);
+        wa[c][ct][s] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = ct * 16 + ko * 4 + i;
+      bs[ct][i] = (p.bias && co < p.Co) ? p.bias[co] : 0.f;
+    }
+  float s1[2][CT][4], s2[2][CT][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s1[c][ct][i] = 0.f; s2[c][ct][i] = 0.f; }
+  const char* in_n = p.in + ((size_t)n * pix * p.in_cs + p.in_co) * 2;
+  char* out_n = p.out + ((size_t)n * p.Do * p.Ho * p.Wo * p.out_cs + p.out_co) * 2;
+  const int m0 = mt * p.bm;
+  auto ldx = [&](int m, bf16x8 (&xb)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ci = (s * 4 + ko) * 8;
+      uint4 x{0u, 0u, 0u, 0u};
+      if (m < pix && ci < p.Ci) x = *reinterpret_cast<const uint4*>(in_n + ((size_t)m * p.in_cs + ci) * 2);
+      xb[s] = __builtin_bit_cast(bf16x8, x);
+    }
+  };
+  bf16x8 xcur[KS], xnext[KS];
+  ldx(m0 + col, xcur);
+  const int ntile = p.bm >> 4;
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const int m = m0 + t * 16 + col;
+    if (t + 1 < ntile) ldx(m + 16, xnext);
+    const bool valid = m < pix;
+    const int zy = div_small(m, p.Wc, p.rcp_wc);
+    const int x = m - zy * p.Wc;
+    const int z = div_small(zy, p.Hc, p.rcp_hc);
+    const int y = zy - z * p.Hc;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cls = wave + 4 * c;
+      const size_t ov = ((size_t)(2 * z + p.cpz[cls]) * p.Ho + (2 * y + p.cpy[cls])) * p.Wo + (2 * x + p.cpx[cls]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        f32x4 acc{bs[ct][0], bs[ct][1], bs[ct][2], bs[ct][3]};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][ct][s], xcur[s], acc, 0, 0, 0);
+        const int co = ct * 16 + ko * 4;
+        if (valid && co < p.Co) {
+          float r[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s1[c][ct][i] += acc[i];
+            s2[c][ct][i] += acc[i] * acc[i];
+            r[i] = apply_act_small(acc[i], p.act, p.slope);
+          }
+          *reinterpret_cast<uint2*>(out_n + (ov * p.out_cs + co) * 2) = uint2{pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3])};
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xcur[s] = xnext[s];
+  }
+  if (p.stats_slots > 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int cls = wave + 4 * c;
+      float* spt = p.stats + (((size_t)n * p.stats_slots + p.cslot0[cls] + mt) * 2) * p.Co;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = row16_sum(s1[c][ct][i]), q = row16_sum(s2[c][ct][i]);
+          const int co = ct * 16 + ko * 4 + i;
+          if (col == 0 && co < p.Co) { spt[co] = a; spt[p.Co + co] = q; }
+        }
+    }
+  }
+}
 }  // namespace
 
 static bool pwise_conv_ok(const gs_gconv_desc* d) {
@@ -207,5 +326,51 @@ int gs_pwise_wgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, flo
   else if (G == 2) hipLaunchKernelGGL(pwise_wgrad_kernel<2>, dim3((unsigned)groups), dim3(256), 0, st, k);
   else hipLaunchKernelGGL(pwise_wgrad_kernel<4>, dim3((unsigned)groups), dim3(256), 0, st, k);
   GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// gconv.hip (gs_gconv_forward_multi): the 8 one-tap parity classes of a k2 stride-2 volume layer in one launch
+int gs_pwise_multi_try(const gs_gconv_desc* const* descs, int count, const void* in, const void* const* w_packs, const float* bias,
+                       void* out, float* stats, void* stream, int* handled) {
+  *handled = 0;
+  const gs_gconv_desc* d = descs[0];
+  if (!gs_opt(GS_OPT_PWISE) || count != 8 || d->so != 2 || d->si != 1 || d->Co > 64 || d->Ci > 128 || d->accumulate) return 0;
+  const long long pix = (long long)d->Dc * d->Hc * d->Wc;
+  if (d->Dc != d->Di || d->Hc != d->Hi || d->Wc != d->Wi || d->Do != 2 * d->Dc || d->Ho != 2 * d->Hc || d->Wo != 2 * d->Wc ||
+      pix >= (1LL << 24) || (long long)d->N * pix < (long long)gs_opt(GS_OPT_PWISE) * 2048)
+    return 0;
+  for (int c = 0; c < count; ++c) {
+    const gs_gconv_desc* dc = descs[c];
+    if (dc->T != 1 || dc->dd[0] || dc->dh[0] || dc->dw[0] || dc->Kp != d->Kp || (unsigned)dc->pz > 1u || (unsigned)dc->py > 1u ||
+        (unsigned)dc->px > 1u)
+      return 0;
+  }
+  PwMK k;
+  k.in = static_cast<const char*>(in);
+  for (int c = 0; c < 8; ++c) {
+    k.w[c] = static_cast<const char*>(w_packs[c]);
+    k.cpz[c] = descs[c]->pz; k.cpy[c] = descs[c]->py; k.cpx[c] = descs[c]->px; k.cslot0[c] = descs[c]->stats_slot0;
+  }
+  k.bias = bias; k.out = static_cast<char*>(out); k.stats = stats;
+  k.N = d->N; k.Dc = d->Dc; k.Hc = d->Hc; k.Wc = d->Wc; k.Do = d->Do; k.Ho = d->Ho; k.Wo = d->Wo;
+  k.Ci = d->Ci; k.Co = d->Co; k.in_cs = d->in_cs; k.in_co = d->in_co; k.out_cs = d->out_cs; k.out_co = d->out_co;
+  k.Kp = d->Kp; k.w_rows = d->w_rows; k.act = d->act; k.slope = d->slope;
+  k.rcp_wc = 1.0f / (float)d->Wc; k.rcp_hc = 1.0f / (float)d->Hc;
+  k.bm = d->Co <= 16 ? 256 : 128;                    // gconv.hip pick_tile: one statistics slot per pixel tile and class
+  k.tiles_m = (int)((pix + k.bm - 1) / k.bm);
+  k.stats_slots = d->stats_slots;
+  const long long blocks = (long long)d->N * k.tiles_m;
+  if (blocks >= (1LL << 31)) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ks = (d->Ci + 31) / 32, ct = (d->Co + 15) / 16;
+#define GS_PWM(KS_, CT_)                                                                                        \
+  if (ks == KS_ && ct == CT_) {                                                                                 \
+    hipLaunchKernelGGL((pwise_multi_kernel<KS_, CT_>), dim3((unsigned)blocks), dim3(256), 0, st, k);            \
+    GS_CHECK_HIP(hipGetLastError());                                                                            \
+    *handled = 1;                                                                                               \
+    return 0;                                                                                                   \
+  }
+  GS_PWM(1, 1) GS_PWM(2, 1) GS_PWM(4, 1) GS_PWM(1, 2) GS_PWM(2, 2) GS_PWM(4, 2) GS_PWM(2, 4) GS_PWM(4, 4)
+#undef GS_PWM
   return 0;
 }

@@ -1022,6 +1022,64 @@ def test_persistent_narrow_volume_kernel(hip_ops, case):
     close_bf16(G2, G0.cpu(), "data gradient, hconv2 vs hconv2 = 0")
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("convT", 64, 16, 2, 2, 0, dims=3), 1, 24, 24, 32),      # V-Net up conv: 8 one-tap classes, bias + statistics
+    (ConvSpec("convT", 128, 64, 2, 2, 0, dims=3), 2, 16, 24, 24),     # four 32-channel k steps, four output tiles
+    (ConvSpec("convT", 32, 24, 2, 2, 0, dims=3), 1, 25, 27, 29),      # voxel count not a multiple of the tile, 24 -> 32 channels
+    (ConvSpec("conv", 16, 32, 2, 2, 0, dims=3), 1, 48, 48, 64),       # V-Net down conv: its data gradient
+], ids=_ids)
+def test_one_tap_parity_classes(hip_ops, case):
+    """pwise_multi_kernel (pwise.hip: the 8 one-tap output-parity classes of a k2 stride-2 volume layer from register operands)
+    against the merged im2col launch of the same library (pwise = 0) and the oracle: outputs to bf16 rounding, every statistics
+    slot written, totals to fp32 summation order"""
+    ops = hip_ops
+    spec, N, sizes = case[0], case[1], case[2:]
+    low, master, bias, fpack, dpack = make_layer(spec, sizes, 71)
+    g = torch.Generator().manual_seed(72)
+    dev = ops.device
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16)
+    fwd_multi, dg_multi = len(low.fwd) == 8, len(low.dgrad) == 8
+    assert fwd_multi or dg_multi
+    res = {}
+    default = ops.get_option("pwise")
+    try:
+        for on in (1, 0):
+            ops.set_option("pwise", on)
+            out = {}
+            if fwd_multi:
+                slots, offs = stats_slots(ops, low, low.fwd, N)
+                ya = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16, device=dev)
+                part = torch.full((N * slots * 2 * spec.cout_p,), float("nan"), dtype=torch.float32, device=dev)
+                ops.gconv_classes(low.fwd, xa.to(dev), fpack.to(dev), bias.to(dev), ya, act="lrelu", slope=0.25, stats=part,
+                                  stats_slots=slots, stats_slot0s=offs)
+                assert not torch.isnan(part).any()
+                out["y"], out["stats"] = ya.cpu(), part.view(N, slots, 2, spec.cout_p).sum(1).cpu()
+            if dg_multi:
+                gx = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16, device=dev)
+                ops.gconv_classes(low.dgrad, gy.to(dev), dpack.to(dev), None, gx)
+                out["gx"] = gx.cpu()
+            torch.cuda.synchronize()
+            res[on] = out
+    finally:
+        ops.set_option("pwise", default)
+    ref = RefOps()
+    if fwd_multi:
+        yr = torch.zeros(N, *low.out_dims, spec.cout_p, dtype=torch.bfloat16)
+        pr = torch.zeros(N * 8 * 2 * spec.cout_p, dtype=torch.float32)
+        ref.gconv_classes(low.fwd, xa, fpack, bias, yr, act="lrelu", slope=0.25, stats=pr, stats_slots=8,
+                          stats_slot0s=list(range(8)))
+        close_bf16(res[1]["y"], res[0]["y"], "forward vs the im2col launch")
+        close_bf16(res[1]["y"], yr, "forward vs oracle")
+        close_f32(res[1]["stats"], res[0]["stats"], "statistics totals vs the im2col launch", rel=2e-3)
+        close_f32(res[1]["stats"], pr.view(N, 8, 2, spec.cout_p).sum(1), "statistics totals vs oracle", rel=2e-3)
+    if dg_multi:
+        gr = torch.zeros(N, *low.dgrad_dims, spec.cin_p, dtype=torch.bfloat16)
+        ref.gconv_classes(low.dgrad, gy, dpack, None, gr)
+        close_bf16(res[1]["gx"], res[0]["gx"], "data gradient vs the im2col launch")
+        close_bf16(res[1]["gx"], gr, "data gradient vs oracle")
+
+
 def test_gconv_accumulate_with_split_k(hip_ops):
     """the accumulate-into form on a layer that runs split-K (64 -> 64 channel k5 coupling conv of the V-Net at 16^3: 32 output
     tiles, K = 8000): the finalize pass does the bf16 read-modify-write of gconv_kernel's own accumulate epilogue"""
