@@ -155,6 +155,21 @@ class BaseGAN(ABC):
             if last:
                 st["busy"], st["fork"] = False, None
 
+    def arm_early_update(self, name):
+        """before the backward pass of a network group that takes ONE backward pass per step: its optimiser updates the layers
+        the pass is done with on the 'opt' stream while the pass goes on (NativeAdam.arm_early). GS_EARLY_ADAM=0: off;
+        =inline: chunks on the current stream (tests, any backend)."""
+        mode = os.environ.get("GS_EARLY_ADAM", "1")
+        optim = self.optimizers[name]
+        if mode == "0" or not hasattr(optim, "arm_early"):
+            return False
+        if mode == "inline":
+            return optim.arm_early(None)
+        st = getattr(self, "_side", {}).get("opt")
+        if st is None or not self._side_stream_enabled("opt"):
+            return False
+        return optim.arm_early(st["stream"])
+
     # ---- captured training step -------------------------------------------------------------------------------
     def _init_step_graph(self):
         """Decide whether iterations run as graph replays. Off for backends without streams (the CPU test oracle) and

@@ -25,7 +25,7 @@ class Pix2PixConditionalGANConfig(configs.base.BaseGANConfig):
 
 class Pix2PixConditionalGAN(BaseGAN):
     graph_capturable = True      # fixed launch sequence, no image pool
-    side_stream_names = ("D",)
+    side_stream_names = ("D", "opt")
 
     def __init__(self, conf):
         super().__init__(conf)
@@ -54,6 +54,8 @@ class Pix2PixConditionalGAN(BaseGAN):
         # ------------------------ G ------------------------
         self.set_requires_grad(self.networks["D"], False)
         self.optimizers["G"].zero_grad(set_to_none=True)
+        # (the generator takes one backward pass per step: its update runs layer group by layer group under that pass)
+        self.arm_early_update("G")
         self.backward_G()
         self.optimizers["G"].step()
         # ------------------------ D ------------------------

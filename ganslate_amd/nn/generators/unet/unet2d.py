@@ -208,6 +208,8 @@ class Unet2D(NativeNet):
                 if final_pass:
                     self._maybe_reduce_bucket(i)
             gcat[k] = self._dgrad(i, lw, pk, dy, N)        # gradient w.r.t. ReLU(cat([h_k, u_{k+1}])) (or ReLU(h_D))
+            if want_w:                                     # (node up(k)'s bias gradient came with iteration k - 1 for k > 1)
+                self._early_step_at(i)
             if k < D:                                      # second half -> u_{k+1} = drop(IN(up_{k+1} raw))
                 dy = torch.empty_like(s.yu[k + 1])
                 p = 0.5 if (k + 1 in self.dropout_levels and s.seed) else 0.0
@@ -234,6 +236,8 @@ class Unet2D(NativeNet):
                     self._maybe_reduce_bucket(i)
             if k > 1 or need_input_grad:
                 gL = self._dgrad(i, lw, pk, dy, N)
+            if want_w:
+                self._early_step_at(i)
         if not need_input_grad:
             return None
         g_in = torch.empty_like(s.x_img)
