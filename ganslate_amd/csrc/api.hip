@@ -94,6 +94,8 @@ OptDef g_opts[GS_OPT_COUNT] = {
                                 // >= 2: also 64 -> 64 channels — wide on both sides — instead of the split-K im2col launch + its finalize;
                                 // >= 3: 32-channel layers on <= 128 boxes as two 16-channel groups per box)
     {"pwise", 8},               // pwise.hip: register-operand kernels for one-tap layers with <= 8 channels on one side (smallest volume in 2048-voxel units, 0 = off)
+    {"adam_blocks", 8192},      // optim.hip: largest grid of the Adam update (the chunks launched under a backward pass take fewer: they
+                                // must not crowd the pass's own launches out of the CUs)
 };
 }  // namespace
 int gs_opt(int id) { return g_opts[id].value; }

@@ -182,7 +182,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum GsOpt {
   GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE,
   GS_OPT_HWGRAD, GS_OPT_HWGRAD_WIDE, GS_OPT_HWGRAD_PLANES, GS_OPT_NORM_BWD_PPB, GS_OPT_NORM_APPLY_UNROLL,
-  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONVW_PERSIST, GS_OPT_HSTRIP_REGS, GS_OPT_GCONV_TWIN, GS_OPT_WGRAD_TWIN, GS_OPT_GCONV_SMALLK, GS_OPT_GCONV_PERSIST, GS_OPT_HCONVT_PERSIST, GS_OPT_RING_APPLY, GS_OPT_NORM_XCD, GS_OPT_WGRAD_ROWS, GS_OPT_SPLITK_MULTI, GS_OPT_SPLITK_RING, GS_OPT_GCONV_RING4, GS_OPT_RING_DBG, GS_OPT_HCONV5, GS_OPT_HCONV5_SEG, GS_OPT_HWGRAD2, GS_OPT_HCONV2, GS_OPT_PWISE,
+  GS_OPT_GCONV_TILE288, GS_OPT_GCONV_MULTI, GS_OPT_HCONVW_RING, GS_OPT_HCONVT, GS_OPT_HSTRIP, GS_OPT_WFOLD_ROWS, GS_OPT_HWGRAD_FT, GS_OPT_GCONV_BIG, GS_OPT_HCONV_BOX8, GS_OPT_HCONVW_PERSIST, GS_OPT_HSTRIP_REGS, GS_OPT_GCONV_TWIN, GS_OPT_WGRAD_TWIN, GS_OPT_GCONV_SMALLK, GS_OPT_GCONV_PERSIST, GS_OPT_HCONVT_PERSIST, GS_OPT_RING_APPLY, GS_OPT_NORM_XCD, GS_OPT_WGRAD_ROWS, GS_OPT_SPLITK_MULTI, GS_OPT_SPLITK_RING, GS_OPT_GCONV_RING4, GS_OPT_RING_DBG, GS_OPT_HCONV5, GS_OPT_HCONV5_SEG, GS_OPT_HWGRAD2, GS_OPT_HCONV2, GS_OPT_PWISE, GS_OPT_ADAM_BLOCKS,
   GS_OPT_COUNT
 };
 int gs_opt(int id);

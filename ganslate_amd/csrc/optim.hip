@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void adam_dev_packs_kernel(float* p, float* g,
 static long long adam_blocks(int64_t n) {
   long long blocks = (n / 4 + 511) / 512;         // two 16-byte vectors per thread per pass
   if (blocks < 1) blocks = 1;
-  if (blocks > 8192) blocks = 8192;
+  const long long cap = gs_opt(GS_OPT_ADAM_BLOCKS) > 0 ? gs_opt(GS_OPT_ADAM_BLOCKS) : 8192;
+  if (blocks > cap) blocks = cap;
   return blocks;
 }
 

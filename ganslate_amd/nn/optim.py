@@ -1,6 +1,8 @@
 """Fused flat Adam over the executor's master buffers (gs_adam_step). Subclasses torch.optim.Optimizer so the
 reference's LambdaLR schedule (nn/utils.py:83-99) and `param_groups[0]['lr']` logging (base.py:318-319) work
 unchanged; constructor signature mirrors torch.optim.Adam(params, lr, betas) as used in cyclegan.py:81-82."""
+import os
+
 import torch
 
 from .native.backend import get_ops
@@ -42,9 +44,11 @@ class NativeAdam(torch.optim.Optimizer):
     # ---- the update in chunks under the backward pass -----------------------------------------------------------------------
     # torch's `loss.backward(); optimizer.step()` (pix2pix.py:84-88) updates after the whole backward pass. A layer's parameters
     # are done with once its own gradients are launched (NativeNet._early_step_at), so for networks that take ONE backward pass
-    # per step the update of the layers already passed can run on another stream while the pass goes on: same arithmetic per
-    # element, the 1.1 ms HBM-bound update of Pix2Pix's 178 M-parameter generator under its latency-bound backward pass.
-    # arm_early() before backward(), step() as always (it updates what the pass did not hand over and joins the stream).
+    # per step the update of the layers already passed can be launched while the pass goes on: same arithmetic per element.
+    # Pix2Pix's 178 M-parameter generator (update 1.1 ms at HBM rate): as launches BETWEEN the pass's own, each chunk right
+    # behind the weight gradients it consumes, the step takes 3.65 instead of 3.82 ms; on a stream of its own beside the pass
+    # it takes 4.1 ms (the HBM-bound chunks slow the pass's weight-streaming launches more than they hide;
+    # profiles/r06_ab_pix2pix.txt). arm_early() before backward(), step() as always (it updates what the pass did not hand over).
     EARLY_MIN = 1 << 21          # smallest chunk worth a launch (elements)
 
     def arm_early(self, stream=None):
@@ -60,7 +64,7 @@ class NativeAdam(torch.optim.Optimizer):
         for net in nets:
             net._early_step = self._early_chunk
             net._early_cursor = net.b_off[-1] + net.nodes[-1].spec.cout_p      # end of the node parameters
-            net._early_min = self.EARLY_MIN
+            net._early_min = int(os.environ.get("GS_EARLY_ADAM_MIN", self.EARLY_MIN))
         return True
 
     @torch.no_grad()
@@ -89,8 +93,14 @@ class NativeAdam(torch.optim.Optimizer):
         ev = streams.new_event()
         ev.record()
         side.wait_event(ev)
+        ops = get_ops()
+        cap = int(os.environ.get("GS_EARLY_ADAM_BLOCKS", "0")) if hasattr(ops, "lib") else 0
+        if cap:      # (the grid is fixed when the launch is enqueued)
+            ops.lib.gs_set_option(b"adam_blocks", cap)
         with torch.cuda.stream(side):
             self._update_range(p, net, start, end)
+        if cap:
+            ops.lib.gs_set_option(b"adam_blocks", 8192)
 
     @torch.no_grad()
     def step(self, closure=None):

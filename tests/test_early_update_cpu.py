@@ -46,7 +46,7 @@ def _run(monkeypatch, mode, n_steps=2):
 
 def test_chunked_update_equals_update_after_backward(fp32_oracle_backend, monkeypatch):
     late = _run(monkeypatch, "0")
-    early = _run(monkeypatch, "inline")
+    early = _run(monkeypatch, "1")
     assert not late["chunks"] and early["step"] == late["step"] == 2
     # every step handed the whole flat buffer over in descending, adjoining chunks (several per step)
     per_step = len(early["chunks"]) // 2

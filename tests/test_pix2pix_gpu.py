@@ -78,15 +78,16 @@ def test_dropout_mask_changes_between_graph_replays(hip_ops):
 
 
 def test_chunked_generator_update_under_backward(hip_ops, monkeypatch):
-    """NativeAdam.arm_early: the generator's update runs layer group by layer group on the 'opt' stream while its one backward pass
-    of the step (pix2pix.py:84-88) goes on — launch by launch and as graph replays — against the update after the pass
-    (GS_EARLY_ADAM=0): parameters, moments and packs bit for bit, losses equal."""
+    """NativeAdam.arm_early: the generator's update runs layer group by layer group while its one backward pass of the step
+    (pix2pix.py:84-88) goes on — between the pass's launches (default) and on the 'opt' stream beside them (GS_EARLY_ADAM=stream),
+    launch by launch and as graph replays — against the update after the pass (GS_EARLY_ADAM=0): parameters, moments and packs
+    bit for bit, losses equal."""
     from ganslate_amd.nn.optim import NativeAdam
     monkeypatch.setattr(NativeAdam, "EARLY_MIN", 1 << 14)
     c = dict(size=[64, 128], batch=2, steps=5, n_iters=100, n_iters_decay=100, num_downs=6, ngf=16, use_dropout=False,
              n_layers=3, lambda_pix2pix=30.0, seed=36)
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "stream"):
         monkeypatch.setenv("GS_EARLY_ADAM", mode)
         model = build_product_pix2pix(c)
         opt, chunks = model.optimizers["G"], []
@@ -100,10 +101,12 @@ def test_chunked_generator_update_under_backward(hip_ops, monkeypatch):
         pk = next(iter(G._packs.values()))
         res[mode] = dict(master=G.master.detach().clone(), m=st["exp_avg"].clone(), v=st["exp_avg_sq"].clone(),
                          fpack=pk["fpack"].clone(), dpack=pk["dpack"].clone(), logs=logs, chunks=chunks)
-    assert not res["0"]["chunks"] and len(res["1"]["chunks"]) >= 3, "the early form must have handed chunks over"
-    for k in ("master", "m", "v", "fpack", "dpack"):
-        assert torch.equal(res["1"][k], res["0"][k]), k
-    assert res["1"]["logs"] == res["0"]["logs"]
+    assert not res["0"]["chunks"]
+    for mode in ("1", "stream"):
+        assert len(res[mode]["chunks"]) >= 3, "the early form must have handed chunks over"
+        for k in ("master", "m", "v", "fpack", "dpack"):
+            assert torch.equal(res[mode][k], res["0"][k]), (mode, k)
+        assert res[mode]["logs"] == res["0"]["logs"], mode
 
 
 def test_pix2pix_data_parallel_graph_step(hip_ops, monkeypatch):
