@@ -178,6 +178,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- Adam (optim.hip; wgrad.hip's fused epilogue) ----------------------------------------------------------------------
+// One element of the update; the same expression for the scalar tail and the four lanes of a 16-byte access.
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float b1, float b2, float eps,
+                                         float bc2_sqrt, float step_size, float gscale, int zero_grad) {
+  const float gi = g * gscale;
+  const float mi = m + (gi - m) * (1.f - b1);                  // torch: exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v * b2 + (1.f - b2) * gi * gi;              // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p = p - step_size * (mi / denom);
+  m = mi;
+  v = vi;
+  if (zero_grad) g = 0.f;
+}
+
+
 // kernel-selection switches (api.hip; set through gs_set_option, never read from the environment by the library)
 enum GsOpt {
   GS_OPT_SPLITK, GS_OPT_SPLITK_MAX_BLOCKS, GS_OPT_SPLITK_TARGET, GS_OPT_HCONV, GS_OPT_HCONV_WIDE,

@@ -4,18 +4,7 @@
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 #include "common.hpp"
 
-// One element of the update; the same expression for the scalar tail and the four lanes of a 16-byte access.
-__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float b1, float b2, float eps,
-                                         float bc2_sqrt, float step_size, float gscale, int zero_grad) {
-  const float gi = g * gscale;
-  const float mi = m + (gi - m) * (1.f - b1);                  // torch: exp_avg.lerp_(grad, 1-beta1)
-  const float vi = v * b2 + (1.f - b2) * gi * gi;              // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p = p - step_size * (mi / denom);
-  m = mi;
-  v = vi;
-  if (zero_grad) g = 0.f;
-}
+// (adam_one — one element of the update — lives in common.hpp: the fused weight-gradient epilogue of wgrad.hip runs it too)
 
 // 28-32 bytes of HBM traffic per parameter and nothing else: 16-byte accesses, two of them per array in flight per
 // thread (dword accesses with one element per iteration ran at 1.5 TB/s: 469 us for the 57 M parameters of pix2pix's

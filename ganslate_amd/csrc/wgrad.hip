@@ -27,6 +27,8 @@ struct WGradK {
   int nets, splits_net, m_net;
   int vec, rmw;               // vec: every row of dw / ws starts on a 16-byte boundary; rmw: one split per network (see the epilogue)
   long long dw_delta;
+  int adam;                   // gs_wgrad_adam: the epilogue updates the parameters instead of storing the sums
+  gs_adam_fuse ad;
   gs_wgrad_desc d;
 };
 
@@ -250,7 +252,28 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
       const int rr = (it * NW + wave) * RPI + rsub, pp = tp * BP + rr;
       if (rr < BP && pp < d.P && col < TQ) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ct + rr * CP + c4);
-        *reinterpret_cast<f32x4*>(obase + (size_t)pp * d.dw_ld + col) = old[it] + v;
+        if (p.adam) {
+          // the only gradient of these four elements in this optimiser step: update them here (gs_adam_step_dev_packs' arithmetic)
+          const size_t e = (size_t)pp * d.dw_ld + col;
+          const float b1 = p.ad.hyper[1], b2 = p.ad.hyper[2], eps = p.ad.hyper[3], bc2_sqrt = p.ad.hyper[5];
+          const float step_size = p.ad.hyper[0] / p.ad.hyper[4];
+          float4 P = *reinterpret_cast<const float4*>(p.ad.p + e), M = *reinterpret_cast<const float4*>(p.ad.m + e);
+          float4 V = *reinterpret_cast<const float4*>(p.ad.v + e), G = {v[0], v[1], v[2], v[3]};
+          adam_one(P.x, G.x, M.x, V.x, b1, b2, eps, bc2_sqrt, step_size, 1.0f, 0);
+          adam_one(P.y, G.y, M.y, V.y, b1, b2, eps, bc2_sqrt, step_size, 1.0f, 0);
+          adam_one(P.z, G.z, M.z, V.z, b1, b2, eps, bc2_sqrt, step_size, 1.0f, 0);
+          adam_one(P.w, G.w, M.w, V.w, b1, b2, eps, bc2_sqrt, step_size, 1.0f, 0);
+          *reinterpret_cast<float4*>(p.ad.p + e) = P;
+          *reinterpret_cast<float4*>(p.ad.m + e) = M;
+          *reinterpret_cast<float4*>(p.ad.v + e) = V;
+          const uint2 o = {pack_bf2(P.x, P.y), pack_bf2(P.z, P.w)};
+          const size_t grp = e >> 3, half = (e >> 2) & 1;
+          const int jf = p.ad.inv_f ? p.ad.inv_f[grp] : -1, jd = p.ad.inv_d ? p.ad.inv_d[grp] : -1;
+          if (jf >= 0) static_cast<uint2*>(p.ad.fpack)[(size_t)jf * 2 + half] = o;
+          if (jd >= 0) static_cast<uint2*>(p.ad.dpack)[(size_t)jd * 2 + half] = o;
+        } else {
+          *reinterpret_cast<f32x4*>(obase + (size_t)pp * d.dw_ld + col) = old[it] + v;
+        }
       }
     }
     return;
@@ -318,6 +341,8 @@ int launch_wgrad_impl(WGradK& k, const gs_wgrad_desc* d, hipStream_t st, int pla
   k.vec = gs_opt(GS_OPT_WGRAD_ROWS) != 0 && (reinterpret_cast<uintptr_t>(k.dw) & 15) == 0 && (k.dw_delta & 3) == 0 &&
           (reinterpret_cast<uintptr_t>(k.ws) & 15) == 0 && (k.ws_stride & 3) == 0;
   if (plan_only) return 0;
+  GS_REQUIRE(!k.adam || (splits == 1 && k.vec && k.rmw && k.nets == 1 && d->dw_ld % 8 == 0),
+             "gs_wgrad_adam: not a one-split launch with 16-byte rows (gs_wgrad_adam_eligible)");
   constexpr int lds = 3 * 64 * (BP + BQ) * 2 + GS_MAX_TAPS * 4 + 1024;
   static bool configured = false;
   if (!configured) {
@@ -414,7 +439,7 @@ int gs_pwise_wgrad_try(const gs_wgrad_desc* d, const void* a, const void* g, flo
 namespace {
 // the im2col kernel for one operand pair; ws != nullptr: partial tiles to slabs, *slabs = how many
 int wgrad_generic(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, float* ws, int plan_only,
-                  void* stream, int* slabs, const gs_twin* tw = nullptr) {
+                  void* stream, int* slabs, const gs_twin* tw = nullptr, const gs_adam_fuse* adam = nullptr) {
   WGradK k;
   k.nets = tw ? 2 : 1;                                       // (*slabs: per network)
   k.dw_delta = tw ? tw->dw_delta / 4 : 0;
@@ -423,6 +448,8 @@ int wgrad_generic(const gs_wgrad_desc* d, const void* a, const void* g, float* d
   k.dw = dw;
   k.ws = ws;
   k.ws_stride = (long long)d->P * d->dw_ld;
+  k.adam = adam ? 1 : 0;
+  if (adam) k.ad = *adam; else k.ad = gs_adam_fuse{};
   k.zero = static_cast<const char*>(gs_zero_page());
   GS_REQUIRE(k.zero || plan_only, "gs_wgrad: library not initialised (call gs_init)");
   int sh = 0;
@@ -537,6 +564,31 @@ extern "C" int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, fl
 
 // dw += wgrad(a1, g1) + wgrad(a2, g2) for two operand pairs of the SAME layer and shapes (the two backward passes a
 // network sees per step): one launch where the kernel can merge them (fixed costs paid once), else two
+// one-split layers of the im2col kernel (what no halo-resident / pointwise kernel takes): weight gradient + Adam in one launch
+extern "C" int gs_wgrad_adam_eligible(const gs_wgrad_desc* d) {
+  if (!d || wgrad_check(d) || !gs_opt(GS_OPT_WGRAD_ROWS) || d->dw_ld % 8) return 0;
+  static const char dummy = 0;
+  int handled = 0;
+  if (gs_pwise_wgrad_try(d, &dummy, &dummy, nullptr, nullptr, 1, nullptr, &handled) || handled) return 0;
+  if (gs_hwgrad_try2(d, &dummy, &dummy, nullptr, nullptr, nullptr, nullptr, 1, nullptr, &handled, nullptr) || handled) return 0;
+  int slabs = -1;
+  if (wgrad_generic(d, &dummy, &dummy, nullptr, nullptr, 1, nullptr, &slabs) || slabs != 0) return 0;
+  return 1;
+}
+extern "C" int gs_wgrad_adam(const gs_wgrad_desc* d, const void* a, const void* g, const gs_adam_fuse* adam, void* stream) {
+  GS_REQUIRE(d && a && g && adam && adam->p && adam->m && adam->v && adam->hyper, "gs_wgrad_adam: null argument");
+  GS_REQUIRE((adam->inv_f == nullptr) == (adam->fpack == nullptr) && (adam->inv_d == nullptr) == (adam->dpack == nullptr),
+             "gs_wgrad_adam: an index table and its pack go together");
+  GS_REQUIRE(((reinterpret_cast<uintptr_t>(adam->p) | reinterpret_cast<uintptr_t>(adam->m) | reinterpret_cast<uintptr_t>(adam->v) |
+               reinterpret_cast<uintptr_t>(adam->fpack) | reinterpret_cast<uintptr_t>(adam->dpack)) & 15) == 0,
+             "gs_wgrad_adam: buffers must be 16-byte aligned");
+  GS_REQUIRE(gs_wgrad_adam_eligible(d), "gs_wgrad_adam: this layer does not run as a one-split im2col launch (gs_wgrad_adam_eligible)");
+  gs_wgrad_desc fresh = *d;
+  fresh.dw_fresh = 1;                                 // (nothing of a gradient buffer is read)
+  int slabs = 0;
+  return wgrad_generic(&fresh, a, g, adam->p, nullptr, 0, stream, &slabs, nullptr, adam);
+}
+
 extern "C" int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2,
                              float* dw, void* stream) {
   GS_REQUIRE(d && a1 && g1 && a2 && g2 && dw, "gs_wgrad_pair: null argument");

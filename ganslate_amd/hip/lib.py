@@ -47,6 +47,12 @@ class Twin(C.Structure):
                 ("dw_delta", C.c_int64)]
 
 
+class AdamFuse(C.Structure):
+    """Mirror of gs_adam_fuse."""
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("hyper", C.c_void_p), ("inv_f", C.c_void_p),
+                ("fpack", C.c_void_p), ("inv_d", C.c_void_p), ("dpack", C.c_void_p)]
+
+
 class NormDbItem(C.Structure):
     """Mirror of gs_norm_db_item."""
     _fields_ = [("sums", C.c_void_p), ("mean_rstd", C.c_void_p), ("db", C.c_void_p), ("N", C.c_int32), ("C", C.c_int32),
@@ -112,6 +118,8 @@ _PROTOS = {
     "gs_wgrad_pair": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "gs_wgrad": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gs_wgrad_adam_eligible": (C.c_int, [C.POINTER(WGradDesc)]),
+    "gs_wgrad_adam": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.POINTER(AdamFuse), C.c_void_p]),
     "gs_wgrad_ws_floats": (C.c_int64, [C.POINTER(WGradDesc), C.c_int32]),
     "gs_wgrad_ws": (C.c_int, [C.POINTER(WGradDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.c_void_p]),

@@ -458,6 +458,46 @@ class HipOps(TwinSplit):
                 and all(w.dd[9 * k + t] == w.dd[9 * k] and w.dh[9 * k + t] == w.dh[t] and w.dw[9 * k + t] == w.dw[t]
                         for k in range(3) for t in range(9)))
 
+    def _wdesc(self, w: WGrad, N, a_cs, a_co, g_cs, g_co, fresh=False):
+        d = L.WGradDesc()
+        d.dw_fresh = int(fresh)
+        d.N, d.Ha, d.Wa, d.P = N, w.Ha, w.Wa, w.P
+        d.Da, d.Dg = w.Da, w.Dg
+        d.a_cs, d.a_co = a_cs, a_co
+        d.Hg, d.Wg, d.Q = w.Hg, w.Wg, w.Q
+        d.g_cs, d.g_co = g_cs, g_co
+        d.si, d.T, d.border, d.dw_ld = w.si, w.T, L.BORDER[w.border], w.T * w.Q
+        for i, (p, q, r) in enumerate(zip(w.dh, w.dw, w.dd)):
+            d.dh[i], d.dw_[i], d.dd[i] = p, q, r
+        return d
+
+    def wgrad_adam(self, w: WGrad, a, g, p, m, v, hyper_dev, packs=None) -> bool:
+        """weight gradient + Adam of ONE layer in one launch (gs_wgrad_adam): p / m / v are the layer's slices of the flat
+        buffers, packs = (inv_f slice, fpack, inv_d slice, dpack) as for adam_step_dev. Returns False (nothing launched) where
+        the layer does not run as a one-split im2col launch — the caller then runs wgrad() and the optimiser as usual."""
+        key = ("wadam", id(w), a.shape[0], a.shape[-1], g.shape[-1])
+        ent = self._desc_cache.get(key)
+        if ent is None:
+            d = self._wdesc(w, a.shape[0], a.shape[-1], 0, g.shape[-1], 0)
+            ok = bool(self.lib.gs_wgrad_adam_eligible(C.byref(d))) and getattr(w, "p_real", 0) != 1
+            ent = (d, ok, w)
+            self._desc_cache[key] = ent
+        if not ent[1]:
+            return False
+        ad = L.AdamFuse()
+        ad.p, ad.m, ad.v, ad.hyper = p.data_ptr(), m.data_ptr(), v.data_ptr(), hyper_dev.data_ptr()
+        if packs is not None:
+            inv_f, fpack, inv_d, dpack = packs
+            if inv_f is not None:
+                ad.inv_f, ad.fpack = inv_f.data_ptr(), fpack.data_ptr()
+            if inv_d is not None:
+                ad.inv_d, ad.dpack = inv_d.data_ptr(), dpack.data_ptr()
+        t_end = self._time_begin("wgrad", w, False, a.shape[0])
+        L.check(self.lib.gs_wgrad_adam(C.byref(ent[0]), _ptr(a), _ptr(g), C.byref(ad), _stream()), "gs_wgrad_adam")
+        if t_end is not None:
+            t_end.record()
+        return True
+
     def wgrad(self, w: WGrad, a, g, dw, *, a_cs=None, a_co=0, g_cs=None, g_co=0, pair=None, fresh=False):
         """dw += the weight gradient. fresh: the caller guarantees that dw holds zeros (the layer's first weight gradient since
         the optimiser cleared the buffer, NativeNet.wgrad_fresh) — a hint (gs_wgrad_desc.dw_fresh), never a requirement"""

@@ -176,7 +176,13 @@ class Unet2D(NativeNet):
     def _param_grads(self, i, lw, x_in, dy, has_norm):
         ops, sp, grad = self.ops, self.nodes[i].spec, self.master.grad
         a_t, g_t = (dy, x_in) if sp.kind == "conv" else (x_in, dy)
-        ops.wgrad(lw.wgrad, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + sp.master_numel], fresh=self.wgrad_fresh(i))
+        fresh, fuse = self.wgrad_fresh(i), getattr(self, "_early_fuse", None)
+        # one backward pass per optimiser step (NativeAdam.arm_early) and a layer of few pixels: gradient + update in one launch
+        args = fuse(self, i) if (fuse is not None and fresh) else None
+        if args is not None and ops.wgrad_adam(lw.wgrad, a_t, g_t, *args):
+            self._early_fused.append((self.w_off[i], self.w_off[i] + sp.master_numel))
+        else:
+            ops.wgrad(lw.wgrad, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + sp.master_numel], fresh=fresh)
         if sp.bias and not has_norm:
             ops.bias_grad(dy, sp.cout_p, grad[self.b_off[i]:self.b_off[i] + sp.cout_p])
         self.grad_dirty = True
@@ -199,16 +205,21 @@ class Unet2D(NativeNet):
         dy = torch.empty_like(s.y1)
         ops.act_to_image_backward(g_img.contiguous().float(), s.out_img, dy, act="tanh")
         gcat = {}
+        # a layer whose weight gradient launch also updates its weights (gs_wgrad_adam) must have launched its data gradient:
+        # parameter gradients after the data gradient then
+        pg_last = want_w and getattr(self, "_early_fuse", None) is not None
         # ---- up path, outermost first ----
         for k in range(1, D + 1):
             i, lw = self._up(k), lows[self._up(k)]
             xin = s.R if k == D else s.cat[k]
-            if want_w:
+            if want_w and not pg_last:
                 self._param_grads(i, lw, xin, dy, has_norm=(k > 1))
                 if final_pass:
                     self._maybe_reduce_bucket(i)
             gcat[k] = self._dgrad(i, lw, pk, dy, N)        # gradient w.r.t. ReLU(cat([h_k, u_{k+1}])) (or ReLU(h_D))
             if want_w:                                     # (node up(k)'s bias gradient came with iteration k - 1 for k > 1)
+                if pg_last:
+                    self._param_grads(i, lw, xin, dy, has_norm=(k > 1))
                 self._early_step_at(i)
             if k < D:                                      # second half -> u_{k+1} = drop(IN(up_{k+1} raw))
                 dy = torch.empty_like(s.yu[k + 1])
@@ -230,13 +241,15 @@ class Unet2D(NativeNet):
             else:
                 dy = torch.empty_like(s.L[1])
                 ops.norm_act_backward_ex(gL, gcat[1], s.L[1], None, dy, act1="lrelu", act2="relu")
-            if want_w:
+            if want_w and not pg_last:
                 self._param_grads(i, lw, s.L[k - 1], dy, has_norm=(1 < k < D))
                 if final_pass:
                     self._maybe_reduce_bucket(i)
             if k > 1 or need_input_grad:
                 gL = self._dgrad(i, lw, pk, dy, N)
             if want_w:
+                if pg_last:
+                    self._param_grads(i, lw, s.L[k - 1], dy, has_norm=(1 < k < D))
                 self._early_step_at(i)
         if not need_input_grad:
             return None

@@ -61,23 +61,45 @@ class NativeAdam(torch.optim.Optimizer):
         if not self.external_prepare:
             self.prepare()
         self._early = {"stream": stream, "prepared": True, "launched": False}
+        fuse = os.environ.get("GS_WGRAD_ADAM", "1") != "0"       # (A/B switch)
         for net in nets:
             net._early_step = self._early_chunk
+            # layers of few pixels: weight gradient + update in one launch (gs_wgrad_adam) — the executor asks per layer
+            net._early_fuse = self._fuse_args if fuse else None
+            net._early_fused = []
             net._early_cursor = net.b_off[-1] + net.nodes[-1].spec.cout_p      # end of the node parameters
             net._early_min = int(os.environ.get("GS_EARLY_ADAM_MIN", self.EARLY_MIN))
         return True
 
+    @staticmethod
+    def _pack_slices(net, start, end):
+        tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
+        if not tgt:
+            return None
+        inv_f, fpack, inv_d, dpack = tgt[1]
+        g0, g1 = start // 8, (end + 7) // 8
+        return (inv_f[g0:g1] if inv_f is not None else None, fpack, inv_d[g0:g1] if inv_d is not None else None, dpack)
+
+    def _fuse_args(self, net, i):
+        """(p, m, v, hyper, packs) of layer i's weights for ops.wgrad_adam, or None"""
+        p = net.master
+        a, b = net.w_off[i], net.w_off[i] + net.nodes[i].spec.master_numel
+        if p.grad is None or a % 8 or p.data_ptr() % 16:
+            return None
+        st = self.state[p]
+        return (p.data[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["hyper"], self._pack_slices(net, a, b))
+
     @torch.no_grad()
     def _update_range(self, p, net, start, end):
+        """the update of [start, end) of the flat buffer, minus the layers that were updated with their weight gradient"""
         st = self.state[p]
-        tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
-        packs = None
-        if tgt:
-            inv_f, fpack, inv_d, dpack = tgt[1]
-            g0, g1 = start // 8, (end + 7) // 8
-            packs = (inv_f[g0:g1] if inv_f is not None else None, fpack, inv_d[g0:g1] if inv_d is not None else None, dpack)
-        get_ops().adam_step_dev(p.data[start:end], p.grad[start:end], st["exp_avg"][start:end], st["exp_avg_sq"][start:end],
-                                st["hyper"], grad_scale=1.0, zero_grad=True, packs=packs)
+        pos = start
+        for a, b in sorted(getattr(net, "_early_fused", ())) + [(end, end)]:
+            a, b = min(max(a, start), end), min(max(b, start), end)
+            if a > pos:
+                get_ops().adam_step_dev(p.data[pos:a], p.grad[pos:a], st["exp_avg"][pos:a], st["exp_avg_sq"][pos:a],
+                                        st["hyper"], grad_scale=1.0, zero_grad=True, packs=self._pack_slices(net, pos, a))
+            pos = max(pos, b)
 
     def _early_chunk(self, net, start, end):
         from ..utils import streams
@@ -123,14 +145,14 @@ class NativeAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 net = p._owner_net
                 if early:
-                    net._early_step = None
+                    net._early_step = net._early_fuse = None
                 if p.grad is None:
                     continue
                 scale = net.finish_grad_reduction()
                 st = self.state[p]
                 # the update writes the row-major bf16 weight packs as it goes where the network has one pack set
                 tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
-                if early and net._early_cursor < net.b_off[-1] + net.nodes[-1].spec.cout_p:
+                if early and (net._early_cursor < net.b_off[-1] + net.nodes[-1].spec.cout_p or net._early_fused):
                     # chunks of this pass are done (or under way on the joined stream): the layers it did not hand over and
                     # whatever follows the node parameters in the flat buffer
                     nodes_end = net.b_off[-1] + net.nodes[-1].spec.cout_p
@@ -141,6 +163,8 @@ class NativeAdam(torch.optim.Optimizer):
                     ops.adam_step_dev(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["hyper"], grad_scale=scale,
                                       zero_grad=True, packs=tgt[1] if tgt else None)
                 net.grad_dirty = False
+                if early:
+                    net._early_fused = []
                 if tgt:
                     net.mark_packs_dirty(ident_fresh=tgt[0])
                 else:

@@ -229,6 +229,22 @@ int gs_wgrad(const gs_wgrad_desc* d, const void* a, const void* g, float* dw, vo
  * generator sees per step (cyclegan.py:139-150: G_AB(real_A) and G_AB(fake_A)) — in one launch where possible */
 int gs_wgrad_pair(const gs_wgrad_desc* d, const void* a1, const void* g1, const void* a2, const void* g2, float* dw,
                   void* stream);
+/* Weight gradient + Adam in one launch, for a layer whose gradient has ONE contributor in the optimiser step (a network that
+ * takes one backward pass per step — Pix2Pix's generator, pix2pix.py:84-88 — and a layer of few pixels, where the launch is one
+ * workgroup per output tile): the tile's sums never go to memory; its workgroup updates the parameters, the moments and the bf16
+ * pack groups right away (the arithmetic of gs_adam_step_dev_packs with grad_scale 1, element for element). The gradient buffer of
+ * the layer is neither read nor written (it stays cleared). Pointers are to the LAYER's slice (element 0 = dw[0][0], a multiple of
+ * 8 elements into the flat buffers, 16-byte aligned); inv_f / inv_d as in gs_adam_step_dev_packs, offset to the slice's first
+ * group. gs_wgrad_adam_eligible: 1 when the layer runs as a one-split launch of the im2col kernel; else run gs_wgrad_ws and the
+ * optimiser as usual. */
+typedef struct gs_adam_fuse {
+  float *p, *m, *v;
+  const float* hyper;          /* device float[6]: lr, beta1, beta2, eps, 1 - beta1^t, sqrt(1 - beta2^t) */
+  const int32_t* inv_f; void* fpack;
+  const int32_t* inv_d; void* dpack;
+} gs_adam_fuse;
+int gs_wgrad_adam_eligible(const gs_wgrad_desc* d);
+int gs_wgrad_adam(const gs_wgrad_desc* d, const void* a, const void* g, const gs_adam_fuse* adam, void* stream);
 /* Deterministic form of gs_wgrad (a2 = g2 = NULL) / gs_wgrad_pair: workgroups that share output elements (split-K over
  * pixels) write partial sums to slabs of a caller-owned workspace and a second launch adds the slabs to dw in a fixed
  * order, instead of fp32 atomics on dw — two runs give bit-identical gradients (torch.use_deterministic_algorithms-like

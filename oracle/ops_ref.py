@@ -692,6 +692,13 @@ class RefOps(TwinSplit):
         if zero_grad:
             g.zero_()
 
+    def wgrad_adam(self, w, a, g, p, m, v, hyper_dev, packs=None) -> bool:
+        """gs_wgrad_adam: the layer's weight gradient, consumed by its Adam update at once (the gradient buffer is not touched)"""
+        dw = torch.zeros(p.numel(), dtype=torch.float32, device=p.device)
+        self.wgrad(w, a, g, dw)
+        self.adam_step_dev(p, dw, m, v, hyper_dev, grad_scale=1.0, zero_grad=False, packs=packs)
+        return True
+
     def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True, packs=None):
         """hyper_dev = float32[6]: lr, beta1, beta2, eps, 1-beta1^t, sqrt(1-beta2^t) — the update of adam_step with the
         scalars taken from the tensor (they were rounded to fp32 when it was written, like the kernel's arguments)"""

@@ -34,6 +34,10 @@ def _run(monkeypatch, mode, n_steps=2):
         chunks.append((start, end))
         return inner(p, net, start, end)
     monkeypatch.setattr(opt, "_update_range", spy)
+    fused = []
+    ops = backend.get_ops()
+    inner_wa = ops.wgrad_adam
+    monkeypatch.setattr(ops, "wgrad_adam", lambda w, *a, **k: (fused.append(id(w)), inner_wa(w, *a, **k))[1])
     logs = run_product_pix2pix_steps(model, c, n_steps)
     G = model.networks["G"]
     st = opt.state[G.master]
@@ -41,13 +45,14 @@ def _run(monkeypatch, mode, n_steps=2):
     G.refresh_packs(torch.zeros(1, 3, 32, 32))
     return {"master": G.master.detach().clone(), "m": st["exp_avg"].clone(), "v": st["exp_avg_sq"].clone(),
             "fpack": packs["fpack"].clone(), "dpack": packs["dpack"].clone(), "logs": logs, "chunks": chunks,
-            "numel": G.numel, "step": st["step"]}
+            "numel": G.numel, "step": st["step"], "fused": list(fused)}
 
 
 def test_chunked_update_equals_update_after_backward(fp32_oracle_backend, monkeypatch):
     late = _run(monkeypatch, "0")
     early = _run(monkeypatch, "1")
-    assert not late["chunks"] and early["step"] == late["step"] == 2
+    assert not late["chunks"] and not late["fused"] and early["step"] == late["step"] == 2
+    assert len(early["fused"]) == 2 * 10, "every layer's weight gradient of the 5-level U-Net took the fused launch (oracle ops)"
     # every step handed the whole flat buffer over in descending, adjoining chunks (several per step)
     per_step = len(early["chunks"]) // 2
     assert per_step >= 3 and len(early["chunks"]) == 2 * per_step

@@ -1448,6 +1448,55 @@ def test_adam_and_repack(hip_ops):
     assert torch.equal(outs[1][4].cpu(), outs[0][4]), "repack must be bit-exact"
 
 
+@pytest.mark.parametrize("case", [
+    (ConvSpec("conv", 64, 128, 4, 2, 1), 1, 16, 16),          # U-Net down conv at 8 x 8 output pixels: one split
+    (ConvSpec("convT", 128, 64, 4, 2, 1, 0), 2, 4, 8),        # U-Net up conv (dense side = its input)
+    (ConvSpec("conv", 32, 72, 4, 2, 1), 1, 8, 8),             # ragged tiles: 72 rows, 16 x 32 columns
+], ids=_ids)
+def test_weight_gradient_with_fused_adam(hip_ops, case):
+    """gs_wgrad_adam (one-split layers: the weight-gradient tile's workgroup updates parameters, moments and both pack sets
+    itself) against gs_wgrad_ws + gs_adam_step_dev_packs of the same library — bit for bit — and against the oracle; elements
+    around the layer's slice are untouched, no gradient buffer is written"""
+    ops = hip_ops
+    spec, N, sizes = case[0], case[1], case[2:]
+    low = lower(spec, *sizes)
+    g = torch.Generator().manual_seed(81)
+    dev = ops.device
+    xa = torch.randn(N, *sizes, spec.cin_p, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, *low.out_dims, spec.cout_p, generator=g).to(torch.bfloat16)
+    a, gt = (gy, xa) if spec.kind == "conv" else (xa, gy)
+    n, off = spec.P * spec.T * spec.Q, 64                      # the layer's slice sits 64 elements into the flat buffers
+    tot = n + 2 * off
+    p0, m0, v0 = torch.randn(tot, generator=g) * 0.05, torch.randn(tot, generator=g) * 1e-3, torch.rand(tot, generator=g) * 1e-4
+    n8 = n // 8
+    perm_f, perm_d = torch.randperm(n8, generator=g).int(), torch.randperm(n8, generator=g).int()
+    perm_d[::5] = -1                                           # groups without a row-major pack group
+    hyper = torch.tensor([2e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** 3, (1 - 0.999 ** 3) ** 0.5])
+
+    def run(o, d, fused):
+        p, m, v = p0.clone().to(d), m0.clone().to(d), v0.clone().to(d)
+        fpack = torch.zeros(n8 * 8, dtype=torch.bfloat16, device=d)
+        dpack = torch.zeros(n8 * 8, dtype=torch.bfloat16, device=d)
+        packs = (perm_f.to(d), fpack, perm_d.to(d), dpack)
+        sl = slice(off, off + n)
+        if fused:
+            assert o.wgrad_adam(low.wgrad, a.to(d), gt.to(d), p[sl], m[sl], v[sl], hyper.to(d), packs)
+        else:
+            dw = torch.zeros(n, dtype=torch.float32, device=d)
+            o.wgrad(low.wgrad, a.to(d), gt.to(d), dw, fresh=True)
+            o.adam_step_dev(p[sl], dw, m[sl], v[sl], hyper.to(d), grad_scale=1.0, zero_grad=True, packs=packs)
+        return [t.cpu() for t in (p, m, v, fpack, dpack)]
+    fused, plain, ref = run(ops, dev, True), run(ops, dev, False), run(RefOps(), "cpu", True)
+    torch.cuda.synchronize()
+    for k, name in enumerate(("p", "m", "v", "fpack", "dpack")):
+        assert torch.equal(fused[k], plain[k]), f"{name}: fused vs weight gradient + update"
+        if k < 3:
+            assert torch.equal(fused[k][:off], (p0, m0, v0)[k][:off]) and torch.equal(fused[k][off + n:], (p0, m0, v0)[k][off + n:])
+            close_f32(fused[k], ref[k], name + " vs oracle", rel=2e-3)
+        else:
+            close_bf16(fused[k], ref[k], name + " vs oracle")
+
+
 def test_group_indexed_repack_equals_the_elementwise_refresh(hip_ops):
     """gs_repack_bf16_groups / gs_repack_bf16_tiled_groups (one base index per 8 pack elements; two launches per pack) against
     gs_repack_bf16 on the expanded index, bit for bit: aligned and unaligned bases, padding groups, irregular groups (-2),
