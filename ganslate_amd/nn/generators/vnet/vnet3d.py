@@ -421,9 +421,11 @@ class Vnet3D(NativeNet):
         ops, h = self.ops, blk.C // 2
         dsl = (lambda name: self._slope(name, grad=True)) if want_w else (lambda name: None)
         gu = torch.empty_like(rec.out)
+        # G (= gu, the residual's gradient: second output of the same pass, not a copy launch behind it) becomes the gradient
+        # w.r.t. core's input, in place
+        G = torch.empty_like(rec.out)
         ops.pnorm_backward(g, rec.Xn, None, gu, C=blk.C, slope=self._slope(blk.tail_slope), dslope=dsl(blk.tail_slope),
-                           g2=g2, g2_co=g2_co, res=rec.D0, res_mode=1)
-        G = gu.clone()                                   # becomes the gradient w.r.t. core's input, in place
+                           g2=g2, g2_co=g2_co, res=rec.D0, res_mode=1, gres=G)
         cur = rec.Xn                                     # memory saving: the core's output, walked back coupling by coupling
         if s.inverse:
             # rec.coup was recorded over reversed(blk.couplings): walk it back. Per coupling x1 = y1 - F(x2), x2 = y2 - G(y1):
