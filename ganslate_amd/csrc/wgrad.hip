@@ -271,8 +271,40 @@ __global__ __launch_bounds__(WP * WQ * 64) void wgrad_kernel(const WGradK p) {
           const int jf = p.ad.inv_f ? p.ad.inv_f[grp] : -1, jd = p.ad.inv_d ? p.ad.inv_d[grp] : -1;
           if (jf >= 0) static_cast<uint2*>(p.ad.fpack)[(size_t)jf * 2 + half] = o;
           if (jd >= 0) static_cast<uint2*>(p.ad.dpack)[(size_t)jd * 2 + half] = o;
+          if (p.ad.tr_pack) *reinterpret_cast<float4*>(ct + rr * CP + c4) = P;      // (for the transposed groups below)
         } else {
           *reinterpret_cast<f32x4*>(obase + (size_t)pp * d.dw_ld + col) = old[it] + v;
+        }
+      }
+    }
+    if (p.adam && p.ad.tr_pack) {
+      // the transposed pack: 8 consecutive rows of one column are one 16-byte group (the tile of updated parameters is in LDS).
+      // Neighbouring lanes take neighbouring COLUMNS (conflict-free LDS reads; with neighbouring row groups of one column per
+      // lane the 8-row stride put 16 lanes on 2 banks: +25 % on the launch); a lane's 16 row groups follow each other in its
+      // pack row, and L2 merges those partial-line writes
+      __syncthreads();
+      constexpr int RG = BP / 8;
+      for (int gi = threadIdx.x; gi < RG * BQ; gi += NW * 64) {
+        int rg, cc;
+        if constexpr (RG % 4 == 0 && BQ % 16 == 0) {
+          // 16 columns x 4 neighbouring row groups per wave: 64-byte runs of the pack rows, 2-way LDS conflicts
+          cc = ((gi >> 6) % (BQ / 16)) * 16 + (gi & 15);
+          rg = (gi / (64 * (BQ / 16))) * 4 + ((gi >> 4) & 3);
+        } else {
+          rg = gi / BQ; cc = gi - rg * BQ;
+        }
+        const int colt = tq * BQ + cc, p0 = tp * BP + rg * 8;
+        if (colt < TQ && p0 < d.P) {
+          const int t = colt >> (3 + p.q_shift), q = colt & ((8 << p.q_shift) - 1);
+          const int base = p.ad.tr_base[t];
+          if (base >= 0) {
+            float f[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) f[k8] = ct[(rg * 8 + k8) * CP + cc];
+            const uint4 o = {pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7])};
+            *reinterpret_cast<uint4*>(static_cast<char*>(p.ad.tr_pack) +
+                                      ((size_t)base + (size_t)q * p.ad.tr_kp[t] + p0) * 2) = o;
+          }
         }
       }
     }
@@ -582,6 +614,9 @@ extern "C" int gs_wgrad_adam(const gs_wgrad_desc* d, const void* a, const void* 
   GS_REQUIRE(((reinterpret_cast<uintptr_t>(adam->p) | reinterpret_cast<uintptr_t>(adam->m) | reinterpret_cast<uintptr_t>(adam->v) |
                reinterpret_cast<uintptr_t>(adam->fpack) | reinterpret_cast<uintptr_t>(adam->dpack)) & 15) == 0,
              "gs_wgrad_adam: buffers must be 16-byte aligned");
+  GS_REQUIRE((adam->tr_pack == nullptr) == (adam->tr_base == nullptr) && (adam->tr_pack == nullptr) == (adam->tr_kp == nullptr) &&
+                 (reinterpret_cast<uintptr_t>(adam->tr_pack) & 15) == 0,
+             "gs_wgrad_adam: the transposed pack comes with both of its tables, 16-byte aligned");
   GS_REQUIRE(gs_wgrad_adam_eligible(d), "gs_wgrad_adam: this layer does not run as a one-split im2col launch (gs_wgrad_adam_eligible)");
   gs_wgrad_desc fresh = *d;
   fresh.dw_fresh = 1;                                 // (nothing of a gradient buffer is read)

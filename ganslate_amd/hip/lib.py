@@ -50,7 +50,8 @@ class Twin(C.Structure):
 class AdamFuse(C.Structure):
     """Mirror of gs_adam_fuse."""
     _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("hyper", C.c_void_p), ("inv_f", C.c_void_p),
-                ("fpack", C.c_void_p), ("inv_d", C.c_void_p), ("dpack", C.c_void_p)]
+                ("fpack", C.c_void_p), ("inv_d", C.c_void_p), ("dpack", C.c_void_p), ("tr_base", C.c_void_p),
+                ("tr_kp", C.c_void_p), ("tr_pack", C.c_void_p)]
 
 
 class NormDbItem(C.Structure):

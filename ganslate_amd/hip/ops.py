@@ -471,9 +471,10 @@ class HipOps(TwinSplit):
             d.dh[i], d.dw_[i], d.dd[i] = p, q, r
         return d
 
-    def wgrad_adam(self, w: WGrad, a, g, p, m, v, hyper_dev, packs=None) -> bool:
+    def wgrad_adam(self, w: WGrad, a, g, p, m, v, hyper_dev, packs=None, tr=None) -> bool:
         """weight gradient + Adam of ONE layer in one launch (gs_wgrad_adam): p / m / v are the layer's slices of the flat
-        buffers, packs = (inv_f slice, fpack, inv_d slice, dpack) as for adam_step_dev. Returns False (nothing launched) where
+        buffers, packs = (inv_f slice, fpack, inv_d slice, dpack) as for adam_step_dev; tr = (base int32[T], kp int32[T], pack):
+        the layer's transposed pack, written by the same launch (gs_adam_fuse.tr_*). Returns False (nothing launched) where
         the layer does not run as a one-split im2col launch — the caller then runs wgrad() and the optimiser as usual."""
         key = ("wadam", id(w), a.shape[0], a.shape[-1], g.shape[-1])
         ent = self._desc_cache.get(key)
@@ -492,6 +493,8 @@ class HipOps(TwinSplit):
                 ad.inv_f, ad.fpack = inv_f.data_ptr(), fpack.data_ptr()
             if inv_d is not None:
                 ad.inv_d, ad.dpack = inv_d.data_ptr(), dpack.data_ptr()
+        if tr is not None:
+            ad.tr_base, ad.tr_kp, ad.tr_pack = tr[0].data_ptr(), tr[1].data_ptr(), tr[2].data_ptr()
         t_end = self._time_begin("wgrad", w, False, a.shape[0])
         L.check(self.lib.gs_wgrad_adam(C.byref(ent[0]), _ptr(a), _ptr(g), C.byref(ad), _stream()), "gs_wgrad_adam")
         if t_end is not None:

@@ -178,9 +178,11 @@ class Unet2D(NativeNet):
         a_t, g_t = (dy, x_in) if sp.kind == "conv" else (x_in, dy)
         fresh, fuse = self.wgrad_fresh(i), getattr(self, "_early_fuse", None)
         # one backward pass per optimiser step (NativeAdam.arm_early) and a layer of few pixels: gradient + update in one launch
-        args = fuse(self, i) if (fuse is not None and fresh) else None
+        args, which = fuse(self, i) if (fuse is not None and fresh) else (None, None)
         if args is not None and ops.wgrad_adam(lw.wgrad, a_t, g_t, *args):
             self._early_fused.append((self.w_off[i], self.w_off[i] + sp.master_numel))
+            if which is not None:                          # (its transposed pack came with the launch)
+                self._early_tr.append((i, which))
         else:
             ops.wgrad(lw.wgrad, a_t, g_t, grad[self.w_off[i]:self.w_off[i] + sp.master_numel], fresh=fresh)
         if sp.bias and not has_norm:

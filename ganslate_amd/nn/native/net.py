@@ -286,13 +286,76 @@ class NativeNet:
         with torch.no_grad():
             flat.copy_(host.to(flat.device))
 
-    def mark_packs_dirty(self, ident_fresh=None):
+    def mark_packs_dirty(self, ident_fresh=None, tr_fresh=()):
         """the master moved. ident_fresh: the pack set whose row-major groups the optimiser wrote with the update itself
-        (fused_pack_targets) — that set only needs its transposed segments refreshed"""
+        (fused_pack_targets) — that set only needs its transposed segments refreshed; tr_fresh: (layer, 'f' | 'd') pairs whose
+        transposed segments were written too (gs_wgrad_adam with gs_adam_fuse.tr_*): the refresh leaves them out"""
         self._packs_dirty = True
         for pk in self._packs.values():
             pk["ident_fresh"] = pk is ident_fresh
+            pk["tr_fresh"] = frozenset(tr_fresh) if pk is ident_fresh else frozenset()
+            if pk["tr_fresh"]:      # the reduced refresh plans now (host work, a download): the refresh itself may be captured
+                for which in ("f", "d"):
+                    skip = frozenset(i for i, w in pk["tr_fresh"] if w == which)
+                    if skip:
+                        self._tiled_plan_without(pk, which, skip)
         self._recent_passes = {}          # (the weights moved: recorded activations no longer describe this network)
+
+    def transposed_tables(self, i):
+        """(which, base int32[T], kp int32[T], pack) of layer i's TRANSPOSED pack — pack element of W[p][t][q] = base[t] + q kp[t] +
+        p, base[t] < 0 for a tap in no class — or None: derived from the layer's gather table and verified element by element
+        (a layer whose table does not have this form keeps the refresh from the master). One pack set only."""
+        if len(self._packs) != 1:
+            return None
+        (key, pk), = self._packs.items()
+        cache = pk.setdefault("tr_tables", {})
+        if i in cache:
+            return cache[i]
+        lw, sp = self._lowered(*key)[i], self.nodes[i].spec
+        n = sp.master_numel
+        wg = lw.wgrad
+        P, T, Q = wg.P, wg.T, wg.Q
+        out = None
+        if P * T * Q == n and P > 1 and Q > 1:
+            for which, index, off in (("f", lw.fwd_index, pk["f_off"][i]), ("d", lw.dgrad_index, pk["d_off"][i])):
+                idx = np.asarray(index).reshape(-1)
+                valid = np.nonzero(idx >= 0)[0]
+                inv = np.full(n, -1, np.int64)
+                inv[idx[valid]] = valid
+                pos = inv.reshape(P, T, Q)
+                base, kp = pos[0, :, 0].copy(), pos[0, :, 1] - pos[0, :, 0]
+                live = base >= 0
+                if not live.any() or (pos[1, live, 0] - base[live] != 1).any():
+                    continue                                     # (row-major pack: consecutive along q, the optimiser writes it)
+                kp = np.where(live, kp, 0)
+                want = base[None, :, None] + np.arange(Q)[None, None, :] * kp[None, :, None] + np.arange(P)[:, None, None]
+                ok = (np.array_equal(pos[:, live, :], want[:, live, :]) and (pos[:, ~live, :] < 0).all()
+                      and valid.size == int(live.sum()) * P * Q and not ((base[live] + off) % 8).any() and not (kp[live] % 8).any()
+                      and (kp[live] > 0).all())
+                if ok:
+                    b = np.where(live, base + off, -1).astype(np.int32)
+                    out = (which, torch.from_numpy(b).to(self.device), torch.from_numpy(kp.astype(np.int32)).to(self.device),
+                           pk[which + "pack"])
+                break
+        cache[i] = out
+        return out
+
+    def _tiled_plan_without(self, pk, which, skip):
+        """(seg, tiles) of pack `which` without the transposed segments of the layers in `skip`"""
+        cache = pk.setdefault("seg_without", {})
+        ck = (which, skip)
+        if ck not in cache:
+            plan, offs = pk[which + "_plan"], pk[which + "_off"]
+            total = pk[which + "pack"].numel()
+            rng = [(offs[i], offs[i + 1] if i + 1 < len(offs) else total) for i in sorted(skip)]
+            seg = plan["seg"].cpu().numpy()
+            keep = [r for r in seg if not any(a <= r[0] < b for a, b in rng)]
+            tiles, rows = 0, []
+            for r in keep:
+                rows.append((r[0], r[1], r[2], r[3], tiles))
+                tiles += (int(r[2]) + 63) // 64 * (int(r[3]) // 64)
+            cache[ck] = (torch.from_numpy(np.asarray(rows, np.int64).reshape(-1, 5)).to(self.device), tiles)
+        return cache[ck]
 
     def fused_pack_targets(self):
         """(pack set, (inv_f, fpack, inv_d, dpack)) for gs_adam_step_dev_packs, or None: inv_x[i] = the group of 8 pack
@@ -471,9 +534,14 @@ class NativeNet:
                         self.ops.repack_groups(m, ident[k][1], pack[:n8 * 8], plan["index"])
                 else:
                     self.ops.repack_groups(m, plan["groups"], pack[:n8 * 8], plan["index"])
-                if plan["tiles"]:
+                skip = frozenset(i for i, w in (pk.get("tr_fresh") or ()) if w == which) if ident else frozenset()
+                if skip:                                              # their fused launches wrote the transposed groups too
+                    seg, tiles = self._tiled_plan_without(pk, which, skip)
+                    if tiles:
+                        self.ops.repack_tiled_groups(m, plan["tgroups"], pack, seg, tiles)
+                elif plan["tiles"]:
                     self.ops.repack_tiled_groups(m, plan["tgroups"], pack, plan["seg"], plan["tiles"])
-            pk["fresh"], pk["ident_fresh"] = True, False
+            pk["fresh"], pk["ident_fresh"], pk["tr_fresh"] = True, False, frozenset()
         return pk
 
     # ---- forward ----------------------------------------------------------------------------------------------------------

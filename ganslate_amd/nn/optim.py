@@ -60,13 +60,14 @@ class NativeAdam(torch.optim.Optimizer):
             return False
         if not self.external_prepare:
             self.prepare()
-        self._early = {"stream": stream, "prepared": True, "launched": False}
+        self._early = {"stream": stream, "prepared": True, "launched": False,
+                       "tr": os.environ.get("GS_WGRAD_ADAM_TR", "1") != "0"}       # (A/B switch: transposed packs by the fused launch)
         fuse = os.environ.get("GS_WGRAD_ADAM", "1") != "0"       # (A/B switch)
         for net in nets:
             net._early_step = self._early_chunk
             # layers of few pixels: weight gradient + update in one launch (gs_wgrad_adam) — the executor asks per layer
             net._early_fuse = self._fuse_args if fuse else None
-            net._early_fused = []
+            net._early_fused, net._early_tr = [], []
             net._early_cursor = net.b_off[-1] + net.nodes[-1].spec.cout_p      # end of the node parameters
             net._early_min = int(os.environ.get("GS_EARLY_ADAM_MIN", self.EARLY_MIN))
         return True
@@ -81,13 +82,17 @@ class NativeAdam(torch.optim.Optimizer):
         return (inv_f[g0:g1] if inv_f is not None else None, fpack, inv_d[g0:g1] if inv_d is not None else None, dpack)
 
     def _fuse_args(self, net, i):
-        """(p, m, v, hyper, packs) of layer i's weights for ops.wgrad_adam, or None"""
+        """((p, m, v, hyper, packs, transposed tables) of layer i's weights for ops.wgrad_adam, which pack the tables are of)"""
         p = net.master
         a, b = net.w_off[i], net.w_off[i] + net.nodes[i].spec.master_numel
         if p.grad is None or a % 8 or p.data_ptr() % 16:
-            return None
+            return None, None
         st = self.state[p]
-        return (p.data[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["hyper"], self._pack_slices(net, a, b))
+        tr = net.transposed_tables(i) if (self._early["tr"] and hasattr(net, "transposed_tables")) else None
+        if tr is not None and not hasattr(net, "fused_pack_targets"):
+            tr = None
+        return (p.data[a:b], st["exp_avg"][a:b], st["exp_avg_sq"][a:b], st["hyper"], self._pack_slices(net, a, b),
+                tr[1:] if tr is not None else None), (tr[0] if tr is not None else None)
 
     @torch.no_grad()
     def _update_range(self, p, net, start, end):
@@ -165,8 +170,10 @@ class NativeAdam(torch.optim.Optimizer):
                 net.grad_dirty = False
                 if early:
                     net._early_fused = []
+                    net._tr_fresh = frozenset(getattr(net, "_early_tr", ())) if tgt else frozenset()
+                    net._early_tr = []
                 if tgt:
-                    net.mark_packs_dirty(ident_fresh=tgt[0])
+                    net.mark_packs_dirty(ident_fresh=tgt[0], tr_fresh=getattr(net, "_tr_fresh", ()) if early else ())
                 else:
                     net.mark_packs_dirty()
 
@@ -178,7 +185,8 @@ class NativeAdam(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
-                net.mark_packs_dirty(**({"ident_fresh": tgt[0]} if tgt else {}))
+                # (a replayed step that was captured with the early form wrote the same transposed segments again)
+                net.mark_packs_dirty(**({"ident_fresh": tgt[0], "tr_fresh": getattr(net, "_tr_fresh", ())} if tgt else {}))
 
     def state_dict(self):
         sd = super().state_dict()       # the hyper vectors are derived state: rebuilt by the next prepare()

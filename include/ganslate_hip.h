@@ -242,6 +242,11 @@ typedef struct gs_adam_fuse {
   const float* hyper;          /* device float[6]: lr, beta1, beta2, eps, 1 - beta1^t, sqrt(1 - beta2^t) */
   const int32_t* inv_f; void* fpack;
   const int32_t* inv_d; void* dpack;
+  /* optional (tr_pack != NULL): the layer's TRANSPOSED pack (data-gradient pack of a conv, forward pack of a transposed conv:
+   * 8 consecutive pack elements = 8 consecutive rows p of one (tap, q) column) written by the same launch, so that no refresh
+   * from the master is needed afterwards: pack element of W[p][t][q] = tr_base[t] + q * tr_kp[t] + p (device int32[T]; tr_base[t]
+   * < 0: the tap is in no class; all three multiples of 8) */
+  const int32_t* tr_base; const int32_t* tr_kp; void* tr_pack;
 } gs_adam_fuse;
 int gs_wgrad_adam_eligible(const gs_wgrad_desc* d);
 int gs_wgrad_adam(const gs_wgrad_desc* d, const void* a, const void* g, const gs_adam_fuse* adam, void* stream);

@@ -692,11 +692,22 @@ class RefOps(TwinSplit):
         if zero_grad:
             g.zero_()
 
-    def wgrad_adam(self, w, a, g, p, m, v, hyper_dev, packs=None) -> bool:
-        """gs_wgrad_adam: the layer's weight gradient, consumed by its Adam update at once (the gradient buffer is not touched)"""
+    def wgrad_adam(self, w, a, g, p, m, v, hyper_dev, packs=None, tr=None) -> bool:
+        """gs_wgrad_adam: the layer's weight gradient, consumed by its Adam update at once (the gradient buffer is not touched);
+        tr = (base[T], kp[T], pack): pack[base[t] + q * kp[t] + p] = W[p][t][q] for the taps with base[t] >= 0"""
         dw = torch.zeros(p.numel(), dtype=torch.float32, device=p.device)
         self.wgrad(w, a, g, dw)
         self.adam_step_dev(p, dw, m, v, hyper_dev, grad_scale=1.0, zero_grad=False, packs=packs)
+        if tr is not None:
+            base, kp, pack = tr
+            P, T, Q = w.P, w.T, w.Q
+            W = p.view(P, T, Q)
+            for t in range(T):
+                b = int(base[t])
+                if b < 0:
+                    continue
+                dst = b + torch.arange(Q)[None, :] * int(kp[t]) + torch.arange(P)[:, None]        # [P][Q]
+                pack[dst.reshape(-1)] = W[:, t, :].reshape(-1).to(pack.dtype)
         return True
 
     def adam_step_dev(self, p, g, m, v, hyper_dev, grad_scale=1.0, zero_grad=True, packs=None):

@@ -45,7 +45,8 @@ def _run(monkeypatch, mode, n_steps=2):
     G.refresh_packs(torch.zeros(1, 3, 32, 32))
     return {"master": G.master.detach().clone(), "m": st["exp_avg"].clone(), "v": st["exp_avg_sq"].clone(),
             "fpack": packs["fpack"].clone(), "dpack": packs["dpack"].clone(), "logs": logs, "chunks": chunks,
-            "numel": G.numel, "step": st["step"], "fused": list(fused)}
+            "numel": G.numel, "step": st["step"], "fused": list(fused),
+            "tr": set(getattr(G, "_tr_fresh", ()))}
 
 
 def test_chunked_update_equals_update_after_backward(fp32_oracle_backend, monkeypatch):
@@ -53,6 +54,8 @@ def test_chunked_update_equals_update_after_backward(fp32_oracle_backend, monkey
     early = _run(monkeypatch, "1")
     assert not late["chunks"] and not late["fused"] and early["step"] == late["step"] == 2
     assert len(early["fused"]) == 2 * 10, "every layer's weight gradient of the 5-level U-Net took the fused launch (oracle ops)"
+    # ... and wrote its transposed pack (data-gradient pack of the convs, forward pack of the transposed convs) with it
+    assert early["tr"] == {(i, "d") for i in range(5)} | {(i, "f") for i in range(5, 10)} and not late["tr"]
     # every step handed the whole flat buffer over in descending, adjoining chunks (several per step)
     per_step = len(early["chunks"]) // 2
     assert per_step >= 3 and len(early["chunks"]) == 2 * per_step

@@ -1473,22 +1473,37 @@ def test_weight_gradient_with_fused_adam(hip_ops, case):
     perm_d[::5] = -1                                           # groups without a row-major pack group
     hyper = torch.tensor([2e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** 3, (1 - 0.999 ** 3) ** 0.5])
 
+    # a transposed pack as the data-gradient pack of a conv has it: element of W[p][t][q] at base[t] + q kp + p; tap 1 in no class
+    P, T, Q = low.wgrad.P, low.wgrad.T, low.wgrad.Q
+    kp = P + 8
+    tr_base = (torch.arange(T, dtype=torch.int32) * Q * kp + 16)
+    tr_base[1] = -1
+    tr_kp = torch.full((T,), kp, dtype=torch.int32)
+
     def run(o, d, fused):
         p, m, v = p0.clone().to(d), m0.clone().to(d), v0.clone().to(d)
         fpack = torch.zeros(n8 * 8, dtype=torch.bfloat16, device=d)
         dpack = torch.zeros(n8 * 8, dtype=torch.bfloat16, device=d)
+        tpack = torch.zeros(T * Q * kp + 16, dtype=torch.bfloat16, device=d)
         packs = (perm_f.to(d), fpack, perm_d.to(d), dpack)
         sl = slice(off, off + n)
         if fused:
-            assert o.wgrad_adam(low.wgrad, a.to(d), gt.to(d), p[sl], m[sl], v[sl], hyper.to(d), packs)
+            assert o.wgrad_adam(low.wgrad, a.to(d), gt.to(d), p[sl], m[sl], v[sl], hyper.to(d), packs,
+                                tr=(tr_base.to(d), tr_kp.to(d), tpack))
         else:
             dw = torch.zeros(n, dtype=torch.float32, device=d)
             o.wgrad(low.wgrad, a.to(d), gt.to(d), dw, fresh=True)
             o.adam_step_dev(p[sl], dw, m[sl], v[sl], hyper.to(d), grad_scale=1.0, zero_grad=True, packs=packs)
-        return [t.cpu() for t in (p, m, v, fpack, dpack)]
+            W = p[sl].view(P, T, Q)
+            for t in range(T):
+                if int(tr_base[t]) >= 0:
+                    dst = int(tr_base[t]) + torch.arange(Q, device=d)[None, :] * kp + torch.arange(P, device=d)[:, None]
+                    tpack[dst.reshape(-1)] = W[:, t, :].reshape(-1).to(torch.bfloat16)
+        return [t.cpu() for t in (p, m, v, fpack, dpack, tpack)]
     fused, plain, ref = run(ops, dev, True), run(ops, dev, False), run(RefOps(), "cpu", True)
     torch.cuda.synchronize()
-    for k, name in enumerate(("p", "m", "v", "fpack", "dpack")):
+    assert fused[5][16:16 + Q * kp].abs().sum() > 0 and fused[5][16 + Q * kp:16 + 2 * Q * kp].abs().sum() == 0, "tap 1 is skipped"
+    for k, name in enumerate(("p", "m", "v", "fpack", "dpack", "transposed pack")):
         assert torch.equal(fused[k], plain[k]), f"{name}: fused vs weight gradient + update"
         if k < 3:
             assert torch.equal(fused[k][:off], (p0, m0, v0)[k][:off]) and torch.equal(fused[k][off + n:], (p0, m0, v0)[k][off + n:])

@@ -98,10 +98,14 @@ def test_chunked_generator_update_under_backward(hip_ops, monkeypatch):
         assert model._graph is not None, "iterations 3-5 must have been graph replays"
         G = model.networks["G"]
         st = opt.state[G.master]
+        G.refresh_packs(torch.zeros(2, 3, 64, 128))        # (what the next forward pass would read)
+        torch.cuda.synchronize()
         pk = next(iter(G._packs.values()))
         res[mode] = dict(master=G.master.detach().clone(), m=st["exp_avg"].clone(), v=st["exp_avg_sq"].clone(),
-                         fpack=pk["fpack"].clone(), dpack=pk["dpack"].clone(), logs=logs, chunks=chunks)
-    assert not res["0"]["chunks"]
+                         fpack=pk["fpack"].clone(), dpack=pk["dpack"].clone(), logs=logs, chunks=chunks,
+                         tr=set(getattr(G, "_tr_fresh", ())))
+    assert not res["0"]["chunks"] and not res["0"]["tr"]
+    assert len(res["1"]["tr"]) >= 6, "the fused launches of the inner levels wrote their transposed packs"
     for mode in ("1", "stream"):
         assert len(res[mode]["chunks"]) >= 3, "the early form must have handed chunks over"
         for k in ("master", "m", "v", "fpack", "dpack"):
