@@ -204,17 +204,6 @@ __global__ __launch_bounds__(256) void pnorm_bwd_finalize_kernel(const float* pa
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (c < C) {
     int sl = lane;
-    for (; sl + 7 * LANES < chunks; sl += 8 * LANES) {      // (32 loads in flight per thread: the sweep is memory latency)
-      float v[8][4];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[k][r] = src[((size_t)(sl + k * LANES) * 4 + r) * C + c];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] += (double)v[k][r];
-    }
     for (; sl + 3 * LANES < chunks; sl += 4 * LANES) {
       float v[4][4];
 #pragma unroll
@@ -358,12 +347,7 @@ extern "C" int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const vo
     else GS_LAUNCH_REDUCE(1);
 #undef GS_LAUNCH_REDUCE
     GS_CHECK_HIP(hipGetLastError());
-    // few channels, thousands of chunks (V-Net levels at 128^3 / 64^3): one channel per workgroup = 8 chunk rows per lane, one
-    // round of loads (four channels per workgroup walked 32 rows per lane in dependent rounds: 9-11 us, 148 launches per step)
-    if (d->C <= 32 && chunks > 1024 && gs_opt(GS_OPT_NORM_BWD_PPB) != -1)
-      hipLaunchKernelGGL((pnorm_bwd_finalize_kernel<1>), dim3(d->C, d->N), dim3(256), 0, st, scratch, sums,
-                         chunks, d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
-    else if (d->C < 128 && chunks > 256)
+    if (d->C < 128 && chunks > 256)
       hipLaunchKernelGGL((pnorm_bwd_finalize_kernel<4>), dim3((d->C + 3) / 4, d->N), dim3(256), 0, st, scratch, sums,
                          chunks, d->C, 1.0f / (float)d->pixels, mean_rstd, slope ? dslope : nullptr, bias_grad);
     else
