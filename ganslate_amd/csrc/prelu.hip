@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void pnorm_bwd_apply_kernel(const PNormK p, co
 }
 
 static int pn_pix_per_block(long long pixels) {
-  long long ppb = (pixels + 2047) / 2048;
+  // (1024 chunks per image: 2048 made the second pass walk twice the rows for nothing — brats 54.48 -> 54.15 ms, 512: 55.08)
+  long long ppb = (pixels + 1023) / 1024;
   return ppb < 64 ? 64 : (int)((ppb + 63) / 64 * 64);
 }
 
