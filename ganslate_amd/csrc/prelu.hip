@@ -19,6 +19,7 @@ struct PNormK {
   gs_pnorm_desc d;
   int C8;
   unsigned HW;
+  int c8_shift;               // log2(C8) when C8 is a power of two (the element loops' grid strides are multiples of 256), else -1
 };
 
 __device__ __forceinline__ void pn_load8(float* f, const float* p) {
@@ -50,7 +51,35 @@ __device__ __forceinline__ void pn_res8(float* f, const gs_pnorm_desc& d, const 
   }
 }
 
+// The per-channel numbers of one 8-channel group. A thread whose channel group does not change over its loop (every power-of-two
+// channel count: the grid stride is a multiple of C8) loads them ONCE: per 16-byte element the kernels fetched three to six
+// 32-byte vectors of statistics / slopes / sums and ran an integer division for the pixel index.
+struct PnCh {
+  float mu[8], rs[8], sl[8];
+};
+__device__ __forceinline__ void pn_ch_load(PnCh& c, const gs_pnorm_desc& d, const float* mr, const float* slope, int c8) {
+  if (mr) { pn_load8(c.mu, mr + c8 * 8); pn_load8(c.rs, mr + d.C + c8 * 8); }
+  if (slope) pn_load8(c.sl, slope + c8 * 8);
+}
+
 // pre-activation u of one 8-channel group
+__device__ __forceinline__ void pn_preact_c(float* u, float* yh, const PNormK& p, const unsigned short* y, bool has_mr,
+                                            const PnCh& c, const unsigned short* res, size_t pix, int c8) {
+  const gs_pnorm_desc& d = p.d;
+  pn_view8(yh, y, pix, d.y_cs, d.y_co, c8);
+  if (has_mr) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) yh[k] = (yh[k] - c.mu[k]) * c.rs[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) u[k] = yh[k];
+  if (d.res_mode == 1) {
+    float r[8];
+    pn_res8(r, d, res, pix, c8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] += r[k];
+  }
+}
 __device__ __forceinline__ void pn_preact(float* u, float* yh, const PNormK& p, const unsigned short* y,
                                           const float* mr, const unsigned short* res, size_t pix, int c8) {
   const gs_pnorm_desc& d = p.d;
@@ -79,16 +108,19 @@ __global__ __launch_bounds__(256) void pnorm_fwd_kernel(const PNormK p, const un
   const int n = blockIdx.y;
   const unsigned per_img = p.HW * (unsigned)p.C8;
   const float* mr = mean_rstd ? mean_rstd + (size_t)n * 2 * d.C : nullptr;
+  const bool fixed = p.c8_shift >= 0;                  // (uniform) power-of-two channel groups: this thread keeps its group
+  PnCh ch;
+  if (fixed) pn_ch_load(ch, d, mr, slope, (int)((blockIdx.x * 256u + threadIdx.x) & (unsigned)(p.C8 - 1)));
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < per_img; e += gridDim.x * 256u) {
-    const unsigned px = e / (unsigned)p.C8;
+    const unsigned px = fixed ? e >> p.c8_shift : e / (unsigned)p.C8;
     const int c8 = (int)(e - px * (unsigned)p.C8);
     const size_t pix = (size_t)n * p.HW + px;
-    float u[8], yh[8], sl[8];
-    pn_preact(u, yh, p, y, mr, res, pix, c8);
+    float u[8], yh[8];
+    if (!fixed) pn_ch_load(ch, d, mr, slope, c8);
+    pn_preact_c(u, yh, p, y, mr != nullptr, ch, res, pix, c8);
     if (slope) {
-      pn_load8(sl, slope + c8 * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) u[k] = u[k] > 0.f ? u[k] : sl[k] * u[k];
+      for (int k = 0; k < 8; ++k) u[k] = u[k] > 0.f ? u[k] : ch.sl[k] * u[k];
     }
     if (d.res_mode == 2) {
       float r[8];
@@ -106,6 +138,32 @@ __global__ __launch_bounds__(256) void pnorm_fwd_kernel(const PNormK p, const un
 }
 
 // gu and the slope-gradient integrand of one 8-channel group
+__device__ __forceinline__ void pn_gu_c(float* gu, float* gs, const PNormK& p, const unsigned short* g,
+                                        const unsigned short* g2, const float* u, bool has_slope, const PnCh& c, size_t pix,
+                                        int c8) {
+  const gs_pnorm_desc& d = p.d;
+  float a[8], b[8];
+  pn_view8(a, g, pix, d.g_cs, d.g_co, c8);
+  if (g2) {
+    pn_view8(b, g2, pix, d.g2_cs, d.g2_co, c8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += b[k];
+  }
+  if (d.res_mode == 3) {                 // out = res - v: the branch sees the negated gradient
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = -a[k];
+  }
+  if (has_slope) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gu[k] = u[k] > 0.f ? a[k] : a[k] * c.sl[k];
+      gs[k] = u[k] > 0.f ? 0.f : a[k] * u[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gu[k] = a[k]; gs[k] = 0.f; }
+  }
+}
 __device__ __forceinline__ void pn_gu(float* gu, float* gs, const PNormK& p, const unsigned short* g,
                                       const unsigned short* g2, const float* u, const float* slope, size_t pix,
                                       int c8) {
@@ -156,11 +214,13 @@ __global__ __launch_bounds__(256) void pnorm_bwd_reduce_kernel(const PNormK p, c
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[r][k] = 0.f;
   if (c8 < p.C8) {
+    PnCh ch;                                         // (the thread's channel group is fixed: its numbers once)
+    pn_ch_load(ch, d, mr, slope, c8);
     for (unsigned px = p0 + row; px < p1; px += ROWS) {
       const size_t pix = (size_t)n * p.HW + px;
       float u[8], yh[8], gu[8], gs[8];
-      pn_preact(u, yh, p, y, mr, res, pix, c8);
-      pn_gu(gu, gs, p, g, g2, u, slope, pix, c8);
+      pn_preact_c(u, yh, p, y, mr != nullptr, ch, res, pix, c8);
+      pn_gu_c(gu, gs, p, g, g2, u, slope != nullptr, ch, pix, c8);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         acc[0][k] += gu[k]; acc[1][k] += gu[k] * yh[k]; acc[2][k] += yh[k]; acc[3][k] += gs[k];
@@ -254,27 +314,39 @@ __global__ __launch_bounds__(256) void pnorm_bwd_apply_kernel(const PNormK p, co
   const float inv_hw = 1.0f / (float)p.HW;
   const float* mr = mean_rstd ? mean_rstd + (size_t)n * 2 * d.C : nullptr;
   const float* sm = sums ? sums + (size_t)n * 4 * d.C : nullptr;
+  const bool fixed = p.c8_shift >= 0;                  // (uniform) see pnorm_fwd_kernel
+  PnCh ch;
+  float s1[8], s2[8];
+  auto load_ch = [&](int c8) {
+    pn_ch_load(ch, d, mr, slope, c8);
+    if (mr) { pn_load8(s1, sm + c8 * 8); pn_load8(s2, sm + d.C + c8 * 8); }
+  };
+  if (fixed) load_ch((int)((blockIdx.x * 256u + threadIdx.x) & (unsigned)(p.C8 - 1)));
   for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < per_img; e += gridDim.x * 256u) {
-    const unsigned px = e / (unsigned)p.C8;
+    const unsigned px = fixed ? e >> p.c8_shift : e / (unsigned)p.C8;
     const int c8 = (int)(e - px * (unsigned)p.C8);
     const size_t pix = (size_t)n * p.HW + px;
     float u[8], yh[8], gu[8], gs[8], o[8];
-    pn_preact(u, yh, p, y, mr, res, pix, c8);
-    pn_gu(gu, gs, p, g, g2, u, slope, pix, c8);
+    if (!fixed) load_ch(c8);
+    pn_preact_c(u, yh, p, y, mr != nullptr, ch, res, pix, c8);
+    pn_gu_c(gu, gs, p, g, g2, u, slope != nullptr, ch, pix, c8);
     if (gres) *reinterpret_cast<uint4*>(gres + pix * d.gres_cs + d.gres_co + c8 * 8) = pn_pack8(gu);
     if (mr) {
-      float rs[8], s1[8], s2[8];
-      pn_load8(rs, mr + d.C + c8 * 8);
-      pn_load8(s1, sm + c8 * 8);
-      pn_load8(s2, sm + d.C + c8 * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = rs[k] * (gu[k] - s1[k] * inv_hw - yh[k] * s2[k] * inv_hw);
+      for (int k = 0; k < 8; ++k) o[k] = ch.rs[k] * (gu[k] - s1[k] * inv_hw - yh[k] * s2[k] * inv_hw);
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = gu[k];
     }
     *reinterpret_cast<uint4*>(dy + pix * d.dy_cs + d.dy_co + c8 * 8) = pn_pack8(o);
   }
+}
+
+static int pn_c8_shift(int C8) {
+  if (C8 <= 0 || C8 > 256 || (C8 & (C8 - 1))) return -1;
+  int sh = 0;
+  while ((1 << sh) < C8) ++sh;
+  return sh;
 }
 
 static int pn_pix_per_block(long long pixels) {
@@ -300,6 +372,7 @@ extern "C" int gs_pnorm_forward(const gs_pnorm_desc* d, const void* y, const flo
   GS_REQUIRE((d->out_cs & 7) == 0 && (d->out_co & 7) == 0, "gs_pnorm_forward: output view must be 8-channel aligned");
   PNormK k;
   k.d = *d; k.C8 = d->C / 8; k.HW = (unsigned)d->pixels;
+  k.c8_shift = pn_c8_shift(k.C8);
   long long bx = ((long long)k.HW * k.C8 + 255) / 256;
   if (bx > 2048) bx = 2048;
   hipLaunchKernelGGL(pnorm_fwd_kernel, dim3((unsigned)bx, d->N), dim3(256), 0, static_cast<hipStream_t>(stream), k,
@@ -326,6 +399,7 @@ extern "C" int gs_pnorm_backward(const gs_pnorm_desc* d, const void* g, const vo
   hipStream_t st = static_cast<hipStream_t>(stream);
   PNormK k;
   k.d = *d; k.C8 = d->C / 8; k.HW = (unsigned)d->pixels;
+  k.c8_shift = pn_c8_shift(k.C8);
   const unsigned short* gp = static_cast<const unsigned short*>(g);
   const unsigned short* g2p = static_cast<const unsigned short*>(g2);
   const unsigned short* yp = static_cast<const unsigned short*>(y);
