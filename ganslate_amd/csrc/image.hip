@@ -115,6 +115,62 @@ extern "C" int gs_image_to_act(const float* img, void* act, int32_t N, int32_t C
   return 0;
 }
 
+// Two images side by side along the channel axis (the conditional discriminator's input torch.cat([real_A, fake_B], dim=1),
+// ganslate/nn/gans/paired/pix2pix.py:70,80) converted in one pass: channel c < Ca comes from a, the others from b.
+__global__ __launch_bounds__(256) void image_pair_to_act_kernel(const float* a, int Ca, const float* b, int Cb,
+                                                                unsigned short* act, long long hw, int Cp) {
+  const int n = blockIdx.y;
+  const float* ia = a + (size_t)n * Ca * hw;
+  const float* ib = b + (size_t)n * Cb * hw;
+  unsigned short* out = act + (size_t)n * hw * Cp;
+  const int C = Ca + Cb;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        f[k] = c < Ca ? ia[(size_t)c * hw + p] : (c < C ? ib[(size_t)(c - Ca) * hw + p] : 0.f);
+      }
+      uint4 o;
+      o.x = pack_bf2(f[0], f[1]); o.y = pack_bf2(f[2], f[3]); o.z = pack_bf2(f[4], f[5]); o.w = pack_bf2(f[6], f[7]);
+      *reinterpret_cast<uint4*>(out + (size_t)p * Cp + c0) = o;
+    }
+  }
+}
+// its gradient: channels [0, Ca) of g to ga, [Ca, Ca + Cb) to gb (either may be null: that part needs no gradient)
+__global__ __launch_bounds__(256) void image_pair_to_act_bwd_kernel(const unsigned short* g, float* ga, int Ca, float* gb,
+                                                                    int Cb, long long hw, int Cp) {
+  const int n = blockIdx.y;
+  const unsigned short* gp = g + (size_t)n * hw * Cp;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    if (ga)
+      for (int c = 0; c < Ca; ++c) ga[((size_t)n * Ca + c) * hw + p] = bf2f(gp[(size_t)p * Cp + c]);
+    if (gb)
+      for (int c = 0; c < Cb; ++c) gb[((size_t)n * Cb + c) * hw + p] = bf2f(gp[(size_t)p * Cp + Ca + c]);
+  }
+}
+
+extern "C" int gs_image_pair_to_act(const float* a, int32_t Ca, const float* b, int32_t Cb, void* act, int32_t N, int32_t H,
+                                    int32_t W, int32_t Cp, void* stream) {
+  GS_REQUIRE(a && b && act && N > 0 && Ca > 0 && Cb > 0 && Cp >= Ca + Cb && (Cp & 7) == 0, "gs_image_pair_to_act: bad argument");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(image_pair_to_act_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream), a, Ca, b, Cb,
+                     static_cast<unsigned short*>(act), hw, Cp);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_image_pair_to_act_backward(const void* g, float* ga, int32_t Ca, float* gb, int32_t Cb, int32_t N, int32_t H,
+                                             int32_t W, int32_t Cp, void* stream) {
+  GS_REQUIRE(g && (ga || gb) && N > 0 && Ca > 0 && Cb > 0 && Cp >= Ca + Cb, "gs_image_pair_to_act_backward: bad argument");
+  const long long hw = (long long)H * W;
+  hipLaunchKernelGGL(image_pair_to_act_bwd_kernel, img_grid(hw, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned short*>(g), ga, Ca, gb, Cb, hw, Cp);
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int gs_act_to_image(const void* act, float* img, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
                                int32_t act_kind, void* stream) {
   GS_REQUIRE(img && act && N > 0 && C > 0 && Cp >= C, "gs_act_to_image: bad argument");

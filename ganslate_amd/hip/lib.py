@@ -159,6 +159,10 @@ _PROTOS = {
                                      C.c_int64, C.c_void_p]),
     "gs_image_to_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p]),
+    "gs_image_pair_to_act": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "gs_image_pair_to_act_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gs_act_to_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
     "gs_act_to_image_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -763,6 +763,19 @@ class HipOps(TwinSplit):
         L.check(self.lib.gs_image_to_act(_ptr(img), _ptr(act_t), N, Cc, H, W, act_t.shape[-1], _stream()),
                 "gs_image_to_act")
 
+    def image_pair_to_act(self, a, b, act_t):
+        """torch.cat([a, b], dim=1) converted in one pass"""
+        N, Ca, H, W = self._img_dims(a)
+        L.check(self.lib.gs_image_pair_to_act(_ptr(a), Ca, _ptr(b), b.shape[1], _ptr(act_t), N, H, W, act_t.shape[-1],
+                                              _stream()), "gs_image_pair_to_act")
+
+    def image_pair_to_act_backward(self, g, ga, gb, Ca, Cb):
+        """gradient of image_pair_to_act into the images' own tensors (None: not needed)"""
+        ref = ga if ga is not None else gb
+        N, _, H, W = self._img_dims(ref)
+        L.check(self.lib.gs_image_pair_to_act_backward(_ptr(g), _ptr(ga), Ca, _ptr(gb), Cb, N, H, W, g.shape[-1], _stream()),
+                "gs_image_pair_to_act_backward")
+
     def act_to_image(self, act_t, img, act="none"):
         N, Cc, H, W = self._img_dims(img)
         L.check(self.lib.gs_act_to_image(_ptr(act_t), _ptr(img), N, Cc, H, W, act_t.shape[-1], L.ACT[act],

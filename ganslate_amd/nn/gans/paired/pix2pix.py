@@ -8,6 +8,7 @@ import torch
 
 from .... import configs
 from ...losses.adversarial_loss import AdversarialLoss
+from ...losses.functional import fanout, scalar_affine, scalar_sum
 from ...losses.pix2pix_losses import Pix2PixLoss
 from ...optim import NativeAdam
 from ..base import BaseGAN
@@ -69,24 +70,37 @@ class Pix2PixConditionalGAN(BaseGAN):
 
     def backward_G(self):
         real_A, real_B, fake_B = self.visuals["real_A"], self.visuals["real_B"], self.visuals["fake_B"]
-        pred = self.networks["D"](torch.cat([real_A, fake_B], dim=1))
+        D = self.networks["D"]
+        # the generated image feeds the discriminator and the L1 term: two aliases whose gradients the library adds
+        # (losses/functional.py: fanout) instead of autograd's accumulation
+        fake_B, fake_B2 = fanout(fake_B)
+        if hasattr(D, "forward_parts_cat"):      # D(torch.cat([real_A, fake_B], dim=1)) without the concatenated tensor
+            pred, = D.forward_parts_cat([(real_A, fake_B)])
+        else:
+            pred = D(torch.cat([real_A, fake_B], dim=1))
         self.fork_side_work()        # the discriminator's own update needs nothing that is launched after this point
         self.losses["G"] = self.criterion_adv(pred, target_is_real=True)
-        self.losses["pix2pix"] = self.criterion_pix2pix(fake_B, real_B)
-        combined_loss_G = self.losses["G"] + self.losses["pix2pix"]
+        # losses['pix2pix'] = lambda * L1 and G + pix2pix (pix2pix.py:74-77) as one launch
+        lam = float(self.criterion_pix2pix.lambda_pix2pix)
+        self.losses["pix2pix"], combined_loss_G = scalar_affine(
+            [self.losses["G"], self.criterion_pix2pix.unweighted(fake_B2, real_B)], [[0.0, lam], [1.0, lam]])
         self.backward(loss=combined_loss_G, optimizer=self.optimizers["G"])
 
     def backward_D(self):
         real_A, real_B, fake_B = self.visuals["real_A"], self.visuals["real_B"], self.visuals["fake_B"]
         D = self.networks["D"]
-        pair_real, pair_fake = torch.cat([real_A, real_B], dim=1), torch.cat([real_A, fake_B.detach()], dim=1)
-        if hasattr(D, "forward_parts"):      # D(real pair) and D(fake pair) as one pass over both batches (per-sample norm)
-            self.pred_real, self.pred_fake = D.forward_parts((pair_real, pair_fake))
+        if hasattr(D, "forward_parts_cat"):  # D(real pair) and D(fake pair) as one pass over both batches (per-sample norm),
+            # each pair converted side by side (no torch.cat)
+            self.pred_real, self.pred_fake = D.forward_parts_cat([(real_A, real_B), (real_A, fake_B.detach())])
         else:
-            self.pred_real, self.pred_fake = D(pair_real), D(pair_fake)
+            pair_real, pair_fake = torch.cat([real_A, real_B], dim=1), torch.cat([real_A, fake_B.detach()], dim=1)
+            if hasattr(D, "forward_parts"):
+                self.pred_real, self.pred_fake = D.forward_parts((pair_real, pair_fake))
+            else:
+                self.pred_real, self.pred_fake = D(pair_real), D(pair_fake)
         loss_real = self.criterion_adv(self.pred_real, target_is_real=True)
         loss_fake = self.criterion_adv(self.pred_fake, target_is_real=False)
-        self.losses["D"] = loss_real + loss_fake
+        self.losses["D"] = scalar_sum([loss_real, loss_fake])
         self.backward(loss=self.losses["D"], optimizer=self.optimizers["D"])
 
     def forward(self):

@@ -9,3 +9,7 @@ class Pix2PixLoss:
 
     def __call__(self, fake_B, real_B):
         return self.lambda_pix2pix * l1_loss(fake_B, real_B)
+
+    def unweighted(self, fake_B, real_B):
+        """L1(fake_B, real_B): the recipe applies lambda_pix2pix inside its one-launch loss assembly (functional.scalar_affine)"""
+        return l1_loss(fake_B, real_B)

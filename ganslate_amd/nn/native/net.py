@@ -567,6 +567,18 @@ class NativeNet:
             return _split_parts(out, xs)
         return _PartsFn.apply(self._token, self, *xs)
 
+    def forward_parts_cat(self, pairs):
+        """forward_parts for batches that are each torch.cat([a, b], dim=1) of two images (the conditional discriminator:
+        D(cat(real_A, fake_B)), pix2pix.py:70,80): the images are converted side by side into the first activation, no
+        concatenated tensor exists -> one output per batch"""
+        pairs = [(a.contiguous().float(), b.contiguous().float()) for a, b in pairs]
+        flat = [t for pair in pairs for t in pair]
+        record = torch.is_grad_enabled() and (self.requires_grad or any(t.requires_grad for t in flat))
+        if not record:
+            out, _ = self._forward(tuple(ChannelCat((a.detach(), b.detach())) for a, b in pairs), save=False)
+            return _split_parts(out, pairs_shape(pairs))
+        return _CatPartsFn.apply(self._token, self, *flat)
+
     def forward_taps(self, x, taps, ids):
         """sampled features of intermediate nodes: taps = [("x"|"y", node)], ids = [LongTensor[P]] (pixel indices);
         returns a tuple of [N, P, C] fp32 tensors that autograd can differentiate into the network"""
@@ -607,7 +619,10 @@ class NativeNet:
         for xh in xs:
             ah = a[n0:n0 + xh.shape[0]]
             n0 += xh.shape[0]
-            if sp0.wfold == "in":      # the W taps of the stem become channels while the image is converted
+            if isinstance(xh, ChannelCat):
+                assert sp0.wfold != "in", "channel pairs enter through the plain image conversion"
+                ops.image_pair_to_act(xh[0], xh[1], ah)
+            elif sp0.wfold == "in":      # the W taps of the stem become channels while the image is converted
                 ops.image_unfold(xh, ah, sp0.k, sp0.pad, sp0.pad_mode)
             else:
                 ops.image_to_act(xh, ah)
@@ -909,9 +924,21 @@ class NativeNet:
         gx, f, _, fmode = pending[:4]
         sp0 = nodes[0].spec
         g_ins, n0 = [], 0
+        need, k = getattr(self, "_cat_need", None), 0
         for xh in x_imgs:
-            g_in, gxh = torch.empty_like(xh), gx[n0:n0 + xh.shape[0]]
+            gxh = gx[n0:n0 + xh.shape[0]]
             n0 += xh.shape[0]
+            if isinstance(xh, ChannelCat):               # (fold is 0 here: the pair form has no padded stem)
+                assert f == 0
+                want = need[k:k + 2] if need is not None else (True, True)
+                k += 2
+                ga = torch.empty_like(xh[0]) if want[0] else None
+                gb = torch.empty_like(xh[1]) if want[1] else None
+                if ga is not None or gb is not None:
+                    ops.image_pair_to_act_backward(gxh, ga, gb, xh[0].shape[1], xh[1].shape[1])
+                g_ins.append((ga, gb))
+                continue
+            g_in = torch.empty_like(xh)
             if sp0.wfold == "in":
                 ops.image_unfold_backward(gxh, g_in, sp0.k, sp0.pad, f, sp0.pad_mode)
             else:
@@ -1031,6 +1058,10 @@ class NativeNet:
         return 1.0 / dist.get_world_size(self._dist)
 
 
+def pairs_shape(pairs):
+    return tuple(ChannelCat(p) for p in pairs)
+
+
 def _split_parts(out, parts):
     outs, n0 = [], 0
     for t in parts:
@@ -1086,6 +1117,52 @@ class _TapFn(torch.autograd.Function):
             return (None,) * (4 + len(ctx.sizes))
         gx = gx if isinstance(gx, tuple) else (gx,)
         return (None, None, None, None) + tuple(g if need else None for g, need in zip(gx, ctx.needs_input_grad[4:]))
+
+
+class ChannelCat(tuple):
+    """(a, b): two image batches that enter a network side by side along the channel axis — torch.cat([a, b], dim=1) without
+    the launch (NativeNet.forward_parts_cat); looks like the concatenated tensor where the executor asks for a shape"""
+
+    @property
+    def shape(self):
+        a, b = self
+        return torch.Size((a.shape[0], a.shape[1] + b.shape[1]) + tuple(a.shape[2:]))
+
+
+class _CatPartsFn(torch.autograd.Function):
+    """forward_parts over batches given as channel pairs: inputs come flattened (a_0, b_0, a_1, b_1, ...)"""
+
+    @staticmethod
+    def forward(ctx, token, net, *ts):
+        xs = tuple(ChannelCat((ts[i].detach(), ts[i + 1].detach())) for i in range(0, len(ts), 2))
+        out, saved = net._forward(xs, save=True)
+        ctx.net, ctx.saved = net, saved
+        ctx.need = tuple(ctx.needs_input_grad[2:])
+        ctx.want_w = net.requires_grad
+        if ctx.want_w:
+            net._fw_pending += 1
+        ctx.set_materialize_grads(False)
+        return _split_parts(out, xs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        net = ctx.net
+        if ctx.want_w:
+            net._fw_pending -= 1
+            net._order_backward_begin()
+        for g in grads:
+            if g is not None and g.is_cuda:
+                g.record_stream(torch.cuda.current_stream())
+        net._cat_need = ctx.need                       # which images want a gradient (NativeNet._backward reads it)
+        gx = net._backward(ctx.saved, grads, any(ctx.need), ctx.want_w)
+        net._cat_need = None
+        if ctx.want_w:
+            net._order_backward_end()
+        ctx.saved = None
+        if gx is None:
+            return (None,) * (2 + len(ctx.need))
+        flat = [t for pair in gx for t in pair]
+        return (None, None) + tuple(g if need else None for g, need in zip(flat, ctx.need))
 
 
 class _PartsFn(torch.autograd.Function):

@@ -384,6 +384,12 @@ int gs_repeat_backward(const void* g, int32_t g_cs, int32_t g_co, float* g_img, 
 /* x NCHW fp32 [N,C,H,W] -> act [N,H,W,Cp]  (set_input, cyclegan.py:84-90) */
 int gs_image_to_act(const float* img, void* act, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
                     void* stream);
+/* torch.cat([a, b], dim=1) -> act in one pass (the conditional discriminator's input, pix2pix.py:70,80), and its gradient into
+ * the two images' own gradient tensors (ga / gb may be NULL: that image needs none) */
+int gs_image_pair_to_act(const float* a, int32_t Ca, const float* b, int32_t Cb, void* act, int32_t N, int32_t H, int32_t W,
+                         int32_t Cp, void* stream);
+int gs_image_pair_to_act_backward(const void* g, float* ga, int32_t Ca, float* gb, int32_t Cb, int32_t N, int32_t H, int32_t W,
+                                  int32_t Cp, void* stream);
 /* act -> NCHW fp32, optional tanh (resnet2d.py:65) */
 int gs_act_to_image(const void* act, float* img, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cp,
                     int32_t act_kind, void* stream);

@@ -511,6 +511,16 @@ class RefOps(TwinSplit):
         act_t.zero_()
         act_t[..., :Cc] = img.movedim(1, -1).to(act_t.dtype)
 
+    def image_pair_to_act(self, a, b, act_t):
+        self.image_to_act(torch.cat([a, b], dim=1), act_t)
+
+    def image_pair_to_act_backward(self, g, ga, gb, Ca, Cb):
+        gi = g.float().movedim(-1, 1)
+        if ga is not None:
+            ga.copy_(gi[:, :Ca])
+        if gb is not None:
+            gb.copy_(gi[:, Ca:Ca + Cb])
+
     def act_to_image(self, act_t, img, act="none"):
         Cc = img.shape[1]
         img.copy_(_act(act_t[..., :Cc].float(), act, 0.0).movedim(-1, 1))

@@ -1512,6 +1512,33 @@ def test_weight_gradient_with_fused_adam(hip_ops, case):
             close_bf16(fused[k], ref[k], name + " vs oracle")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 3, 16, 24), (1, 1, 4, 9, 7)], ids=lambda s: "x".join(map(str, s)))
+def test_image_pair_conversion(hip_ops, shape):
+    """gs_image_pair_to_act / _backward (torch.cat([a, b], dim=1) -> NHWC bf16 in one pass; the gradient into the two images' own
+    tensors, either optional) against cat + gs_image_to_act and its backward, bit for bit"""
+    N, Ca, Cb, H, W = shape
+    g = torch.Generator().manual_seed(91)
+    dev = hip_ops.device
+    a, b = torch.randn(N, Ca, H, W, generator=g).to(dev), torch.randn(N, Cb, H, W, generator=g).to(dev)
+    Cp = (Ca + Cb + 7) // 8 * 8
+    act1 = torch.full((N, H, W, Cp), 3.0, dtype=torch.bfloat16, device=dev)
+    act2 = torch.full((N, H, W, Cp), 5.0, dtype=torch.bfloat16, device=dev)
+    hip_ops.image_pair_to_act(a, b, act1)
+    hip_ops.image_to_act(torch.cat([a, b], dim=1), act2)
+    assert torch.equal(act1, act2)
+    gact = torch.randn(N, H, W, Cp, generator=g).to(torch.bfloat16).to(dev)
+    want = torch.empty(N, Ca + Cb, H, W, device=dev)
+    hip_ops.image_to_act_backward(gact, want, fold=0)
+    for need in ((True, True), (False, True), (True, False)):
+        ga = torch.full((N, Ca, H, W), 7.0, device=dev) if need[0] else None
+        gb = torch.full((N, Cb, H, W), 7.0, device=dev) if need[1] else None
+        hip_ops.image_pair_to_act_backward(gact, ga, gb, Ca, Cb)
+        if ga is not None:
+            assert torch.equal(ga, want[:, :Ca])
+        if gb is not None:
+            assert torch.equal(gb, want[:, Ca:])
+
+
 def test_group_indexed_repack_equals_the_elementwise_refresh(hip_ops):
     """gs_repack_bf16_groups / gs_repack_bf16_tiled_groups (one base index per 8 pack elements; two launches per pack) against
     gs_repack_bf16 on the expanded index, bit for bit: aligned and unaligned bases, padding groups, irregular groups (-2),
