@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, float* g, float
 // group of master elements 8 i .. 8 i + 7, or -1. The lane that updated elements 8 i + 4 h .. + 3 stores half h of the
 // group (8 bytes): the separate refresh launch read every such master element a second time (4 of its 6.5 bytes per weight;
 // 219 of 1630 us of Adam + refresh on the 167 M-parameter U-Net). Transposed packs stay with gs_repack_bf16_tiled_groups.
-__global__ __launch_bounds__(256) void adam_dev_packs_kernel(float* p, float* g, float* m, float* v, long long n,
-                                                             const float* __restrict__ hyper, float gscale, int zero_grad,
-                                                             const int* __restrict__ inv_f, uint2* __restrict__ fpack,
-                                                             const int* __restrict__ inv_d, uint2* __restrict__ dpack) {
+__device__ __forceinline__ void adam_packs_body(float* p, float* g, float* m, float* v, long long n,
+                                                const float* __restrict__ hyper, float gscale, int zero_grad,
+                                                const int* __restrict__ inv_f, uint2* __restrict__ fpack,
+                                                const int* __restrict__ inv_d, uint2* __restrict__ dpack) {
   const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc2_sqrt = hyper[5];
   const float step_size = hyper[0] / hyper[4];
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
@@ -113,6 +113,24 @@ __global__ __launch_bounds__(256) void adam_dev_packs_kernel(float* p, float* g,
   // (a tail of n % 4 elements belongs to no complete group: plain update)
   for (long long e = n4 * 4 + tid; e < n; e += nth) adam_one(p[e], g[e], m[e], v[e], b1, b2, eps, bc2_sqrt, step_size, gscale, zero_grad);
 }
+__global__ __launch_bounds__(256) void adam_dev_packs_kernel(float* p, float* g, float* m, float* v, long long n,
+                                                             const float* __restrict__ hyper, float gscale, int zero_grad,
+                                                             const int* __restrict__ inv_f, uint2* __restrict__ fpack,
+                                                             const int* __restrict__ inv_d, uint2* __restrict__ dpack) {
+  adam_packs_body(p, g, m, v, n, hyper, gscale, zero_grad, inv_f, fpack, inv_d, dpack);
+}
+// the same update over several ranges of the flat buffers in one launch (blockIdx.y = range; [start, end) in elements, start a
+// multiple of 8): what is left of a network after gs_wgrad_adam took its large layers — biases and small layers between them
+__global__ __launch_bounds__(256) void adam_dev_packs_ranges_kernel(float* p, float* g, float* m, float* v,
+                                                                    const long long* __restrict__ ranges,
+                                                                    const float* __restrict__ hyper, float gscale, int zero_grad,
+                                                                    const int* __restrict__ inv_f, uint2* __restrict__ fpack,
+                                                                    const int* __restrict__ inv_d, uint2* __restrict__ dpack) {
+  const long long a = ranges[2 * blockIdx.y], b = ranges[2 * blockIdx.y + 1];
+  if ((long long)blockIdx.x * blockDim.x * 4 >= b - a) return;          // (uniform: this range is shorter than the grid)
+  adam_packs_body(p + a, g + a, m + a, v + a, b - a, hyper, gscale, zero_grad, inv_f ? inv_f + (a >> 3) : nullptr, fpack,
+                  inv_d ? inv_d + (a >> 3) : nullptr, dpack);
+}
 
 static long long adam_blocks(int64_t n) {
   long long blocks = (n / 4 + 511) / 512;         // two 16-byte vectors per thread per pass
@@ -144,6 +162,25 @@ extern "C" int gs_adam_step_dev_packs(float* p, float* g, float* m, float* v, in
   hipLaunchKernelGGL(adam_dev_packs_kernel, dim3((unsigned)adam_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g,
                      m, v, (long long)n, hyper_dev, grad_scale, zero_grad, inv_f, static_cast<uint2*>(fpack), inv_d,
                      static_cast<uint2*>(dpack));
+  GS_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gs_adam_step_dev_packs_ranges(float* p, float* g, float* m, float* v, const int64_t* ranges_dev, int32_t n_ranges,
+                                             int64_t max_len, const float* hyper_dev, float grad_scale, int32_t zero_grad,
+                                             const int32_t* inv_f, void* fpack, const int32_t* inv_d, void* dpack, void* stream) {
+  GS_REQUIRE(p && g && m && v && ranges_dev && hyper_dev && n_ranges > 0 && n_ranges <= 65535 && max_len > 0,
+             "gs_adam_step_dev_packs_ranges: bad argument");
+  GS_REQUIRE((inv_f == nullptr) == (fpack == nullptr) && (inv_d == nullptr) == (dpack == nullptr),
+             "gs_adam_step_dev_packs_ranges: an index table and its pack go together");
+  GS_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+               reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(fpack) | reinterpret_cast<uintptr_t>(dpack)) & 15) == 0,
+             "gs_adam_step_dev_packs_ranges: buffers must be 16-byte aligned");
+  long long bx = adam_blocks(max_len);
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(adam_dev_packs_ranges_kernel, dim3((unsigned)bx, (unsigned)n_ranges), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, g, m, v, reinterpret_cast<const long long*>(ranges_dev), hyper_dev,
+                     grad_scale, zero_grad, inv_f, static_cast<uint2*>(fpack), inv_d, static_cast<uint2*>(dpack));
   GS_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -975,6 +975,15 @@ class HipOps(TwinSplit):
         L.check(self.lib.gs_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev),
                                           float(grad_scale), int(zero_grad), _stream()), "gs_adam_step_dev")
 
+    def adam_step_dev_ranges(self, p, g, m, v, ranges_dev, max_len, hyper_dev, grad_scale=1.0, zero_grad=True, packs=None):
+        """adam_step_dev over the ranges [start, end) (device int64 [n][2]) of the flat buffers in one launch; packs index the
+        whole buffers"""
+        inv_f, fpack, inv_d, dpack = packs if packs is not None else (None, None, None, None)
+        L.check(self.lib.gs_adam_step_dev_packs_ranges(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ranges_dev), ranges_dev.shape[0],
+                                                       int(max_len), _ptr(hyper_dev), float(grad_scale), int(zero_grad),
+                                                       _ptr(inv_f), _ptr(fpack), _ptr(inv_d), _ptr(dpack), _stream()),
+                "gs_adam_step_dev_packs_ranges")
+
     def pool_query(self, pool, images, out, code_dev):
         B = images.shape[0]
         nbytes = images[0].numel() * images.element_size()

@@ -64,7 +64,10 @@ class NativeAdam(torch.optim.Optimizer):
                        "tr": os.environ.get("GS_WGRAD_ADAM_TR", "1") != "0"}       # (A/B switch: transposed packs by the fused launch)
         fuse = os.environ.get("GS_WGRAD_ADAM", "1") != "0"       # (A/B switch)
         for net in nets:
-            net._early_step = self._early_chunk
+            # a network whose large layers took the fused launch last step: what is left (biases, small layers) goes in ONE
+            # multi-range launch behind the pass instead of a dozen chunk launches between its launches
+            ranged = fuse and getattr(net, "_last_fused", 0) > 0 and os.environ.get("GS_ADAM_RANGES", "1") != "0"      # (A/B switch)
+            net._early_step = None if ranged else self._early_chunk
             # layers of few pixels: weight gradient + update in one launch (gs_wgrad_adam) — the executor asks per layer
             net._early_fuse = self._fuse_args if fuse else None
             net._early_fused, net._early_tr = [], []
@@ -105,6 +108,29 @@ class NativeAdam(torch.optim.Optimizer):
                 get_ops().adam_step_dev(p.data[pos:a], p.grad[pos:a], st["exp_avg"][pos:a], st["exp_avg_sq"][pos:a],
                                         st["hyper"], grad_scale=1.0, zero_grad=True, packs=self._pack_slices(net, pos, a))
             pos = max(pos, b)
+
+    @staticmethod
+    def _rest_ranges(p, net):
+        """(device int64 [n][2], longest) ranges of the flat buffer outside the layers in net._early_fused — built when a step has
+        told which layers take the fused launch (host work and an upload: the step that uses it may be a captured one)"""
+        pos, ranges = 0, []
+        for a, b in sorted(net._early_fused) + [(p.numel(), p.numel())]:
+            if a > pos:
+                ranges.append((pos, a))
+            pos = max(pos, b)
+        key = tuple(ranges)
+        cache = net.__dict__.setdefault("_rest_ranges_cache", {})
+        if key not in cache:
+            cache[key] = (torch.tensor(ranges, dtype=torch.int64, device=p.device).reshape(-1, 2), max(b - a for a, b in ranges))
+        return cache[key]
+
+    @torch.no_grad()
+    def _update_rest(self, p, net, tgt):
+        """everything of the flat buffer outside the layers that were updated with their weight gradient, in one launch"""
+        st = self.state[p]
+        dev, max_len = self._rest_ranges(p, net)
+        get_ops().adam_step_dev_ranges(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], dev, max_len, st["hyper"],
+                                       grad_scale=1.0, zero_grad=True, packs=tgt[1] if tgt else None)
 
     def _early_chunk(self, net, start, end):
         from ..utils import streams
@@ -157,7 +183,10 @@ class NativeAdam(torch.optim.Optimizer):
                 st = self.state[p]
                 # the update writes the row-major bf16 weight packs as it goes where the network has one pack set
                 tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
-                if early and (net._early_cursor < net.b_off[-1] + net.nodes[-1].spec.cout_p or net._early_fused):
+                nodes_end = net.b_off[-1] + net.nodes[-1].spec.cout_p
+                if early and net._early_fused and net._early_cursor == nodes_end and hasattr(ops, "adam_step_dev_ranges"):
+                    self._update_rest(p, net, tgt)       # nothing handed over in chunks: the rest of the buffer in one launch
+                elif early and (net._early_cursor < net.b_off[-1] + net.nodes[-1].spec.cout_p or net._early_fused):
                     # chunks of this pass are done (or under way on the joined stream): the layers it did not hand over and
                     # whatever follows the node parameters in the flat buffer
                     nodes_end = net.b_off[-1] + net.nodes[-1].spec.cout_p
@@ -169,6 +198,9 @@ class NativeAdam(torch.optim.Optimizer):
                                       zero_grad=True, packs=tgt[1] if tgt else None)
                 net.grad_dirty = False
                 if early:
+                    net._last_fused = len(net._early_fused)
+                    if net._last_fused and not (p.is_cuda and torch.cuda.is_current_stream_capturing()):
+                        self._rest_ranges(p, net)        # (for the next step's one-launch form)
                     net._early_fused = []
                     net._tr_fresh = frozenset(getattr(net, "_early_tr", ())) if tgt else frozenset()
                     net._early_tr = []

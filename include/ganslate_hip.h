@@ -558,6 +558,12 @@ int gs_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const fl
 int gs_adam_step_dev_packs(float* p, float* g, float* m, float* v, int64_t n, const float* hyper_dev, float grad_scale,
                            int32_t zero_grad, const int32_t* inv_f, void* fpack, const int32_t* inv_d, void* dpack,
                            void* stream);
+/* gs_adam_step_dev_packs over several ranges [start, end) of the flat buffers in ONE launch (ranges_dev: device int64 [n_ranges][2],
+ * elements, starts multiples of 8; max_len = the longest range; inv_f / inv_d index the WHOLE buffers): what gs_wgrad_adam leaves of
+ * a network — biases and small layers between the layers it updated itself */
+int gs_adam_step_dev_packs_ranges(float* p, float* g, float* m, float* v, const int64_t* ranges_dev, int32_t n_ranges,
+                                  int64_t max_len, const float* hyper_dev, float grad_scale, int32_t zero_grad,
+                                  const int32_t* inv_f, void* fpack, const int32_t* inv_d, void* dpack, void* stream);
 /* ---- the PatchGAN's last layer: Conv2d(8 ndf, 1, k4, s1, p1) (patchgan2d.py:62) — one output channel -------------------------
  * A dot product per pixel: on the vector ALUs (v_dot2c_f32_bf16) with the filter in registers and a sliding 4 x 4 window of
  * input pixels, instead of an eighth of an MFMA tile behind a 16-fold im2col gather (csrc/cout1.hip). Same descriptors,

@@ -739,6 +739,16 @@ class RefOps(TwinSplit):
                 dst = inv[:n8][src].long()
                 pack[:pack.numel() // 8 * 8].view(-1, 8)[dst] = p[:n8 * 8].view(-1, 8)[src].to(pack.dtype)
 
+    def adam_step_dev_ranges(self, p, g, m, v, ranges_dev, max_len, hyper_dev, grad_scale=1.0, zero_grad=True, packs=None):
+        """gs_adam_step_dev_packs_ranges: the update of every range [start, end)"""
+        for a, b in ranges_dev.tolist():
+            sub = None
+            if packs is not None:
+                inv_f, fpack, inv_d, dpack = packs
+                g0, g1 = a // 8, (b + 7) // 8
+                sub = (inv_f[g0:g1] if inv_f is not None else None, fpack, inv_d[g0:g1] if inv_d is not None else None, dpack)
+            self.adam_step_dev(p[a:b], g[a:b], m[a:b], v[a:b], hyper_dev, grad_scale=grad_scale, zero_grad=zero_grad, packs=sub)
+
     def pool_query(self, pool, images, out, code_dev):
         """ganslate/data/utils/image_pool.py:31-60 with the coin flips given as codes (see gs_pool_query)"""
         for b, c in enumerate(code_dev.tolist()):

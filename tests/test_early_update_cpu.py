@@ -38,6 +38,10 @@ def _run(monkeypatch, mode, n_steps=2):
     ops = backend.get_ops()
     inner_wa = ops.wgrad_adam
     monkeypatch.setattr(ops, "wgrad_adam", lambda w, *a, **k: (fused.append(id(w)), inner_wa(w, *a, **k))[1])
+    ranged = []
+    inner_rg = ops.adam_step_dev_ranges
+    monkeypatch.setattr(ops, "adam_step_dev_ranges",
+                        lambda p, g, m, v, r, *a, **k: (ranged.append([tuple(x) for x in r.tolist()]), inner_rg(p, g, m, v, r, *a, **k))[1])
     logs = run_product_pix2pix_steps(model, c, n_steps)
     G = model.networks["G"]
     st = opt.state[G.master]
@@ -46,7 +50,7 @@ def _run(monkeypatch, mode, n_steps=2):
     return {"master": G.master.detach().clone(), "m": st["exp_avg"].clone(), "v": st["exp_avg_sq"].clone(),
             "fpack": packs["fpack"].clone(), "dpack": packs["dpack"].clone(), "logs": logs, "chunks": chunks,
             "numel": G.numel, "step": st["step"], "fused": list(fused),
-            "tr": set(getattr(G, "_tr_fresh", ()))}
+            "tr": set(getattr(G, "_tr_fresh", ())), "ranged": list(ranged)}
 
 
 def test_chunked_update_equals_update_after_backward(fp32_oracle_backend, monkeypatch):
@@ -56,15 +60,16 @@ def test_chunked_update_equals_update_after_backward(fp32_oracle_backend, monkey
     assert len(early["fused"]) == 2 * 10, "every layer's weight gradient of the 5-level U-Net took the fused launch (oracle ops)"
     # ... and wrote its transposed pack (data-gradient pack of the convs, forward pack of the transposed convs) with it
     assert early["tr"] == {(i, "d") for i in range(5)} | {(i, "f") for i in range(5, 10)} and not late["tr"]
-    # every step handed the whole flat buffer over in descending, adjoining chunks (several per step)
-    per_step = len(early["chunks"]) // 2
-    assert per_step >= 3 and len(early["chunks"]) == 2 * per_step
-    for s in range(2):
-        ch = early["chunks"][s * per_step:(s + 1) * per_step]
-        assert sorted(ch) == sorted(ch, key=lambda r: r[0])
-        covered = sorted(ch)
-        assert covered[0][0] == 0 and covered[-1][1] == early["numel"]
-        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+    # the first step handed the whole flat buffer over in adjoining chunks (several); the second one — the network's layers took
+    # the fused launch in the first — updated what the fused launches left (the biases) in ONE multi-range launch behind the pass
+    ch = early["chunks"]
+    assert len(ch) >= 3
+    covered = sorted(ch)
+    assert covered[0][0] == 0 and covered[-1][1] == early["numel"]
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+    assert len(early["ranged"]) == 1 and not late["ranged"]
+    (rng,) = early["ranged"]
+    assert len(rng) == 10 and all(b - a <= 64 for a, b in rng), "ten bias vectors"
     for k in ("master", "m", "v", "fpack", "dpack"):
         assert torch.equal(early[k], late[k]), k
     assert early["logs"] == late["logs"]

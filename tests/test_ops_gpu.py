@@ -1539,6 +1539,43 @@ def test_image_pair_conversion(hip_ops, shape):
             assert torch.equal(gb, want[:, Ca:])
 
 
+def test_adam_over_ranges_equals_one_launch_per_range(hip_ops):
+    """gs_adam_step_dev_packs_ranges (several ranges of the flat buffers in one launch: what gs_wgrad_adam leaves of a network)
+    against gs_adam_step_dev_packs range by range, bit for bit, elements outside the ranges untouched; ranges from 8 elements
+    (a bias) to a few hundred thousand"""
+    g = torch.Generator().manual_seed(95)
+    dev = hip_ops.device
+    n = 700_000
+    ranges = [(0, 64), (4096, 4104), (10_000 - 16, 10_000 + 512), (65_536, 65_536 + 300_008), (n - 24, n)]
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-2
+    m0, v0 = torch.randn(n, generator=g) * 1e-3, torch.rand(n, generator=g) * 1e-4
+    n8 = n // 8
+    inv_f, inv_d = torch.randperm(n8, generator=g).int().to(dev), torch.randperm(n8, generator=g).int().to(dev)
+    inv_d[::7] = -1
+    hyper = torch.tensor([2e-4, 0.5, 0.999, 1e-8, 1 - 0.5 ** 5, (1 - 0.999 ** 5) ** 0.5], device=dev)
+    outs = []
+    for form in ("ranges", "single"):
+        p, gr, m, v = (t.clone().to(dev) for t in (p0, g0, m0, v0))
+        fpack = torch.zeros(n8 * 8, dtype=torch.bfloat16, device=dev)
+        dpack = torch.zeros(n8 * 8, dtype=torch.bfloat16, device=dev)
+        if form == "ranges":
+            rd = torch.tensor(ranges, dtype=torch.int64, device=dev)
+            hip_ops.adam_step_dev_ranges(p, gr, m, v, rd, max(b - a for a, b in ranges), hyper, packs=(inv_f, fpack, inv_d, dpack))
+        else:
+            for a, b in ranges:
+                hip_ops.adam_step_dev(p[a:b], gr[a:b], m[a:b], v[a:b], hyper, grad_scale=1.0, zero_grad=True,
+                                      packs=(inv_f[a // 8:(b + 7) // 8], fpack, inv_d[a // 8:(b + 7) // 8], dpack))
+        torch.cuda.synchronize()
+        outs.append([t.cpu() for t in (p, gr, m, v, fpack, dpack)])
+    for k, name in enumerate(("p", "g", "m", "v", "fpack", "dpack")):
+        assert torch.equal(outs[0][k], outs[1][k]), name
+    keep = torch.ones(n, dtype=torch.bool)
+    for a, b in ranges:
+        keep[a:b] = False
+    assert torch.equal(outs[0][0][keep], p0[keep]) and torch.equal(outs[0][1][keep], g0[keep])
+    assert outs[0][1][~keep].abs().max().item() == 0.0
+
+
 def test_group_indexed_repack_equals_the_elementwise_refresh(hip_ops):
     """gs_repack_bf16_groups / gs_repack_bf16_tiled_groups (one base index per 8 pack elements; two launches per pack) against
     gs_repack_bf16 on the expanded index, bit for bit: aligned and unaligned bases, padding groups, irregular groups (-2),
