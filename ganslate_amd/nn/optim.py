@@ -183,7 +183,7 @@ class NativeAdam(torch.optim.Optimizer):
                 st = self.state[p]
                 # the update writes the row-major bf16 weight packs as it goes where the network has one pack set
                 tgt = net.fused_pack_targets() if hasattr(net, "fused_pack_targets") else None
-                nodes_end = net.b_off[-1] + net.nodes[-1].spec.cout_p
+                nodes_end = net.b_off[-1] + net.nodes[-1].spec.cout_p if early else 0      # (armed networks are NativeNets)
                 if early and net._early_fused and net._early_cursor == nodes_end and hasattr(ops, "adam_step_dev_ranges"):
                     self._update_rest(p, net, tgt)       # nothing handed over in chunks: the rest of the buffer in one launch
                 elif early and (net._early_cursor < net.b_off[-1] + net.nodes[-1].spec.cout_p or net._early_fused):
