@@ -1,1 +1,6 @@
-for r in 1 2 3 4; do for v in 0 1; do echo -n "pix2pix GS_ADAM_RANGES=$v "; GS_ADAM_RANGES=$v python bench.py --workload pix2pix --no-cpu-baseline --no-kernel-timing --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done; done
+for r in 1 2; do
+echo -n "default "; python bench.py --workload pix2pix --no-cpu-baseline --no-kernel-timing --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+echo -n "ring=2 target=512 "; GS_SPLITK_RING=2 GS_SPLITK_TARGET=512 python bench.py --workload pix2pix --no-cpu-baseline --no-kernel-timing --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+echo -n "ring=2 target=256 "; GS_SPLITK_RING=2 python bench.py --workload pix2pix --no-cpu-baseline --no-kernel-timing --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+echo -n "ring=1 target=512 "; GS_SPLITK_TARGET=512 python bench.py --workload pix2pix --no-cpu-baseline --no-kernel-timing --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done
