@@ -41,6 +41,11 @@ CASES = {
     # PatchGAN3D's last two layers (patchgan3d.py:50-60) on the 4 images of a discriminator update
     "p3l": (ConvSpec("conv", 256, 1, 4, 1, 1, dims=3), 4, 31, 31, 31),
     "p3m": (ConvSpec("conv", 128, 256, 4, 1, 1, dims=3), 4, 32, 32, 32),
+    # U-Net(7, 128) innermost levels at 256 x 512 (pix2pix): weight streaming for 8 - 32 pixels
+    "un7": (ConvSpec("conv", 1024, 1024, 4, 2, 1), 1, 4, 8),
+    "un6": (ConvSpec("conv", 1024, 1024, 4, 2, 1), 1, 8, 16),
+    "uu7": (ConvSpec("convT", 1024, 1024, 4, 2, 1, 0), 1, 2, 4),
+    "uu6": (ConvSpec("convT", 2048, 1024, 4, 2, 1, 0), 1, 4, 8),
     # V-Net down / up convs (k2 s2)
     "vdn": (ConvSpec("conv", 16, 32, 2, 2, 0, dims=3), 1, 128, 128, 128),
     "vup": (ConvSpec("convT", 64, 16, 2, 2, 0, dims=3), 1, 64, 64, 64),
