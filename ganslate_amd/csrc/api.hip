@@ -90,9 +90,9 @@ OptDef g_opts[GS_OPT_COUNT] = {
     {"hconv5_seg", 0},          // ... z segments per column (0 = as many as fill the chip; tests force long segments with 1 / 2)
     {"hwgrad2", 2},             // hwgrad.hip: double-buffered, decode-once form of the narrow volume weight gradient with 65..128 taps
                                 // (>= 2: also for layers wide on both sides, 33..64 x 17..64 channels, instead of the im2col kernel)
-    {"hconv2", 3},              // hconv.hip: persistent double-buffered form of the narrow volume forward / data-gradient kernel (17..64 output channels;
+    {"hconv2", 4},              // hconv.hip: persistent double-buffered form of the narrow volume forward / data-gradient kernel (17..64 output channels;
                                 // >= 2: also 64 -> 64 channels — wide on both sides — instead of the split-K im2col launch + its finalize;
-                                // >= 3: 32-channel layers on <= 128 boxes as two 16-channel groups per box)
+                                // >= 3: 32-channel layers on <= 128 boxes as two 16-channel groups per box; >= 4: 64-channel layers on <= 64 boxes as four)
     {"pwise", 8},               // pwise.hip: register-operand kernels for one-tap layers with <= 8 channels on one side (smallest volume in 2048-voxel units, 0 = off)
     {"adam_blocks", 8192},      // optim.hip: largest grid of the Adam update (the chunks launched under a backward pass take fewer: they
                                 // must not crowd the pass's own launches out of the CUs)

@@ -635,8 +635,9 @@ HPlan plan(const gs_gconv_desc* d) {
   h.nbd = (d->Do + h.BD - 1) / h.BD; h.nbh = (d->Ho + h.BH - 1) / h.BH; h.nbw = (d->Wo + h.BW - 1) / h.BW;
   h.CC = d->Ci < 16 ? d->Ci : 16;
   h.TI = d->Co <= 16 ? 1 : 2;                      // 16 or 32 output channels per workgroup,
-  // (persistent form on a small volume: 16 channels per workgroup put a 32-channel layer's 64 boxes on 128 workgroups)
+  // (persistent form on a small volume: 16 channels per workgroup put a 32- / 64-channel layer's 64 boxes on 128 / 256 workgroups)
   if (h.v2 && gs_opt(GS_OPT_HCONV2) >= 3 && d->Co == 32 && (long long)d->N * h.nbd * h.nbh * h.nbw * 2 <= 256) h.TI = 1;
+  if (h.v2 && gs_opt(GS_OPT_HCONV2) >= 4 && d->Co == 64 && (long long)d->N * h.nbd * h.nbh * h.nbw * 4 <= 256) h.TI = 1;
   h.cog = (d->Co + h.TI * 16 - 1) / (h.TI * 16);   // wider layers split over blockIdx.y (each stages its own halo)
   const long long hv = (long long)h.HD * h.HH * h.HW;
   const long long halo_bytes = (hv * h.CC * 2 + 1023) / 1024 * 1024 + 1024;

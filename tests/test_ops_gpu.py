@@ -1007,7 +1007,7 @@ def test_persistent_narrow_volume_kernel(hip_ops, case):
     y_ref, mr_ref, G_ref = run(RefOps(), "cpu")
     default = ops.get_option("hconv2")
     try:
-        ops.set_option("hconv2", 3)           # (>= 3: a 32-channel layer on 64 boxes runs as two 16-channel groups per box)
+        ops.set_option("hconv2", 4)           # (>= 3 / 4: a 32- / 64-channel layer on 64 boxes runs as two / four 16-channel groups per box)
         y2, mr2, G2 = run(ops, ops.device)
         ops.set_option("hconv2", 0)
         y0, mr0, G0 = run(ops, ops.device)
